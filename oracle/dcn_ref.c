@@ -1,0 +1,244 @@
+/*
+ * TEST INFRASTRUCTURE -- plain-C restatement of the reference's modulated deformable
+ * convolution (DCNv2), forward and backward.  Never linked into the product.
+ *
+ * Follows, loop for loop, the reference's CUDA extension (paths under
+ * /root/reference/code/models/modules/ops/dcn/src/):
+ *   bilinear sample            deform_conv_cuda_kernel.cu:468-497  (dmcn_im2col_bilinear)
+ *   im2col                     deform_conv_cuda_kernel.cu:571-633
+ *   d(sample)/d(pixel)         deform_conv_cuda_kernel.cu:500-526  (dmcn_get_gradient_weight)
+ *   d(sample)/d(coordinate)    deform_conv_cuda_kernel.cu:528-568  (dmcn_get_coordinate_weight)
+ *   col2im (grad_input)        deform_conv_cuda_kernel.cu:635-693
+ *   col2im_coord (grad_offset, grad_mask)  deform_conv_cuda_kernel.cu:695-767
+ *   host orchestration         deform_conv_cuda.cpp:490-569 (forward), :571-685 (backward)
+ *
+ * PARITY UNPINNED BY EXECUTION: the reference is CUDA-only (deform_conv_ext.cpp:124 errors on
+ * CPU), no nvcc / GPU / alternative implementation exists in the build image, and the reference
+ * holds no test vectors for it.  This file is pinned by identities instead
+ * (tests/test_dcn_oracle.py): zero offsets == conv2d, integer offsets == shifted conv, mask
+ * linearity, border partial weights, fp64 finite differences of all five gradients, and
+ * agreement with the independent pure-torch formulation in oracle/torch_ref.py.
+ *
+ * Layouts are the reference's: NCHW fp32, offset [B][dg*2*K][Ho][Wo], mask [B][dg*K][Ho][Wo],
+ * weight [Co][C/groups][kh][kw].  Accumulation in the GEMMs is double to make the oracle a
+ * better judge of fp32 kernels (the reference's cuBLAS order is unspecified anyway).
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef float real;
+
+static real bilinear(const real* im, int data_width, int height, int width, real h, real w) {
+  int h_low = (int)floorf(h), w_low = (int)floorf(w);
+  int h_high = h_low + 1, w_high = w_low + 1;
+  real lh = h - h_low, lw = w - w_low, hh = 1 - lh, hw = 1 - lw;
+  real v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+  if (h_low >= 0 && w_low >= 0) v1 = im[h_low * data_width + w_low];
+  if (h_low >= 0 && w_high <= width - 1) v2 = im[h_low * data_width + w_high];
+  if (h_high <= height - 1 && w_low >= 0) v3 = im[h_high * data_width + w_low];
+  if (h_high <= height - 1 && w_high <= width - 1) v4 = im[h_high * data_width + w_high];
+  real w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+  return w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+}
+
+static real gradient_weight(real ah, real aw, int h, int w, int height, int width) {
+  if (ah <= -1 || ah >= height || aw <= -1 || aw >= width) return 0;
+  int hl = (int)floorf(ah), wl = (int)floorf(aw), hh = hl + 1, wh = wl + 1;
+  real weight = 0;
+  if (h == hl && w == wl) weight = (h + 1 - ah) * (w + 1 - aw);
+  if (h == hl && w == wh) weight = (h + 1 - ah) * (aw + 1 - w);
+  if (h == hh && w == wl) weight = (ah + 1 - h) * (w + 1 - aw);
+  if (h == hh && w == wh) weight = (ah + 1 - h) * (aw + 1 - w);
+  return weight;
+}
+
+static real coordinate_weight(real ah, real aw, int height, int width, const real* im, int dw, int dir) {
+  if (ah <= -1 || ah >= height || aw <= -1 || aw >= width) return 0;
+  int hl = (int)floorf(ah), wl = (int)floorf(aw), hh = hl + 1, wh = wl + 1;
+  real weight = 0;
+  if (dir == 0) {
+    if (hl >= 0 && wl >= 0) weight += -1 * (wl + 1 - aw) * im[hl * dw + wl];
+    if (hl >= 0 && wh <= width - 1) weight += -1 * (aw - wl) * im[hl * dw + wh];
+    if (hh <= height - 1 && wl >= 0) weight += (wl + 1 - aw) * im[hh * dw + wl];
+    if (hh <= height - 1 && wh <= width - 1) weight += (aw - wl) * im[hh * dw + wh];
+  } else {
+    if (hl >= 0 && wl >= 0) weight += -1 * (hl + 1 - ah) * im[hl * dw + wl];
+    if (hl >= 0 && wh <= width - 1) weight += (hl + 1 - ah) * im[hl * dw + wh];
+    if (hh <= height - 1 && wl >= 0) weight += -1 * (ah - hl) * im[hh * dw + wl];
+    if (hh <= height - 1 && wh <= width - 1) weight += (ah - hl) * im[hh * dw + wh];
+  }
+  return weight;
+}
+
+typedef struct {
+  int B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, groups, dg, Ho, Wo;
+} geom;
+
+static geom make_geom(int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw,
+                      int dh, int dw, int groups, int dg) {
+  geom g = {B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, groups, dg, 0, 0};
+  g.Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) / sh + 1;
+  g.Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) / sw + 1;
+  return g;
+}
+
+/* columns[(c*K + k)][ho][wo] for one sample (deform_conv_cuda_kernel.cu:571-633, batch_size = 1) */
+static void im2col(const geom* g, const real* x, const real* off, const real* msk, real* col) {
+  const int K = g->kh * g->kw, cpg = g->C / g->dg, HW = g->Ho * g->Wo;
+  for (int c = 0; c < g->C; ++c) {
+    const int grp = c / cpg;
+    const real* im = x + (size_t)c * g->H * g->W;
+    const real* offp = off + (size_t)grp * 2 * K * HW;
+    const real* mp = msk + (size_t)grp * K * HW;
+    for (int ho = 0; ho < g->Ho; ++ho)
+      for (int wo = 0; wo < g->Wo; ++wo) {
+        const int h_in = ho * g->sh - g->ph, w_in = wo * g->sw - g->pw;
+        for (int i = 0; i < g->kh; ++i)
+          for (int j = 0; j < g->kw; ++j) {
+            const int k = i * g->kw + j;
+            const real oh = offp[(size_t)(2 * k) * HW + ho * g->Wo + wo];
+            const real ow = offp[(size_t)(2 * k + 1) * HW + ho * g->Wo + wo];
+            const real m = mp[(size_t)k * HW + ho * g->Wo + wo];
+            const real h_im = h_in + i * g->dh + oh, w_im = w_in + j * g->dw + ow;
+            real val = 0;
+            if (h_im > -1 && w_im > -1 && h_im < g->H && w_im < g->W)
+              val = bilinear(im, g->W, g->H, g->W, h_im, w_im);
+            col[((size_t)c * K + k) * HW + ho * g->Wo + wo] = val * m;
+          }
+      }
+  }
+}
+
+/* out[b] = W.flatten(1) @ columns + bias   (deform_conv_cuda.cpp:539-568) */
+int dcn_ref_forward(const real* x, const real* offset, const real* mask, const real* weight, const real* bias,
+                    real* out, int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw,
+                    int dh, int dw, int groups, int dg) {
+  geom g = make_geom(B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, groups, dg);
+  const int K = kh * kw, HW = g.Ho * g.Wo, Cg = C / groups, Cog = Co / groups;
+  real* col = (real*)malloc(sizeof(real) * (size_t)C * K * HW);
+  double* acc = (double*)malloc(sizeof(double) * HW);
+  if (!col || !acc) return -1;
+  for (int b = 0; b < B; ++b) {
+    im2col(&g, x + (size_t)b * C * H * W, offset + (size_t)b * dg * 2 * K * HW, mask + (size_t)b * dg * K * HW, col);
+    for (int co = 0; co < Co; ++co) {
+      const int grp = co / Cog;
+      for (int n = 0; n < HW; ++n) acc[n] = 0.0;
+      for (int r = 0; r < Cg * K; ++r) {
+        const double w = weight[(size_t)co * Cg * K + r];
+        const real* cr = col + ((size_t)grp * Cg * K + r) * HW;
+        for (int n = 0; n < HW; ++n) acc[n] += w * cr[n];
+      }
+      const double bv = bias ? bias[co] : 0.0;
+      real* o = out + ((size_t)b * Co + co) * HW;
+      for (int n = 0; n < HW; ++n) o[n] = (real)(acc[n] + bv);
+    }
+  }
+  free(col);
+  free(acc);
+  return 0;
+}
+
+/* deform_conv_cuda.cpp:571-685.  All gradient buffers are ACCUMULATED into for weight/bias
+ * (caller zero-fills, deform_conv.py:161-165) and overwritten per sample for the others. */
+int dcn_ref_backward(const real* x, const real* offset, const real* mask, const real* weight, const real* gout,
+                     real* gx, real* goff, real* gmask, real* gw, real* gb, int B, int C, int H, int W, int Co,
+                     int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int groups, int dg) {
+  geom g = make_geom(B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, groups, dg);
+  const int K = kh * kw, HW = g.Ho * g.Wo, Cg = C / groups, Cog = Co / groups, cpg = C / dg;
+  real* col = (real*)malloc(sizeof(real) * (size_t)C * K * HW);
+  double* gxd = (double*)calloc((size_t)C * H * W, sizeof(double));
+  double* gwd = (double*)calloc((size_t)Co * Cg * K, sizeof(double));
+  double* gbd = (double*)calloc((size_t)Co, sizeof(double));
+  if (!col || !gxd || !gwd || !gbd) return -1;
+  for (int b = 0; b < B; ++b) {
+    const real* xb = x + (size_t)b * C * H * W;
+    const real* offb = offset + (size_t)b * dg * 2 * K * HW;
+    const real* mb = mask + (size_t)b * dg * K * HW;
+    const real* gob = gout + (size_t)b * Co * HW;
+    /* columns = W^T @ grad_output            (:613-616) */
+    for (int r = 0; r < C * K; ++r) {
+      const int grp = r / (Cg * K), rr = r % (Cg * K);
+      for (int n = 0; n < HW; ++n) {
+        double s = 0.0;
+        for (int co = 0; co < Cog; ++co)
+          s += (double)weight[((size_t)(grp * Cog + co)) * Cg * K + rr] * gob[(size_t)(grp * Cog + co) * HW + n];
+        col[(size_t)r * HW + n] = (real)s;
+      }
+    }
+    /* col2im_coord: grad_offset, grad_mask   (kernel :695-767) */
+    for (int oc = 0; oc < dg * 2 * K; ++oc) {
+      const int grp = oc / (2 * K), offc = oc - grp * 2 * K, k = offc / 2, dir = offc % 2;
+      const int i = k / kw, j = k % kw;
+      for (int ho = 0; ho < g.Ho; ++ho)
+        for (int wo = 0; wo < g.Wo; ++wo) {
+          const int n = ho * g.Wo + wo;
+          real val = 0, mval = 0;
+          const real oh = offb[((size_t)grp * 2 * K + 2 * k) * HW + n];
+          const real ow = offb[((size_t)grp * 2 * K + 2 * k + 1) * HW + n];
+          const real m = mb[((size_t)grp * K + k) * HW + n];
+          for (int cc = 0; cc < cpg; ++cc) {
+            const int c = grp * cpg + cc;
+            const real* im = xb + (size_t)c * H * W;
+            const real cv = col[((size_t)c * K + k) * HW + n];
+            real inv_h = ho * sh - ph + i * dh + oh, inv_w = wo * sw - pw + j * dw + ow;
+            if (inv_h <= -1 || inv_w <= -1 || inv_h >= H || inv_w >= W) {
+              inv_h = inv_w = -2;
+            } else {
+              mval += cv * bilinear(im, W, H, W, inv_h, inv_w);
+            }
+            val += coordinate_weight(inv_h, inv_w, H, W, im, W, dir) * cv * m;
+          }
+          goff[((size_t)b * dg * 2 * K + oc) * HW + n] = val;
+          if (dir == 0) gmask[((size_t)b * dg * K + grp * K + k) * HW + n] = mval;
+        }
+    }
+    /* col2im: grad_input (the reference scatters with atomicAdd, :635-693) */
+    memset(gxd, 0, sizeof(double) * (size_t)C * H * W);
+    for (int c = 0; c < C; ++c) {
+      const int grp = c / cpg;
+      for (int k = 0; k < K; ++k) {
+        const int i = k / kw, j = k % kw;
+        for (int ho = 0; ho < g.Ho; ++ho)
+          for (int wo = 0; wo < g.Wo; ++wo) {
+            const int n = ho * g.Wo + wo;
+            const real oh = offb[((size_t)grp * 2 * K + 2 * k) * HW + n];
+            const real ow = offb[((size_t)grp * 2 * K + 2 * k + 1) * HW + n];
+            const real m = mb[((size_t)grp * K + k) * HW + n];
+            const real ch = ho * sh - ph + i * dh + oh, cw = wo * sw - pw + j * dw + ow;
+            const real top = col[((size_t)c * K + k) * HW + n] * m;
+            const int cur_h = (int)ch, cur_w = (int)cw;
+            for (int dy = -2; dy <= 2; ++dy)
+              for (int dx = -2; dx <= 2; ++dx)
+                if (cur_h + dy >= 0 && cur_h + dy < H && cur_w + dx >= 0 && cur_w + dx < W &&
+                    fabsf(ch - (cur_h + dy)) < 1 && fabsf(cw - (cur_w + dx)) < 1)
+                  gxd[((size_t)c * H + cur_h + dy) * W + cur_w + dx] +=
+                      (double)gradient_weight(ch, cw, cur_h + dy, cur_w + dx, H, W) * top;
+          }
+      }
+    }
+    for (size_t t = 0; t < (size_t)C * H * W; ++t) gx[(size_t)b * C * H * W + t] = (real)gxd[t];
+    /* grad_weight += grad_output @ columns^T, grad_bias += grad_output @ ones (:640-672) */
+    im2col(&g, xb, offb, mb, col);
+    for (int co = 0; co < Co; ++co) {
+      const int grp = co / Cog;
+      for (int r = 0; r < Cg * K; ++r) {
+        double s = 0.0;
+        const real* cr = col + ((size_t)grp * Cg * K + r) * HW;
+        for (int n = 0; n < HW; ++n) s += (double)gob[(size_t)co * HW + n] * cr[n];
+        gwd[(size_t)co * Cg * K + r] += s;
+      }
+      double sb = 0.0;
+      for (int n = 0; n < HW; ++n) sb += gob[(size_t)co * HW + n];
+      gbd[co] += sb;
+    }
+  }
+  for (size_t t = 0; t < (size_t)Co * Cg * K; ++t) gw[t] += (real)gwd[t];
+  if (gb)
+    for (int co = 0; co < Co; ++co) gb[co] += (real)gbd[co];
+  free(col);
+  free(gxd);
+  free(gwd);
+  free(gbd);
+  return 0;
+}

@@ -1,0 +1,149 @@
+"""Generates the golden vectors under tests/golden/ by EXECUTING the upstream reference
+(/root/reference, build container only) on seeded inputs.  Only data is stored: inputs,
+seeded parameters and the reference's outputs -- never reference source.
+
+    python tests/golden/make_golden.py
+
+Fixtures (all float32 unless noted):
+  vq.npz        VectorQuantizer2.forward (quantize.py:271-312): random tokens, an exact-tie set
+                (duplicated codebook rows) and a near-tie set; z_q, int64 indices, the loss, and
+                torch's own distance rows for the first 16 tokens (bit-exactness of `d`).
+  flow.npz      two consecutive FlowSteps (one without coupling, one CondAffineSeparatedAndCond;
+                FlowStep.py:75-119) both directions with logdet.
+  blocks.npz    ResnetBlock(32->64), AttnBlock(64), Downsample(32), Upsample(32)
+                (encoder_decoder.py:38-192).
+  harness.npz   pre-processing (impad + t + log, infer_dataset_lol.py:124-128) and PSNR
+                (utils2.py:32-36) on a seeded uint8 image.
+  graph.npz     end-to-end stage checksums of the full LOL.yml graph A->B->C/D (E needs CUDA in the
+                reference) on a 1x3x24x32 input with seeded weights: outputs only (the 132 M weights
+                are re-created from their parameter names by glare_amd/synthetic.py::seeded_init_,
+                which tests re-run on the oracle's modules).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import refimport as R  # noqa: E402
+from oracle import torch_ref as O  # noqa: E402
+from glare_amd.synthetic import seeded_init_, synthetic_lowlight  # noqa: E402
+
+
+def sd_np(module, prefix):
+    return {prefix + k: v.detach().numpy() for k, v in module.state_dict().items()}
+
+
+def main():
+    R.install()
+    torch.set_num_threads(1)
+    import models.modules.quantize as quantize
+    import models.modules.encoder_decoder as ed
+    import models.modules.FlowStep as FS
+
+    # ---- vq -------------------------------------------------------------------------------
+    g = torch.Generator().manual_seed(11)
+    vq = quantize.VectorQuantizer2(8192, 3, beta=0.25)
+    vq.embedding.weight.data.copy_(torch.randn(8192, 3, generator=g) * 0.7)
+    cb = vq.embedding.weight.data
+    cb[4096] = cb[17]  # exact duplicates: the lower index must win
+    cb[8000] = cb[17]
+    cb[5000] = cb[123]
+    z = torch.randn(2, 3, 8, 12, generator=g)
+    zf = z.permute(0, 2, 3, 1).reshape(-1, 3)
+    zf[0] = cb[17]  # token exactly on a duplicated code
+    zf[1] = cb[123] + 1e-7
+    zf[2] = (cb[10] + cb[11]) / 2  # midpoint: near tie between two codes
+    zf[3] = (cb[200] + cb[201]) / 2 + 1e-8
+    z = zf.view(2, 8, 12, 3).permute(0, 3, 1, 2).contiguous()
+    with torch.no_grad():
+        zq, loss, (_, _, idx) = vq(z)
+        flat = z.permute(0, 2, 3, 1).reshape(-1, 3)
+        d = torch.sum(flat ** 2, dim=1, keepdim=True) + torch.sum(cb ** 2, dim=1) - 2 * torch.einsum(
+            "bd,dn->bn", flat, cb.t())
+    np.savez_compressed(os.path.join(HERE, "vq.npz"), codebook=cb.numpy(), z=z.numpy(), zq=zq.numpy(),
+                        idx=idx.numpy(), loss=loss.numpy(), d16=d[:16].numpy())
+
+    # ---- flow -----------------------------------------------------------------------------
+    torch.manual_seed(5)
+    np.random.seed(5)
+    opt = R.load_opt()
+    s0 = FS.FlowStep(in_channels=3, hidden_channels=64, flow_permutation="invconv", flow_coupling="noCoupling",
+                     opt=opt).eval()
+    s1 = FS.FlowStep(in_channels=3, hidden_channels=64, flow_permutation="invconv",
+                     flow_coupling="CondAffineSeparatedAndCond", opt=opt).eval()
+    seeded_init_(torch.nn.ModuleList([s0, s1]), seed=3)
+    zin = torch.randn(2, 3, 6, 8)
+    ft = torch.sigmoid(torch.randn(2, 64, 6, 8))
+    with torch.no_grad():
+        ld0 = torch.zeros(2)
+        a, ld = s0(zin, ld0, reverse=False, rrdbResults=ft)
+        fwd, ldf = s1(a, ld, reverse=False, rrdbResults=ft)
+        b, ldr = s1(zin, ld0, reverse=True, rrdbResults=ft)
+        rev, ldr = s0(b, ldr, reverse=True, rrdbResults=ft)
+    out = {"z": zin.numpy(), "ft": ft.numpy(), "fwd": fwd.numpy(), "fwd_logdet": ldf.numpy(), "rev": rev.numpy(),
+           "rev_logdet": ldr.numpy()}
+    out.update(sd_np(s0, "s0."))
+    out.update(sd_np(s1, "s1."))
+    np.savez_compressed(os.path.join(HERE, "flow.npz"), **out)
+
+    # ---- blocks ---------------------------------------------------------------------------
+    torch.manual_seed(7)
+    rb = ed.ResnetBlock(in_channels=32, out_channels=64, temb_channels=0, dropout=0.0).eval()
+    ab = ed.AttnBlock(64).eval()
+    dn = ed.Downsample(32, True).eval()
+    up = ed.Upsample(32, True).eval()
+    for m in (rb, ab):  # non-trivial affine GroupNorm parameters
+        for n, p in m.named_parameters():
+            if "norm" in n:
+                p.data.copy_(torch.randn_like(p) * 0.3 + (1.0 if n.endswith("weight") else 0.0))
+    x32 = torch.randn(2, 32, 7, 9)
+    x64 = torch.randn(2, 64, 5, 6)
+    with torch.no_grad():
+        out = {"x32": x32.numpy(), "x64": x64.numpy(), "res": rb(x32, None).numpy(), "attn": ab(x64).numpy(),
+               "down": dn(x32).numpy(), "up": up(x32).numpy()}
+    for name, m in (("res.", rb), ("attn.", ab), ("down.", dn), ("up.", up)):
+        out.update(sd_np(m, name))
+    np.savez_compressed(os.path.join(HERE, "blocks.npz"), **out)
+
+    # ---- harness --------------------------------------------------------------------------
+    hm = R.import_harness()
+    rng = np.random.RandomState(3)
+    img = rng.randint(0, 256, size=(24, 28, 3)).astype(np.uint8)
+    lr = hm.impad(img, bottom=20, left=20)
+    lr_t = hm.t(lr)
+    lr_t = torch.log(torch.clamp(lr_t + 1e-3, min=1e-3))
+    a = rng.rand(16, 24, 3)
+    b = np.clip(a + rng.randn(16, 24, 3) * 0.05, 0, 1)
+    np.savez_compressed(os.path.join(HERE, "harness.npz"), img=img, pre=lr_t.numpy(), a=a, b=b,
+                        psnr=np.float64(hm.PSNR(a, b)))
+
+    # ---- graph ----------------------------------------------------------------------------
+    torch.manual_seed(0)
+    np.random.seed(0)
+    netG, opt = R.build_netG()
+    net_vq, _ = R.build_vqgan(opt)
+    netG.eval()
+    net_vq.eval()
+    seeded_init_(netG, seed=0)
+    seeded_init_(net_vq, seed=1)
+    lr = O.preprocess(synthetic_lowlight(1, 4, 12, seed=1234)[0])  # 1x3x24x32
+    with torch.no_grad():
+        enc = netG.RRDB(lr, mid_feat=True)
+        x, _ = netG.flowUpsamplerNet(rrdbResults=enc, z=enc["color_map"], eps_std=0, reverse=True,
+                                     logdet=torch.zeros(1))
+        rec, _, feats = net_vq.decode(x)
+        idx = net_vq.quantize(x)[2][2]
+    np.savez_compressed(os.path.join(HERE, "graph.npz"), lr=lr.numpy(), cond_feat=enc["cond_feat"].numpy(),
+                        color_map=enc["color_map"].numpy(), mid0=enc["mid_feat"][0][:, :8].numpy(),
+                        mid1=enc["mid_feat"][1][:, :8].numpy(), latent=x.numpy(), idx=idx.numpy(),
+                        rec=rec.numpy(), code0=feats[0][:, :8].numpy(), code1=feats[1][:, :8].numpy())
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,102 @@
+"""CPU: the oracle (oracle/torch_ref.py, oracle/*.c) against the golden vectors that
+tests/golden/make_golden.py captured from the imported reference."""
+import numpy as np
+import torch
+
+from glare_amd.synthetic import seeded_init_
+from oracle import c_ref
+from oracle import torch_ref as O
+
+
+def _load(module, npz, prefix):
+    sd = {k[len(prefix):]: torch.from_numpy(npz[k]) for k in npz.files if k.startswith(prefix)}
+    module.load_state_dict(sd, strict=True)
+    return module.eval()
+
+
+def test_vq_indices_bit_exact(golden):
+    g = golden("vq")
+    vq = O.VectorQuantizer2(8192, 3, 0.25)
+    vq.embedding.weight.data.copy_(torch.from_numpy(g["codebook"]))
+    with torch.no_grad():
+        zq, loss, (_, _, idx) = vq(torch.from_numpy(g["z"]))
+    assert np.array_equal(idx.numpy(), g["idx"])
+    assert np.array_equal(zq.numpy(), g["zq"])
+    assert abs(float(loss) - float(g["loss"])) < 1e-6
+    # duplicates: lowest index wins
+    assert g["idx"][0] == 17 and g["idx"][1] == 123
+
+
+def test_vq_c_oracle_bit_exact(golden):
+    g = golden("vq")
+    tokens = np.ascontiguousarray(g["z"].transpose(0, 2, 3, 1).reshape(-1, 3))
+    idx, zq, d = c_ref.vq_nearest(tokens, g["codebook"], return_d=True)
+    assert np.array_equal(idx, g["idx"])
+    assert np.array_equal(d[:16], g["d16"]), "C restatement must reproduce torch's distance bits"
+    # the module returns the straight-through form z + (e - z) (quantize.py:298), not the raw entry
+    ste = tokens + (zq - tokens)
+    assert np.array_equal(ste.reshape(2, 8, 12, 3).transpose(0, 3, 1, 2), g["zq"])
+
+
+def test_flow_steps(golden):
+    g = golden("flow")
+    s0 = _load(O.FlowStep(3, coupling=False), g, "s0.")
+    s1 = _load(O.FlowStep(3, coupling=True), g, "s1.")
+    z, ft = torch.from_numpy(g["z"]), torch.from_numpy(g["ft"])
+    with torch.no_grad():
+        a, ld = s0(z, torch.zeros(2), False, ft)
+        fwd, ldf = s1(a, ld, False, ft)
+        b, ldr = s1(z, torch.zeros(2), True, ft)
+        rev, ldr = s0(b, ldr, True, ft)
+    np.testing.assert_allclose(fwd.numpy(), g["fwd"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(rev.numpy(), g["rev"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(ldf.numpy(), g["fwd_logdet"], rtol=1e-6)
+    np.testing.assert_allclose(ldr.numpy(), g["rev_logdet"], rtol=1e-6)
+    # invertibility (a size-independent property): forward(reverse(z)) == z
+    with torch.no_grad():
+        a, _ = s0(rev, torch.zeros(2), False, ft)
+        back, _ = s1(a, torch.zeros(2), False, ft)
+    np.testing.assert_allclose(back.numpy(), g["z"], atol=2e-4)
+
+
+def test_blocks(golden):
+    g = golden("blocks")
+    x32, x64 = torch.from_numpy(g["x32"]), torch.from_numpy(g["x64"])
+    with torch.no_grad():
+        res = _load(O.ResnetBlock(32, 64), g, "res.")(x32)
+        att = _load(O.AttnBlock(64), g, "attn.")(x64)
+        dn = _load(O.Downsample(32), g, "down.")(x32)
+        up = _load(O.Upsample(32), g, "up.")(x32)
+    for got, key in ((res, "res"), (att, "attn"), (dn, "down"), (up, "up")):
+        np.testing.assert_allclose(got.numpy(), g[key], rtol=0, atol=1e-6)
+
+
+def test_harness(golden):
+    g = golden("harness")
+    np.testing.assert_array_equal(O.preprocess(g["img"]).numpy(), g["pre"])
+    assert abs(O.psnr(g["a"], g["b"]) - float(g["psnr"])) < 1e-9
+
+
+def test_full_graph_stages(golden):
+    """A -> B -> C/D of the LOL.yml graph with name-seeded weights (132 M parameters)."""
+    g = golden("graph")
+    netG = seeded_init_(O.VQLLFLOWDeformable().eval(), seed=0)
+    net_vq = seeded_init_(O.VQModel().eval(), seed=1)
+    lr = torch.from_numpy(g["lr"])
+    with torch.no_grad():
+        enc = netG.RRDB(lr, mid_feat=True)
+        x, _ = netG.flowUpsamplerNet.decode(enc["color_map"], enc["cond_feat"])
+        # stage C/D is checked on the golden latent: the 24 random-weight coupling steps amplify
+        # the conv reduction-order noise of a different thread count (1e-4 relative), which must
+        # not leak into the bit-exact index comparison
+        rec, _, feats = net_vq.decode(torch.from_numpy(g["latent"]))
+    tol = dict(rtol=0, atol=2e-5)
+    np.testing.assert_allclose(enc["cond_feat"].numpy(), g["cond_feat"], **tol)
+    np.testing.assert_allclose(enc["color_map"].numpy(), g["color_map"], **tol)
+    np.testing.assert_allclose(enc["mid_feat"][0][:, :8].numpy(), g["mid0"], **tol)
+    np.testing.assert_allclose(enc["mid_feat"][1][:, :8].numpy(), g["mid1"], **tol)
+    np.testing.assert_allclose(x.numpy(), g["latent"], rtol=2e-3, atol=1e-3)
+    assert np.array_equal(net_vq.last_indices.numpy(), g["idx"])
+    np.testing.assert_allclose(rec.numpy(), g["rec"], **tol)
+    np.testing.assert_allclose(feats[0][:, :8].numpy(), g["code0"], **tol)
+    np.testing.assert_allclose(feats[1][:, :8].numpy(), g["code1"], **tol)

@@ -1,0 +1,98 @@
+"""CPU, build container only: pins oracle/torch_ref.py against the reference EXECUTED in place
+(oracle/refimport.py).  Skipped where /root/reference does not exist (the GPU box)."""
+import numpy as np
+import pytest
+import torch
+
+from glare_amd.synthetic import seeded_init_, synthetic_lowlight
+from oracle import refimport as R
+from oracle import torch_ref as O
+
+pytestmark = [pytest.mark.reference,
+              pytest.mark.skipif(not R.available(), reason="reference tree not present")]
+
+
+@pytest.fixture(scope="module")
+def nets():
+    torch.manual_seed(0)
+    np.random.seed(0)
+    netG, opt = R.build_netG()
+    net_vq, _ = R.build_vqgan(opt)
+    seeded_init_(netG.eval(), 0)
+    seeded_init_(net_vq.eval(), 1)
+    oG = O.VQLLFLOWDeformable().eval()
+    oV = O.VQModel().eval()
+    oG.load_state_dict(netG.state_dict(), strict=True)  # 824 keys, names identical
+    assert set(oV.state_dict().keys()) == set(net_vq.state_dict().keys())
+    oV.load_state_dict(net_vq.state_dict(), strict=True)
+    return netG, net_vq, oG, oV
+
+
+def test_state_dict_surface(nets):
+    netG, net_vq, oG, oV = nets
+    assert len(netG.state_dict()) == 824
+    assert sorted(oG.state_dict().keys()) == sorted(netG.state_dict().keys())
+
+
+def test_inference_stages_bit_identical(nets):
+    netG, net_vq, oG, oV = nets
+    lr = O.preprocess(synthetic_lowlight(1, 12, 20, seed=5)[0])  # 1x3x32x40
+    with torch.no_grad():
+        er = netG.RRDB(lr, mid_feat=True)
+        eo = oG.RRDB(lr, mid_feat=True)
+        for k in ("cond_feat", "color_map"):
+            assert torch.equal(er[k], eo[k])
+        for a, b in zip(er["mid_feat"], eo["mid_feat"]):
+            assert torch.equal(a, b)
+        xr, _ = netG.flowUpsamplerNet(rrdbResults=er, z=er["color_map"], eps_std=0, reverse=True,
+                                      logdet=torch.zeros(1))
+        xo, _ = oG.flowUpsamplerNet.decode(eo["color_map"], eo["cond_feat"])
+        assert torch.equal(xr, xo)
+        rr, lr_, fr = net_vq.decode(xr)
+        ro, lo, fo = oV.decode(xo)
+        assert torch.equal(rr, ro) and torch.equal(lr_, lo)
+        assert torch.equal(net_vq.quantize(xr)[2][2], oV.last_indices)
+        for a, b in zip(fr, fo):
+            assert torch.equal(a, b)
+
+
+def test_stage_e_with_oracle_dcn(nets, monkeypatch):
+    """MultiScaleDecoder2 glue (Mix, WarpBlock wiring, whole-tensor mean rescale): the reference runs
+    with its CUDA-only DCN op swapped for the oracle's, everything else is the reference's code."""
+    netG, net_vq, oG, oV = nets
+    import models.modules.deformableDecoder_arch as dd
+
+    monkeypatch.setattr(dd, "modulated_deform_conv", O.modulated_deform_conv)
+    lr = torch.cat([O.preprocess(im) for im in synthetic_lowlight(2, 4, 12, seed=6)])  # 2x3x24x32
+    with torch.no_grad(), R.cpu_only():
+        ref_out, ref_lat = netG(net_vq=net_vq, lr=lr, z=None, eps_std=0, reverse=True, reverse_with_grad=False)
+        out, lat = oG(oV, lr)
+    assert torch.equal(ref_lat, lat)
+    np.testing.assert_allclose(out.numpy(), ref_out.numpy(), atol=1e-5)
+
+
+def test_stage2_normal_flow(nets):
+    netG, net_vq, oG, oV = nets
+    import models.modules.LLFlowVQGAN_arch as arch
+
+    opt = R.load_opt()
+    opt["train_gt_ratio"] = 0.0
+    ref = arch.LLFlowVQGAN2(opt=opt, K=12).eval()
+    seeded_init_(ref, 2)
+    mine = O.LLFlowVQGAN2().eval()
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    g = torch.Generator().manual_seed(3)
+    lr = torch.log(torch.rand(2, 3, 32, 32, generator=g) * 0.3 + 1e-3)
+    gt = torch.randn(2, 3, 8, 8, generator=g)
+    lr_r, gt_r = lr.clone().requires_grad_(), gt.clone()
+    z_r, nll_r, ld_r = ref(gt=gt_r, lr=lr_r, reverse=False)
+    z_o, nll_o, ld_o = mine.normal_flow(gt, lr)
+    assert torch.equal(z_r, z_o)
+    np.testing.assert_allclose(nll_o.detach().numpy(), nll_r.detach().numpy(), rtol=1e-6)
+    # backward of the stage-2 objective
+    nll_r.mean().backward()
+    nll_o.mean().backward()
+    gr = dict(ref.named_parameters())
+    for n, p in mine.named_parameters():
+        if p.grad is not None:
+            np.testing.assert_allclose(p.grad.numpy(), gr[n].grad.numpy(), rtol=1e-4, atol=1e-6)
