@@ -1,0 +1,404 @@
+// im2col-free direct convolution (3x3 / 1x1) as an implicit GEMM on bf16 MFMA.
+//
+// Replaces every torch.nn.Conv2d with >= 8 input channels on the path (reference:
+// encoder_decoder.py:43-52,62-75,88-115,146-165,355,399,467,509; deformableDecoder_arch.py:282,
+// 484; deform_conv.py:357-364 conv_offset; flow.py:13-70) -- cuDNN in the reference.
+//
+// Data layout: activations NHWC bf16, so the GEMM's K dimension (input channels) is contiguous
+// per pixel and an MFMA A-fragment (32 pixels x 16 channels) is two dense 512-B runs of LDS.
+//   out[pixel, co] = sum_{tap, ci} in[pixel + tap, ci] * w[tap][co][ci]
+// One workgroup (4 waves) computes an 8 x 32 pixel tile x TN output channels.  Per stage it
+// stages KC = 16*KSTEPS input channels of the (8*s + k - 1) x (32*s + k - 1) halo tile and the
+// matching weights in LDS ONCE; the k*k taps are then just shifted LDS addresses -- no im2col
+// buffer, no re-read of the input per tap.  LDS images are split in 8-channel planes
+// ([kstep][khalf][position][8 ch]) so that a wave's ds_read_b128 fragment read is a dense,
+// bank-conflict-free 512-B run per half-wave.  Both images are double-buffered and filled by
+// LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass) one stage ahead of the
+// MFMAs; 2-3 workgroups per CU cover the barrier skew.
+// The zero padding, the nearest x2 upsample (Upsample, encoder_decoder.py:50) and the
+// asymmetric stride-2 padding (Downsample, encoder_decoder.py:71-73) are address arithmetic
+// in the loader; bias, residual add, activation and layout conversion are the epilogue.
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+constexpr int TH = 8;    // output tile rows
+constexpr int TW = 32;   // output tile cols == MFMA M
+constexpr int NTHREADS = 256;
+
+struct ConvParams {
+  const bf16_t* in0;
+  const bf16_t* in1;
+  const bf16_t* wpk;
+  const float* bias;
+  const bf16_t* res;
+  void* out;
+  int B, H, W;        // source spatial size (before upsample)
+  int IHs, IWs;       // conv input size (after upsample)
+  int OH, OW;
+  int Cin0, Cin1, CinTot;
+  int p0, o0, p1, o1; // pitch / channel offset of the two sources
+  int Cout, opitch, ooff, rpitch, roff;
+  int upsample, act, out_mode;
+  long long plane_pitch;
+  int tiles_x, tiles_y, co_tiles, n_blocks, n_stages;
+};
+
+template <int KS, int STRIDE>
+struct TileGeom {
+  static constexpr int IH = (TH - 1) * STRIDE + KS;
+  static constexpr int IW = (TW - 1) * STRIDE + KS;
+  static constexpr int NPOS = IH * IW;
+  static constexpr int PAD = (KS == 3 && STRIDE == 1) ? 1 : 0;  // stride 2: pad (0,1,0,1) only
+};
+
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case GLARE_ACT_RELU: return fmaxf(v, 0.f);
+    case GLARE_ACT_SIGMOID: return sigmoidf_(v);
+    case GLARE_ACT_SWISH: return swishf_(v);
+    default: return v;
+  }
+}
+
+// 16 zero bytes in global memory: the LDS-DMA source of every padded (out-of-image or
+// beyond-Cin) chunk, so that zero padding costs no branch in the MFMA loop.
+__device__ __attribute__((aligned(16))) const uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ void dma16(const void* gsrc, void* lds_wave_base) {
+  // global -> LDS, 16 B per lane, destination = wave-uniform base + lane*16 (no VGPR round trip)
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// KS kernel size, STRIDE, MT/NT 32x32 MFMA tiles per wave along pixel rows / couts,
+// WM x WN waves (WM*MT == 8 rows), KSTEPS 16-channel k-steps per input stage.
+//
+// Pipeline: an "A stage" is KC = 16*KSTEPS channels of the halo tile; it is consumed in KS
+// "B stages" (one tap row each: KS taps x KSTEPS k-steps of weights).  Both images are
+// double-buffered in LDS and filled by LDS-DMA (global_load_lds_dwordx4), issued one B stage
+// ahead, right after the barrier that retires the buffer they overwrite; one barrier per B stage.
+template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int KSTEPS>
+__global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParams p) {
+  using G = TileGeom<KS, STRIDE>;
+  static_assert(WM * MT == TH && WM * WN == 4, "wave layout");
+  constexpr int TN = WN * NT * 32;
+  constexpr int A_CHUNKS = KSTEPS * 2 * G::NPOS;           // 16-B chunks of one A stage
+  constexpr int A_INSTR = (A_CHUNKS + 63) / 64;            // wave-level DMA instructions per A stage
+  constexpr int A_SLOTS = A_INSTR * 64;
+  constexpr int A_PER_W = (A_INSTR + 3) / 4;
+  constexpr int B_CHUNKS = KS * KSTEPS * 2 * TN;           // 16-B chunks of one B stage (one tap row)
+  static_assert(B_CHUNKS % 64 == 0, "B stage is a whole number of wave DMAs");
+  constexpr int B_INSTR = B_CHUNKS / 64;
+  constexpr int B_PER_W = (B_INSTR + 3) / 4;
+  constexpr int KC = 16 * KSTEPS;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  u32x4* lA = reinterpret_cast<u32x4*>(smem);              // [2][A_SLOTS]
+  u32x4* lB = lA + 2 * A_SLOTS;                            // [2][B_CHUNKS]
+
+  // XCD-aware order: consecutive logical tiles (same pixels, different couts; then neighbouring
+  // pixels) run on one XCD and share its L2 (dispatch is round-robin over the 8 XCDs).
+  int bid = blockIdx.x;
+  {
+    const int n = p.n_blocks, q = n / 8, r = n % 8, xcd = bid % 8, k = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int ct = bid % p.co_tiles;
+  int t = bid / p.co_tiles;
+  const int tx = t % p.tiles_x;
+  t /= p.tiles_x;
+  const int ty = t % p.tiles_y;
+  const int b = t / p.tiles_y;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int iy0 = oy0 * STRIDE - G::PAD, ix0 = ox0 * STRIDE - G::PAD;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // per-lane invariant part of the A addressing: this wave issues DMA instructions
+  // j = wave + 4*i; lane handles chunk c = j*64 + lane = (kstep*2 + khalf)*NPOS + pos
+  long long a_src[A_PER_W];  // element offset of (pixel, channel 0) in its source, or -1 = zero
+  int a_ck[A_PER_W];         // channel offset inside the stage: kstep*16 + khalf*8
+#pragma unroll
+  for (int i = 0; i < A_PER_W; ++i) {
+    const int c = (wave + 4 * i) * 64 + lane;
+    a_src[i] = -1;
+    a_ck[i] = 0;
+    if (c < A_CHUNKS) {
+      const int pos = c % G::NPOS, kk = c / G::NPOS;
+      a_ck[i] = kk * 8;
+      const int iy = iy0 + pos / G::IW, ix = ix0 + pos % G::IW;
+      if (iy >= 0 && iy < p.IHs && ix >= 0 && ix < p.IWs) {
+        const int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
+        a_src[i] = ((long long)b * p.H + sy) * p.W + sx;
+      }
+    }
+  }
+  const bf16_t* wbase = p.wpk + (size_t)ct * p.n_stages * (size_t)(KS * B_CHUNKS) * 8;
+
+  auto issue_a = [&](int chunk, int buf) {
+    const int c0 = chunk * KC;
+#pragma unroll
+    for (int i = 0; i < A_PER_W; ++i) {
+      const int j = wave + 4 * i;
+      if (j < A_INSTR) {
+        const void* src = g_zero16;
+        const int ch = c0 + a_ck[i];
+        if (a_src[i] >= 0) {
+          if (ch < p.Cin0) src = p.in0 + a_src[i] * p.p0 + p.o0 + ch;
+          else if (ch < p.CinTot) src = p.in1 + a_src[i] * p.p1 + p.o1 + (ch - p.Cin0);
+        }
+        dma16(src, lA + buf * A_SLOTS + j * 64);
+      }
+    }
+  };
+  auto issue_b = [&](int bstage, int buf) {
+    const u32x4* wsrc = reinterpret_cast<const u32x4*>(wbase) + (size_t)bstage * B_CHUNKS;
+#pragma unroll
+    for (int i = 0; i < B_PER_W; ++i) {
+      const int j = wave + 4 * i;
+      if (j < B_INSTR) dma16(wsrc + j * 64 + lane, lB + buf * B_CHUNKS + j * 64);
+    }
+  };
+
+  const int khalf = lane >> 5, px = lane & 31;
+  const int n_bstages = p.n_stages * KS;
+  issue_a(0, 0);
+  issue_b(0, 0);
+  int bs = 0;
+  for (int chunk = 0; chunk < p.n_stages; ++chunk) {
+    const u32x4* cA = lA + (chunk & 1) * A_SLOTS;
+#pragma unroll
+    for (int trow = 0; trow < KS; ++trow, ++bs) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
+      __syncthreads();                                   // ... and everybody else's; stage bs-1 retired
+      if (bs + 1 < n_bstages) issue_b(bs + 1, (bs + 1) & 1);
+      if (trow == 0 && chunk + 1 < p.n_stages) issue_a(chunk + 1, (chunk + 1) & 1);
+      const u32x4* cB = lB + (bs & 1) * B_CHUNKS;
+#pragma unroll
+      for (int tcol = 0; tcol < KS; ++tcol) {
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          bf16x8 bf[NT], af[MT];
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const int co = (wn * NT + j) * 32 + px;
+            bf[j] = __builtin_bit_cast(bf16x8, cB[((tcol * KSTEPS + ks) * 2 + khalf) * TN + co]);
+          }
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            const int row = wm * MT + i;
+            const int pos = (row * STRIDE + trow) * G::IW + px * STRIDE + tcol;
+            af[i] = __builtin_bit_cast(bf16x8, cA[(ks * 2 + khalf) * G::NPOS + pos]);
+          }
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int ncol = lane & 31, rhalf = lane >> 5;
+  // static_for: the accumulator indices must be compile-time constants (a runtime-indexed
+  // ext_vector array is demoted to scratch memory)
+  static_for<NT>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const int co = ct * TN + (wn * NT + j) * 32 + ncol;
+    const bool co_ok = co < p.Cout;
+    const float bv = (co_ok && p.bias) ? p.bias[co] : 0.f;
+    static_for<MT>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const int oy = oy0 + wm * MT + i;
+      const bool row_ok = oy < p.OH;
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int xb = ox0 + 8 * rq + 4 * rhalf;  // 4 consecutive x: xb .. xb+3
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rq * 4 + e] + bv;
+        const size_t pix0 = ((size_t)b * p.OH + oy) * p.OW + xb;
+        if (p.out_mode == GLARE_OUT_NHWC_BF16 || p.out_mode == GLARE_OUT_NHWC_F32) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (row_ok && co_ok && xb + e < p.OW) {
+              float y = v[e];
+              if (p.res) y += bf2f(p.res[(pix0 + e) * p.rpitch + p.roff + co]);
+              y = apply_act(y, p.act);
+              if (p.out_mode == GLARE_OUT_NHWC_BF16)
+                reinterpret_cast<bf16_t*>(p.out)[(pix0 + e) * p.opitch + p.ooff + co] = f2bf(y);
+              else
+                reinterpret_cast<float*>(p.out)[(pix0 + e) * p.opitch + p.ooff + co] = y;
+            }
+          }
+        } else {  // planar: [b][co][plane_pitch], pixel index y*OW + x
+          if (co_ok && row_ok) {
+            const size_t base = ((size_t)b * p.opitch + p.ooff + co) * (size_t)p.plane_pitch + (size_t)oy * p.OW + xb;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (xb + e < p.OW) {
+                const float y = apply_act(v[e], p.act);
+                if (p.out_mode == GLARE_OUT_PLANAR_F32)
+                  reinterpret_cast<float*>(p.out)[base + e] = y;
+                else
+                  reinterpret_cast<bf16_t*>(p.out)[base + e] = f2bf(y);
+              }
+            }
+          }
+        }
+      }
+    });
+  });
+}
+
+// Packs OIHW fp32 weights into the stage-ordered bf16 image the kernel copies verbatim:
+// [co_tile][stage][tap][kstep][khalf][TN][8], zero-filled outside Cout / Cin.
+__global__ void pack_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin, int KS,
+                                   int TN, int KSTEPS, int n_stages, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  long long t = i;
+  const int e = t % 8; t /= 8;
+  const int n = t % TN; t /= TN;
+  const int khalf = t % 2; t /= 2;
+  const int ks = t % KSTEPS; t /= KSTEPS;
+  const int tap = t % (KS * KS); t /= (KS * KS);
+  const int s = t % n_stages; t /= n_stages;
+  const int ct = (int)t;
+  const int co = ct * TN + n;
+  const int ci = (s * KSTEPS + ks) * 16 + khalf * 8 + e;
+  float v = 0.f;
+  if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * KS * KS + tap];
+  out[i] = f2bf(v);
+}
+
+struct Variant {
+  int tn, ksteps;
+};
+
+Variant pick_variant(int ksize, int cout) {
+  Variant v;
+  v.tn = cout > 64 ? 128 : (cout > 32 ? 64 : 32);
+  v.ksteps = ksize == 1 ? 2 : 1;
+  return v;
+}
+
+template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int KSTEPS>
+int launch(const ConvParams& p, hipStream_t stream) {
+  using G = TileGeom<KS, STRIDE>;
+  constexpr int TN = WN * NT * 32;
+  const size_t lds = (size_t)(2 * (((KSTEPS * 2 * G::NPOS + 63) / 64) * 64) + 2 * KS * KSTEPS * 2 * TN) * 16;
+  auto kern = conv_igemm_kernel<KS, STRIDE, MT, NT, WM, WN, KSTEPS>;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return GLARE_ERR_LAUNCH;
+  hipLaunchKernelGGL(kern, dim3(p.n_blocks), dim3(NTHREADS), lds, stream, p);
+  return glare_launch_status();
+}
+
+}  // namespace
+
+extern "C" long long glare_conv2d_packed_weight_elems(int cout, int cin_total, int ksize) {
+  if (cout <= 0 || cin_total <= 0 || (ksize != 1 && ksize != 3)) return GLARE_ERR_INVALID;
+  const Variant v = pick_variant(ksize, cout);
+  const int kc = 16 * v.ksteps;
+  const long long stages = (cin_total + kc - 1) / kc, co_tiles = (cout + v.tn - 1) / v.tn;
+  return co_tiles * stages * ksize * ksize * v.ksteps * 2 * v.tn * 8;
+}
+
+extern "C" int glare_conv2d_pack_weight(const float* w_oihw, int cout, int cin_total, int ksize, void* packed_bf16,
+                                        glare_stream_t stream) {
+  const long long total = glare_conv2d_packed_weight_elems(cout, cin_total, ksize);
+  if (total < 0 || !w_oihw || !packed_bf16) return GLARE_ERR_INVALID;
+  const Variant v = pick_variant(ksize, cout);
+  const int kc = 16 * v.ksteps;
+  const int stages = (cin_total + kc - 1) / kc;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     w_oihw, (bf16_t*)packed_bf16, cout, cin_total, ksize, v.tn, v.ksteps, stages, total);
+  return glare_launch_status();
+}
+
+extern "C" int glare_conv2d_bf16(const glare_conv_desc* d, glare_stream_t stream_) {
+  if (!d || !d->in || !d->weight_packed || !d->out) return GLARE_ERR_INVALID;
+  if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0) return GLARE_ERR_INVALID;
+  if (d->ksize != 1 && d->ksize != 3) return GLARE_ERR_UNSUPPORTED;
+  if (d->stride != 1 && d->stride != 2) return GLARE_ERR_UNSUPPORTED;
+  if (d->stride == 2 && (d->ksize != 3 || d->upsample)) return GLARE_ERR_UNSUPPORTED;
+  // 16-B channel chunks: every source's channel count / offset / pitch must be a multiple of 8
+  if ((d->Cin % 8) || (d->in_pitch % 8) || (d->in_off % 8)) return GLARE_ERR_UNSUPPORTED;
+  if (d->in2 && ((d->Cin2 % 8) || (d->in2_pitch % 8) || (d->in2_off % 8) || d->Cin2 <= 0)) return GLARE_ERR_UNSUPPORTED;
+  if (d->out_mode < GLARE_OUT_NHWC_BF16 || d->out_mode > GLARE_OUT_PLANAR_BF16) return GLARE_ERR_INVALID;
+  if (d->residual && d->out_mode > GLARE_OUT_NHWC_F32) return GLARE_ERR_UNSUPPORTED;
+  if (d->in_off + d->Cin > d->in_pitch || d->out_off + d->Cout > d->out_pitch) return GLARE_ERR_INVALID;
+
+  ConvParams p;
+  p.in0 = (const bf16_t*)d->in;
+  p.in1 = (const bf16_t*)d->in2;
+  p.wpk = (const bf16_t*)d->weight_packed;
+  p.bias = d->bias;
+  p.res = (const bf16_t*)d->residual;
+  p.out = d->out;
+  p.B = d->B; p.H = d->H; p.W = d->W;
+  p.IHs = d->upsample ? 2 * d->H : d->H;
+  p.IWs = d->upsample ? 2 * d->W : d->W;
+  if (d->stride == 2) {  // pad (0,1,0,1) then valid 3x3 s2 (encoder_decoder.py:71-73)
+    p.OH = (p.IHs + 1 - 3) / 2 + 1;
+    p.OW = (p.IWs + 1 - 3) / 2 + 1;
+  } else {
+    p.OH = p.IHs; p.OW = p.IWs;
+  }
+  p.Cin0 = d->Cin; p.Cin1 = d->in2 ? d->Cin2 : 0; p.CinTot = p.Cin0 + p.Cin1;
+  p.p0 = d->in_pitch; p.o0 = d->in_off; p.p1 = d->in2_pitch; p.o1 = d->in2_off;
+  p.Cout = d->Cout; p.opitch = d->out_pitch; p.ooff = d->out_off;
+  p.rpitch = d->res_pitch; p.roff = d->res_off;
+  p.upsample = d->upsample; p.act = d->act; p.out_mode = d->out_mode;
+  p.plane_pitch = d->plane_pitch > 0 ? d->plane_pitch : (long long)p.OH * p.OW;
+  if (p.plane_pitch < (long long)p.OH * p.OW) return GLARE_ERR_INVALID;
+  const Variant v = pick_variant(d->ksize, d->Cout);
+  const int kc = 16 * v.ksteps;
+  // a stage must not straddle the two concatenated sources
+  if (p.in1 && (p.Cin0 % kc)) return GLARE_ERR_UNSUPPORTED;
+  p.n_stages = (p.CinTot + kc - 1) / kc;
+  p.tiles_x = cdiv(p.OW, TW); p.tiles_y = cdiv(p.OH, TH); p.co_tiles = cdiv(p.Cout, v.tn);
+  const long long nb = (long long)p.B * p.tiles_x * p.tiles_y * p.co_tiles;
+  if (nb > 0x7fffffffLL) return GLARE_ERR_INVALID;
+  p.n_blocks = (int)nb;
+  hipStream_t stream = (hipStream_t)stream_;
+
+#define GLARE_CONV_DISPATCH(KS_, ST_)                                                     \
+  do {                                                                                    \
+    constexpr int KST = (KS_ == 1) ? 2 : 1;                                               \
+    if (v.tn == 128) return launch<KS_, ST_, 4, 2, 2, 2, KST>(p, stream);                 \
+    if (v.tn == 64) return launch<KS_, ST_, 4, 1, 2, 2, KST>(p, stream);                  \
+    return launch<KS_, ST_, 2, 1, 4, 1, KST>(p, stream);                                  \
+  } while (0)
+
+  if (d->ksize == 1) GLARE_CONV_DISPATCH(1, 1);
+  if (d->stride == 2) GLARE_CONV_DISPATCH(3, 2);
+  GLARE_CONV_DISPATCH(3, 1);
+#undef GLARE_CONV_DISPATCH
+  return GLARE_ERR_UNSUPPORTED;
+}

@@ -92,9 +92,10 @@ __global__ __launch_bounds__(VQ_THREADS, 1) void vq_nearest_kernel(
 extern "C" int glare_vq_nearest_f32(const float* z_nhwc, const float* codebook, long long n_tokens,
                                     int n_codes, int dim, long long* idx_i64, float* zq_nhwc,
                                     glare_stream_t stream) {
-  if (!z_nhwc || !codebook || !idx_i64 || n_tokens < 0 || n_codes <= 0) return GLARE_ERR_INVALID;
+  if (n_tokens < 0 || n_codes <= 0) return GLARE_ERR_INVALID;
   if (dim != 3) return GLARE_ERR_UNSUPPORTED;  // the GLARE codebook is 8192 x 3 (VQModel_arch.py:44)
-  if (n_tokens == 0) return GLARE_OK;
+  if (n_tokens == 0) return GLARE_OK;          // empty batch: nothing to do, pointers may be NULL
+  if (!z_nhwc || !codebook || !idx_i64) return GLARE_ERR_INVALID;
   const size_t lds = (size_t)VQ_CHUNK * sizeof(f32x4);
   // per call, not cached: the attribute is per device and the library keeps no state
   if (hipFuncSetAttribute((const void*)vq_nearest_kernel<VQ_TPT>,

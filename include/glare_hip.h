@@ -57,6 +57,52 @@ int glare_vq_nearest_f32(const float* z_nhwc, const float* codebook, long long n
                          int n_codes, int dim, long long* idx_i64, float* zq_nhwc,
                          glare_stream_t stream);
 
+/* ---- a1/a6/a8: im2col-free direct convolution on bf16 MFMA ----------------------------------
+ * Replaces torch.nn.Conv2d / F.conv2d for the 3x3 and 1x1 convolutions of the VQGAN
+ * encoder/decoder, AttnBlock projections, WarpBlock.offset, DCNv2Pack.conv_offset and the flow
+ * coupling nets (encoder_decoder.py:43-52,62-75,88-115,146-165; deformableDecoder_arch.py:282;
+ * deform_conv.py:357-364; flow.py:13-70).  fp32 accumulation, bf16 NHWC activations.
+ * Fused in the loader: zero padding (pad 1 for 3x3 stride 1; (0,1,0,1) for stride 2 ==
+ * Downsample, encoder_decoder.py:71-73), nearest x2 upsampling of the input (Upsample,
+ * encoder_decoder.py:50), channel concatenation of two sources (torch.cat, deformableDecoder_arch.py:286).
+ * Fused in the epilogue: bias, residual add (encoder_decoder.py:137,192), activation, layout/dtype. */
+#define GLARE_ACT_NONE 0
+#define GLARE_ACT_RELU 1
+#define GLARE_ACT_SIGMOID 2
+#define GLARE_ACT_SWISH 3
+
+#define GLARE_OUT_NHWC_BF16 0   /* out[pixel][out_pitch] bf16                              */
+#define GLARE_OUT_NHWC_F32 1    /* out[pixel][out_pitch] fp32                              */
+#define GLARE_OUT_PLANAR_F32 2  /* out[b][out_off+co][plane_pitch] fp32 (NCHW)             */
+#define GLARE_OUT_PLANAR_BF16 3 /* out[b][out_off+co][plane_pitch] bf16 (e.g. V^T of attention) */
+
+typedef struct glare_conv_desc {
+  const void* in;            /* bf16 NHWC [B][H][W][in_pitch], channels [in_off, in_off+Cin)       */
+  const void* in2;           /* optional second source concatenated after `in` along C, or NULL    */
+  const void* weight_packed; /* from glare_conv2d_pack_weight (Cin = Cin + Cin2)                   */
+  const float* bias;         /* [Cout] fp32 or NULL                                                */
+  const void* residual;      /* bf16 NHWC [B][OH][OW][res_pitch] added before `act`, or NULL       */
+  void* out;                 /* see out_mode                                                       */
+  int B, H, W;               /* source size; conv input is 2H x 2W when upsample != 0              */
+  int Cin, in_pitch, in_off;
+  int Cin2, in2_pitch, in2_off;
+  int Cout, out_pitch, out_off; /* planar modes: out_pitch = number of planes per image            */
+  int res_pitch, res_off;
+  int ksize;                 /* 1 or 3                                                             */
+  int stride;                /* 1 (pad ksize/2) or 2 (3x3 only, pad (0,1,0,1))                     */
+  int upsample;              /* nearest x2 on the input first                                      */
+  int act;                   /* GLARE_ACT_*                                                        */
+  int out_mode;              /* GLARE_OUT_*                                                        */
+  long long plane_pitch;     /* planar modes: elements per plane (>= OH*OW); 0 = OH*OW             */
+} glare_conv_desc;
+
+/* Number of bf16 elements of the packed weight image for an OIHW [cout][cin_total][k][k] filter. */
+long long glare_conv2d_packed_weight_elems(int cout, int cin_total, int ksize);
+/* Packs fp32 OIHW weights (device) into the kernel's stage-ordered bf16 image (device). */
+int glare_conv2d_pack_weight(const float* w_oihw, int cout, int cin_total, int ksize, void* packed_bf16,
+                             glare_stream_t stream);
+int glare_conv2d_bf16(const glare_conv_desc* desc_host, glare_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

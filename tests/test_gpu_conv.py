@@ -1,0 +1,129 @@
+"""GPU: implicit-GEMM convolution (csrc/conv_igemm.hip) through the C ABI against F.conv2d in fp32
+on the same bf16-rounded operands.  Tolerance: fp32 accumulation of bf16 products -> the only
+difference to the fp32 reference is summation order and the final bf16 rounding of the output:
+|err| <= 2^-8 * |ref| + 1e-3 * max|ref|."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from glare_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, g, scale=1.0):
+    return (torch.randn(shape, generator=g) * scale)
+
+
+def _nhwc_bf16(x):  # NCHW fp32 -> NHWC bf16 on GPU
+    return x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
+
+
+def _check(got_nchw, ref, bf16_out=True):
+    ref = ref.float().cpu()
+    got = got_nchw.float().cpu()
+    tol = (2.0 ** -8 if bf16_out else 1e-5) * ref.abs() + 2e-3 * ref.abs().max()
+    bad = (got - ref).abs() > tol
+    assert not bool(bad.any()), "max err %g of max %g at %d elems" % (
+        float((got - ref).abs().max()), float(ref.abs().max()), int(bad.sum()))
+
+
+CASES = [
+    # B, Cin, Cout, H, W, k
+    (1, 128, 128, 16, 40, 3),
+    (2, 64, 256, 9, 33, 3),     # ragged tile edges
+    (1, 256, 128, 8, 32, 1),
+    (2, 512, 512, 7, 45, 1),
+    (1, 64, 64, 11, 35, 3),     # TN=64 variant
+    (1, 64, 6, 10, 37, 3),      # TN=32 variant, Cout < 32
+    (1, 128, 3, 20, 31, 3),
+    (1, 64, 108, 12, 20, 3),    # conv_offset-like (108 channels)
+    (1, 24, 40, 6, 10, 3),      # Cin not a multiple of 16 (zero-filled tail)
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,k", CASES)
+def test_conv_matches_fp32_reference(B, Cin, Cout, H, W, k):
+    g = torch.Generator().manual_seed(B * 1000 + Cin + Cout + H)
+    x = _rand((B, Cin, H, W), g)
+    w = _rand((Cout, Cin, k, k), g, 1.0 / (Cin * k * k) ** 0.5)
+    b = _rand((Cout,), g, 0.1)
+    xb = x.to(torch.bfloat16).float()
+    wb = w.to(torch.bfloat16).float()
+    ref = F.conv2d(xb.cuda(), wb.cuda(), b.cuda(), 1, k // 2)
+    pc = ops.PackedConv(w.cuda(), b.cuda())
+    out = ops.conv2d(_nhwc_bf16(x), pc)
+    _check(out.permute(0, 3, 1, 2), ref)
+
+
+def test_residual_act_and_f32_output():
+    g = torch.Generator().manual_seed(5)
+    x = _rand((2, 128, 10, 34), g)
+    w = _rand((128, 128, 3, 3), g, 0.03)
+    b = _rand((128,), g, 0.1)
+    r = _rand((2, 128, 10, 34), g)
+    ref = F.conv2d(x.to(torch.bfloat16).float().cuda(), w.to(torch.bfloat16).float().cuda(), b.cuda(), 1, 1)
+    ref = F.relu(ref + r.to(torch.bfloat16).float().cuda())
+    pc = ops.PackedConv(w.cuda(), b.cuda())
+    out = ops.conv2d(_nhwc_bf16(x), pc, residual=_nhwc_bf16(r), act="relu", out_mode=ops.OUT_NHWC_F32)
+    _check(out.permute(0, 3, 1, 2), ref, bf16_out=False)
+
+
+def test_upsample_and_downsample_fusions():
+    g = torch.Generator().manual_seed(6)
+    x = _rand((1, 64, 9, 21), g)
+    w = _rand((64, 64, 3, 3), g, 0.04)
+    b = _rand((64,), g, 0.1)
+    xb, wb = x.to(torch.bfloat16).float().cuda(), w.to(torch.bfloat16).float().cuda()
+    pc = ops.PackedConv(w.cuda(), b.cuda())
+    # Upsample: nearest x2 then 3x3 (encoder_decoder.py:49-53)
+    ref = F.conv2d(F.interpolate(xb, scale_factor=2.0, mode="nearest"), wb, b.cuda(), 1, 1)
+    out = ops.conv2d(_nhwc_bf16(x), pc, upsample=True)
+    _check(out.permute(0, 3, 1, 2), ref)
+    # Downsample: pad (0,1,0,1) then 3x3 stride 2 (encoder_decoder.py:69-73), odd and even sizes
+    for hw in ((9, 21), (10, 36)):
+        x2 = _rand((1, 64) + hw, g)
+        ref = F.conv2d(F.pad(x2.to(torch.bfloat16).float().cuda(), (0, 1, 0, 1)), wb, b.cuda(), 2, 0)
+        out = ops.conv2d(_nhwc_bf16(x2), pc, stride=2)
+        assert out.shape[1:3] == ref.shape[2:]
+        _check(out.permute(0, 3, 1, 2), ref)
+
+
+def test_concat_pitch_offsets_and_planar_output():
+    g = torch.Generator().manual_seed(7)
+    a = _rand((1, 32, 12, 33), g)
+    c = _rand((1, 32, 12, 33), g)
+    w = _rand((64, 64, 3, 3), g, 0.04)
+    ref = F.conv2d(torch.cat([a, c], 1).to(torch.bfloat16).float().cuda(), w.to(torch.bfloat16).float().cuda(), None, 1, 1)
+    pc = ops.PackedConv(w.cuda(), None)
+    # source 1 lives at channel offset 16 of a 64-pitch buffer; source 2 is a separate tensor
+    buf = torch.zeros(1, 12, 33, 64, dtype=torch.bfloat16, device="cuda")
+    buf[..., 16:48] = _nhwc_bf16(a)
+    out = torch.zeros(1, 12, 33, 96, dtype=torch.bfloat16, device="cuda")
+    ops.conv2d(buf, pc, cin=32, in_off=16, x2=_nhwc_bf16(c), out=out, out_off=32)
+    _check(out[..., 32:96].permute(0, 3, 1, 2), ref)
+    assert float(out[..., :32].abs().max()) == 0.0
+    # planar (NCHW) fp32 output with a padded plane pitch
+    pl = ops.conv2d(buf, pc, cin=32, in_off=16, x2=_nhwc_bf16(c), out_mode=ops.OUT_PLANAR_F32, plane_pitch=12 * 33 + 20)
+    _check(pl[:, :, :12 * 33].reshape(1, 64, 12, 33), ref, bf16_out=False)
+    assert float(pl[:, :, 12 * 33:].abs().max()) == 0.0
+
+
+def test_full_size_linearity():
+    """BASELINE size (B=8, 128 ch, 420x620): conv(x1 + x2) == conv(x1) + conv(x2) up to bf16
+    rounding, and a spot check of 64 random output pixels against a direct fp32 evaluation."""
+    g = torch.Generator().manual_seed(8)
+    B, C, H, W = 2, 128, 420, 620
+    x = torch.randn(B, H, W, C, generator=g).to(torch.bfloat16).cuda()
+    w = _rand((C, C, 3, 3), g, 0.03)
+    pc = ops.PackedConv(w.cuda(), None)
+    y = ops.conv2d(x, pc, out_mode=ops.OUT_NHWC_F32)
+    y2 = ops.conv2d((x.float() * 2).to(torch.bfloat16), pc, out_mode=ops.OUT_NHWC_F32)
+    assert torch.allclose(y2, 2 * y, rtol=1e-5, atol=1e-5)  # scaling by 2 is exact in bf16
+    wb = w.to(torch.bfloat16).float().cuda()
+    xp = F.pad(x.float().permute(0, 3, 1, 2), (1, 1, 1, 1))
+    for _ in range(64):
+        b = int(torch.randint(0, B, (1,), generator=g)); yy = int(torch.randint(0, H, (1,), generator=g))
+        xx = int(torch.randint(0, W, (1,), generator=g))
+        ref = (xp[b, :, yy:yy + 3, xx:xx + 3][None] * wb).sum(dim=(1, 2, 3))
+        assert torch.allclose(y[b, yy, xx], ref, rtol=1e-3, atol=2e-3)
