@@ -1,0 +1,238 @@
+// Blockwise (flash-style) single-head spatial self-attention, head dim 512, bf16 MFMA.
+//
+// Replaces AttnBlock.forward's two torch.bmm + N x N softmax (reference:
+// encoder_decoder.py:176-188), which materialises a [B, N, N] score tensor (N = 16 275 tokens for a
+// 400x600 image: 1.06 GB fp32 per block per image, 11 blocks).  Here no N^2 tensor exists:
+//   out[q, :] = sum_j softmax_j(q.k_j) v_j        (scale and log2(e) are folded into q by the caller)
+//
+// Shape of the problem on CDNA4: d = 512 means the output accumulator of 32 query rows is
+// 32 x 512 fp32 = 256 registers per lane -- the whole AGPR half of the unified file.  So:
+//   * one workgroup = 4 waves = 128 query rows, one wave per SIMD, 32 rows per wave, 512 regs;
+//   * Q (32 x 512 bf16 = 128 VGPRs) stays in registers for the whole kernel;
+//   * K and V^T tiles of 32 keys stream through LDS (2 x 2 x 32 KB, double-buffered) by LDS-DMA,
+//     shared by the 4 waves; V arrives pre-transposed ([d][token], written that way by the
+//     projection conv's epilogue) so that BOTH MFMA A-operands are contraction-contiguous;
+//   * transposed products keep the softmax lane-local:
+//       S^T[kv, q] = K . Q^T   (A = K tile rows, B = Q^T from registers)  -> lane owns column q
+//       O^T[d,  q] += V^T . P^T (A = V^T tile rows, B = P^T = the lane's own S^T registers)
+//     every accumulator of a lane belongs to ONE query row: max/sum/rescale need no LDS and one
+//     cross-half shuffle; K rows are fetched in a bit-swapped order so that the lane's S^T
+//     registers are already the P^T B-fragment (no permlane, no LDS round trip for P);
+//   * LDS images are XOR-swizzled at 16-B granularity (applied on the DMA source address,
+//     the LDS destination stays lane-linear) so both fragment reads are conflict-free;
+//   * online softmax with deferred rescale (rescale the 256 accumulators only when the running
+//     max grows by more than 2^8), textbook order: decide -> rescale -> exponentiate -> P.V.
+//   * workgroups are numbered so that one XCD works on one image: its 32 CUs stream the same
+//     K/V through one L2.
+#include "common.h"
+
+namespace {
+
+constexpr int AT_THREADS = 256;
+constexpr int HD = 512;          // head dim
+constexpr int BM = 128;          // query rows per workgroup
+constexpr int BN = 32;           // keys per tile
+constexpr int KCH = BN * (HD / 8);   // 16-B chunks per K tile  (2048)
+constexpr float RESCALE_THR = 8.0f;  // log2 units
+
+__device__ __forceinline__ void dma16a(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+struct AttnParams {
+  const bf16_t* q;
+  const bf16_t* k;
+  const bf16_t* vt;
+  bf16_t* o;
+  int B, N;
+  long long Npad;
+  int ldq, ldk, ldo;
+  int n_qblocks, n_blocks;
+};
+
+__global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  u32x4* lK = reinterpret_cast<u32x4*>(smem);   // [2][KCH]
+  u32x4* lV = lK + 2 * KCH;                     // [2][KCH]
+
+  int bid = blockIdx.x;
+  {
+    const int n = p.n_blocks, q = n / 8, r = n % 8, xcd = bid % 8, kk = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kk;
+  }
+  const int b = bid / p.n_qblocks, qb = bid % p.n_qblocks;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ql = lane & 31, hi = lane >> 5;
+  const int qrow = qb * BM + wave * 32 + ql;
+  const bool q_ok = qrow < p.N;
+
+  // Q^T B-fragments: lane (q, hi) holds Q[q][16*ks + 8*hi .. +8]
+  bf16x8 qf[HD / 16];
+  {
+    const bf16_t* qp = p.q + ((size_t)b * p.N + (q_ok ? qrow : 0)) * p.ldq + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks) {
+      u32x4 v = *reinterpret_cast<const u32x4*>(qp + ks * 16);
+      if (!q_ok) v = u32x4{0u, 0u, 0u, 0u};
+      qf[ks] = __builtin_bit_cast(bf16x8, v);
+    }
+  }
+
+  f32x16 o[HD / 32];
+#pragma unroll
+  for (int i = 0; i < HD / 32; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+
+  const int n_tiles = (p.N + BN - 1) / BN;
+  const bf16_t* kbase = p.k + (size_t)b * p.N * p.ldk;
+  const bf16_t* vbase = p.vt + (size_t)b * HD * p.Npad;
+
+  // per-lane DMA source offsets (elements), tile-independent; the tile only moves a uniform base
+  //   K:   one instruction per key row (1 KB); chunk c of row r lands at r*64 + (c ^ (r & 15))
+  //   V^T: one instruction per 16 d-rows (64 B each); chunk c of row d lands at d*4 + (c ^ ((d>>2)&3))
+  int koff[BN / 4], voff[(HD / 16) / 4];
+#pragma unroll
+  for (int i = 0; i < BN / 4; ++i) {
+    const int r = wave + 4 * i;
+    koff[i] = (lane ^ (r & 15)) * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < (HD / 16) / 4; ++i) {
+    const int d = (wave + 4 * i) * 16 + (lane >> 2);
+    voff[i] = (int)(d * p.Npad) + (((lane & 3) ^ ((d >> 2) & 3)) * 8);
+  }
+  auto issue = [&](int tile, int buf) {
+#pragma unroll
+    for (int i = 0; i < BN / 4; ++i) {
+      const int r = wave + 4 * i;
+      // rows beyond N re-read row N-1 (valid memory); their scores are masked to -inf below
+      const int kv = min(tile * BN + r, p.N - 1);
+      dma16a(kbase + (size_t)kv * p.ldk + koff[i], lK + buf * KCH + r * 64);
+    }
+    const bf16_t* vt = vbase + (size_t)tile * BN;
+#pragma unroll
+    for (int i = 0; i < (HD / 16) / 4; ++i) dma16a(vt + voff[i], lV + buf * KCH + (wave + 4 * i) * 64);
+  };
+
+  // K row fetched for MFMA row slot i: bits 2 and 3 swapped, so that output register r of lane
+  // (q, hi) is key 16*(r>>3) + 8*hi + (r&7) -- exactly the P^T B-fragment order.
+  const int krow = (ql & 0x13) | ((ql & 4) << 1) | ((ql & 8) >> 1);
+  const int kswz = krow & 15;
+
+  issue(0, 0);
+  for (int tile = 0; tile < n_tiles; ++tile) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tile + 1 < n_tiles) issue(tile + 1, (tile + 1) & 1);
+    const u32x4* cK = lK + (tile & 1) * KCH + krow * 64;
+    const u32x4* cV = lV + (tile & 1) * KCH;
+
+    // ---- S^T = K . Q^T  (32 keys x 32 queries, contraction over d = 512)
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks) {
+      const bf16x8 a = __builtin_bit_cast(bf16x8, cK[(2 * ks + hi) ^ kswz]);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s, 0, 0, 0);
+      if ((ks & 7) == 7) __builtin_amdgcn_sched_barrier(0);  // bound the fragment reads in flight
+    }
+    if (tile == n_tiles - 1) {  // mask keys beyond N
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kv = tile * BN + 16 * (r >> 3) + 8 * hi + (r & 7);
+        if (kv >= p.N) s[r] = -__builtin_inff();
+      }
+    }
+    // ---- online softmax, lane-local per query column
+    float mx = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (__any(mx > m_run + RESCALE_THR)) {  // wave-uniform: rescale everything still at the old max
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < HD / 32; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          // in place on the accumulator register: a plain `o *= alpha` under this (wave-uniform)
+          // branch makes the register allocator copy all 256 accumulators and spill
+          float x = o[i][r], tmp;
+          asm volatile("v_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\tv_accvgpr_write_b32 %0, %1"
+                       : "+a"(x), "=&v"(tmp)
+                       : "v"(alpha));
+          o[i][r] = x;
+        }
+      m_run = m_new;
+    }
+    float psum = 0.f;
+    bf16x8 pf[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      u32x4 w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float p0 = __builtin_amdgcn_exp2f(s[8 * h + 2 * e] - m_run);
+        const float p1 = __builtin_amdgcn_exp2f(s[8 * h + 2 * e + 1] - m_run);
+        psum += p0 + p1;
+        w[e] = pack_bf2(p0, p1);
+      }
+      pf[h] = __builtin_bit_cast(bf16x8, w);
+    }
+    l_run += psum;
+    // ---- O^T += V^T . P^T  (512 d x 32 queries, contraction over the 32 keys)
+#pragma unroll
+    for (int dt = 0; dt < HD / 32; ++dt) {
+      const int d = dt * 32 + ql;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 a = __builtin_bit_cast(bf16x8, cV[d * 4 + ((2 * ks + hi) ^ ((d >> 2) & 3))]);
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf[ks], o[dt], 0, 0, 0);
+      }
+      if ((dt & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- normalise and store O[q][d] (bf16): a lane owns ONE query row, 4 consecutive d per store
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (q_ok) {
+    bf16_t* op = p.o + ((size_t)b * p.N + qrow) * p.ldo;
+#pragma unroll
+    for (int dt = 0; dt < HD / 32; ++dt)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int d = dt * 32 + 8 * rq + 4 * hi;
+        u32x2 w = {pack_bf2(o[dt][4 * rq] * inv, o[dt][4 * rq + 1] * inv),
+                   pack_bf2(o[dt][4 * rq + 2] * inv, o[dt][4 * rq + 3] * inv)};
+        *reinterpret_cast<u32x2*>(op + d) = w;
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" int glare_attention_d512_bf16(const void* q, int ldq, const void* k, int ldk, const void* v_t,
+                                         long long v_pitch, void* out, int ldo, int B, int N, glare_stream_t stream) {
+  if (!q || !k || !v_t || !out || B <= 0 || N <= 0) return GLARE_ERR_INVALID;
+  if ((ldq % 8) || (ldk % 8) || (ldo % 4) || (v_pitch % 8) || ldq < HD || ldk < HD || ldo < HD) return GLARE_ERR_UNSUPPORTED;
+  if (v_pitch < (long long)((N + BN - 1) / BN) * BN) return GLARE_ERR_INVALID;  // tiles read whole 32-key groups
+  AttnParams p;
+  p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.vt = (const bf16_t*)v_t; p.o = (bf16_t*)out;
+  p.B = B; p.N = N; p.Npad = v_pitch; p.ldq = ldq; p.ldk = ldk; p.ldo = ldo;
+  p.n_qblocks = (N + BM - 1) / BM;
+  const long long nb = (long long)B * p.n_qblocks;
+  if (nb > 0x7fffffffLL) return GLARE_ERR_INVALID;
+  p.n_blocks = (int)nb;
+  const size_t lds = (size_t)4 * KCH * 16;  // 128 KB
+  if (hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return GLARE_ERR_LAUNCH;
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(p.n_blocks), dim3(AT_THREADS), lds, (hipStream_t)stream, p);
+  return glare_launch_status();
+}

@@ -1,0 +1,110 @@
+// Direct convolution for the thin layers whose INPUT has at most 4 channels.
+//
+// Replaces nn.Conv2d for conv_in 3->128 (Encoder, encoder_decoder.py:355), conv_in 3->512
+// (Decoder :467, MultiScaleDecoder2 deformableDecoder_arch.py:436), cond_conv 3->64 + sigmoid and
+// color_conv 3->3 (ConditionEncoder.py:41-43), quant/post_quant 1x1 3->3 (VQModel_arch.py:46-47).
+// These are HBM-bound (27 MACs per output element): no MFMA, fp32 input and arithmetic, each lane
+// produces 8 consecutive output channels of one pixel (one 16-B store), weights sit in LDS as
+// [tap][ci][Cout] so the 8 weights of a lane are one ds_read_b128 pair.
+// Input is addressed with explicit strides, so both the harness' NCHW image and the NHWC fp32
+// latent (tokens x 3) are read in place.
+#include "common.h"
+
+namespace {
+
+constexpr int CS_THREADS = 256;
+
+template <int KS>
+__global__ __launch_bounds__(CS_THREADS) void conv_small_kernel(
+    const float* __restrict__ x, long long sb, long long sc, long long sy, long long sx, const float* __restrict__ w,
+    const float* __restrict__ bias, void* __restrict__ out, int B, int H, int W, int Cin, int Cout, int out_pitch,
+    int out_off, int act, int out_f32) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* wl = reinterpret_cast<float*>(smem);  // [KS*KS][Cin][CoutP]
+  const int CoutP = (Cout + 7) & ~7;
+  const int taps = KS * KS;
+  for (int i = threadIdx.x; i < taps * Cin * CoutP; i += CS_THREADS) {
+    const int co = i % CoutP, ci = (i / CoutP) % Cin, t = i / (CoutP * Cin);
+    wl[i] = co < Cout ? w[((size_t)co * Cin + ci) * taps + t] : 0.f;
+  }
+  __syncthreads();
+  const int groups = CoutP / 8;
+  const long long total = (long long)B * H * W * groups;
+  for (long long idx = (long long)blockIdx.x * CS_THREADS + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * CS_THREADS) {
+    const int g = idx % groups;
+    long long pix = idx / groups;
+    const int xw = pix % W;
+    pix /= W;
+    const int yh = pix % H;
+    const int b = pix / H;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = (bias && g * 8 + e < Cout) ? bias[g * 8 + e] : 0.f;
+#pragma unroll
+    for (int t = 0; t < KS * KS; ++t) {
+      const int iy = yh + t / KS - KS / 2, ix = xw + t % KS - KS / 2;
+      if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+      const float* xp = x + b * sb + iy * sy + ix * sx;
+      for (int ci = 0; ci < Cin; ++ci) {
+        const float v = xp[ci * sc];
+        const f32x4* wp = reinterpret_cast<const f32x4*>(wl + ((size_t)t * Cin + ci) * CoutP + g * 8);
+        const f32x4 w0 = wp[0], w1 = wp[1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[e] = fmaf(v, w0[e], acc[e]);
+          acc[4 + e] = fmaf(v, w1[e], acc[4 + e]);
+        }
+      }
+    }
+    const size_t opix = ((size_t)b * H + yh) * W + xw;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (act == GLARE_ACT_SIGMOID) acc[e] = sigmoidf_(acc[e]);
+      else if (act == GLARE_ACT_RELU) acc[e] = fmaxf(acc[e], 0.f);
+      else if (act == GLARE_ACT_SWISH) acc[e] = swishf_(acc[e]);
+    }
+    if (out_f32) {
+      float* o = reinterpret_cast<float*>(out) + opix * out_pitch + out_off + g * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (g * 8 + e < Cout) o[e] = acc[e];
+    } else {
+      bf16_t* o = reinterpret_cast<bf16_t*>(out) + opix * out_pitch + out_off + g * 8;
+      if (g * 8 + 8 <= Cout && ((out_pitch | out_off) % 8) == 0) {
+        u32x4 v = {pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3]), pack_bf2(acc[4], acc[5]), pack_bf2(acc[6], acc[7])};
+        *reinterpret_cast<u32x4*>(o) = v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (g * 8 + e < Cout) o[e] = f2bf(acc[e]);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int glare_conv2d_smallcin_f32(const float* x, long long stride_b, long long stride_c, long long stride_y,
+                                         long long stride_x, const float* w_oihw, const float* bias, void* out, int B,
+                                         int H, int W, int Cin, int Cout, int ksize, int out_pitch, int out_off, int act,
+                                         int out_is_f32, glare_stream_t stream) {
+  if (!x || !w_oihw || !out || B <= 0 || H <= 0 || W <= 0 || Cout <= 0) return GLARE_ERR_INVALID;
+  if (Cin < 1 || Cin > 4 || (ksize != 1 && ksize != 3)) return GLARE_ERR_UNSUPPORTED;
+  if (out_off + Cout > out_pitch) return GLARE_ERR_INVALID;
+  const int CoutP = (Cout + 7) & ~7;
+  const size_t lds = (size_t)ksize * ksize * Cin * CoutP * sizeof(float);
+  if (lds > 64 * 1024) return GLARE_ERR_UNSUPPORTED;
+  const long long total = (long long)B * H * W * (CoutP / 8);
+  long long blocks = (total + CS_THREADS - 1) / CS_THREADS;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (ksize == 3)
+    hipLaunchKernelGGL(conv_small_kernel<3>, dim3((unsigned)blocks), dim3(CS_THREADS), lds, (hipStream_t)stream, x, stride_b,
+                       stride_c, stride_y, stride_x, w_oihw, bias, out, B, H, W, Cin, Cout, out_pitch, out_off, act,
+                       out_is_f32);
+  else
+    hipLaunchKernelGGL(conv_small_kernel<1>, dim3((unsigned)blocks), dim3(CS_THREADS), lds, (hipStream_t)stream, x, stride_b,
+                       stride_c, stride_y, stride_x, w_oihw, bias, out, B, H, W, Cin, Cout, out_pitch, out_off, act,
+                       out_is_f32);
+  return glare_launch_status();
+}

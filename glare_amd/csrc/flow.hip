@@ -1,0 +1,111 @@
+// Conditional normalizing flow, reverse direction (sampling path), per coupling step.
+//
+// Reference: FlowUpsamplerNet.decode (FlowUpsamplerNet.py:290-326) -> FlowStep.reverse_flow
+// (FlowStep.py:100-119) -> CondAffineSeparatedAndCond.forward(reverse=True)
+// (FlowAffineCouplingsAblation.py:83-110), InvertibleConv1x1 (Permutations.py:45-59),
+// ActNorm2d (FlowActNorms.py:81-100).  The reference runs ~20 tiny torch ops plus a host-side
+// fp64 3x3 inverse and slogdet per step; here the latent state z (3 channels, fp32, token-major
+// [pixel][3] -- the layout the codebook search consumes) is touched by two fused kernels per step:
+//
+//   flow_h1:   h1 = relu( ftA[:, 64s:64s+64] + conv3x3(z[:, 0] -> 64) )        bf16 [pixel][64]
+//              ftA is the z-INDEPENDENT part of fAffine's first conv (65 -> 64 splits into a
+//              64-channel conditional part, batched for all 24 steps into one MFMA conv before
+//              the loop, and this 1-channel part); ActNorm is folded into weights and bias.
+//   (two MFMA convs: 1x1 64->64 + relu, 3x3 64->4, csrc/conv_igemm.hip)
+//   flow_tail: z[1:] = z[1:]/scale - shift;  z = z/scaleFt - shiftFt;  z = M z + t
+//              with scale = sigmoid(h+2)+1e-4 ("cross" split, thops.py:39-47) and (M, t) the
+//              host-precomposed (fp64) invconv^-1, actnorm^-1 and any following coupling-free steps.
+#include "common.h"
+
+namespace {
+
+constexpr int FL_THREADS = 256;
+
+__device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(FL_THREADS) void flow_h1_kernel(const float* __restrict__ z, const float* __restrict__ ftA,
+                                                             int a_pitch, int a_off, const float* __restrict__ wz,
+                                                             bf16_t* __restrict__ h1, int B, int H, int W) {
+  __shared__ float wl[9][64];
+  for (int i = threadIdx.x; i < 576; i += FL_THREADS) wl[i % 9][i / 9] = wz[i];  // wz is [64][9]
+  __syncthreads();
+  const long long total = (long long)B * H * W * 8;
+  for (long long idx = (long long)blockIdx.x * FL_THREADS + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * FL_THREADS) {
+    const int g = (int)(idx & 7);
+    const long long pix = idx >> 3;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H);
+    const float* a = ftA + pix * a_pitch + a_off + g * 8;
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(a), a1 = *reinterpret_cast<const f32x4*>(a + 4);
+    float acc[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+      float v = 0.f;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = z[(pix + (long long)(t / 3 - 1) * W + (t % 3 - 1)) * 3];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = fmaf(v, wl[t][g * 8 + e], acc[e]);
+    }
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack_bf2(fmaxf(acc[2 * e], 0.f), fmaxf(acc[2 * e + 1], 0.f));
+    *reinterpret_cast<u32x4*>(h1 + pix * 64 + g * 8) = o;
+  }
+}
+
+struct TailParams {
+  float M[9];
+  float t[3];
+};
+
+__global__ __launch_bounds__(FL_THREADS) void flow_tail_kernel(float* __restrict__ z, const float* __restrict__ h4,
+                                                               const float* __restrict__ hF, int f_pitch, int f_off,
+                                                               long long npix, TailParams tp, float eps) {
+  for (long long p = (long long)blockIdx.x * FL_THREADS + threadIdx.x; p < npix; p += (long long)gridDim.x * FL_THREADS) {
+    float z0 = z[p * 3], z1 = z[p * 3 + 1], z2 = z[p * 3 + 2];
+    const f32x4 h = *reinterpret_cast<const f32x4*>(h4 + p * 4);
+    // self-conditional coupling on z[1:]  (FlowAffineCouplingsAblation.py:86-92)
+    z1 = z1 / (sigmoid_acc(h[1] + 2.f) + eps) - h[0];
+    z2 = z2 / (sigmoid_acc(h[3] + 2.f) + eps) - h[2];
+    // feature-conditional affine on all channels  (:104-108)
+    const float* f = hF + p * f_pitch + f_off;
+    const f32x4 f0 = *reinterpret_cast<const f32x4*>(f);
+    const f32x2 f1 = *reinterpret_cast<const f32x2*>(f + 4);
+    z0 = z0 / (sigmoid_acc(f0[1] + 2.f) + eps) - f0[0];
+    z1 = z1 / (sigmoid_acc(f0[3] + 2.f) + eps) - f0[2];
+    z2 = z2 / (sigmoid_acc(f1[1] + 2.f) + eps) - f1[0];
+    // invconv^-1, actnorm^-1 (+ following coupling-free steps), composed on the host
+    z[p * 3] = fmaf(tp.M[0], z0, fmaf(tp.M[1], z1, fmaf(tp.M[2], z2, tp.t[0])));
+    z[p * 3 + 1] = fmaf(tp.M[3], z0, fmaf(tp.M[4], z1, fmaf(tp.M[5], z2, tp.t[1])));
+    z[p * 3 + 2] = fmaf(tp.M[6], z0, fmaf(tp.M[7], z1, fmaf(tp.M[8], z2, tp.t[2])));
+  }
+}
+
+int fl_blocks(long long items) {
+  long long b = (items + FL_THREADS - 1) / FL_THREADS;
+  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+}  // namespace
+
+extern "C" int glare_flow_h1_f32(const float* z_nhwc3, const float* ftA, int ftA_pitch, int ftA_off,
+                                 const float* wz_64x9, void* h1_bf16, int B, int H, int W, glare_stream_t stream) {
+  if (!z_nhwc3 || !ftA || !wz_64x9 || !h1_bf16 || B <= 0 || H <= 0 || W <= 0) return GLARE_ERR_INVALID;
+  if ((ftA_pitch % 4) || (ftA_off % 4) || ftA_off + 64 > ftA_pitch) return GLARE_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(flow_h1_kernel, dim3(fl_blocks((long long)B * H * W * 8)), dim3(FL_THREADS), 0, (hipStream_t)stream,
+                     z_nhwc3, ftA, ftA_pitch, ftA_off, wz_64x9, (bf16_t*)h1_bf16, B, H, W);
+  return glare_launch_status();
+}
+
+extern "C" int glare_flow_tail_f32(float* z_nhwc3, const float* h4, const float* hF, int hF_pitch, int hF_off,
+                                   long long n_pixels, const float* M_3x3_host, const float* t_3_host, float eps,
+                                   glare_stream_t stream) {
+  if (!z_nhwc3 || !h4 || !hF || !M_3x3_host || !t_3_host || n_pixels <= 0) return GLARE_ERR_INVALID;
+  if ((hF_pitch % 4) || (hF_off % 4) || hF_off + 6 > hF_pitch) return GLARE_ERR_UNSUPPORTED;
+  TailParams tp;
+  for (int i = 0; i < 9; ++i) tp.M[i] = M_3x3_host[i];
+  for (int i = 0; i < 3; ++i) tp.t[i] = t_3_host[i];
+  hipLaunchKernelGGL(flow_tail_kernel, dim3(fl_blocks(n_pixels)), dim3(FL_THREADS), 0, (hipStream_t)stream, z_nhwc3, h4, hF,
+                     hF_pitch, hF_off, n_pixels, tp, eps);
+  return glare_launch_status();
+}

@@ -1,0 +1,137 @@
+// GroupNorm(32 groups, eps) [+ swish] on NHWC bf16 activations.
+//
+// Replaces torch.nn.GroupNorm(num_groups=32, eps=1e-6) + x*sigmoid(x)
+// (reference: encoder_decoder.py:29-35, used at :119-120,126-127,170 and norm_out :436-437,546-547;
+// deformableDecoder_arch.py:573-574).  HBM-bound: one read for the statistics, one read + one
+// write for the apply; every access is a 16-B (8-channel) chunk, lanes along the channel axis
+// first so a wave reads whole contiguous pixels.
+//   pass 1  (gn_stats_kernel):  per (image, split) partial sum / sum of squares per group, fp32
+//           per-thread accumulation, LDS reduction, one fp32 pair per (image, split, group).
+//   pass 2  (gn_apply_kernel):  combines the partials in fp64, y = (x-mean)*rstd*gamma + beta,
+//           optional swish, bf16 store.
+#include "common.h"
+
+namespace {
+
+constexpr int GN_THREADS = 256;
+constexpr int GN_GROUPS = 32;
+
+// partial layout: [B][splits][32][2] fp32
+__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ partial,
+                                                              long long HW, int C, int pitch, int off, int splits) {
+  __shared__ float red[GN_GROUPS * 2];
+  const int b = blockIdx.y, sp = blockIdx.x;
+  const int CP = C / 8;                 // 16-B chunks per pixel
+  const int ppi = GN_THREADS / CP;      // pixels per iteration (C <= 2048)
+  const int chunk = threadIdx.x % CP, pl = threadIdx.x / CP;
+  const long long per = (HW + splits - 1) / splits;
+  const long long p0 = sp * per, p1 = min(HW, p0 + per);
+  if (threadIdx.x < GN_GROUPS * 2) red[threadIdx.x] = 0.f;
+  __syncthreads();
+  float s[8], q[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+  if (pl < ppi) {
+    const bf16_t* base = x + (size_t)b * HW * pitch + off + chunk * 8;
+    for (long long p = p0 + pl; p < p1; p += ppi) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(base + (size_t)p * pitch);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float lo = bflo(v[e]), hi = bfhi(v[e]);
+        s[2 * e] += lo; q[2 * e] += lo * lo;
+        s[2 * e + 1] += hi; q[2 * e + 1] += hi * hi;
+      }
+    }
+    const int cpg = C / GN_GROUPS;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int g = (chunk * 8 + e) / cpg;
+      atomicAdd(&red[g * 2], s[e]);
+      atomicAdd(&red[g * 2 + 1], q[e]);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < GN_GROUPS * 2)
+    partial[((size_t)b * splits + sp) * GN_GROUPS * 2 + threadIdx.x] = red[threadIdx.x];
+}
+
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ partial,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              bf16_t* __restrict__ y, long long HW, int C, int pitch, int off,
+                                                              int splits, float eps, int swish, int blocks_per_image) {
+  __shared__ float mean_s[GN_GROUPS], rstd_s[GN_GROUPS];
+  const int b = blockIdx.x / blocks_per_image, blk = blockIdx.x % blocks_per_image;
+  const int cpg = C / GN_GROUPS;
+  if (threadIdx.x < GN_GROUPS) {
+    double s = 0.0, q = 0.0;
+    for (int i = 0; i < splits; ++i) {
+      s += partial[((size_t)b * splits + i) * GN_GROUPS * 2 + threadIdx.x * 2];
+      q += partial[((size_t)b * splits + i) * GN_GROUPS * 2 + threadIdx.x * 2 + 1];
+    }
+    const double n = (double)HW * cpg;
+    const double m = s / n;
+    double var = q / n - m * m;   // biased variance, as torch.nn.GroupNorm
+    if (var < 0.0) var = 0.0;
+    mean_s[threadIdx.x] = (float)m;
+    rstd_s[threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const int CP = C / 8, ppi = GN_THREADS / CP;
+  const int chunk = threadIdx.x % CP, pl = threadIdx.x / CP;
+  if (pl >= ppi) return;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = chunk * 8 + e, g = c / cpg;
+    const float a = rstd_s[g] * gamma[c];
+    sc[e] = a;
+    sh[e] = beta[c] - mean_s[g] * a;
+  }
+  const long long per = (HW + blocks_per_image - 1) / blocks_per_image;
+  const long long p0 = blk * per, p1 = min(HW, p0 + per);
+  const bf16_t* xb = x + (size_t)b * HW * pitch + off + chunk * 8;
+  bf16_t* yb = y + (size_t)b * HW * C + chunk * 8;
+  for (long long p = p0 + pl; p < p1; p += ppi) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(xb + (size_t)p * pitch);
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float lo = bflo(v[e]) * sc[2 * e] + sh[2 * e];
+      float hi = bfhi(v[e]) * sc[2 * e + 1] + sh[2 * e + 1];
+      if (swish) { lo = swishf_(lo); hi = swishf_(hi); }
+      o[e] = pack_bf2(lo, hi);
+    }
+    *reinterpret_cast<u32x4*>(yb + (size_t)p * C) = o;
+  }
+}
+
+int gn_splits(long long HW) {
+  long long s = HW / 2048;
+  return (int)(s < 1 ? 1 : (s > 64 ? 64 : s));
+}
+
+}  // namespace
+
+extern "C" size_t glare_groupnorm_workspace_bytes(int B, long long HW) {
+  if (B <= 0 || HW <= 0) return 0;
+  return (size_t)B * gn_splits(HW) * GN_GROUPS * 2 * sizeof(float);
+}
+
+extern "C" int glare_groupnorm_swish_bf16(const void* x, int in_pitch, int in_off, const float* gamma, const float* beta,
+                                          void* y, int B, long long HW, int C, float eps, int swish, void* workspace,
+                                          size_t workspace_bytes, glare_stream_t stream_) {
+  if (!x || !gamma || !beta || !y || B <= 0 || HW <= 0 || C <= 0) return GLARE_ERR_INVALID;
+  // 32 groups (encoder_decoder.py:35); 16-B chunks; a pixel must fit one 256-thread pass
+  if (C % 32 || C % 8 || C > 2048 || (GN_THREADS % (C / 8)) || in_pitch % 8 || in_off % 8) return GLARE_ERR_UNSUPPORTED;
+  if (in_off + C > in_pitch) return GLARE_ERR_INVALID;
+  if (!workspace || workspace_bytes < glare_groupnorm_workspace_bytes(B, HW)) return GLARE_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int splits = gn_splits(HW);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(splits, B), dim3(GN_THREADS), 0, stream, (const bf16_t*)x, (float*)workspace,
+                     HW, C, in_pitch, in_off, splits);
+  int bpi = (int)((HW * (C / 8) + 16 * GN_THREADS - 1) / (16 * GN_THREADS));  // ~16 chunks per thread
+  if (bpi < 1) bpi = 1;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)(bpi * B)), dim3(GN_THREADS), 0, stream, (const bf16_t*)x,
+                     (const float*)workspace, gamma, beta, (bf16_t*)y, HW, C, in_pitch, in_off, splits, eps, swish, bpi);
+  return glare_launch_status();
+}

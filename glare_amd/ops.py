@@ -107,3 +107,134 @@ def conv2d(x, pc, *, x2=None, cin=None, in_off=0, cin2=None, in2_off=0, stride=1
     d.ksize, d.stride, d.upsample, d.act, d.out_mode = pc.ksize, stride, int(bool(upsample)), ACT[act], out_mode
     check(_lib.lib().glare_conv2d_bf16(ctypes.byref(d), stream_handle()), "glare_conv2d_bf16")
     return out
+
+
+# ---- thin convs, GroupNorm, glue -------------------------------------------------------------------
+_f = ctypes.c_float
+_sz = ctypes.c_size_t
+
+
+def _workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def conv2d_smallcin(x, strides, shape_bhw, weight, bias=None, act="none", out=None, out_off=0, out_f32=False):
+    """Direct conv for Cin <= 4.  x: fp32 device tensor read through explicit element strides
+    (sb, sc, sy, sx); shape_bhw = (B, H, W).  Returns NHWC [B,H,W,Cout] bf16 (or fp32)."""
+    require_cuda(x, weight, bias, out)
+    B, H, W = shape_bhw
+    w = weight.detach().float().contiguous()
+    cout, cin, k, _ = w.shape
+    b = None if bias is None else bias.detach().float().contiguous()
+    if out is None:
+        out = torch.empty(B, H, W, cout, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    sb, sc, sy, sx = strides
+    check(_lib.lib().glare_conv2d_smallcin_f32(ptr(x), _ll(sb), _ll(sc), _ll(sy), _ll(sx), ptr(w), ptr(b), ptr(out),
+                                               _i(B), _i(H), _i(W), _i(cin), _i(cout), _i(k), _i(out.shape[3]),
+                                               _i(out_off), _i(ACT[act]), _i(int(out.dtype == torch.float32)),
+                                               stream_handle()), "glare_conv2d_smallcin_f32")
+    return out
+
+
+def groupnorm(x, gamma, beta, swish=True, eps=1e-6, cin=None, in_off=0):
+    """x: bf16 NHWC [B,H,W,pitch]; returns dense bf16 NHWC [B,H,W,C]."""
+    require_cuda(x, gamma, beta)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    B, H, W, pitch = x.shape
+    C = pitch - in_off if cin is None else cin
+    lib = _lib.lib()
+    lib.glare_groupnorm_workspace_bytes.restype = _sz
+    nws = lib.glare_groupnorm_workspace_bytes(_i(B), _ll(H * W))
+    ws = _workspace(nws, x.device)
+    y = torch.empty(B, H, W, C, dtype=torch.bfloat16, device=x.device)
+    check(lib.glare_groupnorm_swish_bf16(ptr(x), _i(pitch), _i(in_off), ptr(gamma), ptr(beta), ptr(y), _i(B), _ll(H * W),
+                                         _i(C), _f(eps), _i(int(swish)), ptr(ws), _sz(ws.numel()), stream_handle()),
+          "glare_groupnorm_swish_bf16")
+    return y
+
+
+def mix(a, b, w, out=None, out_off=0, a_off=0, b_off=0, C=None):
+    require_cuda(a, b, out)
+    assert a.dtype == b.dtype == torch.bfloat16
+    C = a.shape[-1] - a_off if C is None else C
+    npix = a.numel() // a.shape[-1]
+    if out is None:
+        out = torch.empty(a.shape[:-1] + (C,), dtype=torch.bfloat16, device=a.device)
+    check(_lib.lib().glare_mix_bf16(ptr(a), _i(a.shape[-1]), _i(a_off), ptr(b), _i(b.shape[-1]), _i(b_off), ptr(out),
+                                    _i(out.shape[-1]), _i(out_off), _ll(npix), _i(C), _f(float(w)), stream_handle()),
+          "glare_mix_bf16")
+    return out
+
+
+def mean_rescale(h, xw, whole_batch=False):
+    """h bf16 [B,...], xw fp32 same shape -> h + xw * (mean(h)/mean(xw)) (bf16)."""
+    require_cuda(h, xw)
+    assert h.dtype == torch.bfloat16 and xw.dtype == torch.float32 and h.shape == xw.shape
+    B = h.shape[0]
+    n = h.numel() // B
+    lib = _lib.lib()
+    lib.glare_mean_rescale_workspace_bytes.restype = _sz
+    ws = _workspace(lib.glare_mean_rescale_workspace_bytes(_i(B), _ll(n)), h.device)
+    out = torch.empty_like(h)
+    check(lib.glare_mean_rescale_bf16(ptr(h), ptr(xw), ptr(out), _i(B), _ll(n), _i(int(whole_batch)), ptr(ws),
+                                      _sz(ws.numel()), stream_handle()), "glare_mean_rescale_bf16")
+    return out
+
+
+def nchw_to_nhwc(x, bf16=True, out=None, out_off=0):
+    require_cuda(x, out)
+    x = x.float().contiguous()
+    B, C, H, W = x.shape
+    if out is None:
+        out = torch.empty(B, H, W, C, dtype=torch.bfloat16 if bf16 else torch.float32, device=x.device)
+    check(_lib.lib().glare_nchw_to_nhwc(ptr(x), ptr(out), _i(B), _i(C), _ll(H * W), _i(out.shape[3]), _i(out_off),
+                                        _i(int(out.dtype == torch.bfloat16)), stream_handle()), "glare_nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x, C=None, off=0):
+    require_cuda(x)
+    assert x.is_contiguous()
+    B, H, W, pitch = x.shape
+    C = pitch - off if C is None else C
+    out = torch.empty(B, C, H, W, dtype=torch.float32, device=x.device)
+    check(_lib.lib().glare_nhwc_to_nchw(ptr(x), ptr(out), _i(B), _i(C), _ll(H * W), _i(pitch), _i(off),
+                                        _i(int(x.dtype == torch.bfloat16)), stream_handle()), "glare_nhwc_to_nchw")
+    return out
+
+
+# ---- flow ---------------------------------------------------------------------------------------
+def flow_h1(z, ftA, ftA_off, wz, out=None):
+    """z fp32 [B,H,W,3]; ftA fp32 [B,H,W,pitch]; wz fp32 [64,9] -> h1 bf16 [B,H,W,64]."""
+    require_cuda(z, ftA, wz, out)
+    B, H, W, _ = z.shape
+    if out is None:
+        out = torch.empty(B, H, W, 64, dtype=torch.bfloat16, device=z.device)
+    check(_lib.lib().glare_flow_h1_f32(ptr(z), ptr(ftA), _i(ftA.shape[3]), _i(ftA_off), ptr(wz), ptr(out), _i(B), _i(H),
+                                       _i(W), stream_handle()), "glare_flow_h1_f32")
+    return out
+
+
+def flow_tail(z, h4, hF, hF_off, M, t, eps=1e-4):
+    """In-place update of z fp32 [B,H,W,3]; M (9 floats) and t (3 floats) are host sequences."""
+    require_cuda(z, h4, hF)
+    Ma = (ctypes.c_float * 9)(*[float(v) for v in M])
+    ta = (ctypes.c_float * 3)(*[float(v) for v in t])
+    check(_lib.lib().glare_flow_tail_f32(ptr(z), ptr(h4), ptr(hF), _i(hF.shape[3]), _i(hF_off), _ll(z.numel() // 3), Ma, ta,
+                                         _f(eps), stream_handle()), "glare_flow_tail_f32")
+    return z
+
+
+# ---- attention ------------------------------------------------------------------------------------
+def attention_d512(q, k, v_t, N, ldq=None, ldk=None, out=None):
+    """q, k: bf16 [B, N, ld] views (d=512 used); v_t: bf16 [B, 512, v_pitch]; returns bf16 [B, N, 512]."""
+    require_cuda(q, k, v_t, out)
+    B = v_t.shape[0]
+    ldq = q.shape[-1] if ldq is None else ldq
+    ldk = k.shape[-1] if ldk is None else ldk
+    if out is None:
+        out = torch.empty(B, N, 512, dtype=torch.bfloat16, device=v_t.device)
+    check(_lib.lib().glare_attention_d512_bf16(ptr(q), _i(ldq), ptr(k), _i(ldk), ptr(v_t), _ll(v_t.shape[2]), ptr(out),
+                                               _i(out.shape[-1]), _i(B), _i(N), stream_handle()),
+          "glare_attention_d512_bf16")
+    return out

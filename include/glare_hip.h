@@ -103,6 +103,66 @@ int glare_conv2d_pack_weight(const float* w_oihw, int cout, int cin_total, int k
                              glare_stream_t stream);
 int glare_conv2d_bf16(const glare_conv_desc* desc_host, glare_stream_t stream);
 
+/* Thin convolutions whose INPUT has <= 4 channels (conv_in 3->128 / 3->512, cond_conv 3->64 +
+ * sigmoid, color_conv 3->3, quant_conv / post_quant_conv 1x1 3->3: encoder_decoder.py:355,467;
+ * ConditionEncoder.py:41-43; VQModel_arch.py:46-47).  fp32 input addressed by explicit element
+ * strides (NCHW image or NHWC latent read in place), fp32 arithmetic, w OIHW fp32 (device).
+ * out: NHWC [pixel][out_pitch], bf16 or fp32 (out_is_f32). */
+int glare_conv2d_smallcin_f32(const float* x, long long stride_b, long long stride_c, long long stride_y,
+                              long long stride_x, const float* w_oihw, const float* bias, void* out, int B, int H,
+                              int W, int Cin, int Cout, int ksize, int out_pitch, int out_off, int act,
+                              int out_is_f32, glare_stream_t stream);
+
+/* ---- GroupNorm(32, C, eps) [+ swish] --------------------------------------------------------
+ * Replaces Normalize() + nonlinearity() (encoder_decoder.py:29-35,119-120,126-127,170,436-437).
+ * x: bf16 NHWC [B][HW][in_pitch] channels [in_off, in_off+C); y: bf16 NHWC [B][HW][C] dense.
+ * C % 32 == 0, C <= 2048.  workspace: glare_groupnorm_workspace_bytes(B, HW) bytes of scratch. */
+size_t glare_groupnorm_workspace_bytes(int B, long long HW);
+int glare_groupnorm_swish_bf16(const void* x, int in_pitch, int in_off, const float* gamma, const float* beta,
+                               void* y, int B, long long HW, int C, float eps, int swish, void* workspace,
+                               size_t workspace_bytes, glare_stream_t stream);
+
+/* ---- a8 glue: Mix and the mean rescale of MultiScaleDecoder2 --------------------------------
+ * glare_mix_bf16: out = sigmoid(w)*a + (1-sigmoid(w))*b   (Mix.forward, deformableDecoder_arch.py:587-590)
+ * glare_mean_rescale_bf16: out = h + xw * (mean(h)/mean(xw))  (deformableDecoder_arch.py:567); means per
+ * sample (whole_batch_mean = 0, the build's inference contract) or over the whole batch
+ * tensor as the reference does (whole_batch_mean = 1).  h, out: bf16 [B][n_per_sample]; xw: fp32. */
+int glare_mix_bf16(const void* a, int a_pitch, int a_off, const void* b, int b_pitch, int b_off, void* out,
+                   int out_pitch, int out_off, long long n_pixels, int C, float mix_w, glare_stream_t stream);
+size_t glare_mean_rescale_workspace_bytes(int B, long long n_per_sample);
+int glare_mean_rescale_bf16(const void* h, const float* xw, void* out, int B, long long n_per_sample,
+                            int whole_batch_mean, void* workspace, size_t workspace_bytes, glare_stream_t stream);
+
+/* Layout conversion at the module boundary: the reference's tensors are NCHW fp32. */
+int glare_nchw_to_nhwc(const float* src_nchw, void* dst_nhwc, int B, int C, long long HW, int dst_pitch, int dst_off,
+                       int dst_is_bf16, glare_stream_t stream);
+int glare_nhwc_to_nchw(const void* src_nhwc, float* dst_nchw, int B, int C, long long HW, int src_pitch, int src_off,
+                       int src_is_bf16, glare_stream_t stream);
+
+/* ---- a3: conditional flow, reverse direction, per coupling step ------------------------------
+ * Replaces FlowStep.reverse_flow (FlowStep.py:100-119) = CondAffineSeparatedAndCond reverse
+ * (FlowAffineCouplingsAblation.py:83-110) + InvertibleConv1x1 reverse (Permutations.py:45-59) +
+ * ActNorm2d reverse (FlowActNorms.py:81-100).  z: fp32 token-major [B*H*W][3], updated in place.
+ * glare_flow_h1_f32:  h1 = relu(ftA[:, off:off+64] + conv3x3(z[:,0] -> 64; wz[64][9]))  -> bf16 [pixel][64]
+ * glare_flow_tail_f32: self-conditional affine from h4 [pixel][4], feature affine from
+ *                      hF[pixel][pitch] (6 used at hF_off), then z = M z + t (host 3x3 / 3). */
+int glare_flow_h1_f32(const float* z_nhwc3, const float* ftA, int ftA_pitch, int ftA_off, const float* wz_64x9,
+                      void* h1_bf16, int B, int H, int W, glare_stream_t stream);
+int glare_flow_tail_f32(float* z_nhwc3, const float* h4, const float* hF, int hF_pitch, int hF_off,
+                        long long n_pixels, const float* M_3x3_host, const float* t_3_host, float eps,
+                        glare_stream_t stream);
+
+/* ---- a2: blockwise spatial self-attention, one head, d = 512 ---------------------------------
+ * Replaces the bmm / softmax / bmm of AttnBlock.forward (encoder_decoder.py:176-188) without the
+ * [B, N, N] score tensor.   out[b, i, :] = sum_j softmax_j(q_i . k_j) v_j
+ * q, k : bf16 [B][N][ldq|ldk] row-major (d contiguous); the caller folds 512^-0.5 * log2(e) into q
+ *        (the kernel exponentiates with exp2).
+ * v_t  : bf16 [B][512][v_pitch], V TRANSPOSED (token index contiguous), v_pitch >= roundup(N, 32),
+ *        multiple of 8, pad columns zero (written so by glare_conv2d_bf16 with GLARE_OUT_PLANAR_BF16).
+ * out  : bf16 [B][N][ldo]. */
+int glare_attention_d512_bf16(const void* q, int ldq, const void* k, int ldk, const void* v_t, long long v_pitch,
+                              void* out, int ldo, int B, int N, glare_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

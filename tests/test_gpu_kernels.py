@@ -1,0 +1,141 @@
+"""GPU: the HBM-bound kernels and the attention kernel through the C ABI against plain fp32 torch
+formulas of the same op (the oracle's formulas) on identical bf16-rounded inputs."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from glare_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("B,C,H,W,swish", [(2, 128, 13, 17, True), (1, 512, 9, 11, False), (2, 32, 5, 7, True),
+                                            (1, 256, 40, 64, True)])
+def test_groupnorm_swish(B, C, H, W, swish):
+    g = torch.Generator().manual_seed(C + H)
+    x = _bf(torch.randn(B, H, W, C, generator=g) * 2 + 0.5).cuda()
+    gamma = (torch.randn(C, generator=g) * 0.3 + 1).cuda()
+    beta = (torch.randn(C, generator=g) * 0.3).cuda()
+    y = ops.groupnorm(x, gamma, beta, swish=swish)
+    ref = F.group_norm(x.float().permute(0, 3, 1, 2), 32, gamma, beta, eps=1e-6)
+    if swish:
+        ref = ref * torch.sigmoid(ref)
+    ref = ref.permute(0, 2, 3, 1)
+    # tolerance: one bf16 rounding of the output (2^-8 relative) + fp32 statistics
+    assert torch.allclose(y.float(), ref, rtol=2 ** -7, atol=2e-3)
+
+
+def test_smallcin_conv_nchw_and_nhwc_inputs():
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 3, 19, 23, generator=g).cuda()
+    for cout, k, act in ((128, 3, "none"), (64, 3, "sigmoid"), (3, 3, "none"), (3, 1, "none"), (512, 3, "none")):
+        w = (torch.randn(cout, 3, k, k, generator=g) * 0.2).cuda()
+        b = (torch.randn(cout, generator=g) * 0.1).cuda()
+        ref = F.conv2d(x, w, b, 1, k // 2)
+        if act == "sigmoid":
+            ref = torch.sigmoid(ref)
+        out = ops.conv2d_smallcin(x, (3 * 19 * 23, 19 * 23, 23, 1), (2, 19, 23), w, b, act=act, out_f32=True)
+        assert torch.allclose(out.permute(0, 3, 1, 2), ref, rtol=1e-4, atol=1e-5)
+        xn = x.permute(0, 2, 3, 1).contiguous()  # token-major latent
+        out2 = ops.conv2d_smallcin(xn, (19 * 23 * 3, 1, 23 * 3, 3), (2, 19, 23), w, b, act=act)
+        assert torch.allclose(out2.float().permute(0, 3, 1, 2), ref, rtol=2 ** -7, atol=2e-3)
+
+
+def test_mix_rescale_layout():
+    g = torch.Generator().manual_seed(4)
+    a = _bf(torch.randn(2, 6, 10, 128, generator=g)).cuda()
+    b = _bf(torch.randn(2, 6, 10, 128, generator=g)).cuda()
+    f = 1 / (1 + math.exp(0.6))
+    out = ops.mix(a, b, -0.6)
+    assert torch.allclose(out.float(), a.float() * f + b.float() * (1 - f), rtol=2 ** -7, atol=1e-3)
+    xw = (torch.randn(2, 6, 10, 128, generator=g) + 0.3).cuda()
+    h = _bf(torch.randn(2, 6, 10, 128, generator=g) + 0.2).cuda()
+    for whole in (False, True):
+        got = ops.mean_rescale(h, xw, whole_batch=whole)
+        if whole:
+            ratio = h.float().mean() / xw.mean()
+        else:
+            ratio = h.float().mean(dim=(1, 2, 3), keepdim=True) / xw.mean(dim=(1, 2, 3), keepdim=True)
+        assert torch.allclose(got.float(), h.float() + xw * ratio, rtol=2 ** -7, atol=2e-3)
+    x = torch.randn(2, 5, 7, 9, generator=g).cuda()
+    n = ops.nchw_to_nhwc(x, bf16=False)
+    assert torch.equal(n, x.permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(ops.nhwc_to_nchw(n), x)
+    nb = ops.nchw_to_nhwc(x, bf16=True)
+    assert torch.equal(nb, _bf(x.permute(0, 2, 3, 1).contiguous()))
+    assert torch.equal(ops.nhwc_to_nchw(nb), nb.float().permute(0, 3, 1, 2))
+
+
+def test_flow_kernels():
+    g = torch.Generator().manual_seed(5)
+    B, H, W = 2, 9, 11
+    z = torch.randn(B, H, W, 3, generator=g).cuda()
+    ftA = torch.randn(B, H, W, 192, generator=g).cuda()
+    wz = (torch.randn(64, 9, generator=g) * 0.1).cuda()
+    h1 = ops.flow_h1(z, ftA, 64, wz)
+    ref = F.conv2d(z[..., 0].unsqueeze(1), wz.view(64, 1, 3, 3), None, 1, 1).permute(0, 2, 3, 1) + ftA[..., 64:128]
+    assert torch.allclose(h1.float(), torch.relu(ref), rtol=2 ** -7, atol=1e-3)
+    h4 = torch.randn(B, H, W, 4, generator=g).cuda()
+    hF = torch.randn(B, H, W, 16, generator=g).cuda()
+    M = torch.randn(3, 3, generator=g)
+    t = torch.randn(3, generator=g)
+    zz = z.clone()
+    ops.flow_tail(zz, h4, hF, 8, M.flatten().tolist(), t.tolist())
+    z0, z1, z2 = z[..., 0], z[..., 1], z[..., 2]
+    z1 = z1 / (torch.sigmoid(h4[..., 1] + 2) + 1e-4) - h4[..., 0]
+    z2 = z2 / (torch.sigmoid(h4[..., 3] + 2) + 1e-4) - h4[..., 2]
+    f = hF[..., 8:14]
+    zs = torch.stack([z0 / (torch.sigmoid(f[..., 1] + 2) + 1e-4) - f[..., 0],
+                      z1 / (torch.sigmoid(f[..., 3] + 2) + 1e-4) - f[..., 2],
+                      z2 / (torch.sigmoid(f[..., 5] + 2) + 1e-4) - f[..., 4]], -1)
+    ref = zs @ M.cuda().t() + t.cuda()
+    assert torch.allclose(zz, ref, rtol=1e-5, atol=1e-5)
+
+
+def _attn_ref(q, k, v):
+    s = torch.einsum("bid,bjd->bij", q.float(), k.float())  # scale already folded into q (log2 domain)
+    p = torch.softmax(s * math.log(2.0), dim=2)
+    return torch.einsum("bij,bjd->bid", p, v.float())
+
+
+@pytest.mark.parametrize("B,N", [(1, 128), (2, 200), (1, 31), (1, 1000)])
+def test_attention_matches_softmax_reference(B, N):
+    g = torch.Generator().manual_seed(N)
+    q = _bf(torch.randn(B, N, 512, generator=g) * 0.15).cuda()
+    k = _bf(torch.randn(B, N, 512, generator=g)).cuda()
+    v = _bf(torch.randn(B, N, 512, generator=g)).cuda()
+    npad = (N + 63) // 64 * 64
+    vt = torch.zeros(B, 512, npad, dtype=torch.bfloat16, device="cuda")
+    vt[:, :, :N] = v.transpose(1, 2)
+    out = ops.attention_d512(q, k, vt, N)
+    ref = _attn_ref(q, k, v)
+    # P is rounded to bf16 before P.V and the output is bf16: 2^-7 relative of the row scale
+    assert torch.allclose(out.float(), ref, rtol=2 ** -6, atol=2 ** -7 * float(ref.abs().max()))
+
+
+def test_attention_forced_rescale_and_strided_inputs():
+    """Forces the deferred-rescale branch: one key per 32-key tile dominates a chosen query far beyond
+    the 2^8 threshold, at increasing magnitude through the sequence (cdna guide rule 26)."""
+    g = torch.Generator().manual_seed(9)
+    B, N = 1, 320
+    qk = torch.zeros(B, N, 1024)
+    q = torch.randn(B, N, 512, generator=g) * 0.05
+    k = torch.randn(B, N, 512, generator=g)
+    for tile in range(1, 10):
+        k[0, tile * 32 + 3] = q[0, 7] / q[0, 7].norm() * (20.0 * tile)  # score grows tile by tile
+    qk[..., :512] = q
+    qk[..., 512:] = k
+    qk = _bf(qk).cuda()
+    v = _bf(torch.randn(B, N, 512, generator=g)).cuda()
+    vt = torch.zeros(B, 512, 320, dtype=torch.bfloat16, device="cuda")
+    vt[:, :, :N] = v.transpose(1, 2)
+    out = ops.attention_d512(qk, qk[..., 512:], vt, N, ldq=1024, ldk=1024)
+    ref = _attn_ref(qk[..., :512], qk[..., 512:], v)
+    assert torch.isfinite(out.float()).all()
+    assert torch.allclose(out.float(), ref, rtol=2 ** -6, atol=2 ** -7 * float(ref.abs().max()))
