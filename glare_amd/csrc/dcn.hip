@@ -1,0 +1,308 @@
+// Modulated deformable convolution (DCNv2), forward: bilinear gather fused with the weight
+// contraction on the exact-fp32 MFMA -- no `columns` tensor.
+//
+// Replaces modulated_deform_conv_cuda_forward (reference: ops/dcn/src/deform_conv_cuda.cpp:490-569),
+// i.e. per sample: at::zeros(columns) -> modulated_deformable_im2col_gpu_kernel
+// (deform_conv_cuda_kernel.cu:571-633, bilinear :468-497) -> addmm_ -> bias.  The reference writes
+// and re-reads a C*9*H*W fp32 `columns` buffer (1.2 GB per 400x600 image at the full-resolution
+// warp) and gathers channel-planar (NCHW), one 4-B load per channel per corner.
+//
+// Here x is NHWC, so the cpg channels of a deformable group at one sampling corner are ONE contiguous
+// run (64-256 B): 16-B loads, lanes along the channel axis.  A workgroup owns 64 output pixels x all
+// output channels; for each (deformable group, tap) "stage" it samples a 64 x cpg tile into LDS
+// (transposed [c][pixel], so the MFMA A-fragment read is conflict-free) and contracts it with the
+// [cpg x Co] weight slab on v_mfma_f32_32x32x2_f32 (exact fp32, the reference's arithmetic class --
+// DCNv2Pack casts everything to fp32, deformableDecoder_arch.py:143,550-551).  The gather of stage
+// s+1 is issued before the MFMAs of stage s (registers hold the corners in flight); weights come
+// straight from L2 as B-fragments (pre-transposed [stage][c][Co], 128-B coalesced per half-wave).
+//   out[p, co] = bias[co] + sum_{g,k,c} W[co, g*cpg+c, k] * mask[g,k,p] * bilinear(x[., g*cpg+c], pos(p,g,k))
+// Sampling semantics follow the reference exactly: a sample is 0 unless -1 < h < H and -1 < w < W,
+// and each of the 4 corners is dropped individually when it lies outside the image.
+#include "common.h"
+
+namespace {
+
+constexpr int DC_THREADS = 256;
+constexpr int DC_PIX = 64;          // output pixels per workgroup
+constexpr int DC_PITCH = DC_PIX + 1;  // LDS row pitch (floats) of the transposed sample tile
+
+struct DcnParams {
+  const void* x;          // NHWC, fp32 or bf16
+  const float* offset;    // [B][dg*2K][off_plane]
+  const float* mask;      // [B][dg*K][mask_plane]
+  const float* wt;        // packed [dg*K*cpg][Co]
+  const float* bias;
+  float* out;
+  int B, C, H, W, Co, Ho, Wo;
+  int kh, kw, sh, sw, ph, pw, dh, dw, dg, cpg;
+  int xpitch, xoff;
+  long long off_plane, mask_plane, off_bstride, mask_bstride;
+  int mask_is_logit;
+  int out_planar;         // 0: NHWC [p][opitch] at ooff; 1: NCHW planes of out_plane elements
+  int opitch, ooff;
+  long long out_plane;
+  long long total_pix;
+};
+
+template <bool XBF16>
+struct Corner {
+  // 8 channels of one corner, kept as raw 16-B vectors while in flight
+  u32x4 v0, v1;
+};
+
+template <bool XBF16>
+__device__ __forceinline__ void load8(const void* base, long long elem_off, bool ok, Corner<XBF16>& c) {
+  const u32x4 z = {0u, 0u, 0u, 0u};
+  if (XBF16) {
+    c.v0 = ok ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(base) + elem_off) : z;
+  } else {
+    const float* p = reinterpret_cast<const float*>(base) + elem_off;
+    c.v0 = ok ? *reinterpret_cast<const u32x4*>(p) : z;
+    c.v1 = ok ? *reinterpret_cast<const u32x4*>(p + 4) : z;
+  }
+}
+
+template <bool XBF16>
+__device__ __forceinline__ float elem(const Corner<XBF16>& c, int e) {
+  if (XBF16) return (e & 1) ? bfhi(c.v0[e >> 1]) : bflo(c.v0[e >> 1]);
+  return __uint_as_float(e < 4 ? c.v0[e] : c.v1[e - 4]);
+}
+
+// NT: 32-wide output-channel tiles per wave (Co = 2 waves x NT x 32); ITEMS: (pixel, 8-channel) items
+// per thread per stage = 64 * (cpg/8) / 256.
+template <bool XBF16, int NT, int ITEMS>
+__global__ __launch_bounds__(DC_THREADS) void dcn_fwd_kernel(const DcnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* colT = reinterpret_cast<float*>(smem);  // [2][cpg][DC_PITCH]
+  const int cpg = p.cpg;
+  const int K = p.kh * p.kw;
+  const int n_stages = p.dg * K;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nch = cpg >> 3;  // 8-channel chunks per group
+  const long long pix0 = (long long)blockIdx.x * DC_PIX;
+
+  // this thread's items: (pixel, chunk), pixel-major over chunks so 8-channel neighbours are lanes
+  int it_px[ITEMS], it_ch[ITEMS];
+  int it_b[ITEMS], it_ho[ITEMS], it_wo[ITEMS];
+  bool it_ok[ITEMS];
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const int id = tid + i * DC_THREADS;
+    it_ch[i] = id % nch;
+    it_px[i] = id / nch;
+    const long long gp = pix0 + it_px[i];
+    it_ok[i] = gp < p.total_pix;
+    const long long g2 = it_ok[i] ? gp : 0;
+    it_wo[i] = (int)(g2 % p.Wo);
+    it_ho[i] = (int)((g2 / p.Wo) % p.Ho);
+    it_b[i] = (int)(g2 / ((long long)p.Wo * p.Ho));
+  }
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  Corner<XBF16> cr[ITEMS][4];
+  float cw[ITEMS][4], cm[ITEMS];
+
+  auto gather_issue = [&](int s) {
+    const int g = s / K, tap = s % K;
+    const int ti = tap / p.kw, tj = tap % p.kw;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const long long pin = (long long)it_ho[i] * p.Wo + it_wo[i];
+      const float* op = p.offset + (long long)it_b[i] * p.off_bstride + ((long long)g * 2 * K + 2 * tap) * p.off_plane + pin;
+      const float oh = it_ok[i] ? op[0] : 0.f;
+      const float ow = it_ok[i] ? op[p.off_plane] : 0.f;
+      float m = it_ok[i] ? p.mask[(long long)it_b[i] * p.mask_bstride + ((long long)g * K + tap) * p.mask_plane + pin] : 0.f;
+      if (p.mask_is_logit) m = 1.0f / (1.0f + expf(-m));
+      const float h_im = (float)(it_ho[i] * p.sh - p.ph + ti * p.dh) + oh;
+      const float w_im = (float)(it_wo[i] * p.sw - p.pw + tj * p.dw) + ow;
+      const bool inside = it_ok[i] && h_im > -1.f && w_im > -1.f && h_im < (float)p.H && w_im < (float)p.W;
+      const float hf = floorf(h_im), wf = floorf(w_im);
+      const int h_low = (int)hf, w_low = (int)wf, h_high = h_low + 1, w_high = w_low + 1;
+      const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+      const bool ok1 = inside && h_low >= 0 && w_low >= 0;
+      const bool ok2 = inside && h_low >= 0 && w_high <= p.W - 1;
+      const bool ok3 = inside && h_high <= p.H - 1 && w_low >= 0;
+      const bool ok4 = inside && h_high <= p.H - 1 && w_high <= p.W - 1;
+      cw[i][0] = hh * hw; cw[i][1] = hh * lw; cw[i][2] = lh * hw; cw[i][3] = lh * lw;
+      cm[i] = m;
+      const long long cbase = (long long)p.xoff + g * cpg + it_ch[i] * 8;
+      const long long row_lo = ((long long)it_b[i] * p.H + h_low) * p.W, row_hi = row_lo + p.W;
+      load8<XBF16>(p.x, (row_lo + w_low) * p.xpitch + cbase, ok1, cr[i][0]);
+      load8<XBF16>(p.x, (row_lo + w_high) * p.xpitch + cbase, ok2, cr[i][1]);
+      load8<XBF16>(p.x, (row_hi + w_low) * p.xpitch + cbase, ok3, cr[i][2]);
+      load8<XBF16>(p.x, (row_hi + w_high) * p.xpitch + cbase, ok4, cr[i][3]);
+    }
+  };
+  auto gather_finish = [&](int buf) {
+    float* dst = colT + (size_t)buf * cpg * DC_PITCH;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        // reference order: (w1*v1 + w2*v2 + w3*v3 + w4*v4) * mask   (kernel.cu:493-496,625)
+        const float val = cw[i][0] * elem<XBF16>(cr[i][0], e) + cw[i][1] * elem<XBF16>(cr[i][1], e) +
+                          cw[i][2] * elem<XBF16>(cr[i][2], e) + cw[i][3] * elem<XBF16>(cr[i][3], e);
+        dst[(it_ch[i] * 8 + e) * DC_PITCH + it_px[i]] = val * cm[i];
+      }
+    }
+  };
+
+  gather_issue(0);
+  gather_finish(0);
+  const int arow = (lane & 31) + 32 * wm, khalf = lane >> 5;
+  for (int s = 0; s < n_stages; ++s) {
+    __syncthreads();                       // sample tile s visible; tile s-1 retired
+    if (s + 1 < n_stages) gather_issue(s + 1);  // corners of the next stage fly during the MFMAs
+    const float* a_src = colT + (size_t)(s & 1) * cpg * DC_PITCH + arow;
+    const float* w_src = p.wt + (size_t)s * cpg * p.Co + wn * NT * 32 + (lane & 31);
+    for (int ks = 0; ks < cpg / 2; ++ks) {
+      const int kk = 2 * ks + khalf;
+      const float a = a_src[kk * DC_PITCH];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const float bv = w_src[(size_t)kk * p.Co + j * 32];
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[j], 0, 0, 0);
+      }
+    }
+    if (s + 1 < n_stages) gather_finish((s + 1) & 1);
+  }
+
+  // epilogue: C/D layout col = lane&31 (co), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel)
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int co = (wn * NT + j) * 32 + (lane & 31);
+    const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int prow = (r & 3) + 8 * (r >> 2) + 4 * khalf + 32 * wm;
+      const long long gp = pix0 + prow;
+      if (gp < p.total_pix) {
+        const float v = acc[j][r] + bv;
+        if (p.out_planar) {
+          const long long hw = (long long)p.Ho * p.Wo;
+          const long long b = gp / hw, pin = gp % hw;
+          p.out[(b * p.Co + co) * p.out_plane + pin] = v;
+        } else {
+          p.out[gp * p.opitch + p.ooff + co] = v;
+        }
+      }
+    }
+  }
+}
+
+// [Co][C][kh][kw] (reference layout) -> [g][tap][c in group][Co]
+__global__ void dcn_pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wt, int Co, int C, int K, int dg) {
+  const long long total = (long long)Co * C * K;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int cpg = C / dg;
+  const int co = (int)(i % Co);
+  long long t = i / Co;
+  const int c = (int)(t % cpg);
+  t /= cpg;
+  const int tap = (int)(t % K);
+  const int g = (int)(t / K);
+  wt[i] = w[((size_t)co * C + g * cpg + c) * K + tap];
+}
+
+template <bool XBF16>
+int launch_dcn(const DcnParams& p, hipStream_t stream) {
+  const int nt = p.Co / 64;           // 2 waves along Co
+  const int items = DC_PIX * (p.cpg / 8) / DC_THREADS;
+  const size_t lds = (size_t)2 * p.cpg * DC_PITCH * sizeof(float);
+  const unsigned blocks = (unsigned)((p.total_pix + DC_PIX - 1) / DC_PIX);
+#define DCN_CASE(NT_, IT_)                                                                            \
+  if (nt == NT_ && items == IT_) {                                                                    \
+    hipLaunchKernelGGL((dcn_fwd_kernel<XBF16, NT_, IT_>), dim3(blocks), dim3(DC_THREADS), lds, stream, p); \
+    return glare_launch_status();                                                                     \
+  }
+  DCN_CASE(1, 1) DCN_CASE(2, 1) DCN_CASE(4, 1) DCN_CASE(1, 2) DCN_CASE(2, 2) DCN_CASE(4, 2)
+#undef DCN_CASE
+  return GLARE_ERR_UNSUPPORTED;
+}
+
+int dcn_check(int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int dh, int dw, int groups, int dg) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || Co <= 0 || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 ||
+      dg <= 0 || groups <= 0)
+    return GLARE_ERR_INVALID;
+  if (C % dg) return GLARE_ERR_INVALID;                     // shape_check, deform_conv_cuda.cpp:511-516
+  if (groups != 1) return GLARE_ERR_UNSUPPORTED;            // the path uses groups = 1 (deformableDecoder_arch.py:283)
+  const int cpg = C / dg;
+  if (cpg != 32 && cpg != 64) return GLARE_ERR_UNSUPPORTED; // 64 px x cpg/8 items over 256 lanes
+  if (Co % 64 || Co > 256) return GLARE_ERR_UNSUPPORTED;
+  return GLARE_OK;
+}
+
+}  // namespace
+
+extern "C" int glare_mdcn_pack_weight_f32(const float* weight_oihw, float* packed, int Co, int C, int kh, int kw, int dg,
+                                          glare_stream_t stream) {
+  if (!weight_oihw || !packed || Co <= 0 || C <= 0 || kh <= 0 || kw <= 0 || dg <= 0 || C % dg) return GLARE_ERR_INVALID;
+  const long long total = (long long)Co * C * kh * kw;
+  hipLaunchKernelGGL(dcn_pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     weight_oihw, packed, Co, C, kh * kw, dg);
+  return glare_launch_status();
+}
+
+extern "C" int glare_mdcn_forward_nhwc(const void* x, int x_is_bf16, int x_pitch, int x_off, const float* offset,
+                                       long long offset_plane, long long offset_batch_stride, const float* mask,
+                                       long long mask_plane, long long mask_batch_stride, int mask_is_logit,
+                                       const float* weight_packed, const float* bias, float* out, int out_planar,
+                                       int out_pitch, int out_off, long long out_plane, int B, int C, int H, int W, int Co,
+                                       int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int groups, int dg,
+                                       glare_stream_t stream) {
+  if (!x || !offset || !mask || !weight_packed || !out) return GLARE_ERR_INVALID;
+  const int st = dcn_check(B, C, H, W, Co, kh, kw, sh, sw, dh, dw, groups, dg);
+  if (st != GLARE_OK) return st;
+  if ((x_pitch % 8) || (x_off % 8) || x_off + C > x_pitch) return GLARE_ERR_UNSUPPORTED;
+  DcnParams p;
+  p.x = x; p.offset = offset; p.mask = mask; p.wt = weight_packed; p.bias = bias; p.out = out;
+  p.B = B; p.C = C; p.H = H; p.W = W; p.Co = Co;
+  p.Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) / sh + 1;
+  p.Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) / sw + 1;
+  if (p.Ho <= 0 || p.Wo <= 0) return GLARE_ERR_INVALID;
+  p.kh = kh; p.kw = kw; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.dh = dh; p.dw = dw; p.dg = dg; p.cpg = C / dg;
+  p.xpitch = x_pitch; p.xoff = x_off;
+  p.off_plane = offset_plane > 0 ? offset_plane : (long long)p.Ho * p.Wo;
+  p.mask_plane = mask_plane > 0 ? mask_plane : (long long)p.Ho * p.Wo;
+  p.off_bstride = offset_batch_stride > 0 ? offset_batch_stride : (long long)dg * 2 * kh * kw * p.off_plane;
+  p.mask_bstride = mask_batch_stride > 0 ? mask_batch_stride : (long long)dg * kh * kw * p.mask_plane;
+  p.mask_is_logit = mask_is_logit;
+  p.out_planar = out_planar; p.opitch = out_pitch; p.ooff = out_off;
+  p.out_plane = out_plane > 0 ? out_plane : (long long)p.Ho * p.Wo;
+  if (!out_planar && out_off + Co > out_pitch) return GLARE_ERR_INVALID;
+  p.total_pix = (long long)B * p.Ho * p.Wo;
+  return x_is_bf16 ? launch_dcn<true>(p, (hipStream_t)stream) : launch_dcn<false>(p, (hipStream_t)stream);
+}
+
+extern "C" size_t glare_mdcn_workspace_bytes(int B, int C, int H, int W, int Co, int kh, int kw) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || Co <= 0 || kh <= 0 || kw <= 0) return 0;
+  return ((size_t)B * C * H * W + (size_t)Co * C * kh * kw) * sizeof(float) + 256;
+}
+
+// Drop-in for deform_conv_ext.modulated_deform_conv_forward (deform_conv_ext.cpp:107-124): reference
+// layouts (NCHW fp32 everywhere), caller-allocated output, callee-owned scratch replaced by `workspace`.
+extern "C" int glare_mdcn_forward_f32(const float* x, const float* offset, const float* mask, const float* weight,
+                                      const float* bias_or_null, float* out, int B, int C, int H, int W, int Co, int kh,
+                                      int kw, int sh, int sw, int ph, int pw, int dh, int dw, int groups, int dg,
+                                      void* workspace, size_t workspace_bytes, glare_stream_t stream) {
+  if (!x || !offset || !mask || !weight || !out) return GLARE_ERR_INVALID;
+  const int st = dcn_check(B, C, H, W, Co, kh, kw, sh, sw, dh, dw, groups, dg);
+  if (st != GLARE_OK) return st;
+  if (!workspace || workspace_bytes < glare_mdcn_workspace_bytes(B, C, H, W, Co, kh, kw)) return GLARE_ERR_WORKSPACE;
+  float* x_nhwc = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+  float* wt = x_nhwc + (size_t)B * C * H * W;
+  int rc = glare_nchw_to_nhwc(x, x_nhwc, B, C, (long long)H * W, C, 0, 0, stream);
+  if (rc != GLARE_OK) return rc;
+  rc = glare_mdcn_pack_weight_f32(weight, wt, Co, C, kh, kw, dg, stream);
+  if (rc != GLARE_OK) return rc;
+  return glare_mdcn_forward_nhwc(x_nhwc, 0, C, 0, offset, 0, 0, mask, 0, 0, 0, wt, bias_or_null, out, 1, 0, 0, 0, B, C, H, W, Co,
+                                 kh, kw, sh, sw, ph, pw, dh, dw, groups, dg, stream);
+}

@@ -1,0 +1,161 @@
+"""Conditional normalizing flow on HIP kernels.
+
+Mirrors FlowUpsamplerNet (code/models/modules/FlowUpsamplerNet.py:17-326), FlowStep (FlowStep.py:16-127)
+and CondAffineSeparatedAndCond (FlowAffineCouplingsAblation.py:10-151) at the configuration every
+shipped yml uses (confs/LOL.yml:69-83: L=2, K=12, additionalFlowNoAffine=2, no squeeze, no split,
+scale 1 -> conditional feature 'cond_feat').  State-dict keys are the reference's.
+
+MI355X design of the reverse (sampling) pass, decode():
+  * everything that does not depend on the latent z is hoisted out of the 24-step sequential loop and
+    batched: the conditional half of every fAffine first conv (64 -> 24*64) and the whole fFeatures
+    nets run as large MFMA convolutions over the conditional feature once;
+  * ActNorm and the Conv2dZeros scale are folded into conv weights/biases on the host;
+  * invconv^-1 (fp64 inverse, as Permutations.py:38), actnorm^-1 and the coupling-free steps that follow
+    are pre-composed in fp64 into one 3x3 matrix + offset per coupling step (the reference recomputes
+    a fp64 inverse and an slogdet per step per call);
+  * per coupling step: flow_h1 -> 1x1 MFMA conv -> 3x3 MFMA conv -> flow_tail; z stays fp32.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ._base import HipModule, to_nchw, to_nhwc
+from .flow import ActNorm2d, Conv2d, Conv2dZeros, InvertibleConv1x1
+
+
+def _opt_get(opt, keys, default=None):
+    cur = opt
+    for k in keys:
+        if cur is None:
+            return default
+        cur = cur.get(k, None) if hasattr(cur, "get") else None
+    return default if cur is None else cur
+
+
+class CondAffineSeparatedAndCond(nn.Module):
+    def __init__(self, in_channels, opt=None):
+        super().__init__()
+        self.need_features = True
+        self.in_channels = in_channels
+        self.in_channels_rrdb = _opt_get(opt, ["network_G", "flow", "conditionInFeaDim"], 64)
+        self.hidden_channels = _opt_get(opt, ["network_G", "flow", "CondAffineSeparatedAndCond", "hidden_channels"], 64)
+        self.affine_eps = _opt_get(opt, ["network_G", "flow", "CondAffineSeparatedAndCond", "eps"], 0.0001)
+        self.channels_for_nn = in_channels // 2
+        self.channels_for_co = in_channels - self.channels_for_nn
+        self.fAffine = self.F(self.channels_for_nn + self.in_channels_rrdb, self.channels_for_co * 2)
+        self.fFeatures = self.F(self.in_channels_rrdb, in_channels * 2)
+
+    def F(self, in_channels, out_channels):
+        h = self.hidden_channels
+        return nn.Sequential(Conv2d(in_channels, h), nn.ReLU(inplace=False), Conv2d(h, h, kernel_size=[1, 1]),
+                             nn.ReLU(inplace=False), Conv2dZeros(h, out_channels))
+
+
+class FlowStep(nn.Module):
+    def __init__(self, in_channels, hidden_channels=64, actnorm_scale=1.0, flow_permutation="invconv",
+                 flow_coupling="CondAffineSeparatedAndCond", LU_decomposed=False, opt=None, **unused):
+        super().__init__()
+        assert flow_permutation == "invconv"
+        self.flow_coupling = flow_coupling
+        self.actnorm = ActNorm2d(in_channels, actnorm_scale)
+        self.invconv = InvertibleConv1x1(in_channels, LU_decomposed=LU_decomposed)
+        if flow_coupling == "CondAffineSeparatedAndCond":
+            self.affine = CondAffineSeparatedAndCond(in_channels=in_channels, opt=opt)
+        elif flow_coupling != "noCoupling":
+            raise RuntimeError("coupling not Found:", flow_coupling)
+
+    def reverse_affine_fp64(self):
+        """z -> A z + c of (invconv reverse, actnorm reverse) in fp64 (FlowStep.py:112-117)."""
+        winv = torch.inverse(self.invconv.weight.detach().double().cpu())
+        d = torch.exp(-self.actnorm.logs.detach().double().cpu().reshape(-1))
+        return d.view(-1, 1) * winv, -self.actnorm.bias.detach().double().cpu().reshape(-1)
+
+
+class FlowUpsamplerNet(HipModule):
+    def __init__(self, image_shape=(80, 80, 3), hidden_channels=64, K=12, L=None, actnorm_scale=1.0,
+                 flow_permutation=None, flow_coupling="CondAffineSeparatedAndCond", LU_decomposed=False, opt=None):
+        super().__init__()
+        self.opt = opt
+        self.L = _opt_get(opt, ["network_G", "flow", "L"], 2 if L is None else L)
+        K = _opt_get(opt, ["network_G", "flow", "K"], K)
+        n_extra = int(_opt_get(opt, ["network_G", "flow", "additionalFlowNoAffine"], 2))
+        H, W, self.C = image_shape
+        assert self.C == 3
+        self.layers = nn.ModuleList()
+        for _ in range(self.L):
+            for _ in range(n_extra):  # arch_additionalFlowAffine, FlowUpsamplerNet.py:175-187
+                self.layers.append(FlowStep(self.C, hidden_channels, actnorm_scale, "invconv", "noCoupling", LU_decomposed, opt))
+            for _ in range(K):        # arch_FlowStep, :128-148
+                self.layers.append(FlowStep(self.C, hidden_channels, actnorm_scale, "invconv", flow_coupling, LU_decomposed, opt))
+        blocks = _opt_get(opt, ["network_G", "flow", "stackRRDB", "blocks"], [1, 3, 5, 7])
+        affine_in = (len(blocks or []) + 1) * 64
+        self.f = nn.Sequential(nn.Conv2d(affine_in, 2 * 3 * 64, 3, 1, 1))  # built, never called (:113-116)
+
+    # ---- host-side preparation (once per weight set) --------------------------------------------
+    def _prepare(self):
+        dev = self.layers[0].actnorm.bias.device
+        order = list(reversed(range(len(self.layers))))
+        steps = []  # one entry per coupling step, in execution (reverse) order
+        for pos, li in enumerate(order):
+            layer = self.layers[li]
+            if layer.flow_coupling == "noCoupling":
+                continue
+            A, c = layer.reverse_affine_fp64()
+            nxt = pos + 1
+            while nxt < len(order) and self.layers[order[nxt]].flow_coupling == "noCoupling":
+                A2, c2 = self.layers[order[nxt]].reverse_affine_fp64()
+                A, c = A2 @ A, A2 @ c + c2
+                nxt += 1
+            steps.append({"layer": layer, "M": A.float().flatten().tolist(), "t": c.float().tolist()})
+        assert self.layers[order[0]].flow_coupling != "noCoupling", "a leading coupling-free step has no host"
+        n = len(steps)
+        wa_ft, ba_ft, wf0, bf0 = [], [], [], []
+        for s, st in enumerate(steps):
+            aff = st["layer"].affine
+            w0, b0 = aff.fAffine[0].folded()           # [64, 65, 3, 3]: channel 0 = z1, 1..64 = conditional
+            wa_ft.append(w0[:, 1:])
+            ba_ft.append(b0)
+            st["wz"] = w0[:, 0].reshape(64, 9).float().contiguous()
+            st["c2"] = ops.PackedConv(*aff.fAffine[2].folded())
+            st["c4"] = ops.PackedConv(*aff.fAffine[4].folded())
+            f0w, f0b = aff.fFeatures[0].folded()
+            wf0.append(f0w)
+            bf0.append(f0b)
+            st["f2"] = ops.PackedConv(*aff.fFeatures[2].folded())
+            st["f4"] = ops.PackedConv(*aff.fFeatures[4].folded())
+            st["eps"] = float(aff.affine_eps)
+        return {"steps": steps, "n": n, "ftA": ops.PackedConv(torch.cat(wa_ft, 0), torch.cat(ba_ft, 0)),
+                "f0": ops.PackedConv(torch.cat(wf0, 0), torch.cat(bf0, 0)), "dev": dev}
+
+    def decode_nhwc(self, z, ft):
+        """z: fp32 NHWC [B,h,w,3] (color_map); ft: bf16 NHWC [B,h,w,64] (cond_feat) -> latent fp32 NHWC."""
+        P = self._packed("flow", self._prepare)
+        n = P["n"]
+        B, H, W, _ = z.shape
+        z = z.clone()
+        ftA = ops.conv2d(ft, P["ftA"], out_mode=ops.OUT_NHWC_F32)                 # [B,h,w,n*64] fp32
+        h1f = ops.conv2d(ft, P["f0"], act="relu")                                  # [B,h,w,n*64] bf16
+        h2f = torch.empty_like(h1f)
+        hF = torch.zeros(B, H, W, n * 8, dtype=torch.float32, device=z.device)
+        for s, st in enumerate(P["steps"]):                                        # z-independent, batched up front
+            ops.conv2d(h1f, st["f2"], cin=64, in_off=64 * s, act="relu", out=h2f, out_off=64 * s)
+            ops.conv2d(h2f, st["f4"], cin=64, in_off=64 * s, out=hF, out_off=8 * s, out_mode=ops.OUT_NHWC_F32)
+        h1 = torch.empty(B, H, W, 64, dtype=torch.bfloat16, device=z.device)
+        h2 = torch.empty_like(h1)
+        h4 = torch.empty(B, H, W, 4, dtype=torch.float32, device=z.device)
+        for s, st in enumerate(P["steps"]):                                        # the sequential part
+            ops.flow_h1(z, ftA, 64 * s, st["wz"], out=h1)
+            ops.conv2d(h1, st["c2"], act="relu", out=h2)
+            ops.conv2d(h2, st["c4"], out=h4, out_mode=ops.OUT_NHWC_F32)
+            ops.flow_tail(z, h4, hF, 8 * s, st["M"], st["t"], st["eps"])
+        return z
+
+    def decode(self, rrdbResults, z, eps_std=None, epses=None, logdet=0.0, y_onehot=None):
+        ft = rrdbResults["cond_feat"] if isinstance(rrdbResults, dict) else rrdbResults
+        x = self.decode_nhwc(to_nhwc(z, bf16=False), to_nhwc(ft, bf16=True))
+        return to_nchw(x), logdet  # the reverse log-determinant is unused by every caller on the path
+
+    def forward(self, gt=None, rrdbResults=None, z=None, epses=None, logdet=0.0, reverse=False, eps_std=None, y_onehot=None):
+        if reverse:
+            return self.decode(rrdbResults, z, eps_std, epses=epses, logdet=logdet, y_onehot=y_onehot)
+        raise NotImplementedError("the normal (training) direction is not built on HIP yet; see DESIGN.md (row a4)")

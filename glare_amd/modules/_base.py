@@ -1,0 +1,47 @@
+"""Shared plumbing of the HIP-backed modules: lazy weight packing and NCHW <-> NHWC entry/exit."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+class HipModule(nn.Module):
+    """Caches kernel-ready (packed) weights; `invalidate()` after changing parameters."""
+
+    def _packed(self, key, builder):
+        cache = self.__dict__.setdefault("_hip_cache", {})
+        if key not in cache:
+            with torch.no_grad():
+                cache[key] = builder()
+        return cache[key]
+
+    def invalidate(self):
+        for m in self.modules():
+            m.__dict__.pop("_hip_cache", None)
+
+    def _apply(self, fn, *a, **k):  # .to()/.cuda()/.float() move parameters: packed images are stale
+        self.__dict__.pop("_hip_cache", None)
+        return super()._apply(fn, *a, **k)
+
+
+def packed_conv(mod, conv, key=None, scale=None):
+    """PackedConv of an nn.Conv2d owned by `mod` (optionally scaling weight and bias first)."""
+    key = key or ("conv", id(conv))
+
+    def build():
+        w, b = conv.weight, conv.bias
+        if scale is not None:
+            w = w * scale
+            b = None if b is None else b * scale
+        return ops.PackedConv(w, b)
+
+    return mod._packed(key, build)
+
+
+def to_nhwc(x, bf16=True):
+    ops.require_cuda(x)
+    return ops.nchw_to_nhwc(x, bf16=bf16)
+
+
+def to_nchw(x):
+    return ops.nhwc_to_nchw(x)

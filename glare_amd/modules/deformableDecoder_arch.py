@@ -1,0 +1,118 @@
+"""Adaptive-Feature-Transformation decoder on HIP kernels.
+
+Mirrors code/models/modules/deformableDecoder_arch.py: DCNv2Pack (:132-152), WarpBlock (:279-290),
+Mix (:579-590), MultiScaleDecoder2 (:413-576), including the parameters the reference builds but
+never uses (scale / bias / enc, conv_out) so that checkpoints load unchanged."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ._base import HipModule, packed_conv, to_nchw, to_nhwc
+from .encoder_decoder import build_decoder_trunk, decoder_stem, gn_swish, Normalize
+from .ops.dcn import ModulatedDeformConvPack, modulated_deform_conv
+
+
+class DCNv2Pack(ModulatedDeformConvPack, HipModule):
+    """Offsets and masks come from a second feature map (deformableDecoder_arch.py:141-152)."""
+
+    def forward(self, x, feat):  # NCHW fp32, the reference surface
+        out = to_nchw(ops.conv2d(to_nhwc(feat), packed_conv(self, self.conv_offset), out_mode=ops.OUT_NHWC_F32))
+        o1, o2, mask = torch.chunk(out, 3, dim=1)
+        offset = torch.cat((o1, o2), dim=1)
+        return modulated_deform_conv(x.float(), offset, torch.sigmoid(mask), self.weight, self.bias, self.stride,
+                                     self.padding, self.dilation, self.groups, self.deformable_groups)
+
+    def forward_nhwc(self, x, feat, x_off=0):
+        """x: bf16 NHWC (the VQ-decoder feature), feat: bf16 NHWC.  conv_offset writes offsets and mask
+        logits as fp32 planes; the DCN kernel applies the sigmoid while sampling.  -> fp32 NHWC."""
+        B, H, W, _ = feat.shape
+        plane = (H * W + 63) // 64 * 64
+        om = ops.conv2d(feat, packed_conv(self, self.conv_offset), out_mode=ops.OUT_PLANAR_F32, plane_pitch=plane)
+        pd = self._packed("dcn", lambda: ops.PackedDcn(self.weight, self.bias, self.deformable_groups))
+        return ops.mdcn_forward_nhwc(x, om, pd, x_off=x_off, C=self.in_channels, mask_is_logit=True, padding=self.padding)
+
+
+class WarpBlock(HipModule):
+    def __init__(self, in_channel):
+        super().__init__()
+        self.offset = nn.Conv2d(in_channel * 2, in_channel, 3, stride=1, padding=1)
+        self.dcn = DCNv2Pack(in_channel, in_channel, 3, padding=1, deformable_groups=4)
+
+    def forward_nhwc(self, x_vq, x_residual):
+        r = ops.conv2d(x_vq, packed_conv(self, self.offset), x2=x_residual)  # torch.cat fused: two conv sources
+        return self.dcn.forward_nhwc(x_vq, r)
+
+    def forward(self, x_vq, x_residual):
+        return to_nchw(self.forward_nhwc(to_nhwc(x_vq), to_nhwc(x_residual)))
+
+
+class Mix(HipModule):
+    def __init__(self, m=-0.80):
+        super().__init__()
+        self.w = nn.Parameter(torch.FloatTensor([m]))
+        self.mix_block = nn.Sigmoid()
+
+    def forward_nhwc(self, fea1, fea2):
+        return ops.mix(fea1, fea2, float(self.w.detach()))
+
+    def forward(self, fea1, fea2):
+        return to_nchw(self.forward_nhwc(to_nhwc(fea1), to_nhwc(fea2)))
+
+
+class ResBlock(nn.Module):  # deformableDecoder_arch.py:157-180, parameters only (never called on the path)
+    def __init__(self, in_channels, out_channels=None):
+        super().__init__()
+        self.norm1 = Normalize(in_channels)
+        self.conv1 = nn.Conv2d(in_channels, out_channels, 3, 1, 1)
+        self.norm2 = Normalize(out_channels)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, 3, 1, 1)
+        if in_channels != out_channels:
+            self.conv_out = nn.Conv2d(in_channels, out_channels, 1, 1, 0)
+
+
+def _gate(c):  # :490-508, parameters only
+    return nn.Sequential(nn.Conv2d(c, c, 3, padding=1), nn.LeakyReLU(0.2, True), nn.Conv2d(c, c, 3, padding=1), nn.Sigmoid())
+
+
+class MultiScaleDecoder2(HipModule):
+    def __init__(self, ch=64, out_ch=3, ch_mult=(1, 2, 4), num_res_blocks=2, attn_resolutions=(64,), dropout=0.0,
+                 resamp_with_conv=True, in_channels=3, resolution=256, z_channels=3):
+        super().__init__()
+        self.ch, self.temb_ch, self.resolution, self.in_channels = ch, 0, resolution, in_channels
+        block_in = build_decoder_trunk(self, ch, ch_mult, num_res_blocks, attn_resolutions, resolution, z_channels,
+                                       resamp_with_conv)
+        self.conv_out = nn.Conv2d(block_in, out_ch, 3, 1, 1)
+        self.warp = nn.ModuleList([WarpBlock(ch * 2), WarpBlock(ch)])
+        self.residual_conv = nn.Conv2d(ch, out_ch, 3, 1, 1)
+        self.scale = nn.ModuleList([_gate(256), _gate(128)])
+        self.bias = nn.ModuleList([_gate(256), _gate(128)])
+        self.enc = nn.ModuleList([ResBlock(512, 256), ResBlock(256, 128)])
+        self.mix = nn.ModuleList([Mix(m=-1.0), Mix(m=-0.6)])
+        # inference: per-sample means so that a batched run equals the reference's B=1 runs
+        # (SURVEY.md section 8e); True reproduces the reference's whole-tensor means (:567)
+        self.whole_batch_mean = False
+
+    def forward_nhwc(self, z, code_feats, enc_feats):
+        """z: fp32 NHWC latent; code_feats: [bf16 NHWC @half (256), @full (128)] from the VQ decoder;
+        enc_feats: [bf16 NHWC @full (128), @half (256)] from the conditional encoder -> fp32 NCHW image."""
+        h = decoder_stem(self, z)
+        for i_level in reversed(range(self.num_resolutions)):
+            lvl = self.up[i_level]
+            for i_block in range(self.num_res_blocks + 1):
+                h = lvl.block[i_block].forward_nhwc(h)
+                if len(lvl.attn) > 0:
+                    h = lvl.attn[i_block].forward_nhwc(h)
+            if i_level != 2:  # :546-567
+                x_code = code_feats[1 - i_level]
+                h = self.mix[1 - i_level].forward_nhwc(enc_feats[i_level], h)
+                x_w = self.warp[1 - i_level].forward_nhwc(x_code, h)
+                h = ops.mean_rescale(h, x_w, whole_batch=self.whole_batch_mean)
+            if i_level != 0:
+                h = lvl.upsample.forward_nhwc(h)
+        h = gn_swish(h, self.norm_out)
+        B, H, W, _ = h.shape
+        return ops.conv2d(h, packed_conv(self, self.residual_conv), out_mode=ops.OUT_PLANAR_F32).view(B, -1, H, W)
+
+    def forward(self, z, code_decoder_output, enc_feat):
+        return self.forward_nhwc(to_nhwc(z, bf16=False), [to_nhwc(f) for f in code_decoder_output],
+                                 [to_nhwc(f) for f in enc_feat])

@@ -1,0 +1,243 @@
+"""VQGAN encoder / decoder building blocks on HIP kernels.
+
+Mirrors code/models/modules/encoder_decoder.py (ResnetBlock :78-137, AttnBlock :140-192, Upsample
+:38-53, Downsample :56-75, Encoder :342-442, Decoder :445-551): same parameter names, same forward
+signatures (NCHW fp32 in/out).  Internally activations are NHWC bf16; `forward_nhwc` chains modules
+without layout conversions and is what the fused graphs use."""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ._base import HipModule, packed_conv, to_nchw, to_nhwc
+
+
+def Normalize(in_channels):  # encoder_decoder.py:34-35
+    return nn.GroupNorm(num_groups=32, num_channels=in_channels, eps=1e-6, affine=True)
+
+
+def gn_swish(x, norm, swish=True):
+    return ops.groupnorm(x, norm.weight.detach().float(), norm.bias.detach().float(), swish=swish, eps=norm.eps)
+
+
+class Upsample(HipModule):
+    def __init__(self, in_channels, with_conv=True):
+        super().__init__()
+        assert with_conv, "GLARE always resamples with a conv (resamp_with_conv=True)"
+        self.with_conv = with_conv
+        self.conv = nn.Conv2d(in_channels, in_channels, 3, 1, 1)
+
+    def forward_nhwc(self, x, **kw):
+        return ops.conv2d(x, packed_conv(self, self.conv), upsample=True, **kw)  # nearest x2 fused in the loader
+
+    def forward(self, x):
+        return to_nchw(self.forward_nhwc(to_nhwc(x)))
+
+
+class Downsample(HipModule):
+    def __init__(self, in_channels, with_conv=True):
+        super().__init__()
+        assert with_conv
+        self.with_conv = with_conv
+        self.conv = nn.Conv2d(in_channels, in_channels, 3, 2, 0)
+
+    def forward_nhwc(self, x):
+        return ops.conv2d(x, packed_conv(self, self.conv), stride=2)  # pad (0,1,0,1) fused in the loader
+
+    def forward(self, x):
+        return to_nchw(self.forward_nhwc(to_nhwc(x)))
+
+
+class ResnetBlock(HipModule):
+    def __init__(self, *, in_channels, out_channels=None, conv_shortcut=False, dropout=0.0, temb_channels=0):
+        super().__init__()
+        assert temb_channels == 0 and not conv_shortcut and dropout == 0.0
+        out_channels = in_channels if out_channels is None else out_channels
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.norm1 = Normalize(in_channels)
+        self.conv1 = nn.Conv2d(in_channels, out_channels, 3, 1, 1)
+        self.norm2 = Normalize(out_channels)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, 3, 1, 1)
+        if in_channels != out_channels:
+            self.nin_shortcut = nn.Conv2d(in_channels, out_channels, 1, 1, 0)
+
+    def forward_nhwc(self, x, out=None, out_off=0):
+        h = ops.conv2d(gn_swish(x, self.norm1), packed_conv(self, self.conv1))
+        h = gn_swish(h, self.norm2)
+        res = x if self.in_channels == self.out_channels else ops.conv2d(x, packed_conv(self, self.nin_shortcut))
+        return ops.conv2d(h, packed_conv(self, self.conv2), residual=res, out=out, out_off=out_off)
+
+    def forward(self, x, temb=None):
+        return to_nchw(self.forward_nhwc(to_nhwc(x)))
+
+
+class AttnBlock(HipModule):
+    def __init__(self, in_channels):
+        super().__init__()
+        assert in_channels == 512, "the attention kernel is specialised for the GLARE head dim (512)"
+        self.in_channels = in_channels
+        self.norm = Normalize(in_channels)
+        self.q = nn.Conv2d(in_channels, in_channels, 1)
+        self.k = nn.Conv2d(in_channels, in_channels, 1)
+        self.v = nn.Conv2d(in_channels, in_channels, 1)
+        self.proj_out = nn.Conv2d(in_channels, in_channels, 1)
+
+    def _qk(self):
+        # softmax(q.k / sqrt(c)) == exp2-softmax with q pre-scaled by c^-0.5 * log2(e) (folded once here)
+        s = float(self.in_channels) ** -0.5 * math.log2(math.e)
+        w = torch.cat([self.q.weight * s, self.k.weight], 0)
+        b = torch.cat([self.q.bias * s, self.k.bias], 0)
+        return ops.PackedConv(w, b)
+
+    def forward_nhwc(self, x):
+        B, H, W, C = x.shape
+        N = H * W
+        hn = gn_swish(x, self.norm, swish=False)
+        qk = ops.conv2d(hn, self._packed("qk", self._qk))                       # [B,H,W,1024]: q | k
+        npad = (N + 63) // 64 * 64
+        vt = ops.conv2d(hn, packed_conv(self, self.v), out_mode=ops.OUT_PLANAR_BF16, plane_pitch=npad)  # V^T [B,512,npad]
+        o = ops.attention_d512(qk, qk[..., C:], vt, N, ldq=2 * C, ldk=2 * C)     # [B,N,512]
+        return ops.conv2d(o.view(B, H, W, C), packed_conv(self, self.proj_out), residual=x)
+
+    def forward(self, x):
+        return to_nchw(self.forward_nhwc(to_nhwc(x)))
+
+
+class _Level(nn.Module):
+    pass
+
+
+class Encoder(HipModule):
+    def __init__(self, ch=128, out_ch=3, ch_mult=(1, 2, 4, 8), num_res_blocks=2, attn_resolutions=(16,), dropout=0.0,
+                 resamp_with_conv=True, in_channels=3, resolution=256, z_channels=256, double_z=True):
+        super().__init__()
+        self.ch, self.temb_ch = ch, 0
+        self.num_resolutions, self.num_res_blocks = len(ch_mult), num_res_blocks
+        self.resolution, self.in_channels = resolution, in_channels
+        self.conv_in = nn.Conv2d(in_channels, ch, 3, 1, 1)
+        curr_res = resolution
+        in_ch_mult = (1,) + tuple(ch_mult)
+        self.down = nn.ModuleList()
+        for i_level in range(self.num_resolutions):
+            block, attn = nn.ModuleList(), nn.ModuleList()
+            block_in, block_out = ch * in_ch_mult[i_level], ch * ch_mult[i_level]
+            for _ in range(num_res_blocks):
+                block.append(ResnetBlock(in_channels=block_in, out_channels=block_out))
+                block_in = block_out
+                if curr_res in attn_resolutions:
+                    attn.append(AttnBlock(block_in))
+            down = _Level()
+            down.block, down.attn = block, attn
+            if i_level != self.num_resolutions - 1:
+                down.downsample = Downsample(block_in, resamp_with_conv)
+                curr_res //= 2
+            self.down.append(down)
+        self.mid = _Level()
+        self.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in)
+        self.mid.attn_1 = AttnBlock(block_in)
+        self.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in)
+        self.norm_out = Normalize(block_in)
+        self.conv_out = nn.Conv2d(block_in, 2 * z_channels if double_z else z_channels, 3, 1, 1)
+
+    def forward_nhwc(self, x_nchw):
+        """x_nchw: fp32 NCHW image (read in place).  Returns (latent fp32 NHWC [B,h,w,zc], enc_feat list)."""
+        x = x_nchw.float().contiguous()
+        B, C, H, W = x.shape
+        h = ops.conv2d_smallcin(x, (C * H * W, H * W, W, 1), (B, H, W), self.conv_in.weight, self.conv_in.bias)
+        feats = []
+        for i_level in range(self.num_resolutions):
+            lvl = self.down[i_level]
+            for i_block in range(self.num_res_blocks):
+                h = lvl.block[i_block].forward_nhwc(h)
+                if len(lvl.attn) > 0:
+                    h = lvl.attn[i_block].forward_nhwc(h)
+            if i_level != self.num_resolutions - 1:
+                feats.append(h)
+                h = lvl.downsample.forward_nhwc(h)
+        h = self.mid.block_2.forward_nhwc(self.mid.attn_1.forward_nhwc(self.mid.block_1.forward_nhwc(h)))
+        h = gn_swish(h, self.norm_out)
+        z = ops.conv2d(h, packed_conv(self, self.conv_out), out_mode=ops.OUT_NHWC_F32)
+        return z, feats
+
+    def forward(self, x, mid_feat=False):
+        z, feats = self.forward_nhwc(x)
+        z = to_nchw(z)
+        return (z, [to_nchw(f) for f in feats]) if mid_feat else z
+
+
+def build_decoder_trunk(mod, ch, ch_mult, num_res_blocks, attn_resolutions, resolution, z_channels, resamp_with_conv=True):
+    """conv_in / mid / up of Decoder and MultiScaleDecoder2 (identical in the reference:
+    encoder_decoder.py:445-513, deformableDecoder_arch.py:413-482)."""
+    mod.num_resolutions, mod.num_res_blocks = len(ch_mult), num_res_blocks
+    block_in = ch * ch_mult[mod.num_resolutions - 1]
+    curr_res = resolution // 2 ** (mod.num_resolutions - 1)
+    mod.z_shape = (1, z_channels, curr_res, curr_res)
+    mod.conv_in = nn.Conv2d(z_channels, block_in, 3, 1, 1)
+    mod.mid = _Level()
+    mod.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in)
+    mod.mid.attn_1 = AttnBlock(block_in)
+    mod.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in)
+    ups = []
+    for i_level in reversed(range(mod.num_resolutions)):
+        block, attn = nn.ModuleList(), nn.ModuleList()
+        block_out = ch * ch_mult[i_level]
+        for _ in range(num_res_blocks + 1):
+            block.append(ResnetBlock(in_channels=block_in, out_channels=block_out))
+            block_in = block_out
+            if curr_res in attn_resolutions:
+                attn.append(AttnBlock(block_in))
+        up = _Level()
+        up.block, up.attn = block, attn
+        if i_level != 0:
+            up.upsample = Upsample(block_in, resamp_with_conv)
+            curr_res *= 2
+        ups.insert(0, up)
+    mod.up = nn.ModuleList(ups)
+    mod.norm_out = Normalize(block_in)
+    return block_in
+
+
+def decoder_stem(mod, z_nhwc_f32):
+    """conv_in (3 -> 512, thin-input direct conv on the fp32 latent) + mid blocks."""
+    B, H, W, C = z_nhwc_f32.shape
+    h = ops.conv2d_smallcin(z_nhwc_f32, (H * W * C, 1, W * C, C), (B, H, W), mod.conv_in.weight, mod.conv_in.bias)
+    return mod.mid.block_2.forward_nhwc(mod.mid.attn_1.forward_nhwc(mod.mid.block_1.forward_nhwc(h)))
+
+
+class Decoder(HipModule):
+    def __init__(self, ch=128, out_ch=3, ch_mult=(1, 2, 4, 8), num_res_blocks=2, attn_resolutions=(16,), dropout=0.0,
+                 resamp_with_conv=True, in_channels=3, resolution=256, z_channels=256, give_pre_end=False):
+        super().__init__()
+        self.ch, self.temb_ch, self.resolution, self.in_channels = ch, 0, resolution, in_channels
+        self.give_pre_end = give_pre_end
+        block_in = build_decoder_trunk(self, ch, ch_mult, num_res_blocks, attn_resolutions, resolution, z_channels,
+                                       resamp_with_conv)
+        self.conv_out = nn.Conv2d(block_in, out_ch, 3, 1, 1)
+
+    def forward_nhwc(self, z, want_image=True):
+        """z: fp32 NHWC latent.  Returns (image fp32 NCHW or None, [feat@half, feat@full] bf16 NHWC).
+        The reference always computes the RGB image and its caller drops it
+        (VQLLFLOWDeformable_arch.py:246); want_image=False skips norm_out + conv_out."""
+        h = decoder_stem(self, z)
+        feats = []
+        for i_level in reversed(range(self.num_resolutions)):
+            lvl = self.up[i_level]
+            for i_block in range(self.num_res_blocks + 1):
+                h = lvl.block[i_block].forward_nhwc(h)
+                if len(lvl.attn) > 0:
+                    h = lvl.attn[i_block].forward_nhwc(h)
+            if i_level != 2:  # encoder_decoder.py:538-539
+                feats.append(h)
+            if i_level != 0:
+                h = lvl.upsample.forward_nhwc(h)
+        img = None
+        if want_image and not self.give_pre_end:
+            hh = gn_swish(h, self.norm_out)
+            B, H, W, _ = hh.shape
+            img = ops.conv2d(hh, packed_conv(self, self.conv_out), out_mode=ops.OUT_PLANAR_F32).view(B, -1, H, W)
+        return img, feats
+
+    def forward(self, z):
+        img, feats = self.forward_nhwc(to_nhwc(z, bf16=False))
+        return img, [to_nchw(f) for f in feats]

@@ -238,3 +238,56 @@ def attention_d512(q, k, v_t, N, ldq=None, ldk=None, out=None):
                                                _i(out.shape[-1]), _i(B), _i(N), stream_handle()),
           "glare_attention_d512_bf16")
     return out
+
+
+# ---- DCNv2 ------------------------------------------------------------------------------------------
+def mdcn_forward(x, offset, mask, weight, bias, stride=1, padding=1, dilation=1, groups=1, deformable_groups=1):
+    """Reference layouts (NCHW fp32) -> NCHW fp32; the drop-in entry point glare_mdcn_forward_f32."""
+    require_cuda(x, offset, mask, weight, bias)
+    x, offset, mask, weight = [t.float().contiguous() for t in (x, offset, mask, weight)]
+    bias = None if bias is None else bias.float().contiguous()
+    B, C, H, W = x.shape
+    Co, _, kh, kw = weight.shape
+    Ho = (H + 2 * padding - (dilation * (kh - 1) + 1)) // stride + 1
+    Wo = (W + 2 * padding - (dilation * (kw - 1) + 1)) // stride + 1
+    out = torch.empty(B, Co, Ho, Wo, dtype=torch.float32, device=x.device)
+    lib = _lib.lib()
+    lib.glare_mdcn_workspace_bytes.restype = _sz
+    ws = _workspace(lib.glare_mdcn_workspace_bytes(_i(B), _i(C), _i(H), _i(W), _i(Co), _i(kh), _i(kw)), x.device)
+    check(lib.glare_mdcn_forward_f32(ptr(x), ptr(offset), ptr(mask), ptr(weight), ptr(bias), ptr(out), _i(B), _i(C), _i(H),
+                                     _i(W), _i(Co), _i(kh), _i(kw), _i(stride), _i(stride), _i(padding), _i(padding),
+                                     _i(dilation), _i(dilation), _i(groups), _i(deformable_groups), ptr(ws),
+                                     _sz(ws.numel()), stream_handle()), "glare_mdcn_forward_f32")
+    return out
+
+
+class PackedDcn:
+    def __init__(self, weight_oihw, bias, deformable_groups):
+        require_cuda(weight_oihw)
+        w = weight_oihw.detach().float().contiguous()
+        self.co, self.c, self.kh, self.kw = w.shape
+        self.dg = deformable_groups
+        self.packed = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
+        check(_lib.lib().glare_mdcn_pack_weight_f32(ptr(w), ptr(self.packed), _i(self.co), _i(self.c), _i(self.kh),
+                                                     _i(self.kw), _i(self.dg), stream_handle()), "glare_mdcn_pack_weight_f32")
+        self.bias = None if bias is None else bias.detach().float().contiguous()
+
+
+def mdcn_forward_nhwc(x, om, pd, x_off=0, C=None, mask_is_logit=True, padding=1):
+    """x: NHWC bf16/fp32 [B,H,W,pitch]; om: planar fp32 [B, 3*dg*K, plane] (offsets then mask logits,
+    the conv_offset output); returns NHWC fp32 [B,H,W,Co]."""
+    require_cuda(x, om)
+    B, H, W, pitch = x.shape
+    C = pd.c if C is None else C
+    K = pd.kh * pd.kw
+    plane = om.shape[2]
+    out = torch.empty(B, H, W, pd.co, dtype=torch.float32, device=x.device)
+    mask = om[:, 2 * pd.dg * K:]
+    check(_lib.lib().glare_mdcn_forward_nhwc(ptr(x), _i(int(x.dtype == torch.bfloat16)), _i(pitch), _i(x_off), ptr(om),
+                                             _ll(plane), _ll(om.shape[1] * plane), ctypes.c_void_p(mask.data_ptr()),
+                                             _ll(plane), _ll(om.shape[1] * plane), _i(int(mask_is_logit)),
+                                             ptr(pd.packed), ptr(pd.bias), ptr(out), _i(0), _i(pd.co), _i(0), _ll(0), _i(B),
+                                             _i(C), _i(H), _i(W), _i(pd.co), _i(pd.kh), _i(pd.kw), _i(1), _i(1), _i(padding),
+                                             _i(padding), _i(1), _i(1), _i(1), _i(pd.dg), stream_handle()),
+          "glare_mdcn_forward_nhwc")
+    return out

@@ -163,6 +163,38 @@ int glare_flow_tail_f32(float* z_nhwc3, const float* h4, const float* hF, int hF
 int glare_attention_d512_bf16(const void* q, int ldq, const void* k, int ldk, const void* v_t, long long v_pitch,
                               void* out, int ldo, int B, int N, glare_stream_t stream);
 
+/* ---- a9: modulated deformable convolution (DCNv2), forward -----------------------------------
+ * glare_mdcn_forward_f32 is the drop-in for the pybind function
+ *   deform_conv_ext.modulated_deform_conv_forward(input, weight, bias, ones, offset, mask, output,
+ *       columns, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w,
+ *       group, deformable_group, with_bias)            (deform_conv_ext.cpp:107-124,158-160)
+ * called from ModulatedDeformConvFunction.forward (deform_conv.py:149-152): same tensors in the
+ * reference's layouts (NCHW fp32; offset [B][dg*2*kh*kw][Ho][Wo], channel g*2K+2k = dh, +1 = dw;
+ * mask [B][dg*kh*kw][Ho][Wo]; weight [Co][C/groups][kh][kw]), caller-allocated `out`
+ * (deform_conv.py:147).  The reference's callee-owned `columns`/`ones` scratch is replaced by a
+ * caller-owned workspace of glare_mdcn_workspace_bytes(); bias_or_null == NULL is with_bias=False.
+ * Supported: groups == 1, C/dg in {32, 64}, Co % 64 == 0, Co <= 256 (the GLARE warps: C = Co = 256
+ * and 128, dg = 4); anything else returns GLARE_ERR_UNSUPPORTED.
+ *
+ * glare_mdcn_forward_nhwc is the same operator on the pipeline's native layouts: x NHWC (fp32 or
+ * bf16) with pitch/offset, offset/mask planar with explicit plane pitches and per-sample strides in
+ * elements (0 = dense; as written by glare_conv2d_bf16 in GLARE_OUT_PLANAR_F32 mode into ONE buffer), mask optionally still a logit (sigmoid fused,
+ * DCNv2Pack.forward deformableDecoder_arch.py:148), weights pre-packed once by
+ * glare_mdcn_pack_weight_f32 ([Co][C][kh][kw] -> [dg][kh*kw][C/dg][Co]); out NHWC fp32 or planar. */
+size_t glare_mdcn_workspace_bytes(int B, int C, int H, int W, int Co, int kh, int kw);
+int glare_mdcn_forward_f32(const float* x, const float* offset, const float* mask, const float* weight,
+                           const float* bias_or_null, float* out, int B, int C, int H, int W, int Co, int kh, int kw,
+                           int sh, int sw, int ph, int pw, int dh, int dw, int groups, int dg, void* workspace,
+                           size_t workspace_bytes, glare_stream_t stream);
+int glare_mdcn_pack_weight_f32(const float* weight_oihw, float* packed, int Co, int C, int kh, int kw, int dg,
+                               glare_stream_t stream);
+int glare_mdcn_forward_nhwc(const void* x, int x_is_bf16, int x_pitch, int x_off, const float* offset,
+                            long long offset_plane, long long offset_batch_stride, const float* mask,
+                            long long mask_plane, long long mask_batch_stride, int mask_is_logit,
+                            const float* weight_packed, const float* bias, float* out, int out_planar, int out_pitch,
+                            int out_off, long long out_plane, int B, int C, int H, int W, int Co, int kh, int kw, int sh,
+                            int sw, int ph, int pw, int dh, int dw, int groups, int dg, glare_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
