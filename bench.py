@@ -1,0 +1,191 @@
+#!/usr/bin/env python
+"""Headline benchmark: enhanced images/sec at 400x600 (BASELINE.json), synthetic data.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+One "step" = one pass of the full hot path (conditional encoder -> flow reverse -> codebook retrieval
+-> VQGAN decoder -> DCNv2 AFT decoder) over one batch of 8 synthetic 400x600 low-light images per GPU
+(BASELINE configs[1]: "LOL eval15 batch=8 bf16 inference on 1 MI355X"); inputs are resident in HBM when
+the timed region starts.  Images are independent, so N GPUs shard the batch with no data-path
+collective (weak scaling: 8 images per GPU); the only collectives are the timing barrier / max.
+Rank 0 prints ONE JSON line, including
+  roofline     -- the dominant kernel (d=512 blockwise attention) measured live with events on the
+                  launch stream, against the dense bf16 MFMA peak;
+  cpu_baseline -- the CPU oracle (a port of the reference's fp32 torch path) timed on this box's host
+                  cores on one 400x600 image.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+H_IMG, W_IMG, PAD = 400, 600, 20
+
+
+def build_inputs(batch, device, seed=1234):
+    import numpy as np
+
+    from glare_amd.harness import preprocess_batch
+    from glare_amd.synthetic import synthetic_lowlight
+
+    imgs = synthetic_lowlight(batch, H_IMG, W_IMG, seed=seed)
+    return preprocess_batch(imgs).to(device)  # [B,3,420,620] fp32, log domain
+
+
+def build_nets(device):
+    from glare_amd import modules as M
+    from glare_amd.synthetic import seeded_init_
+
+    netG = seeded_init_(M.VQLLFLOWDeformable().eval(), 0).to(device)
+    net_vq = seeded_init_(M.VQModel().eval(), 1).to(device)
+    return netG, net_vq
+
+
+def attention_roofline(device, batch, reps=5):
+    """Times the attention kernel alone at the path's shape (N = 105*155 tokens, d = 512)."""
+    from glare_amd import ops
+
+    N, C = 105 * 155, 512
+    g = torch.Generator().manual_seed(0)
+    qk = (torch.randn(batch, N, 2 * C, generator=g) * 0.3).to(torch.bfloat16).to(device)
+    npad = (N + 63) // 64 * 64
+    vt = torch.zeros(batch, C, npad, dtype=torch.bfloat16, device=device)
+    vt[:, :, :N] = torch.randn(batch, C, N, generator=g).to(torch.bfloat16).to(device)
+    out = torch.empty(batch, N, C, dtype=torch.bfloat16, device=device)
+    for _ in range(2):
+        ops.attention_d512(qk, qk[..., C:], vt, N, ldq=2 * C, ldk=2 * C, out=out)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(reps):
+        ops.attention_d512(qk, qk[..., C:], vt, N, ldq=2 * C, ldk=2 * C, out=out)
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / reps
+    flops = 4.0 * batch * N * N * C  # algorithmic: QK^T + PV, SURVEY.md section 8d
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "attn_fwd_kernel (d=512 blockwise attention)", "achieved": round(achieved, 1),
+            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "ms_per_launch": round(ms, 3), "launch_shape": {"B": batch, "N": N, "d": C}}
+
+
+def cpu_baseline():
+    """The CPU oracle on one 400x600 image (fp32, all host cores).  Test infrastructure used as the
+    reported baseline only -- never on the product path."""
+    from glare_amd.synthetic import seeded_init_, synthetic_lowlight
+    from oracle import torch_ref as O
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    og = seeded_init_(O.VQLLFLOWDeformable(per_sample_mean=True).eval(), 0)
+    ov = seeded_init_(O.VQModel().eval(), 1)
+    lr = O.preprocess(synthetic_lowlight(1, H_IMG, W_IMG)[0])
+    t0 = time.time()
+    with torch.no_grad():
+        og(ov, lr)
+    dt = time.time() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "1 image 400x600 (420x620 padded), fp32 torch CPU oracle, one untimed-warmup-free run of %.1f s" % dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="per-stage timing on stderr")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (the HIP kernels are the only implementation)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)  # RCCL on ROCm
+
+    netG, net_vq = build_nets(device)
+    lr = build_inputs(args.batch, device, seed=1234 + rank)  # every rank enhances different images
+
+    def step():
+        return netG.reverse_flow_nhwc(net_vq, lr)["out"]
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    assert bool(torch.isfinite(out).all())
+    if dist is not None:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if args.breakdown and rank == 0:
+        stage_breakdown(netG, net_vq, lr)
+
+    if rank == 0:
+        total_images = args.batch * world * args.steps
+        res = {
+            "metric": "enhanced images/sec (400x600)", "value": round(total_images / dt, 3), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "LOL eval15-shaped 400x600 inference, batch=8 per GPU, full encoder->flow->VQ->decoder->AFT "
+                                   "(BASELINE configs[1])", "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                       "input": "3x400x600 (reflect-padded to 420x620)", "parallelism": "dp%d" % world,
+                       "weights": "random, name-seeded (no checkpoints offline)"},
+            "roofline": attention_roofline(device, args.batch),
+        }
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def stage_breakdown(netG, net_vq, lr):
+    def timed(fn):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        s.record()
+        r = fn()
+        e.record()
+        torch.cuda.synchronize()
+        return r, s.elapsed_time(e)
+
+    with torch.no_grad():
+        enc, ta = timed(lambda: netG.RRDB.forward_nhwc(lr))
+        lat, tb = timed(lambda: netG.flowUpsamplerNet.decode_nhwc(enc["color_map"], enc["cond_feat"]))
+        (idx, _, feats), tcd = timed(lambda: net_vq.decode_nhwc(lat, want_image=False))
+        _, te = timed(lambda: netG.deformable_decoder.forward_nhwc(lat, feats, enc["mid_feat"]))
+    print("[breakdown ms] A encoder %.1f | B flow %.1f | C+D vq+decoder %.1f | E aft %.1f" % (ta, tb, tcd, te), file=sys.stderr)
+
+
+if __name__ == "__main__":
+    main()
