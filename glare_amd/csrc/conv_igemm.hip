@@ -44,6 +44,7 @@ struct ConvParams {
   int upsample, act, out_mode;
   long long plane_pitch;
   int tiles_x, tiles_y, co_tiles, n_blocks, n_stages;
+  int fast_epilogue;
 };
 
 template <int KS, int STRIDE>
@@ -221,6 +222,69 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
     }
   }
 
+  // ---- fast epilogue (bf16 NHWC output, 16-B aligned records): the accumulators go through LDS so
+  // that the residual read and the output write are 16 B per lane, 128 contiguous bytes per pixel
+  // (the direct C/D layout would store 2 B per lane).  Each wave stages its own 64-row slab (wave-
+  // private region: no workgroup barrier inside), two slabs of MT/2 tile rows per wave.
+  //   phase 1: acc + bias (+act when there is no residual) -> bf16; neighbouring lanes (co n, n+1) swap one
+  //            value so every lane writes one packed 4-B word: even lanes row m(2t), odd lanes row m(2t+1)
+  //   phase 2: 16-B LDS reads, + residual (16-B global load, fp32 add), act, 16-B global store
+  if (p.out_mode == GLARE_OUT_NHWC_BF16 && p.fast_epilogue) {
+    constexpr int HROWS = (MT >= 2 ? MT / 2 : 1) * 32;  // slab rows
+    constexpr int HT = MT >= 2 ? MT / 2 : 1;             // tile rows per slab
+    constexpr int ROWB = NT * 64 + 16;                   // slab row pitch in bytes (pad: bank spread)
+    constexpr int CPR = NT * 4;                          // 16-B chunks per slab row
+    static_assert(4 * HROWS * ROWB <= (2 * A_SLOTS + 2 * B_CHUNKS) * 16, "epilogue slab fits the pipeline LDS");
+    __syncthreads();  // every wave is done reading the pipeline buffers
+    char* slab = smem + wave * (HROWS * ROWB);
+    const int ncol = lane & 31, rhalf = lane >> 5, odd = lane & 1;
+    const bool act_early = p.res == nullptr;
+    static_for<MT / HT>([&](auto hc) {
+      constexpr int half = decltype(hc)::value;
+      static_for<NT>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const int co = ct * TN + (wn * NT + j) * 32 + ncol;
+        const float bv = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+        static_for<HT>([&](auto ic) {
+          constexpr int il = decltype(ic)::value;
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            constexpr int i = half * HT + il;
+            float a = acc[i][j][2 * t] + bv, c = acc[i][j][2 * t + 1] + bv;
+            if (act_early) { a = apply_act(a, p.act); c = apply_act(c, p.act); }
+            const float send = odd ? a : c;
+            const float recv = __shfl_xor(send, 1, 64);
+            const int r = 2 * t + odd;                                  // the register (row) this lane writes
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * rhalf;            // pixel x within the tile row
+            const uint32_t w = odd ? pack_bf2(recv, c) : pack_bf2(a, recv);
+            *reinterpret_cast<uint32_t*>(slab + (il * 32 + m) * ROWB + (j * 32 + (ncol & ~1)) * 2) = w;
+          }
+        });
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < HROWS * CPR / 64; ++it) {
+        const int idx = lane + 64 * it;
+        const int row = idx / CPR, ch = idx % CPR;
+        const int oy = oy0 + wm * MT + half * HT + row / 32, ox = ox0 + (row & 31);
+        const int co = ct * TN + wn * NT * 32 + ch * 8;
+        if (oy < p.OH && ox < p.OW && co < p.Cout) {
+          u32x4 v = *reinterpret_cast<const u32x4*>(slab + row * ROWB + ch * 16);
+          const size_t pix = ((size_t)b * p.OH + oy) * p.OW + ox;
+          if (p.res) {
+            const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + pix * p.rpitch + p.roff + co);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              v[e] = pack_bf2(apply_act(bflo(v[e]) + bflo(rv[e]), p.act), apply_act(bfhi(v[e]) + bfhi(rv[e]), p.act));
+          }
+          *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.out) + pix * p.opitch + p.ooff + co) = v;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    });
+    return;
+  }
+
   // ---- epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int ncol = lane & 31, rhalf = lane >> 5;
   // static_for: the accumulator indices must be compile-time constants (a runtime-indexed
@@ -386,6 +450,9 @@ extern "C" int glare_conv2d_bf16(const glare_conv_desc* d, glare_stream_t stream
   const long long nb = (long long)p.B * p.tiles_x * p.tiles_y * p.co_tiles;
   if (nb > 0x7fffffffLL) return GLARE_ERR_INVALID;
   p.n_blocks = (int)nb;
+  // 16-B records everywhere -> LDS-staged epilogue
+  p.fast_epilogue = (d->out_mode == GLARE_OUT_NHWC_BF16) && !(p.Cout % 8) && !(p.opitch % 8) && !(p.ooff % 8) &&
+                    (!p.res || (!(p.rpitch % 8) && !(p.roff % 8)));
   hipStream_t stream = (hipStream_t)stream_;
 
 #define GLARE_CONV_DISPATCH(KS_, ST_)                                                     \

@@ -33,15 +33,23 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16_t* __re
   for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
   if (pl < ppi) {
     const bf16_t* base = x + (size_t)b * HW * pitch + off + chunk * 8;
-    for (long long p = p0 + pl; p < p1; p += ppi) {
-      const u32x4 v = *reinterpret_cast<const u32x4*>(base + (size_t)p * pitch);
+    auto accum = [&](const u32x4& v) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float lo = bflo(v[e]), hi = bfhi(v[e]);
         s[2 * e] += lo; q[2 * e] += lo * lo;
         s[2 * e + 1] += hi; q[2 * e + 1] += hi * hi;
       }
+    };
+    long long p = p0 + pl;
+    for (; p + 3LL * ppi < p1; p += 4LL * ppi) {  // 4 independent 16-B loads in flight per lane
+      const u32x4 v0 = *reinterpret_cast<const u32x4*>(base + (size_t)p * pitch);
+      const u32x4 v1 = *reinterpret_cast<const u32x4*>(base + (size_t)(p + ppi) * pitch);
+      const u32x4 v2 = *reinterpret_cast<const u32x4*>(base + (size_t)(p + 2LL * ppi) * pitch);
+      const u32x4 v3 = *reinterpret_cast<const u32x4*>(base + (size_t)(p + 3LL * ppi) * pitch);
+      accum(v0); accum(v1); accum(v2); accum(v3);
     }
+    for (; p < p1; p += ppi) accum(*reinterpret_cast<const u32x4*>(base + (size_t)p * pitch));
     const int cpg = C / GN_GROUPS;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -106,7 +114,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __re
 }
 
 int gn_splits(long long HW) {
-  long long s = HW / 2048;
+  long long s = HW / 128;  // >= 128 pixels per block, at most 64 partials per image for the apply prologue
   return (int)(s < 1 ? 1 : (s > 64 ? 64 : s));
 }
 

@@ -1,0 +1,93 @@
+#!/usr/bin/env python
+"""Micro-benchmarks of the individual HIP kernels at the shapes of the 400x600, B=8 path.
+    python tools/kbench.py [attn] [conv] [gn] [dcn] [vq]   (default: all)
+Prints one line per case: time per launch and achieved TFLOP/s or GB/s (algorithmic work)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from glare_amd import ops  # noqa: E402
+
+DEV = "cuda"
+B = int(os.environ.get("KB_BATCH", "8"))
+REPS = int(os.environ.get("KB_REPS", "5"))
+
+
+def timeit(fn, reps=REPS, warm=2):
+    for _ in range(warm):
+        fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps
+
+
+def bench_attn():
+    N, C = 105 * 155, 512
+    qk = (torch.randn(B, N, 2 * C, device=DEV) * 0.3).to(torch.bfloat16)
+    npad = (N + 63) // 64 * 64
+    vt = torch.zeros(B, C, npad, dtype=torch.bfloat16, device=DEV)
+    vt[:, :, :N] = torch.randn(B, C, N, device=DEV).to(torch.bfloat16)
+    out = torch.empty(B, N, C, dtype=torch.bfloat16, device=DEV)
+    ms = timeit(lambda: ops.attention_d512(qk, qk[..., C:], vt, N, ldq=2 * C, ldk=2 * C, out=out))
+    print("attn  B=%d N=%d d=512: %.3f ms  %.0f TFLOP/s" % (B, N, ms, 4.0 * B * N * N * C / ms / 1e9))
+
+
+def bench_conv():
+    cases = [("512->512 3x3 @q", 512, 512, 105, 155, 3), ("256->256 3x3 @half", 256, 256, 210, 310, 3),
+             ("128->128 3x3 @full", 128, 128, 420, 620, 3), ("512->512 3x3 @half", 512, 512, 210, 310, 3),
+             ("256->256 3x3 @full", 256, 256, 420, 620, 3), ("512->1024 1x1 @q", 512, 1024, 105, 155, 1),
+             ("512->512 1x1 @q", 512, 512, 105, 155, 1), ("64->1536 3x3 @q", 64, 1536, 105, 155, 3)]
+    for name, ci, co, h, w, k in cases:
+        x = torch.randn(B, h, w, ci, device=DEV).to(torch.bfloat16)
+        wt = torch.randn(co, ci, k, k, device=DEV) * 0.02
+        pc = ops.PackedConv(wt, torch.zeros(co, device=DEV))
+        out = torch.empty(B, h, w, co, dtype=torch.bfloat16, device=DEV)
+        ms = timeit(lambda: ops.conv2d(x, pc, out=out))
+        fl = 2.0 * B * h * w * ci * co * k * k
+        print("conv  %-22s: %.3f ms  %.0f TFLOP/s" % (name, ms, fl / ms / 1e9))
+        res = torch.randn(B, h, w, co, device=DEV).to(torch.bfloat16)
+        ms = timeit(lambda: ops.conv2d(x, pc, out=out, residual=res))
+        print("conv  %-22s: %.3f ms  %.0f TFLOP/s  (+residual)" % (name, ms, fl / ms / 1e9))
+
+
+def bench_gn():
+    for c, h, w in ((128, 420, 620), (256, 210, 310), (512, 105, 155)):
+        x = torch.randn(B, h, w, c, device=DEV).to(torch.bfloat16)
+        g = torch.ones(c, device=DEV)
+        b = torch.zeros(c, device=DEV)
+        ms = timeit(lambda: ops.groupnorm(x, g, b, swish=True))
+        gb = 3.0 * x.numel() * 2 / 1e9
+        print("gn    C=%d %dx%d: %.3f ms  %.0f GB/s (algorithmic 2 reads + 1 write)" % (c, h, w, ms, gb / ms * 1e3))
+
+
+def bench_dcn():
+    for c, h, w in ((128, 420, 620), (256, 210, 310)):
+        x = torch.randn(B, h, w, c, device=DEV).to(torch.bfloat16)
+        plane = (h * w + 63) // 64 * 64
+        om = torch.randn(B, 108, plane, device=DEV)
+        wt = torch.randn(c, c, 3, 3, device=DEV) * 0.02
+        pd = ops.PackedDcn(wt, torch.zeros(c, device=DEV), 4)
+        ms = timeit(lambda: ops.mdcn_forward_nhwc(x, om, pd))
+        fl = 2.0 * B * h * w * c * c * 9 + 72.0 * B * h * w * c
+        print("dcn   C=%d %dx%d: %.3f ms  %.1f TFLOP/s (fp32)" % (c, h, w, ms, fl / ms / 1e9))
+
+
+def bench_vq():
+    n = B * 105 * 155
+    z = torch.randn(n, 3, device=DEV)
+    cb = torch.randn(8192, 3, device=DEV) * 0.7
+    ms = timeit(lambda: ops.vq_nearest(z, cb))
+    print("vq    %d tokens x 8192 codes: %.3f ms  %.2f Gtoken-code/s" % (n, ms, n * 8192 / ms / 1e6))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["attn", "conv", "gn", "dcn", "vq"]
+    for w in which:
+        globals()["bench_" + w]()
