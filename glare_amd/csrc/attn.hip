@@ -24,6 +24,8 @@
 //     max grows by more than 2^8), textbook order: decide -> rescale -> exponentiate -> P.V.
 //   * workgroups are numbered so that one XCD works on one image: its 32 CUs stream the same
 //     K/V through one L2.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -34,10 +36,21 @@ constexpr int BM = 128;          // query rows per workgroup
 constexpr int BN = 32;           // keys per tile
 constexpr int KCH = BN * (HD / 8);   // 16-B chunks per K tile  (2048)
 constexpr float RESCALE_THR = 8.0f;  // log2 units
+#ifndef ATTN_DMA_PER_GROUP
+#define ATTN_DMA_PER_GROUP 2  // DMA pieces issued per 4-MFMA group (2: all 16 during QK^T; 1: over the whole tile)
+#endif
 
 __device__ __forceinline__ void dma16a(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
 }
 
 struct AttnParams {
@@ -91,56 +104,94 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
   const bf16_t* kbase = p.k + (size_t)b * p.N * p.ldk;
   const bf16_t* vbase = p.vt + (size_t)b * HD * p.Npad;
 
-  // per-lane DMA source offsets (elements), tile-independent; the tile only moves a uniform base
+  // DMA source addressing: a wave-uniform 64-bit base (SGPRs: image, tile, row) plus ONE 32-bit per-lane
+  // offset.  Per-piece 64-bit pointers kept in VGPRs get spilled around the tile loop, and every
+  // scratch reload drags a vmcnt(0) that drains the DMAs in flight (measured 2x slowdown).
   //   K:   one instruction per key row (1 KB); chunk c of row r lands at r*64 + (c ^ (r & 15))
-  //   V^T: one instruction per 16 d-rows (64 B each); chunk c of row d lands at d*4 + (c ^ ((d>>2)&3))
-  int koff[BN / 4], voff[(HD / 16) / 4];
-#pragma unroll
-  for (int i = 0; i < BN / 4; ++i) {
-    const int r = wave + 4 * i;
-    koff[i] = (lane ^ (r & 15)) * 8;
-  }
-#pragma unroll
-  for (int i = 0; i < (HD / 16) / 4; ++i) {
-    const int d = (wave + 4 * i) * 16 + (lane >> 2);
-    voff[i] = (int)(d * p.Npad) + (((lane & 3) ^ ((d >> 2) & 3)) * 8);
-  }
-  auto issue = [&](int tile, int buf) {
-#pragma unroll
-    for (int i = 0; i < BN / 4; ++i) {
+  //   V^T: one instruction per 16 d-rows (64 B each); chunk c of row d lands at d*4 + (c ^ ((d>>2)&3));
+  //        d = 16*t + (lane>>2)  =>  (d>>2)&3 == (lane>>4)&3 for every t
+  const unsigned v_lane_off = (unsigned)((lane >> 2) * p.Npad + (((lane & 3) ^ ((lane >> 4) & 3)) * 8)) * 2u;  // bytes
+  auto issue_piece = [&](auto ic, int tile, int buf) {
+    constexpr int i = decltype(ic)::value;
+    if constexpr (i < BN / 4) {
       const int r = wave + 4 * i;
       // rows beyond N re-read row N-1 (valid memory); their scores are masked to -inf below
       const int kv = min(tile * BN + r, p.N - 1);
-      dma16a(kbase + (size_t)kv * p.ldk + koff[i], lK + buf * KCH + r * 64);
+      const char* row = reinterpret_cast<const char*>(kbase + (size_t)kv * p.ldk);            // uniform
+      const unsigned off = (unsigned)((lane ^ (r & 15)) * 16);                                 // per lane
+      dma16a(row + off, lK + buf * KCH + r * 64);
+    } else {
+      constexpr int j = i - BN / 4;
+      const char* grp = reinterpret_cast<const char*>(vbase + (size_t)(wave + 4 * j) * 16 * p.Npad + (size_t)tile * BN);
+      dma16a(grp + v_lane_off, lV + buf * KCH + (wave + 4 * j) * 64);
     }
-    const bf16_t* vt = vbase + (size_t)tile * BN;
-#pragma unroll
-    for (int i = 0; i < (HD / 16) / 4; ++i) dma16a(vt + voff[i], lV + buf * KCH + (wave + 4 * i) * 64);
   };
+  auto issue = [&](int tile, int buf) { static_for<16>([&](auto ic) { issue_piece(ic, tile, buf); }); };
 
   // K row fetched for MFMA row slot i: bits 2 and 3 swapped, so that output register r of lane
   // (q, hi) is key 16*(r>>3) + 8*hi + (r&7) -- exactly the P^T B-fragment order.
   const int krow = (ql & 0x13) | ((ql & 4) << 1) | ((ql & 8) >> 1);
   const int kswz = krow & 15;
 
-  issue(0, 0);
-  for (int tile = 0; tile < n_tiles; ++tile) {
+  // per-lane LDS byte addresses of the fragment reads; everything else is an instruction immediate:
+  //   K frag (ks)     : kofs[ks & 7] + (ks >> 3) * 256 + buf * 32 KB            (kofs holds the XOR swizzle)
+  //   V^T frag (dt,ks): vofs[ks] + dt * 2048 + buf * 32 KB                      (vofs includes the 64 KB V base)
+  int kofs[8], vofs[2];
+#pragma unroll
+  for (int bb = 0; bb < 8; ++bb) kofs[bb] = (krow * 64 + ((2 * bb + hi) ^ kswz)) * 16;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) vofs[ks] = 2 * KCH * 16 + (ql * 4 + ((2 * ks + hi) ^ ((ql >> 2) & 3))) * 16;
+
+  // One key tile.  BUF is a compile-time constant so that the buffer offset folds into the ds_read
+  // immediate.  Fragment reads run two groups (8 x ds_read_b128) ahead of the MFMAs that consume them
+  // through a 3-deep rotating register set; the first V^T groups are fetched before the softmax.
+  auto tile_body = [&](auto bufc, int tile) {
+    constexpr int BUF = decltype(bufc)::value;
+#ifndef ATTN_ABLATE_NOBARRIER
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tile + 1 < n_tiles) issue(tile + 1, (tile + 1) & 1);
-    const u32x4* cK = lK + (tile & 1) * KCH + krow * 64;
-    const u32x4* cV = lV + (tile & 1) * KCH;
+#endif
+    // The next tile's 16 DMA pieces are NOT issued here in one burst (all four waves would queue on the
+    // texture-address path with the matrix pipe idle: measured -27 %); they are spread, ATTN_DMA_PER_GROUP per
+    // MFMA group, so the address path works under the MFMAs.
+    const int nxt = min(tile + 1, n_tiles - 1);  // last tile: a redundant reload keeps the loop branch-free
+    const char* kb = smem + BUF * KCH * 16;
+    const char* vb = smem + BUF * KCH * 16;
+    bf16x8 fr[3][4];
+    auto ldk = [&](auto gc, bf16x8(&f)[4]) {
+      constexpr int g = decltype(gc)::value;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int ks = 4 * g + e;
+        f[e] = *reinterpret_cast<const bf16x8*>(kb + kofs[ks & 7] + (ks >> 3) * 256);
+      }
+    };
+    auto ldv = [&](auto gc, bf16x8(&f)[4]) {
+      constexpr int g = decltype(gc)::value;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) f[e] = *reinterpret_cast<const bf16x8*>(vb + vofs[e & 1] + (2 * g + (e >> 1)) * 2048);
+    };
 
     // ---- S^T = K . Q^T  (32 keys x 32 queries, contraction over d = 512)
     f32x16 s;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    ldk(std::integral_constant<int, 0>{}, fr[0]);
+    ldk(std::integral_constant<int, 1>{}, fr[1]);
+    static_for<8>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      if constexpr (g + 2 < 8) ldk(std::integral_constant<int, g + 2>{}, fr[(g + 2) % 3]);
+      else ldv(std::integral_constant<int, g + 2 - 8>{}, fr[(g + 2) % 3]);
+#ifndef ATTN_ABLATE_NODMA
+      static_for<ATTN_DMA_PER_GROUP>([&](auto kc) {
+        constexpr int piece = g * ATTN_DMA_PER_GROUP + decltype(kc)::value;
+        if constexpr (piece < 16) issue_piece(std::integral_constant<int, piece>{}, nxt, BUF ^ 1);
+      });
+#endif
 #pragma unroll
-    for (int ks = 0; ks < HD / 16; ++ks) {
-      const bf16x8 a = __builtin_bit_cast(bf16x8, cK[(2 * ks + hi) ^ kswz]);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s, 0, 0, 0);
-      if ((ks & 7) == 7) __builtin_amdgcn_sched_barrier(0);  // bound the fragment reads in flight
-    }
+      for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g % 3][e], qf[4 * g + e], s, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
     if (tile == n_tiles - 1) {  // mask keys beyond N
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -152,7 +203,10 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
     float mx = s[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    {  // the other 16 keys of this query live in lane ^ 32: v_permlane32_swap, no LDS round trip
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = fmaxf(mx, __uint_as_float(hi ? sw[0] : sw[1]));
+    }
     if (__any(mx > m_run + RESCALE_THR)) {  // wave-uniform: rescale everything still at the old max
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -178,25 +232,40 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
       u32x4 w;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
+#ifdef ATTN_ABLATE_NOEXP  // timing ablation only (tools/): wrong results
+        const float p0 = s[8 * h + 2 * e], p1 = s[8 * h + 2 * e + 1];
+#else
         const float p0 = __builtin_amdgcn_exp2f(s[8 * h + 2 * e] - m_run);
         const float p1 = __builtin_amdgcn_exp2f(s[8 * h + 2 * e + 1] - m_run);
+#endif
         psum += p0 + p1;
         w[e] = pack_bf2(p0, p1);
       }
       pf[h] = __builtin_bit_cast(bf16x8, w);
     }
     l_run += psum;
-    // ---- O^T += V^T . P^T  (512 d x 32 queries, contraction over the 32 keys)
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- O^T += V^T . P^T  (512 d x 32 queries, contraction over the 32 keys); group g = d-tiles 2g, 2g+1
+    static_for<8>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      if constexpr (g + 2 < 8) ldv(std::integral_constant<int, g + 2>{}, fr[(8 + g + 2) % 3]);
+#ifndef ATTN_ABLATE_NODMA
+      static_for<ATTN_DMA_PER_GROUP>([&](auto kc) {
+        constexpr int piece = (8 + g) * ATTN_DMA_PER_GROUP + decltype(kc)::value;
+        if constexpr (piece < 16) issue_piece(std::integral_constant<int, piece>{}, nxt, BUF ^ 1);
+      });
+#endif
 #pragma unroll
-    for (int dt = 0; dt < HD / 32; ++dt) {
-      const int d = dt * 32 + ql;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8 a = __builtin_bit_cast(bf16x8, cV[d * 4 + ((2 * ks + hi) ^ ((d >> 2) & 3))]);
-        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf[ks], o[dt], 0, 0, 0);
-      }
-      if ((dt & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-    }
+      for (int e = 0; e < 4; ++e)
+        o[2 * g + (e >> 1)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[(8 + g) % 3][e], pf[e & 1], o[2 * g + (e >> 1)], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  issue(0, 0);
+  for (int tile = 0; tile < n_tiles; tile += 2) {
+    tile_body(std::integral_constant<int, 0>{}, tile);
+    if (tile + 1 < n_tiles) tile_body(std::integral_constant<int, 1>{}, tile + 1);
   }
 
   // ---- normalise and store O[q][d] (bf16): a lane owns ONE query row, 4 consecutive d per store

@@ -14,7 +14,7 @@ OUT = os.path.join(os.path.dirname(HERE), "libglare_hip.so")
 OBJ = os.path.join(HERE, "build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-          "-fno-gpu-rdc"]
+          "-fno-gpu-rdc"] + os.environ.get("GLARE_DEFS", "").split()  # GLARE_DEFS: ablation switches (tools/)
 # vq.hip carries the bit-exactness contract: no fused contraction the source does not spell.
 PER_FILE = {"vq.hip": ["-ffp-contract=off"]}
 
