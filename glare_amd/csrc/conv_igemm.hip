@@ -14,7 +14,7 @@
 // ([kstep][khalf][position][8 ch]) so that a wave's ds_read_b128 fragment read is a dense,
 // bank-conflict-free 512-B run per half-wave.  Both images are double-buffered and filled by
 // LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass) one stage ahead of the
-// MFMAs; 2-3 workgroups per CU cover the barrier skew.
+// MFMAs; 3 workgroups per CU (168 VGPRs, 47 KB LDS each) cover the DMA issue stalls and the barrier skew.
 // The zero padding, the nearest x2 upsample (Upsample, encoder_decoder.py:50) and the
 // asymmetric stride-2 padding (Downsample, encoder_decoder.py:71-73) are address arithmetic
 // in the loader; bias, residual add, activation and layout conversion are the epilogue.
@@ -90,7 +90,7 @@ __device__ __forceinline__ void dma16(const void* gsrc, void* lds_wave_base) {
 // double-buffered in LDS and filled by LDS-DMA (global_load_lds_dwordx4), issued one B stage
 // ahead, right after the barrier that retires the buffer they overwrite; one barrier per B stage.
 template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int KSTEPS>
-__global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParams p) {
+__global__ __launch_bounds__(NTHREADS, (STRIDE == 1 ? 3 : 2)) void conv_igemm_kernel(const ConvParams p) {
   using G = TileGeom<KS, STRIDE>;
   static_assert(WM * MT == TH && WM * WN == 4, "wave layout");
   constexpr int TN = WN * NT * 32;
@@ -173,12 +173,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
       }
     }
   };
+  // Weight stages go through a buffer descriptor: `buffer_load_dwordx4 ... offen lds` takes ONE per-lane
+  // 32-bit offset (lane*16, loop-invariant) plus a scalar offset -- no per-instruction 64-bit VALU address.
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(wbase), 0, (int)((size_t)p.n_stages * KS * B_CHUNKS * 16), 0x00020000);
+  const int lane16 = lane * 16;
   auto issue_b = [&](int bstage, int buf) {
-    const u32x4* wsrc = reinterpret_cast<const u32x4*>(wbase) + (size_t)bstage * B_CHUNKS;
 #pragma unroll
     for (int i = 0; i < B_PER_W; ++i) {
       const int j = wave + 4 * i;
-      if (j < B_INSTR) dma16(wsrc + j * 64 + lane, lB + buf * B_CHUNKS + j * 64);
+      if (j < B_INSTR)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(lB + buf * B_CHUNKS + j * 64),
+                                                 16, lane16, (bstage * B_CHUNKS + j * 64) * 16, 0, 0);
     }
   };
 
@@ -191,10 +197,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
     const u32x4* cA = lA + (chunk & 1) * A_SLOTS;
 #pragma unroll
     for (int trow = 0; trow < KS; ++trow, ++bs) {
+#ifndef CONV_ABLATE_NOBARRIER  // timing ablations only (tools/ablate.sh): wrong results
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
       __syncthreads();                                   // ... and everybody else's; stage bs-1 retired
+#endif
+#ifndef CONV_ABLATE_NODMA
+#ifndef CONV_ABLATE_NODMA_B
       if (bs + 1 < n_bstages) issue_b(bs + 1, (bs + 1) & 1);
+#endif
+#ifndef CONV_ABLATE_NODMA_A
       if (trow == 0 && chunk + 1 < p.n_stages) issue_a(chunk + 1, (chunk + 1) & 1);
+#endif
+#endif
       const u32x4* cB = lB + (bs & 1) * B_CHUNKS;
 #pragma unroll
       for (int tcol = 0; tcol < KS; ++tcol) {

@@ -40,11 +40,14 @@ def bench_attn():
 
 
 def bench_conv():
+    only = os.environ.get("KB_CONV")
     cases = [("512->512 3x3 @q", 512, 512, 105, 155, 3), ("256->256 3x3 @half", 256, 256, 210, 310, 3),
              ("128->128 3x3 @full", 128, 128, 420, 620, 3), ("512->512 3x3 @half", 512, 512, 210, 310, 3),
              ("256->256 3x3 @full", 256, 256, 420, 620, 3), ("512->1024 1x1 @q", 512, 1024, 105, 155, 1),
              ("512->512 1x1 @q", 512, 512, 105, 155, 1), ("64->1536 3x3 @q", 64, 1536, 105, 155, 3)]
     for name, ci, co, h, w, k in cases:
+        if only and only not in name:
+            continue
         x = torch.randn(B, h, w, ci, device=DEV).to(torch.bfloat16)
         wt = torch.randn(co, ci, k, k, device=DEV) * 0.02
         pc = ops.PackedConv(wt, torch.zeros(co, device=DEV))
