@@ -83,7 +83,9 @@ def cpu_baseline():
     from glare_amd.synthetic import seeded_init_, synthetic_lowlight
     from oracle import torch_ref as O
 
-    cores = os.cpu_count() or 1
+    # torch's intra-op pool stops scaling (and then collapses) beyond a few dozen threads on this
+    # graph: 256 threads on a 2-socket EPYC took 433 s for one image.  Use at most 32, and say so.
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     og = seeded_init_(O.VQLLFLOWDeformable(per_sample_mean=True).eval(), 0)
     ov = seeded_init_(O.VQModel().eval(), 1)
@@ -93,7 +95,8 @@ def cpu_baseline():
         og(ov, lr)
     dt = time.time() - t0
     return {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "1 image 400x600 (420x620 padded), fp32 torch CPU oracle, one untimed-warmup-free run of %.1f s" % dt}
+            "sample": "1 image 400x600 (420x620 padded), fp32 torch CPU oracle on %d threads of %d host cores, one run of %.1f s"
+                      % (cores, os.cpu_count() or 1, dt)}
 
 
 def main():
