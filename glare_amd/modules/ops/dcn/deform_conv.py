@@ -55,8 +55,28 @@ class _DeformConvExt:
               "glare_mdcn_forward_f32")
 
     @staticmethod
-    def modulated_deform_conv_backward(*args):
-        raise NotImplementedError("DCNv2 backward (SURVEY.md row a10) is not built on HIP yet; see DESIGN.md")
+    def modulated_deform_conv_backward(input, weight, bias, ones, offset, mask, columns, grad_input, grad_weight,
+                                       grad_bias, grad_offset, grad_mask, grad_output, kernel_h, kernel_w, stride_h,
+                                       stride_w, pad_h, pad_w, dilation_h, dilation_w, group, deformable_group, with_bias):
+        if not input.is_cuda:
+            raise RuntimeError("modulated deform conv is not implemented on CPU")
+        if not (input.is_contiguous() and weight.is_contiguous()):
+            raise RuntimeError("input and weight tensors have to be contiguous")
+        B, C, H, W = input.shape
+        Co, Ck, kh, kw = weight.shape
+        if (kh, kw) != (kernel_h, kernel_w) or C != Ck * group:
+            raise RuntimeError("Input shape and kernel shape won't match")
+        lib = _lib.lib()
+        lib.glare_mdcn_backward_workspace_bytes.restype = _sz
+        nws = lib.glare_mdcn_backward_workspace_bytes(_i(B), _i(C), _i(H), _i(W), _i(Co), _i(kh), _i(kw))
+        ws = torch.empty(int(nws), dtype=torch.uint8, device=input.device)
+        offset, mask, grad_output = offset.contiguous(), mask.contiguous(), grad_output.contiguous()
+        check(lib.glare_mdcn_backward_f32(ptr(input), ptr(offset), ptr(mask), ptr(weight), ptr(grad_output), ptr(grad_input),
+                                          ptr(grad_offset), ptr(grad_mask), ptr(grad_weight),
+                                          ptr(grad_bias if with_bias else None), _i(B), _i(C), _i(H), _i(W), _i(Co), _i(kh),
+                                          _i(kw), _i(stride_h), _i(stride_w), _i(pad_h), _i(pad_w), _i(dilation_h),
+                                          _i(dilation_w), _i(group), _i(deformable_group), ptr(ws), _sz(ws.numel()),
+                                          stream_handle()), "glare_mdcn_backward_f32")
 
     @staticmethod
     def deform_conv_forward(*args):

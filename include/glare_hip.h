@@ -195,6 +195,25 @@ int glare_mdcn_forward_nhwc(const void* x, int x_is_bf16, int x_pitch, int x_off
                             int out_off, long long out_plane, int B, int C, int H, int W, int Co, int kh, int kw, int sh,
                             int sw, int ph, int pw, int dh, int dw, int groups, int dg, glare_stream_t stream);
 
+/* ---- a10: modulated deformable convolution (DCNv2), backward ----------------------------------
+ * Drop-in for the pybind function
+ *   deform_conv_ext.modulated_deform_conv_backward(input, weight, bias, ones, offset, mask, columns,
+ *       grad_input, grad_weight, grad_bias, grad_offset, grad_mask, grad_output, kernel_h, kernel_w,
+ *       stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, group, deformable_group, with_bias)
+ *   (deform_conv_ext.cpp:127-147,161-163), called from ModulatedDeformConvFunction.backward
+ * (deform_conv.py:166-171): reference layouts (NCHW fp32), all gradient buffers caller-allocated and
+ * caller-ZEROED (deform_conv.py:161-165); grad_weight / grad_bias are accumulated into, grad_input /
+ * grad_offset / grad_mask are overwritten.  grad_input may be NULL (skipped: the GLARE warp input needs
+ * no gradient, VQLLFLOWDeformable_arch.py:240-248); grad_bias_or_null NULL = with_bias False.
+ * grad_input is summed with fp32 atomics (order-nondeterministic), like the reference (kernel.cu:688).
+ * Same shape support as the forward, plus Co % 128 == 0. */
+size_t glare_mdcn_backward_workspace_bytes(int B, int C, int H, int W, int Co, int kh, int kw);
+int glare_mdcn_backward_f32(const float* x, const float* offset, const float* mask, const float* weight,
+                            const float* grad_out, float* grad_input, float* grad_offset, float* grad_mask,
+                            float* grad_weight, float* grad_bias_or_null, int B, int C, int H, int W, int Co, int kh,
+                            int kw, int sh, int sw, int ph, int pw, int dh, int dw, int groups, int dg, void* workspace,
+                            size_t workspace_bytes, glare_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

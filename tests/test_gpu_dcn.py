@@ -81,3 +81,62 @@ def test_errors():
         ops.mdcn_forward(x.cuda(), off.cuda(), m.cuda(), w.cuda(), b.cuda(), 1, 1, 1, 1, 4)
     with pytest.raises(NotImplementedError):
         ops.mdcn_forward(x, off, m, w, b, 1, 1, 1, 1, 4)  # CPU tensors: no fallback
+
+
+# ---- backward (row a10) ---------------------------------------------------------------------------
+def _bwd_case(B, C, H, W, Co, dg, seed, off_scale=1.5):
+    x, off, m, w, b = _case(seed, B, C, H, W, Co, dg, off_scale)
+    go = torch.randn(B, Co, H, W, generator=torch.Generator().manual_seed(seed + 1))
+    return x, off, m, w, b, go
+
+
+def _close_grad(got, ref, name):
+    ref = np.asarray(ref)
+    tol = 2e-4 * float(np.abs(ref).max()) + 1e-6
+    np.testing.assert_allclose(got, ref, rtol=2e-4, atol=tol, err_msg=name)
+
+
+@pytest.mark.parametrize("B,C,H,W,Co,dg", [(1, 128, 9, 13, 128, 4), (2, 256, 6, 11, 256, 4), (1, 128, 5, 70, 256, 4)])
+def test_backward_matches_c_oracle(B, C, H, W, Co, dg):
+    """All five gradients through the autograd Function (the reference's call path,
+    deform_conv.py:155-174) against oracle/dcn_ref.c.  fp32 both; the oracle sums in double."""
+    from glare_amd.modules.ops.dcn import modulated_deform_conv
+
+    x, off, m, w, b, go = _bwd_case(B, C, H, W, Co, dg, seed=C + Co + H)
+    ts = [t.clone().cuda().requires_grad_() for t in (x, off, m, w, b)]
+    out = modulated_deform_conv(ts[0], ts[1], ts[2], ts[3], ts[4], 1, 1, 1, 1, dg)
+    out.backward(go.cuda())
+    ref = c_ref.dcn_backward(x.numpy(), off.numpy(), m.numpy(), w.numpy(), go.numpy(), dg=dg)
+    for t, r, name in zip(ts, ref, ("grad_input", "grad_offset", "grad_mask", "grad_weight", "grad_bias")):
+        _close_grad(t.grad.cpu().numpy(), r, name)
+
+
+def test_backward_borders_no_bias_and_accumulation():
+    from glare_amd.modules.ops.dcn import deform_conv_ext
+
+    x, off, m, w, b, go = _bwd_case(1, 128, 7, 9, 128, 4, seed=11, off_scale=5.0)  # many samples leave the image
+    xc, oc, mc, wc, gc = [t.cuda().contiguous() for t in (x, off, m, w, go)]
+    gi, goff, gm = torch.zeros_like(xc), torch.zeros_like(oc), torch.zeros_like(mc)
+    gw = torch.full_like(wc, 0.5)  # grad_weight is ACCUMULATED into (deform_conv_cuda.cpp:655-660)
+    e = xc.new_empty(0)
+    deform_conv_ext.modulated_deform_conv_backward(xc, wc, xc.new_empty(1), e, oc, mc, e, gi, gw, xc.new_empty(1), goff, gm, gc,
+                                                   3, 3, 1, 1, 1, 1, 1, 1, 1, 4, False)
+    ref = c_ref.dcn_backward(x.numpy(), off.numpy(), m.numpy(), w.numpy(), go.numpy(), with_bias=False, dg=4)
+    _close_grad(gi.cpu().numpy(), ref[0], "grad_input")
+    _close_grad(goff.cpu().numpy(), ref[1], "grad_offset")
+    _close_grad(gm.cpu().numpy(), ref[2], "grad_mask")
+    _close_grad(gw.cpu().numpy() - 0.5, ref[3], "grad_weight")
+
+
+def test_backward_zero_offset_equals_conv_gradients():
+    """offset = 0, mask = 1: grad_input / grad_weight / grad_bias are those of conv2d."""
+    from glare_amd.modules.ops.dcn import modulated_deform_conv
+
+    x, off, m, w, b, go = _bwd_case(1, 128, 8, 10, 128, 4, seed=12)
+    ts = [t.clone().cuda().requires_grad_() for t in (x, torch.zeros_like(off), torch.ones_like(m), w, b)]
+    modulated_deform_conv(ts[0], ts[1], ts[2], ts[3], ts[4], 1, 1, 1, 1, 4).backward(go.cuda())
+    xr, wr, br = [t.clone().cuda().requires_grad_() for t in (x, w, b)]
+    F.conv2d(xr, wr, br, 1, 1).backward(go.cuda())
+    assert torch.allclose(ts[0].grad, xr.grad, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(ts[3].grad, wr.grad, rtol=1e-4, atol=1e-3)
+    assert torch.allclose(ts[4].grad, br.grad, rtol=1e-4, atol=1e-4)
