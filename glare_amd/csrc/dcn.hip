@@ -10,11 +10,16 @@
 // Here x is NHWC, so the cpg channels of a deformable group at one sampling corner are ONE contiguous
 // run (64-256 B): 16-B loads, lanes along the channel axis.  A workgroup owns 64 output pixels x all
 // output channels; for each (deformable group, tap) "stage" it samples a 64 x cpg tile into LDS
-// (transposed [c][pixel], so the MFMA A-fragment read is conflict-free) and contracts it with the
-// [cpg x Co] weight slab on v_mfma_f32_32x32x2_f32 (exact fp32, the reference's arithmetic class --
-// DCNv2Pack casts everything to fp32, deformableDecoder_arch.py:143,550-551).  The gather of stage
-// s+1 is issued before the MFMAs of stage s (registers hold the corners in flight); weights come
-// straight from L2 as B-fragments (pre-transposed [stage][c][Co], 128-B coalesced per half-wave).
+// (8-channel planes [c/8][pixel][8], so the MFMA A-fragment read is conflict-free) and contracts it with
+// the [cpg x Co] weight slab.  The reference computes this in fp32 (DCNv2Pack casts everything to fp32,
+// deformableDecoder_arch.py:143,550-551); the f32-input MFMA runs at 1/16 of the bf16 rate and made the
+// kernel contraction-bound (8.9 ms per 8 images at full resolution), so the contraction uses the
+// split-bf16 form: every fp32 operand v is carried as hi = bf16(v), lo = bf16(v - hi) and
+//     a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi          (3 bf16 MFMAs, fp32 accumulate)
+// which keeps 16 mantissa bits per operand (dropped term a_lo*b_lo <= 2^-16 relative): measured max
+// error vs the fp32/double oracle ~1e-5 relative, inside the 1e-4 test tolerance, at 16/3 the speed.
+// The gather of stage s+1 is issued before the MFMAs of stage s (registers hold the corners in
+// flight); weights come straight from L2 as B-fragments (pre-split, fragment-ordered, 1 KB per load).
 //   out[p, co] = bias[co] + sum_{g,k,c} W[co, g*cpg+c, k] * mask[g,k,p] * bilinear(x[., g*cpg+c], pos(p,g,k))
 // Sampling semantics follow the reference exactly: a sample is 0 unless -1 < h < H and -1 < w < W,
 // and each of the 4 corners is dropped individually when it lies outside the image.
@@ -24,13 +29,12 @@ namespace {
 
 constexpr int DC_THREADS = 256;
 constexpr int DC_PIX = 64;          // output pixels per workgroup
-constexpr int DC_PITCH = DC_PIX + 1;  // LDS row pitch (floats) of the transposed sample tile
 
 struct DcnParams {
   const void* x;          // NHWC, fp32 or bf16
   const float* offset;    // [B][dg*2K][off_plane]
   const float* mask;      // [B][dg*K][mask_plane]
-  const float* wt;        // packed [dg*K*cpg][Co]
+  const float* wt;        // packed split-bf16 image, see dcn_pack_weight_kernel
   const float* bias;
   float* out;
   int B, C, H, W, Co, Ho, Wo;
@@ -73,7 +77,7 @@ __device__ __forceinline__ float elem(const Corner<XBF16>& c, int e) {
 template <bool XBF16, int NT, int ITEMS>
 __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_kernel(const DcnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* colT = reinterpret_cast<float*>(smem);  // [2][cpg][DC_PITCH]
+  u32x4* colH = reinterpret_cast<u32x4*>(smem);  // [2 buffers][hi|lo][cpg/8][64 pixels] 16-B chunks
   const int cpg = p.cpg;
   const int K = p.kh * p.kw;
   const int n_stages = p.dg * K;
@@ -141,34 +145,47 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_kernel(const DcnParams p) 
     }
   };
   auto gather_finish = [&](int buf) {
-    float* dst = colT + (size_t)buf * cpg * DC_PITCH;
+    u32x4* dst = colH + (size_t)buf * 2 * nch * DC_PIX;
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
+      float val[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         // reference order: (w1*v1 + w2*v2 + w3*v3 + w4*v4) * mask   (kernel.cu:493-496,625)
-        const float val = cw[i][0] * elem<XBF16>(cr[i][0], e) + cw[i][1] * elem<XBF16>(cr[i][1], e) +
-                          cw[i][2] * elem<XBF16>(cr[i][2], e) + cw[i][3] * elem<XBF16>(cr[i][3], e);
-        dst[(it_ch[i] * 8 + e) * DC_PITCH + it_px[i]] = val * cm[i];
+        val[e] = (cw[i][0] * elem<XBF16>(cr[i][0], e) + cw[i][1] * elem<XBF16>(cr[i][1], e) +
+                  cw[i][2] * elem<XBF16>(cr[i][2], e) + cw[i][3] * elem<XBF16>(cr[i][3], e)) * cm[i];
       }
+      u32x4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        hi[e] = pack_bf2(val[2 * e], val[2 * e + 1]);
+        lo[e] = pack_bf2(val[2 * e] - bflo(hi[e]), val[2 * e + 1] - bfhi(hi[e]));
+      }
+      dst[it_ch[i] * DC_PIX + it_px[i]] = hi;
+      dst[(nch + it_ch[i]) * DC_PIX + it_px[i]] = lo;
     }
   };
 
   gather_issue(0);
   gather_finish(0);
   const int arow = (lane & 31) + 32 * wm, khalf = lane >> 5;
+  const u32x4* wq = reinterpret_cast<const u32x4*>(p.wt);  // [stage][cpg/8][Co][hi 16 B | lo 16 B]
   for (int s = 0; s < n_stages; ++s) {
-    __syncthreads();                       // sample tile s visible; tile s-1 retired
+    __syncthreads();                            // sample tile s visible; tile s-1 retired
     if (s + 1 < n_stages) gather_issue(s + 1);  // corners of the next stage fly during the MFMAs
-    const float* a_src = colT + (size_t)(s & 1) * cpg * DC_PITCH + arow;
-    const float* w_src = p.wt + (size_t)s * cpg * p.Co + wn * NT * 32 + (lane & 31);
-    for (int ks = 0; ks < cpg / 2; ++ks) {
+    const u32x4* a_src = colH + (size_t)(s & 1) * 2 * nch * DC_PIX + arow;
+    for (int ks = 0; ks < cpg / 16; ++ks) {
       const int kk = 2 * ks + khalf;
-      const float a = a_src[kk * DC_PITCH];
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, a_src[kk * DC_PIX]);
+      const bf16x8 al = __builtin_bit_cast(bf16x8, a_src[(nch + kk) * DC_PIX]);
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        const float bv = w_src[(size_t)kk * p.Co + j * 32];
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[j], 0, 0, 0);
+        const u32x4* wp = wq + (((size_t)s * nch + kk) * p.Co + (wn * NT + j) * 32 + (lane & 31)) * 2;
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, wp[0]);
+        const bf16x8 bl = __builtin_bit_cast(bf16x8, wp[1]);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
       }
     }
     if (s + 1 < n_stages) gather_finish((s + 1) & 1);
@@ -197,26 +214,32 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_kernel(const DcnParams p) 
   }
 }
 
-// [Co][C][kh][kw] (reference layout) -> [g][tap][c in group][Co]
-__global__ void dcn_pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wt, int Co, int C, int K, int dg) {
+// [Co][C][kh][kw] fp32 (reference layout) -> split-bf16 B-fragment image
+// [stage = g*K + tap][c/8][Co][hi: 8 bf16 | lo: 8 bf16]  (same byte count as the fp32 filter)
+__global__ void dcn_pack_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ wt, int Co, int C, int K, int dg) {
   const long long total = (long long)Co * C * K;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const int cpg = C / dg;
-  const int co = (int)(i % Co);
-  long long t = i / Co;
-  const int c = (int)(t % cpg);
-  t /= cpg;
-  const int tap = (int)(t % K);
-  const int g = (int)(t / K);
-  wt[i] = w[((size_t)co * C + g * cpg + c) * K + tap];
+  const int cpg = C / dg, nch = cpg / 8;
+  const int e = (int)(i % 8);
+  long long t = i / 8;
+  const int co = (int)(t % Co);
+  t /= Co;
+  const int kk = (int)(t % nch);
+  const int s = (int)(t / nch);
+  const int g = s / K, tap = s % K;
+  const float v = w[((size_t)co * C + g * cpg + kk * 8 + e) * K + tap];
+  const bf16_t hi = f2bf(v);
+  const size_t base = (((size_t)s * nch + kk) * Co + co) * 16;
+  wt[base + e] = hi;
+  wt[base + 8 + e] = f2bf(v - bf2f(hi));
 }
 
 template <bool XBF16>
 int launch_dcn(const DcnParams& p, hipStream_t stream) {
   const int nt = p.Co / 64;           // 2 waves along Co
   const int items = DC_PIX * (p.cpg / 8) / DC_THREADS;
-  const size_t lds = (size_t)2 * p.cpg * DC_PITCH * sizeof(float);
+  const size_t lds = (size_t)2 * 2 * (p.cpg / 8) * DC_PIX * 16;
   const unsigned blocks = (unsigned)((p.total_pix + DC_PIX - 1) / DC_PIX);
 #define DCN_CASE(NT_, IT_)                                                                            \
   if (nt == NT_ && items == IT_) {                                                                    \
@@ -247,7 +270,7 @@ extern "C" int glare_mdcn_pack_weight_f32(const float* weight_oihw, float* packe
   if (!weight_oihw || !packed || Co <= 0 || C <= 0 || kh <= 0 || kw <= 0 || dg <= 0 || C % dg) return GLARE_ERR_INVALID;
   const long long total = (long long)Co * C * kh * kw;
   hipLaunchKernelGGL(dcn_pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     weight_oihw, packed, Co, C, kh * kw, dg);
+                     weight_oihw, reinterpret_cast<bf16_t*>(packed), Co, C, kh * kw, dg);
   return glare_launch_status();
 }
 

@@ -180,7 +180,10 @@ int glare_attention_d512_bf16(const void* q, int ldq, const void* k, int ldk, co
  * bf16) with pitch/offset, offset/mask planar with explicit plane pitches and per-sample strides in
  * elements (0 = dense; as written by glare_conv2d_bf16 in GLARE_OUT_PLANAR_F32 mode into ONE buffer), mask optionally still a logit (sigmoid fused,
  * DCNv2Pack.forward deformableDecoder_arch.py:148), weights pre-packed once by
- * glare_mdcn_pack_weight_f32 ([Co][C][kh][kw] -> [dg][kh*kw][C/dg][Co]); out NHWC fp32 or planar. */
+ * glare_mdcn_pack_weight_f32 (fp32 [Co][C][kh][kw] -> split-bf16 fragment image of the SAME byte size,
+ * `packed` holds Co*C*kh*kw floats' worth of bytes); out NHWC fp32 or planar.
+ * Arithmetic: operands carried as bf16 hi + lo pairs, 3 bf16 MFMAs per product term, fp32 accumulation
+ * (>= 16 mantissa bits per operand; <= ~1e-5 relative vs fp32). */
 size_t glare_mdcn_workspace_bytes(int B, int C, int H, int W, int Co, int kh, int kw);
 int glare_mdcn_forward_f32(const float* x, const float* offset, const float* mask, const float* weight,
                            const float* bias_or_null, float* out, int B, int C, int H, int W, int Co, int kh, int kw,
