@@ -164,7 +164,7 @@ def main():
                        "weights": "random, name-seeded (no checkpoints offline)"},
             "roofline": attention_roofline(device, args.batch),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)
     if dist is not None:
