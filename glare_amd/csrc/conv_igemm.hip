@@ -24,9 +24,7 @@
 
 namespace {
 
-constexpr int TH = 8;    // output tile rows
 constexpr int TW = 32;   // output tile cols == MFMA M
-constexpr int NTHREADS = 256;
 
 struct ConvParams {
   const bf16_t* in0;
@@ -47,7 +45,7 @@ struct ConvParams {
   int fast_epilogue;
 };
 
-template <int KS, int STRIDE>
+template <int KS, int STRIDE, int TH>
 struct TileGeom {
   static constexpr int IH = (TH - 1) * STRIDE + KS;
   static constexpr int IW = (TW - 1) * STRIDE + KS;
@@ -90,18 +88,21 @@ __device__ __forceinline__ void dma16(const void* gsrc, void* lds_wave_base) {
 // double-buffered in LDS and filled by LDS-DMA (global_load_lds_dwordx4), issued one B stage
 // ahead, right after the barrier that retires the buffer they overwrite; one barrier per B stage.
 template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int KSTEPS>
-__global__ __launch_bounds__(NTHREADS, (STRIDE == 1 ? 3 : 2)) void conv_igemm_kernel(const ConvParams p) {
-  using G = TileGeom<KS, STRIDE>;
-  static_assert(WM * MT == TH && WM * WN == 4, "wave layout");
+__global__ __launch_bounds__(64 * WM * WN, (STRIDE == 1 ? 3 : 2)) void conv_igemm_kernel(const ConvParams p) {
+  constexpr int TH = WM * MT;       // output tile rows
+  constexpr int NW = WM * WN;       // waves per workgroup (4, or 6 for the 12 x 32 x 128 tile)
+  constexpr int NTHREADS = 64 * NW;
+  using G = TileGeom<KS, STRIDE, TH>;
+  static_assert(NW == 4 || NW == 6, "wave layout");
   constexpr int TN = WN * NT * 32;
   constexpr int A_CHUNKS = KSTEPS * 2 * G::NPOS;           // 16-B chunks of one A stage
   constexpr int A_INSTR = (A_CHUNKS + 63) / 64;            // wave-level DMA instructions per A stage
   constexpr int A_SLOTS = A_INSTR * 64;
-  constexpr int A_PER_W = (A_INSTR + 3) / 4;
+  constexpr int A_PER_W = (A_INSTR + NW - 1) / NW;
   constexpr int B_CHUNKS = KS * KSTEPS * 2 * TN;           // 16-B chunks of one B stage (one tap row)
   static_assert(B_CHUNKS % 64 == 0, "B stage is a whole number of wave DMAs");
   constexpr int B_INSTR = B_CHUNKS / 64;
-  constexpr int B_PER_W = (B_INSTR + 3) / 4;
+  constexpr int B_PER_W = (B_INSTR + NW - 1) / NW;
   constexpr int KC = 16 * KSTEPS;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -137,12 +138,12 @@ __global__ __launch_bounds__(NTHREADS, (STRIDE == 1 ? 3 : 2)) void conv_igemm_ke
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // per-lane invariant part of the A addressing: this wave issues DMA instructions
-  // j = wave + 4*i; lane handles chunk c = j*64 + lane = (kstep*2 + khalf)*NPOS + pos
+  // j = wave + NW*i; lane handles chunk c = j*64 + lane = (kstep*2 + khalf)*NPOS + pos
   long long a_src[A_PER_W];  // element offset of (pixel, channel 0) in its source, or -1 = zero
   int a_ck[A_PER_W];         // channel offset inside the stage: kstep*16 + khalf*8
 #pragma unroll
   for (int i = 0; i < A_PER_W; ++i) {
-    const int c = (wave + 4 * i) * 64 + lane;
+    const int c = (wave + NW * i) * 64 + lane;
     a_src[i] = -1;
     a_ck[i] = 0;
     if (c < A_CHUNKS) {
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(NTHREADS, (STRIDE == 1 ? 3 : 2)) void conv_igemm_ke
     const int c0 = chunk * KC;
 #pragma unroll
     for (int i = 0; i < A_PER_W; ++i) {
-      const int j = wave + 4 * i;
+      const int j = wave + NW * i;
       if (j < A_INSTR) {
         const void* src = g_zero16;
         const int ch = c0 + a_ck[i];
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(NTHREADS, (STRIDE == 1 ? 3 : 2)) void conv_igemm_ke
   auto issue_b = [&](int bstage, int buf) {
 #pragma unroll
     for (int i = 0; i < B_PER_W; ++i) {
-      const int j = wave + 4 * i;
+      const int j = wave + NW * i;
       if (j < B_INSTR)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(lB + buf * B_CHUNKS + j * 64),
                                                  16, lane16, (bstage * B_CHUNKS + j * 64) * 16, 0, 0);
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(NTHREADS, (STRIDE == 1 ? 3 : 2)) void conv_igemm_ke
     constexpr int HT = MT >= 2 ? MT / 2 : 1;             // tile rows per slab
     constexpr int ROWB = NT * 64 + 16;                   // slab row pitch in bytes (pad: bank spread)
     constexpr int CPR = NT * 4;                          // 16-B chunks per slab row
-    static_assert(4 * HROWS * ROWB <= (2 * A_SLOTS + 2 * B_CHUNKS) * 16, "epilogue slab fits the pipeline LDS");
+    static_assert(NW * HROWS * ROWB <= (2 * A_SLOTS + 2 * B_CHUNKS) * 16, "epilogue slab fits the pipeline LDS");
     __syncthreads();  // every wave is done reading the pipeline buffers
     char* slab = smem + wave * (HROWS * ROWB);
     const int ncol = lane & 31, rhalf = lane >> 5, odd = lane & 1;
@@ -385,15 +386,20 @@ Variant pick_variant(int ksize, int cout) {
 }
 
 template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int KSTEPS>
-int launch(const ConvParams& p, hipStream_t stream) {
-  using G = TileGeom<KS, STRIDE>;
+int launch(const ConvParams& p_in, hipStream_t stream) {
+  using G = TileGeom<KS, STRIDE, WM * MT>;
   constexpr int TN = WN * NT * 32;
+  ConvParams p = p_in;
+  p.tiles_y = cdiv(p.OH, WM * MT);
+  const long long nb = (long long)p.B * p.tiles_x * p.tiles_y * p.co_tiles;
+  if (nb > 0x7fffffffLL) return GLARE_ERR_INVALID;
+  p.n_blocks = (int)nb;
   const size_t lds = (size_t)(2 * (((KSTEPS * 2 * G::NPOS + 63) / 64) * 64) + 2 * KS * KSTEPS * 2 * TN) * 16;
   auto kern = conv_igemm_kernel<KS, STRIDE, MT, NT, WM, WN, KSTEPS>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GLARE_ERR_LAUNCH;
-  hipLaunchKernelGGL(kern, dim3(p.n_blocks), dim3(NTHREADS), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3(p.n_blocks), dim3(64 * WM * WN), lds, stream, p);
   return glare_launch_status();
 }
 
@@ -460,10 +466,8 @@ extern "C" int glare_conv2d_bf16(const glare_conv_desc* d, glare_stream_t stream
   // a stage must not straddle the two concatenated sources
   if (p.in1 && (p.Cin0 % kc)) return GLARE_ERR_UNSUPPORTED;
   p.n_stages = (p.CinTot + kc - 1) / kc;
-  p.tiles_x = cdiv(p.OW, TW); p.tiles_y = cdiv(p.OH, TH); p.co_tiles = cdiv(p.Cout, v.tn);
-  const long long nb = (long long)p.B * p.tiles_x * p.tiles_y * p.co_tiles;
-  if (nb > 0x7fffffffLL) return GLARE_ERR_INVALID;
-  p.n_blocks = (int)nb;
+  p.tiles_x = cdiv(p.OW, TW); p.tiles_y = 0; p.co_tiles = cdiv(p.Cout, v.tn);  // tiles_y / n_blocks: per variant, in launch()
+  p.n_blocks = 0;
   // 16-B records everywhere -> LDS-staged epilogue
   p.fast_epilogue = (d->out_mode == GLARE_OUT_NHWC_BF16) && !(p.Cout % 8) && !(p.opitch % 8) && !(p.ooff % 8) &&
                     (!p.res || (!(p.rpitch % 8) && !(p.roff % 8)));
@@ -472,7 +476,11 @@ extern "C" int glare_conv2d_bf16(const glare_conv_desc* d, glare_stream_t stream
 #define GLARE_CONV_DISPATCH(KS_, ST_)                                                     \
   do {                                                                                    \
     constexpr int KST = (KS_ == 1) ? 2 : 1;                                               \
-    if (v.tn == 128) return launch<KS_, ST_, 4, 2, 2, 2, KST>(p, stream);                 \
+    if (v.tn == 128) {                                                                    \
+      /* a 12 x 32 px tile on 6 waves (fewer weight DMAs per MFMA) measured 20-25 % SLOWER: 6 waves map 2,2,1,1 */ \
+      /* onto the 4 SIMDs and the doubly-loaded SIMDs set the barrier pace; keep wave counts multiples of 4 */      \
+      return launch<KS_, ST_, 4, 2, 2, 2, KST>(p, stream);                                \
+    }                                                                                     \
     if (v.tn == 64) return launch<KS_, ST_, 4, 1, 2, 2, KST>(p, stream);                  \
     return launch<KS_, ST_, 2, 1, 4, 1, KST>(p, stream);                                  \
   } while (0)
