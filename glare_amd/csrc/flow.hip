@@ -81,6 +81,90 @@ __global__ __launch_bounds__(FL_THREADS) void flow_tail_kernel(float* __restrict
   }
 }
 
+
+// ---- normal (training) direction, FlowStep.normal_flow (FlowStep.py:75-98) -------------------------------
+// pre : z = M z + t  (host-composed actnorm . invconv of this step and the coupling-free steps before it),
+//       then the feature-conditional affine z = (z + shiftFt) * scaleFt      (FlowAffineCouplingsAblation.py:55-59)
+// post: z[1:] = (z[1:] + shift) * scale                                      (:74-77)
+// Both add sum(log scale) of their pixels to a per-(sample, block) partial; the data-independent
+// parts of the log-determinant (actnorm logs, slogdet W) are added on the host in fp64.
+__global__ __launch_bounds__(FL_THREADS) void flow_fwd_pre_kernel(float* __restrict__ z, const float* __restrict__ hF, int f_pitch,
+                                                                  int f_off, long long pix_per_sample, int blocks_per_sample,
+                                                                  TailParams tp, float eps, float* __restrict__ ld_partial) {
+  __shared__ float red[FL_THREADS / 64];
+  const int b = blockIdx.x / blocks_per_sample, blk = blockIdx.x % blocks_per_sample;
+  float acc = 0.f;
+  for (long long q = (long long)blk * FL_THREADS + threadIdx.x; q < pix_per_sample; q += (long long)blocks_per_sample * FL_THREADS) {
+    const long long p = (long long)b * pix_per_sample + q;
+    const float a0 = z[p * 3], a1 = z[p * 3 + 1], a2 = z[p * 3 + 2];
+    float z0 = fmaf(tp.M[0], a0, fmaf(tp.M[1], a1, fmaf(tp.M[2], a2, tp.t[0])));
+    float z1 = fmaf(tp.M[3], a0, fmaf(tp.M[4], a1, fmaf(tp.M[5], a2, tp.t[1])));
+    float z2 = fmaf(tp.M[6], a0, fmaf(tp.M[7], a1, fmaf(tp.M[8], a2, tp.t[2])));
+    const float* f = hF + p * f_pitch + f_off;
+    const f32x4 f0 = *reinterpret_cast<const f32x4*>(f);
+    const f32x2 f1 = *reinterpret_cast<const f32x2*>(f + 4);
+    const float s0 = sigmoid_acc(f0[1] + 2.f) + eps, s1 = sigmoid_acc(f0[3] + 2.f) + eps, s2 = sigmoid_acc(f1[1] + 2.f) + eps;
+    z[p * 3] = (z0 + f0[0]) * s0;
+    z[p * 3 + 1] = (z1 + f0[2]) * s1;
+    z[p * 3 + 2] = (z2 + f1[0]) * s2;
+    acc += logf(s0) + logf(s1) + logf(s2);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) ld_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(FL_THREADS) void flow_fwd_post_kernel(float* __restrict__ z, const float* __restrict__ h4,
+                                                                   long long pix_per_sample, int blocks_per_sample, float eps,
+                                                                   float* __restrict__ ld_partial) {
+  __shared__ float red[FL_THREADS / 64];
+  const int b = blockIdx.x / blocks_per_sample, blk = blockIdx.x % blocks_per_sample;
+  float acc = 0.f;
+  for (long long q = (long long)blk * FL_THREADS + threadIdx.x; q < pix_per_sample; q += (long long)blocks_per_sample * FL_THREADS) {
+    const long long p = (long long)b * pix_per_sample + q;
+    const f32x4 h = *reinterpret_cast<const f32x4*>(h4 + p * 4);
+    const float s1 = sigmoid_acc(h[1] + 2.f) + eps, s2 = sigmoid_acc(h[3] + 2.f) + eps;
+    z[p * 3 + 1] = (z[p * 3 + 1] + h[0]) * s1;
+    z[p * 3 + 2] = (z[p * 3 + 2] + h[2]) * s2;
+    acc += logf(s1) + logf(s2);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) ld_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// Gaussian log-likelihood of the latent, GaussianDiag.logp(mean, logs=0, z) (flow.py:76-95), and the final sum of
+// the log-determinant partials: one block per sample.
+//   out[b] = { sum over partial rows, sum_p -0.5 * ((z - mean)^2 + log(2 pi)) }
+__global__ __launch_bounds__(FL_THREADS) void flow_nll_reduce_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+                                                                     const float* __restrict__ ld_partial, int n_rows,
+                                                                     int row_len, int blocks_per_sample, long long elems_per_sample,
+                                                                     double* __restrict__ out) {
+  __shared__ double red[2][FL_THREADS / 64];
+  const int b = blockIdx.x;
+  double ld = 0.0, lp = 0.0;
+  for (int i = threadIdx.x; i < n_rows * blocks_per_sample; i += FL_THREADS) {
+    const int row = i / blocks_per_sample, k = i % blocks_per_sample;
+    ld += ld_partial[(size_t)row * row_len + b * blocks_per_sample + k];
+  }
+  const float log2pi = 1.8378770664093453f;
+  for (long long i = threadIdx.x; i < elems_per_sample; i += FL_THREADS) {
+    const float d = z[(size_t)b * elems_per_sample + i] - mean[(size_t)b * elems_per_sample + i];
+    lp += -0.5 * ((double)(d * d) + (double)log2pi);
+  }
+  for (int o = 32; o > 0; o >>= 1) { ld += __shfl_xor(ld, o, 64); lp += __shfl_xor(lp, o, 64); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ld; red[1][threadIdx.x >> 6] = lp; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, c = 0.0;
+    for (int w = 0; w < FL_THREADS / 64; ++w) { a += red[0][w]; c += red[1][w]; }
+    out[2 * b] = a;
+    out[2 * b + 1] = c;
+  }
+}
+
 int fl_blocks(long long items) {
   long long b = (items + FL_THREADS - 1) / FL_THREADS;
   return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -107,5 +191,44 @@ extern "C" int glare_flow_tail_f32(float* z_nhwc3, const float* h4, const float*
   for (int i = 0; i < 3; ++i) tp.t[i] = t_3_host[i];
   hipLaunchKernelGGL(flow_tail_kernel, dim3(fl_blocks(n_pixels)), dim3(FL_THREADS), 0, (hipStream_t)stream, z_nhwc3, h4, hF,
                      hF_pitch, hF_off, n_pixels, tp, eps);
+  return glare_launch_status();
+}
+
+extern "C" int glare_flow_blocks_per_sample(long long pixels_per_sample) {
+  long long b = (pixels_per_sample + FL_THREADS - 1) / FL_THREADS;
+  return (int)(b < 1 ? 1 : (b > 64 ? 64 : b));
+}
+
+extern "C" int glare_flow_fwd_pre_f32(float* z_nhwc3, const float* hF, int hF_pitch, int hF_off, int B,
+                                      long long pixels_per_sample, const float* M_3x3_host, const float* t_3_host, float eps,
+                                      float* logdet_partial, glare_stream_t stream) {
+  if (!z_nhwc3 || !hF || !M_3x3_host || !t_3_host || !logdet_partial || B <= 0 || pixels_per_sample <= 0) return GLARE_ERR_INVALID;
+  if ((hF_pitch % 4) || (hF_off % 4) || hF_off + 6 > hF_pitch) return GLARE_ERR_UNSUPPORTED;
+  TailParams tp;
+  for (int i = 0; i < 9; ++i) tp.M[i] = M_3x3_host[i];
+  for (int i = 0; i < 3; ++i) tp.t[i] = t_3_host[i];
+  const int bps = glare_flow_blocks_per_sample(pixels_per_sample);
+  hipLaunchKernelGGL(flow_fwd_pre_kernel, dim3(B * bps), dim3(FL_THREADS), 0, (hipStream_t)stream, z_nhwc3, hF, hF_pitch, hF_off,
+                     pixels_per_sample, bps, tp, eps, logdet_partial);
+  return glare_launch_status();
+}
+
+extern "C" int glare_flow_fwd_post_f32(float* z_nhwc3, const float* h4, int B, long long pixels_per_sample, float eps,
+                                       float* logdet_partial, glare_stream_t stream) {
+  if (!z_nhwc3 || !h4 || !logdet_partial || B <= 0 || pixels_per_sample <= 0) return GLARE_ERR_INVALID;
+  const int bps = glare_flow_blocks_per_sample(pixels_per_sample);
+  hipLaunchKernelGGL(flow_fwd_post_kernel, dim3(B * bps), dim3(FL_THREADS), 0, (hipStream_t)stream, z_nhwc3, h4,
+                     pixels_per_sample, bps, eps, logdet_partial);
+  return glare_launch_status();
+}
+
+extern "C" int glare_flow_nll_reduce_f32(const float* z_nhwc3, const float* mean_nhwc3, const float* logdet_partial,
+                                         int n_partial_rows, int B, long long pixels_per_sample, double* out_2_per_sample,
+                                         glare_stream_t stream) {
+  if (!z_nhwc3 || !mean_nhwc3 || !logdet_partial || !out_2_per_sample || B <= 0 || pixels_per_sample <= 0 || n_partial_rows < 0)
+    return GLARE_ERR_INVALID;
+  const int bps = glare_flow_blocks_per_sample(pixels_per_sample);
+  hipLaunchKernelGGL(flow_nll_reduce_kernel, dim3(B), dim3(FL_THREADS), 0, (hipStream_t)stream, z_nhwc3, mean_nhwc3, logdet_partial,
+                     n_partial_rows, B * bps, bps, pixels_per_sample * 3, out_2_per_sample);
   return glare_launch_status();
 }

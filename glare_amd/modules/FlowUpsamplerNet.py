@@ -64,6 +64,15 @@ class FlowStep(nn.Module):
         elif flow_coupling != "noCoupling":
             raise RuntimeError("coupling not Found:", flow_coupling)
 
+    def forward_affine_fp64(self):
+        """z -> A z + c of (actnorm, invconv) in fp64 (FlowStep.py:83-88) and the per-pixel log-determinant."""
+        w = self.invconv.weight.detach().double().cpu()
+        logs = self.actnorm.logs.detach().double().cpu().reshape(-1)
+        bias = self.actnorm.bias.detach().double().cpu().reshape(-1)
+        A = w * torch.exp(logs).view(1, -1)            # W diag(e^logs)
+        c = A @ bias                                     # W ((z + b) e^logs) = A z + A b
+        return A, c, float(logs.sum() + torch.slogdet(w)[1])
+
     def reverse_affine_fp64(self):
         """z -> A z + c of (invconv reverse, actnorm reverse) in fp64 (FlowStep.py:112-117)."""
         winv = torch.inverse(self.invconv.weight.detach().double().cpu())
@@ -150,6 +159,60 @@ class FlowUpsamplerNet(HipModule):
             ops.flow_tail(z, h4, hF, 8 * s, st["M"], st["t"], st["eps"])
         return z
 
+    def _prepare_forward(self):
+        """Host-side composition for the normal direction: per coupling step the affine map of its own
+        actnorm . invconv and of the coupling-free steps before it; the data-independent log-determinant."""
+        steps, const_ld = [], 0.0
+        A, c = torch.eye(3, dtype=torch.float64), torch.zeros(3, dtype=torch.float64)
+        for layer in self.layers:
+            A2, c2, ld = layer.forward_affine_fp64()
+            A, c = A2 @ A, A2 @ c + c2
+            const_ld += ld
+            if layer.flow_coupling != "noCoupling":
+                steps.append({"layer": layer, "M": A.float().flatten().tolist(), "t": c.float().tolist()})
+                A, c = torch.eye(3, dtype=torch.float64), torch.zeros(3, dtype=torch.float64)
+        assert self.layers[len(self.layers) - 1].flow_coupling != "noCoupling", "a trailing coupling-free step has no host"
+        return {"steps": steps, "const_logdet_per_pixel": const_ld}
+
+    def encode_nhwc(self, gt, ft, mean=None):
+        """Normal direction.  gt: fp32 NHWC latent [B,h,w,3]; ft: bf16 NHWC cond_feat.  Returns (z fp32 NHWC,
+        logdet fp64 [B], logp fp64 [B] or None): FlowUpsamplerNet.encode (:228-274) + GaussianDiag.logp."""
+        P = self._packed("flow", self._prepare)      # packed convs are shared with the reverse direction
+        F_ = self._packed("flow_fwd", self._prepare_forward)
+        rev = {id(st["layer"]): st for st in P["steps"]}
+        order = {id(st["layer"]): i for i, st in enumerate(P["steps"])}
+        n = P["n"]
+        B, H, W, _ = gt.shape
+        z = gt.clone()
+        ftA = ops.conv2d(ft, P["ftA"], out_mode=ops.OUT_NHWC_F32)
+        h1f = ops.conv2d(ft, P["f0"], act="relu")
+        h2f = torch.empty_like(h1f)
+        hF = torch.zeros(B, H, W, n * 8, dtype=torch.float32, device=z.device)
+        for s, st in enumerate(P["steps"]):
+            ops.conv2d(h1f, st["f2"], cin=64, in_off=64 * s, act="relu", out=h2f, out_off=64 * s)
+            ops.conv2d(h2f, st["f4"], cin=64, in_off=64 * s, out=hF, out_off=8 * s, out_mode=ops.OUT_NHWC_F32)
+        bps = ops.flow_blocks_per_sample(H * W)
+        partial = torch.zeros(2 * n, B * bps, dtype=torch.float32, device=z.device)
+        h1 = torch.empty(B, H, W, 64, dtype=torch.bfloat16, device=z.device)
+        h2 = torch.empty_like(h1)
+        h4 = torch.empty(B, H, W, 4, dtype=torch.float32, device=z.device)
+        for k, fs in enumerate(F_["steps"]):
+            st = rev[id(fs["layer"])]
+            s = order[id(fs["layer"])]                 # slot of this step in the batched (reverse-ordered) buffers
+            ops.flow_fwd_pre(z, hF, 8 * s, fs["M"], fs["t"], st["eps"], partial[2 * k])
+            ops.flow_h1(z, ftA, 64 * s, st["wz"], out=h1)
+            ops.conv2d(h1, st["c2"], act="relu", out=h2)
+            ops.conv2d(h2, st["c4"], out=h4, out_mode=ops.OUT_NHWC_F32)
+            ops.flow_fwd_post(z, h4, st["eps"], partial[2 * k + 1])
+        red = ops.flow_nll_reduce(z, mean if mean is not None else z, partial, 2 * n)
+        logdet = red[:, 0] + F_["const_logdet_per_pixel"] * (H * W)
+        return z, logdet, (red[:, 1] if mean is not None else None)
+
+    def encode(self, gt, rrdbResults, logdet=0.0, epses=None, y_onehot=None):
+        ft = rrdbResults["cond_feat"] if isinstance(rrdbResults, dict) else rrdbResults
+        z, ld, _ = self.encode_nhwc(to_nhwc(gt, bf16=False), to_nhwc(ft, bf16=True))
+        return to_nchw(z), logdet + ld.float()
+
     def decode(self, rrdbResults, z, eps_std=None, epses=None, logdet=0.0, y_onehot=None):
         ft = rrdbResults["cond_feat"] if isinstance(rrdbResults, dict) else rrdbResults
         x = self.decode_nhwc(to_nhwc(z, bf16=False), to_nhwc(ft, bf16=True))
@@ -158,4 +221,5 @@ class FlowUpsamplerNet(HipModule):
     def forward(self, gt=None, rrdbResults=None, z=None, epses=None, logdet=0.0, reverse=False, eps_std=None, y_onehot=None):
         if reverse:
             return self.decode(rrdbResults, z, eps_std, epses=epses, logdet=logdet, y_onehot=y_onehot)
-        raise NotImplementedError("the normal (training) direction is not built on HIP yet; see DESIGN.md (row a4)")
+        assert gt is not None
+        return self.encode(gt, rrdbResults, logdet=logdet, epses=epses, y_onehot=y_onehot)

@@ -8,3 +8,4 @@ from .ConditionEncoder import ConEncoder1  # noqa: F401
 from .FlowUpsamplerNet import FlowUpsamplerNet  # noqa: F401
 from .deformableDecoder_arch import DCNv2Pack, Mix, MultiScaleDecoder2, WarpBlock  # noqa: F401
 from .VQLLFLOWDeformable_arch import VQLLFLOWDeformable  # noqa: F401
+from .LLFlowVQGAN_arch import LLFlowVQGAN2  # noqa: F401

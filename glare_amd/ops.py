@@ -291,3 +291,33 @@ def mdcn_forward_nhwc(x, om, pd, x_off=0, C=None, mask_is_logit=True, padding=1)
                                              _i(padding), _i(1), _i(1), _i(1), _i(pd.dg), stream_handle()),
           "glare_mdcn_forward_nhwc")
     return out
+
+
+def flow_blocks_per_sample(pixels_per_sample):
+    return int(_lib.lib().glare_flow_blocks_per_sample(_ll(pixels_per_sample)))
+
+
+def flow_fwd_pre(z, hF, hF_off, M, t, eps, partial_row):
+    require_cuda(z, hF, partial_row)
+    B = z.shape[0]
+    Ma = (ctypes.c_float * 9)(*[float(v) for v in M])
+    ta = (ctypes.c_float * 3)(*[float(v) for v in t])
+    check(_lib.lib().glare_flow_fwd_pre_f32(ptr(z), ptr(hF), _i(hF.shape[3]), _i(hF_off), _i(B), _ll(z.numel() // 3 // B), Ma, ta,
+                                            _f(eps), ptr(partial_row), stream_handle()), "glare_flow_fwd_pre_f32")
+
+
+def flow_fwd_post(z, h4, eps, partial_row):
+    require_cuda(z, h4, partial_row)
+    B = z.shape[0]
+    check(_lib.lib().glare_flow_fwd_post_f32(ptr(z), ptr(h4), _i(B), _ll(z.numel() // 3 // B), _f(eps), ptr(partial_row),
+                                             stream_handle()), "glare_flow_fwd_post_f32")
+
+
+def flow_nll_reduce(z, mean, partial, n_rows):
+    """-> float64 [B, 2]: (data-dependent logdet, Gaussian log-likelihood)."""
+    require_cuda(z, mean, partial)
+    B = z.shape[0]
+    out = torch.empty(B, 2, dtype=torch.float64, device=z.device)
+    check(_lib.lib().glare_flow_nll_reduce_f32(ptr(z), ptr(mean), ptr(partial), _i(n_rows), _i(B), _ll(z.numel() // 3 // B),
+                                               ptr(out), stream_handle()), "glare_flow_nll_reduce_f32")
+    return out

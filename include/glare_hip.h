@@ -217,6 +217,25 @@ int glare_mdcn_backward_f32(const float* x, const float* offset, const float* ma
                             int kw, int sh, int sw, int ph, int pw, int dh, int dw, int groups, int dg, void* workspace,
                             size_t workspace_bytes, glare_stream_t stream);
 
+/* ---- a4: conditional flow, normal (training) direction + negative log-likelihood -------------------
+ * Replaces FlowStep.normal_flow (FlowStep.py:75-98), CondAffineSeparatedAndCond forward
+ * (FlowAffineCouplingsAblation.py:51-81), get_logdet (:121-122) and GaussianDiag.logp (flow.py:76-95).
+ * Per coupling step: glare_flow_fwd_pre_f32 (z = M z + t, then the feature affine), glare_flow_h1_f32 and the
+ * two convs as in the reverse direction, glare_flow_fwd_post_f32 (self-conditional affine on z[1:]).
+ * Each call writes B * glare_flow_blocks_per_sample() fp32 partial sums of log(scale) into one row of
+ * logdet_partial; glare_flow_nll_reduce_f32 sums all rows per sample and evaluates the Gaussian term:
+ *   out[2b] = sum of the data-dependent log-determinant, out[2b+1] = sum_p -0.5((z-mean)^2 + log 2pi).
+ * The data-independent part (actnorm logs, slogdet of the 1x1 kernels, times pixels) is the caller's (fp64). */
+int glare_flow_blocks_per_sample(long long pixels_per_sample);
+int glare_flow_fwd_pre_f32(float* z_nhwc3, const float* hF, int hF_pitch, int hF_off, int B, long long pixels_per_sample,
+                           const float* M_3x3_host, const float* t_3_host, float eps, float* logdet_partial,
+                           glare_stream_t stream);
+int glare_flow_fwd_post_f32(float* z_nhwc3, const float* h4, int B, long long pixels_per_sample, float eps,
+                            float* logdet_partial, glare_stream_t stream);
+int glare_flow_nll_reduce_f32(const float* z_nhwc3, const float* mean_nhwc3, const float* logdet_partial,
+                              int n_partial_rows, int B, long long pixels_per_sample, double* out_2_per_sample,
+                              glare_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -126,3 +126,30 @@ def test_reference_module_surface(nets):
     assert out_p.shape == ref["out"].shape and lat_p.shape == ref["latent"].shape
     with pytest.raises(NotImplementedError):
         pg.RRDB(lr)  # CPU tensor: no fallback
+
+
+def test_stage2_normal_flow_and_nll(nets):
+    """Row a4: FlowUpsamplerNet.encode + log-determinant + Gaussian NLL against the oracle's normal_flow
+    (which is bit-identical to the reference's, tests/test_oracle_vs_reference.py)."""
+    og, ov, pg, pv, lr, ref = nets
+    o2 = seeded_init_(O.LLFlowVQGAN2().eval(), 2)
+    p2 = M.LLFlowVQGAN2().eval()
+    p2.load_state_dict(o2.state_dict(), strict=True)
+    p2.cuda()
+    g = torch.Generator().manual_seed(3)
+    gt = torch.randn(2, 3, 10, 14, generator=g) * 0.5
+    with torch.no_grad():
+        z_o, nll_o, ld_o = o2.normal_flow(gt, lr)
+        # flow only, on the oracle's conditional features (isolates the flow kernels)
+        enc = o2.RRDB(lr)
+        z_p, ld_p, lp_p = p2.flowUpsamplerNet.encode_nhwc(nhwc(gt, bf16=False), nhwc(enc["cond_feat"]),
+                                                           mean=nhwc(enc["color_map"], bf16=False))
+        assert rel(nchw(z_p), z_o) < 3e-2
+        assert torch.allclose(ld_p.float().cpu(), ld_o, rtol=2e-2, atol=2.0)
+        # whole stage-2 forward through the reference-shaped entry point
+        z2, nll_p, _ = p2(gt=gt.cuda(), lr=lr.cuda(), reverse=False)
+    assert rel(z2.cpu(), z_o) < 5e-2
+    assert torch.allclose(nll_p.cpu(), nll_o, rtol=5e-2, atol=0.05)
+    # invertibility on the HIP path itself: decode(encode(x)) == x
+    back = p2.flowUpsamplerNet.decode_nhwc(z_p, nhwc(enc["cond_feat"]))
+    assert rel(nchw(back), gt) < 2e-2
