@@ -43,6 +43,8 @@ struct ConvParams {
   long long plane_pitch;
   int tiles_x, tiles_y, co_tiles, n_blocks, n_stages;
   int fast_epilogue;
+  float* gn_part;   // optional GroupNorm partial sums of the OUTPUT: [b][part][Cout/4][2], part = tile*WM + wm
+  int gn_nparts;
 };
 
 template <int KS, int STRIDE, int TH>
@@ -211,6 +213,9 @@ __global__ __launch_bounds__(64 * WM * WN, (STRIDE == 1 ? 3 : 2)) void conv_igem
 #endif
 #endif
       const u32x4* cB = lB + (bs & 1) * B_CHUNKS;
+#ifdef CONV_SETPRIO
+      __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
       for (int tcol = 0; tcol < KS; ++tcol) {
 #pragma unroll
@@ -234,6 +239,9 @@ __global__ __launch_bounds__(64 * WM * WN, (STRIDE == 1 ? 3 : 2)) void conv_igem
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
       }
+#ifdef CONV_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
     }
   }
 
@@ -254,6 +262,9 @@ __global__ __launch_bounds__(64 * WM * WN, (STRIDE == 1 ? 3 : 2)) void conv_igem
     char* slab = smem + wave * (HROWS * ROWB);
     const int ncol = lane & 31, rhalf = lane >> 5, odd = lane & 1;
     const bool act_early = p.res == nullptr;
+    // fused GroupNorm statistics of the tensor being written (the consumer's gn_stats pass would re-read it):
+    // per lane the sum / sum of squares of its two 4-channel units over its pixels, from the ROUNDED values
+    float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
     static_for<MT / HT>([&](auto hc) {
       constexpr int half = decltype(hc)::value;
       static_for<NT>([&](auto jc) {
@@ -293,10 +304,31 @@ __global__ __launch_bounds__(64 * WM * WN, (STRIDE == 1 ? 3 : 2)) void conv_igem
               v[e] = pack_bf2(apply_act(bflo(v[e]) + bflo(rv[e]), p.act), apply_act(bfhi(v[e]) + bfhi(rv[e]), p.act));
           }
           *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.out) + pix * p.opitch + p.ooff + co) = v;
+          if (p.gn_part) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const float x0 = bflo(v[e]), x1 = bfhi(v[e]), y0 = bflo(v[2 + e]), y1 = bfhi(v[2 + e]);
+              gs0 += x0 + x1; gq0 += x0 * x0 + x1 * x1;
+              gs1 += y0 + y1; gq1 += y0 * y0 + y1 * y1;
+            }
+          }
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     });
+    if (p.gn_part) {  // lanes with the same channel chunk are CPR apart: fold them, one lane per chunk writes
+#pragma unroll
+      for (int o = CPR; o < 64; o <<= 1) {
+        gs0 += __shfl_xor(gs0, o, 64); gq0 += __shfl_xor(gq0, o, 64);
+        gs1 += __shfl_xor(gs1, o, 64); gq1 += __shfl_xor(gq1, o, 64);
+      }
+      const int co = ct * TN + wn * NT * 32 + lane * 8;
+      if (lane < CPR && co < p.Cout) {
+        const int part = (ty * p.tiles_x + tx) * WM + wm;
+        float* dst = p.gn_part + (((size_t)b * p.gn_nparts + part) * (p.Cout / 4) + co / 4) * 2;
+        dst[0] = gs0; dst[1] = gq0; dst[2] = gs1; dst[3] = gq1;
+      }
+    }
     return;
   }
 
@@ -374,6 +406,30 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, bf16_t* __restri
   out[i] = f2bf(v);
 }
 
+// GroupNorm partial reduction: [b][part][Cout/4][2] -> the [B][1][32][2] partial format gn_apply consumes
+__global__ __launch_bounds__(256) void gn_part_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts,
+                                                             int Cout) {
+  __shared__ float red[2][4];
+  const int b = blockIdx.x / 32, g = blockIdx.x % 32;
+  const int upg = Cout / 128;  // 4-channel units per group (cpg / 4)
+  const int U = Cout / 4;
+  float s = 0.f, q = 0.f;
+  for (int i = threadIdx.x; i < nparts * upg; i += 256) {
+    const int pt = i / upg, u = g * upg + i % upg;
+    const float* src = part + (((size_t)b * nparts + pt) * U + u) * 2;
+    s += src[0];
+    q += src[1];
+  }
+  s = wave_sum(s);
+  q = wave_sum(q);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[((size_t)b * 32 + g) * 2] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    out[((size_t)b * 32 + g) * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+
 struct Variant {
   int tn, ksteps;
 };
@@ -394,6 +450,8 @@ int launch(const ConvParams& p_in, hipStream_t stream) {
   const long long nb = (long long)p.B * p.tiles_x * p.tiles_y * p.co_tiles;
   if (nb > 0x7fffffffLL) return GLARE_ERR_INVALID;
   p.n_blocks = (int)nb;
+  p.gn_nparts = p.tiles_x * p.tiles_y * WM;
+  if (p.gn_part && !(p.fast_epilogue && p.Cout % 32 == 0)) return GLARE_ERR_UNSUPPORTED;
   const size_t lds = (size_t)(2 * (((KSTEPS * 2 * G::NPOS + 63) / 64) * 64) + 2 * KS * KSTEPS * 2 * TN) * 16;
   auto kern = conv_igemm_kernel<KS, STRIDE, MT, NT, WM, WN, KSTEPS>;
   if (lds > 64 * 1024 &&
@@ -468,6 +526,8 @@ extern "C" int glare_conv2d_bf16(const glare_conv_desc* d, glare_stream_t stream
   p.n_stages = (p.CinTot + kc - 1) / kc;
   p.tiles_x = cdiv(p.OW, TW); p.tiles_y = 0; p.co_tiles = cdiv(p.Cout, v.tn);  // tiles_y / n_blocks: per variant, in launch()
   p.n_blocks = 0;
+  p.gn_part = d->gn_partial;
+  p.gn_nparts = 0;
   // 16-B records everywhere -> LDS-staged epilogue
   p.fast_epilogue = (d->out_mode == GLARE_OUT_NHWC_BF16) && !(p.Cout % 8) && !(p.opitch % 8) && !(p.ooff % 8) &&
                     (!p.res || (!(p.rpitch % 8) && !(p.roff % 8)));
@@ -490,4 +550,19 @@ extern "C" int glare_conv2d_bf16(const glare_conv_desc* d, glare_stream_t stream
   GLARE_CONV_DISPATCH(3, 1);
 #undef GLARE_CONV_DISPATCH
   return GLARE_ERR_UNSUPPORTED;
+}
+
+// Number of floats of the fused-GroupNorm partial buffer for a conv with this output geometry.
+extern "C" long long glare_conv2d_gn_partial_elems(int B, int OH, int OW, int Cout) {
+  if (B <= 0 || OH <= 0 || OW <= 0 || Cout <= 0) return GLARE_ERR_INVALID;
+  const long long parts = (long long)cdiv(OW, TW) * cdiv(OH, 8) * 2;  // 8 x 32 tiles, 2 wave rows per tile
+  return (long long)B * parts * (Cout / 4) * 2;
+}
+
+extern "C" int glare_conv2d_gn_reduce(const float* gn_partial, float* stats_out, int B, int OH, int OW, int Cout,
+                                      glare_stream_t stream) {
+  if (!gn_partial || !stats_out || B <= 0 || Cout % 128) return GLARE_ERR_INVALID;
+  const int parts = cdiv(OW, TW) * cdiv(OH, 8) * 2;
+  hipLaunchKernelGGL(gn_part_reduce_kernel, dim3(B * 32), dim3(256), 0, (hipStream_t)stream, gn_partial, stats_out, parts, Cout);
+  return glare_launch_status();
 }

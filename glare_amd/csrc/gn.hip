@@ -143,3 +143,16 @@ extern "C" int glare_groupnorm_swish_bf16(const void* x, int in_pitch, int in_of
                      (const float*)workspace, gamma, beta, (bf16_t*)y, HW, C, in_pitch, in_off, splits, eps, swish, bpi);
   return glare_launch_status();
 }
+
+extern "C" int glare_groupnorm_apply_bf16(const void* x, int in_pitch, int in_off, const float* gamma, const float* beta,
+                                          void* y, int B, long long HW, int C, float eps, int swish, const float* stats,
+                                          int splits, glare_stream_t stream_) {
+  if (!x || !gamma || !beta || !y || !stats || B <= 0 || HW <= 0 || C <= 0 || splits <= 0) return GLARE_ERR_INVALID;
+  if (C % 32 || C % 8 || C > 2048 || (GN_THREADS % (C / 8)) || in_pitch % 8 || in_off % 8) return GLARE_ERR_UNSUPPORTED;
+  if (in_off + C > in_pitch) return GLARE_ERR_INVALID;
+  int bpi = (int)((HW * (C / 8) + 16 * GN_THREADS - 1) / (16 * GN_THREADS));
+  if (bpi < 1) bpi = 1;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)(bpi * B)), dim3(GN_THREADS), 0, (hipStream_t)stream_, (const bf16_t*)x,
+                     stats, gamma, beta, (bf16_t*)y, HW, C, in_pitch, in_off, splits, eps, swish, bpi);
+  return glare_launch_status();
+}

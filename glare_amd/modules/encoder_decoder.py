@@ -13,6 +13,9 @@ from .. import ops
 from ._base import HipModule, packed_conv, to_nchw, to_nhwc
 
 
+GN_FUSED = True  # GroupNorm statistics gathered by the producing conv's epilogue (False: separate stats pass)
+
+
 def Normalize(in_channels):  # encoder_decoder.py:34-35
     return nn.GroupNorm(num_groups=32, num_channels=in_channels, eps=1e-6, affine=True)
 
@@ -29,7 +32,8 @@ class Upsample(HipModule):
         self.conv = nn.Conv2d(in_channels, in_channels, 3, 1, 1)
 
     def forward_nhwc(self, x, **kw):
-        return ops.conv2d(x, packed_conv(self, self.conv), upsample=True, **kw)  # nearest x2 fused in the loader
+        # nearest x2 fused in the loader; GroupNorm statistics of the output fused in the epilogue
+        return ops.conv2d(x, packed_conv(self, self.conv), upsample=True, gn_stats=GN_FUSED and self.conv.out_channels % 128 == 0, **kw)
 
     def forward(self, x):
         return to_nchw(self.forward_nhwc(to_nhwc(x)))
@@ -43,7 +47,8 @@ class Downsample(HipModule):
         self.conv = nn.Conv2d(in_channels, in_channels, 3, 2, 0)
 
     def forward_nhwc(self, x):
-        return ops.conv2d(x, packed_conv(self, self.conv), stride=2)  # pad (0,1,0,1) fused in the loader
+        return ops.conv2d(x, packed_conv(self, self.conv), stride=2,  # pad (0,1,0,1) fused in the loader
+                          gn_stats=GN_FUSED and self.conv.out_channels % 128 == 0)
 
     def forward(self, x):
         return to_nchw(self.forward_nhwc(to_nhwc(x)))
@@ -63,10 +68,13 @@ class ResnetBlock(HipModule):
             self.nin_shortcut = nn.Conv2d(in_channels, out_channels, 1, 1, 0)
 
     def forward_nhwc(self, x, out=None, out_off=0):
-        h = ops.conv2d(gn_swish(x, self.norm1), packed_conv(self, self.conv1))
+        fuse = GN_FUSED and self.out_channels % 128 == 0
+        h = ops.conv2d(gn_swish(x, self.norm1), packed_conv(self, self.conv1), gn_stats=fuse)  # stats for norm2
         h = gn_swish(h, self.norm2)
         res = x if self.in_channels == self.out_channels else ops.conv2d(x, packed_conv(self, self.nin_shortcut))
-        return ops.conv2d(h, packed_conv(self, self.conv2), residual=res, out=out, out_off=out_off)
+        # the block output feeds the next block's / attention's norm: its statistics ride along too
+        return ops.conv2d(h, packed_conv(self, self.conv2), residual=res, out=out, out_off=out_off,
+                          gn_stats=fuse and out is None)
 
     def forward(self, x, temb=None):
         return to_nchw(self.forward_nhwc(to_nhwc(x)))
@@ -98,7 +106,7 @@ class AttnBlock(HipModule):
         npad = (N + 63) // 64 * 64
         vt = ops.conv2d(hn, packed_conv(self, self.v), out_mode=ops.OUT_PLANAR_BF16, plane_pitch=npad)  # V^T [B,512,npad]
         o = ops.attention_d512(qk, qk[..., C:], vt, N, ldq=2 * C, ldk=2 * C)     # [B,N,512]
-        return ops.conv2d(o.view(B, H, W, C), packed_conv(self, self.proj_out), residual=x)
+        return ops.conv2d(o.view(B, H, W, C), packed_conv(self, self.proj_out), residual=x, gn_stats=GN_FUSED)
 
     def forward(self, x):
         return to_nchw(self.forward_nhwc(to_nhwc(x)))

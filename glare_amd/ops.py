@@ -42,7 +42,7 @@ class ConvDesc(ctypes.Structure):
                 ("Cout", _i), ("out_pitch", _i), ("out_off", _i),
                 ("res_pitch", _i), ("res_off", _i),
                 ("ksize", _i), ("stride", _i), ("upsample", _i), ("act", _i), ("out_mode", _i),
-                ("plane_pitch", _ll)]
+                ("plane_pitch", _ll), ("gn_partial", ctypes.c_void_p)]
 
 
 class PackedConv:
@@ -65,7 +65,7 @@ class PackedConv:
 
 
 def conv2d(x, pc, *, x2=None, cin=None, in_off=0, cin2=None, in2_off=0, stride=1, upsample=False, act="none",
-           residual=None, res_off=0, out=None, out_off=0, out_mode=OUT_NHWC_BF16, plane_pitch=0):
+           residual=None, res_off=0, out=None, out_off=0, out_mode=OUT_NHWC_BF16, plane_pitch=0, gn_stats=False):
     """x: NHWC bf16 [B,H,W,pitch] (channels [in_off, in_off+cin) are used), optional x2 concatenated
     after it.  Returns (or fills `out`) per out_mode; planar outputs are [B, planes, plane_pitch]."""
     require_cuda(x, x2, residual, out)
@@ -105,7 +105,20 @@ def conv2d(x, pc, *, x2=None, cin=None, in_off=0, cin2=None, in2_off=0, stride=1
         assert residual.dtype == torch.bfloat16 and residual.is_contiguous()
         d.residual, d.res_pitch, d.res_off = residual.data_ptr(), residual.shape[3], res_off
     d.ksize, d.stride, d.upsample, d.act, d.out_mode = pc.ksize, stride, int(bool(upsample)), ACT[act], out_mode
-    check(_lib.lib().glare_conv2d_bf16(ctypes.byref(d), stream_handle()), "glare_conv2d_bf16")
+    lib = _lib.lib()
+    gn_part = None
+    if gn_stats:  # GroupNorm statistics of the output, gathered by the epilogue (saves the consumer's read pass)
+        assert out_mode == OUT_NHWC_BF16 and pc.cout % 128 == 0 and out_off == 0 and out.shape[3] == pc.cout
+        lib.glare_conv2d_gn_partial_elems.restype = _ll
+        n = lib.glare_conv2d_gn_partial_elems(_i(B), _i(OH), _i(OW), _i(pc.cout))
+        gn_part = torch.empty(n, dtype=torch.float32, device=x.device)
+        d.gn_partial = gn_part.data_ptr()
+    check(lib.glare_conv2d_bf16(ctypes.byref(d), stream_handle()), "glare_conv2d_bf16")
+    if gn_stats:
+        stats = torch.empty(B, 1, 32, 2, dtype=torch.float32, device=x.device)
+        check(lib.glare_conv2d_gn_reduce(ptr(gn_part), ptr(stats), _i(B), _i(OH), _i(OW), _i(pc.cout), stream_handle()),
+              "glare_conv2d_gn_reduce")
+        out._gn_stats = stats  # consumed by groupnorm(); plain Python attribute, not a tensor property
     return out
 
 
@@ -137,12 +150,20 @@ def conv2d_smallcin(x, strides, shape_bhw, weight, bias=None, act="none", out=No
 
 
 def groupnorm(x, gamma, beta, swish=True, eps=1e-6, cin=None, in_off=0):
-    """x: bf16 NHWC [B,H,W,pitch]; returns dense bf16 NHWC [B,H,W,C]."""
+    """x: bf16 NHWC [B,H,W,pitch]; returns dense bf16 NHWC [B,H,W,C].  If the producing conv left its fused
+    statistics on the tensor (conv2d(..., gn_stats=True)), only the apply pass runs."""
     require_cuda(x, gamma, beta)
     assert x.dtype == torch.bfloat16 and x.is_contiguous()
     B, H, W, pitch = x.shape
     C = pitch - in_off if cin is None else cin
     lib = _lib.lib()
+    stats = getattr(x, "_gn_stats", None)
+    if stats is not None and in_off == 0 and C == pitch:
+        y = torch.empty(B, H, W, C, dtype=torch.bfloat16, device=x.device)
+        check(lib.glare_groupnorm_apply_bf16(ptr(x), _i(pitch), _i(0), ptr(gamma), ptr(beta), ptr(y), _i(B), _ll(H * W), _i(C),
+                                             _f(eps), _i(int(swish)), ptr(stats), _i(1), stream_handle()),
+              "glare_groupnorm_apply_bf16")
+        return y
     lib.glare_groupnorm_workspace_bytes.restype = _sz
     nws = lib.glare_groupnorm_workspace_bytes(_i(B), _ll(H * W))
     ws = _workspace(nws, x.device)

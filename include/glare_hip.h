@@ -94,6 +94,8 @@ typedef struct glare_conv_desc {
   int act;                   /* GLARE_ACT_*                                                        */
   int out_mode;              /* GLARE_OUT_*                                                        */
   long long plane_pitch;     /* planar modes: elements per plane (>= OH*OW); 0 = OH*OW             */
+  float* gn_partial;         /* optional: fused GroupNorm statistics of the OUTPUT (bf16 NHWC, Cout % 128 == 0): */
+                             /* glare_conv2d_gn_partial_elems() floats, reduced by glare_conv2d_gn_reduce()       */
 } glare_conv_desc;
 
 /* Number of bf16 elements of the packed weight image for an OIHW [cout][cin_total][k][k] filter. */
@@ -102,6 +104,12 @@ long long glare_conv2d_packed_weight_elems(int cout, int cin_total, int ksize);
 int glare_conv2d_pack_weight(const float* w_oihw, int cout, int cin_total, int ksize, void* packed_bf16,
                              glare_stream_t stream);
 int glare_conv2d_bf16(const glare_conv_desc* desc_host, glare_stream_t stream);
+/* Fused GroupNorm statistics: the conv epilogue leaves per-tile partial sums of its output; the reduce turns
+ * them into the [B][1][32][2] (sum, sum of squares per group) block glare_groupnorm_apply_bf16 consumes, so the
+ * consumer's statistics pass (one full read of the tensor) disappears. */
+long long glare_conv2d_gn_partial_elems(int B, int OH, int OW, int Cout);
+int glare_conv2d_gn_reduce(const float* gn_partial, float* stats_out, int B, int OH, int OW, int Cout,
+                           glare_stream_t stream);
 
 /* Thin convolutions whose INPUT has <= 4 channels (conv_in 3->128 / 3->512, cond_conv 3->64 +
  * sigmoid, color_conv 3->3, quant_conv / post_quant_conv 1x1 3->3: encoder_decoder.py:355,467;
@@ -118,6 +126,10 @@ int glare_conv2d_smallcin_f32(const float* x, long long stride_b, long long stri
  * x: bf16 NHWC [B][HW][in_pitch] channels [in_off, in_off+C); y: bf16 NHWC [B][HW][C] dense.
  * C % 32 == 0, C <= 2048.  workspace: glare_groupnorm_workspace_bytes(B, HW) bytes of scratch. */
 size_t glare_groupnorm_workspace_bytes(int B, long long HW);
+/* apply only, with statistics already available as `splits` partial blocks [B][splits][32][2] */
+int glare_groupnorm_apply_bf16(const void* x, int in_pitch, int in_off, const float* gamma, const float* beta, void* y,
+                               int B, long long HW, int C, float eps, int swish, const float* stats, int splits,
+                               glare_stream_t stream);
 int glare_groupnorm_swish_bf16(const void* x, int in_pitch, int in_off, const float* gamma, const float* beta,
                                void* y, int B, long long HW, int C, float eps, int swish, void* workspace,
                                size_t workspace_bytes, glare_stream_t stream);

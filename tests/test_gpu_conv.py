@@ -127,3 +127,24 @@ def test_full_size_linearity():
         xx = int(torch.randint(0, W, (1,), generator=g))
         ref = (xp[b, :, yy:yy + 3, xx:xx + 3][None] * wb).sum(dim=(1, 2, 3))
         assert torch.allclose(y[b, yy, xx], ref, rtol=1e-3, atol=2e-3)
+
+
+def test_fused_groupnorm_statistics():
+    """The conv epilogue's fused GroupNorm statistics equal the standalone statistics pass: the normalised
+    output is identical up to fp32 summation order (ragged edges, residual, 128/256/512 channels)."""
+    g = torch.Generator().manual_seed(21)
+    for B, Cin, Cout, H, W in ((2, 64, 128, 13, 37), (1, 128, 256, 9, 33), (1, 64, 512, 8, 40)):
+        x = _rand((B, Cin, H, W), g)
+        w = _rand((Cout, Cin, 3, 3), g, 0.05)
+        b = _rand((Cout,), g, 0.1)
+        r = _rand((B, Cout, H, W), g)
+        gamma = (_rand((Cout,), g, 0.2) + 1).cuda()
+        beta = _rand((Cout,), g, 0.2).cuda()
+        pc = ops.PackedConv(w.cuda(), b.cuda())
+        y1 = ops.conv2d(_nhwc_bf16(x), pc, residual=_nhwc_bf16(r), gn_stats=True)
+        assert hasattr(y1, "_gn_stats")
+        y2 = ops.conv2d(_nhwc_bf16(x), pc, residual=_nhwc_bf16(r))
+        assert torch.equal(y1, y2)
+        n1 = ops.groupnorm(y1, gamma, beta, swish=True)   # apply only, fused statistics
+        n2 = ops.groupnorm(y2, gamma, beta, swish=True)   # stats + apply
+        assert torch.allclose(n1.float(), n2.float(), rtol=2 ** -7, atol=2e-3)
