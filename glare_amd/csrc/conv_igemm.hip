@@ -90,12 +90,12 @@ __device__ __forceinline__ void dma16(const void* gsrc, void* lds_wave_base) {
 // double-buffered in LDS and filled by LDS-DMA (global_load_lds_dwordx4), issued one B stage
 // ahead, right after the barrier that retires the buffer they overwrite; one barrier per B stage.
 template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int KSTEPS>
-__global__ __launch_bounds__(64 * WM * WN, (STRIDE == 1 ? 3 : 2)) void conv_igemm_kernel(const ConvParams p) {
+__global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 2)) void conv_igemm_kernel(const ConvParams p) {
   constexpr int TH = WM * MT;       // output tile rows
   constexpr int NW = WM * WN;       // waves per workgroup (4, or 6 for the 12 x 32 x 128 tile)
   constexpr int NTHREADS = 64 * NW;
   using G = TileGeom<KS, STRIDE, TH>;
-  static_assert(NW == 4 || NW == 6, "wave layout");
+  static_assert(NW == 4 || NW == 6 || NW == 8, "wave layout");
   constexpr int TN = WN * NT * 32;
   constexpr int A_CHUNKS = KSTEPS * 2 * G::NPOS;           // 16-B chunks of one A stage
   constexpr int A_INSTR = (A_CHUNKS + 63) / 64;            // wave-level DMA instructions per A stage
@@ -253,8 +253,8 @@ __global__ __launch_bounds__(64 * WM * WN, (STRIDE == 1 ? 3 : 2)) void conv_igem
   //            value so every lane writes one packed 4-B word: even lanes row m(2t), odd lanes row m(2t+1)
   //   phase 2: 16-B LDS reads, + residual (16-B global load, fp32 add), act, 16-B global store
   if (p.out_mode == GLARE_OUT_NHWC_BF16 && p.fast_epilogue) {
-    constexpr int HROWS = (MT >= 2 ? MT / 2 : 1) * 32;  // slab rows
-    constexpr int HT = MT >= 2 ? MT / 2 : 1;             // tile rows per slab
+    constexpr int HT = (NW == 8 || MT < 2) ? 1 : MT / 2;  // tile rows per slab (smaller slabs when 8 waves share the LDS)
+    constexpr int HROWS = HT * 32;                       // slab rows
     constexpr int ROWB = NT * 64 + 16;                   // slab row pitch in bytes (pad: bank spread)
     constexpr int CPR = NT * 4;                          // 16-B chunks per slab row
     static_assert(NW * HROWS * ROWB <= (2 * A_SLOTS + 2 * B_CHUNKS) * 16, "epilogue slab fits the pipeline LDS");
@@ -324,9 +324,13 @@ __global__ __launch_bounds__(64 * WM * WN, (STRIDE == 1 ? 3 : 2)) void conv_igem
       }
       const int co = ct * TN + wn * NT * 32 + lane * 8;
       if (lane < CPR && co < p.Cout) {
-        const int part = (ty * p.tiles_x + tx) * WM + wm;
-        float* dst = p.gn_part + (((size_t)b * p.gn_nparts + part) * (p.Cout / 4) + co / 4) * 2;
-        dst[0] = gs0; dst[1] = gq0; dst[2] = gs1; dst[3] = gq1;
+        // parts live on the 8-row x 32-col grid whatever the tile: (8-row block, column tile, wave row within the block)
+        const int row0 = oy0 + wm * MT;
+        const int part = ((row0 / 8) * p.tiles_x + tx) * 2 + ((row0 / 4) & 1);
+        if (part < p.gn_nparts) {
+          float* dst = p.gn_part + (((size_t)b * p.gn_nparts + part) * (p.Cout / 4) + co / 4) * 2;
+          dst[0] = gs0; dst[1] = gq0; dst[2] = gs1; dst[3] = gq1;
+        }
       }
     }
     return;
@@ -430,6 +434,10 @@ __global__ __launch_bounds__(256) void gn_part_reduce_kernel(const float* __rest
   }
 }
 
+#ifndef CONV_TILE16
+#define CONV_TILE16 0
+#endif
+
 struct Variant {
   int tn, ksteps;
 };
@@ -450,7 +458,7 @@ int launch(const ConvParams& p_in, hipStream_t stream) {
   const long long nb = (long long)p.B * p.tiles_x * p.tiles_y * p.co_tiles;
   if (nb > 0x7fffffffLL) return GLARE_ERR_INVALID;
   p.n_blocks = (int)nb;
-  p.gn_nparts = p.tiles_x * p.tiles_y * WM;
+  p.gn_nparts = p.tiles_x * cdiv(p.OH, 8) * 2;  // the 8 x 32 grid, 2 wave rows (4 rows each) per block
   if (p.gn_part && !(p.fast_epilogue && p.Cout % 32 == 0)) return GLARE_ERR_UNSUPPORTED;
   const size_t lds = (size_t)(2 * (((KSTEPS * 2 * G::NPOS + 63) / 64) * 64) + 2 * KS * KSTEPS * 2 * TN) * 16;
   auto kern = conv_igemm_kernel<KS, STRIDE, MT, NT, WM, WN, KSTEPS>;
@@ -537,6 +545,7 @@ extern "C" int glare_conv2d_bf16(const glare_conv_desc* d, glare_stream_t stream
   do {                                                                                    \
     constexpr int KST = (KS_ == 1) ? 2 : 1;                                               \
     if (v.tn == 128) {                                                                    \
+      if (KS_ == 3 && ST_ == 1 && CONV_TILE16) return launch<KS_, ST_, 4, 2, 4, 2, KST>(p, stream); /* 16 x 32 px, 8 waves */ \
       /* a 12 x 32 px tile on 6 waves (fewer weight DMAs per MFMA) measured 20-25 % SLOWER: 6 waves map 2,2,1,1 */ \
       /* onto the 4 SIMDs and the doubly-loaded SIMDs set the barrier pace; keep wave counts multiples of 4 */      \
       return launch<KS_, ST_, 4, 2, 2, 2, KST>(p, stream);                                \

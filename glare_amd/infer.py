@@ -1,0 +1,70 @@
+"""Dataset-style inference driver: the GLARE counterpart of code/infer_dataset_lol.py:113-163 on the HIP
+path, data-parallel over the GPUs of one node.
+
+    python -m glare_amd.infer --images 32                      # 1 GPU, synthetic 400x600 pairs
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m glare_amd.infer --images 32
+
+Per image, exactly the reference's harness steps (glare_amd/harness.py): reflect-pad, /255, log -> network ->
+crop, clamp, GT-mean gain, PSNR.  Unlike the reference's one-image-per-iteration loop (one H2D + one D2H +
+a full host sync per image), images are batched (default 8) and each rank enhances its own contiguous slice;
+the only collective is the final gather of the per-image PSNRs to rank 0 (RCCL).
+There are no datasets or checkpoints offline: inputs are synthetic LOL-shaped pairs, weights name-seeded."""
+import argparse
+import json
+
+import numpy as np
+import torch
+
+from . import harness, parallel
+from . import modules as M
+from .synthetic import seeded_init_, synthetic_gt, synthetic_lowlight
+
+
+def enhance_batch(netG, net_vq, imgs_u8, device):
+    """uint8 [n,H,W,3] -> list of float [H,W,3] network outputs (before the GT gain), via the fused NHWC graph."""
+    lr = harness.preprocess_batch(imgs_u8).to(device)
+    with torch.no_grad():
+        out = netG.reverse_flow_nhwc(net_vq, lr)["out"]
+    return out
+
+
+def run(n_images, batch=8, h=400, w=600, seed=1234):
+    rank, world, device = parallel.init_from_env()
+    assert device.type == "cuda", "glare_amd.infer needs an MI355X: the HIP kernels are the only implementation"
+    netG = seeded_init_(M.VQLLFLOWDeformable().eval(), 0).to(device)
+    net_vq = seeded_init_(M.VQModel().eval(), 1).to(device)
+    lows = synthetic_lowlight(n_images, h, w, seed=seed)
+    gts = synthetic_gt(n_images, h, w, seed=seed + 1)
+
+    def psnr_slice(lo, hi):
+        out = enhance_batch(netG, net_vq, lows[lo:hi], device).cpu()
+        vals = []
+        for i in range(hi - lo):
+            restored = harness.postprocess(out[i:i + 1], h, gts[lo + i])
+            vals.append(harness.psnr(gts[lo + i] / 255.0, restored))
+        return torch.tensor(vals, dtype=torch.float64, device=device).view(-1, 1)
+
+    local = parallel.run_sharded(n_images, psnr_slice, rank, world, batch=batch)
+    if local is None:
+        local = torch.zeros(0, 1, dtype=torch.float64, device=device)
+    full = parallel.gather_results(local, n_images, rank, world)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    return None if full is None else full.view(-1).cpu().numpy()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--images", type=int, default=16)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--height", type=int, default=400)
+    ap.add_argument("--width", type=int, default=600)
+    args = ap.parse_args()
+    psnrs = run(args.images, args.batch, args.height, args.width)
+    if psnrs is not None:
+        print(json.dumps({"images": int(len(psnrs)), "mean_psnr": float(np.mean(psnrs)), "psnr": [round(float(v), 4) for v in psnrs]}))
+
+
+if __name__ == "__main__":
+    main()

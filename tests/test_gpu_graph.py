@@ -153,3 +153,53 @@ def test_stage2_normal_flow_and_nll(nets):
     # invertibility on the HIP path itself: decode(encode(x)) == x
     back = p2.flowUpsamplerNet.decode_nhwc(z_p, nhwc(enc["cond_feat"]))
     assert rel(nchw(back), gt) < 2e-2
+
+
+def test_inference_driver_matches_oracle_psnr():
+    """glare_amd.infer (harness + sharding + fused graph) on 3 small images vs the oracle run one image at a
+    time (the reference's B = 1 loop): per-image PSNR within 0.05 dB."""
+    from glare_amd import infer
+
+    h, w = 20, 36
+    psnrs = infer.run(3, batch=2, h=h, w=w, seed=77)
+    og = seeded_init_(O.VQLLFLOWDeformable().eval(), 0)
+    ov = seeded_init_(O.VQModel().eval(), 1)
+    lows, gts = synthetic_lowlight(3, h, w, seed=77), synthetic_gt(3, h, w, seed=78)
+    for i in range(3):
+        with torch.no_grad():
+            out, _ = og(ov, O.preprocess(lows[i]))
+        ref = O.psnr(gts[i] / 255, O.postprocess(out, h, gts[i]))
+        assert abs(psnrs[i] - ref) <= 0.05, (i, psnrs[i], ref)
+
+
+def test_full_size_attention_and_dcn_properties():
+    """BASELINE shapes (N = 105*155 tokens; 420x620 warp): size-independent properties.
+    attention: V = const  =>  out = const (softmax rows sum to 1) and permuting the keys does not change the
+    output; DCN: zero offsets / unit mask => equals the MFMA conv of the same weights."""
+    g = torch.Generator().manual_seed(0)
+    N, C = 105 * 155, 512
+    qk = (torch.randn(1, N, 2 * C, generator=g) * 0.2).to(torch.bfloat16).cuda()
+    npad = (N + 63) // 64 * 64
+    vt = torch.zeros(1, C, npad, dtype=torch.bfloat16, device="cuda")
+    vt[:, :, :N] = 0.75
+    out = ops.attention_d512(qk, qk[..., C:], vt, N, ldq=2 * C, ldk=2 * C)
+    assert torch.allclose(out.float(), torch.full_like(out.float(), 0.75), atol=2e-2)
+    v = torch.randn(1, N, C, generator=g).to(torch.bfloat16).cuda()
+    vt[:, :, :N] = v.transpose(1, 2)
+    ref = ops.attention_d512(qk, qk[..., C:], vt, N, ldq=2 * C, ldk=2 * C)
+    perm = torch.randperm(N, generator=g).cuda()
+    kp = qk[:, perm, C:].contiguous()
+    vt2 = torch.zeros_like(vt)
+    vt2[:, :, :N] = v[:, perm].transpose(1, 2)
+    got = ops.attention_d512(qk, kp, vt2, N, ldq=2 * C, ldk=C)
+    assert rel(got, ref) < 2e-2
+    # DCN at the full-resolution warp shape, B = 1
+    x = torch.randn(1, 420, 620, 128, generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randn(128, 128, 3, 3, generator=g) * 0.03).cuda()
+    b = (torch.randn(128, generator=g) * 0.1).cuda()
+    plane = (420 * 620 + 63) // 64 * 64
+    om = torch.zeros(1, 108, plane, device="cuda")
+    om[:, 72:] = 30.0  # mask logits -> sigmoid = 1
+    got = ops.mdcn_forward_nhwc(x, om, ops.PackedDcn(w, b, 4))
+    ref = ops.conv2d(x, ops.PackedConv(w, b), out_mode=ops.OUT_NHWC_F32)
+    assert rel(got, ref) < 5e-3
