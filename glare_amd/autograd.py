@@ -1,0 +1,178 @@
+"""torch.autograd.Function wrappers: HIP forward + HIP backward for the operators of the training step
+(SURVEY.md section 8 rows a12 / a13).  torch's autograd engine is only the tape: every tensor-sized computation
+in forward() and backward() below is a kernel of libglare_hip.so; torch ops touch filter-sized tensors only
+(flip / transpose / pad of weights before packing).
+
+The reference gets these gradients from `loss.backward()` over cuDNN / ATen (LLFlow_model.py:231-236,
+VQLLFLOWD_model.py:226-229); activations here are NHWC bf16, parameters and their gradients fp32.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from . import train_ops as T
+
+
+def _rup(a, b):
+    return (a + b - 1) // b * b
+
+
+def _grad_bf16(g, y, act, cout):
+    """Upstream gradient -> dense bf16 NHWC with a channel pitch that is a multiple of 8 (extra channels zero),
+    after the fused activation's derivative."""
+    if act != "none":
+        g = g.contiguous().clone()
+        T.act_backward_(g, y, act)
+    g = g.contiguous()
+    cp = _rup(cout, 8)
+    if g.dtype == torch.float32:
+        return T.cast_to_bf16(g, pitch=cp)
+    if cp != cout:
+        return T.cast_to_bf16(T.cast_to_f32(g), pitch=cp)
+    return g
+
+
+def _data_grad(g16, weight, cout, stride, upsample, out_f32=False):
+    """dx of a conv as a stride-1 conv of the (dilated) gradient with the flipped, transposed filter."""
+    cp = g16.shape[-1]
+    wt = weight.detach().float().transpose(0, 1)
+    if weight.shape[-1] == 3:
+        wt = wt.flip(2, 3)
+    if cp != cout:
+        wt = F.pad(wt, (0, 0, 0, 0, 0, cp - cout))
+    pc = ops.PackedConv(wt.contiguous())
+    mode = ops.OUT_NHWC_F32 if out_f32 else ops.OUT_NHWC_BF16
+    if stride == 2:
+        return ops.conv2d(T.dilate2(g16), pc, out_mode=mode)
+    dx = ops.conv2d(g16, pc, out_mode=mode)
+    return T.pool2_sum(dx) if upsample else dx
+
+
+class Conv2dFn(torch.autograd.Function):
+    """y = act(conv(x [, x2]) + bias) [+ residual]; x bf16 NHWC; weight OIHW fp32 (3x3 pad 1 / 1x1; stride 2 with the
+    (0,1,0,1) padding; optional fused nearest x2 upsample of the input)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, x2, stride, upsample, act, out_f32):
+        pc = ops.PackedConv(weight, bias)
+        y = ops.conv2d(x, pc, x2=x2, stride=stride, upsample=upsample, act=act, residual=residual,
+                       out_mode=ops.OUT_NHWC_F32 if out_f32 else ops.OUT_NHWC_BF16)
+        ctx.cfg = (stride, upsample, act, bias is not None, residual is not None, x2 is not None)
+        ctx.save_for_backward(x, weight, y if act != "none" else None, x2)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        stride, upsample, act, has_bias, has_res, has_x2 = ctx.cfg
+        x, weight, y, x2 = ctx.saved_tensors
+        cout, cin_tot, k, _ = weight.shape
+        assert not (has_res and act != "none")
+        g16 = _grad_bf16(gy, y, act, cout)
+        dres = g16 if (has_res and ctx.needs_input_grad[3]) else None
+        dw = db = dx = dx2 = None
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            kk = k * k
+            c1 = x.shape[-1]
+
+            def build(ldp, ones_row):
+                col = T.im2col_t(x, k, stride, upsample=upsample, ldp=ldp, ones_row=ones_row, rows=cin_tot * kk + 1)
+                if has_x2:
+                    T.im2col_t(x2, k, stride, upsample=upsample, ldp=ldp, col=col, row_base=c1 * kk)
+                return col
+
+            dwb = T.conv_weight_grad(build, g16, cout, cin_tot * kk)
+            dw = dwb[:, :-1].reshape(cout, cin_tot, k, k)
+            db = dwb[:, -1].contiguous() if has_bias else None
+        if ctx.needs_input_grad[0] or (has_x2 and ctx.needs_input_grad[4]):
+            dxa = _data_grad(g16, weight, cout, stride, upsample)
+            if has_x2:
+                c1 = x.shape[-1]
+                dx, dx2 = dxa[..., :c1].contiguous(), dxa[..., c1:].contiguous()
+            else:
+                dx = dxa
+        return dx, dw, db, dres, dx2, None, None, None, None
+
+
+def conv2d(x, weight, bias=None, residual=None, x2=None, stride=1, upsample=False, act="none", out_f32=False):
+    return Conv2dFn.apply(x, weight, bias, residual, x2, stride, upsample, act, out_f32)
+
+
+class SmallConv2dFn(torch.autograd.Function):
+    """Convs whose input has <= 4 channels (conv_in on the image, cond / color convs, quant convs): x fp32 read through
+    element strides (NCHW image or NHWC latent)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, layout, act, out_f32):
+        if layout == "nchw":
+            B, C, H, W = x.shape
+            strides = (C * H * W, H * W, W, 1)
+        else:
+            B, H, W, C = x.shape
+            strides = (H * W * C, 1, W * C, C)
+        y = ops.conv2d_smallcin(x, strides, (B, H, W), weight, bias, act=act, out_f32=out_f32)
+        ctx.cfg = (layout, act, strides, (B, H, W), bias is not None)
+        ctx.save_for_backward(x, weight, y if act != "none" else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        layout, act, strides, bhw, has_bias = ctx.cfg
+        x, weight, y = ctx.saved_tensors
+        cout, cin, k, _ = weight.shape
+        g16 = _grad_bf16(gy, y, act, cout)
+        dw = db = dx = None
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            dwb = T.conv_weight_grad(lambda ldp, ones_row: T.im2col_t_f32(x, strides, bhw, cin, k, k // 2, ldp=ldp, ones_row=ones_row),
+                                     g16, cout, cin * k * k)
+            dw = dwb[:, :-1].reshape(cout, cin, k, k)
+            db = dwb[:, -1].contiguous() if has_bias else None
+        if ctx.needs_input_grad[0]:
+            assert layout == "nhwc", "the image needs no gradient"
+            dx = _data_grad(g16, weight, cout, 1, False, out_f32=True)
+        return dx, dw, db, None, None, None
+
+
+def conv2d_small(x, weight, bias=None, layout="nhwc", act="none", out_f32=False):
+    return SmallConv2dFn.apply(x, weight, bias, layout, act, out_f32)
+
+
+class GroupNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, swish, eps):
+        y, stats = T.groupnorm_forward(x, gamma.detach().float(), beta.detach().float(), swish, eps)
+        ctx.cfg = (swish, eps)
+        ctx.save_for_backward(x, stats, gamma, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        swish, eps = ctx.cfg
+        x, stats, gamma, beta = ctx.saved_tensors
+        dx, dgamma, dbeta = T.groupnorm_backward(x, gy.contiguous(), stats, gamma.detach().float(), beta.detach().float(), swish, eps)
+        return dx, dgamma, dbeta, None, None
+
+
+def groupnorm(x, gamma, beta, swish=True, eps=1e-6):
+    return GroupNormFn.apply(x, gamma, beta, swish, eps)
+
+
+class AttentionFn(torch.autograd.Function):
+    """softmax(q k^T) v with q already carrying scale*log2(e) (base-2 logits): q, k, v bf16 [B, N, 512]."""
+
+    @staticmethod
+    def forward(ctx, q, k, v):
+        B, N, d = q.shape
+        assert d == 512 and q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
+        vt = T.transpose(v, _rup(N, 64))
+        o = ops.attention_d512(q, k, vt, N)
+        ctx.save_for_backward(q, k, v, o)
+        return o
+
+    @staticmethod
+    def backward(ctx, go):
+        q, k, v, o = ctx.saved_tensors
+        return T.attention_backward(q, k, v, o, go.contiguous())
+
+
+def attention(q, k, v):
+    return AttentionFn.apply(q, k, v)

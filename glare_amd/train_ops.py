@@ -1,0 +1,266 @@
+"""ctypes wrappers of the training-step kernels (backward of the hot path: rows a12 / a13 of SURVEY.md section 8).
+
+Same rules as ops.py: HIP only, no fallback, CPU tensors raise NotImplementedError.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, require_cuda, stream_handle
+
+_i = ctypes.c_int
+_ll = ctypes.c_longlong
+_f = ctypes.c_float
+
+
+def gemm_nt(a, b, out=None, alpha=1.0, out_dtype=torch.float32, accumulate=False, M=None, N=None, K=None):
+    """C[.., m, n] = alpha * sum_k a[.., m, k] * b[.., n, k]  (+ C).  a, b: bf16, 2-D or 3-D (batched), last dim
+    contiguous; rows may be strided (views of wider buffers are fine)."""
+    require_cuda(a, b, out)
+    assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.stride(-1) == 1 and b.stride(-1) == 1
+    if a.dim() == 2:
+        a, b = a.unsqueeze(0), b.unsqueeze(0)
+        squeeze = True
+    else:
+        squeeze = False
+    batch = a.shape[0]
+    M = a.shape[1] if M is None else M
+    N = b.shape[1] if N is None else N
+    K = a.shape[2] if K is None else K
+    if out is None:
+        out = torch.empty(batch, M, N, dtype=out_dtype, device=a.device)
+        if accumulate:
+            out.zero_()
+    o3 = out if out.dim() == 3 else out.unsqueeze(0)
+    assert o3.stride(-1) == 1 and o3.dtype in (torch.float32, torch.bfloat16)
+    check(_lib.lib().glare_gemm_nt_bf16(ptr(a), ptr(b), ptr(o3), _i(M), _i(N), _i(K), _ll(a.stride(1)), _ll(b.stride(1)),
+                                        _ll(o3.stride(1)), _i(batch), _ll(a.stride(0) if batch > 1 else 0),
+                                        _ll(b.stride(0) if batch > 1 else 0), _ll(o3.stride(0) if batch > 1 else 0),
+                                        _f(alpha), _i(int(o3.dtype == torch.bfloat16)), _i(int(accumulate)), stream_handle()),
+          "glare_gemm_nt_bf16")
+    return out[0] if squeeze and out.dim() == 3 else out
+
+
+def reduce_parts(parts, scale=1.0, out=None, accumulate=False):
+    """parts fp32 [S, ...] -> sum over S (deterministic)."""
+    require_cuda(parts, out)
+    assert parts.dtype == torch.float32 and parts.is_contiguous()
+    S = parts.shape[0]
+    n = parts[0].numel()
+    if out is None:
+        out = torch.empty(parts.shape[1:], dtype=torch.float32, device=parts.device)
+    check(_lib.lib().glare_reduce_parts_f32(ptr(parts), _i(S), _ll(n), _f(scale), ptr(out), _i(int(accumulate)), stream_handle()),
+          "glare_reduce_parts_f32")
+    return out
+
+
+_sz = ctypes.c_size_t
+
+
+def _rup(a, b):
+    return (a + b - 1) // b * b
+
+
+def transpose(x2d, ld_out=None, out=None):
+    """bf16 [.., R, C] (row stride arbitrary, last dim contiguous) -> [.., C, ld_out] with zero-filled tail columns."""
+    require_cuda(x2d, out)
+    assert x2d.dtype == torch.bfloat16 and x2d.stride(-1) == 1
+    x3 = x2d if x2d.dim() == 3 else x2d.unsqueeze(0)
+    batch, R, C = x3.shape
+    ld_out = _rup(R, 64) if ld_out is None else ld_out
+    if out is None:
+        out = torch.empty(batch, C, ld_out, dtype=torch.bfloat16, device=x2d.device)
+    o3 = out if out.dim() == 3 else out.unsqueeze(0)
+    check(_lib.lib().glare_transpose_bf16(ptr(x3), _ll(x3.stride(1)), _ll(x3.stride(0) if batch > 1 else 0), ptr(o3), _ll(o3.stride(1)),
+                                          _ll(o3.stride(0) if batch > 1 else 0), _ll(R), _i(C), _i(batch), stream_handle()),
+          "glare_transpose_bf16")
+    return out if x2d.dim() == 3 else o3[0]
+
+
+def im2col_t(x, ksize, stride=1, pad=None, upsample=False, cin=None, in_off=0, ldp=None, col=None, row_base=0, ones_row=-1,
+             rows=None):
+    """x bf16 NHWC [B,H,W,pitch] -> colT [rows, ldp] bf16 (row = c*k*k + tap), see include/glare_hip.h."""
+    require_cuda(x, col)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    B, H, W, pitch = x.shape
+    cin = pitch - in_off if cin is None else cin
+    pad = (1 if (ksize == 3 and stride == 1) else 0) if pad is None else pad
+    IH, IW = (2 * H, 2 * W) if upsample else (H, W)
+    OH, OW = ((IH + 1 - ksize) // 2 + 1, (IW + 1 - ksize) // 2 + 1) if stride == 2 else (IH + 2 * pad - ksize + 1, IW + 2 * pad - ksize + 1)
+    P = B * OH * OW
+    ldp = _rup(P, 64) if ldp is None else ldp
+    if col is None:
+        nrows = (cin * ksize * ksize + (1 if ones_row >= 0 else 0)) if rows is None else rows
+        col = torch.empty(nrows, ldp, dtype=torch.bfloat16, device=x.device)
+    check(_lib.lib().glare_im2col_t_bf16(ptr(x), _i(B), _i(H), _i(W), _i(pitch), _i(in_off), _i(cin), _i(ksize), _i(stride), _i(pad),
+                                         _i(int(upsample)), ptr(col), _ll(ldp), _i(row_base), _i(ones_row), stream_handle()),
+          "glare_im2col_t_bf16")
+    return col
+
+
+def im2col_t_f32(x, strides, shape_bhw, cin, ksize, pad, ldp=None, ones_row=-1):
+    require_cuda(x)
+    assert x.dtype == torch.float32
+    B, H, W = shape_bhw
+    P = B * H * W
+    ldp = _rup(P, 64) if ldp is None else ldp
+    col = torch.empty(cin * ksize * ksize + (1 if ones_row >= 0 else 0), ldp, dtype=torch.bfloat16, device=x.device)
+    sb, sc, sy, sx = strides
+    check(_lib.lib().glare_im2col_t_f32(ptr(x), _ll(sb), _ll(sc), _ll(sy), _ll(sx), _i(B), _i(H), _i(W), _i(cin), _i(ksize), _i(pad),
+                                        ptr(col), _ll(ldp), _i(0), _i(ones_row), stream_handle()), "glare_im2col_t_f32")
+    return col
+
+
+def dilate2(g):
+    require_cuda(g)
+    assert g.dtype == torch.bfloat16 and g.is_contiguous()
+    B, OH, OW, C = g.shape
+    out = torch.empty(B, 2 * OH, 2 * OW, C, dtype=torch.bfloat16, device=g.device)
+    check(_lib.lib().glare_dilate2_bf16(ptr(g), ptr(out), _i(B), _i(OH), _i(OW), _i(C), stream_handle()), "glare_dilate2_bf16")
+    return out
+
+
+def pool2_sum(g):
+    require_cuda(g)
+    assert g.dtype == torch.bfloat16 and g.is_contiguous()
+    B, H2, W2, C = g.shape
+    out = torch.empty(B, H2 // 2, W2 // 2, C, dtype=torch.bfloat16, device=g.device)
+    check(_lib.lib().glare_pool2_sum_bf16(ptr(g), ptr(out), _i(B), _i(H2 // 2), _i(W2 // 2), _i(C), stream_handle()),
+          "glare_pool2_sum_bf16")
+    return out
+
+
+def act_backward_(g, y, act, C=None, g_off=0, y_off=0):
+    """In place: g *= act'(y); g, y [.., pitch] bf16 or fp32."""
+    require_cuda(g, y)
+    from .ops import ACT
+    C = g.shape[-1] - g_off if C is None else C
+    pixels = g.numel() // g.shape[-1]
+    check(_lib.lib().glare_act_backward(ptr(g), _i(int(g.dtype == torch.float32)), _i(g.shape[-1]), _i(g_off), ptr(y),
+                                        _i(int(y.dtype == torch.float32)), _i(y.shape[-1]), _i(y_off), _ll(pixels), _i(C),
+                                        _i(ACT[act]), stream_handle()), "glare_act_backward")
+    return g
+
+
+def cast_to_bf16(x, pitch=None):
+    """fp32 [.., C] -> bf16 [.., pitch] (extra channels zero)."""
+    require_cuda(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    C = x.shape[-1]
+    pitch = C if pitch is None else pitch
+    out = (torch.zeros if pitch != C else torch.empty)(*x.shape[:-1], pitch, dtype=torch.bfloat16, device=x.device)
+    check(_lib.lib().glare_cast_f32_bf16(ptr(x), _i(C), _i(0), ptr(out), _i(pitch), _i(0), _ll(x.numel() // C), _i(C), stream_handle()),
+          "glare_cast_f32_bf16")
+    return out
+
+
+def cast_to_f32(x, C=None):
+    require_cuda(x)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    pitch = x.shape[-1]
+    C = pitch if C is None else C
+    out = torch.empty(*x.shape[:-1], C, dtype=torch.float32, device=x.device)
+    check(_lib.lib().glare_cast_bf16_f32(ptr(x), _i(pitch), _i(0), ptr(out), _i(C), _i(0), _ll(x.numel() // pitch), _i(C), stream_handle()),
+          "glare_cast_bf16_f32")
+    return out
+
+
+def groupnorm_forward(x, gamma, beta, swish=True, eps=1e-6):
+    """Training-mode GroupNorm: returns (y, stats) with stats = the [B][splits][32][2] block the backward consumes."""
+    require_cuda(x, gamma, beta)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    B, H, W, C = x.shape
+    lib = _lib.lib()
+    lib.glare_groupnorm_workspace_bytes.restype = _sz
+    nws = lib.glare_groupnorm_workspace_bytes(_i(B), _ll(H * W))
+    stats = torch.empty(nws // 4, dtype=torch.float32, device=x.device)
+    y = torch.empty_like(x)
+    check(lib.glare_groupnorm_swish_bf16(ptr(x), _i(C), _i(0), ptr(gamma), ptr(beta), ptr(y), _i(B), _ll(H * W), _i(C), _f(eps),
+                                         _i(int(swish)), ptr(stats), _sz(nws), stream_handle()), "glare_groupnorm_swish_bf16")
+    return y, stats.view(B, -1, 32, 2)
+
+
+def groupnorm_backward(x, dy, stats, gamma, beta, swish=True, eps=1e-6):
+    """-> (dx bf16, dgamma fp32 [C], dbeta fp32 [C])."""
+    require_cuda(x, dy, stats, gamma, beta)
+    assert x.dtype == dy.dtype == torch.bfloat16 and x.is_contiguous() and dy.is_contiguous()
+    B, H, W, C = x.shape
+    lib = _lib.lib()
+    lib.glare_groupnorm_backward_workspace_bytes.restype = _sz
+    nws = lib.glare_groupnorm_backward_workspace_bytes(_i(B), _ll(H * W), _i(C))
+    ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=x.device)
+    dx = torch.empty_like(x)
+    per_image = torch.empty(B, 2, C, dtype=torch.float32, device=x.device)
+    check(lib.glare_groupnorm_swish_backward_bf16(ptr(x), _i(C), _i(0), ptr(dy), ptr(stats), _i(stats.shape[1]), ptr(gamma), ptr(beta),
+                                                  ptr(dx), ptr(per_image), _i(B), _ll(H * W), _i(C), _f(eps), _i(int(swish)), ptr(ws),
+                                                  _sz(nws), stream_handle()), "glare_groupnorm_swish_backward_bf16")
+    s = reduce_parts(per_image)
+    return dx, s[1], s[0]
+
+
+def softmax2_rows(S, n, ldp=None):
+    require_cuda(S)
+    assert S.dtype == torch.float32 and S.dim() == 2 and S.stride(1) == 1
+    rows = S.shape[0]
+    ldp = _rup(n, 64) if ldp is None else ldp
+    P = torch.empty(rows, ldp, dtype=torch.bfloat16, device=S.device)
+    check(_lib.lib().glare_softmax2_rows_f32(ptr(S), _ll(S.stride(0)), ptr(P), _ll(ldp), _ll(rows), _i(n), stream_handle()),
+          "glare_softmax2_rows_f32")
+    return P
+
+
+def attention_ds(P, dP, dO, O, n, scale):
+    require_cuda(P, dP, dO, O)
+    rows, d = dO.shape
+    dS = torch.empty(rows, P.shape[1], dtype=torch.bfloat16, device=P.device)
+    check(_lib.lib().glare_attention_ds_bf16(ptr(P), _ll(P.stride(0)), ptr(dP), _ll(dP.stride(0)), ptr(dO), _i(dO.stride(0)), ptr(O),
+                                             _i(O.stride(0)), _i(d), ptr(dS), _ll(dS.stride(0)), _ll(rows), _i(n), _f(scale),
+                                             stream_handle()), "glare_attention_ds_bf16")
+    return dS
+
+
+def adam_step_(w, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+    require_cuda(w, grad, exp_avg, exp_avg_sq)
+    for t in (w, grad, exp_avg, exp_avg_sq):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    check(_lib.lib().glare_adam_step_f32(ptr(w), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), _ll(w.numel()), _f(lr), _f(betas[0]),
+                                         _f(betas[1]), _f(eps), _f(weight_decay), _i(step), _f(grad_scale), stream_handle()),
+          "glare_adam_step_f32")
+    return w
+
+
+# ---- composite backward passes ------------------------------------------------------------------------
+def conv_weight_grad(x_col_builder, g_bf16, cout, n_rows):
+    """dW|db = gO^T . colT^T by split-K NT GEMM.  x_col_builder(ldp, ones_row) -> colT [n_rows+1, ldp];
+    g_bf16: [B,OH,OW,pitch>=cout] bf16.  Returns fp32 [cout, n_rows+1] (last column = bias gradient)."""
+    P = g_bf16.numel() // g_bf16.shape[-1]
+    tiles = ((cout + 255) // 256) * ((n_rows + 1 + 127) // 128)
+    S = max(1, min((768 + tiles - 1) // tiles, P // 2048, 64))
+    ldp = _rup(P, 64 * S)
+    colT = x_col_builder(ldp, n_rows)
+    gT = transpose(g_bf16.view(P, g_bf16.shape[-1]), ld_out=ldp)[:cout]
+    ks = ldp // S
+    a3 = gT.as_strided((S, cout, ks), (ks, ldp, 1))
+    b3 = colT.as_strided((S, n_rows + 1, ks), (ks, ldp, 1))
+    parts = gemm_nt(a3, b3)
+    return reduce_parts(parts) if S > 1 else parts[0]
+
+
+def attention_backward(q, k, v, o, do, ln2_scale=0.6931471805599453):
+    """q (pre-scaled so that q.k^T are base-2 logits), k, v, o, do: bf16 [B, N, 512] -> (dq, dk, dv) bf16.
+    Materialised form, one sample at a time: N^2 scores live in HBM (82-164 MB at the training crops)."""
+    B, N, d = q.shape
+    npad = _rup(N, 64)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    for b in range(B):
+        S = gemm_nt(q[b], k[b])                         # [N, N] fp32 base-2 logits
+        P = softmax2_rows(S, N, npad)                   # [N, npad] bf16
+        dP = gemm_nt(do[b], v[b], out=S)                # reuse the fp32 buffer
+        dS = attention_ds(P, dP, do[b], o[b], N, ln2_scale)
+        kT, qT, doT = transpose(k[b], npad), transpose(q[b], npad), transpose(do[b], npad)   # [d, npad]
+        PT, dST = transpose(P[:, :N], npad), transpose(dS[:, :N], npad)                      # [N, npad]
+        gemm_nt(dS, kT, out=dq[b], K=npad)
+        gemm_nt(dST, qT, out=dk[b], K=npad)
+        gemm_nt(PT, doT, out=dv[b], K=npad)
+    return dq, dk, dv

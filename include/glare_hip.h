@@ -248,6 +248,75 @@ int glare_flow_nll_reduce_f32(const float* z_nhwc3, const float* mean_nhwc3, con
                               int n_partial_rows, int B, long long pixels_per_sample, double* out_2_per_sample,
                               glare_stream_t stream);
 
+/* ---- training step: contractions over the pixel / token axis (rows a12, a13) --------------------------------
+ * Batched NT GEMM on bf16 MFMA, fp32 accumulate:  C[b][m][n] = alpha * sum_k A[b][m][k] * B[b][n][k]  (+ C[b][m][n]
+ * when accumulate != 0).  A, B bf16 with K contiguous (lda, ldb, strides in ELEMENTS, multiples of 8; K % 32 == 0;
+ * rows beyond M / N are not read); C fp32 or bf16 (out_bf16).  Split-K = a batch whose strideA/strideB is the K slice
+ * and whose C is a partial per slice, summed by glare_reduce_parts_f32.  Replaces the cuDNN weight-gradient and the
+ * autograd of the two torch.bmm in AttnBlock (encoder_decoder.py:176-188) behind `loss.backward()`
+ * (LLFlow_model.py:231-236, VQLLFLOWD_model.py:226-229). */
+int glare_gemm_nt_bf16(const void* A, const void* B, void* C, int M, int N, int K, long long lda, long long ldb,
+                       long long ldc, int batch, long long strideA, long long strideB, long long strideC, float alpha,
+                       int out_bf16, int accumulate, glare_stream_t stream);
+/* out[i] = scale * sum_s parts[s][i] (+ out[i]) -- deterministic second level of split reductions */
+int glare_reduce_parts_f32(const float* parts, int n_parts, long long n, float scale, float* out, int accumulate,
+                           glare_stream_t stream);
+
+/* K-contiguous operand builders for glare_gemm_nt_bf16.
+ * glare_im2col_t_bf16: colT[row_base + c*k*k + tap][p] = x[b, oy*stride+ty-pad, ox*stride+tx-pad, c] (0 outside), p the
+ *   flattened output pixel (b, oy, ox); x bf16 NHWC [B][H][W][pitch], channels [off, off+Ci), optionally seen through
+ *   the nearest x2 upsample; stride 2 uses Downsample's (0,1,0,1) padding (encoder_decoder.py:71-74, pass pad = 0).
+ *   Columns [P, ldp) are zero-filled (ldp % 64 == 0); ones_row >= 0 additionally writes a row of ones (p < P), which
+ *   turns the weight-gradient GEMM's extra column into the bias gradient.  The weight gradient of a k x k conv is then
+ *   dW[co][ci*k*k + tap] = gemm_nt(gO^T [Co][P], colT) -- the layout of an OIHW filter (cuDNN wgrad in the reference).
+ * glare_im2col_t_f32: the same matrix from an fp32 tensor addressed by element strides (stride 1, symmetric pad).
+ * glare_transpose_bf16: out[b][c][r] = in[b][r][c], columns [rows, ld_out) zero-filled (ld_out % 64 == 0). */
+int glare_im2col_t_bf16(const void* x_nhwc, int B, int H, int W, int pitch, int off, int Ci, int ksize, int stride, int pad,
+                        int upsample, void* colT, long long ldp, int row_base, int ones_row, glare_stream_t stream);
+int glare_im2col_t_f32(const float* x, long long stride_b, long long stride_c, long long stride_y, long long stride_x, int B,
+                       int H, int W, int Ci, int ksize, int pad, void* colT, long long ldp, int row_base, int ones_row,
+                       glare_stream_t stream);
+int glare_transpose_bf16(const void* in, long long ld_in, long long batch_stride_in, void* out, long long ld_out,
+                         long long batch_stride_out, long long rows, int cols, int batch, glare_stream_t stream);
+
+/* Data gradients are stride-1 convolutions (glare_conv2d_bf16 with the flipped, transposed filter) after:
+ * glare_dilate2_bf16: out[B][2OH][2OW][C], out[b][2oy+1][2ox+1] = g[b][oy][ox], 0 elsewhere (Downsample backward);
+ * glare_pool2_sum_bf16: out[B][H][W][C] = 2x2 block sums of g[B][2H][2W][C] (Upsample backward, encoder_decoder.py:50).
+ * glare_act_backward: g *= act'(y) in place for the activation the forward conv fused (GLARE_ACT_RELU / _SIGMOID). */
+int glare_dilate2_bf16(const void* g, void* out, int B, int OH, int OW, int C, glare_stream_t stream);
+int glare_pool2_sum_bf16(const void* g, void* out, int B, int H, int W, int C, glare_stream_t stream);
+int glare_act_backward(void* g, int g_is_f32, int g_pitch, int g_off, const void* y, int y_is_f32, int y_pitch, int y_off,
+                       long long pixels, int C, int act, glare_stream_t stream);
+int glare_cast_f32_bf16(const float* in, int in_pitch, int in_off, void* out, int out_pitch, int out_off, long long pixels,
+                        int C, glare_stream_t stream);
+int glare_cast_bf16_f32(const void* in, int in_pitch, int in_off, float* out, int out_pitch, int out_off, long long pixels,
+                        int C, glare_stream_t stream);
+
+/* Backward of glare_groupnorm_swish_bf16 (autograd of Normalize()+nonlinearity(), encoder_decoder.py:29-35).
+ * stats: the forward's statistics block [B][stat_splits][32][2]; dy, dx dense bf16 NHWC [B][HW][C];
+ * dgamma_dbeta_per_image: fp32 [B][2][C] = per-image (dbeta, dgamma) contributions, summed over B by the caller
+ * (glare_reduce_parts_f32) so the result is deterministic. */
+size_t glare_groupnorm_backward_workspace_bytes(int B, long long HW, int C);
+int glare_groupnorm_swish_backward_bf16(const void* x, int in_pitch, int in_off, const void* dy, const float* stats,
+                                        int stat_splits, const float* gamma, const float* beta, void* dx,
+                                        float* dgamma_dbeta_per_image, int B, long long HW, int C, float eps, int swish,
+                                        void* workspace, size_t workspace_bytes, glare_stream_t stream);
+
+/* Attention backward in materialised form (training crops: N = 6400 / 4096 tokens), all contractions through
+ * glare_gemm_nt_bf16: P = softmax2(q' k^T) recomputed by glare_softmax2_rows_f32 (base-2 logits, as the forward
+ * kernel), dP = dO v^T, dS = scale * P o (dP - rowsum(dO o O)) by glare_attention_ds_bf16, then dq' = dS k,
+ * dk = dS^T q', dv = P^T dO. */
+int glare_softmax2_rows_f32(const float* S, long long lds, void* P_bf16, long long ldp, long long rows, int n,
+                            glare_stream_t stream);
+int glare_attention_ds_bf16(const void* P, long long ldp, const float* dP, long long lddp, const void* dO, int ld_do,
+                            const void* O, int ld_o, int d, void* dS, long long ldds, long long rows, int n, float scale,
+                            glare_stream_t stream);
+
+/* torch.optim.Adam step (LLFlow_model.py:110-118, VQLLFLOWD_model.py:112-119) on flat fp32 buffers; `step` is the
+ * 1-based step count, grad_scale multiplies the gradient first (1/world for the data-parallel mean). */
+int glare_adam_step_f32(float* w, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, int step, float grad_scale, glare_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

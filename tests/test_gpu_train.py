@@ -1,0 +1,219 @@
+"""Backward kernels of the training step against torch fp32 autograd
+references evaluated on the CPU (the oracle of a floating-point kernel is the plain fp32 op)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda", 0)
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("M,N,K,batch", [(256, 128, 64, 1), (300, 200, 96, 2), (64, 1152, 2048, 1), (1, 1, 32, 3), (513, 129, 32, 1)])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+def test_gemm_nt(M, N, K, batch, out_dtype):
+    from glare_amd import train_ops as T
+
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a = torch.randn(batch, M, K, generator=g).to(torch.bfloat16)
+    b = torch.randn(batch, N, K, generator=g).to(torch.bfloat16)
+    ref = torch.einsum("bmk,bnk->bmn", a.double(), b.double()) * 0.5
+    c = T.gemm_nt(a.to(_dev()), b.to(_dev()), alpha=0.5, out_dtype=out_dtype)
+    tol = 1e-5 if out_dtype == torch.float32 else 4e-3   # bf16 output rounding 2^-9
+    assert _rel(c, ref) < tol
+    c2 = T.gemm_nt(a.to(_dev()), b.to(_dev()), out=c.clone(), alpha=0.5, accumulate=True)
+    assert _rel(c2, 2 * ref) < (1e-5 if out_dtype == torch.float32 else 8e-3)
+
+
+def test_gemm_nt_strided_views_and_splitk():
+    from glare_amd import train_ops as T
+
+    g = torch.Generator().manual_seed(3)
+    M, N, K, S = 96, 80, 1024, 8
+    big_a = torch.randn(M, K + 64, generator=g).to(torch.bfloat16).to(_dev())
+    big_b = torch.randn(N, K + 32, generator=g).to(torch.bfloat16).to(_dev())
+    a, b = big_a[:, 32:32 + K], big_b[:, :K]          # row-strided views, 16-B aligned starts
+    ref = a.double().cpu() @ b.double().cpu().T
+    assert _rel(T.gemm_nt(a, b), ref) < 1e-5
+    # split-K as a batch over K slices + deterministic reduce
+    ks = K // S
+    a3 = a.as_strided((S, M, ks), (ks, a.stride(0), 1))
+    b3 = b.as_strided((S, N, ks), (ks, b.stride(0), 1))
+    parts = T.gemm_nt(a3, b3)
+    assert _rel(T.reduce_parts(parts), ref) < 1e-5
+
+
+def test_gemm_nt_rejects_bad_shapes():
+    from glare_amd import _lib, train_ops as T
+
+    a = torch.zeros(4, 40, dtype=torch.bfloat16, device=_dev())
+    with pytest.raises(_lib.GlareError):
+        T.gemm_nt(a, a)   # K % 32 != 0
+    with pytest.raises(NotImplementedError):
+        T.gemm_nt(a.cpu(), a.cpu())
+
+
+# ---- autograd Functions vs torch fp32 autograd on the CPU ------------------------------------------------
+def _nhwc16(t):  # NCHW fp32 (cpu) -> NHWC bf16 (gpu)
+    return t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(_dev())
+
+
+def _nchw(t):
+    return t.float().cpu().permute(0, 3, 1, 2)
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,ups,act,res,bias", [
+    (64, 128, 3, 1, False, "none", False, True), (128, 64, 1, 1, False, "none", True, True), (64, 64, 3, 2, False, "none", False, True),
+    (32, 64, 3, 1, True, "none", False, True), (64, 64, 3, 1, False, "relu", False, True), (64, 4, 3, 1, False, "none", False, False),
+    (64, 8, 3, 1, False, "sigmoid", False, True)])
+def test_conv_autograd(cin, cout, k, stride, ups, act, res, bias):
+    import torch.nn.functional as F
+
+    from glare_amd import autograd as A
+
+    g = torch.Generator().manual_seed(cin + cout + k)
+    B, H, W = 2, 20, 24
+    x = _bf(torch.randn(B, cin, H, W, generator=g))
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    b = torch.randn(cout, generator=g) if bias else None
+    xr = x.clone().requires_grad_(True)
+    wr = _bf(w).clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    xi = F.interpolate(xr, scale_factor=2.0, mode="nearest") if ups else xr
+    if stride == 2:
+        yr = F.conv2d(F.pad(xi, (0, 1, 0, 1)), wr, br, stride=2)
+    else:
+        yr = F.conv2d(xi, wr, br, padding=k // 2)
+    yr = {"none": lambda t: t, "relu": torch.relu, "sigmoid": torch.sigmoid}[act](yr)
+    r = _bf(torch.randn(yr.shape, generator=g)) if res else None
+    rr = r.clone().requires_grad_(True) if res else None
+    if res:
+        yr = yr + rr
+    gy = _bf(torch.randn(yr.shape, generator=g))
+    yr.backward(gy)
+
+    xd = _nhwc16(x).requires_grad_(True)
+    wd = w.to(_dev()).requires_grad_(True)
+    bd = b.to(_dev()).requires_grad_(True) if bias else None
+    rd = _nhwc16(r).requires_grad_(True) if res else None
+    out_f32 = cout < 8
+    y = A.conv2d(xd, wd, bd, residual=rd, stride=stride, upsample=ups, act=act, out_f32=out_f32)
+    assert _rel(_nchw(y), yr.detach()) < 1e-2
+    gyd = gy.permute(0, 2, 3, 1).contiguous().to(_dev())
+    y.backward(gyd if out_f32 else gyd.to(torch.bfloat16))
+    assert _rel(_nchw(xd.grad), xr.grad) < 1.5e-2
+    assert _rel(wd.grad, wr.grad) < 1.5e-2
+    if bias:
+        assert _rel(bd.grad, br.grad) < 1e-2
+    if res:
+        assert _rel(_nchw(rd.grad), rr.grad) < 1e-2
+
+
+def test_small_conv_autograd():
+    import torch.nn.functional as F
+
+    from glare_amd import autograd as A
+
+    g = torch.Generator().manual_seed(5)
+    B, H, W = 2, 12, 20
+    # conv_in on the NCHW image: weight/bias gradients only
+    x = torch.randn(B, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 3, 3, generator=g) * 0.2
+    b = torch.randn(64, generator=g)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(x, wr, br, padding=1)
+    gy = _bf(torch.randn(yr.shape, generator=g))
+    yr.backward(gy)
+    wd, bd = w.to(_dev()).requires_grad_(True), b.to(_dev()).requires_grad_(True)
+    y = A.conv2d_small(x.to(_dev()), wd, bd, layout="nchw")
+    y.backward(gy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(_dev()))
+    assert _rel(wd.grad, wr.grad) < 1e-2 and _rel(bd.grad, br.grad) < 1e-2
+    # sigmoid(conv 3->64) on an NHWC fp32 latent with a data gradient (ConditionEncoder.py:41-43,52-53)
+    z = torch.randn(B, 3, H, W, generator=g)
+    zr = z.clone().requires_grad_(True)
+    wr2 = w.clone().requires_grad_(True)
+    yr2 = torch.sigmoid(F.conv2d(zr, wr2, None, padding=1))
+    yr2.backward(gy)
+    zd = z.permute(0, 2, 3, 1).contiguous().to(_dev()).requires_grad_(True)
+    wd2 = w.to(_dev()).requires_grad_(True)
+    y2 = A.conv2d_small(zd, wd2, None, layout="nhwc", act="sigmoid")
+    y2.backward(gy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(_dev()))
+    assert _rel(zd.grad.cpu().permute(0, 3, 1, 2), zr.grad) < 1.5e-2
+    assert _rel(wd2.grad, wr2.grad) < 1.5e-2
+
+
+@pytest.mark.parametrize("C,swish", [(64, True), (128, False), (512, True)])
+def test_groupnorm_autograd(C, swish):
+    import torch.nn.functional as F
+
+    from glare_amd import autograd as A
+
+    g = torch.Generator().manual_seed(C)
+    B, H, W = 2, 18, 22
+    x = _bf(torch.randn(B, C, H, W, generator=g) * 1.5 + 0.3)
+    gamma, beta = torch.randn(C, generator=g) * 0.5 + 1.0, torch.randn(C, generator=g) * 0.2
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    yr = F.group_norm(xr, 32, gr, br, eps=1e-6)
+    if swish:
+        yr = yr * torch.sigmoid(yr)
+    gy = _bf(torch.randn(yr.shape, generator=g))
+    yr.backward(gy)
+    xd = _nhwc16(x).requires_grad_(True)
+    gd, bd = gamma.to(_dev()).requires_grad_(True), beta.to(_dev()).requires_grad_(True)
+    y = A.groupnorm(xd, gd, bd, swish=swish)
+    y.backward(_nhwc16(gy))
+    assert _rel(_nchw(y), yr.detach()) < 1e-2
+    assert _rel(_nchw(xd.grad), xr.grad) < 1.5e-2
+    assert _rel(gd.grad, gr.grad) < 1e-2 and _rel(bd.grad, br.grad) < 1e-2
+
+
+@pytest.mark.parametrize("N", [256, 330])
+def test_attention_autograd(N):
+    import math
+
+    from glare_amd import autograd as A
+
+    g = torch.Generator().manual_seed(N)
+    B, d = 2, 512
+    q, k, v = [_bf(torch.randn(B, N, d, generator=g) * s) for s in (1.0, 1.0, 1.0)]
+    sc = d ** -0.5
+    qr, kr, vr = [t.clone().requires_grad_(True) for t in (q, k, v)]
+    pr = torch.softmax(torch.einsum("bic,bjc->bij", qr, kr) * sc, dim=-1)
+    outr = torch.einsum("bij,bjc->bic", pr, vr)
+    go = _bf(torch.randn(outr.shape, generator=g))
+    outr.backward(go)
+    fold = sc * math.log2(math.e)
+    qd = (q * fold).to(torch.bfloat16).to(_dev()).requires_grad_(True)      # kernel convention: base-2 logits
+    kd, vd = [t.to(torch.bfloat16).to(_dev()).requires_grad_(True) for t in (k, v)]
+    o = A.attention(qd, kd, vd)
+    o.backward(go.to(torch.bfloat16).to(_dev()))
+    assert _rel(o, outr.detach()) < 1.5e-2
+    assert _rel(qd.grad.float().cpu() * fold, qr.grad) < 3e-2     # d/dq = fold * d/dq'
+    assert _rel(kd.grad, kr.grad) < 3e-2
+    assert _rel(vd.grad, vr.grad) < 2e-2
+
+
+def test_adam_matches_torch():
+    from glare_amd import train_ops as T
+
+    g = torch.Generator().manual_seed(9)
+    w = torch.randn(1000, generator=g)
+    p = torch.nn.Parameter(w.clone())
+    opt = torch.optim.Adam([p], lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    wd, m, v = w.to(_dev()), torch.zeros(1000, device=_dev()), torch.zeros(1000, device=_dev())
+    for step in range(1, 4):
+        gr = torch.randn(1000, generator=g)
+        p.grad = gr.clone()
+        opt.step()
+        T.adam_step_(wd, gr.to(_dev()), m, v, step, 1e-3)
+    assert torch.allclose(wd.cpu(), p.detach(), rtol=1e-6, atol=1e-7)
