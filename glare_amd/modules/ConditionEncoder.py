@@ -1,6 +1,7 @@
 """Conditional encoder (mirrors code/models/modules/ConditionEncoder.py:14-55)."""
 import torch.nn as nn
 
+from .. import autograd as A
 from .. import ops
 from ._base import HipModule, to_nchw
 from .encoder_decoder import Encoder
@@ -24,6 +25,13 @@ class ConEncoder1(HipModule):
         st = (H * W * C, 1, W * C, C)
         cond = ops.conv2d_smallcin(enc, st, (B, H, W), self.cond_conv[0].weight, self.cond_conv[0].bias, act="sigmoid")
         color = ops.conv2d_smallcin(enc, st, (B, H, W), self.color_conv.weight, self.color_conv.bias, out_f32=True)
+        return {"cond_feat": cond, "color_map": color, "mid_feat": feats}
+
+    def train_nhwc(self, x_nchw):
+        """forward_nhwc with a tape (stage-2 training, LLFlowVQGAN_arch.py:66)."""
+        enc, feats = self.encoder.train_nhwc(x_nchw)
+        cond = A.conv2d_small(enc, self.cond_conv[0].weight, self.cond_conv[0].bias, layout="nhwc", act="sigmoid")
+        color = A.conv2d_small(enc, self.color_conv.weight, self.color_conv.bias, layout="nhwc", out_f32=True)
         return {"cond_feat": cond, "color_map": color, "mid_feat": feats}
 
     def forward(self, x, mid_feat=False):

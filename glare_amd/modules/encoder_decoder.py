@@ -9,6 +9,7 @@ import math
 import torch
 import torch.nn as nn
 
+from .. import autograd as A
 from .. import ops
 from ._base import HipModule, packed_conv, to_nchw, to_nhwc
 
@@ -24,6 +25,16 @@ def gn_swish(x, norm, swish=True):
     return ops.groupnorm(x, norm.weight.detach().float(), norm.bias.detach().float(), swish=swish, eps=norm.eps)
 
 
+# Training mode (`train_nhwc` methods): the same graph through glare_amd.autograd, i.e. HIP forward + HIP backward
+# with parameters taken live (packed per call) -- what `loss.backward()` differentiates in the reference.
+def gn_swish_t(x, norm, swish=True):
+    return A.groupnorm(x, norm.weight, norm.bias, swish=swish, eps=norm.eps)
+
+
+def conv_t(x, conv, **kw):
+    return A.conv2d(x, conv.weight, conv.bias, **kw)
+
+
 class Upsample(HipModule):
     def __init__(self, in_channels, with_conv=True):
         super().__init__()
@@ -34,6 +45,9 @@ class Upsample(HipModule):
     def forward_nhwc(self, x, **kw):
         # nearest x2 fused in the loader; GroupNorm statistics of the output fused in the epilogue
         return ops.conv2d(x, packed_conv(self, self.conv), upsample=True, gn_stats=GN_FUSED and self.conv.out_channels % 128 == 0, **kw)
+
+    def train_nhwc(self, x):
+        return conv_t(x, self.conv, upsample=True)
 
     def forward(self, x):
         return to_nchw(self.forward_nhwc(to_nhwc(x)))
@@ -49,6 +63,9 @@ class Downsample(HipModule):
     def forward_nhwc(self, x):
         return ops.conv2d(x, packed_conv(self, self.conv), stride=2,  # pad (0,1,0,1) fused in the loader
                           gn_stats=GN_FUSED and self.conv.out_channels % 128 == 0)
+
+    def train_nhwc(self, x):
+        return conv_t(x, self.conv, stride=2)
 
     def forward(self, x):
         return to_nchw(self.forward_nhwc(to_nhwc(x)))
@@ -75,6 +92,12 @@ class ResnetBlock(HipModule):
         # the block output feeds the next block's / attention's norm: its statistics ride along too
         return ops.conv2d(h, packed_conv(self, self.conv2), residual=res, out=out, out_off=out_off,
                           gn_stats=fuse and out is None)
+
+    def train_nhwc(self, x):
+        h = conv_t(gn_swish_t(x, self.norm1), self.conv1)
+        h = gn_swish_t(h, self.norm2)
+        res = x if self.in_channels == self.out_channels else conv_t(x, self.nin_shortcut)
+        return conv_t(h, self.conv2, residual=res)
 
     def forward(self, x, temb=None):
         return to_nchw(self.forward_nhwc(to_nhwc(x)))
@@ -107,6 +130,15 @@ class AttnBlock(HipModule):
         vt = ops.conv2d(hn, packed_conv(self, self.v), out_mode=ops.OUT_PLANAR_BF16, plane_pitch=npad)  # V^T [B,512,npad]
         o = ops.attention_d512(qk, qk[..., C:], vt, N, ldq=2 * C, ldk=2 * C)     # [B,N,512]
         return ops.conv2d(o.view(B, H, W, C), packed_conv(self, self.proj_out), residual=x, gn_stats=GN_FUSED)
+
+    def train_nhwc(self, x):
+        B, H, W, C = x.shape
+        s = float(self.in_channels) ** -0.5 * math.log2(math.e)   # the fold is a (differentiable) op on the filter
+        hn = gn_swish_t(x, self.norm, swish=False)
+        q = A.conv2d(hn, self.q.weight * s, self.q.bias * s)
+        k, v = conv_t(hn, self.k), conv_t(hn, self.v)
+        o = A.attention(q.view(B, H * W, C), k.view(B, H * W, C), v.view(B, H * W, C))
+        return conv_t(o.view(B, H, W, C), self.proj_out, residual=x)
 
     def forward(self, x):
         return to_nchw(self.forward_nhwc(to_nhwc(x)))
@@ -167,6 +199,22 @@ class Encoder(HipModule):
         h = gn_swish(h, self.norm_out)
         z = ops.conv2d(h, packed_conv(self, self.conv_out), out_mode=ops.OUT_NHWC_F32)
         return z, feats
+
+    def train_nhwc(self, x_nchw):
+        h = A.conv2d_small(x_nchw.float().contiguous(), self.conv_in.weight, self.conv_in.bias, layout="nchw")
+        feats = []
+        for i_level in range(self.num_resolutions):
+            lvl = self.down[i_level]
+            for i_block in range(self.num_res_blocks):
+                h = lvl.block[i_block].train_nhwc(h)
+                if len(lvl.attn) > 0:
+                    h = lvl.attn[i_block].train_nhwc(h)
+            if i_level != self.num_resolutions - 1:
+                feats.append(h)
+                h = lvl.downsample.train_nhwc(h)
+        h = self.mid.block_2.train_nhwc(self.mid.attn_1.train_nhwc(self.mid.block_1.train_nhwc(h)))
+        h = gn_swish_t(h, self.norm_out)
+        return conv_t(h, self.conv_out, out_f32=True), feats
 
     def forward(self, x, mid_feat=False):
         z, feats = self.forward_nhwc(x)

@@ -217,3 +217,51 @@ def test_adam_matches_torch():
         opt.step()
         T.adam_step_(wd, gr.to(_dev()), m, v, step, 1e-3)
     assert torch.allclose(wd.cpu(), p.detach(), rtol=1e-6, atol=1e-7)
+
+
+def _param_grad_errors(hip_mod, ref_mod):
+    errs = {}
+    ref = dict(ref_mod.named_parameters())
+    for name, p in hip_mod.named_parameters():
+        if ref[name].grad is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        assert p.grad is not None, name
+        if name.endswith(".k.bias"):
+            # softmax_j(q_i.(k_j + b)) does not depend on b: the true gradient is 0 and both sides hold rounding noise
+            assert float(p.grad.norm()) < 1e-2 * float(dict(hip_mod.named_parameters())[name[:-4] + "weight"].grad.norm()), name
+            continue
+        errs[name] = _rel(p.grad, ref[name].grad)
+    return errs
+
+
+def test_cond_encoder_backward_vs_oracle():
+    """Row a1 in training mode: gradients of every ConEncoder1 parameter against fp32 autograd of the CPU oracle."""
+    from glare_amd import modules as M
+    from glare_amd.synthetic import seeded_init_
+    from oracle import torch_ref as O
+
+    torch.manual_seed(0)
+    B, S = 2, 64
+    hip = seeded_init_(M.ConEncoder1().train(), 7).to(_dev())
+    ref = seeded_init_(O.ConEncoder1().train(), 7)
+    lr = torch.randn(B, 3, S, S) * 0.5 - 1.0
+    g = torch.Generator().manual_seed(1)
+    r_ref = ref(lr, mid_feat=True)
+    w_cond, w_color = torch.randn(r_ref["cond_feat"].shape, generator=g), torch.randn(r_ref["color_map"].shape, generator=g)
+    w_mid = [torch.randn(f.shape, generator=g) * 0.05 for f in r_ref["mid_feat"]]
+    loss_ref = (r_ref["cond_feat"] * w_cond).sum() + (r_ref["color_map"] * w_color).sum() + sum((f * w).sum() for f, w in zip(r_ref["mid_feat"], w_mid))
+    loss_ref.backward()
+
+    r = hip.train_nhwc(lr.to(_dev()))
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(_dev())
+    loss = (r["cond_feat"].float() * nhwc(w_cond)).sum() + (r["color_map"] * nhwc(w_color)).sum() + \
+        sum((f.float() * nhwc(w)).sum() for f, w in zip(r["mid_feat"], w_mid))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < 2e-2 * abs(float(loss_ref.detach())) + 1.0
+    errs = _param_grad_errors(hip, ref)
+    vals = sorted(errs.values())
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    print("median %.4f max %.4f" % (vals[len(vals) // 2], vals[-1]), worst)
+    assert vals[len(vals) // 2] < 3e-2, worst
+    assert vals[-1] < 0.15, worst
