@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from .. import train_ops as T
 from ._base import HipModule, to_nchw, to_nhwc
 from .flow import ActNorm2d, Conv2d, Conv2dZeros, InvertibleConv1x1
 
@@ -208,6 +209,56 @@ class FlowUpsamplerNet(HipModule):
         logdet = red[:, 0] + F_["const_logdet_per_pixel"] * (H * W)
         return z, logdet, (red[:, 1] if mean is not None else None)
 
+    # ---- training: the normal direction with a backward (stage 2, row a12) --------------------------------
+    def _train_params(self):
+        """Kernel-ready parameters as DIFFERENTIABLE functions of the module's parameters (filter-sized torch ops:
+        ActNorm / Conv2dZeros folds on the device, the 3x3 affine compositions and slogdet in fp64 on the host), in
+        forward execution order.  Autograd carries the kernels' gradients through these folds to the raw parameters."""
+        dev = self.layers[0].actnorm.bias.device
+        Ms, ts, steps, const_ld = [], [], [], 0.0
+        A, c = torch.eye(3, dtype=torch.float64), torch.zeros(3, dtype=torch.float64)
+        for layer in self.layers:
+            w = layer.invconv.weight.double().cpu()
+            logs = layer.actnorm.logs.double().cpu().reshape(-1)
+            bias = layer.actnorm.bias.double().cpu().reshape(-1)
+            A2 = w * torch.exp(logs).view(1, -1)                      # W diag(e^logs)   (FlowStep.py:83-88)
+            A, c = A2 @ A, A2 @ c + A2 @ bias
+            const_ld = const_ld + logs.sum() + torch.slogdet(w)[1]    # FlowActNorms.py:93-98, Permutations.py:27
+            if layer.flow_coupling != "noCoupling":
+                Ms.append(A.float())
+                ts.append(c.float())
+                steps.append(layer.affine)
+                A, c = torch.eye(3, dtype=torch.float64), torch.zeros(3, dtype=torch.float64)
+        assert self.layers[len(self.layers) - 1].flow_coupling != "noCoupling"
+
+        def fold(conv):
+            if hasattr(conv, "actnorm"):
+                s_ = torch.exp(conv.actnorm.logs.reshape(-1))
+                return conv.weight * s_.view(-1, 1, 1, 1), conv.actnorm.bias.reshape(-1) * s_
+            s_ = torch.exp(conv.logs.reshape(-1) * conv.logscale_factor)
+            return conv.weight * s_.view(-1, 1, 1, 1), conv.bias * s_
+
+        a0 = [fold(a.fAffine[0]) for a in steps]
+        f0 = [fold(a.fFeatures[0]) for a in steps]
+        stack = lambda items, i: torch.stack([it[i] for it in items])
+        c2, c4 = [fold(a.fAffine[2]) for a in steps], [fold(a.fAffine[4]) for a in steps]
+        f2, f4 = [fold(a.fFeatures[2]) for a in steps], [fold(a.fFeatures[4]) for a in steps]
+        P = {"Ms": torch.stack(Ms), "ts": torch.stack(ts),
+             "wz": torch.stack([w[:, 0].reshape(64, 9) for w, _ in a0]),
+             "ftA_w": torch.cat([w[:, 1:] for w, _ in a0], 0), "ftA_b": torch.cat([b for _, b in a0], 0),
+             "f0_w": torch.cat([w for w, _ in f0], 0), "f0_b": torch.cat([b for _, b in f0], 0),
+             "c2_w": stack(c2, 0), "c2_b": stack(c2, 1), "c4_w": stack(c4, 0), "c4_b": stack(c4, 1),
+             "f2_w": stack(f2, 0), "f2_b": stack(f2, 1), "f4_w": stack(f4, 0), "f4_b": stack(f4, 1)}
+        return P, const_ld, float(steps[0].affine_eps), dev
+
+    def train_nll_terms(self, gt, ft, mean):
+        """gt, mean: fp32 NHWC [B,h,w,3]; ft: bf16 NHWC [B,h,w,64] (both may carry a tape).  Returns per-sample
+        (logdet, logp) float64 tensors on the device, differentiable w.r.t. ft, mean and every flow parameter."""
+        P, const_ld, eps, dev = self._train_params()
+        ld_data, logp = FlowNLLFn.apply(ft, mean, gt, eps, *[P[k] for k in _FLOW_KEYS])
+        pixels = gt.shape[1] * gt.shape[2]
+        return ld_data + (const_ld * pixels).to(dev), logp
+
     def encode(self, gt, rrdbResults, logdet=0.0, epses=None, y_onehot=None):
         ft = rrdbResults["cond_feat"] if isinstance(rrdbResults, dict) else rrdbResults
         z, ld, _ = self.encode_nhwc(to_nhwc(gt, bf16=False), to_nhwc(ft, bf16=True))
@@ -223,3 +274,110 @@ class FlowUpsamplerNet(HipModule):
             return self.decode(rrdbResults, z, eps_std, epses=epses, logdet=logdet, y_onehot=y_onehot)
         assert gt is not None
         return self.encode(gt, rrdbResults, logdet=logdet, epses=epses, y_onehot=y_onehot)
+
+
+_FLOW_KEYS = ("Ms", "ts", "wz", "ftA_w", "ftA_b", "f0_w", "f0_b", "c2_w", "c2_b", "c4_w", "c4_b", "f2_w", "f2_b", "f4_w", "f4_b")
+
+
+def _wt(w, pad_to=None):
+    """Filter of the data-gradient conv: OIHW -> IOHW, taps flipped; input channels zero-padded to `pad_to`."""
+    wt = w.detach().float().transpose(0, 1)
+    if w.shape[-1] == 3:
+        wt = wt.flip(2, 3)
+    if pad_to is not None and pad_to != wt.shape[1]:
+        wt = torch.nn.functional.pad(wt, (0, 0, 0, 0, 0, pad_to - wt.shape[1]))
+    return ops.PackedConv(wt.contiguous())
+
+
+class FlowNLLFn(torch.autograd.Function):
+    """The whole normal-direction flow (FlowUpsamplerNet.encode, :228-274) + Gaussian term as one tape node: forward =
+    FlowUpsamplerNet.encode_nhwc keeping every step's activations, backward = the adjoint sweep of csrc/flow_bwd.hip with
+    the coupling nets' conv gradients on the MFMA conv / GEMM kernels."""
+
+    @staticmethod
+    def forward(ctx, ft, mean, gt, eps, Ms, ts, wz, ftA_w, ftA_b, f0_w, f0_b, c2_w, c2_b, c4_w, c4_b, f2_w, f2_b, f4_w, f4_b):
+        n = Ms.shape[0]
+        B, H, W, _ = gt.shape
+        dev = gt.device
+        Mh, th = Ms.detach().cpu().reshape(n, 9).tolist(), ts.detach().cpu().tolist()
+        wz = wz.detach().float().contiguous()
+        ft = ft.contiguous()
+        ftA = ops.conv2d(ft, ops.PackedConv(ftA_w, ftA_b), out_mode=ops.OUT_NHWC_F32)
+        h1f = ops.conv2d(ft, ops.PackedConv(f0_w, f0_b), act="relu")
+        h2f = torch.empty_like(h1f)
+        hF = torch.zeros(B, H, W, n * 8, dtype=torch.float32, device=dev)
+        for s in range(n):
+            ops.conv2d(h1f, ops.PackedConv(f2_w[s], f2_b[s]), cin=64, in_off=64 * s, act="relu", out=h2f, out_off=64 * s)
+            ops.conv2d(h2f, ops.PackedConv(f4_w[s], f4_b[s]), cin=64, in_off=64 * s, out=hF, out_off=8 * s, out_mode=ops.OUT_NHWC_F32)
+        z = gt.detach().clone().contiguous()
+        z_in = torch.empty(n, B, H, W, 3, dtype=torch.float32, device=dev)
+        z_pre = torch.empty_like(z_in)
+        h1s = torch.empty(n, B, H, W, 64, dtype=torch.bfloat16, device=dev)
+        h2s = torch.empty_like(h1s)
+        h4s = torch.empty(n, B, H, W, 4, dtype=torch.float32, device=dev)
+        bps = ops.flow_blocks_per_sample(H * W)
+        partial = torch.zeros(2 * n, B * bps, dtype=torch.float32, device=dev)
+        for k in range(n):
+            z_in[k].copy_(z)
+            ops.flow_fwd_pre(z, hF, 8 * k, Mh[k], th[k], eps, partial[2 * k])
+            z_pre[k].copy_(z)
+            ops.flow_h1(z, ftA, 64 * k, wz[k], out=h1s[k])
+            ops.conv2d(h1s[k], ops.PackedConv(c2_w[k], c2_b[k]), act="relu", out=h2s[k])
+            ops.conv2d(h2s[k], ops.PackedConv(c4_w[k], c4_b[k]), out=h4s[k], out_mode=ops.OUT_NHWC_F32)
+            ops.flow_fwd_post(z, h4s[k], eps, partial[2 * k + 1])
+        mean = mean.contiguous()
+        red = ops.flow_nll_reduce(z, mean, partial, 2 * n)
+        ctx.eps, ctx.Mh, ctx.th = eps, Mh, th
+        ctx.save_for_backward(ft, mean, z, h1f, h2f, hF, z_in, z_pre, h1s, h2s, h4s, wz, ftA_w, f0_w, c2_w, c4_w, f2_w, f4_w)
+        return red[:, 0].clone(), red[:, 1].clone()
+
+    @staticmethod
+    def backward(ctx, g_logdet, g_logp):
+        ft, mean, z, h1f, h2f, hF, z_in, z_pre, h1s, h2s, h4s, wz, ftA_w, f0_w, c2_w, c4_w, f2_w, f4_w = ctx.saved_tensors
+        eps, Mh, th = ctx.eps, ctx.Mh, ctx.th
+        n, B, H, W, _ = z_in.shape
+        dev = z.device
+        gld = g_logdet.float().contiguous()
+        gz, gmean = T.flow_nll_backward(z, mean, g_logp.float().contiguous())
+        gftA = torch.empty(B, H, W, n * 64, dtype=torch.bfloat16, device=dev)
+        ghF = torch.empty(B, H, W, n * 8, dtype=torch.bfloat16, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        dM, dt, dwz = torch.empty(n, 3, 3, **f32), torch.empty(n, 3, **f32), torch.empty(n, 64, 9, **f32)
+        dc2w, dc2b = torch.empty(n, 64, 64, 1, 1, **f32), torch.empty(n, 64, **f32)
+        dc4w, dc4b = torch.empty(n, 4, 64, 3, 3, **f32), torch.empty(n, 4, **f32)
+        df2w, df2b = torch.empty(n, 64, 64, 1, 1, **f32), torch.empty(n, 64, **f32)
+        df4w, df4b = torch.empty(n, 6, 64, 3, 3, **f32), torch.empty(n, 6, **f32)
+        for k in reversed(range(n)):                                   # the sequential adjoint sweep
+            gh4 = T.flow_post_backward_(gz, z_pre[k], h4s[k], gld, eps)
+            dwb = T.conv_weight_grad(lambda ldp, ones: T.im2col_t(h2s[k], 3, ldp=ldp, ones_row=ones), gh4, 4, 576)
+            dc4w[k], dc4b[k] = dwb[:, :-1].reshape(4, 64, 3, 3), dwb[:, -1]
+            gh2 = ops.conv2d(gh4, _wt(c4_w[k], 8))
+            T.act_backward_(gh2, h2s[k], "relu")
+            dwb = T.conv_weight_grad(lambda ldp, ones: T.im2col_t(h1s[k], 1, ldp=ldp, ones_row=ones), gh2, 64, 64)
+            dc2w[k], dc2b[k] = dwb[:, :-1].reshape(64, 64, 1, 1), dwb[:, -1]
+            ops.conv2d(gh2, _wt(c2_w[k]), out=gftA, out_off=64 * k)
+            T.act_backward_(gftA, h1s[k], "relu", C=64, g_off=64 * k)
+            dwz[k] = T.flow_h1_backward_(gz, gftA, 64 * k, z_pre[k], wz[k])
+            dM[k], dt[k] = T.flow_pre_backward_(gz, z_in[k], hF, 8 * k, gld, Mh[k], th[k], eps, ghF, 8 * k)
+        P = B * H * W
+        gh2f, gh1f = torch.empty_like(h1f), torch.empty_like(h1f)
+        ghF2, gh2f2 = ghF.view(P, n * 8), gh2f.view(P, n * 64)
+        for s in range(n):                                             # the z-independent feature nets
+            dwb = T.conv_weight_grad(lambda ldp, ones: T.im2col_t(h2f, 3, cin=64, in_off=64 * s, ldp=ldp, ones_row=ones),
+                                     ghF2[:, 8 * s:8 * s + 8], 6, 576)
+            df4w[s], df4b[s] = dwb[:, :-1].reshape(6, 64, 3, 3), dwb[:, -1]
+            ops.conv2d(ghF, _wt(f4_w[s], 8), cin=8, in_off=8 * s, out=gh2f, out_off=64 * s)
+            T.act_backward_(gh2f, h2f, "relu", C=64, g_off=64 * s, y_off=64 * s)
+            dwb = T.conv_weight_grad(lambda ldp, ones: T.im2col_t(h1f, 1, cin=64, in_off=64 * s, ldp=ldp, ones_row=ones),
+                                     gh2f2[:, 64 * s:64 * s + 64], 64, 64)
+            df2w[s], df2b[s] = dwb[:, :-1].reshape(64, 64, 1, 1), dwb[:, -1]
+            ops.conv2d(gh2f, _wt(f2_w[s]), cin=64, in_off=64 * s, out=gh1f, out_off=64 * s)
+            T.act_backward_(gh1f, h1f, "relu", C=64, g_off=64 * s, y_off=64 * s)
+        col = lambda ldp, ones: T.im2col_t(ft, 3, ldp=ldp, ones_row=ones)
+        dwb = T.conv_weight_grad(col, gh1f, n * 64, 576)
+        df0w, df0b = dwb[:, :-1].reshape(n * 64, 64, 3, 3), dwb[:, -1].contiguous()
+        dwb = T.conv_weight_grad(col, gftA, n * 64, 576)
+        dftAw, dftAb = dwb[:, :-1].reshape(n * 64, 64, 3, 3), dwb[:, -1].contiguous()
+        gft = ops.conv2d(gh1f, _wt(f0_w))
+        gft = ops.conv2d(gftA, _wt(ftA_w), residual=gft)
+        return (gft, gmean, None, None, dM.cpu(), dt.cpu(), dwz, dftAw, dftAb, df0w, df0b, dc2w, dc2b, dc4w, dc4b, df2w, df2b, df4w, df4b)

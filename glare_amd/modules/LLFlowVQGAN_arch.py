@@ -1,7 +1,7 @@
 """Stage-2 graph, forward (evaluation of the training objective): conditional encoder -> normal flow ->
 negative log-likelihood.  Mirrors LLFlowVQGAN2 (code/models/modules/LLFlowVQGAN_arch.py:17-106; the
 `...2_arch.py` twin fails to import upstream) with `train_gt_ratio: 0`
-(confs/LOL.yml:12): mean = color_map.  The BACKWARD of this objective (row a12) is not built on HIP yet."""
+(confs/LOL.yml:12): mean = color_map.  `train_nll` is the same objective with a tape (HIP backward, row a12)."""
 import math
 
 import torch
@@ -26,6 +26,14 @@ class LLFlowVQGAN2(HipModule):
         pixels = gt_latent.shape[1] * gt_latent.shape[2]
         nll = -(logdet + logp) / (math.log(2.0) * pixels)  # LLFlowVQGAN_arch.py:99-101
         return z, nll.float(), logdet.float()
+
+    def train_nll(self, gt_latent, lr):
+        """Per-sample NLL (float64 [B]) with a tape through the conditional encoder and the flow: what
+        LLFlowModel.optimize_parameters differentiates (LLFlow_model.py:215-236)."""
+        enc = self.RRDB.train_nhwc(lr)
+        logdet, logp = self.flowUpsamplerNet.train_nll_terms(gt_latent, enc["cond_feat"], enc["color_map"])
+        pixels = gt_latent.shape[1] * gt_latent.shape[2]
+        return -(logdet + logp) / (math.log(2.0) * pixels)
 
     def forward(self, gt=None, lr=None, z=None, eps_std=None, reverse=False, epses=None, reverse_with_grad=False, lr_enc=None,
                 add_gt_noise=False, step=None, y_label=None, align_condition_feature=False, get_color_map=False):

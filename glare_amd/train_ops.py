@@ -233,13 +233,16 @@ def adam_step_(w, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1
 # ---- composite backward passes ------------------------------------------------------------------------
 def conv_weight_grad(x_col_builder, g_bf16, cout, n_rows):
     """dW|db = gO^T . colT^T by split-K NT GEMM.  x_col_builder(ldp, ones_row) -> colT [n_rows+1, ldp];
-    g_bf16: [B,OH,OW,pitch>=cout] bf16.  Returns fp32 [cout, n_rows+1] (last column = bias gradient)."""
-    P = g_bf16.numel() // g_bf16.shape[-1]
+    g_bf16: bf16 [B,OH,OW,pitch>=cout] or a 2-D (row-strided) view [P, >=cout].  Returns fp32 [cout, n_rows+1]
+    (last column = bias gradient)."""
+    if g_bf16.dim() != 2:
+        g_bf16 = g_bf16.view(-1, g_bf16.shape[-1])
+    P = g_bf16.shape[0]
     tiles = ((cout + 255) // 256) * ((n_rows + 1 + 127) // 128)
     S = max(1, min((768 + tiles - 1) // tiles, P // 2048, 64))
     ldp = _rup(P, 64 * S)
     colT = x_col_builder(ldp, n_rows)
-    gT = transpose(g_bf16.view(P, g_bf16.shape[-1]), ld_out=ldp)[:cout]
+    gT = transpose(g_bf16, ld_out=ldp)[:cout]
     ks = ldp // S
     a3 = gT.as_strided((S, cout, ks), (ks, ldp, 1))
     b3 = colT.as_strided((S, n_rows + 1, ks), (ks, ldp, 1))
@@ -264,3 +267,55 @@ def attention_backward(q, k, v, o, do, ln2_scale=0.6931471805599453):
         gemm_nt(dST, qT, out=dk[b], K=npad)
         gemm_nt(PT, doT, out=dv[b], K=npad)
     return dq, dk, dv
+
+
+# ---- flow (normal direction) backward -------------------------------------------------------------------
+def _host3(M, t):
+    return (ctypes.c_float * 9)(*[float(v) for v in M]), (ctypes.c_float * 3)(*[float(v) for v in t])
+
+
+def flow_nll_backward(z, mean, g_logp):
+    require_cuda(z, mean, g_logp)
+    B = z.shape[0]
+    gz, gmean = torch.empty_like(z), torch.empty_like(z)
+    check(_lib.lib().glare_flow_nll_backward_f32(ptr(z), ptr(mean), ptr(g_logp), _i(B), _ll(z.numel() // 3 // B), ptr(gz), ptr(gmean),
+                                                 stream_handle()), "glare_flow_nll_backward_f32")
+    return gz, gmean
+
+
+def flow_post_backward_(gz, z_pre, h4, g_logdet, eps):
+    """-> gh4 bf16 [B,H,W,8] (4 used); gz[..., 1:] updated in place."""
+    require_cuda(gz, z_pre, h4, g_logdet)
+    B = gz.shape[0]
+    gh4 = torch.empty(*gz.shape[:-1], 8, dtype=torch.bfloat16, device=gz.device)
+    check(_lib.lib().glare_flow_fwd_post_backward_f32(ptr(gz), ptr(z_pre), ptr(h4), ptr(g_logdet), _i(B), _ll(gz.numel() // 3 // B),
+                                                      _f(eps), ptr(gh4), stream_handle()), "glare_flow_fwd_post_backward_f32")
+    return gh4
+
+
+def flow_h1_backward_(gz, g, g_off, z_pre, wz):
+    """gz[..., 0] += adjoint of the 1-channel conv; returns the filter gradient fp32 [64, 9]."""
+    require_cuda(gz, g, z_pre, wz)
+    B, H, W, _ = gz.shape
+    lib = _lib.lib()
+    nb = int(lib.glare_flow_bwd_blocks(_ll(B * H * W)))
+    part = torch.empty(nb, 576, dtype=torch.float32, device=gz.device)
+    check(lib.glare_flow_h1_backward_f32(ptr(gz), ptr(g), _i(g.shape[-1]), _i(g_off), ptr(z_pre), ptr(wz), _i(B), _i(H), _i(W), ptr(part),
+                                         stream_handle()), "glare_flow_h1_backward_f32")
+    return reduce_parts(part).view(64, 9)
+
+
+def flow_pre_backward_(gz, z_in, hF, hF_off, g_logdet, M, t, eps, ghF, ghF_off):
+    """gz updated in place to the step input's gradient; ghF slice written; returns (dM fp32 [3,3], dt fp32 [3])."""
+    require_cuda(gz, z_in, hF, g_logdet, ghF)
+    B = gz.shape[0]
+    lib = _lib.lib()
+    npix = gz.numel() // 3
+    nb = int(lib.glare_flow_bwd_blocks(_ll(npix)))
+    part = torch.empty(nb, 12, dtype=torch.float32, device=gz.device)
+    Ma, ta = _host3(M, t)
+    check(lib.glare_flow_fwd_pre_backward_f32(ptr(gz), ptr(z_in), ptr(hF), _i(hF.shape[-1]), _i(hF_off), ptr(g_logdet), _i(B),
+                                              _ll(npix // B), Ma, ta, _f(eps), ptr(ghF), _i(ghF.shape[-1]), _i(ghF_off), ptr(part),
+                                              stream_handle()), "glare_flow_fwd_pre_backward_f32")
+    r = reduce_parts(part)
+    return r[:9].view(3, 3), r[9:]

@@ -317,6 +317,23 @@ int glare_attention_ds_bf16(const void* P, long long ldp, const float* dP, long 
 int glare_adam_step_f32(float* w, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1,
                         float beta2, float eps, float weight_decay, int step, float grad_scale, glare_stream_t stream);
 
+/* Backward of the flow's normal direction (adjoint of glare_flow_fwd_pre / _h1 / _fwd_post / _nll_reduce): autograd
+ * through FlowStep.normal_flow (FlowStep.py:75-98) and GaussianDiag.logp (flow.py:76-95).  gz is the latent's gradient,
+ * fp32 [pixel][3], updated in place from the last coupling step to the first; g_logdet / g_logp are the per-sample
+ * gradients of the two sums glare_flow_nll_reduce_f32 returns.  Partials are [glare_flow_bwd_blocks(n_pixels)][...]
+ * rows summed by glare_reduce_parts_f32: gwz [64][9]; gMt = 9 entries of dL/dM then 3 of dL/dt. */
+int glare_flow_bwd_blocks(long long n_pixels);
+int glare_flow_nll_backward_f32(const float* z, const float* mean, const float* g_logp_per_sample, int B,
+                                long long pixels_per_sample, float* gz, float* gmean, glare_stream_t stream);
+int glare_flow_fwd_post_backward_f32(float* gz, const float* z_pre, const float* h4, const float* g_logdet_per_sample, int B,
+                                     long long pixels_per_sample, float eps, void* gh4_bf16x8, glare_stream_t stream);
+int glare_flow_h1_backward_f32(float* gz, const void* gh1_bf16, int g_pitch, int g_off, const float* z_pre,
+                               const float* wz_64x9, int B, int H, int W, float* gwz_partial, glare_stream_t stream);
+int glare_flow_fwd_pre_backward_f32(float* gz, const float* z_in, const float* hF, int hF_pitch, int hF_off,
+                                    const float* g_logdet_per_sample, int B, long long pixels_per_sample,
+                                    const float* M_3x3_host, const float* t_3_host, float eps, void* ghF_bf16, int ghF_pitch,
+                                    int ghF_off, float* gMt_partial, glare_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

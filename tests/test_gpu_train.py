@@ -265,3 +265,64 @@ def test_cond_encoder_backward_vs_oracle():
     print("median %.4f max %.4f" % (vals[len(vals) // 2], vals[-1]), worst)
     assert vals[len(vals) // 2] < 3e-2, worst
     assert vals[-1] < 0.15, worst
+
+
+def _stage2_pair(seed=2):
+    from glare_amd import modules as M
+    from glare_amd.synthetic import seeded_init_
+    from oracle import torch_ref as O
+
+    ref = seeded_init_(O.LLFlowVQGAN2().train(), seed)
+    hip = M.LLFlowVQGAN2().train()
+    hip.load_state_dict(ref.state_dict(), strict=True)
+    return hip.to(_dev()), ref
+
+
+def _report(errs, med_tol, max_tol):
+    vals = sorted(errs.values())
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:6]
+    print("n=%d median %.4f max %.4f" % (len(vals), vals[len(vals) // 2], vals[-1]), worst)
+    assert vals[len(vals) // 2] < med_tol, worst
+    assert vals[-1] < max_tol, worst
+
+
+def test_flow_nll_backward_vs_oracle():
+    """Row a4 backward in isolation: the flow's adjoint sweep on given conditional features."""
+    hip, ref = _stage2_pair()
+    g = torch.Generator().manual_seed(4)
+    B, h, w = 2, 12, 16
+    gt = torch.randn(B, 3, h, w, generator=g) * 0.5
+    ft = torch.rand(B, 64, h, w, generator=g).to(torch.bfloat16).float()
+    mean = torch.randn(B, 3, h, w, generator=g) * 0.3
+    ft_r, mean_r = ft.clone().requires_grad_(True), mean.clone().requires_grad_(True)
+    logdet = torch.zeros(B)
+    z, logdet = ref.flowUpsamplerNet.encode(gt, ft_r, logdet)
+    logp = (-0.5 * ((z - mean_r) ** 2 + 1.8378770664093453)).sum(dim=[1, 2, 3])
+    nll_r = -(logdet + logp) / (0.6931471805599453 * h * w)
+    nll_r.mean().backward()
+
+    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(_dev())
+    ft_d = nh(ft).to(torch.bfloat16).requires_grad_(True)
+    mean_d = nh(mean).requires_grad_(True)
+    ld, lp = hip.flowUpsamplerNet.train_nll_terms(nh(gt), ft_d, mean_d)
+    nll = -(ld + lp) / (0.6931471805599453 * h * w)
+    assert torch.allclose(nll.detach().float().cpu(), nll_r.detach(), rtol=2e-2, atol=0.05), (nll, nll_r)
+    nll.mean().backward()
+    assert _rel(ft_d.grad.float().cpu().permute(0, 3, 1, 2), ft_r.grad) < 8e-2
+    assert _rel(mean_d.grad.cpu().permute(0, 3, 1, 2), mean_r.grad) < 2e-2
+    _report(_param_grad_errors(hip.flowUpsamplerNet, ref.flowUpsamplerNet), 3e-2, 0.2)
+
+
+def test_stage2_objective_backward_vs_oracle():
+    """Row a12: d mean(nll) / d every parameter of RRDB + flow against fp32 autograd of the oracle."""
+    hip, ref = _stage2_pair(5)
+    g = torch.Generator().manual_seed(6)
+    B, S = 2, 64
+    lr = torch.randn(B, 3, S, S, generator=g) * 0.5 - 1.0
+    gt = torch.randn(B, 3, S // 4, S // 4, generator=g) * 0.5
+    _, nll_r, _ = ref.normal_flow(gt, lr)
+    nll_r.mean().backward()
+    nll = hip.train_nll(gt.permute(0, 2, 3, 1).contiguous().to(_dev()), lr.to(_dev()))
+    assert torch.allclose(nll.detach().float().cpu(), nll_r.detach(), rtol=3e-2, atol=0.05), (nll, nll_r)
+    nll.mean().backward()
+    _report(_param_grad_errors(hip, ref), 5e-2, 0.3)
