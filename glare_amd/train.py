@@ -1,0 +1,100 @@
+"""Training steps on the HIP path: stage 2 (row a12: conditional encoder + flow, NLL objective) and the data-parallel
+plumbing both stages share.
+
+Reference: LLFlowModel.optimize_parameters (code/models/LLFlow_model.py:181-250) with its optimizer setup (:90-122):
+torch.optim.Adam over two parameter groups -- the flow ("other", lr_G, weight_decay_G) and the conditional encoder
+(names containing '.RRDB.', lr_RRDB or lr_G, weight decay 1e-5); the `beta1` / `beta2` keys it passes are not Adam's
+`betas`, so torch's defaults (0.9, 0.999) apply.  GradScaler is a no-op without fp16 and is not reproduced.
+
+MI355X design: parameters, gradients and both Adam moments of a group live in four flat fp32 buffers (module parameters
+and their .grad are views), so the optimizer is ONE kernel launch per group and the data-parallel gradient mean is ONE
+RCCL all-reduce per group over xGMI (106 MB at stage 2) instead of nn.DataParallel's per-step replicate / scatter /
+gather through GPU 0 (LLFlow_model.py:72-75).
+"""
+import torch
+import torch.distributed as dist
+
+from . import train_ops as T
+
+
+class FlatGroup:
+    """Flat fp32 storage for a parameter group: w / grad / exp_avg / exp_avg_sq; parameters become views."""
+
+    def __init__(self, params, lr, weight_decay=0.0):
+        self.params = [p for p in params if p.requires_grad]
+        self.lr, self.weight_decay = float(lr), float(weight_decay)
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device if self.params else torch.device("cpu")
+        self.w = torch.empty(n, dtype=torch.float32, device=dev)
+        self.g = torch.zeros_like(self.w)
+        self.m = torch.zeros_like(self.w)
+        self.v = torch.zeros_like(self.w)
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            self.w[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.w[off:off + k].view(p.shape)
+            p.grad = self.g[off:off + k].view(p.shape)
+            off += k
+
+    def zero_grad(self):
+        self.g.zero_()
+        off = 0
+        for p in self.params:   # autograd may have replaced .grad by a fresh tensor: re-point it at the flat buffer
+            k = p.numel()
+            if p.grad is None or p.grad.data_ptr() != self.g.data_ptr() + 4 * off:
+                p.grad = self.g[off:off + k].view(p.shape)
+            off += k
+
+    def all_reduce(self):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.g)            # sum; the 1/world of the mean is folded into the Adam kernel
+            return dist.get_world_size()
+        return 1
+
+
+class FlatAdam:
+    def __init__(self, groups, betas=(0.9, 0.999), eps=1e-8):
+        self.groups, self.betas, self.eps, self.t = groups, betas, eps, 0
+
+    def zero_grad(self):
+        for g in self.groups:
+            g.zero_grad()
+
+    def step(self):
+        self.t += 1
+        for g in self.groups:
+            if g.w.numel() == 0:
+                continue
+            world = g.all_reduce()
+            T.adam_step_(g.w, g.g, g.m, g.v, self.t, g.lr, self.betas, self.eps, g.weight_decay, grad_scale=1.0 / world)
+
+
+class Stage2Trainer:
+    """One optimisation step of the flow objective: a7 (frozen VQGAN encoder, no tape) -> a1 -> a4 -> mean NLL -> backward ->
+    gradient mean over ranks -> Adam."""
+
+    def __init__(self, netG, net_hq, lr_G=5e-4, lr_RRDB=None, weight_decay_G=0.0, train_rrdb=True):
+        self.netG, self.net_hq = netG.train(), net_hq.eval()
+        for p in net_hq.parameters():
+            p.requires_grad_(False)
+        rrdb = [p for n, p in netG.named_parameters() if n.startswith("RRDB.")]
+        other = [p for n, p in netG.named_parameters() if not n.startswith("RRDB.")]
+        if not train_rrdb:  # train_RRDB_delay (LLFlow_model.py:142-150): the encoder joins after a fraction of the run
+            for p in rrdb:
+                p.requires_grad_(False)
+        self.opt = FlatAdam([FlatGroup(other, lr_G, weight_decay_G),
+                             FlatGroup(rrdb, lr_G if lr_RRDB is None else lr_RRDB, 1e-5)] if train_rrdb else
+                            [FlatGroup(other, lr_G, weight_decay_G)])
+
+    def step(self, gt_img, lr_img):
+        """gt_img: fp32 NCHW ground-truth crop in [0,1]; lr_img: fp32 NCHW low-light crop (log domain).  Returns the loss."""
+        with torch.no_grad():
+            gt_latent = self.net_hq.encode_nhwc(gt_img)            # LLFlow_model.py:200-201
+        self.opt.zero_grad()
+        nll = self.netG.train_nll(gt_latent, lr_img)               # :215
+        loss = nll.mean()
+        loss.backward()                                            # :236
+        self.opt.step()                                            # :240
+        self.netG.invalidate()                                     # packed inference weights are stale now
+        return float(loss.detach())

@@ -326,3 +326,27 @@ def test_stage2_objective_backward_vs_oracle():
     assert torch.allclose(nll.detach().float().cpu(), nll_r.detach(), rtol=3e-2, atol=0.05), (nll, nll_r)
     nll.mean().backward()
     _report(_param_grad_errors(hip, ref), 5e-2, 0.3)
+
+
+def test_stage2_trainer_steps_reduce_the_loss():
+    """Row a12 end to end: frozen VQGAN encode -> NLL -> backward -> flat Adam; the loss on a fixed batch must fall,
+    and the flat storage must stay the parameters' storage."""
+    from glare_amd import modules as M
+    from glare_amd.synthetic import seeded_init_
+    from glare_amd.train import Stage2Trainer
+
+    hip, _ = _stage2_pair(8)
+    net_hq = seeded_init_(M.VQModel().eval(), 1).to(_dev())
+    tr = Stage2Trainer(hip, net_hq, lr_G=2e-4)
+    g = torch.Generator().manual_seed(11)
+    gt_img = torch.rand(2, 3, 64, 64, generator=g).to(_dev())
+    lr_img = (torch.randn(2, 3, 64, 64, generator=g) * 0.5 - 1.0).to(_dev())
+    p0 = next(hip.flowUpsamplerNet.parameters())
+    before = p0.detach().clone()
+    losses = [tr.step(gt_img, lr_img) for _ in range(6)]
+    print(losses)
+    assert all(l == l for l in losses)
+    assert losses[-1] < losses[0]
+    assert not torch.equal(before, p0.detach())
+    grp = tr.opt.groups[0]
+    assert p0.data_ptr() == grp.w.data_ptr() and p0.grad.data_ptr() == grp.g.data_ptr()

@@ -52,3 +52,45 @@ def test_two_rank_gather_matches_single_process():
         assert p.exitcode == 0
     ref = torch.arange(n, dtype=torch.float32).view(n, 1, 1).expand(n, 2, 3) * 2 + 1
     assert torch.equal(full, ref)
+
+
+def _grad_worker(rank, world, port, q):
+    """The training step's data-parallel exchange (glare_amd/train.py): flat gradient buffers, one all-reduce per
+    group; the Adam kernel itself is GPU-only and covered by tests/test_gpu_train.py."""
+    from glare_amd.train import FlatGroup
+
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    parallel.init_from_env(backend="gloo")
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.Linear(4, 3))
+    grp = FlatGroup(list(net.parameters()), lr=1e-3)
+    assert all(p.data_ptr() >= grp.w.data_ptr() for p in net.parameters())       # parameters are views of the flat buffer
+    grp.zero_grad()
+    x = torch.full((2, 5), float(rank + 1))
+    net(x).sum().backward()                                                       # accumulates INTO the flat grad buffer
+    local = grp.g.clone()
+    w = grp.all_reduce()
+    q.put((rank, w, local, grp.g.clone()))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_flat_gradient_all_reduce_two_ranks():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, w0, l0, s0), (_, w1, l1, s1) = got
+    assert w0 == w1 == 2
+    assert float(l0.abs().sum()) > 0 and not torch.equal(l0, l1)
+    assert torch.allclose(s0, l0 + l1) and torch.equal(s0, s1)
