@@ -176,3 +176,89 @@ class AttentionFn(torch.autograd.Function):
 
 def attention(q, k, v):
     return AttentionFn.apply(q, k, v)
+
+
+class MixFn(torch.autograd.Function):
+    """Mix.forward (deformableDecoder_arch.py:587-590): sigmoid(w) a + (1 - sigmoid(w)) b."""
+
+    @staticmethod
+    def forward(ctx, a, b, w):
+        ctx.save_for_backward(a, b, w)
+        return ops.mix(a, b, float(w.detach()))
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, w = ctx.saved_tensors
+        ga, gb, dw = T.mix_backward(g.contiguous(), a, b, float(w.detach()), want_ga=ctx.needs_input_grad[0])
+        return ga, gb, dw.to(w.dtype).view_as(w)
+
+
+def mix(a, b, w):
+    return MixFn.apply(a, b, w)
+
+
+class MeanRescaleFn(torch.autograd.Function):
+    """h + x_w * (mean(h) / mean(x_w)) (deformableDecoder_arch.py:567); h bf16, x_w fp32."""
+
+    @staticmethod
+    def forward(ctx, h, xw, whole_batch):
+        ctx.whole = whole_batch
+        ctx.save_for_backward(h, xw)
+        return ops.mean_rescale(h, xw, whole_batch=whole_batch)
+
+    @staticmethod
+    def backward(ctx, g):
+        h, xw = ctx.saved_tensors
+        gh, gxw = T.mean_rescale_backward(g, h, xw, ctx.whole)
+        return gh, gxw, None
+
+
+def mean_rescale(h, xw, whole_batch):
+    return MeanRescaleFn.apply(h, xw, whole_batch)
+
+
+class DcnFn(torch.autograd.Function):
+    """DCNv2 (DCNv2Pack.forward, deformableDecoder_arch.py:141-152) on the NHWC path: x bf16 NHWC, om = conv_offset's
+    output fp32 NHWC [B,H,W,3*dg*9] (offsets | mask logits; the chunk/cat of :146-147 is the identity on that order and
+    the sigmoid is applied by the kernels).  Backward = glare_mdcn_backward_f32, the drop-in of
+    modulated_deform_conv_cuda_backward, which always produces all five gradients (deform_conv.py:161-165)."""
+
+    @staticmethod
+    def forward(ctx, x, om, weight, bias, dg, padding):
+        B, H, W, _ = x.shape
+        om_p = ops.nhwc_to_nchw(om.contiguous())                               # planar [B, 108, H, W]
+        pd = ops.PackedDcn(weight, bias, dg)
+        out = ops.mdcn_forward_nhwc(x, om_p.view(B, om_p.shape[1], H * W), pd, mask_is_logit=True, padding=padding)
+        ctx.cfg = (dg, padding, bias is not None)
+        ctx.save_for_backward(x, om_p, weight, bias)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from .modules.ops.dcn.deform_conv import deform_conv_ext
+
+        dg, padding, with_bias = ctx.cfg
+        x, om_p, weight, bias = ctx.saved_tensors
+        B, H, W, C = x.shape
+        co, _, kh, kw = weight.shape
+        n_off = 2 * dg * kh * kw
+        xin = ops.nhwc_to_nchw(x)
+        offset = om_p[:, :n_off].contiguous()
+        mask = T.sigmoid(om_p[:, n_off:].contiguous())
+        gout = ops.nhwc_to_nchw(g.contiguous())
+        w32 = weight.detach().float().contiguous()
+        b32 = bias.detach().float().contiguous() if with_bias else xin.new_empty(1)
+        gin, goff, gmask = torch.zeros_like(xin), torch.zeros_like(offset), torch.zeros_like(mask)
+        gw, gb = torch.zeros_like(w32), torch.zeros_like(b32)
+        deform_conv_ext.modulated_deform_conv_backward(xin, w32, b32, xin.new_empty(0), offset, mask, xin.new_empty(0), gin, gw, gb,
+                                                       goff, gmask, gout, kh, kw, 1, 1, padding, padding, 1, 1, 1, dg, with_bias)
+        T.act_backward_(gmask, mask, "sigmoid")                               # d / d mask logit
+        gom = torch.empty(B, H, W, om_p.shape[1], dtype=torch.float32, device=x.device)
+        ops.nchw_to_nhwc(goff, bf16=False, out=gom, out_off=0)
+        ops.nchw_to_nhwc(gmask, bf16=False, out=gom, out_off=n_off)
+        gx = ops.nchw_to_nhwc(gin, bf16=True) if ctx.needs_input_grad[0] else None
+        return gx, gom, gw, (gb if with_bias else None), None, None
+
+
+def dcn(x, om, weight, bias, dg, padding=1):
+    return DcnFn.apply(x, om, weight, bias, dg, padding)

@@ -386,6 +386,94 @@ __global__ __launch_bounds__(256) void attn_ds_kernel(const bf16_t* __restrict__
     dS[row * ldds + j] = j < n ? f2bf(scale * bf2f(P[row * ldp + j]) * (dP[row * lddp + j] - delta)) : (bf16_t)0;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Mix backward (deformableDecoder_arch.py:587-590): out = s a + (1-s) b, s = sigmoid(w)
+//   gb = (1-s) g, ga = s g (optional), partial[blk] = sum g (a - b)   (dw = s (1-s) * sum)
+__global__ __launch_bounds__(256) void mix_bwd_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ a,
+                                                      const bf16_t* __restrict__ b, bf16_t* __restrict__ ga, bf16_t* __restrict__ gb,
+                                                      long long n8, float s, float* __restrict__ partial) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    const u32x4 gv = reinterpret_cast<const u32x4*>(g)[i], av = reinterpret_cast<const u32x4*>(a)[i], bv = reinterpret_cast<const u32x4*>(b)[i];
+    u32x4 oa, ob;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float g0 = bflo(gv[e]), g1 = bfhi(gv[e]);
+      acc += g0 * (bflo(av[e]) - bflo(bv[e])) + g1 * (bfhi(av[e]) - bfhi(bv[e]));
+      oa[e] = pack_bf2(s * g0, s * g1);
+      ob[e] = pack_bf2((1.f - s) * g0, (1.f - s) * g1);
+    }
+    if (ga) reinterpret_cast<u32x4*>(ga)[i] = oa;
+    reinterpret_cast<u32x4*>(gb)[i] = ob;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// Mean-rescale backward (deformableDecoder_arch.py:567): out = h + xw r, r = sum(h)/sum(xw) over the sample (or batch)
+//   D = sum g xw;  gh = g + D/Sx;  gxw = g r - D Sh/Sx^2
+// partial[b][blk][3] = (D, Sh, Sx) of a slice; coef[b][3] = (D/Sx, r, D Sh/Sx^2)
+__global__ __launch_bounds__(256) void rescale_bwd_reduce_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ h,
+                                                                 const float* __restrict__ xw, long long n_per_sample, int blocks,
+                                                                 float* __restrict__ partial) {
+  __shared__ float red[3][4];
+  const int b = blockIdx.y;
+  float d = 0.f, sh = 0.f, sx = 0.f;
+  const long long base = (long long)b * n_per_sample;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_per_sample; i += (long long)blocks * 256) {
+    const float x = xw[base + i];
+    d += bf2f(g[base + i]) * x;
+    sh += bf2f(h[base + i]);
+    sx += x;
+  }
+  d = wave_sum(d); sh = wave_sum(sh); sx = wave_sum(sx);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = d; red[1][threadIdx.x >> 6] = sh; red[2][threadIdx.x >> 6] = sx; }
+  __syncthreads();
+  if (threadIdx.x < 3)
+    partial[((size_t)b * blocks + blockIdx.x) * 3 + threadIdx.x] =
+        (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+__global__ void rescale_bwd_finalize_kernel(const float* __restrict__ partial, int B, int blocks, int whole_batch,
+                                            float* __restrict__ coef) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double D = 0, Sh = 0, Sx = 0;
+  for (int b = 0; b < B; ++b) {
+    if (!whole_batch) D = Sh = Sx = 0;
+    for (int k = 0; k < blocks; ++k) {
+      D += partial[((size_t)b * blocks + k) * 3];
+      Sh += partial[((size_t)b * blocks + k) * 3 + 1];
+      Sx += partial[((size_t)b * blocks + k) * 3 + 2];
+    }
+    if (!whole_batch) {
+      coef[b * 3] = (float)(D / Sx); coef[b * 3 + 1] = (float)(Sh / Sx); coef[b * 3 + 2] = (float)(D * Sh / (Sx * Sx));
+    }
+  }
+  if (whole_batch)
+    for (int b = 0; b < B; ++b) {
+      coef[b * 3] = (float)(D / Sx); coef[b * 3 + 1] = (float)(Sh / Sx); coef[b * 3 + 2] = (float)(D * Sh / (Sx * Sx));
+    }
+}
+
+__global__ __launch_bounds__(256) void rescale_bwd_apply_kernel(const bf16_t* __restrict__ g, const float* __restrict__ coef,
+                                                                long long n_per_sample, long long total, bf16_t* __restrict__ gh,
+                                                                float* __restrict__ gxw) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const float* c = coef + (i / n_per_sample) * 3;
+  const float gv = bf2f(g[i]);
+  gh[i] = f2bf(gv + c[0]);
+  gxw[i] = gv * c[1] - c[2];
+}
+
+__global__ __launch_bounds__(256) void sigmoid_kernel(const float* __restrict__ x, float* __restrict__ y, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) y[i] = 1.0f / (1.0f + expf(-x[i]));
+}
+
 // torch.optim.Adam (no amsgrad, no weight decay unless wd != 0 -> L2 added to the gradient as torch does)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
@@ -554,6 +642,48 @@ extern "C" int glare_attention_ds_bf16(const void* P, long long ldp, const float
   hipLaunchKernelGGL(attn_ds_kernel, dim3((unsigned)rows), dim3(256), 0, ST(stream), static_cast<const bf16_t*>(P), ldp, dP, lddp,
                      static_cast<const bf16_t*>(dO), ld_do, static_cast<const bf16_t*>(O), ld_o, d, static_cast<bf16_t*>(dS), ldds, n,
                      scale);
+  return glare_launch_status();
+}
+
+extern "C" int glare_mix_backward_bf16(const void* g, const void* a, const void* b, void* ga_or_null, void* gb, long long n, float w,
+                                       float* dw_out, void* workspace, size_t workspace_bytes, glare_stream_t stream) {
+  if (n < 0 || n % 8) return GLARE_ERR_INVALID;
+  if (!g || !a || !b || !gb || !dw_out) return GLARE_ERR_INVALID;
+  const int blocks = (int)(cdivll(n / 8, 256) < 1 ? 1 : (cdivll(n / 8, 256) > 512 ? 512 : cdivll(n / 8, 256)));
+  if (!workspace || workspace_bytes < (size_t)blocks * sizeof(float)) return GLARE_ERR_WORKSPACE;
+  const float s = 1.0f / (1.0f + expf(-w));
+  hipLaunchKernelGGL(mix_bwd_kernel, dim3(blocks), dim3(256), 0, ST(stream), static_cast<const bf16_t*>(g), static_cast<const bf16_t*>(a),
+                     static_cast<const bf16_t*>(b), static_cast<bf16_t*>(ga_or_null), static_cast<bf16_t*>(gb), n / 8, s,
+                     static_cast<float*>(workspace));
+  return glare_reduce_parts_f32(static_cast<const float*>(workspace), blocks, 1, s * (1.f - s), dw_out, 0, stream);
+}
+
+extern "C" size_t glare_mean_rescale_backward_workspace_bytes(int B, long long n_per_sample) {
+  if (B <= 0 || n_per_sample <= 0) return 0;
+  return ((size_t)B * 64 * 3 + (size_t)B * 3) * sizeof(float);
+}
+
+extern "C" int glare_mean_rescale_backward_bf16(const void* g, const void* h, const float* xw, void* gh, float* gxw, int B,
+                                                long long n_per_sample, int whole_batch_mean, void* workspace, size_t workspace_bytes,
+                                                glare_stream_t stream) {
+  if (!g || !h || !xw || !gh || !gxw || B <= 0 || n_per_sample <= 0) return GLARE_ERR_INVALID;
+  if (!workspace || workspace_bytes < glare_mean_rescale_backward_workspace_bytes(B, n_per_sample)) return GLARE_ERR_WORKSPACE;
+  float* partial = static_cast<float*>(workspace);
+  float* coef = partial + (size_t)B * 64 * 3;
+  hipLaunchKernelGGL(rescale_bwd_reduce_kernel, dim3(64, B), dim3(256), 0, ST(stream), static_cast<const bf16_t*>(g),
+                     static_cast<const bf16_t*>(h), xw, n_per_sample, 64, partial);
+  hipLaunchKernelGGL(rescale_bwd_finalize_kernel, dim3(1), dim3(64), 0, ST(stream), partial, B, 64, whole_batch_mean, coef);
+  const long long total = (long long)B * n_per_sample;
+  hipLaunchKernelGGL(rescale_bwd_apply_kernel, dim3((unsigned)cdivll(total, 256)), dim3(256), 0, ST(stream), static_cast<const bf16_t*>(g),
+                     coef, n_per_sample, total, static_cast<bf16_t*>(gh), gxw);
+  return glare_launch_status();
+}
+
+extern "C" int glare_sigmoid_f32(const float* x, float* y, long long n, glare_stream_t stream) {
+  if (n < 0) return GLARE_ERR_INVALID;
+  if (n == 0) return GLARE_OK;
+  if (!x || !y) return GLARE_ERR_INVALID;
+  hipLaunchKernelGGL(sigmoid_kernel, dim3((unsigned)cdivll(n, 256)), dim3(256), 0, ST(stream), x, y, n);
   return glare_launch_status();
 }
 

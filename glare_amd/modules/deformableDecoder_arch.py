@@ -6,9 +6,10 @@ never uses (scale / bias / enc, conv_out) so that checkpoints load unchanged."""
 import torch
 import torch.nn as nn
 
+from .. import autograd as A
 from .. import ops
 from ._base import HipModule, packed_conv, to_nchw, to_nhwc
-from .encoder_decoder import build_decoder_trunk, decoder_stem, gn_swish, Normalize
+from .encoder_decoder import build_decoder_trunk, conv_t, decoder_stem, gn_swish, gn_swish_t, Normalize
 from .ops.dcn import ModulatedDeformConvPack, modulated_deform_conv
 
 
@@ -31,6 +32,10 @@ class DCNv2Pack(ModulatedDeformConvPack, HipModule):
         pd = self._packed("dcn", lambda: ops.PackedDcn(self.weight, self.bias, self.deformable_groups))
         return ops.mdcn_forward_nhwc(x, om, pd, x_off=x_off, C=self.in_channels, mask_is_logit=True, padding=self.padding)
 
+    def train_nhwc(self, x, feat):
+        om = conv_t(feat, self.conv_offset, out_f32=True)
+        return A.dcn(x, om, self.weight, self.bias, self.deformable_groups, self.padding)
+
 
 class WarpBlock(HipModule):
     def __init__(self, in_channel):
@@ -41,6 +46,9 @@ class WarpBlock(HipModule):
     def forward_nhwc(self, x_vq, x_residual):
         r = ops.conv2d(x_vq, packed_conv(self, self.offset), x2=x_residual)  # torch.cat fused: two conv sources
         return self.dcn.forward_nhwc(x_vq, r)
+
+    def train_nhwc(self, x_vq, x_residual):
+        return self.dcn.train_nhwc(x_vq, conv_t(x_vq, self.offset, x2=x_residual))
 
     def forward(self, x_vq, x_residual):
         return to_nchw(self.forward_nhwc(to_nhwc(x_vq), to_nhwc(x_residual)))
@@ -54,6 +62,9 @@ class Mix(HipModule):
 
     def forward_nhwc(self, fea1, fea2):
         return ops.mix(fea1, fea2, float(self.w.detach()))
+
+    def train_nhwc(self, fea1, fea2):
+        return A.mix(fea1, fea2, self.w)
 
     def forward(self, fea1, fea2):
         return to_nchw(self.forward_nhwc(to_nhwc(fea1), to_nhwc(fea2)))
@@ -112,6 +123,27 @@ class MultiScaleDecoder2(HipModule):
         h = gn_swish(h, self.norm_out)
         B, H, W, _ = h.shape
         return ops.conv2d(h, packed_conv(self, self.residual_conv), out_mode=ops.OUT_PLANAR_F32).view(B, -1, H, W)
+
+    def train_nhwc(self, z, code_feats, enc_feats, whole_batch_mean=True):
+        """forward_nhwc with a tape (stage-3 training, VQLLFLOWDeformable_arch.py:249): only this module's parameters
+        are trained; z / code_feats / enc_feats come from frozen networks.  The mean of `h + x_w * mean(h)/mean(x_w)` is
+        taken over the per-rank batch, as each nn.DataParallel replica does.  -> fp32 NHWC image."""
+        B, H, W, C = z.shape
+        h = A.conv2d_small(z, self.conv_in.weight, self.conv_in.bias, layout="nhwc")
+        h = self.mid.block_2.train_nhwc(self.mid.attn_1.train_nhwc(self.mid.block_1.train_nhwc(h)))
+        for i_level in reversed(range(self.num_resolutions)):
+            lvl = self.up[i_level]
+            for i_block in range(self.num_res_blocks + 1):
+                h = lvl.block[i_block].train_nhwc(h)
+                if len(lvl.attn) > 0:
+                    h = lvl.attn[i_block].train_nhwc(h)
+            if i_level != 2:
+                h = self.mix[1 - i_level].train_nhwc(enc_feats[i_level], h)
+                x_w = self.warp[1 - i_level].train_nhwc(code_feats[1 - i_level], h)
+                h = A.mean_rescale(h, x_w, whole_batch_mean)
+            if i_level != 0:
+                h = lvl.upsample.train_nhwc(h)
+        return conv_t(gn_swish_t(h, self.norm_out), self.residual_conv, out_f32=True)
 
     def forward(self, z, code_decoder_output, enc_feat):
         return self.forward_nhwc(to_nhwc(z, bf16=False), [to_nhwc(f) for f in code_decoder_output],

@@ -319,3 +319,41 @@ def flow_pre_backward_(gz, z_in, hF, hF_off, g_logdet, M, t, eps, ghF, ghF_off):
                                               stream_handle()), "glare_flow_fwd_pre_backward_f32")
     r = reduce_parts(part)
     return r[:9].view(3, 3), r[9:]
+
+
+# ---- a8 glue backward -----------------------------------------------------------------------------------
+def mix_backward(g, a, b, w, want_ga=False):
+    """-> (ga or None, gb, dw fp32 [1])."""
+    require_cuda(g, a, b)
+    assert g.dtype == a.dtype == b.dtype == torch.bfloat16 and g.is_contiguous() and a.is_contiguous() and b.is_contiguous()
+    gb = torch.empty_like(g)
+    ga = torch.empty_like(g) if want_ga else None
+    dw = torch.empty(1, dtype=torch.float32, device=g.device)
+    ws = torch.empty(512, dtype=torch.float32, device=g.device)
+    check(_lib.lib().glare_mix_backward_bf16(ptr(g), ptr(a), ptr(b), ptr(ga), ptr(gb), _ll(g.numel()), _f(float(w)), ptr(dw), ptr(ws),
+                                             _sz(2048), stream_handle()), "glare_mix_backward_bf16")
+    return ga, gb, dw
+
+
+def mean_rescale_backward(g, h, xw, whole_batch):
+    require_cuda(g, h, xw)
+    assert g.dtype == h.dtype == torch.bfloat16 and xw.dtype == torch.float32
+    g, h, xw = g.contiguous(), h.contiguous(), xw.contiguous()
+    B = h.shape[0]
+    n = h.numel() // B
+    lib = _lib.lib()
+    lib.glare_mean_rescale_backward_workspace_bytes.restype = _sz
+    nws = lib.glare_mean_rescale_backward_workspace_bytes(_i(B), _ll(n))
+    ws = torch.empty(nws, dtype=torch.uint8, device=h.device)
+    gh, gxw = torch.empty_like(h), torch.empty_like(xw)
+    check(lib.glare_mean_rescale_backward_bf16(ptr(g), ptr(h), ptr(xw), ptr(gh), ptr(gxw), _i(B), _ll(n), _i(int(whole_batch)), ptr(ws),
+                                               _sz(nws), stream_handle()), "glare_mean_rescale_backward_bf16")
+    return gh, gxw
+
+
+def sigmoid(x):
+    require_cuda(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    y = torch.empty_like(x)
+    check(_lib.lib().glare_sigmoid_f32(ptr(x), ptr(y), _ll(x.numel()), stream_handle()), "glare_sigmoid_f32")
+    return y

@@ -334,6 +334,20 @@ int glare_flow_fwd_pre_backward_f32(float* gz, const float* z_in, const float* h
                                     const float* M_3x3_host, const float* t_3_host, float eps, void* ghF_bf16, int ghF_pitch,
                                     int ghF_off, float* gMt_partial, glare_stream_t stream);
 
+/* Backward of the a8 glue (stage-3 step, row a13).
+ * glare_mix_backward_bf16: out = s a + (1-s) b, s = sigmoid(w): gb = (1-s) g, ga = s g (or NULL), *dw_out = s(1-s) sum g(a-b);
+ *   n elements (n % 8 == 0); workspace >= 512 floats.
+ * glare_mean_rescale_backward_bf16: out = h + xw * (sum h / sum xw): gh (bf16), gxw (fp32) from g (bf16); means per
+ *   sample or over the whole per-rank batch (training), matching glare_mean_rescale_bf16.
+ * glare_sigmoid_f32: y = sigmoid(x) (the DCN mask the backward kernels take explicitly). */
+int glare_mix_backward_bf16(const void* g, const void* a, const void* b, void* ga_or_null, void* gb, long long n, float w,
+                            float* dw_out, void* workspace, size_t workspace_bytes, glare_stream_t stream);
+size_t glare_mean_rescale_backward_workspace_bytes(int B, long long n_per_sample);
+int glare_mean_rescale_backward_bf16(const void* g, const void* h, const float* xw, void* gh, float* gxw, int B,
+                                     long long n_per_sample, int whole_batch_mean, void* workspace, size_t workspace_bytes,
+                                     glare_stream_t stream);
+int glare_sigmoid_f32(const float* x, float* y, long long n, glare_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -350,3 +350,31 @@ def test_stage2_trainer_steps_reduce_the_loss():
     assert not torch.equal(before, p0.detach())
     grp = tr.opt.groups[0]
     assert p0.data_ptr() == grp.w.data_ptr() and p0.grad.data_ptr() == grp.g.data_ptr()
+
+
+def test_aft_decoder_backward_vs_oracle():
+    """Row a13's trainable part: every MultiScaleDecoder2 parameter gradient (trunk, Mix, WarpBlock convs, DCNv2 weight /
+    bias through glare_mdcn_backward_f32, mean rescale) against fp32 autograd of the oracle (differentiable torch DCNv2)."""
+    from glare_amd import modules as M
+    from glare_amd.synthetic import seeded_init_
+    from oracle import torch_ref as O
+
+    ref = seeded_init_(O.MultiScaleDecoder2().train(), 3)
+    hip = M.MultiScaleDecoder2(ch=128).train()
+    hip.load_state_dict(ref.state_dict(), strict=True)
+    hip.to(_dev())
+    g = torch.Generator().manual_seed(12)
+    B, h, w = 2, 8, 12
+    z = torch.randn(B, 3, h, w, generator=g) * 0.5
+    code = [_bf(torch.randn(B, 256, 2 * h, 2 * w, generator=g) * 0.5 + 0.2), _bf(torch.randn(B, 128, 4 * h, 4 * w, generator=g) * 0.5 + 0.2)]
+    enc = [_bf(torch.randn(B, 128, 4 * h, 4 * w, generator=g) * 0.5), _bf(torch.randn(B, 256, 2 * h, 2 * w, generator=g) * 0.5)]
+    wgt = torch.randn(B, 3, 4 * h, 4 * w, generator=g)
+    out_r = ref(z, code, enc)
+    (out_r * wgt).sum().backward()
+    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(_dev())
+    out = hip.train_nhwc(nh(z), [_nhwc16(c) for c in code], [_nhwc16(e) for e in enc], whole_batch_mean=True)
+    assert _rel(out.detach().cpu().permute(0, 3, 1, 2), out_r.detach()) < 3e-2
+    (out * nh(wgt)).sum().backward()
+    errs = _param_grad_errors(hip, ref)
+    _report(errs, 5e-2, 0.3)
+    assert any("warp.0.dcn.weight" in k for k in errs) and any(k.startswith("mix.") for k in errs)
