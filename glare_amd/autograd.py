@@ -262,3 +262,22 @@ class DcnFn(torch.autograd.Function):
 
 def dcn(x, om, weight, bias, dg, padding=1):
     return DcnFn.apply(x, om, weight, bias, dg, padding)
+
+
+class L1ClampLossFn(torch.autograd.Function):
+    """l1_loss of VQLLFLOWDModel.optimize_parameters (VQLLFLOWD_model.py:209-217) on the NHWC output."""
+
+    @staticmethod
+    def forward(ctx, rec, gt_nchw):
+        loss, grad = T.l1_clamp_loss(rec.contiguous(), gt_nchw.float().contiguous())
+        ctx.save_for_backward(grad)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None     # g is the scalar 1 of loss.backward(): an image-sized (3-channel) scale
+
+
+def l1_clamp_loss(rec, gt_nchw):
+    return L1ClampLossFn.apply(rec, gt_nchw)

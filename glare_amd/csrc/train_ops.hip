@@ -474,6 +474,32 @@ __global__ __launch_bounds__(256) void sigmoid_kernel(const float* __restrict__ 
   if (i < n) y[i] = 1.0f / (1.0f + expf(-x[i]));
 }
 
+// Stage-3 pixel loss (VQLLFLOWD_model.py:209-217): sr = clamp(rec, 0, 1), NaN -> 0 and masked;
+//   l1 = mean |sr - gt| over all elements; grad = sign(sr - gt) / n inside the clamp range, 0 outside / at NaN.
+// rec NHWC fp32 [B][HW][3]; gt NCHW fp32 (the loader's layout); partial[blk] = sum |.|
+__global__ __launch_bounds__(256) void l1_loss_kernel(const float* __restrict__ rec, const float* __restrict__ gt, long long HW, int C,
+                                                      long long total, float inv_n, float* __restrict__ grad,
+                                                      float* __restrict__ partial) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long long pix = i / C, b = pix / HW, q = pix % HW;
+    const float r = rec[i], t = gt[(b * C + c) * HW + q];
+    float g = 0.f;
+    if (r == r) {   // not NaN
+      const float sr = fminf(fmaxf(r, 0.f), 1.f), d = sr - t;
+      acc += fabsf(d);
+      if (r > 0.f && r < 1.f) g = d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);
+    }
+    grad[i] = g;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // torch.optim.Adam (no amsgrad, no weight decay unless wd != 0 -> L2 added to the gradient as torch does)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
@@ -685,6 +711,18 @@ extern "C" int glare_sigmoid_f32(const float* x, float* y, long long n, glare_st
   if (!x || !y) return GLARE_ERR_INVALID;
   hipLaunchKernelGGL(sigmoid_kernel, dim3((unsigned)cdivll(n, 256)), dim3(256), 0, ST(stream), x, y, n);
   return glare_launch_status();
+}
+
+extern "C" int glare_l1_clamp_loss_f32(const float* rec_nhwc, const float* gt_nchw, int B, long long HW, int C, float* loss_out,
+                                       float* grad_nhwc, void* workspace, size_t workspace_bytes, glare_stream_t stream) {
+  if (!rec_nhwc || !gt_nchw || !loss_out || !grad_nhwc || B <= 0 || HW <= 0 || C <= 0) return GLARE_ERR_INVALID;
+  const long long total = (long long)B * HW * C;
+  const int blocks = (int)(cdivll(total, 1024) < 1 ? 1 : (cdivll(total, 1024) > 512 ? 512 : cdivll(total, 1024)));
+  if (!workspace || workspace_bytes < (size_t)blocks * sizeof(float)) return GLARE_ERR_WORKSPACE;
+  const float inv_n = 1.0f / (float)total;
+  hipLaunchKernelGGL(l1_loss_kernel, dim3(blocks), dim3(256), 0, ST(stream), rec_nhwc, gt_nchw, HW, C, total, inv_n, grad_nhwc,
+                     static_cast<float*>(workspace));
+  return glare_reduce_parts_f32(static_cast<const float*>(workspace), blocks, 1, inv_n, loss_out, 0, stream);
 }
 
 extern "C" int glare_adam_step_f32(float* w, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1,

@@ -98,3 +98,37 @@ class Stage2Trainer:
         self.opt.step()                                            # :240
         self.netG.invalidate()                                     # packed inference weights are stale now
         return float(loss.detach())
+
+
+class Stage3Trainer:
+    """One optimisation step of stage 3 (row a13, VQLLFLOWDModel.optimize_parameters, VQLLFLOWD_model.py:187-232): the
+    conditional encoder, the flow (reverse) and the VQGAN decoder run without a tape exactly as in inference
+    (VQLLFLOWDeformable_arch.py:231-248); only `deformable_decoder` is trained.  Loss: the L1 term; the VGG-perceptual and
+    MS-SSIM terms (:219-220) are SURVEY.md row f1 and are not built (VGG16 weights cannot be fetched offline)."""
+
+    def __init__(self, netG, net_hq, lr_G=5e-5, weight_decay_G=0.0):
+        from . import autograd as A
+
+        self.A = A
+        self.netG, self.net_hq = netG, net_hq.eval()
+        for p in net_hq.parameters():
+            p.requires_grad_(False)
+        for n, p in netG.named_parameters():
+            p.requires_grad_(n.startswith("deformable_decoder."))
+        self.opt = FlatAdam([FlatGroup([p for n, p in netG.named_parameters() if n.startswith("deformable_decoder.")],
+                                       lr_G, weight_decay_G)])
+
+    def step(self, gt_img, lr_img):
+        """gt_img: fp32 NCHW in [0,1]; lr_img: fp32 NCHW low-light crop (log domain).  Returns the loss."""
+        G = self.netG
+        with torch.no_grad():
+            enc = G.RRDB.forward_nhwc(lr_img)
+            lat = G.flowUpsamplerNet.decode_nhwc(enc["color_map"], enc["cond_feat"])
+            _, _, feats = self.net_hq.decode_nhwc(lat, want_image=False)
+        self.opt.zero_grad()
+        rec = G.deformable_decoder.train_nhwc(lat, feats, enc["mid_feat"], whole_batch_mean=True)
+        loss = self.A.l1_clamp_loss(rec, gt_img)
+        loss.backward()
+        self.opt.step()
+        G.invalidate()
+        return float(loss.detach())

@@ -357,3 +357,17 @@ def sigmoid(x):
     y = torch.empty_like(x)
     check(_lib.lib().glare_sigmoid_f32(ptr(x), ptr(y), _ll(x.numel()), stream_handle()), "glare_sigmoid_f32")
     return y
+
+
+def l1_clamp_loss(rec_nhwc, gt_nchw):
+    """-> (loss fp32 [1], grad fp32 NHWC) of mean |clamp(rec,0,1) - gt| with the reference's NaN masking."""
+    require_cuda(rec_nhwc, gt_nchw)
+    assert rec_nhwc.dtype == gt_nchw.dtype == torch.float32 and rec_nhwc.is_contiguous() and gt_nchw.is_contiguous()
+    B, H, W, C = rec_nhwc.shape
+    assert tuple(gt_nchw.shape) == (B, C, H, W)
+    loss = torch.empty(1, dtype=torch.float32, device=rec_nhwc.device)
+    grad = torch.empty_like(rec_nhwc)
+    ws = torch.empty(512, dtype=torch.float32, device=rec_nhwc.device)
+    check(_lib.lib().glare_l1_clamp_loss_f32(ptr(rec_nhwc), ptr(gt_nchw), _i(B), _ll(H * W), _i(C), ptr(loss), ptr(grad), ptr(ws),
+                                             _sz(2048), stream_handle()), "glare_l1_clamp_loss_f32")
+    return loss, grad

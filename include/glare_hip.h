@@ -348,6 +348,12 @@ int glare_mean_rescale_backward_bf16(const void* g, const void* h, const float* 
                                      glare_stream_t stream);
 int glare_sigmoid_f32(const float* x, float* y, long long n, glare_stream_t stream);
 
+/* Stage-3 pixel loss and its gradient in one pass (VQLLFLOWD_model.py:209-217): sr = clamp(rec, 0, 1) with NaN -> 0 and
+ * masked, *loss_out = mean |sr - gt|, grad = d loss / d rec.  rec, grad: NHWC fp32 [B][HW][C]; gt: NCHW fp32.
+ * workspace >= 512 floats.  (The VGG-perceptual and MS-SSIM terms of :219-220 are SURVEY.md row f1, not built.) */
+int glare_l1_clamp_loss_f32(const float* rec_nhwc, const float* gt_nchw, int B, long long HW, int C, float* loss_out,
+                            float* grad_nhwc, void* workspace, size_t workspace_bytes, glare_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

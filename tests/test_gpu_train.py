@@ -378,3 +378,43 @@ def test_aft_decoder_backward_vs_oracle():
     errs = _param_grad_errors(hip, ref)
     _report(errs, 5e-2, 0.3)
     assert any("warp.0.dcn.weight" in k for k in errs) and any(k.startswith("mix.") for k in errs)
+
+
+def test_l1_clamp_loss_matches_reference_formula():
+    from glare_amd import autograd as A
+
+    g = torch.Generator().manual_seed(13)
+    rec = torch.randn(2, 3, 10, 12, generator=g) * 0.7 + 0.4
+    rec[0, 1, 2, 3] = float("nan")
+    gt = torch.rand(2, 3, 10, 12, generator=g)
+    rr = rec.clone().requires_grad_(True)
+    sr = rr.clamp(0, 1)
+    mask = ~torch.isnan(sr)
+    sr = torch.where(mask, sr, torch.zeros_like(sr))
+    ref = ((sr - gt) * mask).abs().mean()           # VQLLFLOWD_model.py:209-215
+    ref.backward()
+    rd = rec.permute(0, 2, 3, 1).contiguous().to(_dev()).requires_grad_(True)
+    loss = A.l1_clamp_loss(rd, gt.to(_dev()))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) < 1e-6
+    gref = torch.nan_to_num(rr.grad, nan=0.0)
+    assert torch.allclose(rd.grad.cpu().permute(0, 3, 1, 2), gref, atol=1e-8)
+
+
+def test_stage3_trainer_steps_reduce_the_loss():
+    from glare_amd import modules as M
+    from glare_amd.synthetic import seeded_init_
+    from glare_amd.train import Stage3Trainer
+
+    netG = seeded_init_(M.VQLLFLOWDeformable().train(), 0).to(_dev())
+    net_hq = seeded_init_(M.VQModel().eval(), 1).to(_dev())
+    tr = Stage3Trainer(netG, net_hq, lr_G=1e-4)
+    g = torch.Generator().manual_seed(14)
+    gt_img = torch.rand(1, 3, 64, 64, generator=g).to(_dev())
+    lr_img = (torch.randn(1, 3, 64, 64, generator=g) * 0.5 - 1.0).to(_dev())
+    frozen = netG.RRDB.encoder.conv_in.weight.detach().clone()
+    losses = [tr.step(gt_img, lr_img) for _ in range(8)]
+    print(losses)
+    assert all(l == l for l in losses) and losses[-1] < losses[0]
+    assert torch.equal(frozen, netG.RRDB.encoder.conv_in.weight.detach())        # only deformable_decoder trains
+    assert all(p.grad is None for n, p in netG.named_parameters() if not n.startswith("deformable_decoder."))
