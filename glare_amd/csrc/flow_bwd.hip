@@ -60,8 +60,8 @@ __global__ __launch_bounds__(FB_THREADS) void flow_h1_bwd_kernel(float* __restri
                                                                  const float* __restrict__ wz, int B, int H, int W,
                                                                  float* __restrict__ gwz_partial) {
   __shared__ float wl[9][64];
-  __shared__ float red[576];
-  for (int i = threadIdx.x; i < 576; i += FB_THREADS) { wl[i % 9][i / 9] = wz[i]; red[i] = 0.f; }
+  __shared__ float red[FB_THREADS / 64][576];
+  for (int i = threadIdx.x; i < 576; i += FB_THREADS) wl[i % 9][i / 9] = wz[i];
   __syncthreads();
   float acc[8][9];
 #pragma unroll
@@ -106,12 +106,20 @@ __global__ __launch_bounds__(FB_THREADS) void flow_h1_bwd_kernel(float* __restri
     dz += __shfl_xor(dz, 4, 64);
     if (live && grp == 0) gz[pix * 3] += dz;
   }
+  // deterministic: lanes with the same channel group (lane & 7) by a fixed shuffle tree, then the 4 waves in order
 #pragma unroll
   for (int e = 0; e < 8; ++e)
 #pragma unroll
-    for (int t = 0; t < 9; ++t) atomicAdd(&red[(grp * 8 + e) * 9 + t], acc[e][t]);
+    for (int t = 0; t < 9; ++t) {
+      float v = acc[e][t];
+      v += __shfl_xor(v, 8, 64);
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if ((threadIdx.x & 63) < 8) red[threadIdx.x >> 6][(grp * 8 + e) * 9 + t] = v;
+    }
   __syncthreads();
-  for (int i = threadIdx.x; i < 576; i += FB_THREADS) gwz_partial[(size_t)blockIdx.x * 576 + i] = red[i];
+  for (int i = threadIdx.x; i < 576; i += FB_THREADS)
+    gwz_partial[(size_t)blockIdx.x * 576 + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
 }
 
 __global__ __launch_bounds__(FB_THREADS) void flow_pre_bwd_kernel(float* __restrict__ gz, const float* __restrict__ z_in,
@@ -120,9 +128,7 @@ __global__ __launch_bounds__(FB_THREADS) void flow_pre_bwd_kernel(float* __restr
                                                                   long long npix, AffineParams ap, float eps,
                                                                   bf16_t* __restrict__ ghF, int gf_pitch, int gf_off,
                                                                   float* __restrict__ partial) {
-  __shared__ float red[12];
-  if (threadIdx.x < 12) red[threadIdx.x] = 0.f;
-  __syncthreads();
+  __shared__ float red[FB_THREADS / 64][12];
   float acc[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) acc[i] = 0.f;
@@ -158,10 +164,11 @@ __global__ __launch_bounds__(FB_THREADS) void flow_pre_bwd_kernel(float* __restr
 #pragma unroll
   for (int i = 0; i < 12; ++i) {
     const float v = wave_sum(acc[i]);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&red[i], v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i] = v;
   }
   __syncthreads();
-  if (threadIdx.x < 12) partial[(size_t)blockIdx.x * 12 + threadIdx.x] = red[threadIdx.x];
+  if (threadIdx.x < 12)
+    partial[(size_t)blockIdx.x * 12 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 int fb_blocks(long long items, int cap) {

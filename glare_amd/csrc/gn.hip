@@ -19,19 +19,20 @@ constexpr int GN_GROUPS = 32;
 // partial layout: [B][splits][32][2] fp32
 __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ partial,
                                                               long long HW, int C, int pitch, int off, int splits) {
-  __shared__ float red[GN_GROUPS * 2];
+  // deterministic block reduction (no float atomics: the statistics, and everything downstream, must not depend on
+  // the order in which waves happen to arrive): per-thread sums -> per-channel sums -> per-group sums, fixed order
+  __shared__ float vals[GN_THREADS][17];
+  __shared__ float chs[2048][2];
   const int b = blockIdx.y, sp = blockIdx.x;
   const int CP = C / 8;                 // 16-B chunks per pixel
   const int ppi = GN_THREADS / CP;      // pixels per iteration (C <= 2048)
   const int chunk = threadIdx.x % CP, pl = threadIdx.x / CP;
   const long long per = (HW + splits - 1) / splits;
   const long long p0 = sp * per, p1 = min(HW, p0 + per);
-  if (threadIdx.x < GN_GROUPS * 2) red[threadIdx.x] = 0.f;
-  __syncthreads();
   float s[8], q[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
-  if (pl < ppi) {
+  {
     const bf16_t* base = x + (size_t)b * HW * pitch + off + chunk * 8;
     auto accum = [&](const u32x4& v) {
 #pragma unroll
@@ -50,17 +51,23 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16_t* __re
       accum(v0); accum(v1); accum(v2); accum(v3);
     }
     for (; p < p1; p += ppi) accum(*reinterpret_cast<const u32x4*>(base + (size_t)p * pitch));
-    const int cpg = C / GN_GROUPS;
+  }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int g = (chunk * 8 + e) / cpg;
-      atomicAdd(&red[g * 2], s[e]);
-      atomicAdd(&red[g * 2 + 1], q[e]);
-    }
+  for (int e = 0; e < 8; ++e) { vals[threadIdx.x][e] = s[e]; vals[threadIdx.x][8 + e] = q[e]; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += GN_THREADS) {
+    const int ck = c / 8, e = c % 8;
+    float a = 0.f, d = 0.f;
+    for (int r = 0; r < ppi; ++r) { a += vals[r * CP + ck][e]; d += vals[r * CP + ck][8 + e]; }
+    chs[c][0] = a; chs[c][1] = d;
   }
   __syncthreads();
-  if (threadIdx.x < GN_GROUPS * 2)
-    partial[((size_t)b * splits + sp) * GN_GROUPS * 2 + threadIdx.x] = red[threadIdx.x];
+  if (threadIdx.x < GN_GROUPS * 2) {
+    const int g = threadIdx.x >> 1, k = threadIdx.x & 1, cpg = C / GN_GROUPS;
+    float a = 0.f;
+    for (int i = 0; i < cpg; ++i) a += chs[g * cpg + i][k];
+    partial[((size_t)b * splits + sp) * GN_GROUPS * 2 + threadIdx.x] = a;
+  }
 }
 
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ partial,
