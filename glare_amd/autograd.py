@@ -7,8 +7,6 @@ The reference gets these gradients from `loss.backward()` over cuDNN / ATen (LLF
 VQLLFLOWD_model.py:226-229); activations here are NHWC bf16, parameters and their gradients fp32.
 """
 import torch
-import torch.nn.functional as F
-
 from . import ops
 from . import train_ops as T
 
@@ -34,13 +32,7 @@ def _grad_bf16(g, y, act, cout):
 
 def _data_grad(g16, weight, cout, stride, upsample, out_f32=False):
     """dx of a conv as a stride-1 conv of the (dilated) gradient with the flipped, transposed filter."""
-    cp = g16.shape[-1]
-    wt = weight.detach().float().transpose(0, 1)
-    if weight.shape[-1] == 3:
-        wt = wt.flip(2, 3)
-    if cp != cout:
-        wt = F.pad(wt, (0, 0, 0, 0, 0, cp - cout))
-    pc = ops.PackedConv(wt.contiguous())
+    pc = ops.PackedConv(weight, dgrad_pad=g16.shape[-1])     # flip / transpose / channel pad happen inside the pack kernel
     mode = ops.OUT_NHWC_F32 if out_f32 else ops.OUT_NHWC_BF16
     if stride == 2:
         return ops.conv2d(T.dilate2(g16), pc, out_mode=mode)
@@ -81,8 +73,8 @@ class Conv2dFn(torch.autograd.Function):
                 return col
 
             dwb = T.conv_weight_grad(build, g16, cout, cin_tot * kk)
-            dw = dwb[:, :-1].reshape(cout, cin_tot, k, k)
-            db = dwb[:, -1].contiguous() if has_bias else None
+            dw = dwb[:, :-1].unflatten(1, (cin_tot, k, k))      # views of the GEMM output: no copy
+            db = dwb[:, -1] if has_bias else None
         if ctx.needs_input_grad[0] or (has_x2 and ctx.needs_input_grad[4]):
             dxa = _data_grad(g16, weight, cout, stride, upsample)
             if has_x2:
@@ -124,8 +116,8 @@ class SmallConv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             dwb = T.conv_weight_grad(lambda ldp, ones_row: T.im2col_t_f32(x, strides, bhw, cin, k, k // 2, ldp=ldp, ones_row=ones_row),
                                      g16, cout, cin * k * k)
-            dw = dwb[:, :-1].reshape(cout, cin, k, k)
-            db = dwb[:, -1].contiguous() if has_bias else None
+            dw = dwb[:, :-1].unflatten(1, (cin, k, k))
+            db = dwb[:, -1] if has_bias else None
         if ctx.needs_input_grad[0]:
             assert layout == "nhwc", "the image needs no gradient"
             dx = _data_grad(g16, weight, cout, 1, False, out_f32=True)

@@ -391,8 +391,10 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
 
 // Packs OIHW fp32 weights into the stage-ordered bf16 image the kernel copies verbatim:
 // [co_tile][stage][tap][kstep][khalf][TN][8], zero-filled outside Cout / Cin.
+// dgrad != 0: `w` is the FORWARD filter [Cin_real][Cout][KS][KS] of which the data-gradient filter is wanted
+// (w'[co][ci][tap] = w[ci][co][KK-1-tap], input channels ci >= Cin_real zero): no flip/transpose/pad pass on the host.
 __global__ void pack_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin, int KS,
-                                   int TN, int KSTEPS, int n_stages, long long total) {
+                                   int TN, int KSTEPS, int n_stages, long long total, int dgrad, int Cin_real) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   long long t = i;
@@ -406,7 +408,11 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, bf16_t* __restri
   const int co = ct * TN + n;
   const int ci = (s * KSTEPS + ks) * 16 + khalf * 8 + e;
   float v = 0.f;
-  if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * KS * KS + tap];
+  if (dgrad) {
+    if (co < Cout && ci < Cin_real) v = w[((size_t)ci * Cout + co) * KS * KS + (KS * KS - 1 - tap)];
+  } else if (co < Cout && ci < Cin) {
+    v = w[((size_t)co * Cin + ci) * KS * KS + tap];
+  }
   out[i] = f2bf(v);
 }
 
@@ -487,7 +493,21 @@ extern "C" int glare_conv2d_pack_weight(const float* w_oihw, int cout, int cin_t
   const int kc = 16 * v.ksteps;
   const int stages = (cin_total + kc - 1) / kc;
   hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     w_oihw, (bf16_t*)packed_bf16, cout, cin_total, ksize, v.tn, v.ksteps, stages, total);
+                     w_oihw, (bf16_t*)packed_bf16, cout, cin_total, ksize, v.tn, v.ksteps, stages, total, 0, cin_total);
+  return glare_launch_status();
+}
+
+extern "C" int glare_conv2d_pack_weight_dgrad(const float* w_oihw, int cout, int cin, int ksize, int cout_padded, void* packed_bf16,
+                                              glare_stream_t stream) {
+  // the data-gradient conv has cin output channels and cout_padded (>= cout, % 8 == 0) input channels
+  if (!w_oihw || !packed_bf16 || cout <= 0 || cin <= 0 || cout_padded < cout || (cout_padded % 8)) return GLARE_ERR_INVALID;
+  const long long total = glare_conv2d_packed_weight_elems(cin, cout_padded, ksize);
+  if (total <= 0) return GLARE_ERR_UNSUPPORTED;
+  const Variant v = pick_variant(ksize, cin);
+  const int kc = 16 * v.ksteps;
+  const int stages = (cout_padded + kc - 1) / kc;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_oihw,
+                     (bf16_t*)packed_bf16, cin, cout_padded, ksize, v.tn, v.ksteps, stages, total, 1, cout);
   return glare_launch_status();
 }
 

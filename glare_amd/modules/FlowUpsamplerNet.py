@@ -231,24 +231,28 @@ class FlowUpsamplerNet(HipModule):
                 A, c = torch.eye(3, dtype=torch.float64), torch.zeros(3, dtype=torch.float64)
         assert self.layers[len(self.layers) - 1].flow_coupling != "noCoupling"
 
-        def fold(conv):
-            if hasattr(conv, "actnorm"):
-                s_ = torch.exp(conv.actnorm.logs.reshape(-1))
-                return conv.weight * s_.view(-1, 1, 1, 1), conv.actnorm.bias.reshape(-1) * s_
-            s_ = torch.exp(conv.logs.reshape(-1) * conv.logscale_factor)
-            return conv.weight * s_.view(-1, 1, 1, 1), conv.bias * s_
+        # batched folds: stack the raw parameters of all coupling steps once, then ONE op per fold for all steps
+        def fold(convs):
+            w = torch.stack([c.weight for c in convs])                                   # [n, co, ci, k, k]
+            if hasattr(convs[0], "actnorm"):                                             # flow.Conv2d: conv + ActNorm
+                s_ = torch.exp(torch.stack([c.actnorm.logs.reshape(-1) for c in convs]))
+                b = torch.stack([c.actnorm.bias.reshape(-1) for c in convs]) * s_
+            else:                                                                        # Conv2dZeros
+                s_ = torch.exp(torch.stack([c.logs.reshape(-1) for c in convs]) * convs[0].logscale_factor)
+                b = torch.stack([c.bias for c in convs]) * s_
+            return w * s_.view(s_.shape[0], -1, 1, 1, 1), b
 
-        a0 = [fold(a.fAffine[0]) for a in steps]
-        f0 = [fold(a.fFeatures[0]) for a in steps]
-        stack = lambda items, i: torch.stack([it[i] for it in items])
-        c2, c4 = [fold(a.fAffine[2]) for a in steps], [fold(a.fAffine[4]) for a in steps]
-        f2, f4 = [fold(a.fFeatures[2]) for a in steps], [fold(a.fFeatures[4]) for a in steps]
+        a0w, a0b = fold([a.fAffine[0] for a in steps])
+        f0w, f0b = fold([a.fFeatures[0] for a in steps])
+        c2w, c2b = fold([a.fAffine[2] for a in steps])
+        c4w, c4b = fold([a.fAffine[4] for a in steps])
+        f2w, f2b = fold([a.fFeatures[2] for a in steps])
+        f4w, f4b = fold([a.fFeatures[4] for a in steps])
         P = {"Ms": torch.stack(Ms), "ts": torch.stack(ts),
-             "wz": torch.stack([w[:, 0].reshape(64, 9) for w, _ in a0]),
-             "ftA_w": torch.cat([w[:, 1:] for w, _ in a0], 0), "ftA_b": torch.cat([b for _, b in a0], 0),
-             "f0_w": torch.cat([w for w, _ in f0], 0), "f0_b": torch.cat([b for _, b in f0], 0),
-             "c2_w": stack(c2, 0), "c2_b": stack(c2, 1), "c4_w": stack(c4, 0), "c4_b": stack(c4, 1),
-             "f2_w": stack(f2, 0), "f2_b": stack(f2, 1), "f4_w": stack(f4, 0), "f4_b": stack(f4, 1)}
+             "wz": a0w[:, :, 0].reshape(len(steps), 64, 9),
+             "ftA_w": a0w[:, :, 1:].reshape(-1, 64, 3, 3), "ftA_b": a0b.reshape(-1),
+             "f0_w": f0w.reshape(-1, 64, 3, 3), "f0_b": f0b.reshape(-1),
+             "c2_w": c2w, "c2_b": c2b, "c4_w": c4w, "c4_b": c4b, "f2_w": f2w, "f2_b": f2b, "f4_w": f4w, "f4_b": f4b}
         return P, const_ld, float(steps[0].affine_eps), dev
 
     def train_nll_terms(self, gt, ft, mean):
@@ -280,13 +284,8 @@ _FLOW_KEYS = ("Ms", "ts", "wz", "ftA_w", "ftA_b", "f0_w", "f0_b", "c2_w", "c2_b"
 
 
 def _wt(w, pad_to=None):
-    """Filter of the data-gradient conv: OIHW -> IOHW, taps flipped; input channels zero-padded to `pad_to`."""
-    wt = w.detach().float().transpose(0, 1)
-    if w.shape[-1] == 3:
-        wt = wt.flip(2, 3)
-    if pad_to is not None and pad_to != wt.shape[1]:
-        wt = torch.nn.functional.pad(wt, (0, 0, 0, 0, 0, pad_to - wt.shape[1]))
-    return ops.PackedConv(wt.contiguous())
+    """Packed filter of the data-gradient conv (flip / transpose / channel pad inside the pack kernel)."""
+    return ops.PackedConv(w, dgrad_pad=w.shape[0] if pad_to is None else pad_to)
 
 
 class FlowNLLFn(torch.autograd.Function):
@@ -343,18 +342,15 @@ class FlowNLLFn(torch.autograd.Function):
         ghF = torch.empty(B, H, W, n * 8, dtype=torch.bfloat16, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)
         dM, dt, dwz = torch.empty(n, 3, 3, **f32), torch.empty(n, 3, **f32), torch.empty(n, 64, 9, **f32)
-        dc2w, dc2b = torch.empty(n, 64, 64, 1, 1, **f32), torch.empty(n, 64, **f32)
-        dc4w, dc4b = torch.empty(n, 4, 64, 3, 3, **f32), torch.empty(n, 4, **f32)
-        df2w, df2b = torch.empty(n, 64, 64, 1, 1, **f32), torch.empty(n, 64, **f32)
-        df4w, df4b = torch.empty(n, 6, 64, 3, 3, **f32), torch.empty(n, 6, **f32)
+        # weight | bias gradients of the per-step convs land in these (GEMM output layout: last column = bias)
+        dc2, dc4 = torch.empty(n, 64, 65, **f32), torch.empty(n, 4, 577, **f32)
+        df2, df4 = torch.empty(n, 64, 65, **f32), torch.empty(n, 6, 577, **f32)
         for k in reversed(range(n)):                                   # the sequential adjoint sweep
             gh4 = T.flow_post_backward_(gz, z_pre[k], h4s[k], gld, eps)
-            dwb = T.conv_weight_grad(lambda ldp, ones: T.im2col_t(h2s[k], 3, ldp=ldp, ones_row=ones), gh4, 4, 576)
-            dc4w[k], dc4b[k] = dwb[:, :-1].reshape(4, 64, 3, 3), dwb[:, -1]
+            T.conv_weight_grad(lambda ldp, ones: T.im2col_t(h2s[k], 3, ldp=ldp, ones_row=ones), gh4, 4, 576, out=dc4[k])
             gh2 = ops.conv2d(gh4, _wt(c4_w[k], 8))
             T.act_backward_(gh2, h2s[k], "relu")
-            dwb = T.conv_weight_grad(lambda ldp, ones: T.im2col_t(h1s[k], 1, ldp=ldp, ones_row=ones), gh2, 64, 64)
-            dc2w[k], dc2b[k] = dwb[:, :-1].reshape(64, 64, 1, 1), dwb[:, -1]
+            T.conv_weight_grad(lambda ldp, ones: T.im2col_t(h1s[k], 1, ldp=ldp, ones_row=ones), gh2, 64, 64, out=dc2[k])
             ops.conv2d(gh2, _wt(c2_w[k]), out=gftA, out_off=64 * k)
             T.act_backward_(gftA, h1s[k], "relu", C=64, g_off=64 * k)
             dwz[k] = T.flow_h1_backward_(gz, gftA, 64 * k, z_pre[k], wz[k])
@@ -363,21 +359,21 @@ class FlowNLLFn(torch.autograd.Function):
         gh2f, gh1f = torch.empty_like(h1f), torch.empty_like(h1f)
         ghF2, gh2f2 = ghF.view(P, n * 8), gh2f.view(P, n * 64)
         for s in range(n):                                             # the z-independent feature nets
-            dwb = T.conv_weight_grad(lambda ldp, ones: T.im2col_t(h2f, 3, cin=64, in_off=64 * s, ldp=ldp, ones_row=ones),
-                                     ghF2[:, 8 * s:8 * s + 8], 6, 576)
-            df4w[s], df4b[s] = dwb[:, :-1].reshape(6, 64, 3, 3), dwb[:, -1]
+            T.conv_weight_grad(lambda ldp, ones: T.im2col_t(h2f, 3, cin=64, in_off=64 * s, ldp=ldp, ones_row=ones),
+                               ghF2[:, 8 * s:8 * s + 8], 6, 576, out=df4[s])
             ops.conv2d(ghF, _wt(f4_w[s], 8), cin=8, in_off=8 * s, out=gh2f, out_off=64 * s)
             T.act_backward_(gh2f, h2f, "relu", C=64, g_off=64 * s, y_off=64 * s)
-            dwb = T.conv_weight_grad(lambda ldp, ones: T.im2col_t(h1f, 1, cin=64, in_off=64 * s, ldp=ldp, ones_row=ones),
-                                     gh2f2[:, 64 * s:64 * s + 64], 64, 64)
-            df2w[s], df2b[s] = dwb[:, :-1].reshape(64, 64, 1, 1), dwb[:, -1]
+            T.conv_weight_grad(lambda ldp, ones: T.im2col_t(h1f, 1, cin=64, in_off=64 * s, ldp=ldp, ones_row=ones),
+                               gh2f2[:, 64 * s:64 * s + 64], 64, 64, out=df2[s])
             ops.conv2d(gh2f, _wt(f2_w[s]), cin=64, in_off=64 * s, out=gh1f, out_off=64 * s)
             T.act_backward_(gh1f, h1f, "relu", C=64, g_off=64 * s, y_off=64 * s)
         col = lambda ldp, ones: T.im2col_t(ft, 3, ldp=ldp, ones_row=ones)
         dwb = T.conv_weight_grad(col, gh1f, n * 64, 576)
-        df0w, df0b = dwb[:, :-1].reshape(n * 64, 64, 3, 3), dwb[:, -1].contiguous()
+        df0w, df0b = dwb[:, :-1].unflatten(1, (64, 3, 3)), dwb[:, -1]
         dwb = T.conv_weight_grad(col, gftA, n * 64, 576)
-        dftAw, dftAb = dwb[:, :-1].reshape(n * 64, 64, 3, 3), dwb[:, -1].contiguous()
+        dftAw, dftAb = dwb[:, :-1].unflatten(1, (64, 3, 3)), dwb[:, -1]
+        dc2w, dc2b, dc4w, dc4b = dc2[:, :, :-1].unflatten(2, (64, 1, 1)), dc2[:, :, -1], dc4[:, :, :-1].unflatten(2, (64, 3, 3)), dc4[:, :, -1]
+        df2w, df2b, df4w, df4b = df2[:, :, :-1].unflatten(2, (64, 1, 1)), df2[:, :, -1], df4[:, :, :-1].unflatten(2, (64, 3, 3)), df4[:, :, -1]
         gft = ops.conv2d(gh1f, _wt(f0_w))
         gft = ops.conv2d(gftA, _wt(ftA_w), residual=gft)
         return (gft, gmean, None, None, dM.cpu(), dt.cpu(), dwz, dftAw, dftAb, df0w, df0b, dc2w, dc2b, dc4w, dc4b, df2w, df2b, df4w, df4b)

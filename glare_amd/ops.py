@@ -48,19 +48,25 @@ class ConvDesc(ctypes.Structure):
 class PackedConv:
     """A conv filter packed once for the MFMA kernel (weights bf16 stage-ordered, bias fp32)."""
 
-    def __init__(self, weight_oihw, bias=None):
+    def __init__(self, weight_oihw, bias=None, dgrad_pad=None):
+        """dgrad_pad = P: pack the filter of the data-gradient conv (P >= cout input channels, cin outputs) instead."""
         require_cuda(weight_oihw)
         w = weight_oihw.detach().float().contiguous()
-        self.cout, self.cin, kh, kw = w.shape
+        cout, cin, kh, kw = w.shape
         assert kh == kw and kh in (1, 3)
         self.ksize = kh
         lib = _lib.lib()
         lib.glare_conv2d_packed_weight_elems.restype = _ll
+        self.cout, self.cin = (cout, cin) if dgrad_pad is None else (cin, dgrad_pad)
         n = lib.glare_conv2d_packed_weight_elems(_i(self.cout), _i(self.cin), _i(kh))
         assert n > 0
         self.packed = torch.empty(n, dtype=torch.bfloat16, device=w.device)
-        check(lib.glare_conv2d_pack_weight(ptr(w), _i(self.cout), _i(self.cin), _i(kh), ptr(self.packed),
-                                           stream_handle()), "glare_conv2d_pack_weight")
+        if dgrad_pad is None:
+            check(lib.glare_conv2d_pack_weight(ptr(w), _i(cout), _i(cin), _i(kh), ptr(self.packed), stream_handle()),
+                  "glare_conv2d_pack_weight")
+        else:
+            check(lib.glare_conv2d_pack_weight_dgrad(ptr(w), _i(cout), _i(cin), _i(kh), _i(dgrad_pad), ptr(self.packed),
+                                                     stream_handle()), "glare_conv2d_pack_weight_dgrad")
         self.bias = None if bias is None else bias.detach().float().contiguous()
 
 

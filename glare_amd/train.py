@@ -34,16 +34,29 @@ class FlatGroup:
             k = p.numel()
             self.w[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.w[off:off + k].view(p.shape)
-            p.grad = self.g[off:off + k].view(p.shape)
             off += k
 
     def zero_grad(self):
-        self.g.zero_()
+        """Gradients are left None: autograd then hands over each gradient tensor without an accumulation kernel per
+        parameter; collect() gathers them into the flat buffer with a few concatenations."""
+        for p in self.params:
+            p.grad = None
+
+    def collect(self, chunk=64):
         off = 0
-        for p in self.params:   # autograd may have replaced .grad by a fresh tensor: re-point it at the flat buffer
+        for i in range(0, len(self.params), chunk):
+            ps = self.params[i:i + chunk]
+            n = sum(p.numel() for p in ps)
+            if all(p.grad is None for p in ps):
+                self.g[off:off + n].zero_()
+            else:
+                torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(torch.float32) for p in ps],
+                          out=self.g[off:off + n])
+            off += n
+        off = 0
+        for p in self.params:   # expose the gathered gradient as the parameter's .grad (a view of the flat buffer)
             k = p.numel()
-            if p.grad is None or p.grad.data_ptr() != self.g.data_ptr() + 4 * off:
-                p.grad = self.g[off:off + k].view(p.shape)
+            p.grad = self.g[off:off + k].view(p.shape)
             off += k
 
     def all_reduce(self):
@@ -66,6 +79,7 @@ class FlatAdam:
         for g in self.groups:
             if g.w.numel() == 0:
                 continue
+            g.collect()
             world = g.all_reduce()
             T.adam_step_(g.w, g.g, g.m, g.v, self.t, g.lr, self.betas, self.eps, g.weight_decay, grad_scale=1.0 / world)
 

@@ -231,7 +231,7 @@ def adam_step_(w, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1
 
 
 # ---- composite backward passes ------------------------------------------------------------------------
-def conv_weight_grad(x_col_builder, g_bf16, cout, n_rows):
+def conv_weight_grad(x_col_builder, g_bf16, cout, n_rows, out=None):
     """dW|db = gO^T . colT^T by split-K NT GEMM.  x_col_builder(ldp, ones_row) -> colT [n_rows+1, ldp];
     g_bf16: bf16 [B,OH,OW,pitch>=cout] or a 2-D (row-strided) view [P, >=cout].  Returns fp32 [cout, n_rows+1]
     (last column = bias gradient)."""
@@ -239,15 +239,16 @@ def conv_weight_grad(x_col_builder, g_bf16, cout, n_rows):
         g_bf16 = g_bf16.view(-1, g_bf16.shape[-1])
     P = g_bf16.shape[0]
     tiles = ((cout + 255) // 256) * ((n_rows + 1 + 127) // 128)
-    S = max(1, min((768 + tiles - 1) // tiles, P // 2048, 64))
+    S = max(1, min((512 + tiles - 1) // tiles, P // 2048, 64))
     ldp = _rup(P, 64 * S)
     colT = x_col_builder(ldp, n_rows)
     gT = transpose(g_bf16, ld_out=ldp)[:cout]
     ks = ldp // S
     a3 = gT.as_strided((S, cout, ks), (ks, ldp, 1))
     b3 = colT.as_strided((S, n_rows + 1, ks), (ks, ldp, 1))
-    parts = gemm_nt(a3, b3)
-    return reduce_parts(parts) if S > 1 else parts[0]
+    if S == 1:
+        return gemm_nt(a3[0], b3[0], out=out) if out is not None else gemm_nt(a3, b3)[0]
+    return reduce_parts(gemm_nt(a3, b3), out=out)
 
 
 def attention_backward(q, k, v, o, do, ln2_scale=0.6931471805599453):

@@ -103,6 +103,11 @@ long long glare_conv2d_packed_weight_elems(int cout, int cin_total, int ksize);
 /* Packs fp32 OIHW weights (device) into the kernel's stage-ordered bf16 image (device). */
 int glare_conv2d_pack_weight(const float* w_oihw, int cout, int cin_total, int ksize, void* packed_bf16,
                              glare_stream_t stream);
+/* Packs the filter of the DATA-GRADIENT convolution straight from the forward OIHW filter: w'[ci][co][tap] =
+ * w[co][ci][k*k-1-tap], co padded with zeros to cout_padded (% 8 == 0).  The result is a packed filter for a conv with
+ * cout_padded input and cin output channels (glare_conv2d_packed_weight_elems(cin, cout_padded, ksize) elements). */
+int glare_conv2d_pack_weight_dgrad(const float* w_oihw, int cout, int cin, int ksize, int cout_padded, void* packed_bf16,
+                                   glare_stream_t stream);
 int glare_conv2d_bf16(const glare_conv_desc* desc_host, glare_stream_t stream);
 /* Fused GroupNorm statistics: the conv epilogue leaves per-tile partial sums of its output; the reduce turns
  * them into the [B][1][32][2] (sum, sum of squares per group) block glare_groupnorm_apply_bf16 consumes, so the

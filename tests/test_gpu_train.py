@@ -349,7 +349,7 @@ def test_stage2_trainer_steps_reduce_the_loss():
     assert losses[-1] < losses[0]
     assert not torch.equal(before, p0.detach())
     grp = tr.opt.groups[0]
-    assert p0.data_ptr() == grp.w.data_ptr() and p0.grad.data_ptr() == grp.g.data_ptr()
+    assert p0.data_ptr() == grp.w.data_ptr() and p0.grad.data_ptr() == grp.g.data_ptr()   # views of the flat buffers
 
 
 def test_aft_decoder_backward_vs_oracle():
@@ -418,3 +418,4 @@ def test_stage3_trainer_steps_reduce_the_loss():
     assert all(l == l for l in losses) and losses[-1] < losses[0]
     assert torch.equal(frozen, netG.RRDB.encoder.conv_in.weight.detach())        # only deformable_decoder trains
     assert all(p.grad is None for n, p in netG.named_parameters() if not n.startswith("deformable_decoder."))
+    assert all(p.grad is not None for n, p in netG.named_parameters() if n.startswith("deformable_decoder."))

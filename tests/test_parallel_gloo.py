@@ -68,7 +68,9 @@ def _grad_worker(rank, world, port, q):
     assert all(p.data_ptr() >= grp.w.data_ptr() for p in net.parameters())       # parameters are views of the flat buffer
     grp.zero_grad()
     x = torch.full((2, 5), float(rank + 1))
-    net(x).sum().backward()                                                       # accumulates INTO the flat grad buffer
+    net(x).sum().backward()
+    grp.collect()                                                                 # gathers .grad into the flat buffer
+    assert all(p.grad.data_ptr() >= grp.g.data_ptr() for p in net.parameters())
     local = grp.g.clone()
     w = grp.all_reduce()
     q.put((rank, w, local, grp.g.clone()))
