@@ -240,7 +240,10 @@ class DcnFn(torch.autograd.Function):
         gout = ops.nhwc_to_nchw(g.contiguous())
         w32 = weight.detach().float().contiguous()
         b32 = bias.detach().float().contiguous() if with_bias else xin.new_empty(1)
-        gin, goff, gmask = torch.zeros_like(xin), torch.zeros_like(offset), torch.zeros_like(mask)
+        # the reference always scatters grad_input (deform_conv.py:161-165); here it is produced only when the sampled
+        # feature needs it (in stage 3 x is the frozen VQ decoder's feature): a NULL grad_input skips the atomics pass
+        gin = torch.zeros_like(xin) if ctx.needs_input_grad[0] else None
+        goff, gmask = torch.zeros_like(offset), torch.zeros_like(mask)
         gw, gb = torch.zeros_like(w32), torch.zeros_like(b32)
         deform_conv_ext.modulated_deform_conv_backward(xin, w32, b32, xin.new_empty(0), offset, mask, xin.new_empty(0), gin, gw, gb,
                                                        goff, gmask, gout, kh, kw, 1, 1, padding, padding, 1, 1, 1, dg, with_bias)
