@@ -1,5 +1,5 @@
-from .deform_conv import (ModulatedDeformConv, ModulatedDeformConvFunction, ModulatedDeformConvPack, deform_conv_ext,  # noqa: F401
-                          modulated_deform_conv)
+from .deform_conv import (DeformConv, DeformConvFunction, DeformConvPack, ModulatedDeformConv, ModulatedDeformConvFunction,  # noqa: F401
+                          ModulatedDeformConvPack, deform_conv, deform_conv_ext, modulated_deform_conv)
 
-__all__ = ["ModulatedDeformConv", "ModulatedDeformConvPack", "ModulatedDeformConvFunction", "modulated_deform_conv",
-           "deform_conv_ext"]
+__all__ = ["DeformConv", "DeformConvPack", "DeformConvFunction", "deform_conv", "ModulatedDeformConv", "ModulatedDeformConvPack",
+           "ModulatedDeformConvFunction", "modulated_deform_conv", "deform_conv_ext"]

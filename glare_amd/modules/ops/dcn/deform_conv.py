@@ -78,12 +78,55 @@ class _DeformConvExt:
                                           _i(dilation_w), _i(group), _i(deformable_group), ptr(ws), _sz(ws.numel()),
                                           stream_handle()), "glare_mdcn_backward_f32")
 
+    # ---- DCN v1 (deform_conv_ext.cpp:52-104): the unmodulated operator is DCNv2 with mask == 1 and no
+    # bias (same sampling rule, deform_conv_cuda_kernel.cu:190-236 vs :571-633), so the three v1 entry points run on the
+    # v2 kernels.  NOTE the v1 argument order: W before H (deform_conv.py:67-69).
     @staticmethod
-    def deform_conv_forward(*args):
-        raise NotImplementedError("DCN v1 is not on the GLARE path (SURVEY.md row f4)")
+    def _v1_geometry(input, weight, offset, kW, kH, group, deformable_group):
+        if not input.is_cuda:
+            raise RuntimeError("deform conv is not implemented on CPU")  # deform_conv_ext.cpp:67
+        if input.dim() != 4 or offset.dim() != 4:
+            raise RuntimeError("4D input and offset tensors expected")
+        if (weight.shape[2], weight.shape[3]) != (kH, kW) or input.shape[1] != weight.shape[1] * group:
+            raise RuntimeError("invalid kernel / channel configuration")    # shape_check, deform_conv_cuda.cpp:64-150
+        if offset.shape[1] != 2 * deformable_group * kH * kW:
+            raise RuntimeError("invalid number of channels of offset")
+        ones = torch.ones(offset.shape[0], deformable_group * kH * kW, offset.shape[2], offset.shape[3], dtype=torch.float32,
+                          device=input.device)
+        return ones
 
-    deform_conv_backward_input = deform_conv_forward
-    deform_conv_backward_parameters = deform_conv_forward
+    @staticmethod
+    def deform_conv_forward(input, weight, offset, output, columns, ones, kW, kH, dW, dH, padW, padH, dilationW, dilationH, group,
+                            deformable_group, im2col_step):
+        mask = _DeformConvExt._v1_geometry(input, weight, offset, kW, kH, group, deformable_group)
+        _DeformConvExt.modulated_deform_conv_forward(input.contiguous(), weight.contiguous(), None, ones, offset, mask, output, columns,
+                                                     kH, kW, dH, dW, padH, padW, dilationH, dilationW, group, deformable_group, False)
+        return 1   # deform_conv_cuda.cpp:255
+
+    @staticmethod
+    def deform_conv_backward_input(input, offset, gradOutput, gradInput, gradOffset, weight, columns, kW, kH, dW, dH, padW, padH,
+                                   dilationW, dilationH, group, deformable_group, im2col_step):
+        mask = _DeformConvExt._v1_geometry(input, weight, offset, kW, kH, group, deformable_group)
+        gw, gm = torch.zeros_like(weight), torch.zeros_like(mask)
+        _DeformConvExt.modulated_deform_conv_backward(input.contiguous(), weight.contiguous(), None, None, offset, mask, columns,
+                                                      gradInput, gw, None, gradOffset, gm, gradOutput, kH, kW, dH, dW, padH, padW,
+                                                      dilationH, dilationW, group, deformable_group, False)
+        return 1
+
+    @staticmethod
+    def deform_conv_backward_parameters(input, offset, gradOutput, gradWeight, columns, ones, kW, kH, dW, dH, padW, padH, dilationW,
+                                        dilationH, group, deformable_group, scale, im2col_step):
+        mask = torch.ones(offset.shape[0], deformable_group * kH * kW, offset.shape[2], offset.shape[3], dtype=torch.float32,
+                          device=input.device)
+        if (gradWeight.shape[2], gradWeight.shape[3]) != (kH, kW):
+            raise RuntimeError("invalid kernel configuration")
+        gw, go, gm = torch.zeros_like(gradWeight), torch.zeros_like(offset), torch.zeros_like(mask)
+        w0 = torch.zeros_like(gradWeight)   # grad_weight does not depend on the filter values
+        _DeformConvExt.modulated_deform_conv_backward(input.contiguous(), w0, None, None, offset, mask, columns, None, gw, None, go,
+                                                      gm, gradOutput, kH, kW, dH, dW, padH, padW, dilationH, dilationW, group,
+                                                      deformable_group, False)
+        gradWeight.add_(gw, alpha=float(scale))   # filter-sized accumulate (deform_conv_cuda.cpp:478-482)
+        return 1
 
 
 deform_conv_ext = _DeformConvExt()
@@ -129,6 +172,99 @@ class ModulatedDeformConvFunction(Function):
 
 
 modulated_deform_conv = ModulatedDeformConvFunction.apply
+
+
+class DeformConvFunction(Function):
+    """DCN v1 (deform_conv.py:33-118): not on the GLARE path, provided so that the `deform_conv_ext` surface is complete."""
+
+    @staticmethod
+    def forward(ctx, input, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1, im2col_step=64):
+        if input is not None and input.dim() != 4:
+            raise ValueError("Expected 4D tensor as input, got %dD tensor instead." % input.dim())
+        ctx.stride, ctx.padding, ctx.dilation = _pair(stride), _pair(padding), _pair(dilation)
+        ctx.groups, ctx.deformable_groups, ctx.im2col_step = groups, deformable_groups, im2col_step
+        ctx.save_for_backward(input, offset, weight)
+        output = input.new_empty(DeformConvFunction._output_size(input, weight, ctx.padding, ctx.dilation, ctx.stride))
+        ctx.bufs_ = [input.new_empty(0), input.new_empty(0)]
+        if not input.is_cuda:
+            raise NotImplementedError
+        step = min(ctx.im2col_step, input.shape[0])
+        assert input.shape[0] % step == 0, "im2col step must divide batchsize"
+        deform_conv_ext.deform_conv_forward(input, weight, offset, output, ctx.bufs_[0], ctx.bufs_[1], weight.size(3), weight.size(2),
+                                            ctx.stride[1], ctx.stride[0], ctx.padding[1], ctx.padding[0], ctx.dilation[1],
+                                            ctx.dilation[0], ctx.groups, ctx.deformable_groups, step)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        input, offset, weight = ctx.saved_tensors
+        grad_input = grad_offset = grad_weight = None
+        if not grad_output.is_cuda:
+            raise NotImplementedError
+        step = min(ctx.im2col_step, input.shape[0])
+        geo = (weight.size(3), weight.size(2), ctx.stride[1], ctx.stride[0], ctx.padding[1], ctx.padding[0], ctx.dilation[1],
+               ctx.dilation[0], ctx.groups, ctx.deformable_groups)
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            grad_input, grad_offset = torch.zeros_like(input), torch.zeros_like(offset)
+            deform_conv_ext.deform_conv_backward_input(input, offset, grad_output, grad_input, grad_offset, weight, ctx.bufs_[0], *geo, step)
+        if ctx.needs_input_grad[2]:
+            grad_weight = torch.zeros_like(weight)
+            deform_conv_ext.deform_conv_backward_parameters(input, offset, grad_output, grad_weight, ctx.bufs_[0], ctx.bufs_[1], *geo, 1, step)
+        return (grad_input, grad_offset, grad_weight, None, None, None, None, None)
+
+    @staticmethod
+    def _output_size(input, weight, padding, dilation, stride):
+        size = (input.size(0), weight.size(0))
+        for d in range(input.dim() - 2):
+            kernel = dilation[d] * (weight.size(d + 2) - 1) + 1
+            size += ((input.size(d + 2) + 2 * padding[d] - kernel) // stride[d] + 1,)
+        if not all(s > 0 for s in size):
+            raise ValueError("convolution input is too small (output would be %s)" % "x".join(map(str, size)))
+        return size
+
+
+deform_conv = DeformConvFunction.apply
+
+
+class DeformConv(nn.Module):  # deform_conv.py:191-245
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1,
+                 bias=False):
+        super().__init__()
+        assert not bias
+        assert in_channels % groups == 0 and out_channels % groups == 0
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding, self.dilation = _pair(kernel_size), _pair(stride), _pair(padding), _pair(dilation)
+        self.groups, self.deformable_groups = groups, deformable_groups
+        self.transposed, self.output_padding = False, _single(0)
+        self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels // groups, *self.kernel_size))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        n = self.in_channels
+        for k in self.kernel_size:
+            n *= k
+        stdv = 1.0 / math.sqrt(n)
+        self.weight.data.uniform_(-stdv, stdv)
+
+    def forward(self, x, offset):
+        return deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups, self.deformable_groups)
+
+
+class DeformConvPack(DeformConv):  # deform_conv.py:248-286
+    _version = 2
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.conv_offset = nn.Conv2d(self.in_channels, self.deformable_groups * 2 * self.kernel_size[0] * self.kernel_size[1],
+                                     kernel_size=self.kernel_size, stride=_pair(self.stride), padding=_pair(self.padding),
+                                     dilation=_pair(self.dilation), bias=True)
+        self.conv_offset.weight.data.zero_()
+        self.conv_offset.bias.data.zero_()
+
+    def forward(self, x):
+        return deform_conv(x, self.conv_offset(x), self.weight, self.stride, self.padding, self.dilation, self.groups,
+                           self.deformable_groups)
 
 
 class ModulatedDeformConv(nn.Module):

@@ -140,3 +140,31 @@ def test_backward_zero_offset_equals_conv_gradients():
     assert torch.allclose(ts[0].grad, xr.grad, rtol=1e-4, atol=1e-4)
     assert torch.allclose(ts[3].grad, wr.grad, rtol=1e-4, atol=1e-3)
     assert torch.allclose(ts[4].grad, br.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_dcn_v1_surface_matches_oracle_with_unit_mask():
+    """Row f4: the three DCN v1 exports of deform_conv_ext (deform_conv_ext.cpp:52-104) through the reference-shaped
+    DeformConvFunction.  v1 == v2 with mask == 1 and no bias, which is how the oracle evaluates it."""
+    from glare_amd.modules.ops.dcn import DeformConvPack, deform_conv, deform_conv_ext
+
+    x, off, m, w, b, go = _bwd_case(2, 128, 8, 10, 128, 4, seed=21)
+    ones = np.ones_like(m.numpy())
+    ts = [t.clone().cuda().requires_grad_() for t in (x, off, w)]
+    out = deform_conv(ts[0], ts[1], ts[2], 1, 1, 1, 1, 4)
+    ref = c_ref.dcn_forward(x.numpy(), off.numpy(), ones, w.numpy(), None, dg=4)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref, rtol=2e-4, atol=2e-4 * float(np.abs(ref).max()))
+    out.backward(go.cuda())
+    gref = c_ref.dcn_backward(x.numpy(), off.numpy(), ones, w.numpy(), go.numpy(), with_bias=False, dg=4)
+    _close_grad(ts[0].grad.cpu().numpy(), gref[0], "grad_input")
+    _close_grad(ts[1].grad.cpu().numpy(), gref[1], "grad_offset")
+    _close_grad(ts[2].grad.cpu().numpy(), gref[3], "grad_weight")
+    # `scale` and accumulation of deform_conv_backward_parameters (deform_conv_cuda.cpp:478-482); W-before-H argument order
+    gw = torch.full_like(ts[2].detach(), 0.25)
+    e = x.new_empty(0).cuda()
+    rc = deform_conv_ext.deform_conv_backward_parameters(x.cuda(), off.cuda(), go.cuda(), gw, e, e, 3, 3, 1, 1, 1, 1, 1, 1, 1, 4, 0.5, 2)
+    assert rc == 1
+    _close_grad((gw.cpu().numpy() - 0.25) / 0.5, gref[3], "grad_weight (scaled, accumulated)")
+    with pytest.raises(RuntimeError):
+        deform_conv_ext.deform_conv_forward(x, w, off, x.new_empty(1), e, e, 3, 3, 1, 1, 1, 1, 1, 1, 1, 4, 2)   # CPU input
+    pack = DeformConvPack(128, 128, 3, padding=1, deformable_groups=4)
+    assert sorted(k for k, _ in pack.named_parameters()) == ["conv_offset.bias", "conv_offset.weight", "weight"]
