@@ -4,12 +4,51 @@ Mirrors code/infer_dataset_lol.py:113-153: reflect-pad 20 px at the bottom and t
 :71-72), HWC uint8 -> NCHW float /255 (`t`, :42), log(clamp(x + 1e-3, min=1e-3)) (:127-128,
 `log_low: true`); after the network: crop `[:, :, :h, 20:]`, clamp to [0,1], GT-mean gain with the
 cv2.COLOR_BGR2GRAY weights applied to RGB-ordered data (:142-144), PSNR (utils/utils2.py:32-36)."""
+import ctypes
 import math
 
 import numpy as np
 import torch
 
 PAD = 20
+
+
+# ---- device versions (csrc/harness.hip): batched, uint8 in, PSNR out ------------------------------------------
+def preprocess_device(imgs_u8):
+    """uint8 device tensor [B,H,W,3] -> fp32 [B,3,H+20,W+20] in the log domain (same arithmetic as preprocess())."""
+    from . import _lib
+
+    _lib.require_cuda(imgs_u8)
+    assert imgs_u8.dtype == torch.uint8 and imgs_u8.dim() == 4 and imgs_u8.shape[3] == 3 and imgs_u8.is_contiguous()
+    B, H, W, _ = imgs_u8.shape
+    out = torch.empty(B, 3, H + PAD, W + PAD, dtype=torch.float32, device=imgs_u8.device)
+    _lib.check(_lib.lib().glare_harness_preprocess_u8(_lib.ptr(imgs_u8), ctypes.c_int(B), ctypes.c_int(H), ctypes.c_int(W),
+                                                      ctypes.c_int(PAD), _lib.ptr(out), _lib.stream_handle()),
+               "glare_harness_preprocess_u8")
+    return out
+
+
+def postprocess_device(out_nchw, h, w, gts_u8=None):
+    """network output [B,3,Hp,Wp] (device) -> (restored float [B,h,w,3], psnr float64 [B] or None), all on the device."""
+    from . import _lib
+
+    _lib.require_cuda(out_nchw, gts_u8)
+    out_nchw = out_nchw.float().contiguous()
+    B, _, Hp, Wp = out_nchw.shape
+    lib = _lib.lib()
+    lib.glare_harness_postprocess_workspace_bytes.restype = ctypes.c_size_t
+    nws = lib.glare_harness_postprocess_workspace_bytes(ctypes.c_int(B))
+    ws = torch.empty(nws, dtype=torch.uint8, device=out_nchw.device)
+    restored = torch.empty(B, h, w, 3, dtype=torch.float32, device=out_nchw.device)
+    psnr_t = None
+    if gts_u8 is not None:
+        assert gts_u8.dtype == torch.uint8 and tuple(gts_u8.shape) == (B, h, w, 3) and gts_u8.is_contiguous()
+        psnr_t = torch.empty(B, dtype=torch.float64, device=out_nchw.device)
+    i = ctypes.c_int
+    _lib.check(lib.glare_harness_postprocess_f32(_lib.ptr(out_nchw), _lib.ptr(gts_u8), i(B), i(h), i(w), i(Hp), i(Wp), i(PAD),
+                                                 _lib.ptr(restored), _lib.ptr(psnr_t), _lib.ptr(ws), ctypes.c_size_t(nws),
+                                                 _lib.stream_handle()), "glare_harness_postprocess_f32")
+    return restored, psnr_t
 
 
 def preprocess(img_u8):

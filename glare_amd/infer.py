@@ -21,8 +21,9 @@ from .synthetic import seeded_init_, synthetic_gt, synthetic_lowlight
 
 
 def enhance_batch(netG, net_vq, imgs_u8, device):
-    """uint8 [n,H,W,3] -> list of float [H,W,3] network outputs (before the GT gain), via the fused NHWC graph."""
-    lr = harness.preprocess_batch(imgs_u8).to(device)
+    """uint8 [n,H,W,3] (host) -> network outputs [n,3,H+20,W+20] on the device (before the GT gain), via the fused NHWC
+    graph.  The images cross PCIe once, as uint8; padding / log transform run on the device (csrc/harness.hip)."""
+    lr = harness.preprocess_device(torch.from_numpy(np.ascontiguousarray(imgs_u8)).to(device))
     with torch.no_grad():
         out = netG.reverse_flow_nhwc(net_vq, lr)["out"]
     return out
@@ -37,12 +38,10 @@ def run(n_images, batch=8, h=400, w=600, seed=1234):
     gts = synthetic_gt(n_images, h, w, seed=seed + 1)
 
     def psnr_slice(lo, hi):
-        out = enhance_batch(netG, net_vq, lows[lo:hi], device).cpu()
-        vals = []
-        for i in range(hi - lo):
-            restored = harness.postprocess(out[i:i + 1], h, gts[lo + i])
-            vals.append(harness.psnr(gts[lo + i] / 255.0, restored))
-        return torch.tensor(vals, dtype=torch.float64, device=device).view(-1, 1)
+        out = enhance_batch(netG, net_vq, lows[lo:hi], device)
+        gt = torch.from_numpy(np.ascontiguousarray(gts[lo:hi])).to(device)
+        _, vals = harness.postprocess_device(out, h, w, gt)       # crop, clamp, GT-mean gain, PSNR: all on the device
+        return vals.view(-1, 1)
 
     local = parallel.run_sharded(n_images, psnr_slice, rank, world, batch=batch)
     if local is None:

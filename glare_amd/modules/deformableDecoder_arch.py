@@ -61,7 +61,8 @@ class Mix(HipModule):
         self.mix_block = nn.Sigmoid()
 
     def forward_nhwc(self, fea1, fea2):
-        return ops.mix(fea1, fea2, float(self.w.detach()))
+        # the scalar is read back once (cached with the packed weights): no host sync inside the launch sequence
+        return ops.mix(fea1, fea2, self._packed("w", lambda: float(self.w.detach())))
 
     def train_nhwc(self, fea1, fea2):
         return A.mix(fea1, fea2, self.w)

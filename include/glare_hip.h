@@ -359,6 +359,19 @@ int glare_sigmoid_f32(const float* x, float* y, long long n, glare_stream_t stre
 int glare_l1_clamp_loss_f32(const float* rec_nhwc, const float* gt_nchw, int B, long long HW, int C, float* loss_out,
                             float* grad_nhwc, void* workspace, size_t workspace_bytes, glare_stream_t stream);
 
+/* ---- a14 / f2: the inference harness' pre- and post-processing on the device (code/infer_dataset_lol.py:113-153) ------
+ * pre : uint8 HWC [B][H][W][3] -> fp32 NCHW [B][3][H+pad][W+pad]: reflect pad bottom / left (impad :71-72), /255 (t :42),
+ *       log(clamp(x + 1e-3, min = 1e-3)) (:127-128).
+ * post: network output fp32 NCHW [B][3][Hp][Wp] -> restored float HWC [B][h][w][3] = clamp(out[:, :, :h, pad:], 0, 1)
+ *       (:135-140); with gt (uint8 HWC [B][h][w][3]): gain = gray(gt/255)/gray(restored) with gray = 0.114 ch0 + 0.587 ch1 +
+ *       0.299 ch2 (:142-144), clip, and psnr[b] = 10 log10(1 / mean((gt/255 - restored)^2)) (utils2.py:32-36). */
+int glare_harness_preprocess_u8(const unsigned char* img_hwc, int B, int H, int W, int pad, float* out_nchw,
+                                glare_stream_t stream);
+size_t glare_harness_postprocess_workspace_bytes(int B);
+int glare_harness_postprocess_f32(const float* out_nchw, const unsigned char* gt_hwc_or_null, int B, int h, int w, int Hp,
+                                  int Wp, int pad, float* restored_hwc, double* psnr_or_null, void* workspace,
+                                  size_t workspace_bytes, glare_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
