@@ -276,3 +276,93 @@ class L1ClampLossFn(torch.autograd.Function):
 
 def l1_clamp_loss(rec, gt_nchw):
     return L1ClampLossFn.apply(rec, gt_nchw)
+
+
+class Clamp01Fn(torch.autograd.Function):
+    """sr = rec.clamp(0, 1); sr[isnan] = 0 (VQLLFLOWD_model.py:209-215)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return T.clamp01(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return T.clamp01_backward(x, g)
+
+
+def clamp01(x):
+    return Clamp01Fn.apply(x)
+
+
+class MaxPool2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return T.maxpool2(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return T.maxpool2_backward(x, g)
+
+
+def maxpool2(x):
+    return MaxPool2Fn.apply(x)
+
+
+class MseFn(torch.autograd.Function):
+    """F.mse_loss(a, b) of bf16 feature maps; only `a` is differentiated."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        loss, ga = T.mse_loss(a.contiguous(), b.contiguous(), want_grad=ctx.needs_input_grad[0])
+        ctx.save_for_backward(ga)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (ga,) = ctx.saved_tensors
+        return (ga * g.to(ga.dtype) if ga is not None else None), None
+
+
+def mse_loss(a, b):
+    return MseFn.apply(a, b)
+
+
+class MSSSIMTermsFn(torch.autograd.Function):
+    """The ten level scalars of msssim() (pytorch_msssim/__init__.py:71-83): (sim[5], cs[5]) of sr vs gt, NHWC fp32, value range
+    1 (sr is clamped to [0, 1], so ssim()'s data-dependent `L` is 1).  Backward: gradients of the ten scalars -> d / d sr."""
+
+    @staticmethod
+    def forward(ctx, x, y, windows):
+        xs, ys, moms, outs = [x.contiguous()], [y.contiguous()], [], []
+        C1, C2 = 0.01 ** 2, 0.03 ** 2
+        for lvl in range(5):
+            mom, out = T.ssim_forward(xs[lvl], ys[lvl], windows[lvl], C1, C2)
+            moms.append(mom)
+            outs.append(out)
+            if lvl < 4:
+                xs.append(T.avgpool2(xs[lvl]))
+                ys.append(T.avgpool2(ys[lvl]))
+        ctx.windows = windows
+        ctx.save_for_backward(*xs, *ys, *moms)
+        o = torch.stack(outs)                      # [5, 2]: ten scalars
+        return o[:, 0].contiguous(), o[:, 1].contiguous()
+
+    @staticmethod
+    def backward(ctx, g_sim, g_cs):
+        t = ctx.saved_tensors
+        xs, ys, moms = t[0:5], t[5:10], t[10:15]
+        g10 = torch.cat([g_sim.float().reshape(5), g_cs.float().reshape(5)]).contiguous()
+        g_next = None
+        for lvl in reversed(range(5)):
+            g_next = T.ssim_backward(xs[lvl], ys[lvl], moms[lvl], ctx.windows[lvl], 0.01 ** 2, 0.03 ** 2, g10, lvl, g_next)
+        return g_next, None, None
+
+
+def msssim_terms(x, y, windows):
+    return MSSSIMTermsFn.apply(x, y, windows)

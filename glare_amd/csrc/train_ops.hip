@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256) void l1_loss_kernel(const float* __restrict__ 
     if (r == r) {   // not NaN
       const float sr = fminf(fmaxf(r, 0.f), 1.f), d = sr - t;
       acc += fabsf(d);
-      if (r > 0.f && r < 1.f) g = d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);
+      if (r >= 0.f && r <= 1.f) g = d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);   // torch.clamp: closed interval
     }
     grad[i] = g;
   }

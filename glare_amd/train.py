@@ -117,13 +117,16 @@ class Stage2Trainer:
 class Stage3Trainer:
     """One optimisation step of stage 3 (row a13, VQLLFLOWDModel.optimize_parameters, VQLLFLOWD_model.py:187-232): the
     conditional encoder, the flow (reverse) and the VQGAN decoder run without a tape exactly as in inference
-    (VQLLFLOWDeformable_arch.py:231-248); only `deformable_decoder` is trained.  Loss: the L1 term; the VGG-perceptual and
-    MS-SSIM terms (:219-220) are SURVEY.md row f1 and are not built (VGG16 weights cannot be fetched offline)."""
+    (VQLLFLOWDeformable_arch.py:231-248); only `deformable_decoder` is trained.  Loss (:217-223): L1 + 0.01 * VGG16-feature
+    perceptual + 0.2 * (1 - MS-SSIM(normalize=True)).  The perceptual network's weights are the caller's (`perceptual=`): the
+    reference downloads torchvision's pretrained VGG16, which is not available offline; pass None to train on L1 + MS-SSIM."""
 
-    def __init__(self, netG, net_hq, lr_G=5e-5, weight_decay_G=0.0):
+    def __init__(self, netG, net_hq, lr_G=5e-5, weight_decay_G=0.0, perceptual=None, use_msssim=True):
         from . import autograd as A
+        from . import losses
 
-        self.A = A
+        self.A, self.losses, self.perceptual, self.use_msssim = A, losses, perceptual, use_msssim
+        self.last_terms = {}
         self.netG, self.net_hq = netG, net_hq.eval()
         for p in net_hq.parameters():
             p.requires_grad_(False)
@@ -141,8 +144,26 @@ class Stage3Trainer:
             _, _, feats = self.net_hq.decode_nhwc(lat, want_image=False)
         self.opt.zero_grad()
         rec = G.deformable_decoder.train_nhwc(lat, feats, enc["mid_feat"], whole_batch_mean=True)
-        loss = self.A.l1_clamp_loss(rec, gt_img)
+        loss, self.last_terms = stage3_loss(rec, gt_img, self.perceptual, self.use_msssim)
         loss.backward()
         self.opt.step()
         G.invalidate()
         return float(loss.detach())
+
+
+def stage3_loss(rec_nhwc, gt_nchw, perceptual=None, use_msssim=True):
+    """total = l1 + 0.01 * percep + 0.2 * (1 - msssim(sr, gt, normalize=True)) on the NHWC fp32 network output
+    (VQLLFLOWD_model.py:209-223).  Returns (total, {term: float-able tensor})."""
+    from . import autograd as A
+    from . import losses, ops
+
+    gt_nchw = gt_nchw.float().contiguous()
+    terms = {"l1_loss": A.l1_clamp_loss(rec_nhwc, gt_nchw)}
+    if perceptual is not None or use_msssim:
+        sr = A.clamp01(rec_nhwc)
+        gt_nhwc = ops.nchw_to_nhwc(gt_nchw, bf16=False)
+        if perceptual is not None:
+            terms["percep_loss"] = perceptual(sr, gt_nhwc) * 0.01
+        if use_msssim:
+            terms["ssim_loss"] = (1 - losses.msssim(sr, gt_nhwc, normalize=True)) * 0.2
+    return sum(terms.values()), terms

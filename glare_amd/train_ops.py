@@ -372,3 +372,91 @@ def l1_clamp_loss(rec_nhwc, gt_nchw):
     check(_lib.lib().glare_l1_clamp_loss_f32(ptr(rec_nhwc), ptr(gt_nchw), _i(B), _ll(H * W), _i(C), ptr(loss), ptr(grad), ptr(ws),
                                              _sz(2048), stream_handle()), "glare_l1_clamp_loss_f32")
     return loss, grad
+
+
+# ---- stage-3 loss stack (row f1) ------------------------------------------------------------------------
+def clamp01(x):
+    require_cuda(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    y = torch.empty_like(x)
+    check(_lib.lib().glare_clamp01_f32(ptr(x), ptr(y), _ll(x.numel()), stream_handle()), "glare_clamp01_f32")
+    return y
+
+
+def clamp01_backward(x, g):
+    require_cuda(x, g)
+    g = g.contiguous()
+    gx = torch.empty_like(x)
+    check(_lib.lib().glare_clamp01_backward_f32(ptr(x), ptr(g), ptr(gx), _ll(x.numel()), stream_handle()), "glare_clamp01_backward_f32")
+    return gx
+
+
+def avgpool2(x):
+    require_cuda(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    B, H, W, C = x.shape
+    y = torch.empty(B, H // 2, W // 2, C, dtype=torch.float32, device=x.device)
+    check(_lib.lib().glare_avgpool2_f32(ptr(x), ptr(y), _i(B), _i(H), _i(W), _i(C), stream_handle()), "glare_avgpool2_f32")
+    return y
+
+
+def _win(window):
+    return (ctypes.c_float * len(window))(*[float(v) for v in window])
+
+
+def ssim_forward(x, y, window, C1, C2):
+    """x, y fp32 NHWC -> (moments [B,OH,OW,C,5], out fp32 [2] = (mean ssim_map, mean cs_map))."""
+    require_cuda(x, y)
+    B, H, W, C = x.shape
+    ws = len(window)
+    lib = _lib.lib()
+    lib.glare_ssim_workspace_bytes.restype = _sz
+    nws = lib.glare_ssim_workspace_bytes()
+    wsb = torch.empty(nws, dtype=torch.uint8, device=x.device)
+    mom = torch.empty(B, H - ws + 1, W - ws + 1, C, 5, dtype=torch.float32, device=x.device)
+    out = torch.empty(2, dtype=torch.float32, device=x.device)
+    check(lib.glare_ssim_forward_f32(ptr(x), ptr(y), _i(B), _i(H), _i(W), _i(C), _win(window), _i(ws), _f(C1), _f(C2), ptr(mom), ptr(out),
+                                     ptr(wsb), _sz(nws), stream_handle()), "glare_ssim_forward_f32")
+    return mom, out
+
+
+def ssim_backward(x, y, mom, window, C1, C2, g10, level, g_next):
+    require_cuda(x, y, mom, g10, g_next)
+    B, H, W, C = x.shape
+    scratch = torch.empty(mom.shape[:-1] + (3,), dtype=torch.float32, device=x.device)
+    gx = torch.empty_like(x)
+    check(_lib.lib().glare_ssim_backward_f32(ptr(x), ptr(y), ptr(mom), _i(B), _i(H), _i(W), _i(C), _win(window), _i(len(window)), _f(C1),
+                                             _f(C2), ptr(g10), _i(level), ptr(g_next), ptr(scratch), ptr(gx), stream_handle()),
+          "glare_ssim_backward_f32")
+    return gx
+
+
+def maxpool2(x):
+    require_cuda(x)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    B, H, W, C = x.shape
+    y = torch.empty(B, H // 2, W // 2, C, dtype=torch.bfloat16, device=x.device)
+    check(_lib.lib().glare_maxpool2_bf16(ptr(x), ptr(y), _i(B), _i(H), _i(W), _i(C), stream_handle()), "glare_maxpool2_bf16")
+    return y
+
+
+def maxpool2_backward(x, g):
+    require_cuda(x, g)
+    B, H, W, C = x.shape
+    g = g.contiguous()
+    gx = torch.empty_like(x)
+    check(_lib.lib().glare_maxpool2_backward_bf16(ptr(x), ptr(g), ptr(gx), _i(B), _i(H), _i(W), _i(C), stream_handle()),
+          "glare_maxpool2_backward_bf16")
+    return gx
+
+
+def mse_loss(a, b, want_grad=True):
+    """bf16 feature maps -> (loss fp32 [1], grad_a bf16 or None)."""
+    require_cuda(a, b)
+    assert a.dtype == b.dtype == torch.bfloat16 and a.is_contiguous() and b.is_contiguous() and a.shape == b.shape
+    loss = torch.empty(1, dtype=torch.float32, device=a.device)
+    ga = torch.empty_like(a) if want_grad else None
+    ws = torch.empty(256, dtype=torch.float64, device=a.device)
+    check(_lib.lib().glare_mse_loss_bf16(ptr(a), ptr(b), _ll(a.numel()), ptr(loss), ptr(ga), ptr(ws), _sz(2048), stream_handle()),
+          "glare_mse_loss_bf16")
+    return loss, ga

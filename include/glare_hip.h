@@ -372,6 +372,32 @@ int glare_harness_postprocess_f32(const float* out_nchw, const unsigned char* gt
                                   int Wp, int pad, float* restored_hwc, double* psnr_or_null, void* workspace,
                                   size_t workspace_bytes, glare_stream_t stream);
 
+/* ---- f1: the rest of the stage-3 loss (VQLLFLOWD_model.py:209-223) -------------------------------------------------
+ * glare_clamp01_f32 / _backward: sr = clamp(rec, 0, 1) with NaN -> 0 (:209-215) and torch.clamp's gradient mask.
+ * MS-SSIM (modules/pytorch_msssim/__init__.py:21-98) on NHWC fp32 images: per pyramid level glare_ssim_forward_f32 writes the
+ *   five windowed moments per output pixel (moments: [B][OH][OW][C][5], OH = H - window + 1) and ssim_cs_out[2] = (mean
+ *   ssim_map, mean cs_map); glare_avgpool2_f32 builds the next level (F.avg_pool2d 2x2).  glare_ssim_backward_f32 turns the
+ *   gradients of the ten level scalars (g_sim_cs_5_5: d/d sim[0..4] then d/d cs[0..4]) into the image gradient of `level`,
+ *   adding the pooled gradient of the next level (g_next: [B][H/2][W/2][C] or NULL); scratch_maps: [B][OH][OW][C][3].
+ *   window_host: the 1-D normalised Gaussian (<= 11 taps) exactly as create_window() builds it; C1, C2 as ssim() does.
+ * VGG16-feature perceptual loss (modules/losses.py:12-40): convolutions = glare_conv2d_bf16 (+ReLU); here the 2x2 max-pool
+ *   (backward to the first maximum in scan order, as ATen) and F.mse_loss of two bf16 feature maps with grad 2(a-b)/n. */
+int glare_clamp01_f32(const float* x, float* y, long long n, glare_stream_t stream);
+int glare_clamp01_backward_f32(const float* x, const float* g, float* gx, long long n, glare_stream_t stream);
+int glare_avgpool2_f32(const float* x_nhwc, float* y_nhwc, int B, int H, int W, int C, glare_stream_t stream);
+size_t glare_ssim_workspace_bytes(void);
+int glare_ssim_forward_f32(const float* x_nhwc, const float* y_nhwc, int B, int H, int W, int C, const float* window_host,
+                           int window_size, float C1, float C2, float* moments, float* ssim_cs_out, void* workspace,
+                           size_t workspace_bytes, glare_stream_t stream);
+int glare_ssim_backward_f32(const float* x_nhwc, const float* y_nhwc, const float* moments, int B, int H, int W, int C,
+                            const float* window_host, int window_size, float C1, float C2, const float* g_sim_cs_5_5,
+                            int level, const float* g_next_or_null, float* scratch_maps, float* gx, glare_stream_t stream);
+int glare_maxpool2_bf16(const void* x_nhwc, void* y_nhwc, int B, int H, int W, int C, glare_stream_t stream);
+int glare_maxpool2_backward_bf16(const void* x_nhwc, const void* g_nhwc, void* gx_nhwc, int B, int H, int W, int C,
+                                 glare_stream_t stream);
+int glare_mse_loss_bf16(const void* a, const void* b, long long n, float* loss_out, void* grad_a_or_null, void* workspace,
+                        size_t workspace_bytes, glare_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

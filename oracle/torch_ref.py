@@ -646,3 +646,98 @@ def gray_mean(img):
 def psnr(a, b):  # utils2.py:32-36
     mse = np.mean((a - b) ** 2)
     return 10 * np.log10(1.0 / mse)
+
+
+# --------------------------------------------------------------------------------------------
+# Stage-3 loss terms         modules/pytorch_msssim/__init__.py, modules/losses.py, VQLLFLOWD_model.py:209-223
+# --------------------------------------------------------------------------------------------
+def _gaussian(window_size, sigma):  # pytorch_msssim/__init__.py:8-10
+    from math import exp
+    g = torch.Tensor([exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(window_size)])
+    return g / g.sum()
+
+
+def _create_window(window_size, channel=1):  # :13-17
+    w1 = _gaussian(window_size, 1.5).unsqueeze(1)
+    w2 = w1.mm(w1.t()).float().unsqueeze(0).unsqueeze(0)
+    return w2.expand(channel, 1, window_size, window_size).contiguous()
+
+
+def ssim(img1, img2, window_size=11, val_range=None):
+    """ssim(..., full=True) of :21-68: returns (mean ssim_map, mean cs_map); NCHW."""
+    if val_range is None:
+        max_val = 255 if torch.max(img1) > 128 else 1
+        min_val = -1 if torch.min(img1) < -0.5 else 0
+        L = max_val - min_val
+    else:
+        L = val_range
+    _, channel, height, width = img1.size()
+    window = _create_window(min(window_size, height, width), channel=channel).to(img1.device)
+    mu1 = F.conv2d(img1, window, padding=0, groups=channel)
+    mu2 = F.conv2d(img2, window, padding=0, groups=channel)
+    mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    sigma1_sq = F.conv2d(img1 * img1, window, padding=0, groups=channel) - mu1_sq
+    sigma2_sq = F.conv2d(img2 * img2, window, padding=0, groups=channel) - mu2_sq
+    sigma12 = F.conv2d(img1 * img2, window, padding=0, groups=channel) - mu1_mu2
+    C1, C2 = (0.01 * L) ** 2, (0.03 * L) ** 2
+    v1, v2 = 2.0 * sigma12 + C2, sigma1_sq + sigma2_sq + C2
+    cs = torch.mean(v1 / v2)
+    ssim_map = ((2 * mu1_mu2 + C1) * v1) / ((mu1_sq + mu2_sq + C1) * v2)
+    return ssim_map.mean(), cs
+
+
+def msssim(img1, img2, window_size=11, val_range=None, normalize=False):  # :71-98
+    weights = torch.FloatTensor([0.0448, 0.2856, 0.3001, 0.2363, 0.1333]).to(img1.device)
+    mssim, mcs = [], []
+    for _ in range(weights.size()[0]):
+        sim, cs = ssim(img1, img2, window_size=window_size, val_range=val_range)
+        mssim.append(sim)
+        mcs.append(cs)
+        img1, img2 = F.avg_pool2d(img1, (2, 2)), F.avg_pool2d(img2, (2, 2))
+    mssim, mcs = torch.stack(mssim), torch.stack(mcs)
+    if normalize:
+        mssim, mcs = (mssim + 1) / 2, (mcs + 1) / 2
+    pow1, pow2 = mcs ** weights, mssim ** weights
+    return torch.prod(pow1[:-1] * pow2[-1])
+
+
+class PerceptualNetwork(nn.Module):
+    """losses.py:12-40 with vgg16.features[:16] written out (torchvision cfg 'D': 64 64 M 128 128 M 256 256 256).  The
+    reference loads torchvision's pretrained weights; torchvision is absent here, so the structure is restated from its
+    published definition and the weights are the caller's: parity unpinned by execution for this module."""
+
+    def __init__(self):
+        super().__init__()
+        layers, cin = [], 3
+        for v in (64, 64, "M", 128, 128, "M", 256, 256, 256):
+            if v == "M":
+                layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+            else:
+                layers += [nn.Conv2d(cin, v, 3, padding=1), nn.ReLU(inplace=False)]
+                cin = v
+        self.vgg_model = nn.Sequential(*layers)
+        for p in self.vgg_model.parameters():
+            p.requires_grad = False
+
+    def output_features(self, x):
+        out = []
+        for i, m in enumerate(self.vgg_model):
+            x = m(x)
+            if i in (3, 8, 15):
+                out.append(x)
+        return out
+
+    def forward(self, dehaze, gt):
+        fa, fb = self.output_features(dehaze), self.output_features(gt)
+        return sum(F.mse_loss(a, b) for a, b in zip(fa, fb)) / len(fa)
+
+
+def stage3_loss(rec, real_H, perceptual):
+    """VQLLFLOWD_model.py:209-223: returns (total, l1, percep * 0.01, ssim * 0.2)."""
+    sr = rec.to(torch.float32).clamp(0, 1)
+    not_nan = ~torch.isnan(sr)
+    sr = torch.where(not_nan, sr, torch.zeros_like(sr))
+    l1 = ((sr - real_H) * not_nan).abs().mean()
+    pl = perceptual(sr, real_H) * 0.01
+    sl = (1 - msssim(sr, real_H, normalize=True)) * 0.2
+    return l1 + pl + sl, l1, pl, sl

@@ -14,6 +14,7 @@ Fixtures (all float32 unless noted):
                 (encoder_decoder.py:38-192).
   harness.npz   pre-processing (impad + t + log, infer_dataset_lol.py:124-128) and PSNR
                 (utils2.py:32-36) on a seeded uint8 image.
+  msssim.npz    msssim(normalize=True) of modules/pytorch_msssim (stage-3 loss term), its gradient, and ssim() level 0.
   graph.npz     end-to-end stage checksums of the full LOL.yml graph A->B->C/D (E needs CUDA in the
                 reference) on a 1x3x24x32 input with seeded weights: outputs only (the 132 M weights
                 are re-created from their parameter names by glare_amd/synthetic.py::seeded_init_,
@@ -140,10 +141,33 @@ def main():
                         color_map=enc["color_map"].numpy(), mid0=enc["mid_feat"][0][:, :8].numpy(),
                         mid1=enc["mid_feat"][1][:, :8].numpy(), latent=x.numpy(), idx=idx.numpy(),
                         rec=rec.numpy(), code0=feats[0][:, :8].numpy(), code1=feats[1][:, :8].numpy())
+    msssim_fixture()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KB")
 
 
+def msssim_fixture():
+    """msssim.npz: modules/pytorch_msssim msssim(sr, gt, normalize=True) (the stage-3 ssim term, VQLLFLOWD_model.py:221) and its
+    gradient w.r.t. sr, on seeded [0,1] images; plus the plain (normalize=False) value and one single-scale ssim()."""
+    R.install()
+    from models.modules import pytorch_msssim as PM
+
+    g = torch.Generator().manual_seed(2024)
+    gt = torch.rand(2, 3, 96, 112, generator=g)
+    sr = (gt + 0.15 * torch.randn(2, 3, 96, 112, generator=g)).clamp(0, 1).requires_grad_(True)
+    val = PM.msssim(sr, gt, normalize=True)
+    val.backward()
+    with torch.no_grad():
+        plain = PM.msssim(sr, gt)
+        s, cs = PM.ssim(sr, gt, full=True)
+    np.savez_compressed(os.path.join(HERE, "msssim.npz"), sr=sr.detach().numpy(), gt=gt.numpy(), msssim_norm=np.float32(val.item()),
+                        grad=sr.grad.numpy(), msssim_plain=np.float32(plain.item()), ssim0=np.float32(s.item()),
+                        cs0=np.float32(cs.item()))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "msssim":
+        msssim_fixture()
+    else:
+        main()

@@ -419,3 +419,90 @@ def test_stage3_trainer_steps_reduce_the_loss():
     assert torch.equal(frozen, netG.RRDB.encoder.conv_in.weight.detach())        # only deformable_decoder trains
     assert all(p.grad is None for n, p in netG.named_parameters() if not n.startswith("deformable_decoder."))
     assert all(p.grad is not None for n, p in netG.named_parameters() if n.startswith("deformable_decoder."))
+
+
+# ---- stage-3 loss stack (row f1) ---------------------------------------------------------------------------
+def test_msssim_matches_reference_vectors_and_gradient(golden):
+    """HIP MS-SSIM against the values and the gradient the REFERENCE produced (tests/golden/msssim.npz)."""
+    from glare_amd import losses
+
+    g = golden("msssim")
+    nh = lambda a: torch.from_numpy(a).permute(0, 2, 3, 1).contiguous().to(_dev())
+    sr = nh(g["sr"]).requires_grad_(True)
+    gt = nh(g["gt"])
+    val = losses.msssim(sr, gt, normalize=True)
+    val.backward()
+    assert abs(float(val.detach()) - float(g["msssim_norm"])) < 2e-5
+    assert _rel(sr.grad.cpu().permute(0, 3, 1, 2), torch.from_numpy(g["grad"])) < 2e-3
+    with torch.no_grad():
+        assert abs(float(losses.msssim(sr.detach(), gt)) - float(g["msssim_plain"])) < 2e-5
+
+
+def test_msssim_small_images_shrinking_window():
+    """Levels whose side drops below 11 use a shorter Gaussian (real_size = min(window_size, h, w))."""
+    from glare_amd import losses
+    from oracle import torch_ref as O
+
+    g = torch.Generator().manual_seed(31)
+    gt = torch.rand(1, 3, 48, 40, generator=g)
+    a = (gt + 0.2 * torch.randn(1, 3, 48, 40, generator=g)).clamp(0, 1)
+    ar = a.clone().requires_grad_(True)
+    vr = O.msssim(ar, gt, normalize=True)
+    vr.backward()
+    ad = a.permute(0, 2, 3, 1).contiguous().to(_dev()).requires_grad_(True)
+    v = losses.msssim(ad, gt.permute(0, 2, 3, 1).contiguous().to(_dev()), normalize=True)
+    v.backward()
+    assert abs(float(v.detach()) - float(vr.detach())) < 2e-5
+    assert _rel(ad.grad.cpu().permute(0, 3, 1, 2), ar.grad) < 2e-3
+
+
+def test_perceptual_network_vs_oracle():
+    from glare_amd import losses
+    from glare_amd.synthetic import seeded_init_
+    from oracle import torch_ref as O
+
+    ref = seeded_init_(O.PerceptualNetwork(), 4)
+    hip = losses.PerceptualNetwork()
+    hip.load_state_dict(ref.state_dict(), strict=True)
+    hip.to(_dev())
+    g = torch.Generator().manual_seed(32)
+    gt = torch.rand(2, 3, 32, 48, generator=g)
+    a = (gt + 0.2 * torch.randn(2, 3, 32, 48, generator=g)).clamp(0, 1)
+    ar = a.clone().requires_grad_(True)
+    lr_ = ref(ar, gt)
+    lr_.backward()
+    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(_dev())
+    ad = nh(a).requires_grad_(True)
+    l = hip(ad, nh(gt))
+    l.backward()
+    assert abs(float(l.detach()) - float(lr_.detach())) < 3e-2 * abs(float(lr_.detach()))
+    assert _rel(ad.grad.cpu().permute(0, 3, 1, 2), ar.grad) < 5e-2
+    assert all(p.grad is None for p in hip.parameters())          # the VGG weights are frozen (losses.py:18-19)
+
+
+def test_stage3_total_loss_vs_oracle():
+    """l1 + 0.01 percep + 0.2 (1 - msssim) and d/d rec (VQLLFLOWD_model.py:209-223), including clamp / NaN handling."""
+    from glare_amd import losses
+    from glare_amd.synthetic import seeded_init_
+    from glare_amd.train import stage3_loss
+    from oracle import torch_ref as O
+
+    ref = seeded_init_(O.PerceptualNetwork(), 4)
+    hip = losses.PerceptualNetwork()
+    hip.load_state_dict(ref.state_dict(), strict=True)
+    hip.to(_dev())
+    g = torch.Generator().manual_seed(33)
+    gt = torch.rand(1, 3, 64, 64, generator=g)
+    rec = gt + 0.3 * torch.randn(1, 3, 64, 64, generator=g)        # leaves [0,1] in places
+    rec[0, 2, 5, 7] = float("nan")
+    rr = rec.clone().requires_grad_(True)
+    tot_r, l1_r, pl_r, sl_r = O.stage3_loss(rr, gt, ref)
+    tot_r.backward()
+    rd = rec.permute(0, 2, 3, 1).contiguous().to(_dev()).requires_grad_(True)
+    tot, terms = stage3_loss(rd, gt.to(_dev()), hip)
+    tot.backward()
+    assert abs(float(terms["l1_loss"].detach()) - float(l1_r.detach())) < 1e-6
+    assert abs(float(terms["ssim_loss"].detach()) - float(sl_r.detach())) < 1e-5
+    assert abs(float(terms["percep_loss"].detach()) - float(pl_r.detach())) < 3e-2 * abs(float(pl_r.detach()))
+    gref = torch.nan_to_num(rr.grad, nan=0.0)
+    assert _rel(rd.grad.cpu().permute(0, 3, 1, 2), gref) < 2e-2

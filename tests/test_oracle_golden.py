@@ -100,3 +100,18 @@ def test_full_graph_stages(golden):
     np.testing.assert_allclose(rec.numpy(), g["rec"], **tol)
     np.testing.assert_allclose(feats[0][:, :8].numpy(), g["code0"], **tol)
     np.testing.assert_allclose(feats[1][:, :8].numpy(), g["code1"], **tol)
+
+
+def test_msssim_matches_reference_vectors(golden):
+    """oracle msssim()/ssim() (pytorch_msssim/__init__.py:21-98) against values and the gradient the reference produced."""
+    g = golden("msssim")
+    sr = torch.from_numpy(g["sr"]).requires_grad_(True)
+    gt = torch.from_numpy(g["gt"])
+    val = O.msssim(sr, gt, normalize=True)
+    val.backward()
+    assert abs(float(val) - float(g["msssim_norm"])) < 1e-6
+    np.testing.assert_allclose(sr.grad.numpy(), g["grad"], rtol=1e-4, atol=1e-8)
+    with torch.no_grad():
+        assert abs(float(O.msssim(sr, gt)) - float(g["msssim_plain"])) < 1e-6
+        s, cs = O.ssim(sr, gt)
+        assert abs(float(s) - float(g["ssim0"])) < 1e-6 and abs(float(cs) - float(g["cs0"])) < 1e-6

@@ -96,3 +96,18 @@ def test_stage2_normal_flow(nets):
     for n, p in mine.named_parameters():
         if p.grad is not None:
             np.testing.assert_allclose(p.grad.numpy(), gr[n].grad.numpy(), rtol=1e-4, atol=1e-6)
+
+
+def test_msssim_bit_identical_to_reference():
+    R.install()
+    from models.modules import pytorch_msssim as PM
+
+    g = torch.Generator().manual_seed(5)
+    gt = torch.rand(1, 3, 64, 80, generator=g)
+    a = (gt + 0.2 * torch.randn(1, 3, 64, 80, generator=g)).clamp(0, 1)
+    ar, ao = a.clone().requires_grad_(True), a.clone().requires_grad_(True)
+    vr, vo = PM.msssim(ar, gt, normalize=True), O.msssim(ao, gt, normalize=True)
+    assert torch.equal(vr, vo)
+    vr.backward()
+    vo.backward()
+    assert torch.equal(ar.grad, ao.grad)
