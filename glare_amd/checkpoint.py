@@ -1,0 +1,82 @@
+"""Checkpoint compatibility with the reference.
+
+Mirrors BaseModel.save_network / load_network / save_training_state / resume_training (code/models/base_model.py:93-122,
+188-219) and the pretrained-weight loading of VQLLFLOWDModel.__init__ (code/models/VQLLFLOWD_model.py:42-63): network files are
+plain CPU state dicts with the reference's 824 / 257 key names (a leading 'module.' from nn.DataParallel is stripped on load),
+the training state is {'epoch', 'iter', 'schedulers', 'optimizers', 'scaler'} with each optimizer in torch.optim.Adam's own
+state_dict layout -- so a `.state` file written by the reference resumes here and vice versa.
+"""
+from collections import OrderedDict
+
+import torch
+
+
+def save_network(network, path):
+    network = getattr(network, "module", network)
+    torch.save(OrderedDict((k, v.detach().cpu()) for k, v in network.state_dict().items()), path)
+
+
+def load_network(path_or_state, network, strict=True, submodule=None):
+    network = getattr(network, "module", network)
+    if submodule is not None and str(submodule).lower() != "none":
+        network = getattr(network, submodule)
+    sd = torch.load(path_or_state, map_location="cpu") if isinstance(path_or_state, str) else path_or_state
+    clean = OrderedDict((k[7:] if k.startswith("module.") else k, v) for k, v in sd.items())
+    result = network.load_state_dict(clean, strict=strict)
+    if hasattr(network, "invalidate"):
+        network.invalidate()          # packed kernel weights are stale
+    return result
+
+
+def adam_state_dict(opt):
+    """FlatAdam -> the dict torch.optim.Adam.state_dict() would produce for the same groups (params indexed in order)."""
+    state, groups, idx = {}, [], 0
+    for g in opt.groups:
+        ids, off = [], 0
+        for p in g.params:
+            k = p.numel()
+            state[idx] = {"step": torch.tensor(float(opt.t)), "exp_avg": g.m[off:off + k].view(p.shape).detach().cpu().clone(),
+                          "exp_avg_sq": g.v[off:off + k].view(p.shape).detach().cpu().clone()}
+            ids.append(idx)
+            idx += 1
+            off += k
+        groups.append({"lr": g.lr, "betas": tuple(opt.betas), "eps": opt.eps, "weight_decay": g.weight_decay, "amsgrad": False,
+                       "maximize": False, "params": ids})
+    return {"state": state, "param_groups": groups}
+
+
+def load_adam_state_dict(opt, sd):
+    """Accepts the layout above or one written by torch.optim.Adam in the reference (same group / parameter order)."""
+    assert len(sd["param_groups"]) == len(opt.groups), "Wrong lengths of optimizers' param groups"
+    step = 0
+    for g, sg in zip(opt.groups, sd["param_groups"]):
+        assert len(sg["params"]) == len(g.params), "parameter count of a group differs"
+        g.lr, g.weight_decay = float(sg["lr"]), float(sg.get("weight_decay", 0.0))
+        off = 0
+        for p, pid in zip(g.params, sg["params"]):
+            k = p.numel()
+            st = sd["state"].get(pid)
+            if st is None:               # torch keeps no state for parameters that never received a gradient
+                g.m[off:off + k].zero_()
+                g.v[off:off + k].zero_()
+            else:
+                g.m[off:off + k].copy_(st["exp_avg"].reshape(-1).to(g.m.device))
+                g.v[off:off + k].copy_(st["exp_avg_sq"].reshape(-1).to(g.v.device))
+                step = max(step, int(float(st["step"])))
+            off += k
+    opt.t = step
+
+
+def save_training_state(path, trainer, epoch, iter_step, schedulers=()):
+    torch.save({"epoch": epoch, "iter": iter_step, "schedulers": [s.state_dict() for s in schedulers],
+                "optimizers": [adam_state_dict(trainer.opt)], "scaler": {}}, path)   # GradScaler: no fp16 here, empty state
+
+
+def resume_training(path_or_state, trainer, schedulers=()):
+    st = torch.load(path_or_state, map_location="cpu") if isinstance(path_or_state, str) else path_or_state
+    assert len(st["optimizers"]) == 1, "Wrong lengths of optimizers"
+    assert len(st["schedulers"]) == len(schedulers), "Wrong lengths of schedulers"
+    load_adam_state_dict(trainer.opt, st["optimizers"][0])
+    for s, sd in zip(schedulers, st["schedulers"]):
+        s.load_state_dict(sd)
+    return st["epoch"], st["iter"]
