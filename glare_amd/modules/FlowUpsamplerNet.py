@@ -341,32 +341,48 @@ class FlowNLLFn(torch.autograd.Function):
         gftA = torch.empty(B, H, W, n * 64, dtype=torch.bfloat16, device=dev)
         ghF = torch.empty(B, H, W, n * 8, dtype=torch.bfloat16, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)
-        dM, dt, dwz = torch.empty(n, 3, 3, **f32), torch.empty(n, 3, **f32), torch.empty(n, 64, 9, **f32)
+        dMt, dwz = torch.empty(n, 12, **f32), torch.empty(n, 64, 9, **f32)
         # weight | bias gradients of the per-step convs land in these (GEMM output layout: last column = bias)
         dc2, dc4 = torch.empty(n, 64, 65, **f32), torch.empty(n, 4, 577, **f32)
         df2, df4 = torch.empty(n, 64, 65, **f32), torch.empty(n, 6, 577, **f32)
-        for k in reversed(range(n)):                                   # the sequential adjoint sweep
-            gh4 = T.flow_post_backward_(gz, z_pre[k], h4s[k], gld, eps)
-            T.conv_weight_grad(lambda ldp, ones: T.im2col_t(h2s[k], 3, ldp=ldp, ones_row=ones), gh4, 4, 576, out=dc4[k])
-            gh2 = ops.conv2d(gh4, _wt(c4_w[k], 8))
-            T.act_backward_(gh2, h2s[k], "relu")
-            T.conv_weight_grad(lambda ldp, ones: T.im2col_t(h1s[k], 1, ldp=ldp, ones_row=ones), gh2, 64, 64, out=dc2[k])
-            ops.conv2d(gh2, _wt(c2_w[k]), out=gftA, out_off=64 * k)
-            T.act_backward_(gftA, h1s[k], "relu", C=64, g_off=64 * k)
-            dwz[k] = T.flow_h1_backward_(gz, gftA, 64 * k, z_pre[k], wz[k])
-            dM[k], dt[k] = T.flow_pre_backward_(gz, z_in[k], hF, 8 * k, gld, Mh[k], th[k], eps, ghF, 8 * k)
         P = B * H * W
+        gh4s = torch.empty(n, B, H, W, 8, dtype=torch.bfloat16, device=dev)     # kept: their filter gradients are batched below
+        gh2s = torch.empty(n, B, H, W, 64, dtype=torch.bfloat16, device=dev)
+        for k in reversed(range(n)):                                   # the sequential adjoint sweep
+            T.flow_post_backward_(gz, z_pre[k], h4s[k], gld, eps, out=gh4s[k])
+            ops.conv2d(gh4s[k], _wt(c4_w[k], 8), out=gh2s[k])
+            T.act_backward_(gh2s[k], h2s[k], "relu")
+            ops.conv2d(gh2s[k], _wt(c2_w[k]), out=gftA, out_off=64 * k)
+            T.act_backward_(gftA, h1s[k], "relu", C=64, g_off=64 * k)
+            T.flow_h1_backward_(gz, gftA, 64 * k, z_pre[k], wz[k], out=dwz[k])
+            T.flow_pre_backward_(gz, z_in[k], hF, 8 * k, gld, Mh[k], th[k], eps, ghF, 8 * k, out=dMt[k])
+        # filter gradients of the 2 x n coupling convs: ONE transposed-operand pair + ONE batched GEMM per conv type, the
+        # batch index being the step (its pixels are a contiguous K slice of the step-major buffers)
+        if P % 64 == 0:
+            for g_all, x_all, ks, cout, dst in ((gh4s, h2s, 3, 4, dc4), (gh2s, h1s, 1, 64, dc2)):
+                rows = 64 * ks * ks
+                gT = T.transpose(g_all.view(n * P, g_all.shape[-1]), ld_out=n * P)
+                colT = T.im2col_t(x_all.view(n * B, H, W, 64), ks, ldp=n * P, ones_row=rows)
+                T.gemm_nt(gT.as_strided((n, cout, P), (P, n * P, 1)), colT.as_strided((n, rows + 1, P), (P, n * P, 1)), out=dst)
+        else:
+            for k in range(n):
+                T.conv_weight_grad(lambda ldp, ones: T.im2col_t(h2s[k], 3, ldp=ldp, ones_row=ones), gh4s[k], 4, 576, out=dc4[k])
+                T.conv_weight_grad(lambda ldp, ones: T.im2col_t(h1s[k], 1, ldp=ldp, ones_row=ones), gh2s[k], 64, 64, out=dc2[k])
         gh2f, gh1f = torch.empty_like(h1f), torch.empty_like(h1f)
-        ghF2, gh2f2 = ghF.view(P, n * 8), gh2f.view(P, n * 64)
-        for s in range(n):                                             # the z-independent feature nets
-            T.conv_weight_grad(lambda ldp, ones: T.im2col_t(h2f, 3, cin=64, in_off=64 * s, ldp=ldp, ones_row=ones),
-                               ghF2[:, 8 * s:8 * s + 8], 6, 576, out=df4[s])
+        for s in range(n):                                             # the z-independent feature nets: data gradients
             ops.conv2d(ghF, _wt(f4_w[s], 8), cin=8, in_off=8 * s, out=gh2f, out_off=64 * s)
             T.act_backward_(gh2f, h2f, "relu", C=64, g_off=64 * s, y_off=64 * s)
-            T.conv_weight_grad(lambda ldp, ones: T.im2col_t(h1f, 1, cin=64, in_off=64 * s, ldp=ldp, ones_row=ones),
-                               gh2f2[:, 64 * s:64 * s + 64], 64, 64, out=df2[s])
             ops.conv2d(gh2f, _wt(f2_w[s]), cin=64, in_off=64 * s, out=gh1f, out_off=64 * s)
             T.act_backward_(gh1f, h1f, "relu", C=64, g_off=64 * s, y_off=64 * s)
+        # ... and their filter gradients, batched over the steps: step s owns a row block of both transposed operands
+        Pp = (P + 63) // 64 * 64
+        for g_all, gc, x_all, ks, cout, dst in ((ghF, 8, h2f, 3, 6, df4), (gh2f, 64, h1f, 1, 64, df2)):
+            rows = 64 * ks * ks
+            gT = T.transpose(g_all.view(P, n * gc), ld_out=Pp)                          # [n*gc, Pp]
+            colT = T.im2col_t(x_all, ks, ldp=Pp, ones_row=n * rows)                      # [n*rows + 1, Pp], row = c*k*k + tap
+            a3 = gT.as_strided((n, cout, Pp), (gc * Pp, Pp, 1))
+            T.gemm_nt(a3, colT.as_strided((n, rows, Pp), (rows * Pp, Pp, 1)), out=dst[:, :, :rows])
+            T.gemm_nt(a3, colT[n * rows:].as_strided((n, 1, Pp), (0, Pp, 1)), out=dst[:, :, rows:])   # bias: the row of ones
         col = lambda ldp, ones: T.im2col_t(ft, 3, ldp=ldp, ones_row=ones)
         dwb = T.conv_weight_grad(col, gh1f, n * 64, 576)
         df0w, df0b = dwb[:, :-1].unflatten(1, (64, 3, 3)), dwb[:, -1]
@@ -376,4 +392,5 @@ class FlowNLLFn(torch.autograd.Function):
         df2w, df2b, df4w, df4b = df2[:, :, :-1].unflatten(2, (64, 1, 1)), df2[:, :, -1], df4[:, :, :-1].unflatten(2, (64, 3, 3)), df4[:, :, -1]
         gft = ops.conv2d(gh1f, _wt(f0_w))
         gft = ops.conv2d(gftA, _wt(ftA_w), residual=gft)
-        return (gft, gmean, None, None, dM.cpu(), dt.cpu(), dwz, dftAw, dftAb, df0w, df0b, dc2w, dc2b, dc4w, dc4b, df2w, df2b, df4w, df4b)
+        dMt_h = dMt.cpu()
+        return (gft, gmean, None, None, dMt_h[:, :9].reshape(n, 3, 3), dMt_h[:, 9:], dwz, dftAw, dftAb, df0w, df0b, dc2w, dc2b, dc4w, dc4b, df2w, df2b, df4w, df4b)

@@ -238,7 +238,9 @@ def conv_weight_grad(x_col_builder, g_bf16, cout, n_rows, out=None):
     if g_bf16.dim() != 2:
         g_bf16 = g_bf16.view(-1, g_bf16.shape[-1])
     P = g_bf16.shape[0]
-    tiles = ((cout + 255) // 256) * ((n_rows + 1 + 127) // 128)
+    # the GEMM tile is 256 (m) x 128 (n): put the filter's Cout on the 128 side when it would waste half a 256-row tile
+    swap = out is None and cout <= 128 and n_rows + 1 > 128
+    tiles = ((n_rows + 256) // 256) * ((cout + 127) // 128) if swap else ((cout + 255) // 256) * ((n_rows + 1 + 127) // 128)
     S = max(1, min((512 + tiles - 1) // tiles, P // 2048, 64))
     ldp = _rup(P, 64 * S)
     colT = x_col_builder(ldp, n_rows)
@@ -246,6 +248,9 @@ def conv_weight_grad(x_col_builder, g_bf16, cout, n_rows, out=None):
     ks = ldp // S
     a3 = gT.as_strided((S, cout, ks), (ks, ldp, 1))
     b3 = colT.as_strided((S, n_rows + 1, ks), (ks, ldp, 1))
+    if swap:   # C^T = colT . gT^T; the caller gets the transposed view (gradients may be strided)
+        parts = gemm_nt(b3, a3)
+        return (reduce_parts(parts) if S > 1 else parts[0]).t()
     if S == 1:
         return gemm_nt(a3[0], b3[0], out=out) if out is not None else gemm_nt(a3, b3)[0]
     return reduce_parts(gemm_nt(a3, b3), out=out)
@@ -284,17 +289,17 @@ def flow_nll_backward(z, mean, g_logp):
     return gz, gmean
 
 
-def flow_post_backward_(gz, z_pre, h4, g_logdet, eps):
+def flow_post_backward_(gz, z_pre, h4, g_logdet, eps, out=None):
     """-> gh4 bf16 [B,H,W,8] (4 used); gz[..., 1:] updated in place."""
-    require_cuda(gz, z_pre, h4, g_logdet)
+    require_cuda(gz, z_pre, h4, g_logdet, out)
     B = gz.shape[0]
-    gh4 = torch.empty(*gz.shape[:-1], 8, dtype=torch.bfloat16, device=gz.device)
+    gh4 = torch.empty(*gz.shape[:-1], 8, dtype=torch.bfloat16, device=gz.device) if out is None else out
     check(_lib.lib().glare_flow_fwd_post_backward_f32(ptr(gz), ptr(z_pre), ptr(h4), ptr(g_logdet), _i(B), _ll(gz.numel() // 3 // B),
                                                       _f(eps), ptr(gh4), stream_handle()), "glare_flow_fwd_post_backward_f32")
     return gh4
 
 
-def flow_h1_backward_(gz, g, g_off, z_pre, wz):
+def flow_h1_backward_(gz, g, g_off, z_pre, wz, out=None):
     """gz[..., 0] += adjoint of the 1-channel conv; returns the filter gradient fp32 [64, 9]."""
     require_cuda(gz, g, z_pre, wz)
     B, H, W, _ = gz.shape
@@ -303,10 +308,10 @@ def flow_h1_backward_(gz, g, g_off, z_pre, wz):
     part = torch.empty(nb, 576, dtype=torch.float32, device=gz.device)
     check(lib.glare_flow_h1_backward_f32(ptr(gz), ptr(g), _i(g.shape[-1]), _i(g_off), ptr(z_pre), ptr(wz), _i(B), _i(H), _i(W), ptr(part),
                                          stream_handle()), "glare_flow_h1_backward_f32")
-    return reduce_parts(part).view(64, 9)
+    return reduce_parts(part, out=None if out is None else out.view(576)).view(64, 9)
 
 
-def flow_pre_backward_(gz, z_in, hF, hF_off, g_logdet, M, t, eps, ghF, ghF_off):
+def flow_pre_backward_(gz, z_in, hF, hF_off, g_logdet, M, t, eps, ghF, ghF_off, out=None):
     """gz updated in place to the step input's gradient; ghF slice written; returns (dM fp32 [3,3], dt fp32 [3])."""
     require_cuda(gz, z_in, hF, g_logdet, ghF)
     B = gz.shape[0]
@@ -318,7 +323,7 @@ def flow_pre_backward_(gz, z_in, hF, hF_off, g_logdet, M, t, eps, ghF, ghF_off):
     check(lib.glare_flow_fwd_pre_backward_f32(ptr(gz), ptr(z_in), ptr(hF), _i(hF.shape[-1]), _i(hF_off), ptr(g_logdet), _i(B),
                                               _ll(npix // B), Ma, ta, _f(eps), ptr(ghF), _i(ghF.shape[-1]), _i(ghF_off), ptr(part),
                                               stream_handle()), "glare_flow_fwd_pre_backward_f32")
-    r = reduce_parts(part)
+    r = reduce_parts(part, out=out)
     return r[:9].view(3, 3), r[9:]
 
 
