@@ -36,6 +36,16 @@ constexpr int BM = 128;          // query rows per workgroup
 constexpr int BN = 32;           // keys per tile
 constexpr int KCH = BN * (HD / 8);   // 16-B chunks per K tile  (2048)
 constexpr float RESCALE_THR = 8.0f;  // log2 units
+// ATTN_PIPELINED=1 selects a software-pipelined tile loop (S(j+1) on the matrix pipe while the vector ALU runs softmax(j);
+// the last quarter of Q moved to LDS to make room for the second score accumulator).  Measured on MI355X: +1 % (1036 vs 1023
+// TFLOP/s, run-to-run noise is 2 %), and 1206 vs 1303 TFLOP/s with the DMA ablated -- the serial softmax is NOT what
+// limits the kernel; the 64 LDS-DMA pieces per tile are (~25 %).  Kept as a reproducible negative result; default off.
+#ifndef ATTN_PIPELINED
+#define ATTN_PIPELINED 0
+#endif
+#ifndef ATTN_V_IN_PHASE_B
+#define ATTN_V_IN_PHASE_B 0
+#endif
 #ifndef ATTN_DMA_PER_GROUP
 #define ATTN_DMA_PER_GROUP 2  // DMA pieces issued per 4-MFMA group (2: all 16 during QK^T; 1: over the whole tile)
 #endif
@@ -142,6 +152,178 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) vofs[ks] = 2 * KCH * 16 + (ql * 4 + ((2 * ks + hi) ^ ((ql >> 2) & 3))) * 16;
 
+#if ATTN_PIPELINED
+  // Software-pipelined tile loop: iteration j computes S(j+1) = K(j+1).Q^T on the matrix pipe WHILE the vector ALU turns
+  // S(j) into P(j) (online softmax), then O += V(j).P(j).  The softmax (max / exp2 / sum / bf16 pack, ~15 % of a tile when
+  // serialised) hides in the issue slack of the 32-deep dependent S accumulation.  K and V^T keep separate double buffers
+  // with different deadlines: during iteration j the DMA fetches K(j+2) and V^T(j+1).
+  const char* const kbuf[2] = {smem, smem + KCH * 16};
+  auto ldk = [&](int ks4, const char* kb, bf16x8(&f)[4]) {   // ks4: compile-time group index
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int ks = 4 * ks4 + e;
+      f[e] = *reinterpret_cast<const bf16x8*>(kb + kofs[ks & 7] + (ks >> 3) * 256);
+    }
+  };
+  auto ldv = [&](int g, const char* vb, bf16x8(&f)[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f[e] = *reinterpret_cast<const bf16x8*>(vb + vofs[e & 1] + (2 * g + (e >> 1)) * 2048);
+  };
+  auto issue_k = [&](auto ic, int tile, int buf) {   // piece i of a K tile (8 per wave)
+    constexpr int i = decltype(ic)::value;
+    const int r = wave + 4 * i;
+    const int kv = min(tile * BN + r, p.N - 1);
+    const char* row = reinterpret_cast<const char*>(kbase + (size_t)kv * p.ldk);
+    dma16a(row + (unsigned)((lane ^ (r & 15)) * 16), lK + buf * KCH + r * 64);
+  };
+  auto issue_v = [&](auto ic, int tile, int buf) {   // piece j of a V^T tile (8 per wave)
+    constexpr int j = decltype(ic)::value;
+    const char* grp = reinterpret_cast<const char*>(vbase + (size_t)(wave + 4 * j) * 16 * p.Npad + (size_t)tile * BN);
+    dma16a(grp + v_lane_off, lV + buf * KCH + (wave + 4 * j) * 64);
+  };
+  auto mask_tail = [&](f32x16& sc, int tile) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kv = tile * BN + 16 * (r >> 3) + 8 * hi + (r & 7);
+      if (kv >= p.N) sc[r] = -__builtin_inff();
+    }
+  };
+
+  // The last quarter of Q (k-steps 24..31, 32 VGPRs) lives in a wave-private 8 KB LDS slab and is re-read per tile: the
+  // registers it frees hold the second score accumulator of the pipeline.
+  char* const qslab = smem + 4 * KCH * 16 + wave * 8192 + lane * 16;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) *reinterpret_cast<bf16x8*>(qslab + i * 1024) = qf[24 + i];
+  auto ldq = [&](int g, bf16x8(&f)[4]) {   // g = 6, 7
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f[e] = *reinterpret_cast<const bf16x8*>(qslab + (4 * (g - 6) + e) * 1024);
+  };
+
+  f32x16 s_cur;
+  {  // prologue: K(0), K(1), V^T(0) in flight; S(0)
+    static_for<8>([&](auto ic) { issue_k(ic, 0, 0); });
+    static_for<8>([&](auto ic) { issue_v(ic, 0, 0); });
+    static_for<8>([&](auto ic) { issue_k(ic, min(1, n_tiles - 1), 1); });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_cur[r] = 0.f;
+    bf16x8 f0[4];
+    static_for<8>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      ldk(g, kbuf[0], f0);
+      if constexpr (g < 6) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s_cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0[e], qf[4 * g + e], s_cur, 0, 0, 0);
+      } else {
+        bf16x8 q0[4];
+        ldq(g, q0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s_cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0[e], q0[e], s_cur, 0, 0, 0);
+      }
+    });
+    if (n_tiles == 1) mask_tail(s_cur, 0);
+  }
+
+  auto tile_body = [&](auto bufc, int tile) {
+    constexpr int BUF = decltype(bufc)::value;   // == tile & 1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K(tile+1), V^T(tile) have landed ...
+    __syncthreads();                                    // ... for everybody; K(tile), V^T(tile-1) are retired
+    const int t1 = min(tile + 1, n_tiles - 1), t2 = min(tile + 2, n_tiles - 1);   // clamped: redundant reloads, branch-free
+    const char* kb = kbuf[BUF ^ 1];                     // K(tile+1)
+    const char* vb = smem + BUF * KCH * 16;             // V^T(tile) (vofs carries the V base)
+    bf16x8 fr[3][4], qt[4];
+    f32x16 s_nxt;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_nxt[r] = 0.f;
+    float mx = 0.f, psum = 0.f;
+    u32x4 w[2];
+    // ---- phase A: S(tile+1) on the matrix pipe, softmax(tile) in its shadow, one slice per MFMA group
+    ldk(0, kb, fr[0]);
+    ldk(1, kb, fr[1]);
+    static_for<8>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      if constexpr (g + 2 < 8) ldk(g + 2, kb, fr[(g + 2) % 3]);
+      else ldv(g + 2 - 8, vb, fr[(g + 2) % 3]);
+#ifndef ATTN_ABLATE_NODMA
+      issue_k(std::integral_constant<int, g>{}, t2, BUF);        // K(tile+2) over K(tile)'s buffer
+#if !ATTN_V_IN_PHASE_B
+      issue_v(std::integral_constant<int, g>{}, t1, BUF ^ 1);    // V^T(tile+1) over V^T(tile-1)'s buffer
+#endif
+#endif
+      if constexpr (g == 5) ldq(6, qt);                 // Q tail for group 6, one group ahead
+      if constexpr (g < 6) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s_nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g % 3][e], qf[4 * g + e], s_nxt, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s_nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g % 3][e], qt[e], s_nxt, 0, 0, 0);
+        if constexpr (g == 6) ldq(7, qt);               // reuses the registers group 6 has just consumed
+      }
+      if constexpr (g == 0) {
+        mx = s_cur[0];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) mx = fmaxf(mx, s_cur[r]);
+      } else if constexpr (g == 1) {
+#pragma unroll
+        for (int r = 8; r < 16; ++r) mx = fmaxf(mx, s_cur[r]);
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        mx = fmaxf(mx, __uint_as_float(hi ? sw[0] : sw[1]));
+      } else if constexpr (g == 2) {
+        if (__any(mx > m_run + RESCALE_THR)) {  // wave-uniform, rare: rescale everything still at the old max
+          const float m_new = fmaxf(m_run, mx);
+          const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+          l_run *= alpha;
+#pragma unroll
+          for (int i = 0; i < HD / 32; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              float x = o[i][r], tmp;
+              asm volatile("v_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\tv_accvgpr_write_b32 %0, %1"
+                           : "+a"(x), "=&v"(tmp)
+                           : "v"(alpha));
+              o[i][r] = x;
+            }
+          m_run = m_new;
+        }
+      } else if constexpr (g <= 6) {   // g = 3..6: four scores each
+        constexpr int q4 = g - 3;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float p0 = __builtin_amdgcn_exp2f(s_cur[4 * q4 + 2 * e] - m_run);
+          const float p1 = __builtin_amdgcn_exp2f(s_cur[4 * q4 + 2 * e + 1] - m_run);
+          psum += p0 + p1;
+          w[q4 >> 1][2 * (q4 & 1) + e] = pack_bf2(p0, p1);
+        }
+      } else {
+        l_run += psum;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    // branch-free (a conditional call here costs the register allocator ~60 spills): real tiles mask keys >= N, the redundant
+    // tile past the end is masked entirely and never consumed
+    mask_tail(s_nxt, tile + 1 < n_tiles ? tile + 1 : n_tiles);
+    const bf16x8 pf[2] = {__builtin_bit_cast(bf16x8, w[0]), __builtin_bit_cast(bf16x8, w[1])};
+    s_cur = s_nxt;
+    // ---- phase B: O^T += V^T(tile) . P^T(tile)
+    static_for<8>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      if constexpr (g + 2 < 8) ldv(g + 2, vb, fr[(8 + g + 2) % 3]);
+#if ATTN_V_IN_PHASE_B && !defined(ATTN_ABLATE_NODMA)
+      issue_v(std::integral_constant<int, g>{}, t1, BUF ^ 1);
+#endif
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        o[2 * g + (e >> 1)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[(8 + g) % 3][e], pf[e & 1], o[2 * g + (e >> 1)], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  for (int tile = 0; tile < n_tiles; tile += 2) {
+    tile_body(std::integral_constant<int, 0>{}, tile);
+    if (tile + 1 < n_tiles) tile_body(std::integral_constant<int, 1>{}, tile + 1);
+  }
+#else
   // One key tile.  BUF is a compile-time constant so that the buffer offset folds into the ds_read
   // immediate.  Fragment reads run two groups (8 x ds_read_b128) ahead of the MFMAs that consume them
   // through a 3-deep rotating register set; the first V^T groups are fetched before the softmax.
@@ -268,6 +450,8 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
     if (tile + 1 < n_tiles) tile_body(std::integral_constant<int, 1>{}, tile + 1);
   }
 
+#endif
+
   // ---- normalise and store O[q][d] (bf16): a lane owns ONE query row, 4 consecutive d per store
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
@@ -299,7 +483,7 @@ extern "C" int glare_attention_d512_bf16(const void* q, int ldq, const void* k, 
   const long long nb = (long long)B * p.n_qblocks;
   if (nb > 0x7fffffffLL) return GLARE_ERR_INVALID;
   p.n_blocks = (int)nb;
-  const size_t lds = (size_t)4 * KCH * 16;  // 128 KB
+  const size_t lds = (size_t)4 * KCH * 16 + (ATTN_PIPELINED ? 4 * 8192 : 0);  // 128 KB K/V ring (+ 32 KB Q tail)
   if (hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GLARE_ERR_LAUNCH;
   hipLaunchKernelGGL(attn_fwd_kernel, dim3(p.n_blocks), dim3(AT_THREADS), lds, (hipStream_t)stream, p);
