@@ -90,8 +90,15 @@ __global__ __launch_bounds__(FL_THREADS) void flow_tail_kernel(float* __restrict
 // parts of the log-determinant (actnorm logs, slogdet W) are added on the host in fp64.
 __global__ __launch_bounds__(FL_THREADS) void flow_fwd_pre_kernel(float* __restrict__ z, const float* __restrict__ hF, int f_pitch,
                                                                   int f_off, long long pix_per_sample, int blocks_per_sample,
-                                                                  TailParams tp, float eps, float* __restrict__ ld_partial) {
+                                                                  TailParams tp, const float* __restrict__ mt_dev, float eps,
+                                                                  float* __restrict__ ld_partial) {
   __shared__ float red[FL_THREADS / 64];
+  if (mt_dev) {  // the 3x3 + offset read from device memory (wave-uniform loads): no host round trip, graph-capturable
+#pragma unroll
+    for (int i = 0; i < 9; ++i) tp.M[i] = mt_dev[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tp.t[i] = mt_dev[9 + i];
+  }
   const int b = blockIdx.x / blocks_per_sample, blk = blockIdx.x % blocks_per_sample;
   float acc = 0.f;
   for (long long q = (long long)blk * FL_THREADS + threadIdx.x; q < pix_per_sample; q += (long long)blocks_per_sample * FL_THREADS) {
@@ -209,7 +216,19 @@ extern "C" int glare_flow_fwd_pre_f32(float* z_nhwc3, const float* hF, int hF_pi
   for (int i = 0; i < 3; ++i) tp.t[i] = t_3_host[i];
   const int bps = glare_flow_blocks_per_sample(pixels_per_sample);
   hipLaunchKernelGGL(flow_fwd_pre_kernel, dim3(B * bps), dim3(FL_THREADS), 0, (hipStream_t)stream, z_nhwc3, hF, hF_pitch, hF_off,
-                     pixels_per_sample, bps, tp, eps, logdet_partial);
+                     pixels_per_sample, bps, tp, (const float*)nullptr, eps, logdet_partial);
+  return glare_launch_status();
+}
+
+extern "C" int glare_flow_fwd_pre_dev_f32(float* z_nhwc3, const float* hF, int hF_pitch, int hF_off, int B,
+                                          long long pixels_per_sample, const float* Mt_12_device, float eps, float* logdet_partial,
+                                          glare_stream_t stream) {
+  if (!z_nhwc3 || !hF || !Mt_12_device || !logdet_partial || B <= 0 || pixels_per_sample <= 0) return GLARE_ERR_INVALID;
+  if ((hF_pitch % 4) || (hF_off % 4) || hF_off + 6 > hF_pitch) return GLARE_ERR_UNSUPPORTED;
+  TailParams tp = {};
+  const int bps = glare_flow_blocks_per_sample(pixels_per_sample);
+  hipLaunchKernelGGL(flow_fwd_pre_kernel, dim3(B * bps), dim3(FL_THREADS), 0, (hipStream_t)stream, z_nhwc3, hF, hF_pitch, hF_off,
+                     pixels_per_sample, bps, tp, Mt_12_device, eps, logdet_partial);
   return glare_launch_status();
 }
 

@@ -125,10 +125,16 @@ __global__ __launch_bounds__(FB_THREADS) void flow_h1_bwd_kernel(float* __restri
 __global__ __launch_bounds__(FB_THREADS) void flow_pre_bwd_kernel(float* __restrict__ gz, const float* __restrict__ z_in,
                                                                   const float* __restrict__ hF, int f_pitch, int f_off,
                                                                   const float* __restrict__ g_logdet, long long pix_per_sample,
-                                                                  long long npix, AffineParams ap, float eps,
-                                                                  bf16_t* __restrict__ ghF, int gf_pitch, int gf_off,
+                                                                  long long npix, AffineParams ap, const float* __restrict__ mt_dev,
+                                                                  float eps, bf16_t* __restrict__ ghF, int gf_pitch, int gf_off,
                                                                   float* __restrict__ partial) {
   __shared__ float red[FB_THREADS / 64][12];
+  if (mt_dev) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) ap.M[i] = mt_dev[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ap.t[i] = mt_dev[9 + i];
+  }
   float acc[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) acc[i] = 0.f;
@@ -223,7 +229,23 @@ extern "C" int glare_flow_fwd_pre_backward_f32(float* gz, const float* z_in, con
   for (int i = 0; i < 3; ++i) ap.t[i] = t_3_host[i];
   const long long npix = (long long)B * pixels_per_sample;
   hipLaunchKernelGGL(flow_pre_bwd_kernel, dim3(glare_flow_bwd_blocks(npix)), dim3(FB_THREADS), 0, ST(stream), gz, z_in, hF, hF_pitch,
-                     hF_off, g_logdet_per_sample, pixels_per_sample, npix, ap, eps, static_cast<bf16_t*>(ghF_bf16), ghF_pitch, ghF_off,
-                     gMt_partial);
+                     hF_off, g_logdet_per_sample, pixels_per_sample, npix, ap, (const float*)nullptr, eps,
+                     static_cast<bf16_t*>(ghF_bf16), ghF_pitch, ghF_off, gMt_partial);
+  return glare_launch_status();
+}
+
+extern "C" int glare_flow_fwd_pre_backward_dev_f32(float* gz, const float* z_in, const float* hF, int hF_pitch, int hF_off,
+                                                   const float* g_logdet_per_sample, int B, long long pixels_per_sample,
+                                                   const float* Mt_12_device, float eps, void* ghF_bf16, int ghF_pitch, int ghF_off,
+                                                   float* gMt_partial, glare_stream_t stream) {
+  if (!gz || !z_in || !hF || !g_logdet_per_sample || !Mt_12_device || !ghF_bf16 || !gMt_partial || B <= 0 || pixels_per_sample <= 0)
+    return GLARE_ERR_INVALID;
+  if ((hF_pitch % 4) || (hF_off % 4) || hF_off + 6 > hF_pitch || (ghF_pitch % 8) || (ghF_off % 8) || ghF_off + 8 > ghF_pitch)
+    return GLARE_ERR_UNSUPPORTED;
+  AffineParams ap = {};
+  const long long npix = (long long)B * pixels_per_sample;
+  hipLaunchKernelGGL(flow_pre_bwd_kernel, dim3(glare_flow_bwd_blocks(npix)), dim3(FB_THREADS), 0, ST(stream), gz, z_in, hF, hF_pitch,
+                     hF_off, g_logdet_per_sample, pixels_per_sample, npix, ap, Mt_12_device, eps, static_cast<bf16_t*>(ghF_bf16),
+                     ghF_pitch, ghF_off, gMt_partial);
   return glare_launch_status();
 }

@@ -215,20 +215,29 @@ class FlowUpsamplerNet(HipModule):
         ActNorm / Conv2dZeros folds on the device, the 3x3 affine compositions and slogdet in fp64 on the host), in
         forward execution order.  Autograd carries the kernels' gradients through these folds to the raw parameters."""
         dev = self.layers[0].actnorm.bias.device
-        Ms, ts, steps, const_ld = [], [], [], 0.0
-        A, c = torch.eye(3, dtype=torch.float64), torch.zeros(3, dtype=torch.float64)
-        for layer in self.layers:
-            w = layer.invconv.weight.double().cpu()
-            logs = layer.actnorm.logs.double().cpu().reshape(-1)
-            bias = layer.actnorm.bias.double().cpu().reshape(-1)
-            A2 = w * torch.exp(logs).view(1, -1)                      # W diag(e^logs)   (FlowStep.py:83-88)
-            A, c = A2 @ A, A2 @ c + A2 @ bias
-            const_ld = const_ld + logs.sum() + torch.slogdet(w)[1]    # FlowActNorms.py:93-98, Permutations.py:27
-            if layer.flow_coupling != "noCoupling":
-                Ms.append(A.float())
-                ts.append(c.float())
+        # actnorm . invconv of ALL layers at once, in fp64 ON THE DEVICE (no host round trip: the training step must not
+        # synchronise): A = W diag(e^logs), c = A b (FlowStep.py:83-88); log|det W| by the closed 3x3 formula
+        # (Permutations.py:27 uses slogdet), actnorm's logdet is sum(logs) (FlowActNorms.py:93-98)
+        Wm = torch.stack([l.invconv.weight for l in self.layers]).double()                 # [L, 3, 3]
+        logs = torch.stack([l.actnorm.logs.reshape(-1) for l in self.layers]).double()     # [L, 3]
+        bias = torch.stack([l.actnorm.bias.reshape(-1) for l in self.layers]).double()
+        A2 = Wm * torch.exp(logs).unsqueeze(1)
+        c2 = (A2 @ bias.unsqueeze(-1)).squeeze(-1)
+        det = (Wm[:, 0, 0] * (Wm[:, 1, 1] * Wm[:, 2, 2] - Wm[:, 1, 2] * Wm[:, 2, 1])
+               - Wm[:, 0, 1] * (Wm[:, 1, 0] * Wm[:, 2, 2] - Wm[:, 1, 2] * Wm[:, 2, 0])
+               + Wm[:, 0, 2] * (Wm[:, 1, 0] * Wm[:, 2, 1] - Wm[:, 1, 1] * Wm[:, 2, 0]))
+        const_ld = logs.sum() + torch.log(det.abs()).sum()
+        Mts, steps, pend = [], [], None
+        for i, layer in enumerate(self.layers):          # only the coupling-free layers before a coupling step need composing
+            A, c = A2[i], c2[i]
+            if pend is not None:
+                A, c = A @ pend[0], A @ pend[1] + c
+            if layer.flow_coupling == "noCoupling":
+                pend = (A, c)
+            else:
+                Mts.append(torch.cat([A.reshape(9), c]))
                 steps.append(layer.affine)
-                A, c = torch.eye(3, dtype=torch.float64), torch.zeros(3, dtype=torch.float64)
+                pend = None
         assert self.layers[len(self.layers) - 1].flow_coupling != "noCoupling"
 
         # batched folds: stack the raw parameters of all coupling steps once, then ONE op per fold for all steps
@@ -248,20 +257,22 @@ class FlowUpsamplerNet(HipModule):
         c4w, c4b = fold([a.fAffine[4] for a in steps])
         f2w, f2b = fold([a.fFeatures[2] for a in steps])
         f4w, f4b = fold([a.fFeatures[4] for a in steps])
-        P = {"Ms": torch.stack(Ms), "ts": torch.stack(ts),
+        P = {"Mt": torch.stack(Mts).float(),
              "wz": a0w[:, :, 0].reshape(len(steps), 64, 9),
              "ftA_w": a0w[:, :, 1:].reshape(-1, 64, 3, 3), "ftA_b": a0b.reshape(-1),
              "f0_w": f0w.reshape(-1, 64, 3, 3), "f0_b": f0b.reshape(-1),
              "c2_w": c2w, "c2_b": c2b, "c4_w": c4w, "c4_b": c4b, "f2_w": f2w, "f2_b": f2b, "f4_w": f4w, "f4_b": f4b}
         return P, const_ld, float(steps[0].affine_eps), dev
 
-    def train_nll_terms(self, gt, ft, mean):
+    def train_nll_terms(self, gt, ft, mean, params=None):
         """gt, mean: fp32 NHWC [B,h,w,3]; ft: bf16 NHWC [B,h,w,64] (both may carry a tape).  Returns per-sample
-        (logdet, logp) float64 tensors on the device, differentiable w.r.t. ft, mean and every flow parameter."""
-        P, const_ld, eps, dev = self._train_params()
+        (logdet, logp) float64 tensors on the device, differentiable w.r.t. ft, mean and every flow parameter.  `params` =
+        a `_train_params()` result computed EARLIER in the step: its tape nodes are then older than the encoder's, so their
+        (tiny) backward runs after the encoder's backward has been enqueued."""
+        P, const_ld, eps, dev = self._train_params() if params is None else params
         ld_data, logp = FlowNLLFn.apply(ft, mean, gt, eps, *[P[k] for k in _FLOW_KEYS])
         pixels = gt.shape[1] * gt.shape[2]
-        return ld_data + (const_ld * pixels).to(dev), logp
+        return ld_data + const_ld * pixels, logp
 
     def encode(self, gt, rrdbResults, logdet=0.0, epses=None, y_onehot=None):
         ft = rrdbResults["cond_feat"] if isinstance(rrdbResults, dict) else rrdbResults
@@ -280,7 +291,7 @@ class FlowUpsamplerNet(HipModule):
         return self.encode(gt, rrdbResults, logdet=logdet, epses=epses, y_onehot=y_onehot)
 
 
-_FLOW_KEYS = ("Ms", "ts", "wz", "ftA_w", "ftA_b", "f0_w", "f0_b", "c2_w", "c2_b", "c4_w", "c4_b", "f2_w", "f2_b", "f4_w", "f4_b")
+_FLOW_KEYS = ("Mt", "wz", "ftA_w", "ftA_b", "f0_w", "f0_b", "c2_w", "c2_b", "c4_w", "c4_b", "f2_w", "f2_b", "f4_w", "f4_b")
 
 
 def _wt(w, pad_to=None):
@@ -294,11 +305,11 @@ class FlowNLLFn(torch.autograd.Function):
     the coupling nets' conv gradients on the MFMA conv / GEMM kernels."""
 
     @staticmethod
-    def forward(ctx, ft, mean, gt, eps, Ms, ts, wz, ftA_w, ftA_b, f0_w, f0_b, c2_w, c2_b, c4_w, c4_b, f2_w, f2_b, f4_w, f4_b):
-        n = Ms.shape[0]
+    def forward(ctx, ft, mean, gt, eps, Mt, wz, ftA_w, ftA_b, f0_w, f0_b, c2_w, c2_b, c4_w, c4_b, f2_w, f2_b, f4_w, f4_b):
+        n = Mt.shape[0]
         B, H, W, _ = gt.shape
         dev = gt.device
-        Mh, th = Ms.detach().cpu().reshape(n, 9).tolist(), ts.detach().cpu().tolist()
+        Mt = Mt.detach().float().contiguous()            # [n, 12] on the device: the kernels read it there
         wz = wz.detach().float().contiguous()
         ft = ft.contiguous()
         ftA = ops.conv2d(ft, ops.PackedConv(ftA_w, ftA_b), out_mode=ops.OUT_NHWC_F32)
@@ -318,7 +329,7 @@ class FlowNLLFn(torch.autograd.Function):
         partial = torch.zeros(2 * n, B * bps, dtype=torch.float32, device=dev)
         for k in range(n):
             z_in[k].copy_(z)
-            ops.flow_fwd_pre(z, hF, 8 * k, Mh[k], th[k], eps, partial[2 * k])
+            ops.flow_fwd_pre(z, hF, 8 * k, None, None, eps, partial[2 * k], Mt_dev=Mt[k])
             z_pre[k].copy_(z)
             ops.flow_h1(z, ftA, 64 * k, wz[k], out=h1s[k])
             ops.conv2d(h1s[k], ops.PackedConv(c2_w[k], c2_b[k]), act="relu", out=h2s[k])
@@ -326,14 +337,14 @@ class FlowNLLFn(torch.autograd.Function):
             ops.flow_fwd_post(z, h4s[k], eps, partial[2 * k + 1])
         mean = mean.contiguous()
         red = ops.flow_nll_reduce(z, mean, partial, 2 * n)
-        ctx.eps, ctx.Mh, ctx.th = eps, Mh, th
-        ctx.save_for_backward(ft, mean, z, h1f, h2f, hF, z_in, z_pre, h1s, h2s, h4s, wz, ftA_w, f0_w, c2_w, c4_w, f2_w, f4_w)
+        ctx.eps = eps
+        ctx.save_for_backward(ft, mean, z, h1f, h2f, hF, z_in, z_pre, h1s, h2s, h4s, wz, ftA_w, f0_w, c2_w, c4_w, f2_w, f4_w, Mt)
         return red[:, 0].clone(), red[:, 1].clone()
 
     @staticmethod
     def backward(ctx, g_logdet, g_logp):
-        ft, mean, z, h1f, h2f, hF, z_in, z_pre, h1s, h2s, h4s, wz, ftA_w, f0_w, c2_w, c4_w, f2_w, f4_w = ctx.saved_tensors
-        eps, Mh, th = ctx.eps, ctx.Mh, ctx.th
+        ft, mean, z, h1f, h2f, hF, z_in, z_pre, h1s, h2s, h4s, wz, ftA_w, f0_w, c2_w, c4_w, f2_w, f4_w, Mt = ctx.saved_tensors
+        eps = ctx.eps
         n, B, H, W, _ = z_in.shape
         dev = z.device
         gld = g_logdet.float().contiguous()
@@ -355,7 +366,7 @@ class FlowNLLFn(torch.autograd.Function):
             ops.conv2d(gh2s[k], _wt(c2_w[k]), out=gftA, out_off=64 * k)
             T.act_backward_(gftA, h1s[k], "relu", C=64, g_off=64 * k)
             T.flow_h1_backward_(gz, gftA, 64 * k, z_pre[k], wz[k], out=dwz[k])
-            T.flow_pre_backward_(gz, z_in[k], hF, 8 * k, gld, Mh[k], th[k], eps, ghF, 8 * k, out=dMt[k])
+            T.flow_pre_backward_(gz, z_in[k], hF, 8 * k, gld, None, None, eps, ghF, 8 * k, out=dMt[k], Mt_dev=Mt[k])
         # filter gradients of the 2 x n coupling convs: ONE transposed-operand pair + ONE batched GEMM per conv type, the
         # batch index being the step (its pixels are a contiguous K slice of the step-major buffers)
         if P % 64 == 0:
@@ -392,5 +403,4 @@ class FlowNLLFn(torch.autograd.Function):
         df2w, df2b, df4w, df4b = df2[:, :, :-1].unflatten(2, (64, 1, 1)), df2[:, :, -1], df4[:, :, :-1].unflatten(2, (64, 3, 3)), df4[:, :, -1]
         gft = ops.conv2d(gh1f, _wt(f0_w))
         gft = ops.conv2d(gftA, _wt(ftA_w), residual=gft)
-        dMt_h = dMt.cpu()
-        return (gft, gmean, None, None, dMt_h[:, :9].reshape(n, 3, 3), dMt_h[:, 9:], dwz, dftAw, dftAb, df0w, df0b, dc2w, dc2b, dc4w, dc4b, df2w, df2b, df4w, df4b)
+        return (gft, gmean, None, None, dMt, dwz, dftAw, dftAb, df0w, df0b, dc2w, dc2b, dc4w, dc4b, df2w, df2b, df4w, df4b)

@@ -30,8 +30,9 @@ class LLFlowVQGAN2(HipModule):
     def train_nll(self, gt_latent, lr):
         """Per-sample NLL (float64 [B]) with a tape through the conditional encoder and the flow: what
         LLFlowModel.optimize_parameters differentiates (LLFlow_model.py:215-236)."""
+        flow_params = self.flowUpsamplerNet._train_params()     # first: see train_nll_terms
         enc = self.RRDB.train_nhwc(lr)
-        logdet, logp = self.flowUpsamplerNet.train_nll_terms(gt_latent, enc["cond_feat"], enc["color_map"])
+        logdet, logp = self.flowUpsamplerNet.train_nll_terms(gt_latent, enc["cond_feat"], enc["color_map"], params=flow_params)
         pixels = gt_latent.shape[1] * gt_latent.shape[2]
         return -(logdet + logp) / (math.log(2.0) * pixels)
 

@@ -311,14 +311,20 @@ def flow_h1_backward_(gz, g, g_off, z_pre, wz, out=None):
     return reduce_parts(part, out=None if out is None else out.view(576)).view(64, 9)
 
 
-def flow_pre_backward_(gz, z_in, hF, hF_off, g_logdet, M, t, eps, ghF, ghF_off, out=None):
+def flow_pre_backward_(gz, z_in, hF, hF_off, g_logdet, M, t, eps, ghF, ghF_off, out=None, Mt_dev=None):
     """gz updated in place to the step input's gradient; ghF slice written; returns (dM fp32 [3,3], dt fp32 [3])."""
-    require_cuda(gz, z_in, hF, g_logdet, ghF)
+    require_cuda(gz, z_in, hF, g_logdet, ghF, Mt_dev)
     B = gz.shape[0]
     lib = _lib.lib()
     npix = gz.numel() // 3
     nb = int(lib.glare_flow_bwd_blocks(_ll(npix)))
     part = torch.empty(nb, 12, dtype=torch.float32, device=gz.device)
+    if Mt_dev is not None:
+        check(lib.glare_flow_fwd_pre_backward_dev_f32(ptr(gz), ptr(z_in), ptr(hF), _i(hF.shape[-1]), _i(hF_off), ptr(g_logdet), _i(B),
+                                                      _ll(npix // B), ptr(Mt_dev), _f(eps), ptr(ghF), _i(ghF.shape[-1]), _i(ghF_off),
+                                                      ptr(part), stream_handle()), "glare_flow_fwd_pre_backward_dev_f32")
+        r = reduce_parts(part, out=out)
+        return r[:9].view(3, 3), r[9:]
     Ma, ta = _host3(M, t)
     check(lib.glare_flow_fwd_pre_backward_f32(ptr(gz), ptr(z_in), ptr(hF), _i(hF.shape[-1]), _i(hF_off), ptr(g_logdet), _i(B),
                                               _ll(npix // B), Ma, ta, _f(eps), ptr(ghF), _i(ghF.shape[-1]), _i(ghF_off), ptr(part),

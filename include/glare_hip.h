@@ -247,6 +247,10 @@ int glare_flow_blocks_per_sample(long long pixels_per_sample);
 int glare_flow_fwd_pre_f32(float* z_nhwc3, const float* hF, int hF_pitch, int hF_off, int B, long long pixels_per_sample,
                            const float* M_3x3_host, const float* t_3_host, float eps, float* logdet_partial,
                            glare_stream_t stream);
+/* same, with the 3x3 matrix (9 floats, row-major) followed by the offset (3 floats) read from DEVICE memory: no host round trip
+ * inside the training step (the launch sequence stays capturable in a hipGraph) */
+int glare_flow_fwd_pre_dev_f32(float* z_nhwc3, const float* hF, int hF_pitch, int hF_off, int B, long long pixels_per_sample,
+                               const float* Mt_12_device, float eps, float* logdet_partial, glare_stream_t stream);
 int glare_flow_fwd_post_f32(float* z_nhwc3, const float* h4, int B, long long pixels_per_sample, float eps,
                             float* logdet_partial, glare_stream_t stream);
 int glare_flow_nll_reduce_f32(const float* z_nhwc3, const float* mean_nhwc3, const float* logdet_partial,
@@ -338,6 +342,10 @@ int glare_flow_fwd_pre_backward_f32(float* gz, const float* z_in, const float* h
                                     const float* g_logdet_per_sample, int B, long long pixels_per_sample,
                                     const float* M_3x3_host, const float* t_3_host, float eps, void* ghF_bf16, int ghF_pitch,
                                     int ghF_off, float* gMt_partial, glare_stream_t stream);
+int glare_flow_fwd_pre_backward_dev_f32(float* gz, const float* z_in, const float* hF, int hF_pitch, int hF_off,
+                                        const float* g_logdet_per_sample, int B, long long pixels_per_sample,
+                                        const float* Mt_12_device, float eps, void* ghF_bf16, int ghF_pitch, int ghF_off,
+                                        float* gMt_partial, glare_stream_t stream);
 
 /* Backward of the a8 glue (stage-3 step, row a13).
  * glare_mix_backward_bf16: out = s a + (1-s) b, s = sigmoid(w): gb = (1-s) g, ga = s g (or NULL), *dw_out = s(1-s) sum g(a-b);
