@@ -176,12 +176,12 @@ class MixFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b, w):
         ctx.save_for_backward(a, b, w)
-        return ops.mix(a, b, float(w.detach()))
+        return ops.mix(a, b, w)                        # w stays on the device: no host synchronisation
 
     @staticmethod
     def backward(ctx, g):
         a, b, w = ctx.saved_tensors
-        ga, gb, dw = T.mix_backward(g.contiguous(), a, b, float(w.detach()), want_ga=ctx.needs_input_grad[0])
+        ga, gb, dw = T.mix_backward(g.contiguous(), a, b, w, want_ga=ctx.needs_input_grad[0])
         return ga, gb, dw.to(w.dtype).view_as(w)
 
 

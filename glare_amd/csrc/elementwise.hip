@@ -13,7 +13,8 @@ constexpr int EW_THREADS = 256;
 __global__ __launch_bounds__(EW_THREADS) void mix_kernel(const bf16_t* __restrict__ a, int a_pitch, int a_off,
                                                          const bf16_t* __restrict__ b, int b_pitch, int b_off,
                                                          bf16_t* __restrict__ out, int o_pitch, int o_off, long long npix,
-                                                         int C, float f) {
+                                                         int C, float f, const float* __restrict__ w_dev) {
+  if (w_dev) f = 1.0f / (1.0f + expf(-w_dev[0]));   // the mixing logit read on the device: no host round trip
   const int CP = C / 8;
   const long long total = npix * CP;
   for (long long i = (long long)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (long long)gridDim.x * EW_THREADS) {
@@ -162,7 +163,18 @@ extern "C" int glare_mix_bf16(const void* a, int a_pitch, int a_off, const void*
   const float f = 1.0f / (1.0f + expf(-mix_w));
   hipLaunchKernelGGL(mix_kernel, dim3(ew_blocks(n_pixels * (C / 8))), dim3(EW_THREADS), 0, (hipStream_t)stream,
                      (const bf16_t*)a, a_pitch, a_off, (const bf16_t*)b, b_pitch, b_off, (bf16_t*)out, out_pitch, out_off,
-                     n_pixels, C, f);
+                     n_pixels, C, f, (const float*)nullptr);
+  return glare_launch_status();
+}
+
+extern "C" int glare_mix_dev_bf16(const void* a, int a_pitch, int a_off, const void* b, int b_pitch, int b_off, void* out,
+                                  int out_pitch, int out_off, long long n_pixels, int C, const float* mix_w_device,
+                                  glare_stream_t stream) {
+  if (!a || !b || !out || !mix_w_device || n_pixels <= 0 || C <= 0) return GLARE_ERR_INVALID;
+  if ((C | a_pitch | a_off | b_pitch | b_off | out_pitch | out_off) % 8) return GLARE_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(mix_kernel, dim3(ew_blocks(n_pixels * (C / 8))), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                     (const bf16_t*)a, a_pitch, a_off, (const bf16_t*)b, b_pitch, b_off, (bf16_t*)out, out_pitch, out_off,
+                     n_pixels, C, 0.f, mix_w_device);
   return glare_launch_status();
 }
 

@@ -391,8 +391,14 @@ __global__ __launch_bounds__(256) void attn_ds_kernel(const bf16_t* __restrict__
 //   gb = (1-s) g, ga = s g (optional), partial[blk] = sum g (a - b)   (dw = s (1-s) * sum)
 __global__ __launch_bounds__(256) void mix_bwd_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ a,
                                                       const bf16_t* __restrict__ b, bf16_t* __restrict__ ga, bf16_t* __restrict__ gb,
-                                                      long long n8, float s, float* __restrict__ partial) {
+                                                      long long n8, float s, const float* __restrict__ w_dev,
+                                                      float* __restrict__ partial) {
   __shared__ float red[4];
+  float post = 1.f;
+  if (w_dev) {   // logit on the device: the partial sums leave already scaled by s (1 - s)
+    s = 1.0f / (1.0f + expf(-w_dev[0]));
+    post = s * (1.f - s);
+  }
   float acc = 0.f;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
     const u32x4 gv = reinterpret_cast<const u32x4*>(g)[i], av = reinterpret_cast<const u32x4*>(a)[i], bv = reinterpret_cast<const u32x4*>(b)[i];
@@ -410,7 +416,7 @@ __global__ __launch_bounds__(256) void mix_bwd_kernel(const bf16_t* __restrict__
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (threadIdx.x == 0) partial[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) * post;
 }
 
 // Mean-rescale backward (deformableDecoder_arch.py:567): out = h + xw r, r = sum(h)/sum(xw) over the sample (or batch)
@@ -680,8 +686,21 @@ extern "C" int glare_mix_backward_bf16(const void* g, const void* a, const void*
   const float s = 1.0f / (1.0f + expf(-w));
   hipLaunchKernelGGL(mix_bwd_kernel, dim3(blocks), dim3(256), 0, ST(stream), static_cast<const bf16_t*>(g), static_cast<const bf16_t*>(a),
                      static_cast<const bf16_t*>(b), static_cast<bf16_t*>(ga_or_null), static_cast<bf16_t*>(gb), n / 8, s,
-                     static_cast<float*>(workspace));
+                     (const float*)nullptr, static_cast<float*>(workspace));
   return glare_reduce_parts_f32(static_cast<const float*>(workspace), blocks, 1, s * (1.f - s), dw_out, 0, stream);
+}
+
+extern "C" int glare_mix_backward_dev_bf16(const void* g, const void* a, const void* b, void* ga_or_null, void* gb, long long n,
+                                           const float* w_device, float* dw_out, void* workspace, size_t workspace_bytes,
+                                           glare_stream_t stream) {
+  if (n < 0 || n % 8) return GLARE_ERR_INVALID;
+  if (!g || !a || !b || !gb || !dw_out || !w_device) return GLARE_ERR_INVALID;
+  const int blocks = (int)(cdivll(n / 8, 256) < 1 ? 1 : (cdivll(n / 8, 256) > 512 ? 512 : cdivll(n / 8, 256)));
+  if (!workspace || workspace_bytes < (size_t)blocks * sizeof(float)) return GLARE_ERR_WORKSPACE;
+  hipLaunchKernelGGL(mix_bwd_kernel, dim3(blocks), dim3(256), 0, ST(stream), static_cast<const bf16_t*>(g), static_cast<const bf16_t*>(a),
+                     static_cast<const bf16_t*>(b), static_cast<bf16_t*>(ga_or_null), static_cast<bf16_t*>(gb), n / 8, 0.f, w_device,
+                     static_cast<float*>(workspace));
+  return glare_reduce_parts_f32(static_cast<const float*>(workspace), blocks, 1, 1.f, dw_out, 0, stream);
 }
 
 extern "C" size_t glare_mean_rescale_backward_workspace_bytes(int B, long long n_per_sample) {

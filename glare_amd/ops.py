@@ -187,6 +187,13 @@ def mix(a, b, w, out=None, out_off=0, a_off=0, b_off=0, C=None):
     npix = a.numel() // a.shape[-1]
     if out is None:
         out = torch.empty(a.shape[:-1] + (C,), dtype=torch.bfloat16, device=a.device)
+    if torch.is_tensor(w):   # device scalar: read by the kernel, no .item() synchronisation
+        require_cuda(w)
+        w32 = w.detach().float().reshape(1)
+        check(_lib.lib().glare_mix_dev_bf16(ptr(a), _i(a.shape[-1]), _i(a_off), ptr(b), _i(b.shape[-1]), _i(b_off), ptr(out),
+                                            _i(out.shape[-1]), _i(out_off), _ll(npix), _i(C), ptr(w32), stream_handle()),
+              "glare_mix_dev_bf16")
+        return out
     check(_lib.lib().glare_mix_bf16(ptr(a), _i(a.shape[-1]), _i(a_off), ptr(b), _i(b.shape[-1]), _i(b_off), ptr(out),
                                     _i(out.shape[-1]), _i(out_off), _ll(npix), _i(C), _f(float(w)), stream_handle()),
           "glare_mix_bf16")

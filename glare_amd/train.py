@@ -147,7 +147,7 @@ class Stage3Trainer:
         loss, self.last_terms = stage3_loss(rec, gt_img, self.perceptual, self.use_msssim)
         loss.backward()
         self.opt.step()
-        G.invalidate()
+        G.deformable_decoder.invalidate()   # only its packed inference weights went stale; the frozen nets keep theirs
         return float(loss.detach())
 
 

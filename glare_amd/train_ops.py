@@ -342,6 +342,11 @@ def mix_backward(g, a, b, w, want_ga=False):
     ga = torch.empty_like(g) if want_ga else None
     dw = torch.empty(1, dtype=torch.float32, device=g.device)
     ws = torch.empty(512, dtype=torch.float32, device=g.device)
+    if torch.is_tensor(w):
+        w32 = w.detach().float().reshape(1)
+        check(_lib.lib().glare_mix_backward_dev_bf16(ptr(g), ptr(a), ptr(b), ptr(ga), ptr(gb), _ll(g.numel()), ptr(w32), ptr(dw), ptr(ws),
+                                                     _sz(2048), stream_handle()), "glare_mix_backward_dev_bf16")
+        return ga, gb, dw
     check(_lib.lib().glare_mix_backward_bf16(ptr(g), ptr(a), ptr(b), ptr(ga), ptr(gb), _ll(g.numel()), _f(float(w)), ptr(dw), ptr(ws),
                                              _sz(2048), stream_handle()), "glare_mix_backward_bf16")
     return ga, gb, dw

@@ -355,6 +355,12 @@ int glare_flow_fwd_pre_backward_dev_f32(float* gz, const float* z_in, const floa
  * glare_sigmoid_f32: y = sigmoid(x) (the DCN mask the backward kernels take explicitly). */
 int glare_mix_backward_bf16(const void* g, const void* a, const void* b, void* ga_or_null, void* gb, long long n, float w,
                             float* dw_out, void* workspace, size_t workspace_bytes, glare_stream_t stream);
+/* the same two with the mixing logit read from DEVICE memory (training: no host synchronisation inside the step) */
+int glare_mix_dev_bf16(const void* a, int a_pitch, int a_off, const void* b, int b_pitch, int b_off, void* out, int out_pitch,
+                       int out_off, long long n_pixels, int C, const float* mix_w_device, glare_stream_t stream);
+int glare_mix_backward_dev_bf16(const void* g, const void* a, const void* b, void* ga_or_null, void* gb, long long n,
+                                const float* w_device, float* dw_out, void* workspace, size_t workspace_bytes,
+                                glare_stream_t stream);
 size_t glare_mean_rescale_backward_workspace_bytes(int B, long long n_per_sample);
 int glare_mean_rescale_backward_bf16(const void* g, const void* h, const float* xw, void* gh, float* gxw, int B,
                                      long long n_per_sample, int whole_batch_mean, void* workspace, size_t workspace_bytes,
