@@ -507,11 +507,23 @@ __global__ __launch_bounds__(256) void l1_loss_kernel(const float* __restrict__ 
 }
 
 // torch.optim.Adam (no amsgrad, no weight decay unless wd != 0 -> L2 added to the gradient as torch does)
+// step counter and bias corrections kept on the device, so that an optimizer step has no host-side state and the whole
+// training step can be replayed from a hipGraph: state = {bc1, sqrt(bc2), lr multiplier}, step_dev = the 1-based step count
+__global__ void adam_prepare_kernel(int* __restrict__ step_dev, float* __restrict__ state, float b1, float b2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int t = step_dev[0] + 1;
+  step_dev[0] = t;
+  state[0] = (float)(1.0 - pow((double)b1, t));
+  state[1] = (float)sqrt(1.0 - pow((double)b2, t));
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
-                                                   float wd, float bc1, float bc2_sqrt, float grad_scale) {
+                                                   float wd, float bc1, float bc2_sqrt, float grad_scale,
+                                                   const float* __restrict__ state_dev) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  if (state_dev) { bc1 = state_dev[0]; bc2_sqrt = state_dev[1]; lr *= state_dev[2]; }
   float gi = g[i] * grad_scale;
   if (wd != 0.f) gi += wd * w[i];
   const float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -751,6 +763,23 @@ extern "C" int glare_adam_step_f32(float* w, const float* grad, float* exp_avg, 
   if (!w || !grad || !exp_avg || !exp_avg_sq) return GLARE_ERR_INVALID;
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)cdivll(n, 256)), dim3(256), 0, ST(stream), w, grad, exp_avg, exp_avg_sq, n, lr, beta1,
-                     beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+                     beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale, (const float*)nullptr);
+  return glare_launch_status();
+}
+
+extern "C" int glare_adam_prepare(int* step_device, float* state3_device, float beta1, float beta2, glare_stream_t stream) {
+  if (!step_device || !state3_device) return GLARE_ERR_INVALID;
+  hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(64), 0, ST(stream), step_device, state3_device, beta1, beta2);
+  return glare_launch_status();
+}
+
+extern "C" int glare_adam_step_dev_f32(float* w, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1,
+                                       float beta2, float eps, float weight_decay, const float* state3_device, float grad_scale,
+                                       glare_stream_t stream) {
+  if (n < 0) return GLARE_ERR_INVALID;
+  if (n == 0) return GLARE_OK;
+  if (!w || !grad || !exp_avg || !exp_avg_sq || !state3_device) return GLARE_ERR_INVALID;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)cdivll(n, 256)), dim3(256), 0, ST(stream), w, grad, exp_avg, exp_avg_sq, n, lr, beta1,
+                     beta2, eps, weight_decay, 1.f, 1.f, grad_scale, state3_device);
   return glare_launch_status();
 }

@@ -15,6 +15,7 @@ from . import autograd as A
 from .modules._base import HipModule
 
 MSSSIM_WEIGHTS = (0.0448, 0.2856, 0.3001, 0.2363, 0.1333)   # pytorch_msssim/__init__.py:73
+_WEIGHTS = {}
 
 
 def gaussian(window_size, sigma=1.5):
@@ -32,11 +33,14 @@ def msssim(sr, gt, window_size=11, normalize=False):
         windows.append(gaussian(min(window_size, h, w)))     # real_size = min(window_size, height, width), :40-42
         h, w = h // 2, w // 2
     sims, css = A.msssim_terms(sr, gt, windows)
-    weights = torch.tensor(MSSSIM_WEIGHTS, dtype=torch.float32, device=sr.device)
+    weights = _WEIGHTS.get(sr.device)
+    if weights is None:   # uploaded once per device (a pageable H2D copy is not allowed inside a captured step)
+        weights = _WEIGHTS[sr.device] = torch.tensor(MSSSIM_WEIGHTS, dtype=torch.float32, device=sr.device)
     if normalize:                                             # :86-88
         sims, css = (sims + 1) / 2, (css + 1) / 2
     pow1, pow2 = css ** weights, sims ** weights
-    return torch.prod(pow1[:-1] * pow2[-1])                   # :92
+    x = pow1[:-1] * pow2[-1]                                  # :92 torch.prod(...), written out: prod's backward inspects
+    return x[0] * x[1] * x[2] * x[3]                          # its input for zeros on the host (a sync; not graph-capturable)
 
 
 class PerceptualNetwork(HipModule):

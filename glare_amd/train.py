@@ -67,28 +67,56 @@ class FlatGroup:
 
 
 class FlatAdam:
-    def __init__(self, groups, betas=(0.9, 0.999), eps=1e-8):
-        self.groups, self.betas, self.eps, self.t = groups, betas, eps, 0
+    """device_state=True keeps the step count, the bias corrections and an lr multiplier in device memory (no host-side optimizer
+    state inside a step): required for replaying the training step from a hipGraph (GraphedStep)."""
+
+    def __init__(self, groups, betas=(0.9, 0.999), eps=1e-8, device_state=False):
+        self.groups, self.betas, self.eps, self._t = groups, betas, eps, 0
+        self.device_state = device_state
+        if device_state:
+            dev = next(g.w.device for g in groups if g.w.numel())
+            self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.state3 = torch.tensor([1.0, 1.0, 1.0], dtype=torch.float32, device=dev)   # bc1, sqrt(bc2), lr multiplier
+
+    @property
+    def t(self):
+        return int(self.step_dev.item()) if self.device_state else self._t
+
+    @t.setter
+    def t(self, v):
+        if self.device_state:
+            self.step_dev.fill_(int(v))
+        self._t = int(v)
+
+    def set_lr_scale(self, s):
+        """Scheduler hook for the device-state mode: lr_effective = group lr * s (a device scalar the graph reads)."""
+        self.state3[2] = float(s)
 
     def zero_grad(self):
         for g in self.groups:
             g.zero_grad()
 
     def step(self):
-        self.t += 1
+        if self.device_state:
+            T.adam_prepare_(self.step_dev, self.state3, self.betas)
+        else:
+            self._t += 1
         for g in self.groups:
             if g.w.numel() == 0:
                 continue
             g.collect()
             world = g.all_reduce()
-            T.adam_step_(g.w, g.g, g.m, g.v, self.t, g.lr, self.betas, self.eps, g.weight_decay, grad_scale=1.0 / world)
+            if self.device_state:
+                T.adam_step_dev_(g.w, g.g, g.m, g.v, self.state3, g.lr, self.betas, self.eps, g.weight_decay, grad_scale=1.0 / world)
+            else:
+                T.adam_step_(g.w, g.g, g.m, g.v, self._t, g.lr, self.betas, self.eps, g.weight_decay, grad_scale=1.0 / world)
 
 
 class Stage2Trainer:
     """One optimisation step of the flow objective: a7 (frozen VQGAN encoder, no tape) -> a1 -> a4 -> mean NLL -> backward ->
     gradient mean over ranks -> Adam."""
 
-    def __init__(self, netG, net_hq, lr_G=5e-4, lr_RRDB=None, weight_decay_G=0.0, train_rrdb=True):
+    def __init__(self, netG, net_hq, lr_G=5e-4, lr_RRDB=None, weight_decay_G=0.0, train_rrdb=True, device_state=False):
         self.netG, self.net_hq = netG.train(), net_hq.eval()
         for p in net_hq.parameters():
             p.requires_grad_(False)
@@ -99,10 +127,14 @@ class Stage2Trainer:
                 p.requires_grad_(False)
         self.opt = FlatAdam([FlatGroup(other, lr_G, weight_decay_G),
                              FlatGroup(rrdb, lr_G if lr_RRDB is None else lr_RRDB, 1e-5)] if train_rrdb else
-                            [FlatGroup(other, lr_G, weight_decay_G)])
+                            [FlatGroup(other, lr_G, weight_decay_G)], device_state=device_state)
 
     def step(self, gt_img, lr_img):
         """gt_img: fp32 NCHW ground-truth crop in [0,1]; lr_img: fp32 NCHW low-light crop (log domain).  Returns the loss."""
+        return float(self.step_tensor(gt_img, lr_img))
+
+    def step_tensor(self, gt_img, lr_img):
+        """The step without any host synchronisation: returns the loss as a device tensor."""
         with torch.no_grad():
             gt_latent = self.net_hq.encode_nhwc(gt_img)            # LLFlow_model.py:200-201
         self.opt.zero_grad()
@@ -111,7 +143,7 @@ class Stage2Trainer:
         loss.backward()                                            # :236
         self.opt.step()                                            # :240
         self.netG.invalidate()                                     # packed inference weights are stale now
-        return float(loss.detach())
+        return loss.detach()
 
 
 class Stage3Trainer:
@@ -121,7 +153,7 @@ class Stage3Trainer:
     perceptual + 0.2 * (1 - MS-SSIM(normalize=True)).  The perceptual network's weights are the caller's (`perceptual=`): the
     reference downloads torchvision's pretrained VGG16, which is not available offline; pass None to train on L1 + MS-SSIM."""
 
-    def __init__(self, netG, net_hq, lr_G=5e-5, weight_decay_G=0.0, perceptual=None, use_msssim=True):
+    def __init__(self, netG, net_hq, lr_G=5e-5, weight_decay_G=0.0, perceptual=None, use_msssim=True, device_state=False):
         from . import autograd as A
         from . import losses
 
@@ -133,10 +165,13 @@ class Stage3Trainer:
         for n, p in netG.named_parameters():
             p.requires_grad_(n.startswith("deformable_decoder."))
         self.opt = FlatAdam([FlatGroup([p for n, p in netG.named_parameters() if n.startswith("deformable_decoder.")],
-                                       lr_G, weight_decay_G)])
+                                       lr_G, weight_decay_G)], device_state=device_state)
 
     def step(self, gt_img, lr_img):
         """gt_img: fp32 NCHW in [0,1]; lr_img: fp32 NCHW low-light crop (log domain).  Returns the loss."""
+        return float(self.step_tensor(gt_img, lr_img))
+
+    def step_tensor(self, gt_img, lr_img):
         G = self.netG
         with torch.no_grad():
             enc = G.RRDB.forward_nhwc(lr_img)
@@ -148,7 +183,7 @@ class Stage3Trainer:
         loss.backward()
         self.opt.step()
         G.deformable_decoder.invalidate()   # only its packed inference weights went stale; the frozen nets keep theirs
-        return float(loss.detach())
+        return loss.detach()
 
 
 def stage3_loss(rec_nhwc, gt_nchw, perceptual=None, use_msssim=True):
@@ -167,3 +202,33 @@ def stage3_loss(rec_nhwc, gt_nchw, perceptual=None, use_msssim=True):
         if use_msssim:
             terms["ssim_loss"] = (1 - losses.msssim(sr, gt_nhwc, normalize=True)) * 0.2
     return sum(terms.values()), terms
+
+
+class GraphedStep:
+    """A training step captured once into a hipGraph (torch.cuda.CUDAGraph) and replayed: the ~5 000 kernel launches of a step
+    at the reference's crop sizes are launch-bound from Python, the graph removes the host from the loop.  Needs a trainer
+    built with device_state=True (no host-side optimizer state) and fixed input shapes; inputs are copied into static buffers.
+    World size 1 only (a collective inside the captured region is not attempted)."""
+
+    def __init__(self, trainer, gt_img, lr_img, warmup=3):
+        assert trainer.opt.device_state, "build the trainer with device_state=True"
+        self.trainer = trainer
+        self.gt, self.lr = gt_img.clone(), lr_img.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):                 # allocator / lazy-init warm-up outside the capture
+                trainer.step_tensor(self.gt, self.lr)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = trainer.step_tensor(self.gt, self.lr)
+
+    def step_tensor(self, gt_img, lr_img):
+        self.gt.copy_(gt_img)
+        self.lr.copy_(lr_img)
+        self.graph.replay()
+        return self.loss
+
+    def step(self, gt_img, lr_img):
+        return float(self.step_tensor(gt_img, lr_img))

@@ -476,3 +476,17 @@ def mse_loss(a, b, want_grad=True):
     check(_lib.lib().glare_mse_loss_bf16(ptr(a), ptr(b), _ll(a.numel()), ptr(loss), ptr(ga), ptr(ws), _sz(2048), stream_handle()),
           "glare_mse_loss_bf16")
     return loss, ga
+
+
+def adam_prepare_(step_dev, state3, betas):
+    require_cuda(step_dev, state3)
+    assert step_dev.dtype == torch.int32 and state3.dtype == torch.float32 and state3.numel() == 3
+    check(_lib.lib().glare_adam_prepare(ptr(step_dev), ptr(state3), _f(betas[0]), _f(betas[1]), stream_handle()), "glare_adam_prepare")
+
+
+def adam_step_dev_(w, grad, exp_avg, exp_avg_sq, state3, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+    require_cuda(w, grad, exp_avg, exp_avg_sq, state3)
+    check(_lib.lib().glare_adam_step_dev_f32(ptr(w), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), _ll(w.numel()), _f(lr), _f(betas[0]),
+                                             _f(betas[1]), _f(eps), _f(weight_decay), ptr(state3), _f(grad_scale), stream_handle()),
+          "glare_adam_step_dev_f32")
+    return w

@@ -325,6 +325,13 @@ int glare_attention_ds_bf16(const void* P, long long ldp, const float* dP, long 
  * 1-based step count, grad_scale multiplies the gradient first (1/world for the data-parallel mean). */
 int glare_adam_step_f32(float* w, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1,
                         float beta2, float eps, float weight_decay, int step, float grad_scale, glare_stream_t stream);
+/* The same step with ALL optimizer state on the device, so that a whole training step replays from a hipGraph:
+ * glare_adam_prepare increments *step_device and writes state3 = {1 - beta1^t, sqrt(1 - beta2^t), (unchanged) lr multiplier};
+ * glare_adam_step_dev_f32 reads the bias corrections and the lr multiplier from state3 (lr_effective = lr * state3[2]). */
+int glare_adam_prepare(int* step_device, float* state3_device, float beta1, float beta2, glare_stream_t stream);
+int glare_adam_step_dev_f32(float* w, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1,
+                            float beta2, float eps, float weight_decay, const float* state3_device, float grad_scale,
+                            glare_stream_t stream);
 
 /* Backward of the flow's normal direction (adjoint of glare_flow_fwd_pre / _h1 / _fwd_post / _nll_reduce): autograd
  * through FlowStep.normal_flow (FlowStep.py:75-98) and GaussianDiag.logp (flow.py:76-95).  gz is the latent's gradient,

@@ -506,3 +506,29 @@ def test_stage3_total_loss_vs_oracle():
     assert abs(float(terms["percep_loss"].detach()) - float(pl_r.detach())) < 3e-2 * abs(float(pl_r.detach()))
     gref = torch.nan_to_num(rr.grad, nan=0.0)
     assert _rel(rd.grad.cpu().permute(0, 3, 1, 2), gref) < 2e-2
+
+
+def test_graphed_step_replays_the_eager_step_bit_identically():
+    """The whole stage-2 step (frozen encode, forward, backward, flat Adam with device-side state) captured into a hipGraph and
+    replayed must produce exactly the parameters the eager steps produce: no host state, no synchronisation, no atomics."""
+    from glare_amd import modules as M
+    from glare_amd.synthetic import seeded_init_
+    from glare_amd.train import GraphedStep, Stage2Trainer
+
+    g = torch.Generator().manual_seed(41)
+    gt_img = torch.rand(2, 3, 64, 64, generator=g).to(_dev())
+    lr_img = (torch.randn(2, 3, 64, 64, generator=g) * 0.5 - 1.0).to(_dev())
+    net_hq = seeded_init_(M.VQModel().eval(), 1).to(_dev())
+    finals = []
+    for graphed in (False, True):
+        hip, _ = _stage2_pair(9)
+        tr = Stage2Trainer(hip, net_hq, lr_G=2e-4, device_state=True)
+        if graphed:
+            gs = GraphedStep(tr, gt_img, lr_img, warmup=2)         # 2 eager steps, then capture
+            losses = [gs.step(gt_img, lr_img) for _ in range(3)]   # 3 replays
+        else:
+            losses = [tr.step(gt_img, lr_img) for _ in range(5)]
+        assert tr.opt.t == 5
+        finals.append((losses[-1], torch.cat([grp.w for grp in tr.opt.groups]).clone()))
+    assert finals[0][0] == finals[1][0]
+    assert torch.equal(finals[0][1], finals[1][1])

@@ -1,5 +1,5 @@
 """Times the training steps at the reference's per-GPU shapes (T2 = stage 2, 2 x 3x320x320 per GPU;
-T3 = stage 3, 1 x 3x256x256 per GPU).  python tools/train_bench.py [stage2|stage3] [steps]"""
+T3 = stage 3, 1 x 3x256x256 per GPU).  python tools/train_bench.py [stage2|stage3] [steps] [graph]"""
 import os
 import sys
 import time
@@ -9,28 +9,31 @@ import torch
 
 from glare_amd import modules as M
 from glare_amd.synthetic import seeded_init_
-from glare_amd.train import Stage2Trainer, Stage3Trainer
+from glare_amd.train import GraphedStep, Stage2Trainer, Stage3Trainer
 
 which = sys.argv[1] if len(sys.argv) > 1 else "stage2"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+graph = len(sys.argv) > 3 and sys.argv[3] == "graph"
 dev = torch.device("cuda", 0)
 g = torch.Generator().manual_seed(10)
 net_hq = seeded_init_(M.VQModel().eval(), 1).to(dev)
 if which == "stage2":
     B, S = 2, 320
-    tr = Stage2Trainer(seeded_init_(M.LLFlowVQGAN2().train(), 2).to(dev), net_hq)
+    tr = Stage2Trainer(seeded_init_(M.LLFlowVQGAN2().train(), 2).to(dev), net_hq, device_state=graph)
 else:
     B, S = 1, 256
-    tr = Stage3Trainer(seeded_init_(M.VQLLFLOWDeformable().train(), 0).to(dev), net_hq)
+    tr = Stage3Trainer(seeded_init_(M.VQLLFLOWDeformable().train(), 0).to(dev), net_hq, device_state=graph)
 gt = torch.rand(B, 3, S, S, generator=g).to(dev)
 lr = (torch.randn(B, 3, S, S, generator=g) * 0.5 - 1.0).to(dev)
+if graph:
+    tr = GraphedStep(tr, gt, lr)
 for _ in range(2):
     loss = tr.step(gt, lr)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(steps):
-    loss = tr.step(gt, lr)
+    loss = tr.step_tensor(gt, lr)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
-print("%s: B=%d %dx%d  %.1f ms/step  %.2f samples/s  loss %.4f  peak mem %.2f GB"
-      % (which, B, S, S, dt * 1e3, B / dt, loss, torch.cuda.max_memory_allocated() / 2**30))
+print("%s%s: B=%d %dx%d  %.1f ms/step  %.2f samples/s  loss %.4f  peak mem %.2f GB"
+      % (which, " (hipGraph replay)" if graph else "", B, S, S, dt * 1e3, B / dt, float(loss), torch.cuda.max_memory_allocated() / 2**30))
