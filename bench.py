@@ -49,6 +49,27 @@ def build_nets(device):
     return netG, net_vq
 
 
+def profiled_traffic(batch):
+    """HBM bytes per launch of the attention kernel from the committed PMC passes (profiles/r01_pmc_traffic.txt: rocprofv3 --pmc
+    FETCH_SIZE and WRITE_SIZE in separate counter-only runs at B=8; FETCH x2 per the gfx950 note of MI355X_MICROARCH.md).
+    Counters cannot be read inside this process, so the figure is the profiled one for the SAME launch shape, else None."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.txt")
+    if batch != 8 or not os.path.exists(path):
+        return None, None
+    fetch = write = None
+    with open(path) as f:
+        block = f.read().split("== attn", 1)[-1].split("==", 1)[0]
+    for line in block.splitlines():
+        t = line.split()
+        if len(t) >= 2 and t[0] == "FETCH_SIZE":
+            fetch = float(t[1])
+        if len(t) >= 2 and t[0] == "WRITE_SIZE":
+            write = float(t[1])
+    if fetch is None or write is None:
+        return None, None
+    return int((2.0 * fetch + write) * 1024), "profiles/r01_pmc_traffic.txt (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes, KB, FETCH x2)"
+
+
 def attention_roofline(device, batch, reps=5):
     """Times the attention kernel alone at the path's shape (N = 105*155 tokens, d = 512)."""
     from glare_amd import ops
@@ -72,8 +93,10 @@ def attention_roofline(device, batch, reps=5):
     ms = s.elapsed_time(e) / reps
     flops = 4.0 * batch * N * N * C  # algorithmic: QK^T + PV, SURVEY.md section 8d
     achieved = flops / (ms * 1e-3) / 1e12
+    traffic, source = profiled_traffic(batch)
     return {"bound": "mfma", "kernel": "attn_fwd_kernel (d=512 blockwise attention)", "achieved": round(achieved, 1),
-            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+            "traffic_unit": "HBM bytes per launch", "traffic_source": source, "algorithmic_bytes": int(4 * 2 * batch * N * C),
             "ms_per_launch": round(ms, 3), "launch_shape": {"B": batch, "N": N, "d": C}}
 
 

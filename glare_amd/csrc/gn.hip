@@ -106,8 +106,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __re
   const long long p0 = blk * per, p1 = min(HW, p0 + per);
   const bf16_t* xb = x + (size_t)b * HW * pitch + off + chunk * 8;
   bf16_t* yb = y + (size_t)b * HW * C + chunk * 8;
-  for (long long p = p0 + pl; p < p1; p += ppi) {
-    const u32x4 v = *reinterpret_cast<const u32x4*>(xb + (size_t)p * pitch);
+  auto apply = [&](const u32x4& v) {
     u32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -116,8 +115,20 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __re
       if (swish) { lo = swishf_(lo); hi = swishf_(hi); }
       o[e] = pack_bf2(lo, hi);
     }
-    *reinterpret_cast<u32x4*>(yb + (size_t)p * C) = o;
+    return o;
+  };
+  long long p = p0 + pl;
+  for (; p + 3LL * ppi < p1; p += 4LL * ppi) {   // 4 independent 16-B loads in flight per lane
+    const u32x4 v0 = *reinterpret_cast<const u32x4*>(xb + (size_t)p * pitch);
+    const u32x4 v1 = *reinterpret_cast<const u32x4*>(xb + (size_t)(p + ppi) * pitch);
+    const u32x4 v2 = *reinterpret_cast<const u32x4*>(xb + (size_t)(p + 2LL * ppi) * pitch);
+    const u32x4 v3 = *reinterpret_cast<const u32x4*>(xb + (size_t)(p + 3LL * ppi) * pitch);
+    *reinterpret_cast<u32x4*>(yb + (size_t)p * C) = apply(v0);
+    *reinterpret_cast<u32x4*>(yb + (size_t)(p + ppi) * C) = apply(v1);
+    *reinterpret_cast<u32x4*>(yb + (size_t)(p + 2LL * ppi) * C) = apply(v2);
+    *reinterpret_cast<u32x4*>(yb + (size_t)(p + 3LL * ppi) * C) = apply(v3);
   }
+  for (; p < p1; p += ppi) *reinterpret_cast<u32x4*>(yb + (size_t)p * C) = apply(*reinterpret_cast<const u32x4*>(xb + (size_t)p * pitch));
 }
 
 int gn_splits(long long HW) {
