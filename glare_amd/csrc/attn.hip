@@ -72,6 +72,9 @@ struct AttnParams {
   long long Npad;
   int ldq, ldk, ldo;
   int n_qblocks, n_blocks;
+  int key_splits;      // > 1: each workgroup covers 1/key_splits of the keys and leaves an un-normalised partial
+  float* part_o;       // [B][key_splits][N][512] fp32
+  float* part_ml;      // [B][key_splits][N][2]   (running max in log2 units, sum)
 };
 
 __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParams p) {
@@ -84,7 +87,8 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
     const int n = p.n_blocks, q = n / 8, r = n % 8, xcd = bid % 8, kk = bid / 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kk;
   }
-  const int b = bid / p.n_qblocks, qb = bid % p.n_qblocks;
+  // block order: (image, key split, query block) -- neighbours stream the same K/V range through one L2
+  const int qb = bid % p.n_qblocks, ksplit = (bid / p.n_qblocks) % p.key_splits, b = bid / (p.n_qblocks * p.key_splits);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ql = lane & 31, hi = lane >> 5;
@@ -111,6 +115,8 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
   float m_run = -1e30f, l_run = 0.f;
 
   const int n_tiles = (p.N + BN - 1) / BN;
+  // this workgroup's key tiles (all of them unless the keys are split across workgroups to fill the chip at small batch)
+  const int t_begin = (int)((long long)n_tiles * ksplit / p.key_splits), t_end = (int)((long long)n_tiles * (ksplit + 1) / p.key_splits);
   const bf16_t* kbase = p.k + (size_t)b * p.N * p.ldk;
   const bf16_t* vbase = p.vt + (size_t)b * HD * p.Npad;
 
@@ -336,7 +342,7 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
     // The next tile's 16 DMA pieces are NOT issued here in one burst (all four waves would queue on the
     // texture-address path with the matrix pipe idle: measured -27 %); they are spread, ATTN_DMA_PER_GROUP per
     // MFMA group, so the address path works under the MFMAs.
-    const int nxt = min(tile + 1, n_tiles - 1);  // last tile: a redundant reload keeps the loop branch-free
+    const int nxt = min(tile + 1, t_end - 1);  // last tile: a redundant reload keeps the loop branch-free
     const char* kb = smem + BUF * KCH * 16;
     const char* vb = smem + BUF * KCH * 16;
     bf16x8 fr[3][4];
@@ -444,16 +450,31 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
     });
   };
 
-  issue(0, 0);
-  for (int tile = 0; tile < n_tiles; tile += 2) {
+  issue(t_begin, 0);
+  for (int tile = t_begin; tile < t_end; tile += 2) {
     tile_body(std::integral_constant<int, 0>{}, tile);
-    if (tile + 1 < n_tiles) tile_body(std::integral_constant<int, 1>{}, tile + 1);
+    if (tile + 1 < t_end) tile_body(std::integral_constant<int, 1>{}, tile + 1);
   }
 
 #endif
 
   // ---- normalise and store O[q][d] (bf16): a lane owns ONE query row, 4 consecutive d per store
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  if (p.key_splits > 1) {   // partial: un-normalised accumulators + (max, sum); attn_combine_kernel merges the splits
+    if (q_ok) {
+      const size_t row = ((size_t)b * p.key_splits + ksplit) * p.N + qrow;
+      float* po = p.part_o + row * HD;
+#pragma unroll
+      for (int dt = 0; dt < HD / 32; ++dt)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const int d = dt * 32 + 8 * rq + 4 * hi;
+          *reinterpret_cast<f32x4*>(po + d) = f32x4{o[dt][4 * rq], o[dt][4 * rq + 1], o[dt][4 * rq + 2], o[dt][4 * rq + 3]};
+        }
+      if (hi == 0) { p.part_ml[row * 2] = m_run; p.part_ml[row * 2 + 1] = l_tot; }
+    }
+    return;
+  }
   const float inv = 1.0f / l_tot;
   if (q_ok) {
     bf16_t* op = p.o + ((size_t)b * p.N + qrow) * p.ldo;
@@ -469,23 +490,79 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
   }
 }
 
+// out[q] = sum_s 2^(m_s - m) O_s[q] / sum_s 2^(m_s - m) l_s,  m = max_s m_s: merges the key splits (one wave per query row)
+__global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                                           bf16_t* __restrict__ out, int ldo, int B, int N, int KS) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // b * N + q
+  if (row >= (long long)B * N) return;
+  const int lane = threadIdx.x & 63, b = (int)(row / N), q = (int)(row % N);
+  float m = -1e30f;
+  for (int s = 0; s < KS; ++s) m = fmaxf(m, part_ml[(((size_t)b * KS + s) * N + q) * 2]);
+  float acc[8], L = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  for (int s = 0; s < KS; ++s) {
+    const size_t r = ((size_t)b * KS + s) * N + q;
+    const float w = __builtin_amdgcn_exp2f(part_ml[r * 2] - m);
+    L += w * part_ml[r * 2 + 1];
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(part_o + r * HD + lane * 8);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(part_o + r * HD + lane * 8 + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { acc[e] = fmaf(w, v0[e], acc[e]); acc[4 + e] = fmaf(w, v1[e], acc[4 + e]); }
+  }
+  const float inv = 1.0f / L;
+  u32x4 o = {pack_bf2(acc[0] * inv, acc[1] * inv), pack_bf2(acc[2] * inv, acc[3] * inv), pack_bf2(acc[4] * inv, acc[5] * inv),
+             pack_bf2(acc[6] * inv, acc[7] * inv)};
+  *reinterpret_cast<u32x4*>(out + (size_t)row * ldo + lane * 8) = o;
+}
+
 }  // namespace
+
+static int attn_launch(const void* q, int ldq, const void* k, int ldk, const void* v_t, long long v_pitch, void* out, int ldo, int B,
+                       int N, int key_splits, void* workspace, size_t workspace_bytes, glare_stream_t stream);
+
+extern "C" size_t glare_attention_d512_splitk_workspace_bytes(int B, int N, int key_splits) {
+  if (B <= 0 || N <= 0 || key_splits <= 1) return 0;
+  return (size_t)B * key_splits * N * (HD + 2) * sizeof(float);
+}
+
+extern "C" int glare_attention_d512_splitk_bf16(const void* q, int ldq, const void* k, int ldk, const void* v_t, long long v_pitch,
+                                                void* out, int ldo, int B, int N, int key_splits, void* workspace,
+                                                size_t workspace_bytes, glare_stream_t stream) {
+  return attn_launch(q, ldq, k, ldk, v_t, v_pitch, out, ldo, B, N, key_splits, workspace, workspace_bytes, stream);
+}
 
 extern "C" int glare_attention_d512_bf16(const void* q, int ldq, const void* k, int ldk, const void* v_t,
                                          long long v_pitch, void* out, int ldo, int B, int N, glare_stream_t stream) {
-  if (!q || !k || !v_t || !out || B <= 0 || N <= 0) return GLARE_ERR_INVALID;
+  return attn_launch(q, ldq, k, ldk, v_t, v_pitch, out, ldo, B, N, 1, nullptr, 0, stream);
+}
+
+static int attn_launch(const void* q, int ldq, const void* k, int ldk, const void* v_t, long long v_pitch, void* out, int ldo, int B,
+                       int N, int key_splits, void* workspace, size_t workspace_bytes, glare_stream_t stream) {
+  if (!q || !k || !v_t || !out || B <= 0 || N <= 0 || key_splits < 1) return GLARE_ERR_INVALID;
+  if (key_splits > (N + BN - 1) / BN) return GLARE_ERR_INVALID;   // every split owns at least one key tile
+  if (key_splits > 1) {
+    if (ATTN_PIPELINED) return GLARE_ERR_UNSUPPORTED;
+    if ((ldo % 8) || !workspace || workspace_bytes < glare_attention_d512_splitk_workspace_bytes(B, N, key_splits)) return GLARE_ERR_WORKSPACE;
+  }
   if ((ldq % 8) || (ldk % 8) || (ldo % 4) || (v_pitch % 8) || ldq < HD || ldk < HD || ldo < HD) return GLARE_ERR_UNSUPPORTED;
   if (v_pitch < (long long)((N + BN - 1) / BN) * BN) return GLARE_ERR_INVALID;  // tiles read whole 32-key groups
   AttnParams p;
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.vt = (const bf16_t*)v_t; p.o = (bf16_t*)out;
   p.B = B; p.N = N; p.Npad = v_pitch; p.ldq = ldq; p.ldk = ldk; p.ldo = ldo;
   p.n_qblocks = (N + BM - 1) / BM;
-  const long long nb = (long long)B * p.n_qblocks;
+  p.key_splits = key_splits;
+  p.part_o = static_cast<float*>(workspace);
+  p.part_ml = p.part_o ? p.part_o + (size_t)B * key_splits * N * HD : nullptr;
+  const long long nb = (long long)B * p.n_qblocks * key_splits;
   if (nb > 0x7fffffffLL) return GLARE_ERR_INVALID;
   p.n_blocks = (int)nb;
   const size_t lds = (size_t)4 * KCH * 16 + (ATTN_PIPELINED ? 4 * 8192 : 0);  // 128 KB K/V ring (+ 32 KB Q tail)
   if (hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GLARE_ERR_LAUNCH;
   hipLaunchKernelGGL(attn_fwd_kernel, dim3(p.n_blocks), dim3(AT_THREADS), lds, (hipStream_t)stream, p);
+  if (key_splits > 1)
+    hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)(((long long)B * N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p.part_o,
+                       p.part_ml, p.o, ldo, B, N, key_splits);
   return glare_launch_status();
 }

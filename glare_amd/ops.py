@@ -260,7 +260,15 @@ def flow_tail(z, h4, hF, hF_off, M, t, eps=1e-4):
 
 
 # ---- attention ------------------------------------------------------------------------------------
-def attention_d512(q, k, v_t, N, ldq=None, ldk=None, out=None):
+def attention_key_splits(B, N):
+    """Workgroups = B * ceil(N/128) query blocks; below two full rounds of the 256 CUs the keys are split to fill the chip."""
+    blocks = B * ((N + 127) // 128)
+    if blocks >= 512:
+        return 1
+    return max(1, min(4, (512 + blocks - 1) // blocks, (N + 31) // 32))
+
+
+def attention_d512(q, k, v_t, N, ldq=None, ldk=None, out=None, key_splits=None):
     """q, k: bf16 [B, N, ld] views (d=512 used); v_t: bf16 [B, 512, v_pitch]; returns bf16 [B, N, 512]."""
     require_cuda(q, k, v_t, out)
     B = v_t.shape[0]
@@ -268,6 +276,16 @@ def attention_d512(q, k, v_t, N, ldq=None, ldk=None, out=None):
     ldk = k.shape[-1] if ldk is None else ldk
     if out is None:
         out = torch.empty(B, N, 512, dtype=torch.bfloat16, device=v_t.device)
+    ks = attention_key_splits(B, N) if key_splits is None else key_splits
+    if ks > 1:
+        lib = _lib.lib()
+        lib.glare_attention_d512_splitk_workspace_bytes.restype = _sz
+        nws = lib.glare_attention_d512_splitk_workspace_bytes(_i(B), _i(N), _i(ks))
+        ws = _workspace(nws, v_t.device)
+        check(lib.glare_attention_d512_splitk_bf16(ptr(q), _i(ldq), ptr(k), _i(ldk), ptr(v_t), _ll(v_t.shape[2]), ptr(out),
+                                                   _i(out.shape[-1]), _i(B), _i(N), _i(ks), ptr(ws), _sz(nws), stream_handle()),
+              "glare_attention_d512_splitk_bf16")
+        return out
     check(_lib.lib().glare_attention_d512_bf16(ptr(q), _i(ldq), ptr(k), _i(ldk), ptr(v_t), _ll(v_t.shape[2]), ptr(out),
                                                _i(out.shape[-1]), _i(B), _i(N), stream_handle()),
           "glare_attention_d512_bf16")

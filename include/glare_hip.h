@@ -179,6 +179,13 @@ int glare_flow_tail_f32(float* z_nhwc3, const float* h4, const float* hF, int hF
  * out  : bf16 [B][N][ldo]. */
 int glare_attention_d512_bf16(const void* q, int ldq, const void* k, int ldk, const void* v_t, long long v_pitch,
                               void* out, int ldo, int B, int N, glare_stream_t stream);
+/* The same product with the KEYS split over `key_splits` workgroups per query block (flash-decoding style), for batches too
+ * small to fill 256 CUs with 128-row query blocks (one 400x600 image = 128 blocks): each split leaves an un-normalised fp32
+ * partial + (max, sum) in `workspace`, a second kernel merges them.  key_splits == 1 is glare_attention_d512_bf16. */
+size_t glare_attention_d512_splitk_workspace_bytes(int B, int N, int key_splits);
+int glare_attention_d512_splitk_bf16(const void* q, int ldq, const void* k, int ldk, const void* v_t, long long v_pitch, void* out,
+                                     int ldo, int B, int N, int key_splits, void* workspace, size_t workspace_bytes,
+                                     glare_stream_t stream);
 
 /* ---- a9: modulated deformable convolution (DCNv2), forward -----------------------------------
  * glare_mdcn_forward_f32 is the drop-in for the pybind function

@@ -139,3 +139,29 @@ def test_attention_forced_rescale_and_strided_inputs():
     ref = _attn_ref(qk[..., :512], qk[..., 512:], v)
     assert torch.isfinite(out.float()).all()
     assert torch.allclose(out.float(), ref, rtol=2 ** -6, atol=2 ** -7 * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("N,ks", [(300, 1), (300, 2), (300, 3), (1000, 4), (33, 2)])
+def test_attention_key_splits_agree(N, ks):
+    """The small-batch variant (keys split over workgroups + merge kernel) against the single-pass kernel and the reference;
+    includes ragged splits (tile counts not divisible by the split count) and the deferred-rescale state per split."""
+    g = torch.Generator().manual_seed(N + ks)
+    B = 2
+    q = _bf(torch.randn(B, N, 512, generator=g) * 0.2).cuda()
+    k = _bf(torch.randn(B, N, 512, generator=g)).cuda()
+    k[0, N // 2] = k[0, N // 2] * 6.0            # a dominant key inside one split only
+    v = _bf(torch.randn(B, N, 512, generator=g)).cuda()
+    npad = (N + 63) // 64 * 64
+    vt = torch.zeros(B, 512, npad, dtype=torch.bfloat16, device="cuda")
+    vt[:, :, :N] = v.transpose(1, 2)
+    out = ops.attention_d512(q, k, vt, N, key_splits=ks)
+    ref = _attn_ref(q, k, v)
+    assert torch.allclose(out.float(), ref, rtol=2 ** -6, atol=2 ** -7 * float(ref.abs().max()))
+    one = ops.attention_d512(q, k, vt, N, key_splits=1)
+    assert torch.allclose(out.float(), one.float(), rtol=2 ** -6, atol=2 ** -7 * float(ref.abs().max()))
+
+
+def test_attention_key_split_heuristic():
+    assert ops.attention_key_splits(8, 16275) == 1 and ops.attention_key_splits(4, 16275) == 1
+    assert ops.attention_key_splits(1, 16275) == 4 and ops.attention_key_splits(2, 16275) == 2
+    assert ops.attention_key_splits(1, 40) == 2      # never more splits than key tiles
