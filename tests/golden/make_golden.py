@@ -14,6 +14,7 @@ Fixtures (all float32 unless noted):
                 (encoder_decoder.py:38-192).
   harness.npz   pre-processing (impad + t + log, infer_dataset_lol.py:124-128) and PSNR
                 (utils2.py:32-36) on a seeded uint8 image.
+  stage2_grads.npz  the reference's stage-2 objective: nll + per-parameter gradient norms and seeded projections.
   msssim.npz    msssim(normalize=True) of modules/pytorch_msssim (stage-3 loss term), its gradient, and ssim() level 0.
   graph.npz     end-to-end stage checksums of the full LOL.yml graph A->B->C/D (E needs CUDA in the
                 reference) on a 1x3x24x32 input with seeded weights: outputs only (the 132 M weights
@@ -166,8 +167,45 @@ def msssim_fixture():
                         cs0=np.float32(cs.item()))
 
 
+def sketch(t, k=8):
+    """k seeded Gaussian projections of a tensor (float64): <t, r_i>.  A gradient g with relative error eps reproduces
+    them to about eps * |g|."""
+    gen = torch.Generator().manual_seed(t.numel() % 9973 + 17)
+    r = torch.randn(k, t.numel(), generator=gen, dtype=torch.float64)
+    return (r @ t.reshape(-1).double()).numpy()
+
+
+def stage2_grads_fixture():
+    """stage2_grads.npz: the REFERENCE's stage-2 objective (LLFlowVQGAN_arch.LLFlowVQGAN2, mean NLL) on a seeded 2x3x64x64 batch
+    with name-seeded weights: per-sample nll and, for each of the 625 parameter tensors, the gradient's L2 norm and 8
+    seeded projections (the 26.5 M gradients themselves would be 106 MB)."""
+    R.install()
+    import models.modules.LLFlowVQGAN_arch as arch
+
+    opt = R.load_opt()
+    opt["train_gt_ratio"] = 0.0
+    ref = arch.LLFlowVQGAN2(opt=opt, K=12).train()
+    seeded_init_(ref, 5)
+    g = torch.Generator().manual_seed(6)
+    lr = torch.randn(2, 3, 64, 64, generator=g) * 0.5 - 1.0
+    gt = torch.randn(2, 3, 16, 16, generator=g) * 0.5
+    z, nll, _ = ref(gt=gt, lr=lr, reverse=False)
+    nll.mean().backward()
+    names, norms, sk = [], [], []
+    for n, p in ref.named_parameters():
+        if p.grad is None:
+            continue
+        names.append(n)
+        norms.append(float(p.grad.double().norm()))
+        sk.append(sketch(p.grad))
+    np.savez_compressed(os.path.join(HERE, "stage2_grads.npz"), lr=lr.numpy(), gt=gt.numpy(), nll=nll.detach().numpy(),
+                        names=np.array(names), norms=np.array(norms), sketches=np.stack(sk))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "msssim":
         msssim_fixture()
+    elif len(sys.argv) > 1 and sys.argv[1] == "stage2":
+        stage2_grads_fixture()
     else:
         main()

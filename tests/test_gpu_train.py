@@ -532,3 +532,35 @@ def test_graphed_step_replays_the_eager_step_bit_identically():
         finals.append((losses[-1], torch.cat([grp.w for grp in tr.opt.groups]).clone()))
     assert finals[0][0] == finals[1][0]
     assert torch.equal(finals[0][1], finals[1][1])
+
+
+def test_stage2_gradients_match_reference_vectors(golden):
+    """Row a12 against the REFERENCE directly: the HIP path's NLL and every parameter gradient (norm + 8 seeded projections)
+    vs what the reference's own LLFlowVQGAN2 produced in the build container (tests/golden/stage2_grads.npz)."""
+    from glare_amd import modules as M
+    from glare_amd.synthetic import seeded_init_
+
+    g = golden("stage2_grads")
+    hip = seeded_init_(M.LLFlowVQGAN2().train(), 5).to(_dev())
+    gt = torch.from_numpy(g["gt"]).permute(0, 2, 3, 1).contiguous().to(_dev())
+    nll = hip.train_nll(gt, torch.from_numpy(g["lr"]).to(_dev()))
+    assert torch.allclose(nll.detach().float().cpu(), torch.from_numpy(g["nll"]), rtol=3e-2, atol=0.05)
+    nll.mean().backward()
+    grads = dict(hip.named_parameters())
+    rel_norm, rel_sk = [], []
+    for name, norm, sk in zip(g["names"], g["norms"], g["sketches"]):
+        name = str(name)
+        gr = grads[name].grad
+        assert gr is not None, name
+        if name.endswith(".k.bias"):          # true gradient is zero (softmax shift invariance): both sides are rounding noise
+            continue
+        gen = torch.Generator().manual_seed(gr.numel() % 9973 + 17)
+        r = torch.randn(8, gr.numel(), generator=gen, dtype=torch.float64)
+        mine = (r @ gr.reshape(-1).double().cpu()).numpy()
+        rel_norm.append(abs(float(gr.double().norm()) - norm) / norm)
+        rel_sk.append(float(abs(mine - sk).max()) / norm)
+    rel_norm.sort()
+    rel_sk.sort()
+    print("norm err median %.4f max %.4f | projection err (of |g|) median %.4f max %.4f"
+          % (rel_norm[len(rel_norm) // 2], rel_norm[-1], rel_sk[len(rel_sk) // 2], rel_sk[-1]))
+    assert rel_norm[-1] < 0.05 and rel_sk[-1] < 0.12     # a projection error of eps |g| ~ N(0, eps^2 |g|^2): 4 sigma of 3 %

@@ -115,3 +115,23 @@ def test_msssim_matches_reference_vectors(golden):
         assert abs(float(O.msssim(sr, gt)) - float(g["msssim_plain"])) < 1e-6
         s, cs = O.ssim(sr, gt)
         assert abs(float(s) - float(g["ssim0"])) < 1e-6 and abs(float(cs) - float(g["cs0"])) < 1e-6
+
+
+def _sketch(t, k=8):
+    gen = torch.Generator().manual_seed(t.numel() % 9973 + 17)
+    r = torch.randn(k, t.numel(), generator=gen, dtype=torch.float64)
+    return (r @ t.reshape(-1).double().cpu()).numpy()
+
+
+def test_stage2_gradients_match_reference_vectors(golden):
+    """oracle LLFlowVQGAN2 backward against the gradient norms / projections the reference produced (row a12)."""
+    g = golden("stage2_grads")
+    m = seeded_init_(O.LLFlowVQGAN2().train(), 5)
+    _, nll, _ = m.normal_flow(torch.from_numpy(g["gt"]), torch.from_numpy(g["lr"]))
+    np.testing.assert_allclose(nll.detach().numpy(), g["nll"], rtol=1e-5)
+    nll.mean().backward()
+    grads = dict(m.named_parameters())
+    for name, norm, sk in zip(g["names"], g["norms"], g["sketches"]):
+        gr = grads[str(name)].grad
+        assert abs(float(gr.double().norm()) - norm) <= 1e-4 * norm + 1e-12, name
+        np.testing.assert_allclose(_sketch(gr), sk, rtol=0, atol=2e-4 * norm + 1e-12, err_msg=str(name))
