@@ -13,7 +13,7 @@
 // buffer, no re-read of the input per tap.  LDS images are split in 8-channel planes
 // ([kstep][khalf][position][8 ch]) so that a wave's ds_read_b128 fragment read is a dense,
 // bank-conflict-free 512-B run per half-wave.  Both images are double-buffered and filled by
-// LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass) one stage ahead of the
+// LDS-DMA (buffer_load_dwordx4 ... lds through per-image descriptors: no staging VGPRs, no ds_write pass, zero padding by range check) one stage ahead of the
 // MFMAs; 3 workgroups per CU (168 VGPRs, 47 KB LDS each) cover the DMA issue stalls and the barrier skew.
 // The zero padding, the nearest x2 upsample (Upsample, encoder_decoder.py:50) and the
 // asymmetric stride-2 padding (Downsample, encoder_decoder.py:71-73) are address arithmetic
@@ -43,6 +43,7 @@ struct ConvParams {
   long long plane_pitch;
   int tiles_x, tiles_y, co_tiles, n_blocks, n_stages;
   int fast_epilogue;
+  unsigned in0_bytes, in1_bytes;   // bytes of ONE image of each source (range of the halo DMA's buffer descriptors)
   float* gn_part;   // optional GroupNorm partial sums of the OUTPUT: [b][part][Cout/4][2], part = tile*WM + wm
   int gn_nparts;
 };
@@ -72,15 +73,6 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
-// 16 zero bytes in global memory: the LDS-DMA source of every padded (out-of-image or
-// beyond-Cin) chunk, so that zero padding costs no branch in the MFMA loop.
-__device__ __attribute__((aligned(16))) const uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};
-
-__device__ __forceinline__ void dma16(const void* gsrc, void* lds_wave_base) {
-  // global -> LDS, 16 B per lane, destination = wave-uniform base + lane*16 (no VGPR round trip)
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
 
 // KS kernel size, STRIDE, MT/NT 32x32 MFMA tiles per wave along pixel rows / couts,
 // WM x WN waves (WM*MT == 8 rows), KSTEPS 16-channel k-steps per input stage.
@@ -139,14 +131,19 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // per-lane invariant part of the A addressing: this wave issues DMA instructions
-  // j = wave + NW*i; lane handles chunk c = j*64 + lane = (kstep*2 + khalf)*NPOS + pos
-  long long a_src[A_PER_W];  // element offset of (pixel, channel 0) in its source, or -1 = zero
+  // per-lane invariant part of the A addressing: this wave issues DMA instructions j = wave + NW*i; lane handles chunk
+  // c = j*64 + lane = (kstep*2 + khalf)*NPOS + pos.  The halo goes through buffer descriptors based at THIS IMAGE (32-bit byte
+  // offsets: one image of one source stays below 2 GB): a loop-invariant offset per lane and piece (pixel, 8-channel half)
+  // plus the stage's channel offset as the scalar offset; padded positions, slots beyond the tile and channels beyond Cin
+  // carry an offset beyond the descriptor's range, which the hardware turns into zeros -- no 64-bit address arithmetic, no
+  // divergent branches and no zero source in the issue sequence.
+  constexpr unsigned A_OOB = 0x80000000u;
+  unsigned a_vo0[A_PER_W], a_vo1[A_PER_W];
   int a_ck[A_PER_W];         // channel offset inside the stage: kstep*16 + khalf*8
 #pragma unroll
   for (int i = 0; i < A_PER_W; ++i) {
     const int c = (wave + NW * i) * 64 + lane;
-    a_src[i] = -1;
+    a_vo0[i] = a_vo1[i] = A_OOB;
     a_ck[i] = 0;
     if (c < A_CHUNKS) {
       const int pos = c % G::NPOS, kk = c / G::NPOS;
@@ -154,25 +151,35 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
       const int iy = iy0 + pos / G::IW, ix = ix0 + pos % G::IW;
       if (iy >= 0 && iy < p.IHs && ix >= 0 && ix < p.IWs) {
         const int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
-        a_src[i] = ((long long)b * p.H + sy) * p.W + sx;
+        const unsigned pix = (unsigned)(sy * p.W + sx);
+        a_vo0[i] = (pix * (unsigned)p.p0 + (unsigned)(p.o0 + kk * 8)) * 2u;
+        a_vo1[i] = (pix * (unsigned)p.p1 + (unsigned)(p.o1 + kk * 8)) * 2u;
       }
     }
   }
+  const size_t img = (size_t)b * p.H * p.W;
+  const __amdgpu_buffer_rsrc_t arsrc0 =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.in0 + img * p.p0), 0, (int)p.in0_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t arsrc1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(p.in1 ? p.in1 + img * p.p1 : p.in0), 0, (int)(p.in1 ? p.in1_bytes : p.in0_bytes), 0x00020000);
   const bf16_t* wbase = p.wpk + (size_t)ct * p.n_stages * (size_t)(KS * B_CHUNKS) * 8;
 
   auto issue_a = [&](int chunk, int buf) {
     const int c0 = chunk * KC;
+    const bool src0 = c0 < p.Cin0;                       // uniform: a stage never straddles the two concatenated sources
+    const int cbase = src0 ? c0 : c0 - p.Cin0, climit = src0 ? p.Cin0 : p.Cin1;
 #pragma unroll
     for (int i = 0; i < A_PER_W; ++i) {
       const int j = wave + NW * i;
       if (j < A_INSTR) {
-        const void* src = g_zero16;
-        const int ch = c0 + a_ck[i];
-        if (a_src[i] >= 0) {
-          if (ch < p.Cin0) src = p.in0 + a_src[i] * p.p0 + p.o0 + ch;
-          else if (ch < p.CinTot) src = p.in1 + a_src[i] * p.p1 + p.o1 + (ch - p.Cin0);
-        }
-        dma16(src, lA + buf * A_SLOTS + j * 64);
+        unsigned vo = src0 ? a_vo0[i] : a_vo1[i];
+        if (cbase + a_ck[i] >= climit) vo = A_OOB;       // channels beyond Cin (last stage only): v_cndmask, not a branch
+        if (src0)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc0, (__attribute__((address_space(3))) void*)(lA + buf * A_SLOTS + j * 64), 16, vo,
+                                                   cbase * 2, 0, 0);
+        else
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc1, (__attribute__((address_space(3))) void*)(lA + buf * A_SLOTS + j * 64), 16, vo,
+                                                   cbase * 2, 0, 0);
       }
     }
   };
@@ -552,6 +559,12 @@ extern "C" int glare_conv2d_bf16(const glare_conv_desc* d, glare_stream_t stream
   // a stage must not straddle the two concatenated sources
   if (p.in1 && (p.Cin0 % kc)) return GLARE_ERR_UNSUPPORTED;
   p.n_stages = (p.CinTot + kc - 1) / kc;
+  {  // halo DMA through per-image buffer descriptors: 32-bit byte offsets inside one image of one source
+    const long long b0 = (long long)p.H * p.W * p.p0 * 2, b1 = p.in1 ? (long long)p.H * p.W * p.p1 * 2 : 0;
+    if (b0 >= 0x7ff00000LL || b1 >= 0x7ff00000LL) return GLARE_ERR_UNSUPPORTED;
+    p.in0_bytes = (unsigned)b0;
+    p.in1_bytes = (unsigned)b1;
+  }
   p.tiles_x = cdiv(p.OW, TW); p.tiles_y = 0; p.co_tiles = cdiv(p.Cout, v.tn);  // tiles_y / n_blocks: per variant, in launch()
   p.n_blocks = 0;
   p.gn_part = d->gn_partial;
