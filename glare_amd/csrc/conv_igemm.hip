@@ -164,14 +164,14 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
       const_cast<bf16_t*>(p.in1 ? p.in1 + img * p.p1 : p.in0), 0, (int)(p.in1 ? p.in1_bytes : p.in0_bytes), 0x00020000);
   const bf16_t* wbase = p.wpk + (size_t)ct * p.n_stages * (size_t)(KS * B_CHUNKS) * 8;
 
-  auto issue_a = [&](int chunk, int buf) {
+  auto issue_a = [&](int chunk, int buf, int i_lo = 0, int i_hi = 1 << 20) {   // pieces [i_lo, i_hi) of this wave
     const int c0 = chunk * KC;
     const bool src0 = c0 < p.Cin0;                       // uniform: a stage never straddles the two concatenated sources
     const int cbase = src0 ? c0 : c0 - p.Cin0, climit = src0 ? p.Cin0 : p.Cin1;
 #pragma unroll
     for (int i = 0; i < A_PER_W; ++i) {
       const int j = wave + NW * i;
-      if (j < A_INSTR) {
+      if (i >= i_lo && i < i_hi && j < A_INSTR) {
         unsigned vo = src0 ? a_vo0[i] : a_vo1[i];
         if (cbase + a_ck[i] >= climit) vo = A_OOB;       // channels beyond Cin (last stage only): v_cndmask, not a branch
         if (src0)
@@ -188,11 +188,11 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<bf16_t*>(wbase), 0, (int)((size_t)p.n_stages * KS * B_CHUNKS * 16), 0x00020000);
   const int lane16 = lane * 16;
-  auto issue_b = [&](int bstage, int buf) {
+  auto issue_b = [&](int bstage, int buf, int i_lo = 0, int i_hi = 1 << 20) {
 #pragma unroll
     for (int i = 0; i < B_PER_W; ++i) {
       const int j = wave + NW * i;
-      if (j < B_INSTR)
+      if (i >= i_lo && i < i_hi && j < B_INSTR)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(lB + buf * B_CHUNKS + j * 64),
                                                  16, lane16, (bstage * B_CHUNKS + j * 64) * 16, 0, 0);
     }
@@ -211,12 +211,19 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
       __syncthreads();                                   // ... and everybody else's; stage bs-1 retired
 #endif
+      // The next stage's DMA pieces are not issued in one burst behind the barrier (12 waves would queue 47 pieces on the
+      // CU's address path with the matrix pipe waiting): they are spread over the stage's KS*KSTEPS MFMA groups.
+      constexpr int NGRP = KS * KSTEPS;
+      constexpr int B_PG = (B_PER_W + NGRP - 1) / NGRP, A_PG = (A_PER_W + NGRP - 1) / NGRP;
+      const bool more_b = bs + 1 < n_bstages, more_a = trow == 0 && chunk + 1 < p.n_stages;
+#if !CONV_DMA_SPREAD
 #ifndef CONV_ABLATE_NODMA
 #ifndef CONV_ABLATE_NODMA_B
-      if (bs + 1 < n_bstages) issue_b(bs + 1, (bs + 1) & 1);
+      if (more_b) issue_b(bs + 1, (bs + 1) & 1);
 #endif
 #ifndef CONV_ABLATE_NODMA_A
-      if (trow == 0 && chunk + 1 < p.n_stages) issue_a(chunk + 1, (chunk + 1) & 1);
+      if (more_a) issue_a(chunk + 1, (chunk + 1) & 1);
+#endif
 #endif
 #endif
       const u32x4* cB = lB + (bs & 1) * B_CHUNKS;
@@ -227,6 +234,19 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
       for (int tcol = 0; tcol < KS; ++tcol) {
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
+#if CONV_DMA_SPREAD
+#ifndef CONV_ABLATE_NODMA
+          {
+            const int grp = tcol * KSTEPS + ks;
+#ifndef CONV_ABLATE_NODMA_B
+            if (more_b) issue_b(bs + 1, (bs + 1) & 1, grp * B_PG, (grp + 1) * B_PG);
+#endif
+#ifndef CONV_ABLATE_NODMA_A
+            if (more_a) issue_a(chunk + 1, (chunk + 1) & 1, grp * A_PG, (grp + 1) * A_PG);
+#endif
+          }
+#endif
+#endif
           bf16x8 bf[NT], af[MT];
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
@@ -447,6 +467,9 @@ __global__ __launch_bounds__(256) void gn_part_reduce_kernel(const float* __rest
   }
 }
 
+#ifndef CONV_DMA_SPREAD
+#define CONV_DMA_SPREAD 1
+#endif
 #ifndef CONV_TILE16
 #define CONV_TILE16 0
 #endif
