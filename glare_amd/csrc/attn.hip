@@ -127,19 +127,24 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
   //   V^T: one instruction per 16 d-rows (64 B each); chunk c of row d lands at d*4 + (c ^ ((d>>2)&3));
   //        d = 16*t + (lane>>2)  =>  (d>>2)&3 == (lane>>4)&3 for every t
   const unsigned v_lane_off = (unsigned)((lane >> 2) * p.Npad + (((lane & 3) ^ ((lane >> 4) & 3)) * 8)) * 2u;  // bytes
+  // Both tiles are fetched through per-image buffer descriptors: the per-piece address is a scalar offset (row / d-group and
+  // tile) plus a 32-bit per-lane offset -- no 64-bit vector add per piece; key rows beyond N fall outside the descriptor's
+  // range and arrive as zeros (their scores are masked to -inf below), so no row clamp either.
+  const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(kbase), 0, (int)((((long long)p.N - 1) * p.ldk + HD) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t vrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vbase), 0, (int)((long long)HD * p.Npad * 2), 0x00020000);
+  const int lane16 = lane * 16;
   auto issue_piece = [&](auto ic, int tile, int buf) {
     constexpr int i = decltype(ic)::value;
     if constexpr (i < BN / 4) {
       const int r = wave + 4 * i;
-      // rows beyond N re-read row N-1 (valid memory); their scores are masked to -inf below
-      const int kv = min(tile * BN + r, p.N - 1);
-      const char* row = reinterpret_cast<const char*>(kbase + (size_t)kv * p.ldk);            // uniform
-      const unsigned off = (unsigned)((lane ^ (r & 15)) * 16);                                 // per lane
-      dma16a(row + off, lK + buf * KCH + r * 64);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(krsrc, (__attribute__((address_space(3))) void*)(lK + buf * KCH + r * 64), 16,
+                                               lane16 ^ ((r & 15) * 16), (tile * BN + r) * p.ldk * 2, 0, 0);
     } else {
       constexpr int j = i - BN / 4;
-      const char* grp = reinterpret_cast<const char*>(vbase + (size_t)(wave + 4 * j) * 16 * p.Npad + (size_t)tile * BN);
-      dma16a(grp + v_lane_off, lV + buf * KCH + (wave + 4 * j) * 64);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(vrsrc, (__attribute__((address_space(3))) void*)(lV + buf * KCH + (wave + 4 * j) * 64), 16,
+                                               v_lane_off, (int)(((long long)(wave + 4 * j) * 16 * p.Npad + (long long)tile * BN) * 2), 0, 0);
     }
   };
   auto issue = [&](int tile, int buf) { static_for<16>([&](auto ic) { issue_piece(ic, tile, buf); }); };
@@ -541,6 +546,7 @@ static int attn_launch(const void* q, int ldq, const void* k, int ldk, const voi
                        int N, int key_splits, void* workspace, size_t workspace_bytes, glare_stream_t stream) {
   if (!q || !k || !v_t || !out || B <= 0 || N <= 0 || key_splits < 1) return GLARE_ERR_INVALID;
   if (key_splits > (N + BN - 1) / BN) return GLARE_ERR_INVALID;   // every split owns at least one key tile
+  if (((long long)N * ldk + HD) * 2 >= 0x7ff00000LL || (long long)HD * v_pitch * 2 >= 0x7ff00000LL) return GLARE_ERR_UNSUPPORTED;  // 32-bit DMA offsets per image
   if (key_splits > 1) {
     if (ATTN_PIPELINED) return GLARE_ERR_UNSUPPORTED;
     if ((ldo % 8) || !workspace || workspace_bytes < glare_attention_d512_splitk_workspace_bytes(B, N, key_splits)) return GLARE_ERR_WORKSPACE;
