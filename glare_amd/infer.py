@@ -29,13 +29,36 @@ def enhance_batch(netG, net_vq, imgs_u8, device):
     return out
 
 
-def run(n_images, batch=8, h=400, w=600, seed=1234):
+def load_lol_pairs(root):
+    """uint8 (low, high) stacks of a LOL `eval15`-style folder (glare_amd.data.LoL_Dataset layout); all images one size."""
+    from .data import LoL_Dataset
+
+    ds = LoL_Dataset({"root": root}, train=False)
+    lows = np.stack([p[0] for p in ds.pairs])
+    gts = np.stack([p[1] for p in ds.pairs])
+    return lows, gts
+
+
+def run(n_images, batch=8, h=400, w=600, seed=1234, root=None, net_g=None, net_vq=None):
+    """Synthetic LOL-shaped pairs by default; `root` = a LOL dataset folder (eval15 split), `net_g` / `net_vq` = checkpoint
+    files in the reference's format (glare_amd.checkpoint) -- without them the weights are name-seeded."""
+    from . import checkpoint
+
     rank, world, device = parallel.init_from_env()
     assert device.type == "cuda", "glare_amd.infer needs an MI355X: the HIP kernels are the only implementation"
-    netG = seeded_init_(M.VQLLFLOWDeformable().eval(), 0).to(device)
-    net_vq = seeded_init_(M.VQModel().eval(), 1).to(device)
-    lows = synthetic_lowlight(n_images, h, w, seed=seed)
-    gts = synthetic_gt(n_images, h, w, seed=seed + 1)
+    netG = seeded_init_(M.VQLLFLOWDeformable().eval(), 0)
+    net_vq_m = seeded_init_(M.VQModel().eval(), 1)
+    if net_g:
+        checkpoint.load_network(net_g, netG, strict=False)       # VQLLFLOWD_model.py:53-63 loads with strict=False
+    if net_vq:
+        checkpoint.load_network(net_vq, net_vq_m, strict=False)
+    netG, net_vq = netG.to(device), net_vq_m.to(device)
+    if root:
+        lows, gts = load_lol_pairs(root)
+        n_images, h, w = lows.shape[0], lows.shape[1], lows.shape[2]
+    else:
+        lows = synthetic_lowlight(n_images, h, w, seed=seed)
+        gts = synthetic_gt(n_images, h, w, seed=seed + 1)
 
     def psnr_slice(lo, hi):
         out = enhance_batch(netG, net_vq, lows[lo:hi], device)
@@ -59,8 +82,11 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--height", type=int, default=400)
     ap.add_argument("--width", type=int, default=600)
+    ap.add_argument("--root", default=None, help="LOL dataset folder (uses <root>/eval15/{low,high}/*.png)")
+    ap.add_argument("--net-g", default=None, help="net_G checkpoint (reference format)")
+    ap.add_argument("--net-vq", default=None, help="VQGAN checkpoint (reference format)")
     args = ap.parse_args()
-    psnrs = run(args.images, args.batch, args.height, args.width)
+    psnrs = run(args.images, args.batch, args.height, args.width, root=args.root, net_g=args.net_g, net_vq=args.net_vq)
     if psnrs is not None:
         print(json.dumps({"images": int(len(psnrs)), "mean_psnr": float(np.mean(psnrs)), "psnr": [round(float(v), 4) for v in psnrs]}))
 
