@@ -1,7 +1,7 @@
 """torch.autograd.Function wrappers: HIP forward + HIP backward for the operators of the training step
-(SURVEY.md section 8 rows a12 / a13).  torch's autograd engine is only the tape: every tensor-sized computation
-in forward() and backward() below is a kernel of libglare_hip.so; torch ops touch filter-sized tensors only
-(flip / transpose / pad of weights before packing).
+(SURVEY.md section 8 rows a12 / a13).  torch's autograd engine is only the tape: every feature-map-sized computation
+in forward() and backward() below is a kernel of libglare_hip.so, including the gradient accumulation at fan-out points
+(ForkFn); torch ops touch filter-sized tensors, the 3-channel latent / image gradients and per-sample scalars only.
 
 The reference gets these gradients from `loss.backward()` over cuDNN / ATen (LLFlow_model.py:231-236,
 VQLLFLOWD_model.py:226-229); activations here are NHWC bf16, parameters and their gradients fp32.
@@ -366,3 +366,27 @@ class MSSSIMTermsFn(torch.autograd.Function):
 
 def msssim_terms(x, y, windows):
     return MSSSIMTermsFn.apply(x, y, windows)
+
+
+class ForkFn(torch.autograd.Function):
+    """A fan-out point of the tape made explicit: returns n aliases of x; the backward sums their gradients with
+    glare_add_bf16, so the accumulation of activation gradients runs on this library, not on the autograd engine's add."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n = n
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g for g in gs if g is not None]
+        acc = gs[0]
+        i = 1
+        while i < len(gs):
+            acc = T.add_bf16(acc, gs[i], gs[i + 1] if i + 1 < len(gs) else None)
+            i += 2
+        return acc, None
+
+
+def fork(x, n=2):
+    return ForkFn.apply(x, n)

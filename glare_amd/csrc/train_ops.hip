@@ -506,6 +506,22 @@ __global__ __launch_bounds__(256) void l1_loss_kernel(const float* __restrict__ 
   if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// out = a + b (+ c): the gradient accumulation at a fan-out point of the tape (an activation read by several consumers);
+// bf16 in / out, fp32 add.  Keeps the accumulation on this library instead of the autograd engine's own add.
+__global__ __launch_bounds__(256) void add_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
+                                                       const bf16_t* __restrict__ c, bf16_t* __restrict__ out, long long n8) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const u32x4 va = reinterpret_cast<const u32x4*>(a)[i], vb = reinterpret_cast<const u32x4*>(b)[i];
+  u32x4 vc = {0u, 0u, 0u, 0u};
+  if (c) vc = reinterpret_cast<const u32x4*>(c)[i];
+  u32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    o[e] = pack_bf2(bflo(va[e]) + bflo(vb[e]) + bflo(vc[e]), bfhi(va[e]) + bfhi(vb[e]) + bfhi(vc[e]));
+  reinterpret_cast<u32x4*>(out)[i] = o;
+}
+
 // torch.optim.Adam (no amsgrad, no weight decay unless wd != 0 -> L2 added to the gradient as torch does)
 // step counter and bias corrections kept on the device, so that an optimizer step has no host-side state and the whole
 // training step can be replayed from a hipGraph: state = {bc1, sqrt(bc2), lr multiplier}, step_dev = the 1-based step count
@@ -754,6 +770,15 @@ extern "C" int glare_l1_clamp_loss_f32(const float* rec_nhwc, const float* gt_nc
   hipLaunchKernelGGL(l1_loss_kernel, dim3(blocks), dim3(256), 0, ST(stream), rec_nhwc, gt_nchw, HW, C, total, inv_n, grad_nhwc,
                      static_cast<float*>(workspace));
   return glare_reduce_parts_f32(static_cast<const float*>(workspace), blocks, 1, inv_n, loss_out, 0, stream);
+}
+
+extern "C" int glare_add_bf16(const void* a, const void* b, const void* c_or_null, void* out, long long n, glare_stream_t stream) {
+  if (n < 0 || n % 8) return GLARE_ERR_INVALID;
+  if (n == 0) return GLARE_OK;
+  if (!a || !b || !out) return GLARE_ERR_INVALID;
+  hipLaunchKernelGGL(add_bf16_kernel, dim3((unsigned)cdivll(n / 8, 256)), dim3(256), 0, ST(stream), static_cast<const bf16_t*>(a),
+                     static_cast<const bf16_t*>(b), static_cast<const bf16_t*>(c_or_null), static_cast<bf16_t*>(out), n / 8);
+  return glare_launch_status();
 }
 
 extern "C" int glare_adam_step_f32(float* w, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1,

@@ -139,8 +139,8 @@ class MultiScaleDecoder2(HipModule):
                 if len(lvl.attn) > 0:
                     h = lvl.attn[i_block].train_nhwc(h)
             if i_level != 2:
-                h = self.mix[1 - i_level].train_nhwc(enc_feats[i_level], h)
-                x_w = self.warp[1 - i_level].train_nhwc(code_feats[1 - i_level], h)
+                h, hw = A.fork(self.mix[1 - i_level].train_nhwc(enc_feats[i_level], h))   # read by the warp and the rescale
+                x_w = self.warp[1 - i_level].train_nhwc(code_feats[1 - i_level], hw)
                 h = A.mean_rescale(h, x_w, whole_batch_mean)
             if i_level != 0:
                 h = lvl.upsample.train_nhwc(h)

@@ -94,9 +94,10 @@ class ResnetBlock(HipModule):
                           gn_stats=fuse and out is None)
 
     def train_nhwc(self, x):
+        x, xr = A.fork(x)                                         # x feeds the block body and the shortcut
         h = conv_t(gn_swish_t(x, self.norm1), self.conv1)
         h = gn_swish_t(h, self.norm2)
-        res = x if self.in_channels == self.out_channels else conv_t(x, self.nin_shortcut)
+        res = xr if self.in_channels == self.out_channels else conv_t(xr, self.nin_shortcut)
         return conv_t(h, self.conv2, residual=res)
 
     def forward(self, x, temb=None):
@@ -134,11 +135,12 @@ class AttnBlock(HipModule):
     def train_nhwc(self, x):
         B, H, W, C = x.shape
         s = float(self.in_channels) ** -0.5 * math.log2(math.e)   # the fold is a (differentiable) op on the filter
-        hn = gn_swish_t(x, self.norm, swish=False)
-        q = A.conv2d(hn, self.q.weight * s, self.q.bias * s)
-        k, v = conv_t(hn, self.k), conv_t(hn, self.v)
+        x, xr = A.fork(x)
+        hq, hk, hv = A.fork(gn_swish_t(x, self.norm, swish=False), 3)
+        q = A.conv2d(hq, self.q.weight * s, self.q.bias * s)
+        k, v = conv_t(hk, self.k), conv_t(hv, self.v)
         o = A.attention(q.view(B, H * W, C), k.view(B, H * W, C), v.view(B, H * W, C))
-        return conv_t(o.view(B, H, W, C), self.proj_out, residual=x)
+        return conv_t(o.view(B, H, W, C), self.proj_out, residual=xr)
 
     def forward(self, x):
         return to_nchw(self.forward_nhwc(to_nhwc(x)))

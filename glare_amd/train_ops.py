@@ -490,3 +490,13 @@ def adam_step_dev_(w, grad, exp_avg, exp_avg_sq, state3, lr, betas=(0.9, 0.999),
                                              _f(betas[1]), _f(eps), _f(weight_decay), ptr(state3), _f(grad_scale), stream_handle()),
           "glare_adam_step_dev_f32")
     return w
+
+
+def add_bf16(a, b, c=None):
+    require_cuda(a, b, c)
+    a, b = a.contiguous(), b.contiguous()
+    c = None if c is None else c.contiguous()
+    assert a.dtype == b.dtype == torch.bfloat16 and a.shape == b.shape
+    out = torch.empty_like(a)
+    check(_lib.lib().glare_add_bf16(ptr(a), ptr(b), ptr(c), ptr(out), _ll(a.numel()), stream_handle()), "glare_add_bf16")
+    return out

@@ -303,6 +303,9 @@ int glare_dilate2_bf16(const void* g, void* out, int B, int OH, int OW, int C, g
 int glare_pool2_sum_bf16(const void* g, void* out, int B, int H, int W, int C, glare_stream_t stream);
 int glare_act_backward(void* g, int g_is_f32, int g_pitch, int g_off, const void* y, int y_is_f32, int y_pitch, int y_off,
                        long long pixels, int C, int act, glare_stream_t stream);
+/* out = a + b (+ c), bf16, n % 8 == 0: gradient accumulation where an activation feeds several consumers (the residual
+ * branch of ResnetBlock / AttnBlock, the q / k / v projections) -- done here rather than by the autograd engine's add */
+int glare_add_bf16(const void* a, const void* b, const void* c_or_null, void* out, long long n, glare_stream_t stream);
 int glare_cast_f32_bf16(const float* in, int in_pitch, int in_off, void* out, int out_pitch, int out_off, long long pixels,
                         int C, glare_stream_t stream);
 int glare_cast_bf16_f32(const void* in, int in_pitch, int in_off, float* out, int out_pitch, int out_off, long long pixels,
