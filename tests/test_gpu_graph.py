@@ -128,6 +128,21 @@ def test_reference_module_surface(nets):
         pg.RRDB(lr)  # CPU tensor: no fallback
 
 
+def test_row_a7_vqgan_encode(nets):
+    """Row a7: VQModel.encode (Encoder + quant_conv, VQModel_arch.py:74-79) -- the frozen ground-truth encoder of stage 2 --
+    through the reference-shaped entry point and the NHWC one."""
+    og, ov, pg, pv, lr, ref = nets
+    g = torch.Generator().manual_seed(17)
+    gt = torch.rand(2, 3, 40, 56, generator=g)
+    with torch.no_grad():
+        z_o, _ = ov.encode(gt)
+        z_p, none = pv.encode(gt.cuda())
+        z_n = pv.encode_nhwc(gt.cuda())
+    assert none is None and z_p.shape == z_o.shape
+    assert rel(z_p.cpu(), z_o) < 3e-2
+    assert torch.equal(nchw(z_n).cpu(), z_p.cpu())
+
+
 def test_stage2_normal_flow_and_nll(nets):
     """Row a4: FlowUpsamplerNet.encode + log-determinant + Gaussian NLL against the oracle's normal_flow
     (which is bit-identical to the reference's, tests/test_oracle_vs_reference.py)."""
