@@ -148,3 +148,51 @@ def test_fused_groupnorm_statistics():
         n1 = ops.groupnorm(y1, gamma, beta, swish=True)   # apply only, fused statistics
         n2 = ops.groupnorm(y2, gamma, beta, swish=True)   # stats + apply
         assert torch.allclose(n1.float(), n2.float(), rtol=2 ** -7, atol=2e-3)
+
+
+def test_conv_randomised_shapes_and_fusions():
+    """Seeded sweep over ragged sizes and every fused loader / epilogue feature (stride-2 (0,1,0,1) padding, nearest x2 upsample,
+    two concatenated sources read at channel offsets of wider buffers, residual, activations, fp32 / planar outputs)."""
+    import random
+
+    rnd = random.Random(2024)
+    g = torch.Generator().manual_seed(2024)
+    acts = {"none": lambda t: t, "relu": torch.relu, "sigmoid": torch.sigmoid, "swish": lambda t: t * torch.sigmoid(t)}
+    for case in range(36):
+        B, H, W = rnd.choice([1, 2, 3]), rnd.randint(1, 41), rnd.randint(1, 70)
+        k = rnd.choice([1, 3, 3])
+        cin = rnd.choice([8, 16, 24, 64, 72, 128])
+        cout = rnd.choice([3, 8, 32, 64, 100, 128, 136, 256])
+        stride = rnd.choice([1, 1, 2]) if (k == 3 and H >= 2 and W >= 2) else 1
+        ups = stride == 1 and rnd.random() < 0.25
+        two = rnd.random() < 0.3 and cin % (16 if k == 3 else 32) == 0   # a stage must not straddle the two sources
+        act = rnd.choice(["none", "none", "relu", "sigmoid", "swish"])
+        mode = rnd.choice([ops.OUT_NHWC_BF16, ops.OUT_NHWC_BF16, ops.OUT_NHWC_F32])
+        res = mode == ops.OUT_NHWC_BF16 and act == "none" and rnd.random() < 0.4 and cout % 8 == 0
+        # sources live inside wider buffers at channel offsets
+        pad_l, pad_r = rnd.choice([0, 8, 16]), rnd.choice([0, 8])
+        x = _rand((B, cin, H, W), g)
+        xbuf = torch.zeros(B, H, W, pad_l + cin + pad_r)
+        xbuf[..., pad_l:pad_l + cin] = x.permute(0, 2, 3, 1)
+        xd = xbuf.to(torch.bfloat16).cuda()
+        cin2 = rnd.choice([16, 32]) if two else 0
+        x2 = _rand((B, cin2, H, W), g) if two else None
+        w = _rand((cout, cin + cin2, k, k), g, 1.0 / ((cin + cin2) * k * k) ** 0.5)
+        b = _rand((cout,), g, 0.1)
+        xin = torch.cat([x, x2], 1) if two else x
+        xin = xin.to(torch.bfloat16).float()
+        if ups:
+            xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+        wb = w.to(torch.bfloat16).float()
+        ref = F.conv2d(F.pad(xin, (0, 1, 0, 1)), wb, b, stride=2) if stride == 2 else F.conv2d(xin, wb, b, padding=k // 2)
+        r = _rand(ref.shape, g) if res else None
+        ref = acts[act](ref)
+        if res:
+            ref = ref + r.to(torch.bfloat16).float()
+        try:
+            out = ops.conv2d(xd, ops.PackedConv(w.cuda(), b.cuda()), cin=cin, in_off=pad_l, x2=_nhwc_bf16(x2) if two else None,
+                             stride=stride, upsample=ups, act=act, residual=_nhwc_bf16(r) if res else None, out_mode=mode)
+            _check(out.permute(0, 3, 1, 2), ref, bf16_out=(mode == ops.OUT_NHWC_BF16))
+        except Exception as e:
+            raise AssertionError("case %d: B%d %dx%d k%d s%d ups%d cin%d+%d@%d cout%d act=%s res=%d mode=%d: %s"
+                                 % (case, B, H, W, k, stride, ups, cin, cin2, pad_l, cout, act, res, mode, e))

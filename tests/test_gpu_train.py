@@ -564,3 +564,41 @@ def test_stage2_gradients_match_reference_vectors(golden):
     print("norm err median %.4f max %.4f | projection err (of |g|) median %.4f max %.4f"
           % (rel_norm[len(rel_norm) // 2], rel_norm[-1], rel_sk[len(rel_sk) // 2], rel_sk[-1]))
     assert rel_norm[-1] < 0.05 and rel_sk[-1] < 0.12     # a projection error of eps |g| ~ N(0, eps^2 |g|^2): 4 sigma of 3 %
+
+
+def test_conv_autograd_randomised_ragged_sizes():
+    """Seeded sweep of the conv backward (data gradient as a flipped conv after dilate / before pool, weight + bias gradient by
+    im2col_t + split-K GEMM) over odd / tiny spatial sizes and channel counts off the tile sizes."""
+    import random
+
+    import torch.nn.functional as F
+
+    from glare_amd import autograd as A
+
+    rnd = random.Random(7)
+    g = torch.Generator().manual_seed(7)
+    for case in range(10):
+        k = rnd.choice([1, 3, 3])
+        stride = rnd.choice([1, 1, 2]) if k == 3 else 1
+        ups = stride == 1 and rnd.random() < 0.3
+        B = rnd.choice([1, 2])
+        H, W = rnd.randint(2, 19), rnd.randint(2, 27)
+        if stride == 2:
+            H, W = 2 * (H // 2 + 1), 2 * (W // 2 + 1)             # Downsample sees even sizes on the path
+        cin, cout = rnd.choice([8, 24, 64, 72]), rnd.choice([8, 40, 64, 136])
+        x = _bf(torch.randn(B, cin, H, W, generator=g))
+        w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+        b = torch.randn(cout, generator=g)
+        xr, wr, br = x.clone().requires_grad_(True), _bf(w).clone().requires_grad_(True), b.clone().requires_grad_(True)
+        xi = F.interpolate(xr, scale_factor=2.0, mode="nearest") if ups else xr
+        yr = F.conv2d(F.pad(xi, (0, 1, 0, 1)), wr, br, stride=2) if stride == 2 else F.conv2d(xi, wr, br, padding=k // 2)
+        gy = _bf(torch.randn(yr.shape, generator=g))
+        yr.backward(gy)
+        xd, wd, bd = _nhwc16(x).requires_grad_(True), w.to(_dev()).requires_grad_(True), b.to(_dev()).requires_grad_(True)
+        y = A.conv2d(xd, wd, bd, stride=stride, upsample=ups)
+        y.backward(_nhwc16(gy))
+        tag = "case %d: B%d %dx%d k%d s%d ups%d %d->%d" % (case, B, H, W, k, stride, ups, cin, cout)
+        assert _rel(_nchw(y), yr.detach()) < 1e-2, tag
+        assert _rel(_nchw(xd.grad), xr.grad) < 2e-2, tag
+        assert _rel(wd.grad, wr.grad) < 2e-2, tag
+        assert _rel(bd.grad, br.grad) < 1e-2, tag
