@@ -165,3 +165,47 @@ def test_attention_key_split_heuristic():
     assert ops.attention_key_splits(8, 16275) == 1 and ops.attention_key_splits(4, 16275) == 1
     assert ops.attention_key_splits(1, 16275) == 4 and ops.attention_key_splits(2, 16275) == 2
     assert ops.attention_key_splits(1, 40) == 2      # never more splits than key tiles
+
+
+def test_groupnorm_and_attention_randomised_sizes():
+    """Seeded sweeps: GroupNorm(+swish) forward AND backward over tiny / odd spatial sizes and every channel width on the path;
+    attention over token counts that are not multiples of the 32-key tile or the 128-row query block."""
+    import random
+
+    from glare_amd import autograd as A
+
+    rnd = random.Random(11)
+    g = torch.Generator().manual_seed(11)
+    for case in range(10):
+        B, C = rnd.choice([1, 2, 3]), rnd.choice([32, 64, 128, 256, 512])
+        H, W = rnd.randint(1, 23), rnd.randint(1, 37)
+        swish = rnd.random() < 0.6
+        x = _bf(torch.randn(B, C, H, W, generator=g) * 1.5 + 0.3).float()
+        gamma, beta = torch.randn(C, generator=g) * 0.3 + 1, torch.randn(C, generator=g) * 0.3
+        xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        yr = F.group_norm(xr, 32, gr, br, eps=1e-6)
+        yr = yr * torch.sigmoid(yr) if swish else yr
+        gy = _bf(torch.randn(yr.shape, generator=g)).float()
+        yr.backward(gy)
+        xd = x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda().requires_grad_(True)
+        gd, bd = gamma.cuda().requires_grad_(True), beta.cuda().requires_grad_(True)
+        y = A.groupnorm(xd, gd, bd, swish=swish)
+        y.backward(gy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda())
+        tag = "gn case %d: B%d C%d %dx%d swish%d" % (case, B, C, H, W, swish)
+        n = lambda t: t.float().cpu().permute(0, 3, 1, 2)
+        if H * W * (C // 32) > 1:                     # a single-element group normalises to exactly beta: nothing to compare
+            assert torch.allclose(n(y), yr.detach(), rtol=2 ** -6, atol=1e-2), tag
+            assert float((n(xd.grad) - xr.grad).norm()) <= 3e-2 * float(xr.grad.norm()) + 1e-3, tag
+        assert float((gd.grad.cpu() - gr.grad).norm()) <= 2e-2 * float(gr.grad.norm()) + 1e-2, tag
+        assert float((bd.grad.cpu() - br.grad).norm()) <= 2e-2 * float(br.grad.norm()) + 1e-2, tag
+    for case in range(8):
+        B, N = rnd.choice([1, 2]), rnd.choice([1, 2, 31, 33, 127, 129, 257, rnd.randint(300, 900)])
+        q = _bf(torch.randn(B, N, 512, generator=g) * 0.2).cuda()
+        k = _bf(torch.randn(B, N, 512, generator=g)).cuda()
+        v = _bf(torch.randn(B, N, 512, generator=g)).cuda()
+        npad = (N + 63) // 64 * 64
+        vt = torch.zeros(B, 512, npad, dtype=torch.bfloat16, device="cuda")
+        vt[:, :, :N] = v.transpose(1, 2)
+        out = ops.attention_d512(q, k, vt, N)
+        ref = _attn_ref(q, k, v)
+        assert torch.allclose(out.float(), ref, rtol=2 ** -6, atol=2 ** -7 * float(ref.abs().max())), "attn case %d: B%d N%d" % (case, B, N)
