@@ -191,16 +191,25 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(TG* __restrict__ g, int g_
   if constexpr (sizeof(TG) == 2) *gp = f2bf(gv); else *gp = gv;
 }
 
-__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ in, int in_pitch, int in_off, bf16_t* __restrict__ out,
-                                                   int out_pitch, int out_off, long long pixels, int C, int to_f32) {
+// fp32 <-> bf16 with independent channel pitches / offsets (the gradient of an fp32-output conv enters the MFMA path as bf16)
+__global__ __launch_bounds__(256) void cast_f32_to_bf16_kernel(const float* __restrict__ in, int in_pitch, int in_off,
+                                                               bf16_t* __restrict__ out, int out_pitch, int out_off, long long pixels,
+                                                               int C) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= pixels * C) return;
   const long long px = i / C;
   const int c = (int)(i % C);
-  if (to_f32)  // roles swapped: `out` is the bf16 source, `in` the fp32 destination
-    const_cast<float*>(in)[px * in_pitch + in_off + c] = bf2f(out[px * out_pitch + out_off + c]);
-  else
-    out[px * out_pitch + out_off + c] = f2bf(in[px * in_pitch + in_off + c]);
+  out[px * out_pitch + out_off + c] = f2bf(in[px * in_pitch + in_off + c]);
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_to_f32_kernel(const bf16_t* __restrict__ in, int in_pitch, int in_off,
+                                                               float* __restrict__ out, int out_pitch, int out_off, long long pixels,
+                                                               int C) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= pixels * C) return;
+  const long long px = i / C;
+  const int c = (int)(i % C);
+  out[px * out_pitch + out_off + c] = bf2f(in[px * in_pitch + in_off + c]);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -636,8 +645,8 @@ extern "C" int glare_cast_f32_bf16(const float* in, int in_pitch, int in_off, vo
   if (pixels < 0 || C < 0) return GLARE_ERR_INVALID;
   if (pixels == 0 || C == 0) return GLARE_OK;
   if (!in || !out) return GLARE_ERR_INVALID;
-  hipLaunchKernelGGL(cast_kernel, dim3((unsigned)cdivll(pixels * C, 256)), dim3(256), 0, ST(stream), in, in_pitch, in_off,
-                     static_cast<bf16_t*>(out), out_pitch, out_off, pixels, C, 0);
+  hipLaunchKernelGGL(cast_f32_to_bf16_kernel, dim3((unsigned)cdivll(pixels * C, 256)), dim3(256), 0, ST(stream), in, in_pitch, in_off,
+                     static_cast<bf16_t*>(out), out_pitch, out_off, pixels, C);
   return glare_launch_status();
 }
 
@@ -646,8 +655,8 @@ extern "C" int glare_cast_bf16_f32(const void* in, int in_pitch, int in_off, flo
   if (pixels < 0 || C < 0) return GLARE_ERR_INVALID;
   if (pixels == 0 || C == 0) return GLARE_OK;
   if (!in || !out) return GLARE_ERR_INVALID;
-  hipLaunchKernelGGL(cast_kernel, dim3((unsigned)cdivll(pixels * C, 256)), dim3(256), 0, ST(stream), out, out_pitch, out_off,
-                     const_cast<bf16_t*>(static_cast<const bf16_t*>(in)), in_pitch, in_off, pixels, C, 1);
+  hipLaunchKernelGGL(cast_bf16_to_f32_kernel, dim3((unsigned)cdivll(pixels * C, 256)), dim3(256), 0, ST(stream),
+                     static_cast<const bf16_t*>(in), in_pitch, in_off, out, out_pitch, out_off, pixels, C);
   return glare_launch_status();
 }
 
