@@ -11,6 +11,9 @@ from . import ops
 from . import train_ops as T
 
 
+IMPLICIT_WGRAD = True   # 3x3 stride-1 weight gradients straight from padded planar operands (False: im2col_t + GEMM)
+
+
 def _rup(a, b):
     return (a + b - 1) // b * b
 
@@ -62,7 +65,11 @@ class Conv2dFn(torch.autograd.Function):
         g16 = _grad_bf16(gy, y, act, cout)
         dres = g16 if (has_res and ctx.needs_input_grad[3]) else None
         dw = db = dx = dx2 = None
-        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+        if (ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2])) and k == 3 and stride == 1 and not upsample \
+                and not has_x2 and cin_tot % 16 == 0 and IMPLICIT_WGRAD:
+            dw, db = T.conv3x3_weight_grad_implicit(x, g16, cout)      # no im2col matrix
+            db = db if has_bias else None
+        elif ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             kk = k * k
             c1 = x.shape[-1]
 

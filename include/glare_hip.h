@@ -292,6 +292,22 @@ int glare_im2col_t_bf16(const void* x_nhwc, int B, int H, int W, int pitch, int 
 int glare_im2col_t_f32(const float* x, long long stride_b, long long stride_c, long long stride_y, long long stride_x, int B,
                        int H, int W, int Ci, int ksize, int pad, void* colT, long long ldp, int row_base, int ones_row,
                        glare_stream_t stream);
+/* Implicit (im2col-free) weight gradient of a 3x3, stride-1, pad-1 convolution.  glare_pad_planar_t_bf16 writes an NHWC tensor as
+ * planar zero-bordered rows in the padded pixel space p' = b*(H+2)*Wp + yy*Wp + xx, Wp = roundup(W+2, 8), after a margin of Wp
+ * elements: out[s*C + c][Wp + p'] = x[b, yy-1, xx-1 + (s - n_shifts/2), c]; n_shifts = 3 for the activation (one copy per
+ * horizontal tap), 1 for the output gradient.  Whole rows (margins and tail included) are written; pitch ld = glare_pad_planar_ld();
+ * ones_row >= 0 additionally fills that row with ones (the activation operand carries it at row 3*C: bias gradient).
+ * glare_conv3x3_wgrad_implicit_bf16 then contracts over the padded pixels on the MFMA GEMM, vertical taps being aligned
+ * pointer shifts of +-Wp: dWt[b][(ty*3+tx)*Ci + ci][co] plus row 9*Ci = the bias gradient, one [9*Ci+1][Co] partial per K
+ * slice b (sum with glare_reduce_parts_f32). */
+long long glare_pad_planar_ld(int B, int H, int W, int k_multiple);
+int glare_pad_planar_t_bf16(const void* x_nhwc, int B, int H, int W, int pitch, int off, int C, int n_shifts, void* out,
+                            long long ld, int ones_row, glare_stream_t stream);
+int glare_conv3x3_wgrad_implicit_bf16(const void* xT3, const void* gT, float* dWt, int Ci, int Co, int W, long long ld,
+                                      int k_per_batch, int batch, glare_stream_t stream);
+/* out[c] = sum_p g[p][c] (bias gradient); g bf16 [P][pitch]; workspace >= 256 * C floats */
+int glare_colsum_bf16(const void* g, int pitch, long long P, int C, float* out, void* workspace, size_t workspace_bytes,
+                      glare_stream_t stream);
 int glare_transpose_bf16(const void* in, long long ld_in, long long batch_stride_in, void* out, long long ld_out,
                          long long batch_stride_out, long long rows, int cols, int batch, glare_stream_t stream);
 
