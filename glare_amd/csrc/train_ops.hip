@@ -749,8 +749,8 @@ extern "C" int glare_cast_bf16_f32(const void* in, int in_pitch, int in_off, flo
 }
 
 static int gn_bwd_splits(long long HW) {
-  long long s = HW / 128;   // >= 128 pixels per block; enough blocks to fill 256 CUs twice even at batch 2
-  return (int)(s < 1 ? 1 : (s > 512 ? 512 : s));
+  long long s = HW / 256;   // the per-image finalize walks all splits serially: more than 128 costs there what it saves here
+  return (int)(s < 1 ? 1 : (s > 128 ? 128 : s));
 }
 
 extern "C" size_t glare_groupnorm_backward_workspace_bytes(int B, long long HW, int C) {
