@@ -602,3 +602,26 @@ def test_conv_autograd_randomised_ragged_sizes():
         assert _rel(_nchw(xd.grad), xr.grad) < 2e-2, tag
         assert _rel(wd.grad, wr.grad) < 2e-2, tag
         assert _rel(bd.grad, br.grad) < 1e-2, tag
+
+
+def test_implicit_weight_gradient_equals_im2col_form():
+    """The im2col-free 3x3 weight gradient (padded planar operands, taps as pointer shifts) against the im2col_t + GEMM form it
+    replaces: same products, different summation order only."""
+    from glare_amd import autograd as A
+
+    g = torch.Generator().manual_seed(51)
+    for B, H, W, cin, cout in ((2, 17, 23, 64, 128), (1, 8, 8, 512, 512), (3, 5, 41, 16, 40)):
+        x = _nhwc16(torch.randn(B, cin, H, W, generator=g))
+        w = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).to(_dev())
+        b = torch.randn(cout, generator=g).to(_dev())
+        gy = _nhwc16(torch.randn(B, cout, H, W, generator=g))
+        grads = []
+        for implicit in (True, False):
+            A.IMPLICIT_WGRAD = implicit
+            try:
+                wd, bd = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+                A.conv2d(x, wd, bd).backward(gy)
+            finally:
+                A.IMPLICIT_WGRAD = True
+            grads.append((wd.grad.clone(), bd.grad.clone()))
+        assert _rel(grads[0][0], grads[1][0]) < 1e-5 and _rel(grads[0][1], grads[1][1]) < 1e-5
