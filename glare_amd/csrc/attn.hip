@@ -43,6 +43,13 @@ constexpr float RESCALE_THR = 8.0f;  // log2 units
 #ifndef ATTN_PIPELINED
 #define ATTN_PIPELINED 0
 #endif
+// ATTN_8WAVES=1 selects attn8w_fwd_kernel (8 waves x 16 query rows on v_mfma_f32_16x16x32_bf16, two waves per SIMD).  Measured:
+// 975-995 TFLOP/s vs 1 030-1 045 for the 4-wave kernel; with the DMA compiled out 1 056 vs 1 288.  Two waves per SIMD do hide
+// the DMA issue cost (8 % instead of 25 %), but every 1-KB fragment then feeds a 16-row MFMA: twice the LDS read traffic per
+// flop (512 KB per 32-key tile per CU) becomes the limit.  Kept as a reproducible alternative; default off.
+#ifndef ATTN_8WAVES
+#define ATTN_8WAVES 0
+#endif
 #ifndef ATTN_V_IN_PHASE_B
 #define ATTN_V_IN_PHASE_B 0
 #endif
@@ -495,6 +502,203 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 8-wave variant (ATTN_8WAVES): the same 128 query rows and the same LDS images, but 8 waves x 16 rows on
+// v_mfma_f32_16x16x32_bf16: O^T of a wave is 512 x 16 fp32 = 128 registers, Q 64, so TWO waves share a SIMD and cover
+// each other's waits (LDS-DMA issue, fragment reads, the softmax's vector ALU work), and every wave issues half the
+// DMA pieces.  Price: every K / V^T fragment (1 KB) feeds a 16-row MFMA instead of a 32-row one -- twice the LDS read
+// traffic per flop.  Transposed products as above; K rows are fetched in the order key(t, i) = 8*(i>>2) + 4*t + (i&3) so
+// that a lane's two score tiles ARE its P^T B-fragment (keys 8g .. 8g+7 for lane group g = lane>>4).
+typedef __attribute__((ext_vector_type(4))) float f32x4a;
+
+__global__ __launch_bounds__(512, 1) void attn8w_fwd_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  u32x4* lK = reinterpret_cast<u32x4*>(smem);   // [2][KCH]
+  u32x4* lV = lK + 2 * KCH;                     // [2][KCH]
+  int bid = blockIdx.x;
+  {
+    const int n = p.n_blocks, q = n / 8, r = n % 8, xcd = bid % 8, kk = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kk;
+  }
+  const int qb = bid % p.n_qblocks, ksplit = (bid / p.n_qblocks) % p.key_splits, b = bid / (p.n_qblocks * p.key_splits);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qi = lane & 15, g = lane >> 4;
+  const int qrow = qb * BM + wave * 16 + qi;
+  const bool q_ok = qrow < p.N;
+
+  bf16x8 qf[HD / 32];   // Q^T B-fragments: lane (q, g) holds Q[q][32*ks + 8*g .. +8]
+  {
+    const bf16_t* qp = p.q + ((size_t)b * p.N + (q_ok ? qrow : 0)) * p.ldq + g * 8;
+#pragma unroll
+    for (int ks = 0; ks < HD / 32; ++ks) {
+      u32x4 v = *reinterpret_cast<const u32x4*>(qp + ks * 32);
+      if (!q_ok) v = u32x4{0u, 0u, 0u, 0u};
+      qf[ks] = __builtin_bit_cast(bf16x8, v);
+    }
+  }
+  f32x4a o[HD / 16];
+#pragma unroll
+  for (int i = 0; i < HD / 16; ++i) o[i] = f32x4a{0.f, 0.f, 0.f, 0.f};
+  float m_run = -1e30f, l_run = 0.f;
+
+  const int n_tiles = (p.N + BN - 1) / BN;
+  const int t_begin = (int)((long long)n_tiles * ksplit / p.key_splits), t_end = (int)((long long)n_tiles * (ksplit + 1) / p.key_splits);
+  const bf16_t* kbase = p.k + (size_t)b * p.N * p.ldk;
+  const bf16_t* vbase = p.vt + (size_t)b * HD * p.Npad;
+  const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(kbase), 0, (int)((((long long)p.N - 1) * p.ldk + HD) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t vrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vbase), 0, (int)((long long)HD * p.Npad * 2), 0x00020000);
+  const int lane16 = lane * 16;
+  const unsigned v_lane_off = (unsigned)((lane >> 2) * p.Npad + (((lane & 3) ^ ((lane >> 4) & 3)) * 8)) * 2u;
+  // 64 pieces per tile, 8 per wave: K rows r = wave + 8*i (i < 4), V^T 16-row groups wave + 8*j (j < 4)
+  auto issue_piece = [&](auto ic, int tile, int buf) {
+    constexpr int i = decltype(ic)::value;
+    if constexpr (i < 4) {
+      const int r = wave + 8 * i;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(krsrc, (__attribute__((address_space(3))) void*)(lK + buf * KCH + r * 64), 16,
+                                               lane16 ^ ((r & 15) * 16), (tile * BN + r) * p.ldk * 2, 0, 0);
+    } else {
+      constexpr int j = i - 4;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(vrsrc, (__attribute__((address_space(3))) void*)(lV + buf * KCH + (wave + 8 * j) * 64), 16,
+                                               v_lane_off, (int)(((long long)(wave + 8 * j) * 16 * p.Npad + (long long)tile * BN) * 2), 0, 0);
+    }
+  };
+
+  // fragment addresses: K frag (t, ks): row key(t, qi) of the [32][64 chunks] image, chunk (4*ks + g) ^ (key & 15);
+  //                     V^T frag (dt): row 16*dt + qi of the [512][4 chunks] image, chunk g ^ ((qi >> 2) & 3)
+  int kofs[2][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int key = 8 * (qi >> 2) + 4 * t + (qi & 3);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) kofs[t][c] = (key * 64 + (((c << 2) | g) ^ (key & 15))) * 16;
+  }
+  const int vofs = 2 * KCH * 16 + (qi * 4 + (g ^ ((qi >> 2) & 3))) * 16;
+
+  auto tile_body = [&](auto bufc, int tile) {
+    constexpr int BUF = decltype(bufc)::value;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int nxt = min(tile + 1, t_end - 1);
+    const char* kb = smem + BUF * KCH * 16;
+    // ---- S^T tiles (2 x 16 keys x 16 queries), contraction over d in 16 steps of 32: two independent accumulation chains
+    f32x4a s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    // fragment reads run one group ahead of the MFMAs through two rotating register sets (fr[set][0..1] = tile-0 rows,
+    // [2..3] = tile-1 rows of two k-steps); the first V^T group is fetched before the softmax
+    bf16x8 fr[2][4];
+    const char* vb = smem + BUF * KCH * 16 + vofs;
+    auto ldk2 = [&](auto gc, bf16x8(&f)[4]) {
+      constexpr int gq = decltype(gc)::value;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int ks = 2 * gq + e;
+        f[e] = *reinterpret_cast<const bf16x8*>(kb + kofs[0][ks & 3] + (ks >> 2) * 256);
+        f[2 + e] = *reinterpret_cast<const bf16x8*>(kb + kofs[1][ks & 3] + (ks >> 2) * 256);
+      }
+    };
+    auto ldv4 = [&](auto gc, bf16x8(&f)[4]) {
+      constexpr int gq = decltype(gc)::value;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) f[e] = *reinterpret_cast<const bf16x8*>(vb + (4 * gq + e) * 1024);
+    };
+    ldk2(std::integral_constant<int, 0>{}, fr[0]);
+    static_for<8>([&](auto gc) {     // groups of 2 k-steps: 4 fragment reads, 4 MFMAs, 1 DMA piece (register budget: 128 VGPRs)
+      constexpr int gq = decltype(gc)::value;
+      if constexpr (gq + 1 < 8) ldk2(std::integral_constant<int, gq + 1>{}, fr[(gq + 1) & 1]);
+      else ldv4(std::integral_constant<int, 0>{}, fr[(gq + 1) & 1]);
+#ifndef ATTN_ABLATE_NODMA
+      issue_piece(std::integral_constant<int, gq>{}, nxt, BUF ^ 1);
+#endif
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[gq & 1][e], qf[2 * gq + e], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[gq & 1][2 + e], qf[2 * gq + e], s1, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if (tile == n_tiles - 1) {   // keys beyond N
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kv = tile * BN + 8 * g + r;
+        if (kv >= p.N) s0[r] = -__builtin_inff();
+        if (kv + 4 >= p.N) s1[r] = -__builtin_inff();
+      }
+    }
+    // ---- online softmax: a query's 32 keys live in the 4 lanes q, q+16, q+32, q+48
+    float mx = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+    {
+      const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = fmaxf(mx, __uint_as_float((g & 1) ? a[0] : a[1]));
+      const auto c = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = fmaxf(mx, __uint_as_float((g & 2) ? c[0] : c[1]));
+    }
+    if (__any(mx > m_run + RESCALE_THR)) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < HD / 16; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[i][r] *= alpha;   // 128 accumulators: they live in VGPRs here, no AGPR round trip
+      m_run = m_new;
+    }
+    float psum = 0.f;
+    u32x4 w;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float a0 = __builtin_amdgcn_exp2f(s0[2 * e] - m_run), a1 = __builtin_amdgcn_exp2f(s0[2 * e + 1] - m_run);
+      const float c0 = __builtin_amdgcn_exp2f(s1[2 * e] - m_run), c1 = __builtin_amdgcn_exp2f(s1[2 * e + 1] - m_run);
+      psum += (a0 + a1) + (c0 + c1);
+      w[e] = pack_bf2(a0, a1);
+      w[2 + e] = pack_bf2(c0, c1);
+    }
+    l_run += psum;
+    const bf16x8 pf = __builtin_bit_cast(bf16x8, w);   // P^T B-fragment: keys 8g .. 8g+7 of query qi
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- O^T += V^T . P^T : 32 d-tiles of 16, one 32-key step each
+    static_for<8>([&](auto gc) {     // groups of 4 d-tiles; set parity continues from the S phase (group 8 + gq)
+      constexpr int gq = decltype(gc)::value;
+      if constexpr (gq + 1 < 8) ldv4(std::integral_constant<int, gq + 1>{}, fr[(gq + 1) & 1]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[4 * gq + e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[gq & 1][e], pf, o[4 * gq + e], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  static_for<8>([&](auto ic) { issue_piece(ic, t_begin, 0); });
+  for (int tile = t_begin; tile < t_end; tile += 2) {
+    tile_body(std::integral_constant<int, 0>{}, tile);
+    if (tile + 1 < t_end) tile_body(std::integral_constant<int, 1>{}, tile + 1);
+  }
+
+  // ---- epilogue: lane (q, g) holds O[q][16*dt + 4*g + r]
+  float l_tot = l_run;
+  {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(l_tot), __float_as_uint(l_tot), false, false);
+    l_tot += __uint_as_float((g & 1) ? a[0] : a[1]);
+    const auto c = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_tot), __float_as_uint(l_tot), false, false);
+    l_tot += __uint_as_float((g & 2) ? c[0] : c[1]);
+  }
+  if (!q_ok) return;
+  if (p.key_splits > 1) {
+    const size_t row = ((size_t)b * p.key_splits + ksplit) * p.N + qrow;
+    float* po = p.part_o + row * HD;
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) *reinterpret_cast<f32x4a*>(po + dt * 16 + 4 * g) = o[dt];
+    if (g == 0) { p.part_ml[row * 2] = m_run; p.part_ml[row * 2 + 1] = l_tot; }
+    return;
+  }
+  const float inv = 1.0f / l_tot;
+  bf16_t* op = p.o + ((size_t)b * p.N + qrow) * p.ldo;
+#pragma unroll
+  for (int dt = 0; dt < HD / 16; ++dt) {
+    u32x2 w2 = {pack_bf2(o[dt][0] * inv, o[dt][1] * inv), pack_bf2(o[dt][2] * inv, o[dt][3] * inv)};
+    *reinterpret_cast<u32x2*>(op + dt * 16 + 4 * g) = w2;
+  }
+}
+
 // out[q] = sum_s 2^(m_s - m) O_s[q] / sum_s 2^(m_s - m) l_s,  m = max_s m_s: merges the key splits (one wave per query row)
 __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
                                                            bf16_t* __restrict__ out, int ldo, int B, int N, int KS) {
@@ -564,9 +768,15 @@ static int attn_launch(const void* q, int ldq, const void* k, int ldk, const voi
   if (nb > 0x7fffffffLL) return GLARE_ERR_INVALID;
   p.n_blocks = (int)nb;
   const size_t lds = (size_t)4 * KCH * 16 + (ATTN_PIPELINED ? 4 * 8192 : 0);  // 128 KB K/V ring (+ 32 KB Q tail)
+#if ATTN_8WAVES && !ATTN_PIPELINED
+  if (hipFuncSetAttribute((const void*)attn8w_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return GLARE_ERR_LAUNCH;
+  hipLaunchKernelGGL(attn8w_fwd_kernel, dim3(p.n_blocks), dim3(512), lds, (hipStream_t)stream, p);
+#else
   if (hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GLARE_ERR_LAUNCH;
   hipLaunchKernelGGL(attn_fwd_kernel, dim3(p.n_blocks), dim3(AT_THREADS), lds, (hipStream_t)stream, p);
+#endif
   if (key_splits > 1)
     hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)(((long long)B * N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p.part_o,
                        p.part_ml, p.o, ldo, B, N, key_splits);
