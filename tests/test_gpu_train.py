@@ -625,3 +625,32 @@ def test_implicit_weight_gradient_equals_im2col_form():
                 A.IMPLICIT_WGRAD = True
             grads.append((wd.grad.clone(), bd.grad.clone()))
         assert _rel(grads[0][0], grads[1][0]) < 1e-5 and _rel(grads[0][1], grads[1][1]) < 1e-5
+
+
+@pytest.mark.parametrize("stage", ["stage2", "stage3"])
+def test_training_steps_at_the_reference_crop_sizes(stage):
+    """SURVEY.md section 8 configs T2 (2 x 3x320x320 per GPU) and T3 (1 x 3x256x256 per GPU): steps run at the full sizes, losses are
+    finite and fall on a fixed batch, trained parameters move, frozen ones do not."""
+    from glare_amd import modules as M
+    from glare_amd.synthetic import seeded_init_
+    from glare_amd.train import Stage2Trainer, Stage3Trainer
+
+    g = torch.Generator().manual_seed(61)
+    net_hq = seeded_init_(M.VQModel().eval(), 1).to(_dev())
+    if stage == "stage2":
+        B, S = 2, 320
+        net = seeded_init_(M.LLFlowVQGAN2().train(), 2).to(_dev())
+        tr = Stage2Trainer(net, net_hq, lr_G=2e-4)
+        moving, frozen = net.flowUpsamplerNet.layers[5].actnorm.bias, net_hq.encoder.conv_in.weight
+    else:
+        B, S = 1, 256
+        net = seeded_init_(M.VQLLFLOWDeformable().train(), 0).to(_dev())
+        tr = Stage3Trainer(net, net_hq, lr_G=1e-4)
+        moving, frozen = net.deformable_decoder.warp[0].dcn.weight, net.RRDB.encoder.conv_in.weight
+    gt = torch.rand(B, 3, S, S, generator=g).to(_dev())
+    lr = (torch.randn(B, 3, S, S, generator=g) * 0.5 - 1.0).to(_dev())
+    m0, f0 = moving.detach().clone(), frozen.detach().clone()
+    losses = [tr.step(gt, lr) for _ in range(6)]
+    assert all(l == l and abs(l) < 1e6 for l in losses), losses
+    assert min(losses[3:]) < losses[0], losses
+    assert not torch.equal(m0, moving.detach()) and torch.equal(f0, frozen.detach())
