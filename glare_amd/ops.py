@@ -268,9 +268,26 @@ def attention_key_splits(B, N):
     return max(1, min(4, (512 + blocks - 1) // blocks, (N + 31) // 32))
 
 
+# Measurement hook (bench.py): when this is a list, every attention launch is bracketed by a pair of events recorded on the
+# stream the kernel is launched on, and (start, end, B, N) is appended.  None (the default) records nothing.
+ATTENTION_LAUNCH_EVENTS = None
+
+
 def attention_d512(q, k, v_t, N, ldq=None, ldk=None, out=None, key_splits=None):
     """q, k: bf16 [B, N, ld] views (d=512 used); v_t: bf16 [B, 512, v_pitch]; returns bf16 [B, N, 512]."""
     require_cuda(q, k, v_t, out)
+    if ATTENTION_LAUNCH_EVENTS is not None:
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        try:
+            return _attention_d512(q, k, v_t, N, ldq, ldk, out, key_splits)
+        finally:
+            end.record()
+            ATTENTION_LAUNCH_EVENTS.append((start, end, int(v_t.shape[0]), int(N)))
+    return _attention_d512(q, k, v_t, N, ldq, ldk, out, key_splits)
+
+
+def _attention_d512(q, k, v_t, N, ldq, ldk, out, key_splits):
     B = v_t.shape[0]
     ldq = q.shape[-1] if ldq is None else ldq
     ldk = k.shape[-1] if ldk is None else ldk
