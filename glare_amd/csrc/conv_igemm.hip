@@ -18,6 +18,13 @@
 // The zero padding, the nearest x2 upsample (Upsample, encoder_decoder.py:50) and the
 // asymmetric stride-2 padding (Downsample, encoder_decoder.py:71-73) are address arithmetic
 // in the loader; bias, residual add, activation and layout conversion are the epilogue.
+//
+// KS == 2 is the SUB-PIXEL form of "nearest x2 upsample, then 3x3 conv" (Upsample, encoder_decoder.py:43-52): output pixel
+// (2i+a, 2j+b) only ever sees input rows {i-1, i} (a = 0) or {i, i+1} (a = 1) of the LOW-resolution source, likewise for
+// columns, so each of the four output phases (a, b) is a 2x2 conv of the source with the 3x3 taps that land on the same
+// source pixel pre-summed (in fp32, then rounded to bf16 once): 16 tap-MACs per source pixel instead of 36, the same
+// result up to that one rounding.  A workgroup computes one phase of an 8 x 32 SOURCE tile and scatters it to the
+// interleaved output positions; the four phases of a tile are adjacent in the launch order (shared halo in L2).
 #include <type_traits>
 
 #include "common.h"
@@ -112,6 +119,9 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
   }
   const int ct = bid % p.co_tiles;
   int t = bid / p.co_tiles;
+  int phase = 0;
+  if (KS == 2) { phase = t & 3; t >>= 2; }
+  const int pa = phase >> 1, pb = phase & 1;   // output row / column parity of this sub-pixel phase
   const int tx = t % p.tiles_x;
   t /= p.tiles_x;
   const int ty = t % p.tiles_y;
@@ -121,7 +131,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int oy0 = ty * TH, ox0 = tx * TW;
-  const int iy0 = oy0 * STRIDE - G::PAD, ix0 = ox0 * STRIDE - G::PAD;
+  const int iy0 = oy0 * STRIDE - G::PAD - (KS == 2 ? 1 - pa : 0), ix0 = ox0 * STRIDE - G::PAD - (KS == 2 ? 1 - pb : 0);
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -162,7 +172,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
       __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.in0 + img * p.p0), 0, (int)p.in0_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t arsrc1 = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<bf16_t*>(p.in1 ? p.in1 + img * p.p1 : p.in0), 0, (int)(p.in1 ? p.in1_bytes : p.in0_bytes), 0x00020000);
-  const bf16_t* wbase = p.wpk + (size_t)ct * p.n_stages * (size_t)(KS * B_CHUNKS) * 8;
+  const bf16_t* wbase = p.wpk + ((size_t)phase * p.co_tiles + ct) * p.n_stages * (size_t)(KS * B_CHUNKS) * 8;
 
   auto issue_a = [&](int chunk, int buf, int i_lo = 0, int i_hi = 1 << 20) {   // pieces [i_lo, i_hi) of this wave
     const int c0 = chunk * KC;
@@ -323,7 +333,8 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
         const int co = ct * TN + wn * NT * 32 + ch * 8;
         if (oy < p.OH && ox < p.OW && co < p.Cout) {
           u32x4 v = *reinterpret_cast<const u32x4*>(slab + row * ROWB + ch * 16);
-          const size_t pix = ((size_t)b * p.OH + oy) * p.OW + ox;
+          const size_t pix = KS == 2 ? ((size_t)b * (2 * p.OH) + 2 * oy + pa) * (size_t)(2 * p.OW) + 2 * ox + pb
+                                     : ((size_t)b * p.OH + oy) * p.OW + ox;
           if (p.res) {
             const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + pix * p.rpitch + p.roff + co);
 #pragma unroll
@@ -353,7 +364,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
       if (lane < CPR && co < p.Cout) {
         // parts live on the 8-row x 32-col grid whatever the tile: (8-row block, column tile, wave row within the block)
         const int row0 = oy0 + wm * MT;
-        const int part = ((row0 / 8) * p.tiles_x + tx) * 2 + ((row0 / 4) & 1);
+        const int part = ((phase * ((p.OH + 7) / 8) + row0 / 8) * p.tiles_x + tx) * 2 + ((row0 / 4) & 1);
         if (part < p.gn_nparts) {
           float* dst = p.gn_part + (((size_t)b * p.gn_nparts + part) * (p.Cout / 4) + co / 4) * 2;
           dst[0] = gs0; dst[1] = gq0; dst[2] = gs1; dst[3] = gq1;
@@ -443,6 +454,35 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, bf16_t* __restri
   out[i] = f2bf(v);
 }
 
+// Sub-pixel upsample filters: [phase = a*2+b][co_tile][stage][tap = r*2+c][khalf][TN][8] (KSTEPS = 1), where tap (r, c)
+// of phase (a, b) is the sum of the 3x3 taps (ky, kx) that read the same source pixel: rows a=0: r=0 <- {0}, r=1 <- {1,2};
+// a=1: r=0 <- {0,1}, r=1 <- {2}; columns alike with b.
+__global__ void pack_weight_subpix_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin, int TN,
+                                          int n_stages, int co_tiles, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  long long t = i;
+  const int e = t % 8; t /= 8;
+  const int n = t % TN; t /= TN;
+  const int khalf = t % 2; t /= 2;
+  const int tap = t % 4; t /= 4;
+  const int s = t % n_stages; t /= n_stages;
+  const int ct = t % co_tiles; t /= co_tiles;
+  const int phase = (int)t;
+  const int a = phase >> 1, b = phase & 1, r = tap >> 1, c = tap & 1;
+  const int ky0 = a == 0 ? (r == 0 ? 0 : 1) : (r == 0 ? 0 : 2), ky1 = a == 0 ? (r == 0 ? 0 : 2) : (r == 0 ? 1 : 2);
+  const int kx0 = b == 0 ? (c == 0 ? 0 : 1) : (c == 0 ? 0 : 2), kx1 = b == 0 ? (c == 0 ? 0 : 2) : (c == 0 ? 1 : 2);
+  const int co = ct * TN + n;
+  const int ci = s * 16 + khalf * 8 + e;
+  float v = 0.f;
+  if (co < Cout && ci < Cin) {
+    const float* wp = w + ((size_t)co * Cin + ci) * 9;
+    for (int ky = ky0; ky <= ky1; ++ky)
+      for (int kx = kx0; kx <= kx1; ++kx) v += wp[ky * 3 + kx];
+  }
+  out[i] = f2bf(v);
+}
+
 // GroupNorm partial reduction: [b][part][Cout/4][2] -> the [B][1][32][2] partial format gn_apply consumes
 __global__ __launch_bounds__(256) void gn_part_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts,
                                                              int Cout) {
@@ -491,10 +531,10 @@ int launch(const ConvParams& p_in, hipStream_t stream) {
   constexpr int TN = WN * NT * 32;
   ConvParams p = p_in;
   p.tiles_y = cdiv(p.OH, WM * MT);
-  const long long nb = (long long)p.B * p.tiles_x * p.tiles_y * p.co_tiles;
+  const long long nb = (long long)p.B * p.tiles_x * p.tiles_y * p.co_tiles * (KS == 2 ? 4 : 1);
   if (nb > 0x7fffffffLL) return GLARE_ERR_INVALID;
   p.n_blocks = (int)nb;
-  p.gn_nparts = p.tiles_x * cdiv(p.OH, 8) * 2;  // the 8 x 32 grid, 2 wave rows (4 rows each) per block
+  p.gn_nparts = p.tiles_x * cdiv(p.OH, 8) * 2 * (KS == 2 ? 4 : 1);  // the 8 x 32 grid, 2 wave rows (4 rows each) per block
   if (p.gn_part && !(p.fast_epilogue && p.Cout % 32 == 0)) return GLARE_ERR_UNSUPPORTED;
   const size_t lds = (size_t)(2 * (((KSTEPS * 2 * G::NPOS + 63) / 64) * 64) + 2 * KS * KSTEPS * 2 * TN) * 16;
   auto kern = conv_igemm_kernel<KS, STRIDE, MT, NT, WM, WN, KSTEPS>;
@@ -527,6 +567,23 @@ extern "C" int glare_conv2d_pack_weight(const float* w_oihw, int cout, int cin_t
   return glare_launch_status();
 }
 
+extern "C" long long glare_conv2d_upsample_packed_weight_elems(int cout, int cin_total) {
+  if (cout <= 0 || cin_total <= 0) return GLARE_ERR_INVALID;
+  const Variant v = pick_variant(3, cout);
+  const long long stages = (cin_total + 15) / 16, co_tiles = (cout + v.tn - 1) / v.tn;
+  return 4 * co_tiles * stages * 4 * 2 * v.tn * 8;
+}
+
+extern "C" int glare_conv2d_pack_weight_upsample(const float* w_oihw, int cout, int cin_total, void* packed_bf16,
+                                                 glare_stream_t stream) {
+  const long long total = glare_conv2d_upsample_packed_weight_elems(cout, cin_total);
+  if (total < 0 || !w_oihw || !packed_bf16) return GLARE_ERR_INVALID;
+  const Variant v = pick_variant(3, cout);
+  hipLaunchKernelGGL(pack_weight_subpix_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     w_oihw, (bf16_t*)packed_bf16, cout, cin_total, v.tn, (cin_total + 15) / 16, (cout + v.tn - 1) / v.tn, total);
+  return glare_launch_status();
+}
+
 extern "C" int glare_conv2d_pack_weight_dgrad(const float* w_oihw, int cout, int cin, int ksize, int cout_padded, void* packed_bf16,
                                               glare_stream_t stream) {
   // the data-gradient conv has cin output channels and cout_padded (>= cout, % 8 == 0) input channels
@@ -547,6 +604,8 @@ extern "C" int glare_conv2d_bf16(const glare_conv_desc* d, glare_stream_t stream
   if (d->ksize != 1 && d->ksize != 3) return GLARE_ERR_UNSUPPORTED;
   if (d->stride != 1 && d->stride != 2) return GLARE_ERR_UNSUPPORTED;
   if (d->stride == 2 && (d->ksize != 3 || d->upsample)) return GLARE_ERR_UNSUPPORTED;
+  const bool subpix = d->upsample == 2;   // sub-pixel form: weights from glare_conv2d_pack_weight_upsample
+  if (subpix && (d->ksize != 3 || d->stride != 1)) return GLARE_ERR_UNSUPPORTED;
   // 16-B channel chunks: every source's channel count / offset / pitch must be a multiple of 8
   if ((d->Cin % 8) || (d->in_pitch % 8) || (d->in_off % 8)) return GLARE_ERR_UNSUPPORTED;
   if (d->in2 && ((d->Cin2 % 8) || (d->in2_pitch % 8) || (d->in2_off % 8) || d->Cin2 <= 0)) return GLARE_ERR_UNSUPPORTED;
@@ -562,8 +621,8 @@ extern "C" int glare_conv2d_bf16(const glare_conv_desc* d, glare_stream_t stream
   p.res = (const bf16_t*)d->residual;
   p.out = d->out;
   p.B = d->B; p.H = d->H; p.W = d->W;
-  p.IHs = d->upsample ? 2 * d->H : d->H;
-  p.IWs = d->upsample ? 2 * d->W : d->W;
+  p.IHs = (d->upsample && !subpix) ? 2 * d->H : d->H;   // sub-pixel form: the kernel works on the source grid
+  p.IWs = (d->upsample && !subpix) ? 2 * d->W : d->W;
   if (d->stride == 2) {  // pad (0,1,0,1) then valid 3x3 s2 (encoder_decoder.py:71-73)
     p.OH = (p.IHs + 1 - 3) / 2 + 1;
     p.OW = (p.IWs + 1 - 3) / 2 + 1;
@@ -574,7 +633,7 @@ extern "C" int glare_conv2d_bf16(const glare_conv_desc* d, glare_stream_t stream
   p.p0 = d->in_pitch; p.o0 = d->in_off; p.p1 = d->in2_pitch; p.o1 = d->in2_off;
   p.Cout = d->Cout; p.opitch = d->out_pitch; p.ooff = d->out_off;
   p.rpitch = d->res_pitch; p.roff = d->res_off;
-  p.upsample = d->upsample; p.act = d->act; p.out_mode = d->out_mode;
+  p.upsample = subpix ? 0 : d->upsample; p.act = d->act; p.out_mode = d->out_mode;
   p.plane_pitch = d->plane_pitch > 0 ? d->plane_pitch : (long long)p.OH * p.OW;
   if (p.plane_pitch < (long long)p.OH * p.OW) return GLARE_ERR_INVALID;
   const Variant v = pick_variant(d->ksize, d->Cout);
@@ -610,6 +669,10 @@ extern "C" int glare_conv2d_bf16(const glare_conv_desc* d, glare_stream_t stream
     return launch<KS_, ST_, 2, 1, 4, 1, KST>(p, stream);                                  \
   } while (0)
 
+  if (subpix) {   // interleaved scatter lives in the LDS-staged epilogue only
+    if (!p.fast_epilogue) return GLARE_ERR_UNSUPPORTED;
+    GLARE_CONV_DISPATCH(2, 1);
+  }
   if (d->ksize == 1) GLARE_CONV_DISPATCH(1, 1);
   if (d->stride == 2) GLARE_CONV_DISPATCH(3, 2);
   GLARE_CONV_DISPATCH(3, 1);
@@ -622,6 +685,20 @@ extern "C" long long glare_conv2d_gn_partial_elems(int B, int OH, int OW, int Co
   if (B <= 0 || OH <= 0 || OW <= 0 || Cout <= 0) return GLARE_ERR_INVALID;
   const long long parts = (long long)cdiv(OW, TW) * cdiv(OH, 8) * 2;  // 8 x 32 tiles, 2 wave rows per tile
   return (long long)B * parts * (Cout / 4) * 2;
+}
+
+// The sub-pixel upsample conv (desc.upsample == 2) lays its partials on the SOURCE grid, four phases per tile.
+extern "C" long long glare_conv2d_upsample_gn_partial_elems(int B, int H, int W, int Cout) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0) return GLARE_ERR_INVALID;
+  return 4 * glare_conv2d_gn_partial_elems(B, H, W, Cout);
+}
+
+extern "C" int glare_conv2d_upsample_gn_reduce(const float* gn_partial, float* stats_out, int B, int H, int W, int Cout,
+                                               glare_stream_t stream) {
+  if (!gn_partial || !stats_out || B <= 0 || Cout % 128) return GLARE_ERR_INVALID;
+  const int parts = cdiv(W, TW) * cdiv(H, 8) * 2 * 4;
+  hipLaunchKernelGGL(gn_part_reduce_kernel, dim3(B * 32), dim3(256), 0, (hipStream_t)stream, gn_partial, stats_out, parts, Cout);
+  return glare_launch_status();
 }
 
 extern "C" int glare_conv2d_gn_reduce(const float* gn_partial, float* stats_out, int B, int OH, int OW, int Cout,

@@ -10,6 +10,8 @@ a full host sync per image), images are batched (default 8) and each rank enhanc
 the only collective is the final gather of the per-image PSNRs to rank 0 (RCCL).
 There are no datasets or checkpoints offline: inputs are synthetic LOL-shaped pairs, weights name-seeded."""
 import argparse
+import os
+import time
 import json
 
 import numpy as np
@@ -66,9 +68,14 @@ def run(n_images, batch=8, h=400, w=600, seed=1234, root=None, net_g=None, net_v
         _, vals = harness.postprocess_device(out, h, w, gt)       # crop, clamp, GT-mean gain, PSNR: all on the device
         return vals.view(-1, 1)
 
+    psnr_slice(0, min(batch, n_images))                           # warm-up: weight packing, workspace growth
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     local = parallel.run_sharded(n_images, psnr_slice, rank, world, batch=batch)
     if local is None:
         local = torch.zeros(0, 1, dtype=torch.float64, device=device)
+    torch.cuda.synchronize()
+    run.last_seconds = time.perf_counter() - t0                   # host uint8 in -> PSNR on the device, this rank's share
     full = parallel.gather_results(local, n_images, rank, world)
     if world > 1:
         torch.distributed.barrier()
@@ -88,7 +95,9 @@ def main():
     args = ap.parse_args()
     psnrs = run(args.images, args.batch, args.height, args.width, root=args.root, net_g=args.net_g, net_vq=args.net_vq)
     if psnrs is not None:
-        print(json.dumps({"images": int(len(psnrs)), "mean_psnr": float(np.mean(psnrs)), "psnr": [round(float(v), 4) for v in psnrs]}))
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        print(json.dumps({"images": int(len(psnrs)), "mean_psnr": float(np.mean(psnrs)), "psnr": [round(float(v), 4) for v in psnrs],
+                          "images_per_sec_incl_host_transfers": round(len(psnrs) / run.last_seconds, 2), "ranks": world}))
 
 
 if __name__ == "__main__":

@@ -35,6 +35,9 @@ def conv_t(x, conv, **kw):
     return A.conv2d(x, conv.weight, conv.bias, **kw)
 
 
+SUBPIXEL_UPSAMPLE = True
+
+
 class Upsample(HipModule):
     def __init__(self, in_channels, with_conv=True):
         super().__init__()
@@ -43,8 +46,14 @@ class Upsample(HipModule):
         self.conv = nn.Conv2d(in_channels, in_channels, 3, 1, 1)
 
     def forward_nhwc(self, x, **kw):
-        # nearest x2 fused in the loader; GroupNorm statistics of the output fused in the epilogue
-        return ops.conv2d(x, packed_conv(self, self.conv), upsample=True, gn_stats=GN_FUSED and self.conv.out_channels % 128 == 0, **kw)
+        # sub-pixel form of nearest x2 + 3x3 (four 2x2 convs of the source with pre-summed taps: 4/9 of the MACs, conv_igemm.hip);
+        # GroupNorm statistics of the output fused in the epilogue.  SUBPIXEL_UPSAMPLE = False: upsample fused in the loader.
+        if SUBPIXEL_UPSAMPLE:
+            pc = self._packed(("conv_subpixel", id(self.conv)),
+                              lambda: ops.PackedConv(self.conv.weight, self.conv.bias, upsample_subpixel=True))
+        else:
+            pc = packed_conv(self, self.conv)
+        return ops.conv2d(x, pc, upsample=True, gn_stats=GN_FUSED and self.conv.out_channels % 128 == 0, **kw)
 
     def train_nhwc(self, x):
         return conv_t(x, self.conv, upsample=True)

@@ -48,14 +48,28 @@ class ConvDesc(ctypes.Structure):
 class PackedConv:
     """A conv filter packed once for the MFMA kernel (weights bf16 stage-ordered, bias fp32)."""
 
-    def __init__(self, weight_oihw, bias=None, dgrad_pad=None):
-        """dgrad_pad = P: pack the filter of the data-gradient conv (P >= cout input channels, cin outputs) instead."""
+    def __init__(self, weight_oihw, bias=None, dgrad_pad=None, upsample_subpixel=False):
+        """dgrad_pad = P: pack the filter of the data-gradient conv (P >= cout input channels, cin outputs) instead.
+        upsample_subpixel: pack the four 2x2 sub-pixel filters of "nearest x2 upsample, then this 3x3 conv" (conv2d then runs
+        desc.upsample = 2: 16 instead of 36 tap-MACs per source pixel)."""
         require_cuda(weight_oihw)
         w = weight_oihw.detach().float().contiguous()
         cout, cin, kh, kw = w.shape
         assert kh == kw and kh in (1, 3)
         self.ksize = kh
+        self.subpixel = bool(upsample_subpixel)
         lib = _lib.lib()
+        if self.subpixel:
+            assert kh == 3 and dgrad_pad is None
+            self.cout, self.cin = cout, cin
+            lib.glare_conv2d_upsample_packed_weight_elems.restype = _ll
+            n = lib.glare_conv2d_upsample_packed_weight_elems(_i(cout), _i(cin))
+            assert n > 0
+            self.packed = torch.empty(n, dtype=torch.bfloat16, device=w.device)
+            check(lib.glare_conv2d_pack_weight_upsample(ptr(w), _i(cout), _i(cin), ptr(self.packed), stream_handle()),
+                  "glare_conv2d_pack_weight_upsample")
+            self.bias = None if bias is None else bias.detach().float().contiguous()
+            return
         lib.glare_conv2d_packed_weight_elems.restype = _ll
         self.cout, self.cin = (cout, cin) if dgrad_pad is None else (cin, dgrad_pad)
         n = lib.glare_conv2d_packed_weight_elems(_i(self.cout), _i(self.cin), _i(kh))
@@ -110,20 +124,30 @@ def conv2d(x, pc, *, x2=None, cin=None, in_off=0, cin2=None, in2_off=0, stride=1
     if residual is not None:
         assert residual.dtype == torch.bfloat16 and residual.is_contiguous()
         d.residual, d.res_pitch, d.res_off = residual.data_ptr(), residual.shape[3], res_off
-    d.ksize, d.stride, d.upsample, d.act, d.out_mode = pc.ksize, stride, int(bool(upsample)), ACT[act], out_mode
+    subpixel = getattr(pc, "subpixel", False)
+    assert not subpixel or upsample, "a sub-pixel packed filter only implements the upsample conv"
+    d.ksize, d.stride, d.upsample, d.act, d.out_mode = pc.ksize, stride, (2 if subpixel else int(bool(upsample))), ACT[act], out_mode
     lib = _lib.lib()
     gn_part = None
     if gn_stats:  # GroupNorm statistics of the output, gathered by the epilogue (saves the consumer's read pass)
         assert out_mode == OUT_NHWC_BF16 and pc.cout % 128 == 0 and out_off == 0 and out.shape[3] == pc.cout
         lib.glare_conv2d_gn_partial_elems.restype = _ll
-        n = lib.glare_conv2d_gn_partial_elems(_i(B), _i(OH), _i(OW), _i(pc.cout))
+        lib.glare_conv2d_upsample_gn_partial_elems.restype = _ll
+        if subpixel:
+            n = lib.glare_conv2d_upsample_gn_partial_elems(_i(B), _i(H), _i(W), _i(pc.cout))
+        else:
+            n = lib.glare_conv2d_gn_partial_elems(_i(B), _i(OH), _i(OW), _i(pc.cout))
         gn_part = torch.empty(n, dtype=torch.float32, device=x.device)
         d.gn_partial = gn_part.data_ptr()
     check(lib.glare_conv2d_bf16(ctypes.byref(d), stream_handle()), "glare_conv2d_bf16")
     if gn_stats:
         stats = torch.empty(B, 1, 32, 2, dtype=torch.float32, device=x.device)
-        check(lib.glare_conv2d_gn_reduce(ptr(gn_part), ptr(stats), _i(B), _i(OH), _i(OW), _i(pc.cout), stream_handle()),
-              "glare_conv2d_gn_reduce")
+        if subpixel:
+            check(lib.glare_conv2d_upsample_gn_reduce(ptr(gn_part), ptr(stats), _i(B), _i(H), _i(W), _i(pc.cout), stream_handle()),
+                  "glare_conv2d_upsample_gn_reduce")
+        else:
+            check(lib.glare_conv2d_gn_reduce(ptr(gn_part), ptr(stats), _i(B), _i(OH), _i(OW), _i(pc.cout), stream_handle()),
+                  "glare_conv2d_gn_reduce")
         out._gn_stats = stats  # consumed by groupnorm(); plain Python attribute, not a tensor property
     return out
 

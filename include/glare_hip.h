@@ -90,7 +90,11 @@ typedef struct glare_conv_desc {
   int res_pitch, res_off;
   int ksize;                 /* 1 or 3                                                             */
   int stride;                /* 1 (pad ksize/2) or 2 (3x3 only, pad (0,1,0,1))                     */
-  int upsample;              /* nearest x2 on the input first                                      */
+  int upsample;              /* 0: none; 1: nearest x2 on the input first (Upsample, encoder_decoder.py:43-52);   */
+                             /* 2: the same operator in SUB-PIXEL form (3x3, stride 1, bf16 NHWC out): four 2x2   */
+                             /* convs of the source, 16 instead of 36 tap-MACs per source pixel; weight_packed    */
+                             /* from glare_conv2d_pack_weight_upsample, gn_partial sized / reduced by the         */
+                             /* glare_conv2d_upsample_gn_* pair                                                   */
   int act;                   /* GLARE_ACT_*                                                        */
   int out_mode;              /* GLARE_OUT_*                                                        */
   long long plane_pitch;     /* planar modes: elements per plane (>= OH*OW); 0 = OH*OW             */
@@ -108,6 +112,10 @@ int glare_conv2d_pack_weight(const float* w_oihw, int cout, int cin_total, int k
  * cout_padded input and cin output channels (glare_conv2d_packed_weight_elems(cin, cout_padded, ksize) elements). */
 int glare_conv2d_pack_weight_dgrad(const float* w_oihw, int cout, int cin, int ksize, int cout_padded, void* packed_bf16,
                                    glare_stream_t stream);
+/* Sub-pixel filters of "nearest x2 upsample, then 3x3 conv": per output phase (row parity a, column parity b) the 3x3 taps
+ * that read the same source pixel are summed in fp32 and rounded to bf16 once (rows a=0: {0},{1,2}; a=1: {0,1},{2}). */
+long long glare_conv2d_upsample_packed_weight_elems(int cout, int cin_total);
+int glare_conv2d_pack_weight_upsample(const float* w_oihw, int cout, int cin_total, void* packed_bf16, glare_stream_t stream);
 int glare_conv2d_bf16(const glare_conv_desc* desc_host, glare_stream_t stream);
 /* Fused GroupNorm statistics: the conv epilogue leaves per-tile partial sums of its output; the reduce turns
  * them into the [B][1][32][2] (sum, sum of squares per group) block glare_groupnorm_apply_bf16 consumes, so the
@@ -115,6 +123,10 @@ int glare_conv2d_bf16(const glare_conv_desc* desc_host, glare_stream_t stream);
 long long glare_conv2d_gn_partial_elems(int B, int OH, int OW, int Cout);
 int glare_conv2d_gn_reduce(const float* gn_partial, float* stats_out, int B, int OH, int OW, int Cout,
                            glare_stream_t stream);
+/* The same pair for desc.upsample == 2 (partials laid out on the SOURCE grid H x W, four phases per tile). */
+long long glare_conv2d_upsample_gn_partial_elems(int B, int H, int W, int Cout);
+int glare_conv2d_upsample_gn_reduce(const float* gn_partial, float* stats_out, int B, int H, int W, int Cout,
+                                    glare_stream_t stream);
 
 /* Thin convolutions whose INPUT has <= 4 channels (conv_in 3->128 / 3->512, cond_conv 3->64 +
  * sigmoid, color_conv 3->3, quant_conv / post_quant_conv 1x1 3->3: encoder_decoder.py:355,467;

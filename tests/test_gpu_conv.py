@@ -89,6 +89,41 @@ def test_upsample_and_downsample_fusions():
         _check(out.permute(0, 3, 1, 2), ref)
 
 
+@pytest.mark.parametrize("B,C,Co,H,W", [(1, 64, 64, 9, 21), (2, 128, 128, 13, 45), (1, 256, 256, 8, 32), (1, 512, 512, 5, 33),
+                                        (1, 64, 40, 1, 1), (1, 32, 128, 17, 70)])
+def test_upsample_subpixel_form(B, C, Co, H, W):
+    """desc.upsample = 2: nearest x2 + 3x3 as four 2x2 convs of the source with pre-summed taps.  Checked against the
+    operator itself (fp32 weights; the regular path rounds each tap to bf16, this one rounds each tap SUM), against the
+    regular fused path, and with a residual + fused GroupNorm statistics on ragged tiles."""
+    g = torch.Generator().manual_seed(B * 100 + H)
+    x = _rand((B, C, H, W), g)
+    w = _rand((Co, C, 3, 3), g, 0.03)
+    b = _rand((Co,), g, 0.1)
+    xb = x.to(torch.bfloat16).float().cuda()
+    ref = F.conv2d(F.interpolate(xb, scale_factor=2.0, mode="nearest"), w.cuda(), b.cuda(), 1, 1)
+    pcs = ops.PackedConv(w.cuda(), b.cuda(), upsample_subpixel=True)
+    sub = ops.conv2d(_nhwc_bf16(x), pcs, upsample=True)
+    assert tuple(sub.shape) == (B, 2 * H, 2 * W, Co)
+    _check(sub.permute(0, 3, 1, 2), ref)
+    reg = ops.conv2d(_nhwc_bf16(x), ops.PackedConv(w.cuda(), b.cuda()), upsample=True)
+    d = (sub.float() - reg.float()).norm() / reg.float().norm()
+    assert float(d) < 6e-3, float(d)
+    # residual + activation through the same scatter (the LDS-staged epilogue rounds the conv result to bf16 before the
+    # residual add, so the element-wise bound of _check does not apply where the two cancel: compare in norm)
+    r = _rand((B, Co, 2 * H, 2 * W), g)
+    got = ops.conv2d(_nhwc_bf16(x), pcs, upsample=True, residual=_nhwc_bf16(r), act="relu").permute(0, 3, 1, 2).float()
+    want = F.relu(ref + r.to(torch.bfloat16).float().cuda())
+    assert float((got - want).norm() / want.norm()) < 4e-3
+    assert float((got - want).abs().max()) < 2.0 ** -7 * float(ref.abs().max() + r.abs().max())
+    if Co % 128 == 0:   # fused GroupNorm statistics: identical output, statistics equal to a fresh pass over it
+        y1 = ops.conv2d(_nhwc_bf16(x), pcs, upsample=True, gn_stats=True)
+        assert torch.equal(y1, sub)
+        gamma, beta = _rand((Co,), g, 0.5).cuda() + 1.0, _rand((Co,), g, 0.2).cuda()
+        n1 = ops.groupnorm(y1, gamma, beta, swish=True)
+        n2 = ops.groupnorm(sub, gamma, beta, swish=True)
+        assert torch.allclose(n1.float(), n2.float(), rtol=2 ** -7, atol=2e-3)
+
+
 def test_concat_pitch_offsets_and_planar_output():
     g = torch.Generator().manual_seed(7)
     a = _rand((1, 32, 12, 33), g)
