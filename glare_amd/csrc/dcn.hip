@@ -470,6 +470,16 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_fast_kernel(const DcnParam
       mfma_step(a_src, ks, bA);
       if (ks + 2 < KSN) load_b(s, ks + 2, bA);
       else if (more) load_b(s + 1, 0, bA);
+      // FULL wait, pinned: every vector-memory consumer of the loop (the weight fragments of this and the next k-step, the
+      // corners blended below, the plan triples) sits behind a vmcnt(0).  With the compiler's counted waits (vmcnt(3) /
+      // vmcnt(1) here, "all but the N youngest have landed") the kernel was NONDETERMINISTIC at 2 x 210x310 with scattered
+      // offsets (0.2 % of the pixels, quarter-wave groups, different on every run; -mllvm -amdgpu-waitcnt-forcezero cured
+      // it, so did this line; moving the next stage's prefetch later made it 40x worse): counted waits assume loads
+      // return in issue order, and between the scattered corner gathers and the dense weight loads that did not hold
+      // on this part.  Same speed (3.35 / 2.39 ms).
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
       mfma_step(a_src, ks + 1, bB);
     }
     if (more) gather_finish((s + 1) & 1, cs0);

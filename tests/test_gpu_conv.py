@@ -124,6 +124,22 @@ def test_upsample_subpixel_form(B, C, Co, H, W):
         assert torch.allclose(n1.float(), n2.float(), rtol=2 ** -7, atol=2e-3)
 
 
+def test_upsample_subpixel_full_size():
+    """The two decoder shapes at BASELINE size (256 ch 210x310 -> 420x620, 512 ch 105x155 -> 210x310): the sub-pixel form
+    agrees with the loader-fused form (each rounds different bf16 filters: tap sums vs taps) and commutes with a flip of the
+    image (a size-independent property: flipping rows swaps the roles of the two row phases)."""
+    g = torch.Generator().manual_seed(12)
+    for C, H, W in ((256, 210, 310), (512, 105, 155)):
+        x = (torch.randn(1, H, W, C, generator=g)).to(torch.bfloat16).cuda()
+        w = (torch.randn(C, C, 3, 3, generator=g) * 0.02).cuda()
+        b = (torch.randn(C, generator=g) * 0.1).cuda()
+        sub = ops.conv2d(x, ops.PackedConv(w, b, upsample_subpixel=True), upsample=True).float()
+        reg = ops.conv2d(x, ops.PackedConv(w, b), upsample=True).float()
+        assert float((sub - reg).norm() / reg.norm()) < 6e-3
+        subf = ops.conv2d(x.flip(1).contiguous(), ops.PackedConv(w.flip(2).contiguous(), b, upsample_subpixel=True), upsample=True).float()
+        assert float((subf.flip(1) - sub).norm() / sub.norm()) < 1e-6 + 2.0 ** -9   # same sums, other phase's code path
+
+
 def test_concat_pitch_offsets_and_planar_output():
     g = torch.Generator().manual_seed(7)
     a = _rand((1, 32, 12, 33), g)
