@@ -75,6 +75,21 @@ def test_nhwc_bf16_pipeline_entry():
     _close(got, ref)
 
 
+def test_nhwc_bf16_latent_size_against_c_oracle():
+    """The pipeline entry at the latent resolution (105 x 155, 254 workgroups in flight) with scattered samples against the
+    plain-C oracle: the small cases above fit in a handful of workgroups and cannot see a fault that depends on timing."""
+    x, off, m, w, b = _case(21, 1, 128, 105, 155, 128, 4, off_scale=3.0)
+    xb = x.to(torch.bfloat16)
+    plane = (105 * 155 + 63) // 64 * 64
+    om = torch.zeros(1, 108, plane)
+    om[:, :72, :105 * 155] = off.reshape(1, 72, -1)
+    om[:, 72:, :105 * 155] = m.reshape(1, 36, -1)
+    pd = ops.PackedDcn(w.cuda(), b.cuda(), 4)
+    got = ops.mdcn_forward_nhwc(xb.permute(0, 2, 3, 1).contiguous().cuda(), om.cuda(), pd, mask_is_logit=False)
+    ref = c_ref.dcn_forward(xb.float().numpy(), off.numpy(), m.numpy(), w.numpy(), b.numpy(), dg=4)
+    _close(got.permute(0, 3, 1, 2).cpu().numpy(), ref)
+
+
 def test_errors():
     x, off, m, w, b = _case(6, 1, 24, 4, 4, 64, 4)  # cpg = 6: unsupported, must say so (not crash)
     with pytest.raises(Exception, match="unsupported"):

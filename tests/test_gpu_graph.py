@@ -5,6 +5,8 @@ cannot hide in another's; an end-to-end run then reports the accumulated differe
 Tolerance: activations are bf16 between kernels (relative rounding 2^-9 per store) with fp32
 accumulation; over the ~100 layer deep random-weight stacks the relative L2 error of a stage output
 stays below 3e-2 (measured ~5e-3); codebook indices are bit-exact given identical latent input."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -185,6 +187,42 @@ def test_inference_driver_matches_oracle_psnr():
             out, _ = og(ov, O.preprocess(lows[i]))
         ref = O.psnr(gts[i] / 255, O.postprocess(out, h, gts[i]))
         assert abs(psnrs[i] - ref) <= 0.05, (i, psnrs[i], ref)
+
+
+def test_full_size_stage_parity_against_oracle():
+    """One 400 x 600 image (the BASELINE shape, 420 x 620 padded) through the CPU oracle once (~20-60 s), then every HIP stage
+    on the ORACLE's inputs for that stage: the kernels see their production launch shapes (attention N = 16275, full-resolution
+    convs and DCN warps, 254+ workgroups in flight), where a timing-dependent fault would show and the small fixtures cannot."""
+    torch.manual_seed(0)
+    og = seeded_init_(O.VQLLFLOWDeformable(per_sample_mean=True).eval(), 0)
+    ov = seeded_init_(O.VQModel().eval(), 1)
+    pg, pv = M.VQLLFLOWDeformable().eval(), M.VQModel().eval()
+    pg.load_state_dict(og.state_dict(), strict=True)
+    pv.load_state_dict(ov.state_dict(), strict=True)
+    pg.cuda()
+    pv.cuda()
+    lr = O.preprocess(synthetic_lowlight(1, 400, 600, seed=11)[0])
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    try:
+        with torch.no_grad():
+            ref = og.stages(ov, lr)
+    finally:
+        torch.set_num_threads(threads)
+    enc = pg.RRDB.forward_nhwc(lr.cuda())
+    assert rel(nchw(enc["cond_feat"]), ref["enc"]["cond_feat"]) < 3e-2
+    for a, b in zip(enc["mid_feat"], ref["enc"]["mid_feat"]):
+        assert rel(nchw(a), b) < 3e-2
+    z = pg.flowUpsamplerNet.decode_nhwc(nhwc(ref["enc"]["color_map"], bf16=False), nhwc(ref["enc"]["cond_feat"]))
+    assert rel(nchw(z), ref["latent"]) < 3e-2
+    idx, img, feats = pv.decode_nhwc(nhwc(ref["latent"], bf16=False), want_image=True)
+    assert torch.equal(idx.cpu(), ref["indices"])
+    for a, b in zip(feats, ref["code_feats"]):
+        assert rel(nchw(a), b) < 3e-2
+    assert rel(img.cpu(), ref["vq_rec"]) < 3e-2
+    out = pg.deformable_decoder.forward_nhwc(nhwc(ref["latent"], bf16=False), [nhwc(f) for f in ref["code_feats"]],
+                                             [nhwc(f) for f in ref["enc"]["mid_feat"]])
+    assert rel(out.cpu(), ref["out"]) < 3e-2
 
 
 def test_full_size_attention_and_dcn_properties():
