@@ -23,6 +23,8 @@
 //   out[p, co] = bias[co] + sum_{g,k,c} W[co, g*cpg+c, k] * mask[g,k,p] * bilinear(x[., g*cpg+c], pos(p,g,k))
 // Sampling semantics follow the reference exactly: a sample is 0 unless -1 < h < H and -1 < w < W,
 // and each of the 4 corners is dropped individually when it lies outside the image.
+#include <atomic>
+
 #include "common.h"
 
 namespace {
@@ -46,6 +48,7 @@ struct DcnParams {
   int opitch, ooff;
   long long out_plane;
   long long total_pix;
+  unsigned x_bytes, off_bytes, mask_bytes, wt_bytes;   // buffer-descriptor extents (fast path only; each < 2^31)
 };
 
 template <bool XBF16>
@@ -214,6 +217,314 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_kernel(const DcnParams p) 
   }
 }
 
+
+// ---- fast path: bf16 x, every tensor < 2 GB, kh*kw % 3 == 0 ----------------------------------------------------------
+// Same algorithm and arithmetic as dcn_fwd_kernel; what changes is the instruction and memory-request count around it.
+// Ablation of the generic kernel at 8 x 420x620x128 (tools/ablate.sh, DCN_ABL): 1.35 ms with no loads at all, and each of
+// the three load families (offset/mask triples, the 4 corners, the weight fragments) adds ~0.85 ms on top -- the cost is
+// per vector-memory instruction and per exposed latency, not per byte.  Hence:
+//   * every global access is a buffer load: 32-bit per-lane offsets computed once per item, the per-stage part (group,
+//     tap, k-step) in the scalar offset; a dropped corner is an out-of-range offset (the descriptor returns zeros), so
+//     the four corner loads are branch-free;
+//   * the sampling plan -- corner byte offsets, bilinear weights, modulation -- is computed ONCE per (pixel, tap) by one
+//     thread (coalesced 256-B loads of the offset / mask planes) and staged through LDS three taps ahead; the cpg/8 lanes
+//     that gather one pixel's channels read it back (2 x 16 B + 4 B) instead of each redoing the coordinate arithmetic
+//     and the sigmoid;
+//   * weight fragments are prefetched into registers one k-step ahead;
+//
+// NO PACKED FP32 IN THIS KERNEL (dcn.hip is compiled with -fno-slp-vectorize, build.py; tests/test_build_invariants.py greps
+// the ISA).  Written with v_pk_mul_f32 / v_pk_fma_f32 for the blend -- whose destinations the register allocator places on
+// the B-fragment registers the MFMAs issued a few instructions earlier are still reading -- the kernel was NOT deterministic
+// at the full-size shapes: 0.2 % (C = 128) to 12 % (C = 256) of the pixels, whole quarter-waves of the gather lanes,
+// differed from the general kernel and from launch to launch, while every small-image parity test passed.  Plain (unpacked)
+// VALU writes over the same registers at the same place are harmless, as they are in the general kernel.  What did NOT
+// matter: LDS barriers, counted vs full s_waitcnt, buffer vs global loads, scalar-offset operands, out-of-range loads; loads
+// of one wave do return in issue order (tools/probes/vmcnt_order_probe.hip).  The same blend in scalar fp32 is bit-stable
+// over every shape of tools/determinism_check.py and just as fast (the kernel is not VALU-bound enough to notice).
+#ifndef DCN_ABL
+#define DCN_ABL 0   // timing ablations only (tools/ablate.sh): 1 no weight loads, 2 no corner loads, 4 no MFMA, 8 no offset loads
+#endif
+template <int NT, int NCH, int MT>
+__global__ __launch_bounds__(DC_THREADS) void dcn_fwd_fast_kernel(const DcnParams p) {
+  constexpr int PIX = 64 * MT;
+  constexpr int ITEMS = PIX * NCH / DC_THREADS;
+  constexpr int KSN = NCH / 2;                      // 16-channel MFMA k-steps per stage
+  constexpr int CT = 3;                             // taps per staged sampling-plan chunk (K % 3 == 0 on this path)
+  constexpr int NPASS = (CT * PIX + DC_THREADS - 1) / DC_THREADS;
+  constexpr unsigned OOB = 0x80000000u;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  u32x4* colH = reinterpret_cast<u32x4*>(smem);                    // [2 buffers][hi|lo][NCH][PIX] 16-B chunks
+  // sampling plan, [2 buffers] x { corner offsets u32x4 [CT][PIX] | corner weights f32x4 [CT][PIX] | mask f32 [CT][PIX] }
+  constexpr int PLAN_BYTES = CT * PIX * 36;
+  char* plan = smem + (size_t)2 * 2 * NCH * PIX * 16;
+  const int K = p.kh * p.kw;
+  const int n_stages = p.dg * K, n_chunks = n_stages / CT;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const unsigned pix0 = blockIdx.x * (unsigned)PIX;
+  const unsigned total = (unsigned)p.total_pix;
+
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t offr =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.offset), 0, (int)p.off_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.mask), 0, (int)p.mask_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, (int)p.wt_bytes, 0x00020000);
+
+  // ---- sampling plan: one thread per (tap of the chunk, pixel) turns (offset_h, offset_w, mask) into the four corner
+  // byte offsets (out-of-range when the corner is dropped), the four bilinear weights and the modulation, ONCE per
+  // pixel and tap; the NCH lanes that gather the channels of that pixel read the plan back from LDS ----
+  const int spx = tid % PIX;
+  unsigned s_ovo, s_mvo, s_xvo;
+  float s_h0, s_w0;
+  bool s_ok;
+  {
+    const unsigned gp = pix0 + spx;
+    s_ok = gp < total;
+    const unsigned g2 = s_ok ? gp : 0u;
+    const unsigned wo = g2 % (unsigned)p.Wo, t = g2 / (unsigned)p.Wo;
+    const unsigned ho = t % (unsigned)p.Ho, b = t / (unsigned)p.Ho;
+    const unsigned pin = ho * p.Wo + wo;
+    s_ovo = (b * (unsigned)p.off_bstride + pin) * 4u;
+    s_mvo = (b * (unsigned)p.mask_bstride + pin) * 4u;
+    s_xvo = ((b * (unsigned)p.H * p.W) * p.xpitch + p.xoff) * 2u;
+    s_h0 = (float)((int)ho * p.sh - p.ph);
+    s_w0 = (float)((int)wo * p.sw - p.pw);
+  }
+  const unsigned px_b = (unsigned)p.xpitch * 2u, row_b = (unsigned)p.W * px_b;
+  float s_oh[NPASS], s_ow[NPASS], s_m[NPASS];
+  auto plan_load = [&](int c) {
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q) {
+      const int tl = __builtin_amdgcn_readfirstlane((tid + q * DC_THREADS) / PIX);   // tap within the chunk, wave-uniform
+      if (tl < CT) {
+        const int s = c * CT + tl, g = s / K, tap = s - g * K;
+#if DCN_ABL & 8
+        s_oh[q] = __uint_as_float((s_ovo + s) & 0x3f800000u); s_ow[q] = 0.5f * s_oh[q]; s_m[q] = 0.5f;
+#else
+        const unsigned so = (unsigned)((g * 2 * K + 2 * tap) * p.off_plane) * 4u;
+        s_oh[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(offr, s_ovo, so, 0));
+        s_ow[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(offr, s_ovo, so + (unsigned)p.off_plane * 4u, 0));
+        s_m[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(mr, s_mvo, (unsigned)((g * K + tap) * p.mask_plane) * 4u, 0));
+#endif
+      }
+    }
+  };
+  auto plan_write = [&](int c) {
+    char* dst = plan + (size_t)(c & 1) * PLAN_BYTES;
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q) {
+      const int tl = __builtin_amdgcn_readfirstlane((tid + q * DC_THREADS) / PIX);
+      if (tl < CT) {
+        const int s = c * CT + tl, tap = s % K;
+        const int ti = tap / p.kw, tj = tap - ti * p.kw;
+        const float h_im = (s_h0 + (float)(ti * p.dh)) + s_oh[q];
+        const float w_im = (s_w0 + (float)(tj * p.dw)) + s_ow[q];
+        const bool inside = s_ok && h_im > -1.f && w_im > -1.f && h_im < (float)p.H && w_im < (float)p.W;
+        const float hf = floorf(h_im), wf = floorf(w_im);
+        const int h_low = (int)hf, w_low = (int)wf;
+        const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+        const bool top = inside && h_low >= 0, bot = inside && h_low + 1 <= p.H - 1;
+        const bool lft = w_low >= 0, rgt = w_low + 1 <= p.W - 1;
+        const unsigned o1 = s_xvo + (unsigned)(h_low * p.W + w_low) * px_b;
+        u32x4 vo;
+        vo[0] = (top && lft) ? o1 : OOB;
+        vo[1] = (top && rgt) ? o1 + px_b : OOB;
+        vo[2] = (bot && lft) ? o1 + row_b : OOB;
+        vo[3] = (bot && rgt) ? o1 + row_b + px_b : OOB;
+        float m = s_m[q];
+        if (p.mask_is_logit) m = 1.0f / (1.0f + expf(-m));
+        const int e = tl * PIX + spx;
+        reinterpret_cast<u32x4*>(dst)[e] = vo;
+        reinterpret_cast<f32x4*>(dst + CT * PIX * 16)[e] = f32x4{hh * hw, hh * lw, lh * hw, lh * lw};
+        reinterpret_cast<float*>(dst + CT * PIX * 32)[e] = m;
+      }
+    }
+  };
+
+  // ---- gather items: (pixel, 8-channel chunk), chunk fastest so the lanes of one pixel read one contiguous run ----
+  int it_lds[ITEMS], it_px[ITEMS];
+  unsigned it_cb[ITEMS];
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const int id = tid + i * DC_THREADS;
+    const int ch = id % NCH, px = id / NCH;
+    it_lds[i] = ch * PIX + px;
+    it_px[i] = px;
+    it_cb[i] = ch * 16u;     // out-of-range offsets stay out of range: 2^31 + 16*ch + the group offset < 2^32
+  }
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
+
+  struct CornerSet {       // one stage's samples in flight: raw corners, bilinear weights, modulation
+    u32x4 cr[ITEMS][4];
+    f32x4 cw[ITEMS];
+    float cm[ITEMS];
+  };
+  CornerSet cs0;
+  auto gather_issue = [&](int s, CornerSet& cs) {
+    u32x4 (&cr)[ITEMS][4] = cs.cr;
+    f32x4 (&cw)[ITEMS] = cs.cw;
+    float (&cm)[ITEMS] = cs.cm;
+    const int c = s / CT, tl = s - c * CT;
+    const unsigned sx = (unsigned)((s / K) * p.cpg) * 2u;
+    const char* src = plan + (size_t)(c & 1) * PLAN_BYTES;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const int e = tl * PIX + it_px[i];
+      const u32x4 vo = reinterpret_cast<const u32x4*>(src)[e];
+      cw[i] = reinterpret_cast<const f32x4*>(src + CT * PIX * 16)[e];
+      cm[i] = reinterpret_cast<const float*>(src + CT * PIX * 32)[e];
+#if DCN_ABL & 2
+      cr[i][0] = u32x4{vo[0], sx, vo[1], vo[2]}; cr[i][1] = u32x4{vo[1], sx, vo[3], vo[2]};
+      cr[i][2] = u32x4{vo[2], sx, vo[0], vo[1]}; cr[i][3] = u32x4{vo[3], sx, vo[1], vo[0]};
+#else
+      cr[i][0] = __builtin_amdgcn_raw_buffer_load_b128(xr, vo[0] + it_cb[i], sx, 0);
+      cr[i][1] = __builtin_amdgcn_raw_buffer_load_b128(xr, vo[1] + it_cb[i], sx, 0);
+      cr[i][2] = __builtin_amdgcn_raw_buffer_load_b128(xr, vo[2] + it_cb[i], sx, 0);
+      cr[i][3] = __builtin_amdgcn_raw_buffer_load_b128(xr, vo[3] + it_cb[i], sx, 0);
+#endif
+    }
+  };
+  auto gather_finish = [&](int buf, const CornerSet& cs) {
+    const u32x4 (&cr)[ITEMS][4] = cs.cr;
+    const f32x4 (&cw)[ITEMS] = cs.cw;
+    const float (&cm)[ITEMS] = cs.cm;
+    u32x4* dst = colH + (size_t)buf * 2 * NCH * PIX;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const float m = cm[i];
+      u32x4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // reference order: (w1*v1 + w2*v2 + w3*v3 + w4*v4) * mask   (kernel.cu:493-496,625), on (even, odd) channel pairs.
+        // SCALAR fp32 on purpose, see the note on packed fp32 in the kernel's header comment.
+        float v0 = bflo(cr[i][0][e]) * cw[i][0], v1 = bfhi(cr[i][0][e]) * cw[i][0];
+        v0 = __builtin_fmaf(bflo(cr[i][1][e]), cw[i][1], v0); v1 = __builtin_fmaf(bfhi(cr[i][1][e]), cw[i][1], v1);
+        v0 = __builtin_fmaf(bflo(cr[i][2][e]), cw[i][2], v0); v1 = __builtin_fmaf(bfhi(cr[i][2][e]), cw[i][2], v1);
+        v0 = __builtin_fmaf(bflo(cr[i][3][e]), cw[i][3], v0); v1 = __builtin_fmaf(bfhi(cr[i][3][e]), cw[i][3], v1);
+        v0 *= m; v1 *= m;
+        asm volatile("" : "+v"(v0), "+v"(v1));   // keeps the pair out of the vectoriser's hands
+        hi[e] = pack_bf2(v0, v1);
+        float r0 = v0 - bflo(hi[e]), r1 = v1 - bfhi(hi[e]);
+        asm volatile("" : "+v"(r0), "+v"(r1));
+        lo[e] = pack_bf2(r0, r1);
+      }
+      dst[it_lds[i]] = hi;
+      dst[NCH * PIX + it_lds[i]] = lo;
+    }
+  };
+
+  // ---- weight fragments: [stage][c/8][Co][hi 16 B | lo 16 B], one (hi, lo) pair per (k-step, N tile) ----
+  const int khalf = lane >> 5;
+  const unsigned wvo = (unsigned)(khalf * p.Co + wn * NT * 32 + (lane & 31)) * 32u;
+  auto load_b = [&](int s, int ks, u32x4 (&dst)[NT][2]) {
+    const unsigned ws = (unsigned)((s * NCH + 2 * ks) * p.Co) * 32u;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#if DCN_ABL & 1
+      dst[j][0] = u32x4{wvo + j, ws, wvo, ws};
+      dst[j][1] = u32x4{wvo, ws + j, ws, wvo};
+#else
+      dst[j][0] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvo + j * 1024, ws, 0);
+      dst[j][1] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvo + j * 1024 + 16, ws, 0);
+#endif
+    }
+  };
+  auto mfma_step = [&](const u32x4* a_src, int ks, const u32x4 (&b)[NT][2]) {
+    const int kk = 2 * ks + khalf;
+    bf16x8 ah[MT], al[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      ah[m] = __builtin_bit_cast(bf16x8, a_src[kk * PIX + 32 * m]);
+      al[m] = __builtin_bit_cast(bf16x8, a_src[(NCH + kk) * PIX + 32 * m]);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const bf16x8 bh = __builtin_bit_cast(bf16x8, b[j][0]);
+      const bf16x8 bl = __builtin_bit_cast(bf16x8, b[j][1]);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+#if DCN_ABL & 4
+        acc[m][j][0] += (float)(al[m][0] + bh[0]) + (float)(ah[m][1] + bl[1]);
+#else
+        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh, acc[m][j], 0, 0, 0);
+        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl, acc[m][j], 0, 0, 0);
+        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh, acc[m][j], 0, 0, 0);
+#endif
+      }
+    }
+  };
+
+  u32x4 bA[NT][2], bB[NT][2];
+
+  // one stage: barrier; the gather of stage s+1 is issued; the MFMAs of stage s (the weight fragments of the next
+  // k-step always in flight); the samples of stage s+1 are blended into the other tile.  Measured and dropped: weight
+  // fragments a whole stage ahead (+32 VGPRs: 3.82 ms vs 3.38 ms at 8 x 420x620x128 -- occupancy 2 instead of 3) and
+  // the gather two stages ahead with a second corner set (3.81 ms, same reason): this kernel hides latency with waves.
+  auto stage_body = [&](int s) {
+    __syncthreads();                            // sample tile s (and any staged plan chunk) visible; tile s-1 retired
+    const bool more = s + 1 < n_stages;
+    const int c = s / CT, tl = s - c * CT;
+    if (more) gather_issue(s + 1, cs0);
+    if (tl == 0 && c + 1 < n_chunks) plan_load(c + 1);
+    const u32x4* a_src = colH + (size_t)(s & 1) * 2 * NCH * PIX + (lane & 31) + 32 * MT * wm;
+    // KSN is even: the k-steps alternate between the two register sets and every stage starts on bA
+#pragma unroll
+    for (int ks = 0; ks < KSN; ks += 2) {
+      load_b(s, ks + 1, bB);
+      mfma_step(a_src, ks, bA);
+      if (ks + 2 < KSN) load_b(s, ks + 2, bA);
+      else if (more) load_b(s + 1, 0, bA);
+      mfma_step(a_src, ks + 1, bB);
+    }
+    if (more) gather_finish((s + 1) & 1, cs0);
+    if (tl == CT - 2 && c + 1 < n_chunks) plan_write(c + 1);
+  };
+
+  plan_load(0);
+  plan_write(0);
+  load_b(0, 0, bA);
+  __syncthreads();
+  gather_issue(0, cs0);
+  gather_finish(0, cs0);
+  for (int s = 0; s < n_stages; ++s) stage_body(s);
+
+  // epilogue: C/D layout col = lane&31 (co), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel)
+  const unsigned hw = (unsigned)p.Ho * p.Wo;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const unsigned gp_t = pix0 + 32 * (MT * wm + m) + 4 * khalf;   // first row of this lane in the tile
+    const unsigned b_t = gp_t / hw, pin_t = gp_t % hw;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int co = (wn * NT + j) * 32 + (lane & 31);
+      const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned dr = (r & 3) + 8 * (r >> 2);
+        const unsigned gp = gp_t + dr;
+        if (gp < total) {
+          const float v = acc[m][j][r] + bv;
+          if (p.out_planar) {
+            unsigned b = b_t, pin = pin_t + dr;
+            while (pin >= hw) { pin -= hw; ++b; }
+            p.out[((size_t)b * p.Co + co) * p.out_plane + pin] = v;
+          } else {
+            p.out[(size_t)gp * p.opitch + p.ooff + co] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
 // [Co][C][kh][kw] fp32 (reference layout) -> split-bf16 B-fragment image
 // [stage = g*K + tap][c/8][Co][hi: 8 bf16 | lo: 8 bf16]  (same byte count as the fp32 filter)
 __global__ void dcn_pack_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ wt, int Co, int C, int K, int dg) {
@@ -248,6 +559,25 @@ int launch_dcn(const DcnParams& p, hipStream_t stream) {
   }
   DCN_CASE(1, 1) DCN_CASE(2, 1) DCN_CASE(4, 1) DCN_CASE(1, 2) DCN_CASE(2, 2) DCN_CASE(4, 2)
 #undef DCN_CASE
+  return GLARE_ERR_UNSUPPORTED;
+}
+
+std::atomic<int> g_force_generic{0};
+
+// MT = 1 everywhere: 128-pixel workgroups (MT = 2) halve the weight-fragment traffic but run at occupancy 2 and measured
+// 3.35 ms vs 3.32 ms (C = 128) and 2.95 ms vs 2.42 ms (C = 256) at 8 images -- the kernel needs the waves.
+int launch_dcn_fast(const DcnParams& p, hipStream_t stream) {
+  const int nt = p.Co / 64, nch = p.cpg / 8;
+  const int pix = 64;
+  const size_t lds = (size_t)2 * 2 * nch * pix * 16 + (size_t)2 * 3 * pix * 36;   // sample tiles + sampling plan
+  const unsigned blocks = (unsigned)((p.total_pix + pix - 1) / pix);
+#define DCN_FAST(NT_, NCH_)                                                                                  \
+  if (nt == NT_ && nch == NCH_) {                                                                            \
+    hipLaunchKernelGGL((dcn_fwd_fast_kernel<NT_, NCH_, 1>), dim3(blocks), dim3(DC_THREADS), lds, stream, p); \
+    return glare_launch_status();                                                                            \
+  }
+  DCN_FAST(1, 4) DCN_FAST(2, 4) DCN_FAST(4, 4) DCN_FAST(1, 8) DCN_FAST(2, 8) DCN_FAST(4, 8)
+#undef DCN_FAST
   return GLARE_ERR_UNSUPPORTED;
 }
 
@@ -302,7 +632,26 @@ extern "C" int glare_mdcn_forward_nhwc(const void* x, int x_is_bf16, int x_pitch
   p.out_plane = out_plane > 0 ? out_plane : (long long)p.Ho * p.Wo;
   if (!out_planar && out_off + Co > out_pitch) return GLARE_ERR_INVALID;
   p.total_pix = (long long)B * p.Ho * p.Wo;
+  // fast path: bf16 x and every extent addressable by a 31-bit buffer offset (the out-of-range sentinel is 2^31)
+  const long long LIM = 0x7fffffffLL;
+  const long long x_bytes = (long long)B * H * W * x_pitch * 2;
+  const long long off_bytes = ((long long)(B - 1) * p.off_bstride + (long long)dg * 2 * kh * kw * p.off_plane) * 4;
+  const long long mask_bytes = ((long long)(B - 1) * p.mask_bstride + (long long)dg * kh * kw * p.mask_plane) * 4;
+  const long long wt_bytes = (long long)Co * C * kh * kw * 4;
+  const bool generic_only = g_force_generic.load() != 0;
+  const int taps = kh * kw;
+  if (x_is_bf16 && !generic_only && taps % 3 == 0 && x_bytes < LIM && off_bytes < LIM && mask_bytes < LIM && wt_bytes < LIM &&
+      p.total_pix < LIM - 256) {
+    p.x_bytes = (unsigned)x_bytes; p.off_bytes = (unsigned)off_bytes; p.mask_bytes = (unsigned)mask_bytes;
+    p.wt_bytes = (unsigned)wt_bytes;
+    return launch_dcn_fast(p, (hipStream_t)stream);
+  }
+  p.x_bytes = p.off_bytes = p.mask_bytes = p.wt_bytes = 0;
   return x_is_bf16 ? launch_dcn<true>(p, (hipStream_t)stream) : launch_dcn<false>(p, (hipStream_t)stream);
+}
+
+extern "C" int glare_mdcn_force_generic(int on) {
+  return g_force_generic.exchange(on ? 1 : 0);
 }
 
 extern "C" size_t glare_mdcn_workspace_bytes(int B, int C, int H, int W, int Co, int kh, int kw) {

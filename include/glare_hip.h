@@ -234,6 +234,11 @@ int glare_mdcn_forward_nhwc(const void* x, int x_is_bf16, int x_pitch, int x_off
                             int out_off, long long out_plane, int B, int C, int H, int W, int Co, int kh, int kw, int sh,
                             int sw, int ph, int pw, int dh, int dw, int groups, int dg, glare_stream_t stream);
 
+/* glare_mdcn_forward_nhwc picks between two kernels with the same arithmetic: the general one (any extent, fp32 or bf16 x)
+ * and a leaner one for bf16 x when every tensor is < 2 GB and kh*kw % 3 == 0.  Test hook: on != 0 pins the general kernel
+ * process-wide (so a test can compare the two on the same input); returns the previous setting. */
+int glare_mdcn_force_generic(int on);
+
 /* ---- a10: modulated deformable convolution (DCNv2), backward ----------------------------------
  * Drop-in for the pybind function
  *   deform_conv_ext.modulated_deform_conv_backward(input, weight, bias, ones, offset, mask, columns,

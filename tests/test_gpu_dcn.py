@@ -75,6 +75,37 @@ def test_nhwc_bf16_pipeline_entry():
     _close(got, ref)
 
 
+@pytest.mark.parametrize("B,C,H,W,Co,off_scale", [(2, 128, 8, 10, 128, 0.3), (3, 128, 13, 21, 128, 4.0), (2, 256, 9, 11, 256, 1.5),
+                                                   (1, 128, 40, 60, 256, 1.0), (2, 128, 210, 310, 128, 3.0), (4, 256, 210, 310, 256, 1.0)])
+def test_fast_and_general_kernels_agree(B, C, H, W, Co, off_scale):
+    """The bf16 pipeline entry has two kernels with the same arithmetic (glare_hip.h, glare_mdcn_force_generic): the lean
+    one must reproduce the general one on ragged tiles, image boundaries inside a tile and out-of-image samples."""
+    import ctypes
+
+    from glare_amd import _lib
+
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    x = torch.randn(B, H, W, C, generator=g).to(torch.bfloat16).cuda()
+    plane = H * W + 16
+    om = torch.zeros(B, 108, plane)
+    om[:, :72, :H * W] = torch.randn(B, 72, H * W, generator=g) * off_scale
+    om[:, 72:, :H * W] = torch.randn(B, 36, H * W, generator=g)
+    om = om.cuda()
+    w = torch.randn(Co, C, 3, 3, generator=g) * 0.05
+    pd = ops.PackedDcn(w.cuda(), torch.randn(Co, generator=g).cuda(), 4)
+    lib = _lib.lib()
+    fast = ops.mdcn_forward_nhwc(x, om, pd).cpu().numpy()
+    for _ in range(3):   # run-to-run identical: the packed-fp32 version of this kernel was not (dcn.hip)
+        assert np.array_equal(ops.mdcn_forward_nhwc(x, om, pd).cpu().numpy(), fast)
+    prev = lib.glare_mdcn_force_generic(ctypes.c_int(1))
+    try:
+        general = ops.mdcn_forward_nhwc(x, om, pd).cpu().numpy()
+    finally:
+        lib.glare_mdcn_force_generic(ctypes.c_int(prev))
+    # same products in the same order per (pixel, tap); only the fp32 accumulation grouping inside the MFMA chain is shared
+    np.testing.assert_allclose(fast, general, rtol=0, atol=2e-5 * float(np.abs(general).max()))
+
+
 def test_nhwc_bf16_latent_size_against_c_oracle():
     """The pipeline entry at the latent resolution (105 x 155, 254 workgroups in flight) with scattered samples against the
     plain-C oracle: the small cases above fit in a handful of workgroups and cannot see a fault that depends on timing."""

@@ -1,12 +1,13 @@
 """Run-to-run determinism of the big kernels at production shapes: every launch is repeated and compared bit for bit
 (no kernel on the inference path uses atomics, so any difference is a hazard or a race)."""
+import ctypes
 import os
 import sys
 
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from glare_amd import ops  # noqa: E402
+from glare_amd import _lib, ops  # noqa: E402
 
 REPS = int(os.environ.get("DET_REPS", "6"))
 DEV = "cuda"
@@ -54,6 +55,9 @@ def main():
         om = torch.randn(B, 108, plane, generator=g).to(DEV)
         pd = ops.PackedDcn((torch.randn(c, c, 3, 3, generator=g) * 0.02).to(DEV), torch.zeros(c, device=DEV), 4)
         total += check("dcn forward C=%d %dx%d" % (c, h, w), lambda: ops.mdcn_forward_nhwc(x, om, pd))
+        _lib.lib().glare_mdcn_force_generic(ctypes.c_int(1))
+        total += check("dcn forward (general kernel) C=%d" % c, lambda: ops.mdcn_forward_nhwc(x, om, pd))
+        _lib.lib().glare_mdcn_force_generic(ctypes.c_int(0))
     x = torch.randn(B, 420, 620, 128, generator=g).to(torch.bfloat16).to(DEV)
     gm, bt = torch.ones(128, device=DEV), torch.zeros(128, device=DEV)
     total += check("groupnorm 128 420x620", lambda: ops.groupnorm(x, gm, bt))
