@@ -17,7 +17,7 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-
           "-fno-gpu-rdc"] + os.environ.get("GLARE_DEFS", "").split()  # GLARE_DEFS: ablation switches (tools/)
 # vq.hip carries the bit-exactness contract: no fused contraction the source does not spell.
 # dcn.hip: no compiler-formed packed-fp32 (v_pk_*_f32) ops next to its MFMAs -- see the note in dcn_fwd_fast_kernel.
-PER_FILE = {"vq.hip": ["-ffp-contract=off"], "dcn.hip": ["-fno-slp-vectorize"]}
+PER_FILE = {"vq.hip": ["-ffp-contract=off"], "dcn.hip": ["-fno-slp-vectorize"], "dcn_bwd.hip": ["-fno-slp-vectorize"]}
 
 
 def _newer(a, b):
