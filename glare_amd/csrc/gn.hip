@@ -17,8 +17,12 @@ constexpr int GN_THREADS = 256;
 constexpr int GN_GROUPS = 32;
 
 // partial layout: [B][splits][32][2] fp32
+// ADD: y = x + addend (dense, pitch C) is formed, rounded to bf16, stored to `sum_out`, and the statistics are those of y --
+// the residual add that is left of AttnBlock once proj_out is folded into v, fused with the next norm's statistics pass.
+template <bool ADD>
 __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ partial,
-                                                              long long HW, int C, int pitch, int off, int splits) {
+                                                              long long HW, int C, int pitch, int off, int splits,
+                                                              const bf16_t* __restrict__ addend, bf16_t* __restrict__ sum_out) {
   // deterministic block reduction (no float atomics: the statistics, and everything downstream, must not depend on
   // the order in which waves happen to arrive): per-thread sums -> per-channel sums -> per-group sums, fixed order
   __shared__ float vals[GN_THREADS][17];
@@ -34,6 +38,8 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16_t* __re
   for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
   {
     const bf16_t* base = x + (size_t)b * HW * pitch + off + chunk * 8;
+    const bf16_t* abase = ADD ? addend + (size_t)b * HW * C + chunk * 8 : nullptr;
+    bf16_t* obase = ADD ? sum_out + (size_t)b * HW * C + chunk * 8 : nullptr;
     auto accum = [&](const u32x4& v) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -43,14 +49,31 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16_t* __re
       }
     };
     long long p = p0 + pl;
-    for (; p + 3LL * ppi < p1; p += 4LL * ppi) {  // 4 independent 16-B loads in flight per lane
-      const u32x4 v0 = *reinterpret_cast<const u32x4*>(base + (size_t)p * pitch);
-      const u32x4 v1 = *reinterpret_cast<const u32x4*>(base + (size_t)(p + ppi) * pitch);
-      const u32x4 v2 = *reinterpret_cast<const u32x4*>(base + (size_t)(p + 2LL * ppi) * pitch);
-      const u32x4 v3 = *reinterpret_cast<const u32x4*>(base + (size_t)(p + 3LL * ppi) * pitch);
-      accum(v0); accum(v1); accum(v2); accum(v3);
+    if (ADD) {
+      auto add_store = [&](long long q) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(base + (size_t)q * pitch);
+        const u32x4 c = *reinterpret_cast<const u32x4*>(abase + (size_t)q * C);
+        u32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = pack_bf2(bflo(a[e]) + bflo(c[e]), bfhi(a[e]) + bfhi(c[e]));
+        *reinterpret_cast<u32x4*>(obase + (size_t)q * C) = y;
+        return y;
+      };
+      for (; p + ppi < p1; p += 2LL * ppi) {
+        const u32x4 y0 = add_store(p), y1 = add_store(p + ppi);
+        accum(y0); accum(y1);
+      }
+      for (; p < p1; p += ppi) accum(add_store(p));
+    } else {
+      for (; p + 3LL * ppi < p1; p += 4LL * ppi) {  // 4 independent 16-B loads in flight per lane
+        const u32x4 v0 = *reinterpret_cast<const u32x4*>(base + (size_t)p * pitch);
+        const u32x4 v1 = *reinterpret_cast<const u32x4*>(base + (size_t)(p + ppi) * pitch);
+        const u32x4 v2 = *reinterpret_cast<const u32x4*>(base + (size_t)(p + 2LL * ppi) * pitch);
+        const u32x4 v3 = *reinterpret_cast<const u32x4*>(base + (size_t)(p + 3LL * ppi) * pitch);
+        accum(v0); accum(v1); accum(v2); accum(v3);
+      }
+      for (; p < p1; p += ppi) accum(*reinterpret_cast<const u32x4*>(base + (size_t)p * pitch));
     }
-    for (; p < p1; p += ppi) accum(*reinterpret_cast<const u32x4*>(base + (size_t)p * pitch));
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) { vals[threadIdx.x][e] = s[e]; vals[threadIdx.x][8 + e] = q[e]; }
@@ -163,12 +186,23 @@ extern "C" int glare_groupnorm_swish_bf16(const void* x, int in_pitch, int in_of
   if (!workspace || workspace_bytes < glare_groupnorm_workspace_bytes(B, HW)) return GLARE_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
   const int splits = gn_splits(HW);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(splits, B), dim3(GN_THREADS), 0, stream, (const bf16_t*)x, (float*)workspace,
-                     HW, C, in_pitch, in_off, splits);
+  hipLaunchKernelGGL(gn_stats_kernel<false>, dim3(splits, B), dim3(GN_THREADS), 0, stream, (const bf16_t*)x, (float*)workspace,
+                     HW, C, in_pitch, in_off, splits, (const bf16_t*)nullptr, (bf16_t*)nullptr);
   int bpi = (int)((HW * (C / 8) + 16 * GN_THREADS - 1) / (16 * GN_THREADS));  // ~16 chunks per thread
   if (bpi < 1) bpi = 1;
   hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)(bpi * B)), dim3(GN_THREADS), 0, stream, (const bf16_t*)x,
                      (const float*)workspace, gamma, beta, (bf16_t*)y, HW, C, in_pitch, in_off, splits, eps, swish, bpi);
+  return glare_launch_status();
+}
+
+extern "C" int glare_add_groupnorm_stats_bf16(const void* a, const void* b, void* out, int B, long long HW, int C, void* stats,
+                                              size_t stats_bytes, glare_stream_t stream_) {
+  if (!a || !b || !out || !stats || B <= 0 || HW <= 0 || C <= 0) return GLARE_ERR_INVALID;
+  if (C % 32 || C > 2048 || (GN_THREADS % (C / 8))) return GLARE_ERR_UNSUPPORTED;
+  if (stats_bytes < glare_groupnorm_workspace_bytes(B, HW)) return GLARE_ERR_WORKSPACE;
+  const int splits = gn_splits(HW);
+  hipLaunchKernelGGL(gn_stats_kernel<true>, dim3(splits, B), dim3(GN_THREADS), 0, (hipStream_t)stream_, (const bf16_t*)a,
+                     (float*)stats, HW, C, C, 0, splits, (const bf16_t*)b, (bf16_t*)out);
   return glare_launch_status();
 }
 

@@ -36,6 +36,7 @@ def conv_t(x, conv, **kw):
 
 
 SUBPIXEL_UPSAMPLE = True
+FOLD_PROJ_INTO_V = True
 
 
 class Upsample(HipModule):
@@ -131,12 +132,24 @@ class AttnBlock(HipModule):
         b = torch.cat([self.q.bias * s, self.k.bias], 0)
         return ops.PackedConv(w, b)
 
+    def _v_proj(self):
+        wp, wv = self.proj_out.weight[:, :, 0, 0].double(), self.v.weight[:, :, 0, 0].double()
+        w = (wp @ wv).float()[:, :, None, None].contiguous()
+        b = (wp @ self.v.bias.double() + self.proj_out.bias.double()).float()
+        return ops.PackedConv(w, b)
+
     def forward_nhwc(self, x):
         B, H, W, C = x.shape
         N = H * W
         hn = gn_swish(x, self.norm, swish=False)
         qk = ops.conv2d(hn, self._packed("qk", self._qk))                       # [B,H,W,1024]: q | k
         npad = (N + 63) // 64 * 64
+        if FOLD_PROJ_INTO_V:
+            # proj_out(softmax(S) V) = softmax(S) (Wp Wv h + Wp bv) + bp because every softmax row sums to 1: the output
+            # projection is folded into the value projection (one 1x1 conv less per block), what remains of proj_out is "+ x"
+            vt = ops.conv2d(hn, self._packed("v_proj", self._v_proj), out_mode=ops.OUT_PLANAR_BF16, plane_pitch=npad)
+            o = ops.attention_d512(qk, qk[..., C:], vt, N, ldq=2 * C, ldk=2 * C)
+            return ops.add_bf16(x, o.view(B, H, W, C), gn_stats=GN_FUSED)   # + the next norm's statistics
         vt = ops.conv2d(hn, packed_conv(self, self.v), out_mode=ops.OUT_PLANAR_BF16, plane_pitch=npad)  # V^T [B,512,npad]
         o = ops.attention_d512(qk, qk[..., C:], vt, N, ldq=2 * C, ldk=2 * C)     # [B,N,512]
         return ops.conv2d(o.view(B, H, W, C), packed_conv(self, self.proj_out), residual=x, gn_stats=GN_FUSED)

@@ -191,7 +191,7 @@ def groupnorm(x, gamma, beta, swish=True, eps=1e-6, cin=None, in_off=0):
     if stats is not None and in_off == 0 and C == pitch:
         y = torch.empty(B, H, W, C, dtype=torch.bfloat16, device=x.device)
         check(lib.glare_groupnorm_apply_bf16(ptr(x), _i(pitch), _i(0), ptr(gamma), ptr(beta), ptr(y), _i(B), _ll(H * W), _i(C),
-                                             _f(eps), _i(int(swish)), ptr(stats), _i(1), stream_handle()),
+                                             _f(eps), _i(int(swish)), ptr(stats), _i(int(stats.shape[1])), stream_handle()),
               "glare_groupnorm_apply_bf16")
         return y
     lib.glare_groupnorm_workspace_bytes.restype = _sz
@@ -330,6 +330,27 @@ def _attention_d512(q, k, v_t, N, ldq, ldk, out, key_splits):
     check(_lib.lib().glare_attention_d512_bf16(ptr(q), _i(ldq), ptr(k), _i(ldk), ptr(v_t), _ll(v_t.shape[2]), ptr(out),
                                                _i(out.shape[-1]), _i(B), _i(N), stream_handle()),
           "glare_attention_d512_bf16")
+    return out
+
+
+def add_bf16(a, b, out=None, gn_stats=False):
+    """out = a + b on bf16 NHWC tensors of one shape (the residual add left of AttnBlock's folded output projection); with
+    gn_stats the GroupNorm statistics of the sum ride along (consumed by groupnorm(), which then only runs its apply pass)."""
+    require_cuda(a, b, out)
+    assert a.dtype == b.dtype == torch.bfloat16 and a.shape == b.shape and a.is_contiguous() and b.is_contiguous()
+    if out is None:
+        out = torch.empty_like(a)
+    lib = _lib.lib()
+    if gn_stats:
+        B, H, W, C = a.shape
+        lib.glare_groupnorm_workspace_bytes.restype = _sz
+        nb = lib.glare_groupnorm_workspace_bytes(_i(B), _ll(H * W))
+        stats = torch.empty(B, nb // (B * 256), 32, 2, dtype=torch.float32, device=a.device)
+        check(lib.glare_add_groupnorm_stats_bf16(ptr(a), ptr(b), ptr(out), _i(B), _ll(H * W), _i(C), ptr(stats), _sz(nb),
+                                                 stream_handle()), "glare_add_groupnorm_stats_bf16")
+        out._gn_stats = stats
+        return out
+    check(lib.glare_add_bf16(ptr(a), ptr(b), None, ptr(out), _ll(a.numel()), stream_handle()), "glare_add_bf16")
     return out
 
 

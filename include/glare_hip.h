@@ -144,6 +144,12 @@ int glare_conv2d_smallcin_f32(const float* x, long long stride_b, long long stri
  * C % 32 == 0, C <= 2048.  workspace: glare_groupnorm_workspace_bytes(B, HW) bytes of scratch. */
 size_t glare_groupnorm_workspace_bytes(int B, long long HW);
 /* apply only, with statistics already available as `splits` partial blocks [B][splits][32][2] */
+/* out = a + b (bf16, dense [B][HW][C]) together with the GroupNorm statistics of `out`: stats receives
+ * glare_groupnorm_workspace_bytes(B, HW) bytes = [B][splits][32][2] partial sums for glare_groupnorm_apply_bf16(..., stats,
+ * splits) with splits = that size / (B * 256).  The residual add of AttnBlock (encoder_decoder.py:188: x + proj_out(h)) once
+ * proj_out has been folded into v, fused with the statistics pass of the norm that consumes the block's output. */
+int glare_add_groupnorm_stats_bf16(const void* a, const void* b, void* out, int B, long long HW, int C, void* stats,
+                                   size_t stats_bytes, glare_stream_t stream);
 int glare_groupnorm_apply_bf16(const void* x, int in_pitch, int in_off, const float* gamma, const float* beta, void* y,
                                int B, long long HW, int C, float eps, int swish, const float* stats, int splits,
                                glare_stream_t stream);

@@ -167,6 +167,22 @@ def test_attention_key_split_heuristic():
     assert ops.attention_key_splits(1, 40) == 2      # never more splits than key tiles
 
 
+@pytest.mark.parametrize("B,C,H,W", [(2, 512, 13, 21), (1, 512, 105, 155), (3, 128, 7, 5)])
+def test_add_with_fused_groupnorm_statistics(B, C, H, W):
+    """glare_add_groupnorm_stats_bf16: the sum is the bf16 sum, and the norm that consumes it gives the same result from the
+    fused statistics (apply pass only) as from its own statistics pass."""
+    g = torch.Generator().manual_seed(C + H)
+    a = torch.randn(B, H, W, C, generator=g).to(torch.bfloat16).cuda()
+    b = (torch.randn(B, H, W, C, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    y = ops.add_bf16(a, b, gn_stats=True)
+    assert torch.equal(y, (a.float() + b.float()).to(torch.bfloat16))
+    assert torch.equal(y, ops.add_bf16(a, b))
+    gamma, beta = (torch.randn(C, generator=g) * 0.3 + 1.0).cuda(), (torch.randn(C, generator=g) * 0.2).cuda()
+    n1 = ops.groupnorm(y, gamma, beta, swish=False)
+    n2 = ops.groupnorm(y.clone(), gamma, beta, swish=False)       # no statistics attached: stats + apply
+    assert torch.allclose(n1.float(), n2.float(), rtol=2 ** -7, atol=2e-3)
+
+
 def test_groupnorm_and_attention_randomised_sizes():
     """Seeded sweeps: GroupNorm(+swish) forward AND backward over tiny / odd spatial sizes and every channel width on the path;
     attention over token counts that are not multiples of the 32-key tile or the 128-row query block."""
