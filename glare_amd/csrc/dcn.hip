@@ -88,7 +88,13 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_kernel(const DcnParams p) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int nch = cpg >> 3;  // 8-channel chunks per group
-  const long long pix0 = (long long)blockIdx.x * DC_PIX;
+  // XCD-aware tile order (see dcn_fwd_fast_kernel): XCD j takes the j-th contiguous eighth of the pixel tiles
+  unsigned tile = blockIdx.x;
+  {
+    const unsigned n = gridDim.x, q = n / 8, r = n % 8, xcd = tile % 8, k = tile / 8;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const long long pix0 = (long long)tile * DC_PIX;
 
   // this thread's items: (pixel, chunk), pixel-major over chunks so 8-channel neighbours are lanes
   int it_px[ITEMS], it_ch[ITEMS];
@@ -262,7 +268,14 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_fast_kernel(const DcnParam
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const unsigned pix0 = blockIdx.x * (unsigned)PIX;
+  // XCD-aware order: workgroups are dispatched round-robin over the 8 XCDs, so XCD j takes the j-th contiguous eighth of the
+  // pixel tiles -- vertically adjacent tiles (which gather from the same rows of x) then share one L2 instead of eight
+  unsigned tile = blockIdx.x;
+  {
+    const unsigned n = gridDim.x, q = n / 8, r = n % 8, xcd = tile % 8, k = tile / 8;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const unsigned pix0 = tile * (unsigned)PIX;
   const unsigned total = (unsigned)p.total_pix;
 
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
