@@ -151,7 +151,14 @@ __global__ __launch_bounds__(DB_THREADS) void dcn_bwd_data_kernel(const DcnBwdPa
   const int cpg = p.cpg, K = p.kh * p.kw, n_stages = p.dg * K;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const long long pix0 = (long long)blockIdx.x * DB_PIX;
+  // XCD-aware tile order (dcn.hip): XCD j takes the j-th contiguous eighth of the pixel tiles, so the rows a tile gathers from
+  // and scatters to stay in one L2
+  unsigned tile = blockIdx.x;
+  {
+    const unsigned n = gridDim.x, q = n / 8, r = n % 8, xcd = tile % 8, k = tile / 8;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const long long pix0 = (long long)tile * DB_PIX;
   const long long hw_out = (long long)p.Ho * p.Wo;
 
   // gO tile -> LDS, transposed [co][pixel] (each plane row of 64 pixels is contiguous in HBM)
