@@ -362,7 +362,11 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_fast_kernel(const DcnParam
   for (int i = 0; i < ITEMS; ++i) {
     const int id = tid + i * DC_THREADS;
     const int ch = id % NCH, px = id / NCH;
-    it_lds[i] = ch * PIX + px;
+    // tile layout [c/8][pixel] in 16-B chunks, pixel index XOR-swizzled by the chunk: the NCH lanes of one pixel write chunks that
+    // are a multiple of 1 KB apart -- the same banks, an NCH-way conflict on every tile write (SQ_LDS_BANK_CONFLICT was 50-70 %
+    // of the LDS-active cycles); with px ^ (ch * 16 / NCH) the 16 lanes of a write phase cover 16 different bank groups, and
+    // the MFMA fragment read of chunk kk (32 consecutive rows) stays a permutation inside each 16-row block
+    it_lds[i] = ch * PIX + (px ^ (ch * (16 / NCH)));
     it_px[i] = px;
     it_cb[i] = ch * 16u;     // out-of-range offsets stay out of range: 2^31 + 16*ch + the group offset < 2^32
   }
@@ -455,8 +459,9 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_fast_kernel(const DcnParam
     bf16x8 ah[MT], al[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      ah[m] = __builtin_bit_cast(bf16x8, a_src[kk * PIX + 32 * m]);
-      al[m] = __builtin_bit_cast(bf16x8, a_src[(NCH + kk) * PIX + 32 * m]);
+      const int sw = ((lane & 31) ^ (kk * (16 / NCH))) - (lane & 31);   // swizzled row of this lane, relative to a_src
+      ah[m] = __builtin_bit_cast(bf16x8, a_src[kk * PIX + 32 * m + sw]);
+      al[m] = __builtin_bit_cast(bf16x8, a_src[(NCH + kk) * PIX + 32 * m + sw]);
     }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
