@@ -71,7 +71,7 @@ def run(n_images, batch=8, h=400, w=600, seed=1234, root=None, net_g=None, net_v
     psnr_slice(0, min(batch, n_images))                           # warm-up: weight packing, workspace growth
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    local = parallel.run_sharded(n_images, psnr_slice, rank, world, batch=batch)
+    local = parallel.run_sharded(n_images, psnr_slice, rank, world, batch=batch, streams=2)
     if local is None:
         local = torch.zeros(0, 1, dtype=torch.float64, device=device)
     torch.cuda.synchronize()
