@@ -134,9 +134,11 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
-    ap.add_argument("--streams", type=int, default=2,
-                    help="HIP streams the steps are issued on round-robin (2: consecutive batches overlap, the tail of one "
-                         "step's kernels and its latency-bound flow section run under the next step's convs; 1: serial)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams the steps are issued on round-robin.  1 (default): steps run back to back and the "
+                         "roofline's per-launch event timing is the kernel's own duration.  2: consecutive batches overlap (the "
+                         "tail of one step's kernels and its latency-bound flow section run under the next step's convs): +3 %% "
+                         "throughput, but a launch then shares the GPU and its event-timed duration is no longer a kernel figure")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="per-stage timing on stderr")
     args = ap.parse_args()
