@@ -247,3 +247,31 @@ def test_conv_randomised_shapes_and_fusions():
         except Exception as e:
             raise AssertionError("case %d: B%d %dx%d k%d s%d ups%d cin%d+%d@%d cout%d act=%s res=%d mode=%d: %s"
                                  % (case, B, H, W, k, stride, ups, cin, cin2, pad_l, cout, act, res, mode, e))
+
+
+def test_error_behaviour_of_the_new_entry_points():
+    """Status codes instead of crashes: CPU tensors are refused before any launch, a sub-pixel filter cannot serve a plain
+    conv, the sub-pixel form exists for stride 1 only, and the fused add refuses shapes its statistics pass cannot tile."""
+    import ctypes
+
+    from glare_amd import _lib
+
+    w = torch.randn(64, 64, 3, 3) * 0.02
+    x = torch.randn(1, 6, 7, 64).to(torch.bfloat16)
+    with pytest.raises(NotImplementedError):
+        ops.conv2d(x, ops.PackedConv(w.cuda(), None, upsample_subpixel=True), upsample=True)      # CPU activation
+    pcs = ops.PackedConv(w.cuda(), None, upsample_subpixel=True)
+    with pytest.raises(AssertionError):
+        ops.conv2d(x.cuda(), pcs)                                                                   # sub-pixel filter, no upsample
+    with pytest.raises(_lib.GlareError, match="unsupported"):
+        ops.conv2d(x.cuda(), pcs, upsample=True, stride=2)
+    with pytest.raises(_lib.GlareError, match="unsupported"):
+        ops.conv2d(x.cuda(), pcs, upsample=True, out_mode=ops.OUT_NHWC_F32)                         # scatter lives in the bf16 epilogue
+    a = torch.randn(1, 4, 4, 24).to(torch.bfloat16).cuda()                                          # 24 channels: not 32 groups
+    with pytest.raises(_lib.GlareError, match="unsupported"):
+        ops.add_bf16(a, a, gn_stats=True)
+    lib = _lib.lib()
+    lib.glare_conv2d_upsample_packed_weight_elems.restype = ctypes.c_longlong
+    assert lib.glare_conv2d_upsample_packed_weight_elems(ctypes.c_int(0), ctypes.c_int(64)) < 0
+    assert lib.glare_add_groupnorm_stats_bf16(None, None, None, ctypes.c_int(1), ctypes.c_longlong(16), ctypes.c_int(64), None,
+                                              ctypes.c_size_t(0), None) != 0
