@@ -8,7 +8,9 @@ One "step" = one pass of the full hot path (conditional encoder -> flow reverse 
 -> VQGAN decoder -> DCNv2 AFT decoder) over one batch of 8 synthetic 400x600 low-light images per GPU
 (BASELINE configs[1]: "LOL eval15 batch=8 bf16 inference on 1 MI355X"); inputs are resident in HBM when
 the timed region starts.  Images are independent, so N GPUs shard the batch with no data-path
-collective (weak scaling: 8 images per GPU); the only collectives are the timing barrier / max.
+collective (weak scaling: 8 images per GPU); at N > 1 every step ends with the one exchange the inference
+path has -- the RCCL gather of the enhanced images to rank 0 (BASELINE configs[2]) -- plus the timing
+barrier / max.  Started as a plain process with --gpus N > 1, bench.py launches the N ranks itself.
 Rank 0 prints ONE JSON line, including
   roofline     -- the dominant kernel (d=512 blockwise attention) measured live with events on the
                   launch stream, against the dense bf16 MFMA peak;
@@ -143,10 +145,19 @@ def main():
     ap.add_argument("--breakdown", action="store_true", help="per-stage timing on stderr")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as a plain process (`python bench.py --gpus N`): start the N ranks ourselves, one per GPU over RCCL;
+        # rank 0 of that job prints the JSON line.  Under torch.distributed.run (WORLD_SIZE set) this is skipped.
+        from glare_amd import parallel
+
+        sys.exit(parallel.launch_ranks(os.path.abspath(__file__), args.gpus, sys.argv[1:]))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the HIP kernels are the only implementation)"
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d: launch one rank per GPU (or let bench.py do it)" % (args.gpus, world)
+    assert torch.cuda.device_count() > local_rank, "rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -155,17 +166,34 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)  # RCCL on ROCm
+        assert dist.get_world_size() == args.gpus and dist.get_backend() == "nccl"
 
     netG, net_vq = build_nets(device)
     lr = build_inputs(args.batch, device, seed=1234 + rank)  # every rank enhances different images
 
     streams = [torch.cuda.Stream(device) for _ in range(args.streams)] if args.streams > 1 else None
 
+    gatherer = None
+    if world > 1:
+        # BASELINE configs[2] ("data-parallel across 8 MI355X, RCCL gather only"): every step each rank crops / clamps its
+        # enhanced batch on the device (harness.hip) and the [B,400,600,3] results are gathered to rank 0 over RCCL --
+        # the one exchange of the inference path (no data-path collective).  N = 1 has nothing to gather.
+        from glare_amd import harness, parallel
+
+        gatherer = parallel.RankGather(torch.empty(args.batch, H_IMG, W_IMG, 3, device=device), rank, world)
+
+    def enhance():
+        out = netG.reverse_flow_nhwc(net_vq, lr)["out"]
+        if gatherer is not None:
+            restored, _ = harness.postprocess_device(out, H_IMG, W_IMG)
+            gatherer.gather(restored)
+        return out
+
     def step(i=0):
         if streams is None:
-            return netG.reverse_flow_nhwc(net_vq, lr)["out"]
+            return enhance()
         with torch.cuda.stream(streams[i % len(streams)]):   # every op launches on torch's current stream
-            return netG.reverse_flow_nhwc(net_vq, lr)["out"]
+            return enhance()
 
     with torch.no_grad():
         out = step()                                          # weights are packed once, on first use
@@ -208,6 +236,8 @@ def main():
                                    "(BASELINE configs[1])", "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "input": "3x400x600 (reflect-padded to 420x620)", "parallelism": "dp%d" % world,
                        "streams_per_gpu": args.streams,
+                       "exchange": "none (1 GPU)" if world == 1 else "per step: crop/clamp on device + RCCL gather of the "
+                                   "enhanced [B,400,600,3] fp32 batches to rank 0 (inside the timed region)",
                        "weights": "random, name-seeded (no checkpoints offline)"},
             "roofline": attention_roofline(device, args.batch, live_events),
         }

@@ -4,6 +4,9 @@ final gather of per-image results to rank 0 over RCCL (`torch.distributed`, back
 "gloo" in the CPU tests).  Replaces the reference's single-process nn.DataParallel
 (code/models/VQLLFLOWD_model.py:72-75), which replicates weights and gathers outputs every iteration."""
 import os
+import socket
+import subprocess
+import sys
 
 import torch
 import torch.distributed as dist
@@ -28,6 +31,51 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend or ("nccl" if use_cuda else "gloo"), rank=rank, world_size=world)
     return rank, world, device
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def rank_launch_command(script, n_ranks, argv, port=None, module=False):
+    """The `torch.distributed.run` command line that starts `script argv...` as n_ranks processes of ONE node, one per GPU
+    (rendezvous on 127.0.0.1: the container hostname may not resolve)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(n_ranks)),
+           "--master-addr", "127.0.0.1", "--master-port", str(port or free_port())]
+    if module:
+        cmd.append("-m")
+    return cmd + [script] + list(argv)
+
+
+def launch_ranks(script, n_ranks, argv, env=None, **popen_kw):
+    """Self-launch used by `bench.py --gpus N` when it is started as a plain process (no WORLD_SIZE in the environment):
+    re-executes the script under torch.distributed.run with n_ranks ranks, passes its stdout/stderr through and returns
+    its exit code.  Rank 0 of the child job prints the result line."""
+    e = dict(os.environ if env is None else env)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what the host driver supports for RCCL between processes
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        e.pop(k, None)
+    return subprocess.run(rank_launch_command(script, n_ranks, argv), env=e, **popen_kw).returncode
+
+
+class RankGather:
+    """Per-step gather of equal-sized per-rank results to rank 0 with buffers allocated ONCE (the inference exchange of
+    BASELINE configs[2]: "RCCL gather only").  `gather(t)` enqueues on the current stream; rank 0's `bufs` then hold every
+    rank's tensor in rank order."""
+
+    def __init__(self, like, rank, world, dst=0):
+        self.rank, self.world, self.dst = rank, world, dst
+        self.bufs = [torch.empty_like(like) for _ in range(world)] if (world > 1 and rank == dst) else None
+
+    def gather(self, t):
+        if self.world == 1:
+            return t
+        dist.gather(t, self.bufs, dst=self.dst)
+        return self.bufs
 
 
 def gather_results(local_tensor, n_total, rank, world, dst=0):

@@ -1,0 +1,52 @@
+"""CPU: `bench.py --gpus N` started as a plain process must start N ranks itself (glare_amd.parallel.launch_ranks), and a
+launched job really has WORLD_SIZE = N ranks that can talk (gloo here; nccl = RCCL on the GPU box)."""
+import os
+import subprocess
+import sys
+import textwrap
+
+from glare_amd import parallel
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_rank_launch_command_shape():
+    cmd = parallel.rank_launch_command("bench.py", 4, ["--gpus", "4", "--steps", "3"], port=29511)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    assert cmd[-5:] == ["bench.py", "--gpus", "4", "--steps", "3"]
+
+
+def test_launch_ranks_starts_world_size_processes(tmp_path):
+    script = tmp_path / "probe.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %r)
+        import torch, torch.distributed as dist
+        from glare_amd import parallel
+        rank, world, dev = parallel.init_from_env(backend="gloo")
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t)
+        g = parallel.RankGather(torch.zeros(2), rank, world)
+        bufs = g.gather(torch.full((2,), float(rank)))
+        if rank == 0:
+            print("WORLD", world, "SUM", int(t.item()), "GATHER", [int(b[0]) for b in bufs], sys.argv[1:], flush=True)
+        dist.barrier(); dist.destroy_process_group()
+    """ % ROOT))
+    env = dict(os.environ, RANK="7", WORLD_SIZE="9")      # stale variables of an outer job must not leak into the launch
+    r = subprocess.run([sys.executable, "-c",
+                        "import sys; sys.path.insert(0, %r); from glare_amd import parallel; "
+                        "sys.exit(parallel.launch_ranks(%r, 2, ['--flag', '1']))" % (ROOT, str(script))],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "WORLD 2 SUM 3 GATHER [0, 1] ['--flag', '1']" in r.stdout
+
+
+def test_bench_refuses_a_mismatched_world(monkeypatch):
+    """bench.py's own contract, read from its source (it cannot run without a GPU): self-launch when WORLD_SIZE is unset,
+    and an assertion that the world size equals --gpus."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'args.gpus > 1 and "WORLD_SIZE" not in os.environ' in src and "parallel.launch_ranks(" in src
+    assert "assert world == args.gpus" in src and "dist.get_world_size() == args.gpus" in src
+    assert '"n_gpus": world' in src
