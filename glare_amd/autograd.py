@@ -375,6 +375,26 @@ def msssim_terms(x, y, windows):
     return MSSSIMTermsFn.apply(x, y, windows)
 
 
+class NhwcToNchwFn(torch.autograd.Function):
+    """fp32 NHWC -> fp32 NCHW at the module surface, differentiable (backward = the opposite layout kernel)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return ops.nhwc_to_nchw(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.nchw_to_nhwc(g.contiguous(), bf16=False)
+
+
+def nhwc_to_nchw(x):
+    return NhwcToNchwFn.apply(x)
+
+
+def to_nhwc_f32(x_nchw):
+    return ops.nchw_to_nhwc(x_nchw, bf16=False)
+
+
 class ForkFn(torch.autograd.Function):
     """A fan-out point of the tape made explicit: returns n aliases of x; the backward sums their gradients with
     glare_add_bf16, so the accumulation of activation gradients runs on this library, not on the autograd engine's add."""

@@ -28,15 +28,26 @@ def load_network(path_or_state, network, strict=True, submodule=None):
     return result
 
 
+GRAD_SCALER_STATE = {"scale": 65536.0, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2000, "_growth_tracker": 0}
+"""What an enabled torch.cuda.amp.GradScaler.state_dict() holds at its defaults.  The reference creates `GradScaler()`
+(LLFlow_model.py:120, VQLLFLOWD_model.py:126) and its resume path calls `scaler.load_state_dict(state['scaler'])`, which raises on
+an empty dict -- so the saved training state always carries these keys.  This path computes the loss in fp32 and needs no loss
+scaling: on resume the scaler entry is accepted and ignored."""
+
+
 def adam_state_dict(opt):
-    """FlatAdam -> the dict torch.optim.Adam.state_dict() would produce for the same groups (params indexed in order)."""
+    """FlatAdam -> the dict torch.optim.Adam.state_dict() would produce for the same groups (params indexed in order).  As in
+    torch, parameters that never received a gradient have no state entry (FlatGroup.has_grad), and an empty group (the frozen
+    RRDB group of stage 3 / stage 2 with train_RRDB: false) is emitted as an empty `params` list."""
     state, groups, idx = {}, [], 0
     for g in opt.groups:
         ids, off = [], 0
-        for p in g.params:
+        used = getattr(g, "has_grad", None)
+        for j, p in enumerate(g.params):
             k = p.numel()
-            state[idx] = {"step": torch.tensor(float(opt.t)), "exp_avg": g.m[off:off + k].view(p.shape).detach().cpu().clone(),
-                          "exp_avg_sq": g.v[off:off + k].view(p.shape).detach().cpu().clone()}
+            if used is None or used[j]:
+                state[idx] = {"step": torch.tensor(float(opt.t)), "exp_avg": g.m[off:off + k].view(p.shape).detach().cpu().clone(),
+                              "exp_avg_sq": g.v[off:off + k].view(p.shape).detach().cpu().clone()}
             ids.append(idx)
             idx += 1
             off += k
@@ -53,9 +64,11 @@ def load_adam_state_dict(opt, sd):
         assert len(sg["params"]) == len(g.params), "parameter count of a group differs"
         g.lr, g.weight_decay = float(sg["lr"]), float(sg.get("weight_decay", 0.0))
         off = 0
+        g.has_grad = []
         for p, pid in zip(g.params, sg["params"]):
             k = p.numel()
             st = sd["state"].get(pid)
+            g.has_grad.append(st is not None)
             if st is None:               # torch keeps no state for parameters that never received a gradient
                 g.m[off:off + k].zero_()
                 g.v[off:off + k].zero_()
@@ -69,7 +82,7 @@ def load_adam_state_dict(opt, sd):
 
 def save_training_state(path, trainer, epoch, iter_step, schedulers=()):
     torch.save({"epoch": epoch, "iter": iter_step, "schedulers": [s.state_dict() for s in schedulers],
-                "optimizers": [adam_state_dict(trainer.opt)], "scaler": {}}, path)   # GradScaler: no fp16 here, empty state
+                "optimizers": [adam_state_dict(trainer.opt)], "scaler": dict(GRAD_SCALER_STATE)}, path)
 
 
 def resume_training(path_or_state, trainer, schedulers=()):

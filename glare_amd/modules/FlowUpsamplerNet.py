@@ -264,14 +264,17 @@ class FlowUpsamplerNet(HipModule):
              "c2_w": c2w, "c2_b": c2b, "c4_w": c4w, "c4_b": c4b, "f2_w": f2w, "f2_b": f2b, "f4_w": f4w, "f4_b": f4b}
         return P, const_ld, float(steps[0].affine_eps), dev
 
-    def train_nll_terms(self, gt, ft, mean, params=None):
+    def train_nll_terms(self, gt, ft, mean, params=None, want_z=False):
         """gt, mean: fp32 NHWC [B,h,w,3]; ft: bf16 NHWC [B,h,w,64] (both may carry a tape).  Returns per-sample
-        (logdet, logp) float64 tensors on the device, differentiable w.r.t. ft, mean and every flow parameter.  `params` =
+        (logdet, logp) float64 tensors on the device, differentiable w.r.t. ft, mean and every flow parameter (want_z: plus
+        the encoded latent z, fp32 NHWC, without a tape).  `params` =
         a `_train_params()` result computed EARLIER in the step: its tape nodes are then older than the encoder's, so their
         (tiny) backward runs after the encoder's backward has been enqueued."""
         P, const_ld, eps, dev = self._train_params() if params is None else params
-        ld_data, logp = FlowNLLFn.apply(ft, mean, gt, eps, *[P[k] for k in _FLOW_KEYS])
+        ld_data, logp, z = FlowNLLFn.apply(ft, mean, gt, eps, *[P[k] for k in _FLOW_KEYS])
         pixels = gt.shape[1] * gt.shape[2]
+        if want_z:
+            return ld_data + const_ld * pixels, logp, z
         return ld_data + const_ld * pixels, logp
 
     def encode(self, gt, rrdbResults, logdet=0.0, epses=None, y_onehot=None):
@@ -339,10 +342,12 @@ class FlowNLLFn(torch.autograd.Function):
         red = ops.flow_nll_reduce(z, mean, partial, 2 * n)
         ctx.eps = eps
         ctx.save_for_backward(ft, mean, z, h1f, h2f, hF, z_in, z_pre, h1s, h2s, h4s, wz, ftA_w, f0_w, c2_w, c4_w, f2_w, f4_w, Mt)
-        return red[:, 0].clone(), red[:, 1].clone()
+        z_out = z.clone()                       # the encoded latent, handed out as a plain (non-differentiable) result
+        ctx.mark_non_differentiable(z_out)
+        return red[:, 0].clone(), red[:, 1].clone(), z_out
 
     @staticmethod
-    def backward(ctx, g_logdet, g_logp):
+    def backward(ctx, g_logdet, g_logp, _g_z=None):
         ft, mean, z, h1f, h2f, hF, z_in, z_pre, h1s, h2s, h4s, wz, ftA_w, f0_w, c2_w, c4_w, f2_w, f4_w, Mt = ctx.saved_tensors
         eps = ctx.eps
         n, B, H, W, _ = z_in.shape

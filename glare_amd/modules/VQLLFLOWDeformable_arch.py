@@ -2,9 +2,12 @@
 decoder -> AFT decoder.  Mirrors VQLLFLOWDeformable (code/models/modules/VQLLFLOWDeformable_arch.py:
 ctor :19-52, forward :103-128, reverse_flow :222-250) with the same submodule names (RRDB,
 flowUpsamplerNet, deformable_decoder) and therefore the same 824 state-dict keys."""
+import math
+
 import torch
 import torch.nn as nn
 
+from .. import autograd as A
 from ._base import HipModule, to_nchw
 from .ConditionEncoder import ConEncoder1
 from .deformableDecoder_arch import MultiScaleDecoder2
@@ -33,12 +36,36 @@ class VQLLFLOWDeformable(HipModule):
         out = self.deformable_decoder.forward_nhwc(latent, code_feats, enc["mid_feat"])
         return {"out": out, "latent": latent, "indices": idx, "enc": enc, "code_feats": code_feats}
 
+    def reverse_flow_train_nhwc(self, net_vq, lr, whole_batch_mean=True):
+        """reverse_flow with a tape where the reference has one (VQLLFLOWDeformable_arch.py:231-249): the conditional
+        encoder, the flow and the VQGAN decoder run under no_grad there too (:231, :245), only `deformable_decoder` is
+        differentiated.  -> (fp32 NHWC image with a tape, fp32 NHWC latent)."""
+        with torch.no_grad():
+            enc = self.RRDB.forward_nhwc(lr)
+            latent = self.flowUpsamplerNet.decode_nhwc(enc["color_map"], enc["cond_feat"])
+            _, _, code_feats = net_vq.decode_nhwc(latent, want_image=False)
+        out = self.deformable_decoder.train_nhwc(latent, code_feats, enc["mid_feat"], whole_batch_mean=whole_batch_mean)
+        return out, latent
+
     def forward(self, net_vq=None, gt=None, lr=None, z=None, eps_std=None, reverse=True, epses=None,
                 reverse_with_grad=True, lr_enc=None, add_gt_noise=False, step=None, y_label=None,
                 align_condition_feature=False, get_color_map=False):
+        """The reference's entry point (VQLLFLOWDeformable_arch.py:103-128).  reverse=True, reverse_with_grad=True under
+        autograd (VQLLFLOWD_model.py:205-208, stage 3) returns an image that carries the tape of `deformable_decoder`, so
+        `total_loss.backward()` of the reference's optimize_parameters works on it; otherwise the fused no-grad graph runs.
+        The normal direction of THIS class is never called by the reference (stage 2 uses LLFlowVQGAN2): it delegates to the
+        same flow kernels for completeness."""
         if not reverse:
-            raise NotImplementedError("normal flow is the stage-2 graph (LLFlowVQGAN2); not on HIP yet")
+            assert gt is not None
+            enc = self.RRDB.forward_nhwc(lr)
+            zz, logdet, logp = self.flowUpsamplerNet.encode_nhwc(A.to_nhwc_f32(gt.detach()), enc["cond_feat"], mean=enc["color_map"])
+            pixels = gt.shape[2] * gt.shape[3]
+            nll = -(logdet + logp) / (math.log(2.0) * pixels)
+            return to_nchw(zz), nll.float(), logdet.float()
         assert lr.shape[1] == 3
+        if reverse_with_grad and torch.is_grad_enabled() and any(p.requires_grad for p in self.deformable_decoder.parameters()):
+            out, latent = self.reverse_flow_train_nhwc(net_vq, lr)
+            return A.nhwc_to_nchw(out), to_nchw(latent)
         with torch.no_grad():
             r = self.reverse_flow_nhwc(net_vq, lr)
         return r["out"], to_nchw(r["latent"])

@@ -27,6 +27,11 @@ class VectorQuantizer2(HipModule):
         assert temp is None or temp == 1.0
         assert not rescale_logits and not return_logits
         ops.require_cuda(z)
+        if torch.is_grad_enabled() and z.requires_grad:
+            # GLARE only ever runs the codebook under no_grad (VQLLFLOWDeformable_arch.py:245, LLFlow_model.py:200): the HIP
+            # lookup has no tape, so the commitment / codebook losses below could not train anything -- refuse loudly
+            raise NotImplementedError("VectorQuantizer2 on HIP is inference-only (stage-1 VQGAN training is out of scope): "
+                                      "call it under torch.no_grad()")
         zp = ops.nchw_to_nhwc(z, bf16=False)  # 'b c h w -> b h w c' (quantize.py:276)
         flat = zp.view(-1, self.e_dim)
         idx, zq = self.quantize_tokens(flat)

@@ -100,17 +100,24 @@ def gather_results(local_tensor, n_total, rank, world, dst=0):
 def run_sharded(n_items, fn, rank, world, batch=8, streams=1):
     """Calls fn(lo, hi) -> tensor [hi-lo, ...] over this rank's slice in batches; returns the local results.
     streams > 1 (CUDA only): consecutive batches are issued round-robin on that many streams, so the tail and the
-    latency-bound sections of one batch run under the next batch's kernels (+3 % at batch 8); the results are joined after a
-    device synchronisation."""
+    latency-bound sections of one batch run under the next batch's kernels (+3 % at batch 8); the side streams wait on the
+    caller's stream first and the caller's stream waits on them before the results are joined (stream-ordered, no host sync)."""
     lo, hi = shard_range(n_items, rank, world)
     starts = list(range(lo, hi, batch))
     if streams > 1 and torch.cuda.is_available():
+        cur = torch.cuda.current_stream()
         pool = [torch.cuda.Stream() for _ in range(streams)]
+        for st in pool:
+            st.wait_stream(cur)          # weights / inputs produced asynchronously on the caller's stream are ordered before us
         outs = []
         for i, s in enumerate(starts):
             with torch.cuda.stream(pool[i % streams]):
-                outs.append(fn(s, min(hi, s + batch)))
-        torch.cuda.synchronize()
+                o = fn(s, min(hi, s + batch))
+                if o is not None:
+                    o.record_stream(cur)  # consumed (concatenated) on the caller's stream below
+                outs.append(o)
+        for st in pool:
+            cur.wait_stream(st)          # stream-ordered join: no device-wide synchronisation needed by the caller
     else:
         outs = [fn(s, min(hi, s + batch)) for s in starts]
     return torch.cat(outs, 0) if outs else None

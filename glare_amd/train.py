@@ -20,11 +20,11 @@ from . import train_ops as T
 class FlatGroup:
     """Flat fp32 storage for a parameter group: w / grad / exp_avg / exp_avg_sq; parameters become views."""
 
-    def __init__(self, params, lr, weight_decay=0.0):
+    def __init__(self, params, lr, weight_decay=0.0, device=None):
         self.params = [p for p in params if p.requires_grad]
         self.lr, self.weight_decay = float(lr), float(weight_decay)
         n = sum(p.numel() for p in self.params)
-        dev = self.params[0].device if self.params else torch.device("cpu")
+        dev = self.params[0].device if self.params else torch.device(device or "cpu")
         self.w = torch.empty(n, dtype=torch.float32, device=dev)
         self.g = torch.zeros_like(self.w)
         self.m = torch.zeros_like(self.w)
@@ -42,7 +42,28 @@ class FlatGroup:
         for p in self.params:
             p.grad = None
 
+    def active_ranges(self):
+        """[lo, hi) element ranges of the flat buffer whose parameters have EVER received a gradient.  torch.optim.Adam (the
+        reference's optimizer) skips a parameter whose .grad is None -- no moment update, no weight decay, no state entry:
+        the parameters the graph never uses (flowUpsamplerNet.f, deformable_decoder.{scale,bias,enc,conv_out}) must not
+        move under weight decay.  Merged, these are 1-3 ranges, i.e. 1-3 Adam launches per group."""
+        out, off = [], 0
+        for p, used in zip(self.params, self.has_grad):
+            k = p.numel()
+            if used:
+                if out and out[-1][1] == off:
+                    out[-1][1] = off + k
+                else:
+                    out.append([off, off + k])
+            off += k
+        return [(a, b) for a, b in out]
+
     def collect(self, chunk=64):
+        if not hasattr(self, "has_grad"):
+            self.has_grad = [False] * len(self.params)
+        for i, p in enumerate(self.params):
+            if p.grad is not None:
+                self.has_grad[i] = True
         off = 0
         for i in range(0, len(self.params), chunk):
             ps = self.params[i:i + chunk]
@@ -54,9 +75,9 @@ class FlatGroup:
                           out=self.g[off:off + n])
             off += n
         off = 0
-        for p in self.params:   # expose the gathered gradient as the parameter's .grad (a view of the flat buffer)
-            k = p.numel()
-            p.grad = self.g[off:off + k].view(p.shape)
+        for p, used in zip(self.params, self.has_grad):   # expose the gathered gradient as .grad (a view of the flat buffer);
+            k = p.numel()                                  # parameters the graph never reaches keep .grad = None, as in torch
+            p.grad = self.g[off:off + k].view(p.shape) if used else None
             off += k
 
     def all_reduce(self):
@@ -106,10 +127,12 @@ class FlatAdam:
                 continue
             g.collect()
             world = g.all_reduce()
-            if self.device_state:
-                T.adam_step_dev_(g.w, g.g, g.m, g.v, self.state3, g.lr, self.betas, self.eps, g.weight_decay, grad_scale=1.0 / world)
-            else:
-                T.adam_step_(g.w, g.g, g.m, g.v, self._t, g.lr, self.betas, self.eps, g.weight_decay, grad_scale=1.0 / world)
+            for lo, hi in g.active_ranges():       # parameters that never had a gradient are skipped, as torch.optim.Adam does
+                w, gr, m, v = g.w[lo:hi], g.g[lo:hi], g.m[lo:hi], g.v[lo:hi]
+                if self.device_state:
+                    T.adam_step_dev_(w, gr, m, v, self.state3, g.lr, self.betas, self.eps, g.weight_decay, grad_scale=1.0 / world)
+                else:
+                    T.adam_step_(w, gr, m, v, self._t, g.lr, self.betas, self.eps, g.weight_decay, grad_scale=1.0 / world)
 
 
 class Stage2Trainer:
@@ -125,20 +148,29 @@ class Stage2Trainer:
         if not train_rrdb:  # train_RRDB_delay (LLFlow_model.py:142-150): the encoder joins after a fraction of the run
             for p in rrdb:
                 p.requires_grad_(False)
+        # always the reference's two groups [other, RRDB] (LLFlow_model.py:110-118); the RRDB group is EMPTY while the
+        # conditional encoder is frozen (train_RRDB: false / before train_RRDB_delay), exactly as in the reference's
+        # optimizer -- so `.state` files are interchangeable (glare_amd/checkpoint.py)
         self.opt = FlatAdam([FlatGroup(other, lr_G, weight_decay_G),
-                             FlatGroup(rrdb, lr_G if lr_RRDB is None else lr_RRDB, 1e-5)] if train_rrdb else
-                            [FlatGroup(other, lr_G, weight_decay_G)], device_state=device_state)
+                             FlatGroup(rrdb if train_rrdb else [], lr_G if lr_RRDB is None else lr_RRDB, 1e-5,
+                                       device=other[0].device)], device_state=device_state)
 
-    def step(self, gt_img, lr_img):
+    def draw_branch(self):
+        """The step's one host-side random decision (LLFlowVQGAN_arch.py:95): is the Gaussian's mean the ground truth?"""
+        return self.netG._mean_is_gt(None)
+
+    def step(self, gt_img, lr_img, mean_is_gt=None):
         """gt_img: fp32 NCHW ground-truth crop in [0,1]; lr_img: fp32 NCHW low-light crop (log domain).  Returns the loss."""
-        return float(self.step_tensor(gt_img, lr_img))
+        return float(self.step_tensor(gt_img, lr_img, mean_is_gt))
 
-    def step_tensor(self, gt_img, lr_img):
-        """The step without any host synchronisation: returns the loss as a device tensor."""
+    def step_tensor(self, gt_img, lr_img, mean_is_gt=None):
+        """The step without any host synchronisation: returns the loss as a device tensor.  mean_is_gt: None = draw with
+        probability train_gt_ratio as the reference does; True / False = forced (GraphedStep draws before choosing a graph)."""
+        flag = self.draw_branch() if mean_is_gt is None else bool(mean_is_gt)
         with torch.no_grad():
             gt_latent = self.net_hq.encode_nhwc(gt_img)            # LLFlow_model.py:200-201
         self.opt.zero_grad()
-        nll = self.netG.train_nll(gt_latent, lr_img)               # :215
+        nll = self.netG.train_nll(gt_latent, lr_img, mean_is_gt=flag)   # :215
         loss = nll.mean()
         loss.backward()                                            # :236
         self.opt.step()                                            # :240
@@ -164,8 +196,11 @@ class Stage3Trainer:
             p.requires_grad_(False)
         for n, p in netG.named_parameters():
             p.requires_grad_(n.startswith("deformable_decoder."))
-        self.opt = FlatAdam([FlatGroup([p for n, p in netG.named_parameters() if n.startswith("deformable_decoder.")],
-                                       lr_G, weight_decay_G)], device_state=device_state)
+        dd = [p for n, p in netG.named_parameters() if n.startswith("deformable_decoder.")]
+        # the reference's optimizer always has the two groups [other, RRDB] (VQLLFLOWD_model.py:113-121); at stage 3 the
+        # conditional encoder is frozen (fix_modules), so its group is empty -- kept for `.state` file compatibility
+        self.opt = FlatAdam([FlatGroup(dd, lr_G, weight_decay_G), FlatGroup([], lr_G, 1e-5, device=dd[0].device)],
+                            device_state=device_state)
 
     def step(self, gt_img, lr_img):
         """gt_img: fp32 NCHW in [0,1]; lr_img: fp32 NCHW low-light crop (log domain).  Returns the loss."""
@@ -208,27 +243,55 @@ class GraphedStep:
     """A training step captured once into a hipGraph (torch.cuda.CUDAGraph) and replayed: the ~5 000 kernel launches of a step
     at the reference's crop sizes are launch-bound from Python, the graph removes the host from the loop.  Needs a trainer
     built with device_state=True (no host-side optimizer state) and fixed input shapes; inputs are copied into static buffers.
-    World size 1 only (a collective inside the captured region is not attempted)."""
+    World size 1 only (a collective inside the captured region is not attempted).
+
+    A stage-2 step has one host-side random decision (mean = ground truth with probability train_gt_ratio,
+    LLFlowVQGAN_arch.py:95) that changes the captured kernel sequence: the decision is drawn on the host BEFORE the replay
+    and selects one of two graphs (the second is captured the first time its branch is drawn)."""
 
     def __init__(self, trainer, gt_img, lr_img, warmup=3):
         assert trainer.opt.device_state, "build the trainer with device_state=True"
         self.trainer = trainer
+        self.branching = hasattr(trainer, "draw_branch")
         self.gt, self.lr = gt_img.clone(), lr_img.clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):                 # allocator / lazy-init warm-up outside the capture
-                trainer.step_tensor(self.gt, self.lr)
+                self._eager(False)
         torch.cuda.current_stream().wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.loss = trainer.step_tensor(self.gt, self.lr)
+        self.graphs = {}
+        self._capture(False)
 
-    def step_tensor(self, gt_img, lr_img):
+    def _eager(self, flag):
+        return self.trainer.step_tensor(self.gt, self.lr, flag) if self.branching else self.trainer.step_tensor(self.gt, self.lr)
+
+    def _capture(self, flag):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            loss = self._eager(flag)
+        self.graphs[flag] = (g, loss)
+        # the capture only RECORDS: it must not advance the optimizer.  (Capturing runs no kernels; the host-side step
+        # counter lives on the device in device_state mode, so nothing to undo.)
+
+    def _invalidate(self):
+        # the host code inside step_tensor (netG.invalidate()) ran at capture time only: packed inference weights built
+        # since then (a validation pass between steps) would be stale after this replay
+        tr = self.trainer
+        (tr.netG.deformable_decoder if isinstance(tr, Stage3Trainer) else tr.netG).invalidate()
+
+    def step_tensor(self, gt_img, lr_img, mean_is_gt=None):
+        flag = False
+        if self.branching:
+            flag = self.trainer.draw_branch() if mean_is_gt is None else bool(mean_is_gt)
         self.gt.copy_(gt_img)
         self.lr.copy_(lr_img)
-        self.graph.replay()
-        return self.loss
+        if flag not in self.graphs:
+            self._capture(flag)
+        g, loss = self.graphs[flag]
+        g.replay()
+        self._invalidate()
+        return loss
 
     def step(self, gt_img, lr_img):
         return float(self.step_tensor(gt_img, lr_img))

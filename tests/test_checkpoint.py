@@ -48,3 +48,79 @@ def test_adam_state_is_torch_optim_layout(tmp_path):
     fopt2 = FlatAdam([FlatGroup(list(_net(2).parameters())[:2], 1.0), FlatGroup(list(_net(2).parameters())[2:], 1.0)])
     assert C.resume_training(str(tmp_path / "30.state"), type("T", (), {"opt": fopt2})) == (1, 30)
     assert fopt2.t == 3 and torch.equal(fopt2.groups[0].m, fopt.groups[0].m)
+
+
+def _reference_adam(netG, wd_G=0.0, lr=5e-4):
+    """torch.optim.Adam built the way the reference builds it (LLFlow_model.py:95-118 / VQLLFLOWD_model.py:101-121): two groups,
+    [other, RRDB], from the parameters with requires_grad; the names carry nn.DataParallel's 'module.' prefix there, so
+    '.RRDB.' in the name == our names starting with 'RRDB.'."""
+    rrdb, other = [], []
+    for k, v in netG.named_parameters():
+        if v.requires_grad:
+            (rrdb if ".RRDB." in "module." + k else other).append(v)
+    return torch.optim.Adam([{"params": other, "lr": lr, "beta1": 0.9, "beta2": 0.99, "weight_decay": wd_G},
+                             {"params": rrdb, "lr": lr, "beta1": 0.9, "beta2": 0.99, "weight_decay": 1e-5}])
+
+
+def _fake_step(trainer, topt):
+    """Give both optimizers the same state without a GPU: every used parameter gets a gradient; the parameters the graph
+    never reaches (flowUpsamplerNet.f, deformable_decoder.{scale,bias,enc,conv_out}) get none, as after a real backward."""
+    unused = ("flowUpsamplerNet.f.", "deformable_decoder.scale.", "deformable_decoder.bias.", "deformable_decoder.enc.",
+              "deformable_decoder.conv_out.")
+    names = {id(p): n for n, p in trainer.netG.named_parameters()}
+    g = torch.Generator().manual_seed(0)
+    for grp in trainer.opt.groups:
+        grp.zero_grad()
+        for p in grp.params:
+            if not names[id(p)].startswith(unused):
+                p.grad = torch.randn(p.shape, generator=g) * 1e-3
+        grp.collect()
+    topt.step()                         # p.grad of the used parameters are now views of the flat buffers: same values
+    trainer.opt._t = 1
+    for grp in trainer.opt.groups:      # the Adam arithmetic itself is a GPU kernel (tests/test_gpu_train.py); mirror torch's here
+        off = 0
+        for p in grp.params:
+            k = p.numel()
+            st = topt.state.get(p)
+            if st:
+                grp.m[off:off + k].copy_(st["exp_avg"].reshape(-1))
+                grp.v[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+            off += k
+
+
+def test_real_trainers_write_and_read_the_reference_state_layout(tmp_path):
+    """The `.state` of the real Stage2 / Stage3 trainers against torch.optim.Adam + GradScaler built as the reference builds them:
+    two param groups with an EMPTY RRDB group where the encoder is frozen, no state entry for parameters without a gradient,
+    a scaler dict torch's GradScaler.load_state_dict accepts -- in both directions."""
+    from glare_amd import modules as M
+    from glare_amd.train import Stage2Trainer, Stage3Trainer
+
+    cases = [("stage2", lambda: Stage2Trainer(M.LLFlowVQGAN2(), M.VQModel(), lr_G=5e-4)),
+             ("stage2 frozen encoder", lambda: Stage2Trainer(M.LLFlowVQGAN2(), M.VQModel(), lr_G=5e-4, train_rrdb=False)),
+             ("stage3", lambda: Stage3Trainer(M.VQLLFLOWDeformable(), M.VQModel(), lr_G=5e-4))]
+    for tag, make in cases:
+        tr = make()
+        topt = _reference_adam(tr.netG)
+        assert [len(g["params"]) for g in topt.param_groups] == [len(g.params) for g in tr.opt.groups], tag
+        if tag != "stage2":
+            assert len(tr.opt.groups) == 2 and len(tr.opt.groups[1].params) == 0, tag
+        _fake_step(tr, topt)
+        path = str(tmp_path / "s.state")
+        C.save_training_state(path, tr, epoch=3, iter_step=1)
+        st = torch.load(path)
+        # ours -> the reference's resume path (base_model.py:207-219)
+        topt2 = _reference_adam(tr.netG)
+        topt2.load_state_dict(st["optimizers"][0])
+        torch.amp.GradScaler("cpu").load_state_dict(st["scaler"])       # an empty dict raises here
+        ref_sd = topt.state_dict()
+        assert sorted(st["optimizers"][0]["state"]) == sorted(ref_sd["state"]), tag      # same parameters have state
+        for k, v in ref_sd["state"].items():
+            assert torch.equal(st["optimizers"][0]["state"][k]["exp_avg"], v["exp_avg"])
+        # the reference's -> ours
+        tr2 = make()
+        ep, it = C.resume_training({"epoch": 3, "iter": 1, "schedulers": [], "optimizers": [ref_sd],
+                                    "scaler": torch.amp.GradScaler("cpu").state_dict()}, tr2)
+        assert (ep, it) == (3, 1) and tr2.opt.t == 1
+        for a, b in zip(tr.opt.groups, tr2.opt.groups):
+            assert torch.equal(a.m, b.m) and torch.equal(a.v, b.v) and a.has_grad == b.has_grad
+        assert any(not all(g.has_grad) for g in tr2.opt.groups), "the never-used parameters must stay without state"
