@@ -41,9 +41,10 @@ def load_lol_pairs(root):
     return lows, gts
 
 
-def run(n_images, batch=8, h=400, w=600, seed=1234, root=None, net_g=None, net_vq=None):
+def run(n_images, batch=8, h=400, w=600, seed=1234, root=None, net_g=None, net_vq=None, pairs=None):
     """Synthetic LOL-shaped pairs by default; `root` = a LOL dataset folder (eval15 split), `net_g` / `net_vq` = checkpoint
-    files in the reference's format (glare_amd.checkpoint) -- without them the weights are name-seeded."""
+    files in the reference's format (glare_amd.checkpoint) -- without them the weights are name-seeded; `pairs` = (lows, gts)
+    uint8 stacks [n,h,w,3] supplied by the caller."""
     from . import checkpoint
 
     rank, world, device = parallel.init_from_env()
@@ -55,7 +56,10 @@ def run(n_images, batch=8, h=400, w=600, seed=1234, root=None, net_g=None, net_v
     if net_vq:
         checkpoint.load_network(net_vq, net_vq_m, strict=False)
     netG, net_vq = netG.to(device), net_vq_m.to(device)
-    if root:
+    if pairs is not None:
+        lows, gts = pairs
+        n_images, h, w = lows.shape[0], lows.shape[1], lows.shape[2]
+    elif root:
         lows, gts = load_lol_pairs(root)
         n_images, h, w = lows.shape[0], lows.shape[1], lows.shape[2]
     else:

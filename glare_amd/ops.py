@@ -292,6 +292,11 @@ def attention_key_splits(B, N):
     return max(1, min(4, (512 + blocks - 1) // blocks, (N + 31) // 32))
 
 
+# Test / tool hook: force the number of key splits of every attention launch (None = attention_key_splits()).  A B = 1 run
+# splits the keys over 4 workgroups per query block to fill the chip, a B = 8 run does not: the two differ in summation order
+# (rounding), so the batch-invariance test pins both to one configuration.
+ATTENTION_KEY_SPLITS_OVERRIDE = None
+
 # Measurement hook (bench.py): when this is a list, every attention launch is bracketed by a pair of events recorded on the
 # stream the kernel is launched on, and (start, end, B, N) is appended.  None (the default) records nothing.
 ATTENTION_LAUNCH_EVENTS = None
@@ -317,6 +322,8 @@ def _attention_d512(q, k, v_t, N, ldq, ldk, out, key_splits):
     ldk = k.shape[-1] if ldk is None else ldk
     if out is None:
         out = torch.empty(B, N, 512, dtype=torch.bfloat16, device=v_t.device)
+    if key_splits is None:
+        key_splits = ATTENTION_KEY_SPLITS_OVERRIDE
     ks = attention_key_splits(B, N) if key_splits is None else key_splits
     if ks > 1:
         lib = _lib.lib()

@@ -607,12 +607,16 @@ class LLFlowVQGAN2(nn.Module):  # LLFlowVQGAN_arch.py:17-106 (stage 2, normal fl
         self.RRDB = ConEncoder1()
         self.flowUpsamplerNet = FlowUpsamplerNet()
 
-    def normal_flow(self, gt, lr):
+    def normal_flow(self, gt, lr, train_gt_ratio=0.0):
+        """train_gt_ratio: confs/LOL.yml:12 = 0, confs/train_stage2_LOL.yml:14 = 0.2; one `random.random()` draw per call
+        decides whether the Gaussian's mean is color_map or the ground-truth latent (LLFlowVQGAN_arch.py:95)."""
+        import random
+
         enc = self.RRDB(lr)
         pixels = gt.shape[2] * gt.shape[3]
         logdet = torch.zeros_like(gt[:, 0, 0, 0])
         z, logdet = self.flowUpsamplerNet.encode(gt, enc["cond_feat"], logdet)
-        mean = enc["color_map"]  # train_gt_ratio = 0 (confs/LOL.yml:12)
+        mean = enc["color_map"] if random.random() > train_gt_ratio else gt  # LLFlowVQGAN_arch.py:95
         logp = (-0.5 * ((z - mean) ** 2 + float(np.log(2 * np.pi)))).sum(dim=[1, 2, 3])  # flow.py:76-95
         nll = -(logdet + logp) / float(np.log(2.0) * pixels)  # LLFlowVQGAN_arch.py:99-101
         return z, nll, logdet

@@ -175,15 +175,17 @@ def sketch(t, k=8):
     return (r @ t.reshape(-1).double()).numpy()
 
 
-def stage2_grads_fixture():
+def stage2_grads_fixture(train_gt_ratio=0.0, fname="stage2_grads.npz"):
     """stage2_grads.npz: the REFERENCE's stage-2 objective (LLFlowVQGAN_arch.LLFlowVQGAN2, mean NLL) on a seeded 2x3x64x64 batch
     with name-seeded weights: per-sample nll and, for each of the 625 parameter tensors, the gradient's L2 norm and 8
-    seeded projections (the 26.5 M gradients themselves would be 106 MB)."""
+    seeded projections (the 26.5 M gradients themselves would be 106 MB).
+    stage2_grads_gtmean.npz: the same with opt['train_gt_ratio'] = 1, i.e. the `mean = gt` branch of LLFlowVQGAN_arch.py:95
+    forced (random.random() > 1 is never true); `color_conv` then receives no gradient and is absent from the name list."""
     R.install()
     import models.modules.LLFlowVQGAN_arch as arch
 
     opt = R.load_opt()
-    opt["train_gt_ratio"] = 0.0
+    opt["train_gt_ratio"] = float(train_gt_ratio)
     ref = arch.LLFlowVQGAN2(opt=opt, K=12).train()
     seeded_init_(ref, 5)
     g = torch.Generator().manual_seed(6)
@@ -198,7 +200,7 @@ def stage2_grads_fixture():
         names.append(n)
         norms.append(float(p.grad.double().norm()))
         sk.append(sketch(p.grad))
-    np.savez_compressed(os.path.join(HERE, "stage2_grads.npz"), lr=lr.numpy(), gt=gt.numpy(), nll=nll.detach().numpy(),
+    np.savez_compressed(os.path.join(HERE, fname), lr=lr.numpy(), gt=gt.numpy(), nll=nll.detach().numpy(),
                         names=np.array(names), norms=np.array(norms), sketches=np.stack(sk))
 
 
@@ -207,5 +209,7 @@ if __name__ == "__main__":
         msssim_fixture()
     elif len(sys.argv) > 1 and sys.argv[1] == "stage2":
         stage2_grads_fixture()
+    elif len(sys.argv) > 1 and sys.argv[1] == "stage2_gtmean":
+        stage2_grads_fixture(1.0, "stage2_grads_gtmean.npz")
     else:
         main()

@@ -534,19 +534,22 @@ def test_graphed_step_replays_the_eager_step_bit_identically():
     assert torch.equal(finals[0][1], finals[1][1])
 
 
-def test_stage2_gradients_match_reference_vectors(golden):
+@pytest.mark.parametrize("fixture,mean_is_gt", [("stage2_grads", False), ("stage2_grads_gtmean", True)])
+def test_stage2_gradients_match_reference_vectors(golden, fixture, mean_is_gt):
     """Row a12 against the REFERENCE directly: the HIP path's NLL and every parameter gradient (norm + 8 seeded projections)
-    vs what the reference's own LLFlowVQGAN2 produced in the build container (tests/golden/stage2_grads.npz)."""
+    vs what the reference's own LLFlowVQGAN2 produced in the build container, on both branches of the train_gt_ratio draw
+    (tests/golden/stage2_grads.npz: mean = color_map; stage2_grads_gtmean.npz: mean = ground truth, LLFlowVQGAN_arch.py:95)."""
     from glare_amd import modules as M
     from glare_amd.synthetic import seeded_init_
 
-    g = golden("stage2_grads")
+    g = golden(fixture)
     hip = seeded_init_(M.LLFlowVQGAN2().train(), 5).to(_dev())
     gt = torch.from_numpy(g["gt"]).permute(0, 2, 3, 1).contiguous().to(_dev())
-    nll = hip.train_nll(gt, torch.from_numpy(g["lr"]).to(_dev()))
+    nll = hip.train_nll(gt, torch.from_numpy(g["lr"]).to(_dev()), mean_is_gt=mean_is_gt)
     assert torch.allclose(nll.detach().float().cpu(), torch.from_numpy(g["nll"]), rtol=3e-2, atol=0.05)
     nll.mean().backward()
     grads = dict(hip.named_parameters())
+    assert {n for n, p in grads.items() if p.grad is not None} == {str(n) for n in g["names"]}   # gt mean: none into color_conv
     rel_norm, rel_sk = [], []
     for name, norm, sk in zip(g["names"], g["norms"], g["sketches"]):
         name = str(name)
@@ -654,3 +657,110 @@ def test_training_steps_at_the_reference_crop_sizes(stage):
     assert all(l == l and abs(l) < 1e6 for l in losses), losses
     assert min(losses[3:]) < losses[0], losses
     assert not torch.equal(m0, moving.detach()) and torch.equal(f0, frozen.detach())
+
+
+def test_reference_shaped_stage2_forward_is_taped_and_runs_the_references_step():
+    """Row a11/a12 boundary: `netG(gt=..., lr=..., reverse=False)` is what LLFlowModel.optimize_parameters calls
+    (LLFlow_model.py:215-217); its `nll` must carry the tape so that the lines that follow there -- mean, GradScaler-scaled
+    backward, `scaler.step(optimizer_G)` of a torch.optim.Adam over netG's parameters (:218-241) -- run on the module unmodified.
+    The gradients equal train_nll's bit for bit (same kernels, same order)."""
+    hip, _ = _stage2_pair(5)
+    g = torch.Generator().manual_seed(6)
+    lr = (torch.randn(2, 3, 64, 64, generator=g) * 0.5 - 1.0).to(_dev())
+    encoder_gt = (torch.randn(2, 3, 16, 16, generator=g) * 0.5).to(_dev())
+    nll_a = hip.train_nll(encoder_gt.permute(0, 2, 3, 1).contiguous(), lr, mean_is_gt=False)
+    nll_a.mean().backward()
+    want = {n: p.grad.clone() for n, p in hip.named_parameters() if p.grad is not None}
+    for p in hip.parameters():
+        p.grad = None
+    # --- the reference's lines -------------------------------------------------------------------------------
+    optimizer_G = torch.optim.Adam([{"params": [p for n, p in hip.named_parameters() if not n.startswith("RRDB.")], "lr": 5e-4},
+                                    {"params": [p for n, p in hip.named_parameters() if n.startswith("RRDB.")], "lr": 5e-4,
+                                     "weight_decay": 1e-5}])
+    scaler = torch.amp.GradScaler("cuda")
+    optimizer_G.zero_grad()
+    z, nll, y_logits = hip(gt=encoder_gt.detach(), lr=lr, reverse=False, epses=None, align_condition_feature=False)
+    assert nll.requires_grad and z.shape == encoder_gt.shape and not z.requires_grad
+    nll_loss = torch.mean(nll)
+    total_loss = nll_loss * 1
+    scaler.scale(total_loss).backward()
+    scale = float(scaler.get_scale())
+    got = {n: p.grad / scale for n, p in hip.named_parameters() if p.grad is not None}
+    assert set(got) == set(want)
+    worst = max(_rel(got[n], want[n]) for n in want if float(want[n].norm()) > 0)
+    assert worst < 1e-6, worst                       # the loss scale (a power of two) is the only difference
+    before = hip.flowUpsamplerNet.layers[3].actnorm.bias.detach().clone()
+    scaler.step(optimizer_G)
+    scaler.update()
+    assert not torch.equal(before, hip.flowUpsamplerNet.layers[3].actnorm.bias.detach())
+    hip.invalidate()
+    # without autograd the same call is the plain forward
+    with torch.no_grad():
+        z2, nll2, _ = hip(gt=encoder_gt, lr=lr, reverse=False)
+    assert not nll2.requires_grad and torch.isfinite(nll2).all()
+
+
+def test_reference_shaped_stage3_forward_is_taped():
+    """VQLLFLOWDModel.optimize_parameters calls `netG(net_vq=..., lr=..., z=None, eps_std=0, reverse=True,
+    reverse_with_grad=True)` (VQLLFLOWD_model.py:205-208) and backpropagates a loss on the returned NCHW image (:209-229):
+    the image must carry deformable_decoder's tape; with reverse_with_grad=False (or under no_grad) the fused graph runs."""
+    from glare_amd import modules as M
+    from glare_amd.synthetic import seeded_init_
+
+    netG = seeded_init_(M.VQLLFLOWDeformable().train(), 0).to(_dev())
+    net_hq = seeded_init_(M.VQModel().eval(), 1).to(_dev())
+    g = torch.Generator().manual_seed(14)
+    gt_img = torch.rand(1, 3, 64, 64, generator=g).to(_dev())
+    lr_img = (torch.randn(1, 3, 64, 64, generator=g) * 0.5 - 1.0).to(_dev())
+    sr, latent = netG(net_vq=net_hq, lr=lr_img, z=None, eps_std=0, reverse=True, reverse_with_grad=True)
+    assert sr.requires_grad and sr.shape == gt_img.shape and not latent.requires_grad
+    sr_c = sr.clamp(0, 1)                                            # :209-215, on stock torch ops as in the reference
+    l1 = (sr_c - gt_img).abs().mean()
+    l1.backward()
+    with_grad = [n for n, p in netG.named_parameters() if p.grad is not None]
+    assert with_grad and all(n.startswith("deformable_decoder.") for n in with_grad)
+    assert float(netG.deformable_decoder.warp[0].dcn.weight.grad.norm()) > 0
+    # the gradient equals the Stage3Trainer path's (same kernels): compare against train_nhwc + the HIP L1 kernel
+    from glare_amd import autograd as A
+    ga = {n: p.grad.clone() for n, p in netG.named_parameters() if p.grad is not None}
+    for p in netG.parameters():
+        p.grad = None
+    out, _ = netG.reverse_flow_train_nhwc(net_hq, lr_img)
+    A.l1_clamp_loss(out, gt_img).backward()
+    worst = max(_rel(p.grad, ga[n]) for n, p in netG.named_parameters() if p.grad is not None and float(ga[n].norm()) > 0)
+    assert worst < 2e-2, worst       # clamp's sub-gradient at exactly 0 / 1 and fp32 layout round trip: tiny differences only
+    sr2, _ = netG(net_vq=net_hq, lr=lr_img, z=None, eps_std=0, reverse=True, reverse_with_grad=False)
+    assert not sr2.requires_grad
+    with torch.no_grad():
+        sr3, _ = netG(net_vq=net_hq, lr=lr_img, reverse=True, reverse_with_grad=True)
+    assert not sr3.requires_grad
+
+
+def test_adam_skips_parameters_without_gradient_and_graph_replay_invalidates():
+    """(1) torch.optim.Adam skips a parameter whose grad is None -- no weight decay either; FlatAdam must too (the parameters
+    the stage-3 graph never reaches: deformable_decoder.scale / bias / enc / conv_out).  (2) A packed inference cache built
+    between two replays of a captured step must not survive the replay."""
+    from glare_amd import modules as M
+    from glare_amd.synthetic import seeded_init_
+    from glare_amd.train import GraphedStep, Stage3Trainer
+
+    netG = seeded_init_(M.VQLLFLOWDeformable().train(), 0).to(_dev())
+    net_hq = seeded_init_(M.VQModel().eval(), 1).to(_dev())
+    tr = Stage3Trainer(netG, net_hq, lr_G=1e-4, weight_decay_G=0.1, use_msssim=False, device_state=True)
+    g = torch.Generator().manual_seed(14)
+    gt_img = torch.rand(1, 3, 64, 64, generator=g).to(_dev())
+    lr_img = (torch.randn(1, 3, 64, 64, generator=g) * 0.5 - 1.0).to(_dev())
+    unused = netG.deformable_decoder.enc[0].conv1.weight
+    used = netG.deformable_decoder.residual_conv.weight
+    u0, w0 = unused.detach().clone(), used.detach().clone()
+    gs = GraphedStep(tr, gt_img, lr_img, warmup=2)
+    gs.step(gt_img, lr_img)
+    assert torch.equal(unused.detach(), u0), "a parameter without gradient moved (weight decay applied to it)"
+    assert not torch.equal(used.detach(), w0)
+    assert unused.grad is None
+    with torch.no_grad():
+        netG.reverse_flow_nhwc(net_hq, lr_img)                         # a validation pass builds packed weights ...
+    assert "_hip_cache" in netG.deformable_decoder.mid.block_1.__dict__
+    gs.step(gt_img, lr_img)                                            # ... which the next replay must drop
+    assert "_hip_cache" not in netG.deformable_decoder.mid.block_1.__dict__
+    assert "_hip_cache" in netG.RRDB.encoder.mid.block_1.__dict__       # the frozen nets keep theirs

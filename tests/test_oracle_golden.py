@@ -123,11 +123,17 @@ def _sketch(t, k=8):
     return (r @ t.reshape(-1).double().cpu()).numpy()
 
 
-def test_stage2_gradients_match_reference_vectors(golden):
-    """oracle LLFlowVQGAN2 backward against the gradient norms / projections the reference produced (row a12)."""
-    g = golden("stage2_grads")
+import pytest
+
+
+@pytest.mark.parametrize("fixture,ratio", [("stage2_grads", 0.0), ("stage2_grads_gtmean", 1.0)])
+def test_stage2_gradients_match_reference_vectors(golden, fixture, ratio):
+    """oracle LLFlowVQGAN2 backward against the gradient norms / projections the reference produced (row a12), on both
+    branches of `mean = color_map if random.random() > train_gt_ratio else gt` (LLFlowVQGAN_arch.py:95): ratio 0 (always
+    color_map) and ratio 1 (always the ground truth; color_conv then has no gradient)."""
+    g = golden(fixture)
     m = seeded_init_(O.LLFlowVQGAN2().train(), 5)
-    _, nll, _ = m.normal_flow(torch.from_numpy(g["gt"]), torch.from_numpy(g["lr"]))
+    _, nll, _ = m.normal_flow(torch.from_numpy(g["gt"]), torch.from_numpy(g["lr"]), train_gt_ratio=ratio)
     np.testing.assert_allclose(nll.detach().numpy(), g["nll"], rtol=1e-5)
     nll.mean().backward()
     grads = dict(m.named_parameters())
@@ -135,3 +141,23 @@ def test_stage2_gradients_match_reference_vectors(golden):
         gr = grads[str(name)].grad
         assert abs(float(gr.double().norm()) - norm) <= 1e-4 * norm + 1e-12, name
         np.testing.assert_allclose(_sketch(gr), sk, rtol=0, atol=2e-4 * norm + 1e-12, err_msg=str(name))
+    with_grad = {n for n, p in m.named_parameters() if p.grad is not None}
+    assert with_grad == {str(n) for n in g["names"]}      # ratio 1: RRDB.color_conv.* is absent on both sides
+
+
+def test_train_gt_ratio_draw_is_one_python_random_call_per_forward():
+    """The branch is decided by exactly one `random.random()` per forward, `draw > ratio` -> color_map
+    (LLFlowVQGAN_arch.py:95): the product's host-side draw (glare_amd LLFlowVQGAN2._mean_is_gt) follows the same stream."""
+    import random
+
+    from glare_amd.modules import LLFlowVQGAN2
+
+    net = LLFlowVQGAN2(opt={"train_gt_ratio": 0.2})
+    assert net.train_gt_ratio == 0.2 and LLFlowVQGAN2().train_gt_ratio == 0.0
+    random.seed(1234)
+    want = [not random.random() > 0.2 for _ in range(200)]
+    random.seed(1234)
+    got = [net._mean_is_gt() for _ in range(200)]
+    assert got == want and 20 < sum(got) < 60
+    state = random.getstate()
+    assert net._mean_is_gt(True) is True and net._mean_is_gt(False) is False and random.getstate() == state   # forced: no draw
