@@ -22,7 +22,7 @@ from oracle import torch_ref as O
 
 pytestmark = pytest.mark.gpu
 
-from tolerances import TOL  # noqa: E402  (tests/tolerances.py: per-stage bounds, <= 2x measured)
+from tolerances import TOL, within  # noqa: E402  (tests/tolerances.py: per-stage bounds, <= 2x measured)
 
 
 def rel(a, b):
@@ -59,20 +59,20 @@ def nets():
 def test_stage_a_conditional_encoder(nets):
     og, ov, pg, pv, lr, ref = nets
     enc = pg.RRDB.forward_nhwc(lr.cuda())
-    assert rel(nchw(enc["cond_feat"]), ref["enc"]["cond_feat"]) < TOL["cond_feat"]
-    assert rel(nchw(enc["color_map"]), ref["enc"]["color_map"]) < TOL["color_map"]
+    within(rel(nchw(enc["cond_feat"]), ref["enc"]["cond_feat"]), TOL["cond_feat"])
+    within(rel(nchw(enc["color_map"]), ref["enc"]["color_map"]), TOL["color_map"])
     for i, (a, b) in enumerate(zip(enc["mid_feat"], ref["enc"]["mid_feat"])):
-        assert rel(nchw(a), b) < TOL["mid_feat%d" % i]
+        within(rel(nchw(a), b), TOL["mid_feat%d" % i])
 
 
 def test_stage_b_flow_reverse(nets):
     og, ov, pg, pv, lr, ref = nets
     z = pg.flowUpsamplerNet.decode_nhwc(nhwc(ref["enc"]["color_map"], bf16=False), nhwc(ref["enc"]["cond_feat"]))
-    assert rel(nchw(z), ref["latent"]) < TOL["latent"]
+    within(rel(nchw(z), ref["latent"]), TOL["latent"])
     # reference-surface entry point (NCHW tensors, rrdbResults dict, reverse=True)
     x, _ = pg.flowUpsamplerNet(rrdbResults={k: v.cuda() for k, v in ref["enc"].items() if k != "mid_feat"},
                                z=ref["enc"]["color_map"].cuda(), eps_std=0, reverse=True)
-    assert rel(x.cpu(), ref["latent"]) < TOL["latent"]
+    within(rel(x.cpu(), ref["latent"]), TOL["latent"])
 
 
 def test_stage_c_codebook_indices_bit_exact(nets):
@@ -90,15 +90,15 @@ def test_stage_d_vq_decoder(nets):
     idx, img, feats = pv.decode_nhwc(nhwc(ref["latent"], bf16=False), want_image=True)
     assert torch.equal(idx.cpu(), ref["indices"])
     for i, (a, b) in enumerate(zip(feats, ref["code_feats"])):
-        assert rel(nchw(a), b) < TOL["code_feat%d" % i]
-    assert rel(img.cpu(), ref["vq_rec"]) < TOL["vq_rec"]
+        within(rel(nchw(a), b), TOL["code_feat%d" % i])
+    within(rel(img.cpu(), ref["vq_rec"]), TOL["vq_rec"])
 
 
 def test_stage_e_aft_decoder(nets):
     og, ov, pg, pv, lr, ref = nets
     out = pg.deformable_decoder.forward_nhwc(nhwc(ref["latent"], bf16=False), [nhwc(f) for f in ref["code_feats"]],
                                              [nhwc(f) for f in ref["enc"]["mid_feat"]])
-    assert rel(out.cpu(), ref["out"]) < TOL["aft_out"]
+    within(rel(out.cpu(), ref["out"]), TOL["aft_out"])
 
 
 def correlated_gt(ref_img, db=27.0, seed=5):
@@ -168,10 +168,10 @@ def test_reference_module_surface(nets):
     rb_o, rb_p = og.RRDB.encoder.down[1].block[0], pg.RRDB.encoder.down[1].block[0]
     x = torch.randn(1, 128, 12, 20)
     with torch.no_grad():
-        assert rel(rb_p(x.cuda(), None), rb_o(x)) < 2e-2
+        within(rel(rb_p(x.cuda(), None), rb_o(x)), 2e-2)
         at_o, at_p = og.RRDB.encoder.mid.attn_1, pg.RRDB.encoder.mid.attn_1
         x5 = torch.randn(1, 512, 9, 13)
-        assert rel(at_p(x5.cuda()), at_o(x5)) < 2e-2
+        within(rel(at_p(x5.cuda()), at_o(x5)), 2e-2)
         out_p, lat_p = pg(net_vq=pv, lr=lr.cuda(), z=None, eps_std=0, reverse=True, reverse_with_grad=False)
     assert out_p.shape == ref["out"].shape and lat_p.shape == ref["latent"].shape
     with pytest.raises(NotImplementedError):
@@ -189,7 +189,7 @@ def test_row_a7_vqgan_encode(nets):
         z_p, none = pv.encode(gt.cuda())
         z_n = pv.encode_nhwc(gt.cuda())
     assert none is None and z_p.shape == z_o.shape
-    assert rel(z_p.cpu(), z_o) < 3e-2
+    within(rel(z_p.cpu(), z_o), 3e-2)
     assert torch.equal(nchw(z_n).cpu(), z_p.cpu())
 
 
@@ -209,15 +209,15 @@ def test_stage2_normal_flow_and_nll(nets):
         enc = o2.RRDB(lr)
         z_p, ld_p, lp_p = p2.flowUpsamplerNet.encode_nhwc(nhwc(gt, bf16=False), nhwc(enc["cond_feat"]),
                                                            mean=nhwc(enc["color_map"], bf16=False))
-        assert rel(nchw(z_p), z_o) < 3e-2
+        within(rel(nchw(z_p), z_o), 3e-2)
         assert torch.allclose(ld_p.float().cpu(), ld_o, rtol=2e-2, atol=2.0)
         # whole stage-2 forward through the reference-shaped entry point
         z2, nll_p, _ = p2(gt=gt.cuda(), lr=lr.cuda(), reverse=False)
-    assert rel(z2.cpu(), z_o) < 5e-2
+    within(rel(z2.cpu(), z_o), 5e-2)
     assert torch.allclose(nll_p.cpu(), nll_o, rtol=5e-2, atol=0.05)
     # invertibility on the HIP path itself: decode(encode(x)) == x
     back = p2.flowUpsamplerNet.decode_nhwc(z_p, nhwc(enc["cond_feat"]))
-    assert rel(nchw(back), gt) < 2e-2
+    within(rel(nchw(back), gt), 2e-2)
 
 
 def test_inference_driver_matches_oracle_psnr():
@@ -237,12 +237,21 @@ def test_inference_driver_matches_oracle_psnr():
         for i in range(3):
             outs.append(og(ov, O.preprocess(lows[i]))[0])
     gts = np.stack([correlated_gt(O.postprocess(o, h), seed=50 + i) for i, o in enumerate(outs)])
-    psnrs = infer.run(3, batch=2, pairs=(lows, gts))
     pg = seeded_init_(M.VQLLFLOWDeformable().eval(), 0).cuda()
     pv = seeded_init_(M.VQModel().eval(), 1).cuda()
+    # one attention configuration for the batched and the single-image runs (a different key split is a different summation
+    # order: a handful of near-tie tokens would flip and move the per-image PSNR by ~1 dB -- see check_end_to_end)
+    ops.ATTENTION_KEY_SPLITS_OVERRIDE = 1
+    try:
+        psnrs = infer.run(3, batch=2, pairs=(lows, gts))
+        mines = []
+        for i in range(3):
+            with torch.no_grad():
+                mines.append(pg.reverse_flow_nhwc(pv, O.preprocess(lows[i]).cuda())["out"].cpu())
+    finally:
+        ops.ATTENTION_KEY_SPLITS_OVERRIDE = None
     for i in range(3):
-        with torch.no_grad():
-            mine = pg.reverse_flow_nhwc(pv, O.preprocess(lows[i]).cuda())["out"].cpu()
+        mine = mines[i]
         direct = O.psnr(gts[i] / 255, O.postprocess(mine, h, gts[i]))
         assert abs(psnrs[i] - direct) <= 1e-3, (i, psnrs[i], direct)                       # (a) the driver adds nothing
         ref = O.psnr(gts[i] / 255, O.postprocess(outs[i], h, gts[i]))
@@ -283,20 +292,20 @@ def test_full_size_stage_parity_against_oracle(full_size):
     lr = lr8[:1]
     with torch.no_grad():
         enc = pg.RRDB.forward_nhwc(lr.cuda())
-        assert rel(nchw(enc["cond_feat"]), ref["enc"]["cond_feat"]) < TOL["cond_feat"]
-        assert rel(nchw(enc["color_map"]), ref["enc"]["color_map"]) < TOL["color_map"]
+        within(rel(nchw(enc["cond_feat"]), ref["enc"]["cond_feat"]), TOL["cond_feat"])
+        within(rel(nchw(enc["color_map"]), ref["enc"]["color_map"]), TOL["color_map"])
         for i, (a, b) in enumerate(zip(enc["mid_feat"], ref["enc"]["mid_feat"])):
-            assert rel(nchw(a), b) < TOL["mid_feat%d" % i]
+            within(rel(nchw(a), b), TOL["mid_feat%d" % i])
         z = pg.flowUpsamplerNet.decode_nhwc(nhwc(ref["enc"]["color_map"], bf16=False), nhwc(ref["enc"]["cond_feat"]))
-        assert rel(nchw(z), ref["latent"]) < TOL["latent"]
+        within(rel(nchw(z), ref["latent"]), TOL["latent"])
         idx, img, feats = pv.decode_nhwc(nhwc(ref["latent"], bf16=False), want_image=True)
         assert torch.equal(idx.cpu(), ref["indices"])
         for i, (a, b) in enumerate(zip(feats, ref["code_feats"])):
-            assert rel(nchw(a), b) < TOL["code_feat%d" % i]
-        assert rel(img.cpu(), ref["vq_rec"]) < TOL["vq_rec"]
+            within(rel(nchw(a), b), TOL["code_feat%d" % i])
+        within(rel(img.cpu(), ref["vq_rec"]), TOL["vq_rec"])
         out = pg.deformable_decoder.forward_nhwc(nhwc(ref["latent"], bf16=False), [nhwc(f) for f in ref["code_feats"]],
                                                  [nhwc(f) for f in ref["enc"]["mid_feat"]])
-        assert rel(out.cpu(), ref["out"]) < TOL["aft_out"]
+        within(rel(out.cpu(), ref["out"]), TOL["aft_out"])
 
 
 def test_full_size_end_to_end_against_oracle(full_size, capsys):
@@ -330,7 +339,7 @@ def test_batch_of_8_equals_eight_single_runs(full_size):
         r1s = pg.reverse_flow_nhwc(pv, lr8[:1].cuda())
         n = r1s["indices"].numel()
         assert float((r1s["indices"] == r8["indices"][:n]).float().mean()) > 0.99
-        assert rel(r1s["enc"]["cond_feat"], r8["enc"]["cond_feat"][:1]) < 2e-3
+        within(rel(r1s["enc"]["cond_feat"], r8["enc"]["cond_feat"][:1]), 2e-3)
     # and image 0 of the batch is the image the oracle comparison above was made on
     assert torch.equal(lr8[0], lr8[:1][0])
 
@@ -355,7 +364,7 @@ def test_full_size_attention_and_dcn_properties():
     vt2 = torch.zeros_like(vt)
     vt2[:, :, :N] = v[:, perm].transpose(1, 2)
     got = ops.attention_d512(qk, kp, vt2, N, ldq=2 * C, ldk=C)
-    assert rel(got, ref) < 2e-2
+    within(rel(got, ref), 2e-2)
     # DCN at the full-resolution warp shape, B = 1
     x = torch.randn(1, 420, 620, 128, generator=g).to(torch.bfloat16).cuda()
     w = (torch.randn(128, 128, 3, 3, generator=g) * 0.03).cuda()
@@ -365,4 +374,4 @@ def test_full_size_attention_and_dcn_properties():
     om[:, 72:] = 30.0  # mask logits -> sigmoid = 1
     got = ops.mdcn_forward_nhwc(x, om, ops.PackedDcn(w, b, 4))
     ref = ops.conv2d(x, ops.PackedConv(w, b), out_mode=ops.OUT_NHWC_F32)
-    assert rel(got, ref) < 5e-3
+    within(rel(got, ref), 5e-3)

@@ -3,6 +3,8 @@ references evaluated on the CPU (the oracle of a floating-point kernel is the pl
 import pytest
 import torch
 
+from tolerances import within  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 
 
@@ -26,9 +28,9 @@ def test_gemm_nt(M, N, K, batch, out_dtype):
     ref = torch.einsum("bmk,bnk->bmn", a.double(), b.double()) * 0.5
     c = T.gemm_nt(a.to(_dev()), b.to(_dev()), alpha=0.5, out_dtype=out_dtype)
     tol = 1e-5 if out_dtype == torch.float32 else 4e-3   # bf16 output rounding 2^-9
-    assert _rel(c, ref) < tol
+    within(_rel(c, ref), tol)
     c2 = T.gemm_nt(a.to(_dev()), b.to(_dev()), out=c.clone(), alpha=0.5, accumulate=True)
-    assert _rel(c2, 2 * ref) < (1e-5 if out_dtype == torch.float32 else 8e-3)
+    within(_rel(c2, 2 * ref), (1e-5 if out_dtype == torch.float32 else 8e-3))
 
 
 def test_gemm_nt_strided_views_and_splitk():
@@ -40,13 +42,13 @@ def test_gemm_nt_strided_views_and_splitk():
     big_b = torch.randn(N, K + 32, generator=g).to(torch.bfloat16).to(_dev())
     a, b = big_a[:, 32:32 + K], big_b[:, :K]          # row-strided views, 16-B aligned starts
     ref = a.double().cpu() @ b.double().cpu().T
-    assert _rel(T.gemm_nt(a, b), ref) < 1e-5
+    within(_rel(T.gemm_nt(a, b), ref), 1e-5)
     # split-K as a batch over K slices + deterministic reduce
     ks = K // S
     a3 = a.as_strided((S, M, ks), (ks, a.stride(0), 1))
     b3 = b.as_strided((S, N, ks), (ks, b.stride(0), 1))
     parts = T.gemm_nt(a3, b3)
-    assert _rel(T.reduce_parts(parts), ref) < 1e-5
+    within(_rel(T.reduce_parts(parts), ref), 1e-5)
 
 
 def test_gemm_nt_rejects_bad_shapes():
@@ -108,15 +110,15 @@ def test_conv_autograd(cin, cout, k, stride, ups, act, res, bias):
     rd = _nhwc16(r).requires_grad_(True) if res else None
     out_f32 = cout < 8
     y = A.conv2d(xd, wd, bd, residual=rd, stride=stride, upsample=ups, act=act, out_f32=out_f32)
-    assert _rel(_nchw(y), yr.detach()) < 1e-2
+    within(_rel(_nchw(y), yr.detach()), 1e-2)
     gyd = gy.permute(0, 2, 3, 1).contiguous().to(_dev())
     y.backward(gyd if out_f32 else gyd.to(torch.bfloat16))
-    assert _rel(_nchw(xd.grad), xr.grad) < 1.5e-2
-    assert _rel(wd.grad, wr.grad) < 1.5e-2
+    within(_rel(_nchw(xd.grad), xr.grad), 1.5e-2)
+    within(_rel(wd.grad, wr.grad), 1.5e-2)
     if bias:
-        assert _rel(bd.grad, br.grad) < 1e-2
+        within(_rel(bd.grad, br.grad), 1e-2)
     if res:
-        assert _rel(_nchw(rd.grad), rr.grad) < 1e-2
+        within(_rel(_nchw(rd.grad), rr.grad), 1e-2)
 
 
 def test_small_conv_autograd():
@@ -137,7 +139,7 @@ def test_small_conv_autograd():
     wd, bd = w.to(_dev()).requires_grad_(True), b.to(_dev()).requires_grad_(True)
     y = A.conv2d_small(x.to(_dev()), wd, bd, layout="nchw")
     y.backward(gy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(_dev()))
-    assert _rel(wd.grad, wr.grad) < 1e-2 and _rel(bd.grad, br.grad) < 1e-2
+    within(_rel(wd.grad, wr.grad) < 1e-2 and _rel(bd.grad, br.grad), 1e-2)
     # sigmoid(conv 3->64) on an NHWC fp32 latent with a data gradient (ConditionEncoder.py:41-43,52-53)
     z = torch.randn(B, 3, H, W, generator=g)
     zr = z.clone().requires_grad_(True)
@@ -148,8 +150,8 @@ def test_small_conv_autograd():
     wd2 = w.to(_dev()).requires_grad_(True)
     y2 = A.conv2d_small(zd, wd2, None, layout="nhwc", act="sigmoid")
     y2.backward(gy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(_dev()))
-    assert _rel(zd.grad.cpu().permute(0, 3, 1, 2), zr.grad) < 1.5e-2
-    assert _rel(wd2.grad, wr2.grad) < 1.5e-2
+    within(_rel(zd.grad.cpu().permute(0, 3, 1, 2), zr.grad), 1.5e-2)
+    within(_rel(wd2.grad, wr2.grad), 1.5e-2)
 
 
 @pytest.mark.parametrize("C,swish", [(64, True), (128, False), (512, True)])
@@ -172,9 +174,9 @@ def test_groupnorm_autograd(C, swish):
     gd, bd = gamma.to(_dev()).requires_grad_(True), beta.to(_dev()).requires_grad_(True)
     y = A.groupnorm(xd, gd, bd, swish=swish)
     y.backward(_nhwc16(gy))
-    assert _rel(_nchw(y), yr.detach()) < 1e-2
-    assert _rel(_nchw(xd.grad), xr.grad) < 1.5e-2
-    assert _rel(gd.grad, gr.grad) < 1e-2 and _rel(bd.grad, br.grad) < 1e-2
+    within(_rel(_nchw(y), yr.detach()), 1e-2)
+    within(_rel(_nchw(xd.grad), xr.grad), 1.5e-2)
+    within(_rel(gd.grad, gr.grad) < 1e-2 and _rel(bd.grad, br.grad), 1e-2)
 
 
 @pytest.mark.parametrize("N", [256, 330])
@@ -197,10 +199,10 @@ def test_attention_autograd(N):
     kd, vd = [t.to(torch.bfloat16).to(_dev()).requires_grad_(True) for t in (k, v)]
     o = A.attention(qd, kd, vd)
     o.backward(go.to(torch.bfloat16).to(_dev()))
-    assert _rel(o, outr.detach()) < 1.5e-2
-    assert _rel(qd.grad.float().cpu() * fold, qr.grad) < 3e-2     # d/dq = fold * d/dq'
-    assert _rel(kd.grad, kr.grad) < 3e-2
-    assert _rel(vd.grad, vr.grad) < 2e-2
+    within(_rel(o, outr.detach()), 1.5e-2)
+    within(_rel(qd.grad.float().cpu() * fold, qr.grad), 3e-2)  # d/dq = fold * d/dq'
+    within(_rel(kd.grad, kr.grad), 3e-2)
+    within(_rel(vd.grad, vr.grad), 2e-2)
 
 
 def test_adam_matches_torch():
@@ -279,11 +281,14 @@ def _stage2_pair(seed=2):
 
 
 def _report(errs, med_tol, max_tol):
+    import inspect
+
     vals = sorted(errs.values())
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:6]
     print("n=%d median %.4f max %.4f" % (len(vals), vals[len(vals) // 2], vals[-1]), worst)
-    assert vals[len(vals) // 2] < med_tol, worst
-    assert vals[-1] < max_tol, worst
+    who = inspect.stack()[1].function
+    within(vals[len(vals) // 2], med_tol, tag=who + ":median")
+    within(vals[-1], max_tol, tag=who + ":max")
 
 
 def test_flow_nll_backward_vs_oracle():
@@ -308,9 +313,9 @@ def test_flow_nll_backward_vs_oracle():
     nll = -(ld + lp) / (0.6931471805599453 * h * w)
     assert torch.allclose(nll.detach().float().cpu(), nll_r.detach(), rtol=2e-2, atol=0.05), (nll, nll_r)
     nll.mean().backward()
-    assert _rel(ft_d.grad.float().cpu().permute(0, 3, 1, 2), ft_r.grad) < 8e-2
-    assert _rel(mean_d.grad.cpu().permute(0, 3, 1, 2), mean_r.grad) < 2e-2
-    _report(_param_grad_errors(hip.flowUpsamplerNet, ref.flowUpsamplerNet), 3e-2, 0.2)
+    within(_rel(ft_d.grad.float().cpu().permute(0, 3, 1, 2), ft_r.grad), 8e-2)
+    within(_rel(mean_d.grad.cpu().permute(0, 3, 1, 2), mean_r.grad), 2e-2)
+    _report(_param_grad_errors(hip.flowUpsamplerNet, ref.flowUpsamplerNet), 4.2e-3, 2.4e-2)   # measured 0.0021 / 0.0119
 
 
 def test_stage2_objective_backward_vs_oracle():
@@ -325,7 +330,7 @@ def test_stage2_objective_backward_vs_oracle():
     nll = hip.train_nll(gt.permute(0, 2, 3, 1).contiguous().to(_dev()), lr.to(_dev()))
     assert torch.allclose(nll.detach().float().cpu(), nll_r.detach(), rtol=3e-2, atol=0.05), (nll, nll_r)
     nll.mean().backward()
-    _report(_param_grad_errors(hip, ref), 5e-2, 0.3)
+    _report(_param_grad_errors(hip, ref), 7e-3, 4.9e-2)    # measured: median 0.0035, max 0.0243 over 625 tensors
 
 
 def test_stage2_trainer_steps_reduce_the_loss():
@@ -373,10 +378,10 @@ def test_aft_decoder_backward_vs_oracle():
     (out_r * wgt).sum().backward()
     nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(_dev())
     out = hip.train_nhwc(nh(z), [_nhwc16(c) for c in code], [_nhwc16(e) for e in enc], whole_batch_mean=True)
-    assert _rel(out.detach().cpu().permute(0, 3, 1, 2), out_r.detach()) < 3e-2
+    within(_rel(out.detach().cpu().permute(0, 3, 1, 2), out_r.detach()), 3e-2)
     (out * nh(wgt)).sum().backward()
     errs = _param_grad_errors(hip, ref)
-    _report(errs, 5e-2, 0.3)
+    _report(errs, 5e-2, 0.17)     # measured: median 0.0249, max 0.0847 over 152 tensors (random weights make mean(h)/mean(x_w) ill-conditioned)
     assert any("warp.0.dcn.weight" in k for k in errs) and any(k.startswith("mix.") for k in errs)
 
 
@@ -418,7 +423,12 @@ def test_stage3_trainer_steps_reduce_the_loss():
     assert all(l == l for l in losses) and losses[-1] < losses[0]
     assert torch.equal(frozen, netG.RRDB.encoder.conv_in.weight.detach())        # only deformable_decoder trains
     assert all(p.grad is None for n, p in netG.named_parameters() if not n.startswith("deformable_decoder."))
-    assert all(p.grad is not None for n, p in netG.named_parameters() if n.startswith("deformable_decoder."))
+    # the parameters the reference builds but never calls (deformableDecoder_arch.py:157-180,490-508; conv_out) get no gradient,
+    # every other deformable_decoder parameter does
+    unused = ("deformable_decoder.scale.", "deformable_decoder.bias.", "deformable_decoder.enc.", "deformable_decoder.conv_out.")
+    for n, p in netG.named_parameters():
+        if n.startswith("deformable_decoder."):
+            assert (p.grad is None) == n.startswith(unused), n
 
 
 # ---- stage-3 loss stack (row f1) ---------------------------------------------------------------------------
@@ -433,7 +443,7 @@ def test_msssim_matches_reference_vectors_and_gradient(golden):
     val = losses.msssim(sr, gt, normalize=True)
     val.backward()
     assert abs(float(val.detach()) - float(g["msssim_norm"])) < 2e-5
-    assert _rel(sr.grad.cpu().permute(0, 3, 1, 2), torch.from_numpy(g["grad"])) < 2e-3
+    within(_rel(sr.grad.cpu().permute(0, 3, 1, 2), torch.from_numpy(g["grad"])), 2e-3)
     with torch.no_grad():
         assert abs(float(losses.msssim(sr.detach(), gt)) - float(g["msssim_plain"])) < 2e-5
 
@@ -453,7 +463,7 @@ def test_msssim_small_images_shrinking_window():
     v = losses.msssim(ad, gt.permute(0, 2, 3, 1).contiguous().to(_dev()), normalize=True)
     v.backward()
     assert abs(float(v.detach()) - float(vr.detach())) < 2e-5
-    assert _rel(ad.grad.cpu().permute(0, 3, 1, 2), ar.grad) < 2e-3
+    within(_rel(ad.grad.cpu().permute(0, 3, 1, 2), ar.grad), 2e-3)
 
 
 def test_perceptual_network_vs_oracle():
@@ -476,7 +486,7 @@ def test_perceptual_network_vs_oracle():
     l = hip(ad, nh(gt))
     l.backward()
     assert abs(float(l.detach()) - float(lr_.detach())) < 3e-2 * abs(float(lr_.detach()))
-    assert _rel(ad.grad.cpu().permute(0, 3, 1, 2), ar.grad) < 5e-2
+    within(_rel(ad.grad.cpu().permute(0, 3, 1, 2), ar.grad), 5e-2)
     assert all(p.grad is None for p in hip.parameters())          # the VGG weights are frozen (losses.py:18-19)
 
 
@@ -505,7 +515,7 @@ def test_stage3_total_loss_vs_oracle():
     assert abs(float(terms["ssim_loss"].detach()) - float(sl_r.detach())) < 1e-5
     assert abs(float(terms["percep_loss"].detach()) - float(pl_r.detach())) < 3e-2 * abs(float(pl_r.detach()))
     gref = torch.nan_to_num(rr.grad, nan=0.0)
-    assert _rel(rd.grad.cpu().permute(0, 3, 1, 2), gref) < 2e-2
+    within(_rel(rd.grad.cpu().permute(0, 3, 1, 2), gref), 2e-2)
 
 
 def test_graphed_step_replays_the_eager_step_bit_identically():
@@ -566,7 +576,7 @@ def test_stage2_gradients_match_reference_vectors(golden, fixture, mean_is_gt):
     rel_sk.sort()
     print("norm err median %.4f max %.4f | projection err (of |g|) median %.4f max %.4f"
           % (rel_norm[len(rel_norm) // 2], rel_norm[-1], rel_sk[len(rel_sk) // 2], rel_sk[-1]))
-    assert rel_norm[-1] < 0.05 and rel_sk[-1] < 0.12     # a projection error of eps |g| ~ N(0, eps^2 |g|^2): 4 sigma of 3 %
+    assert rel_norm[-1] < 0.02 and rel_sk[-1] < 0.12     # measured 0.0101 / 0.0582     # a projection error of eps |g| ~ N(0, eps^2 |g|^2): 4 sigma of 3 %
 
 
 def test_conv_autograd_randomised_ragged_sizes():
@@ -601,10 +611,10 @@ def test_conv_autograd_randomised_ragged_sizes():
         y = A.conv2d(xd, wd, bd, stride=stride, upsample=ups)
         y.backward(_nhwc16(gy))
         tag = "case %d: B%d %dx%d k%d s%d ups%d %d->%d" % (case, B, H, W, k, stride, ups, cin, cout)
-        assert _rel(_nchw(y), yr.detach()) < 1e-2, tag
-        assert _rel(_nchw(xd.grad), xr.grad) < 2e-2, tag
-        assert _rel(wd.grad, wr.grad) < 2e-2, tag
-        assert _rel(bd.grad, br.grad) < 1e-2, tag
+        within(_rel(_nchw(y), yr.detach()), 1e-2, tag=tag)
+        within(_rel(_nchw(xd.grad), xr.grad), 2e-2, tag=tag)
+        within(_rel(wd.grad, wr.grad), 2e-2, tag=tag)
+        within(_rel(bd.grad, br.grad), 1e-2, tag=tag)
 
 
 def test_implicit_weight_gradient_equals_im2col_form():
@@ -627,7 +637,7 @@ def test_implicit_weight_gradient_equals_im2col_form():
             finally:
                 A.IMPLICIT_WGRAD = True
             grads.append((wd.grad.clone(), bd.grad.clone()))
-        assert _rel(grads[0][0], grads[1][0]) < 1e-5 and _rel(grads[0][1], grads[1][1]) < 1e-5
+        within(_rel(grads[0][0], grads[1][0]) < 1e-5 and _rel(grads[0][1], grads[1][1]), 1e-5)
 
 
 @pytest.mark.parametrize("stage", ["stage2", "stage3"])

@@ -1,0 +1,17 @@
+#!/usr/bin/env python
+"""Lists the parity bounds of the GPU tests next to what was measured (gpurun_out/parity_measured.json, written by
+tests/tolerances.py::within) and flags any bound looser than 2x the measured maximum."""
+import json
+import os
+import sys
+
+path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out",
+                                                             "parity_measured.json")
+rec = json.load(open(path))
+loose = 0
+for k, v in sorted(rec.items()):
+    ratio = v["limit"] / v["max_measured"] if v["max_measured"] > 0 else float("inf")
+    flag = "  <-- looser than 2x" if ratio > 2.0 and v["limit"] > 1e-6 else ""
+    loose += bool(flag)
+    print("%-110s measured %.3e  bound %.3e  (x%.1f)%s" % (k, v["max_measured"], v["limit"], ratio, flag))
+print("%d bounds, %d looser than 2x measured" % (len(rec), loose))
