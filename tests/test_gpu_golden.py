@@ -12,7 +12,7 @@ from glare_amd import ops
 from glare_amd.modules import encoder_decoder as ED
 from glare_amd.modules.FlowUpsamplerNet import FlowStep, FlowUpsamplerNet
 from glare_amd.synthetic import seeded_init_
-from tolerances import TOL, within
+from tolerances import TOL, TOL_SLICE, within
 
 pytestmark = pytest.mark.gpu
 
@@ -51,7 +51,7 @@ def test_flow_steps_reference_vectors(golden):
     assert np.allclose(logdet.cpu().numpy(), g["fwd_logdet"], rtol=2e-3, atol=2e-2)
     with torch.no_grad():                               # invertibility on the HIP path itself
         back, _, _ = net.encode_nhwc(rev, ft)
-    within(rel(ops.nhwc_to_nchw(back), g["z"]), 2e-3)
+    within(rel(ops.nhwc_to_nchw(back), g["z"]), 1.5e-7)   # measured 7.75e-08
 
 
 def test_blocks_reference_vectors(golden):
@@ -80,12 +80,12 @@ def test_graph_reference_vectors(golden):
         enc = pg.RRDB.forward_nhwc(torch.from_numpy(g["lr"]).cuda())
         within(rel(ops.nhwc_to_nchw(enc["cond_feat"]), g["cond_feat"]), TOL["cond_feat"])
         within(rel(ops.nhwc_to_nchw(enc["color_map"]), g["color_map"]), TOL["color_map"])
-        within(rel(ops.nhwc_to_nchw(enc["mid_feat"][0])[:, :8], g["mid0"]), 2 * TOL["mid_feat0"])  # an 8-channel slice: noisier
-        within(rel(ops.nhwc_to_nchw(enc["mid_feat"][1])[:, :8], g["mid1"]), 2 * TOL["mid_feat1"])
+        within(rel(ops.nhwc_to_nchw(enc["mid_feat"][0])[:, :8], g["mid0"]), TOL_SLICE["mid0"])
+        within(rel(ops.nhwc_to_nchw(enc["mid_feat"][1])[:, :8], g["mid1"]), TOL_SLICE["mid1"])
         z = pg.flowUpsamplerNet.decode_nhwc(nhwc(g["color_map"], bf16=False), nhwc(g["cond_feat"]))
         within(rel(ops.nhwc_to_nchw(z), g["latent"]), TOL["latent"])
         idx, img, feats = pv.decode_nhwc(nhwc(g["latent"], bf16=False), want_image=True)
         assert np.array_equal(idx.cpu().numpy(), g["idx"])                                # bit-exact on the reference's latent
         within(rel(img, g["rec"]), TOL["vq_rec"])
-        within(rel(ops.nhwc_to_nchw(feats[0])[:, :8], g["code0"]), 2 * TOL["code_feat0"])
-        within(rel(ops.nhwc_to_nchw(feats[1])[:, :8], g["code1"]), 2 * TOL["code_feat1"])
+        within(rel(ops.nhwc_to_nchw(feats[0])[:, :8], g["code0"]), TOL_SLICE["code0"])
+        within(rel(ops.nhwc_to_nchw(feats[1])[:, :8], g["code1"]), TOL_SLICE["code1"])

@@ -168,10 +168,10 @@ def test_reference_module_surface(nets):
     rb_o, rb_p = og.RRDB.encoder.down[1].block[0], pg.RRDB.encoder.down[1].block[0]
     x = torch.randn(1, 128, 12, 20)
     with torch.no_grad():
-        within(rel(rb_p(x.cuda(), None), rb_o(x)), 2e-2)
+        within(rel(rb_p(x.cuda(), None), rb_o(x)), 7.4e-3)   # measured 3.86e-03
         at_o, at_p = og.RRDB.encoder.mid.attn_1, pg.RRDB.encoder.mid.attn_1
         x5 = torch.randn(1, 512, 9, 13)
-        within(rel(at_p(x5.cuda()), at_o(x5)), 2e-2)
+        within(rel(at_p(x5.cuda()), at_o(x5)), 4.5e-3)   # measured 2.35e-03
         out_p, lat_p = pg(net_vq=pv, lr=lr.cuda(), z=None, eps_std=0, reverse=True, reverse_with_grad=False)
     assert out_p.shape == ref["out"].shape and lat_p.shape == ref["latent"].shape
     with pytest.raises(NotImplementedError):
@@ -209,15 +209,15 @@ def test_stage2_normal_flow_and_nll(nets):
         enc = o2.RRDB(lr)
         z_p, ld_p, lp_p = p2.flowUpsamplerNet.encode_nhwc(nhwc(gt, bf16=False), nhwc(enc["cond_feat"]),
                                                            mean=nhwc(enc["color_map"], bf16=False))
-        within(rel(nchw(z_p), z_o), 3e-2)
+        within(rel(nchw(z_p), z_o), 2.0e-3)   # measured 1.05e-03
         assert torch.allclose(ld_p.float().cpu(), ld_o, rtol=2e-2, atol=2.0)
         # whole stage-2 forward through the reference-shaped entry point
         z2, nll_p, _ = p2(gt=gt.cuda(), lr=lr.cuda(), reverse=False)
-    within(rel(z2.cpu(), z_o), 5e-2)
+    within(rel(z2.cpu(), z_o), 2.2e-3)   # measured 1.13e-03
     assert torch.allclose(nll_p.cpu(), nll_o, rtol=5e-2, atol=0.05)
     # invertibility on the HIP path itself: decode(encode(x)) == x
     back = p2.flowUpsamplerNet.decode_nhwc(z_p, nhwc(enc["cond_feat"]))
-    within(rel(nchw(back), gt), 2e-2)
+    within(rel(nchw(back), gt), 1.5e-3)   # measured 7.58e-04
 
 
 def test_inference_driver_matches_oracle_psnr():
@@ -226,7 +226,7 @@ def test_inference_driver_matches_oracle_psnr():
         isolates the driver -- per-image PSNR equal to 1e-3 dB;
     (b) the oracle network run one image at a time (the reference's B = 1 loop), with a ground truth correlated with the
         output (oracle output + 27 dB noise): the accumulated model difference, bounded at 2x what was measured."""
-    from glare_amd import infer
+    from glare_amd import harness, infer
 
     h, w = 60, 92
     lows = synthetic_lowlight(3, h, w, seed=77)
@@ -246,8 +246,9 @@ def test_inference_driver_matches_oracle_psnr():
         psnrs = infer.run(3, batch=2, pairs=(lows, gts))
         mines = []
         for i in range(3):
-            with torch.no_grad():
-                mines.append(pg.reverse_flow_nhwc(pv, O.preprocess(lows[i]).cuda())["out"].cpu())
+            with torch.no_grad():     # the driver's own device pre-processing: its log() differs from numpy's in the last bit,
+                lr_i = harness.preprocess_device(torch.from_numpy(np.ascontiguousarray(lows[i:i + 1])).cuda())   # which flips tokens
+                mines.append(pg.reverse_flow_nhwc(pv, lr_i)["out"].cpu())
     finally:
         ops.ATTENTION_KEY_SPLITS_OVERRIDE = None
     for i in range(3):
@@ -364,7 +365,7 @@ def test_full_size_attention_and_dcn_properties():
     vt2 = torch.zeros_like(vt)
     vt2[:, :, :N] = v[:, perm].transpose(1, 2)
     got = ops.attention_d512(qk, kp, vt2, N, ldq=2 * C, ldk=C)
-    within(rel(got, ref), 2e-2)
+    within(rel(got, ref), 6.1e-3)   # measured 3.17e-03
     # DCN at the full-resolution warp shape, B = 1
     x = torch.randn(1, 420, 620, 128, generator=g).to(torch.bfloat16).cuda()
     w = (torch.randn(128, 128, 3, 3, generator=g) * 0.03).cuda()
@@ -374,4 +375,4 @@ def test_full_size_attention_and_dcn_properties():
     om[:, 72:] = 30.0  # mask logits -> sigmoid = 1
     got = ops.mdcn_forward_nhwc(x, om, ops.PackedDcn(w, b, 4))
     ref = ops.conv2d(x, ops.PackedConv(w, b), out_mode=ops.OUT_NHWC_F32)
-    within(rel(got, ref), 5e-3)
+    within(rel(got, ref), 3.2e-3)   # measured 1.66e-03

@@ -42,13 +42,13 @@ def test_gemm_nt_strided_views_and_splitk():
     big_b = torch.randn(N, K + 32, generator=g).to(torch.bfloat16).to(_dev())
     a, b = big_a[:, 32:32 + K], big_b[:, :K]          # row-strided views, 16-B aligned starts
     ref = a.double().cpu() @ b.double().cpu().T
-    within(_rel(T.gemm_nt(a, b), ref), 1e-5)
+    within(_rel(T.gemm_nt(a, b), ref), 3.6e-7)   # measured 1.85e-07
     # split-K as a batch over K slices + deterministic reduce
     ks = K // S
     a3 = a.as_strided((S, M, ks), (ks, a.stride(0), 1))
     b3 = b.as_strided((S, N, ks), (ks, b.stride(0), 1))
     parts = T.gemm_nt(a3, b3)
-    within(_rel(T.reduce_parts(parts), ref), 1e-5)
+    within(_rel(T.reduce_parts(parts), ref), 1.6e-7)   # measured 8.15e-08
 
 
 def test_gemm_nt_rejects_bad_shapes():
@@ -110,13 +110,13 @@ def test_conv_autograd(cin, cout, k, stride, ups, act, res, bias):
     rd = _nhwc16(r).requires_grad_(True) if res else None
     out_f32 = cout < 8
     y = A.conv2d(xd, wd, bd, residual=rd, stride=stride, upsample=ups, act=act, out_f32=out_f32)
-    within(_rel(_nchw(y), yr.detach()), 1e-2)
+    within(_rel(_nchw(y), yr.detach()), 4.3e-3)   # measured 2.24e-03
     gyd = gy.permute(0, 2, 3, 1).contiguous().to(_dev())
     y.backward(gyd if out_f32 else gyd.to(torch.bfloat16))
-    within(_rel(_nchw(xd.grad), xr.grad), 1.5e-2)
-    within(_rel(wd.grad, wr.grad), 1.5e-2)
+    within(_rel(_nchw(xd.grad), xr.grad), 5.8e-3)   # measured 3.02e-03
+    within(_rel(wd.grad, wr.grad), 4.7e-3)   # measured 2.44e-03
     if bias:
-        within(_rel(bd.grad, br.grad), 1e-2)
+        within(_rel(bd.grad, br.grad), 3.3e-3)   # measured 1.70e-03
     if res:
         within(_rel(_nchw(rd.grad), rr.grad), 1e-2)
 
@@ -139,7 +139,8 @@ def test_small_conv_autograd():
     wd, bd = w.to(_dev()).requires_grad_(True), b.to(_dev()).requires_grad_(True)
     y = A.conv2d_small(x.to(_dev()), wd, bd, layout="nchw")
     y.backward(gy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(_dev()))
-    within(_rel(wd.grad, wr.grad) < 1e-2 and _rel(bd.grad, br.grad), 1e-2)
+    within(_rel(wd.grad, wr.grad), 6e-3)
+    within(_rel(bd.grad, br.grad), 1e-6)   # measured 5.35e-09 (a plain fp32 sum)
     # sigmoid(conv 3->64) on an NHWC fp32 latent with a data gradient (ConditionEncoder.py:41-43,52-53)
     z = torch.randn(B, 3, H, W, generator=g)
     zr = z.clone().requires_grad_(True)
@@ -150,8 +151,8 @@ def test_small_conv_autograd():
     wd2 = w.to(_dev()).requires_grad_(True)
     y2 = A.conv2d_small(zd, wd2, None, layout="nhwc", act="sigmoid")
     y2.backward(gy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(_dev()))
-    within(_rel(zd.grad.cpu().permute(0, 3, 1, 2), zr.grad), 1.5e-2)
-    within(_rel(wd2.grad, wr2.grad), 1.5e-2)
+    within(_rel(zd.grad.cpu().permute(0, 3, 1, 2), zr.grad), 5.5e-3)   # measured 2.85e-03
+    within(_rel(wd2.grad, wr2.grad), 5.6e-3)   # measured 2.90e-03
 
 
 @pytest.mark.parametrize("C,swish", [(64, True), (128, False), (512, True)])
@@ -174,9 +175,10 @@ def test_groupnorm_autograd(C, swish):
     gd, bd = gamma.to(_dev()).requires_grad_(True), beta.to(_dev()).requires_grad_(True)
     y = A.groupnorm(xd, gd, bd, swish=swish)
     y.backward(_nhwc16(gy))
-    within(_rel(_nchw(y), yr.detach()), 1e-2)
-    within(_rel(_nchw(xd.grad), xr.grad), 1.5e-2)
-    within(_rel(gd.grad, gr.grad) < 1e-2 and _rel(bd.grad, br.grad), 1e-2)
+    within(_rel(_nchw(y), yr.detach()), 3.2e-3)   # measured 1.67e-03
+    within(_rel(_nchw(xd.grad), xr.grad), 3.2e-3)   # measured 1.67e-03
+    within(_rel(gd.grad, gr.grad), 6e-3)
+    within(_rel(bd.grad, br.grad), 1e-6)   # measured 2.35e-07
 
 
 @pytest.mark.parametrize("N", [256, 330])
@@ -199,10 +201,10 @@ def test_attention_autograd(N):
     kd, vd = [t.to(torch.bfloat16).to(_dev()).requires_grad_(True) for t in (k, v)]
     o = A.attention(qd, kd, vd)
     o.backward(go.to(torch.bfloat16).to(_dev()))
-    within(_rel(o, outr.detach()), 1.5e-2)
-    within(_rel(qd.grad.float().cpu() * fold, qr.grad), 3e-2)  # d/dq = fold * d/dq'
-    within(_rel(kd.grad, kr.grad), 3e-2)
-    within(_rel(vd.grad, vr.grad), 2e-2)
+    within(_rel(o, outr.detach()), 5.3e-3)   # measured 2.77e-03
+    within(_rel(qd.grad.float().cpu() * fold, qr.grad), 6.3e-3)  # d/dq = fold * d/dq'   # measured 3.28e-03
+    within(_rel(kd.grad, kr.grad), 7.0e-3)   # measured 3.68e-03
+    within(_rel(vd.grad, vr.grad), 5.5e-3)   # measured 2.85e-03
 
 
 def test_adam_matches_torch():
@@ -314,7 +316,7 @@ def test_flow_nll_backward_vs_oracle():
     assert torch.allclose(nll.detach().float().cpu(), nll_r.detach(), rtol=2e-2, atol=0.05), (nll, nll_r)
     nll.mean().backward()
     within(_rel(ft_d.grad.float().cpu().permute(0, 3, 1, 2), ft_r.grad), 8e-2)
-    within(_rel(mean_d.grad.cpu().permute(0, 3, 1, 2), mean_r.grad), 2e-2)
+    within(_rel(mean_d.grad.cpu().permute(0, 3, 1, 2), mean_r.grad), 1.6e-3)   # measured 8.16e-04
     _report(_param_grad_errors(hip.flowUpsamplerNet, ref.flowUpsamplerNet), 4.2e-3, 2.4e-2)   # measured 0.0021 / 0.0119
 
 
@@ -378,7 +380,7 @@ def test_aft_decoder_backward_vs_oracle():
     (out_r * wgt).sum().backward()
     nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(_dev())
     out = hip.train_nhwc(nh(z), [_nhwc16(c) for c in code], [_nhwc16(e) for e in enc], whole_batch_mean=True)
-    within(_rel(out.detach().cpu().permute(0, 3, 1, 2), out_r.detach()), 3e-2)
+    within(_rel(out.detach().cpu().permute(0, 3, 1, 2), out_r.detach()), 9.1e-3)   # measured 4.78e-03
     (out * nh(wgt)).sum().backward()
     errs = _param_grad_errors(hip, ref)
     _report(errs, 5e-2, 0.17)     # measured: median 0.0249, max 0.0847 over 152 tensors (random weights make mean(h)/mean(x_w) ill-conditioned)
@@ -443,7 +445,7 @@ def test_msssim_matches_reference_vectors_and_gradient(golden):
     val = losses.msssim(sr, gt, normalize=True)
     val.backward()
     assert abs(float(val.detach()) - float(g["msssim_norm"])) < 2e-5
-    within(_rel(sr.grad.cpu().permute(0, 3, 1, 2), torch.from_numpy(g["grad"])), 2e-3)
+    within(_rel(sr.grad.cpu().permute(0, 3, 1, 2), torch.from_numpy(g["grad"])), 2.3e-5)   # measured 1.21e-05
     with torch.no_grad():
         assert abs(float(losses.msssim(sr.detach(), gt)) - float(g["msssim_plain"])) < 2e-5
 
@@ -463,7 +465,7 @@ def test_msssim_small_images_shrinking_window():
     v = losses.msssim(ad, gt.permute(0, 2, 3, 1).contiguous().to(_dev()), normalize=True)
     v.backward()
     assert abs(float(v.detach()) - float(vr.detach())) < 2e-5
-    within(_rel(ad.grad.cpu().permute(0, 3, 1, 2), ar.grad), 2e-3)
+    within(_rel(ad.grad.cpu().permute(0, 3, 1, 2), ar.grad), 1.8e-5)   # measured 9.03e-06
 
 
 def test_perceptual_network_vs_oracle():
@@ -486,7 +488,7 @@ def test_perceptual_network_vs_oracle():
     l = hip(ad, nh(gt))
     l.backward()
     assert abs(float(l.detach()) - float(lr_.detach())) < 3e-2 * abs(float(lr_.detach()))
-    within(_rel(ad.grad.cpu().permute(0, 3, 1, 2), ar.grad), 5e-2)
+    within(_rel(ad.grad.cpu().permute(0, 3, 1, 2), ar.grad), 2.0e-2)   # measured 1.03e-02
     assert all(p.grad is None for p in hip.parameters())          # the VGG weights are frozen (losses.py:18-19)
 
 
@@ -515,7 +517,7 @@ def test_stage3_total_loss_vs_oracle():
     assert abs(float(terms["ssim_loss"].detach()) - float(sl_r.detach())) < 1e-5
     assert abs(float(terms["percep_loss"].detach()) - float(pl_r.detach())) < 3e-2 * abs(float(pl_r.detach()))
     gref = torch.nan_to_num(rr.grad, nan=0.0)
-    within(_rel(rd.grad.cpu().permute(0, 3, 1, 2), gref), 2e-2)
+    within(_rel(rd.grad.cpu().permute(0, 3, 1, 2), gref), 2.4e-5)   # measured 1.25e-05
 
 
 def test_graphed_step_replays_the_eager_step_bit_identically():
@@ -611,10 +613,10 @@ def test_conv_autograd_randomised_ragged_sizes():
         y = A.conv2d(xd, wd, bd, stride=stride, upsample=ups)
         y.backward(_nhwc16(gy))
         tag = "case %d: B%d %dx%d k%d s%d ups%d %d->%d" % (case, B, H, W, k, stride, ups, cin, cout)
-        within(_rel(_nchw(y), yr.detach()), 1e-2, tag=tag)
-        within(_rel(_nchw(xd.grad), xr.grad), 2e-2, tag=tag)
-        within(_rel(wd.grad, wr.grad), 2e-2, tag=tag)
-        within(_rel(bd.grad, br.grad), 1e-2, tag=tag)
+        within(_rel(_nchw(y), yr.detach()), 3.3e-3, tag=tag)   # measured 1.73e-03
+        within(_rel(_nchw(xd.grad), xr.grad), 4.7e-3, tag=tag)   # measured 2.44e-03
+        within(_rel(wd.grad, wr.grad), 3.6e-7, tag=tag)   # measured 1.88e-07
+        within(_rel(bd.grad, br.grad), 2.8e-8, tag=tag)   # measured 1.47e-08
 
 
 def test_implicit_weight_gradient_equals_im2col_form():
@@ -637,7 +639,7 @@ def test_implicit_weight_gradient_equals_im2col_form():
             finally:
                 A.IMPLICIT_WGRAD = True
             grads.append((wd.grad.clone(), bd.grad.clone()))
-        within(_rel(grads[0][0], grads[1][0]) < 1e-5 and _rel(grads[0][1], grads[1][1]), 1e-5)
+        within(_rel(grads[0][0], grads[1][0]) < 1e-5 and _rel(grads[0][1], grads[1][1]), 4.4e-8)   # measured 2.27e-08
 
 
 @pytest.mark.parametrize("stage", ["stage2", "stage3"])

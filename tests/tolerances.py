@@ -1,14 +1,17 @@
 """Per-stage parity bounds shared by the GPU graph / golden tests (bf16 activations between kernels, fp32 accumulation)."""
-# relative L2 error of each stage output on the oracle's inputs: measured (20x36 / 400x600) -> bound (<= 2x)
-TOL = {"cond_feat": 4.5e-3,    # 2.1e-3 / 2.1e-3
-       "color_map": 2.0e-2,    # 9.7e-3 / 9.1e-3
-       "mid_feat0": 6.5e-3,    # 3.1e-3 / 3.1e-3
-       "mid_feat1": 1.25e-2,   # 6.1e-3 / 6.2e-3
-       "latent": 5.5e-3,       # 2.8e-3 / 2.4e-3   (flow reverse on the oracle's color_map / cond_feat)
-       "code_feat0": 2.1e-2,   # 1.03e-2 / 1.04e-2
-       "code_feat1": 3.4e-2,   # 1.60e-2 / 1.67e-2
-       "vq_rec": 3.6e-2,       # 1.61e-2 / 1.76e-2
+# relative L2 error of each stage output on its reference inputs; bound = 2x the LARGEST value measured on MI355X over the
+# configurations that use it (20x36 and 400x600 vs the oracle, 4x12 vs the reference's graph.npz; gpurun_out/parity_measured.json)
+TOL = {"cond_feat": 4.2e-3,    # 2.09e-3 / 2.12e-3 / 2.07e-3
+       "color_map": 1.9e-2,    # 9.7e-3 / 9.1e-3
+       "mid_feat0": 6.2e-3,    # 3.1e-3 / 3.1e-3
+       "mid_feat1": 1.23e-2,   # 6.1e-3 / 6.2e-3
+       "latent": 5.5e-3,       # 2.8e-3 / 2.4e-3 / 1.5e-3   (flow reverse on the reference side's color_map / cond_feat)
+       "code_feat0": 2.07e-2,  # 1.03e-2 / 1.04e-2
+       "code_feat1": 3.3e-2,   # 1.60e-2 / 1.67e-2
+       "vq_rec": 3.5e-2,       # 1.73e-2 / 1.76e-2
        "aft_out": 2.4e-2}      # 1.21e-2 / 0.82e-2
+# 8-channel slices of the wide feature maps (graph.npz stores [:, :8]): the error of a slice, measured on the fixture
+TOL_SLICE = {"mid0": 6.2e-3, "mid1": 1.3e-2, "code0": 1.7e-2, "code1": 3.8e-2}   # 3.1e-3 / 6.6e-3 / 8.6e-3 / 1.95e-2
 
 
 # ---- measured-vs-bound bookkeeping ---------------------------------------------------------------------------------
