@@ -699,6 +699,751 @@ __global__ __launch_bounds__(512, 1) void attn8w_fwd_kernel(const AttnParams p) 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Shared-K/V form (attn_kv_fwd_kernel): out[i] = sum_j softmax_j(q'_i . x_j) x_j  -- keys AND values are the same tensor x.
+//
+// AttnBlock (encoder_decoder.py:168-192) is single-head self-attention on ONE input h = GroupNorm(x):
+//     s_ij = (Wq h_i + bq) . (Wk h_j + bk),   out_i = Wp (sum_j P_ij (Wv h_j + bv)) + bp
+// Every term of s_ij that does not depend on j cancels in softmax_j, so s_ij ~ (Wk^T (Wq h_i + bq)) . h_j: the key projection
+// folds into the query projection (q'_i = Wk^T Wq h_i + Wk^T bq), and because softmax rows sum to 1 the value projection
+// commutes with the average (sum_j P_ij (Wv h_j + bv) = Wv (sum_j P_ij h_j) + bv) and folds into proj_out.  What is left in the
+// N^2 part is attention with K = V = h:
+//   * ONE tile per 32 keys streams through LDS instead of two (32 KB instead of 64 KB per tile: 8 LDS-DMA pieces per wave
+//     and tile instead of 16 -- the issue cost of those pieces was ~25 % of the two-tensor kernel), and h is read from HBM / L2
+//     once per query block instead of K and V^T;
+//   * the K and V projections (two of the block's four 512x512 1x1 convs) disappear, and so does the transposed V^T copy.
+// QK^T reads the tile as before (K-row A-fragments, ds_read_b128).  P.V needs the same tile TRANSPOSED (A = V^T rows = tile
+// columns): gfx950's ds_read_b64_tr_b16 delivers exactly that from the row-major image -- per 16-lane group a 4-key x 16-d block,
+// two reads per A-fragment.  The XOR swizzle f(key) = ((key & 3) << 2) | ((key >> 2) & 3) on the 16-B chunk index keeps BOTH
+// read patterns bank-conflict free (b128: 16 lanes of a group have distinct key & 15, f is a bijection; tr_b16: the 4 keys x 2
+// d-halves of a 32-lane pass fall into 8 distinct 32-B slots of the 256-B bank row).
+// Everything else (one wave per SIMD, transposed products, lane-local online softmax, deferred rescale, split keys) is the
+// structure of attn_fwd_kernel above.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+#ifndef ATTNKV_PV_AHEAD
+#define ATTNKV_PV_AHEAD 1    // P.V fragment reads issued this many 4-MFMA groups ahead (1 or 2)
+#endif
+#ifndef ATTNKV_PIPELINED
+#define ATTNKV_PIPELINED 0   // 1: attn_kv_pipe_kernel (three-stage software pipeline); 0: attn_kv_fwd_kernel (sequential phases)
+#endif
+#ifndef ATTNKV_DMA_PHASE
+#define ATTNKV_DMA_PHASE 0   // 0: the tile's 8 DMA pieces go one per QK^T group; 1: one per P.V group
+#endif
+
+__device__ __forceinline__ int kv_swz(int key) { return ((key & 3) << 2) | ((key >> 2) & 3); }
+
+// ds_read_b64_tr_b16 / its wait as free functions: clang rejects asm operands that are lambda captures
+template <int OFF>
+__device__ __forceinline__ void tr_read_b64(u32x2& dst, int addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait8(u32x2 (&f)[8]) {   // ties the wait to the 8 destinations: nothing that reads them moves above
+  asm volatile("s_waitcnt lgkmcnt(%8)"
+               : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7])
+               : "i"(N));
+}
+
+__global__ __launch_bounds__(AT_THREADS, 1) void attn_kv_fwd_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  u32x4* lKV = reinterpret_cast<u32x4*>(smem);   // [2][KCH]: tile image [32 keys][64 chunks], chunk c of key r at r*64 + (c ^ f(r))
+
+  int bid = blockIdx.x;
+  {
+    const int n = p.n_blocks, q = n / 8, r = n % 8, xcd = bid % 8, kk = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kk;
+  }
+  const int qb = bid % p.n_qblocks, ksplit = (bid / p.n_qblocks) % p.key_splits, b = bid / (p.n_qblocks * p.key_splits);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ql = lane & 31, hi = lane >> 5;
+  const int qrow = qb * BM + wave * 32 + ql;
+  const bool q_ok = qrow < p.N;
+
+  bf16x8 qf[HD / 16];   // Q^T B-fragments: lane (q, hi) holds Q[q][16*ks + 8*hi .. +8]
+  {
+    const bf16_t* qp = p.q + ((size_t)b * p.N + (q_ok ? qrow : 0)) * p.ldq + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks) {
+      u32x4 v = *reinterpret_cast<const u32x4*>(qp + ks * 16);
+      if (!q_ok) v = u32x4{0u, 0u, 0u, 0u};
+      qf[ks] = __builtin_bit_cast(bf16x8, v);
+    }
+  }
+  f32x16 o[HD / 32];
+#pragma unroll
+  for (int i = 0; i < HD / 32; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+
+  const int n_tiles = (p.N + BN - 1) / BN;
+  const int t_begin = (int)((long long)n_tiles * ksplit / p.key_splits), t_end = (int)((long long)n_tiles * (ksplit + 1) / p.key_splits);
+  const bf16_t* kbase = p.k + (size_t)b * p.N * p.ldk;
+  // rows beyond N fall outside the descriptor's range and arrive as zeros: their scores are masked, their values are zero
+  const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(kbase), 0, (int)((((long long)p.N - 1) * p.ldk + HD) * 2), 0x00020000);
+  // piece i of this wave = key row r = wave + 4*i (1 KB): lane L writes LDS chunk r*64 + L and therefore fetches source chunk
+  // L ^ f(r); f(r) = (wave << 2) | (i & 3) for these rows
+  const int lane16w = (lane ^ (wave << 2)) * 16;
+  auto issue_piece = [&](auto ic, int tile, int buf) {
+    constexpr int i = decltype(ic)::value;
+    const int r = wave + 4 * i;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(krsrc, (__attribute__((address_space(3))) void*)(lKV + buf * KCH + r * 64), 16,
+                                             lane16w ^ ((i & 3) * 16), (tile * BN + r) * p.ldk * 2, 0, 0);
+  };
+
+  // QK^T: K row fetched for MFMA row slot ql: bits 2 and 3 swapped, so that output register r of lane (q, hi) is key
+  // 16*(r>>3) + 8*hi + (r&7) -- the P^T B-fragment order (as in attn_fwd_kernel)
+  const int krow = (ql & 0x13) | ((ql & 4) << 1) | ((ql & 8) >> 1);
+  const int kf = kv_swz(krow);
+  int kofs[8];          // K frag (ks): kofs[ks & 7] + (ks >> 3) * 256 + buf * 32 KB
+#pragma unroll
+  for (int bb = 0; bb < 8; ++bb) kofs[bb] = (krow * 64 + ((2 * bb + hi) ^ kf)) * 16;
+  // P.V: transpose reads.  For MFMA (dt, kstep) and half h (keys 8*hi + 4*h .. +3 of the k-step), lane i of a 16-lane group
+  // supplies the address of 4 consecutive d of key row 8*hi + 4*h + (i >> 2): d = 32*dt + 16*g4 + 4*(i & 3); it receives
+  // V[those 4 keys][d = 32*dt + 16*g4 + i].   address = vofs[dt & 3][h] + kstep * 16 KB + (dt >> 2) * 256 + buf * 32 KB
+  int vofs[4][2];
+  {
+    const int i16 = lane & 15, g4 = (lane >> 4) & 1;
+#pragma unroll
+    for (int dtl = 0; dtl < 4; ++dtl)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int key = 8 * hi + 4 * h + (i16 >> 2);
+        const int chunk = 4 * dtl + 2 * g4 + ((i16 & 3) >> 1);
+        vofs[dtl][h] = key * 1024 + ((chunk ^ kv_swz(key)) * 16) + (i16 & 1) * 8;
+      }
+  }
+
+#ifdef ATTNKV_PROFILE   // per-phase cycle sums of wave 0 of workgroup 0 (s_memtime; costs ~10 %): tools/kbench.py KB_PROF=1
+  unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, pt = __builtin_readcyclecounter();
+#define PROF_MARK(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); pc[i] += t_ - pt; pt = t_; } while (0)
+#else
+#define PROF_MARK(i) do {} while (0)
+#endif
+  auto tile_body = [&](auto bufc, int tile) {
+    constexpr int BUF = decltype(bufc)::value;
+    PROF_MARK(0);                                  // loop overhead
+#ifndef ATTN_ABLATE_NOBARRIER
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#endif
+    PROF_MARK(1);                                  // wait + barrier
+    const int nxt = min(tile + 1, t_end - 1);  // last tile: a redundant reload keeps the loop branch-free
+    const char* tb = smem + BUF * KCH * 16;
+    bf16x8 fr[3][4];
+    auto ldk = [&](auto gc, bf16x8(&f)[4]) {
+      constexpr int g = decltype(gc)::value;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int ks = 4 * g + e;
+        f[e] = *reinterpret_cast<const bf16x8*>(tb + kofs[ks & 7] + (ks >> 3) * 256);
+      }
+    };
+    // P.V fragments: transpose reads in inline asm.  Through the builtin (__builtin_amdgcn_ds_read_tr16_b64) hipcc cannot tell
+    // that the read does not alias the LDS-DMA writes in flight into the OTHER buffer and puts `s_waitcnt vmcnt(0)` in front of
+    // every transpose read that follows a DMA issue (measured: +800 cycles per tile, the whole DMA latency exposed twice).  An asm
+    // read is invisible to that pass -- and to hipcc's lgkmcnt bookkeeping, so the P.V phase counts its own reads: they are the
+    // only LDS operations between the end of QK^T and the next barrier, issued one group (8 reads) ahead, retired in order.
+    auto ldv1 = [&](auto gc, auto ic, u32x2(&f)[8]) {   // read i of group g: f[i], i = 2*e + h
+      constexpr int g = decltype(gc)::value, i = decltype(ic)::value, e = i >> 1;
+      constexpr int dt = 2 * g + (e >> 1), ks = e & 1;
+      tr_read_b64<BUF * KCH * 16 + ks * 16384 + (dt >> 2) * 256>(f[i], vofs[dt & 3][i & 1]);
+    };
+    auto ldv = [&](auto gc, u32x2(&f)[8]) {   // group g: d-tiles 2g, 2g+1; f[2*e + h], e = (dt & 1) * 2 + kstep, h = key half
+      static_for<8>([&](auto ic) { ldv1(gc, ic, f); });
+    };
+    auto wait_v = [&](auto nc, u32x2(&f)[8]) {   // the 8 reads of `f` have landed once at most N newer LDS operations are in flight
+      lgkm_wait8<decltype(nc)::value>(f);
+    };
+    auto vfrag = [&](const u32x2(&f)[8], int e) {
+      return __builtin_bit_cast(bf16x8, u32x4{f[2 * e][0], f[2 * e][1], f[2 * e + 1][0], f[2 * e + 1][1]});
+    };
+#if ATTNKV_PV_AHEAD == 2
+    u32x2 vf[3][8];   // fragments two groups ahead: 16 reads in flight behind the group being consumed, one more than lgkmcnt counts
+#else
+    u32x2 vf[2][8];
+#endif
+
+    // ---- S^T = K . Q^T
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    ldk(std::integral_constant<int, 0>{}, fr[0]);
+    ldk(std::integral_constant<int, 1>{}, fr[1]);
+    static_for<8>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      if constexpr (g + 2 < 8) ldk(std::integral_constant<int, g + 2>{}, fr[(g + 2) % 3]);
+#if !defined(ATTN_ABLATE_NODMA) && !ATTNKV_DMA_PHASE
+      issue_piece(gc, nxt, BUF ^ 1);
+#endif
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g % 3][e], qf[4 * g + e], s, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    PROF_MARK(2);                                  // QK^T
+    ldv(std::integral_constant<int, 0>{}, vf[0]);  // the first P.V fragments fly under the softmax
+#if ATTNKV_PV_AHEAD == 2
+    ldv(std::integral_constant<int, 1>{}, vf[1]);
+#endif
+    if (tile == n_tiles - 1) {  // mask keys beyond N
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kv = tile * BN + 16 * (r >> 3) + 8 * hi + (r & 7);
+        if (kv >= p.N) s[r] = -__builtin_inff();
+      }
+    }
+#ifndef ATTN_ABLATE_NOSOFTMAX   // timing ablation only: wrong results
+    // ---- online softmax, lane-local per query column
+    float mx = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+    {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = fmaxf(mx, __uint_as_float(hi ? sw[0] : sw[1]));
+    }
+    if (__any(mx > m_run + RESCALE_THR)) {  // wave-uniform: rescale everything still at the old max
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < HD / 32; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float x = o[i][r], tmp;
+          asm volatile("v_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\tv_accvgpr_write_b32 %0, %1"
+                       : "+a"(x), "=&v"(tmp)
+                       : "v"(alpha));
+          o[i][r] = x;
+        }
+      m_run = m_new;
+    }
+#endif
+    float psum = 0.f;
+    bf16x8 pf[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      u32x4 w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#if defined(ATTN_ABLATE_NOSOFTMAX)  // timing ablation only: wrong results (scores kept alive, P constant)
+        asm volatile("" ::"v"(s[8 * h + 2 * e]), "v"(s[8 * h + 2 * e + 1]));
+        const float p0 = 0.03125f, p1 = 0.03125f;
+#elif defined(ATTN_ABLATE_NOEXP)  // timing ablation only: wrong results
+        const float p0 = s[8 * h + 2 * e], p1 = s[8 * h + 2 * e + 1];
+#else
+        const float p0 = __builtin_amdgcn_exp2f(s[8 * h + 2 * e] - m_run);
+        const float p1 = __builtin_amdgcn_exp2f(s[8 * h + 2 * e + 1] - m_run);
+#endif
+        psum += p0 + p1;
+        w[e] = pack_bf2(p0, p1);
+      }
+      pf[h] = __builtin_bit_cast(bf16x8, w);
+    }
+    l_run += psum;
+    __builtin_amdgcn_sched_barrier(0);
+    PROF_MARK(3);                                  // softmax
+    // ---- O^T += V^T . P^T  (512 d x 32 queries, contraction over the 32 keys); group g = d-tiles 2g, 2g+1
+    static_for<8>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+#if ATTNKV_PV_AHEAD == 2
+      if constexpr (g + 2 < 8) {   // 7 reads of group g+2, the wait (15 newer in flight = the counter's maximum), then the 8th
+        static_for<7>([&](auto ic) { ldv1(std::integral_constant<int, g + 2>{}, ic, vf[(g + 2) % 3]); });
+        wait_v(std::integral_constant<int, 15>{}, vf[g % 3]);
+        ldv1(std::integral_constant<int, g + 2>{}, std::integral_constant<int, 7>{}, vf[(g + 2) % 3]);
+      } else if constexpr (g + 1 < 8) {
+        wait_v(std::integral_constant<int, 8>{}, vf[g % 3]);
+      } else {
+        wait_v(std::integral_constant<int, 0>{}, vf[g % 3]);
+      }
+#define VF_CUR vf[g % 3]
+#else
+      if constexpr (g + 1 < 8) {
+        ldv(std::integral_constant<int, g + 1>{}, vf[(g + 1) & 1]);
+        wait_v(std::integral_constant<int, 8>{}, vf[g & 1]);
+      } else {
+        wait_v(std::integral_constant<int, 0>{}, vf[g & 1]);
+      }
+#define VF_CUR vf[g & 1]
+#endif
+#if !defined(ATTN_ABLATE_NODMA) && ATTNKV_DMA_PHASE
+      issue_piece(gc, nxt, BUF ^ 1);
+#endif
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        o[2 * g + (e >> 1)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(VF_CUR, e), pf[e & 1], o[2 * g + (e >> 1)], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    PROF_MARK(4);                                  // P.V
+  };
+
+  static_for<8>([&](auto ic) { issue_piece(ic, t_begin, 0); });
+  for (int tile = t_begin; tile < t_end; tile += 2) {
+    tile_body(std::integral_constant<int, 0>{}, tile);
+    if (tile + 1 < t_end) tile_body(std::integral_constant<int, 1>{}, tile + 1);
+  }
+
+#ifdef ATTNKV_PROFILE
+  if (blockIdx.x == 0 && tid == 0 && p.key_splits == 1 && p.part_o) {
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.part_o);
+    for (int i = 0; i < 5; ++i) dst[i] = pc[i];
+    dst[5] = (unsigned long long)(t_end - t_begin);
+  }
+#endif
+  // ---- normalise and store O[q][d] (bf16): a lane owns ONE query row, 4 consecutive d per store
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  if (p.key_splits > 1) {
+    if (q_ok) {
+      const size_t row = ((size_t)b * p.key_splits + ksplit) * p.N + qrow;
+      float* po = p.part_o + row * HD;
+#pragma unroll
+      for (int dt = 0; dt < HD / 32; ++dt)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const int d = dt * 32 + 8 * rq + 4 * hi;
+          *reinterpret_cast<f32x4*>(po + d) = f32x4{o[dt][4 * rq], o[dt][4 * rq + 1], o[dt][4 * rq + 2], o[dt][4 * rq + 3]};
+        }
+      if (hi == 0) { p.part_ml[row * 2] = m_run; p.part_ml[row * 2 + 1] = l_tot; }
+    }
+    return;
+  }
+  const float inv = 1.0f / l_tot;
+  if (q_ok) {
+    bf16_t* op = p.o + ((size_t)b * p.N + qrow) * p.ldo;
+#pragma unroll
+    for (int dt = 0; dt < HD / 32; ++dt)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int d = dt * 32 + 8 * rq + 4 * hi;
+        u32x2 w = {pack_bf2(o[dt][4 * rq] * inv, o[dt][4 * rq + 1] * inv),
+                   pack_bf2(o[dt][4 * rq + 2] * inv, o[dt][4 * rq + 3] * inv)};
+        *reinterpret_cast<u32x2*>(op + d) = w;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// attn_kv_pipe_kernel (ATTNKV_PIPELINED = 1 / 2; NOT the default -- a reproducible negative result, see the numbers at the end of
+// this comment): the shared-K/V attention as a THREE-STAGE software pipeline.  In attn_kv_fwd_kernel a tile is
+// QK^T -> softmax -> P.V in sequence: one wave per SIMD means nothing covers the softmax's vector-ALU work (~900 of ~4000
+// cycles per tile, measured) and the 32-deep dependent score accumulation.  Here iteration i runs three INDEPENDENT pieces:
+//     matrix pipe :  S(i+1) = K(i+1).Q^T   interleaved one-for-one with   O += V(i-1).P(i-1)
+//     vector ALU  :  P(i) = softmax-step(S(i))          (in the issue gaps of the 64 MFMAs)
+// so consecutive MFMAs never share an accumulator (the S chain is spaced by a P.V MFMA) and the exponentials, the running
+// max and the bf16 packing hide under the matrix pipe.  Cost: two score tiles and two P tiles live at once (the last quarter
+// of Q moves to a wave-private LDS slab to make room) and four 32-key tiles resident in LDS (i-1: values, i: idle, i+1: keys,
+// i+2: landing) = 128 KB + 32 KB of Q = the whole 160 KB.
+// The deferred rescale is applied at the END of an iteration, when every accumulator holds tiles <= i-1 at the old scale.
+// Every LDS read of the loop is inline asm with hand-counted lgkmcnt (the transpose read forces that, see attn_kv_fwd_kernel;
+// mixing compiler-counted reads into the same phase would make hipcc's own counts wrong): reads are issued in a fixed order,
+// PIPE_D slots ahead of the MFMA pair that consumes them, and retire in order.
+//
+// Measured on MI355X (B = 8, N = 16 275, tools/attn_ablate.sh; same box, TFLOP/s): sequential attn_kv_fwd_kernel 1 127-1 163;
+// three-stage (ATTNKV_PIPELINED=1) 1 035-1 089; two-phase variant with QK^T(i+1) then P.V(i-1) || softmax(i) (=2) 997.
+// The softmax does vanish under the MFMAs (removing it from the pipelined loop changes nothing: 1 024 vs 1 035), but the eight
+// LDS-DMA pieces per tile cost 28-30 % there against 13 % in the sequential kernel (DMA compiled out: 1 326 / 1 291 vs 1 293-
+// 1 315), and staggering the pieces across the waves makes it worse (1 025, 881): with one wave per SIMD every stall of the
+// in-order stream -- DMA issue, the wait at the barrier -- idles the matrix pipe, and the sequential kernel happens to put the
+// DMA issue where the dependent score chain has slack.  What would pay here is a fifth (loader) wave, which 512 registers per
+// wave do not leave room for.
+#ifndef ATTNKV_PIPE_D
+#define ATTNKV_PIPE_D 2
+#endif
+#ifndef ATTNKV_DMA_STAGGER
+#define ATTNKV_DMA_STAGGER 0
+#endif
+
+template <int OFF>
+__device__ __forceinline__ void lds_read_b128(u32x4& dst, int addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait_kv(u32x4& k, u32x2& v0, u32x2& v1) {
+  asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(k), "+v"(v0), "+v"(v1) : "i"(N));
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait_kvq(u32x4& k, u32x2& v0, u32x2& v1, u32x4& q) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(k), "+v"(v0), "+v"(v1), "+v"(q) : "i"(N));
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait_v(u32x2& v0, u32x2& v1) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(v0), "+v"(v1) : "i"(N));
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait_k(u32x4& k) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(k) : "i"(N));
+}
+
+constexpr int QT_KS = 24;   // k-steps 24..31 of Q live in LDS
+
+__global__ __launch_bounds__(AT_THREADS, 1) void attn_kv_pipe_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  u32x4* lKV = reinterpret_cast<u32x4*>(smem);   // [4][KCH] tile ring, then [4 waves][8 KB] Q tail
+  [[maybe_unused]] constexpr int D = ATTNKV_PIPE_D;
+
+  int bid = blockIdx.x;
+  {
+    const int n = p.n_blocks, q = n / 8, r = n % 8, xcd = bid % 8, kk = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kk;
+  }
+  const int qb = bid % p.n_qblocks, ksplit = (bid / p.n_qblocks) % p.key_splits, b = bid / (p.n_qblocks * p.key_splits);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ql = lane & 31, hi = lane >> 5;
+  const int qrow = qb * BM + wave * 32 + ql;
+  const bool q_ok = qrow < p.N;
+
+  bf16x8 qf[QT_KS];
+  const int qtail = 4 * KCH * 16 + wave * 8192 + lane * 16;   // LDS byte address of this lane's Q-tail fragments
+  {
+    const bf16_t* qp = p.q + ((size_t)b * p.N + (q_ok ? qrow : 0)) * p.ldq + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks) {
+      u32x4 v = *reinterpret_cast<const u32x4*>(qp + ks * 16);
+      if (!q_ok) v = u32x4{0u, 0u, 0u, 0u};
+      if (ks < QT_KS) qf[ks] = __builtin_bit_cast(bf16x8, v);
+      else *reinterpret_cast<u32x4*>(smem + qtail + (ks - QT_KS) * 1024) = v;
+    }
+  }
+  f32x16 o[HD / 32];
+#pragma unroll
+  for (int i = 0; i < HD / 32; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+
+  const int n_tiles = (p.N + BN - 1) / BN;
+  const int t_begin = (int)((long long)n_tiles * ksplit / p.key_splits), t_end = (int)((long long)n_tiles * (ksplit + 1) / p.key_splits);
+  const bf16_t* kbase = p.k + (size_t)b * p.N * p.ldk;
+  const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(kbase), 0, (int)((((long long)p.N - 1) * p.ldk + HD) * 2), 0x00020000);
+  const int lane16w = (lane ^ (wave << 2)) * 16;
+  auto issue_piece = [&](auto ic, int tile, int buf) {
+    constexpr int i = decltype(ic)::value;
+    const int r = wave + 4 * i;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(krsrc, (__attribute__((address_space(3))) void*)(lKV + buf * KCH + r * 64), 16,
+                                             lane16w ^ ((i & 3) * 16), (tile * BN + r) * p.ldk * 2, 0, 0);
+  };
+
+  const int krow = (ql & 0x13) | ((ql & 4) << 1) | ((ql & 8) >> 1);
+  const int kf = kv_swz(krow);
+  // fragment addresses INCLUDING the tile buffer's base: the ds offset immediate is 16 bits and the ring spans 128 KB, so the
+  // registers rotate with the ring (kofs -> buffer of K(tile+1), vofs -> buffer of V(tile-1)) instead of the immediates
+  int kofs[8], vofs[4][2];
+#pragma unroll
+  for (int bb = 0; bb < 8; ++bb) kofs[bb] = (krow * 64 + ((2 * bb + hi) ^ kf)) * 16;
+  {
+    const int i16 = lane & 15, g4 = (lane >> 4) & 1;
+#pragma unroll
+    for (int dtl = 0; dtl < 4; ++dtl)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int key = 8 * hi + 4 * h + (i16 >> 2);
+        const int chunk = 4 * dtl + 2 * g4 + ((i16 & 3) >> 1);
+        vofs[dtl][h] = key * 1024 + ((chunk ^ kv_swz(key)) * 16) + (i16 & 1) * 8;
+      }
+  }
+  auto mask_tail = [&](f32x16& sc, int tile) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kv = tile * BN + 16 * (r >> 3) + 8 * hi + (r & 7);
+      if (kv >= p.N) sc[r] = -__builtin_inff();
+    }
+  };
+
+  // ---- prologue: tiles t_begin (buffer 0) and t_begin + 1 (buffer 1) in flight; buffer 3 stands in for "tile t_begin - 1"
+  // (zeros, multiplied by P = 0 in the first iteration); S(t_begin) computed alone.
+  static_for<8>([&](auto ic) { issue_piece(ic, t_begin, 0); });
+  static_for<8>([&](auto ic) { issue_piece(ic, min(t_begin + 1, t_end - 1), 1); });
+#pragma unroll
+  for (int i = 0; i < 8; ++i) lKV[3 * KCH + wave * 512 + i * 64 + lane] = u32x4{0u, 0u, 0u, 0u};
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  f32x16 s_cur;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s_cur[r] = 0.f;
+  static_for<HD / 16>([&](auto kc) {
+    constexpr int ks = decltype(kc)::value;
+    u32x4 a;
+    lds_read_b128<(ks >> 3) * 256>(a, kofs[ks & 7]);
+    if constexpr (ks < QT_KS) {
+      lgkm_wait_k<0>(a);
+      s_cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), qf[ks], s_cur, 0, 0, 0);
+    } else {
+      u32x4 qq;
+      lds_read_b128<(ks - QT_KS) * 1024>(qq, qtail);
+      lgkm_wait_k<0>(qq);
+      lgkm_wait_k<0>(a);
+      s_cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, qq), s_cur, 0, 0, 0);
+    }
+  });
+  if (t_begin == n_tiles - 1) mask_tail(s_cur, t_begin);
+  u32x4 p_prev[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
+#pragma unroll
+  for (int bb = 0; bb < 8; ++bb) kofs[bb] += 1 * KCH * 16;          // iteration 0 reads K from buffer 1 ...
+#pragma unroll
+  for (int dtl = 0; dtl < 4; ++dtl) { vofs[dtl][0] += 3 * KCH * 16; vofs[dtl][1] += 3 * KCH * 16; }   // ... and V from buffer 3
+
+  // LDS operations issued for slot s of an iteration: K fragment, two transpose reads, (Q tail fragment)
+  // ops(s) = 3 + (s >= QT_KS); those of slots t+1 .. t+D are in flight behind slot t's when it is consumed
+  auto iteration = [&](auto rc, int tile) {
+    constexpr int R = decltype(rc)::value;                 // (tile - t_begin) % 4: tile in buffer R, K(tile+1) in R+1, V(tile-1) in R+3
+    [[maybe_unused]] constexpr int KB = 0, VB = 0;         // kofs / vofs already point into those buffers
+#ifndef ATTN_ABLATE_NOBARRIER
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // tile+1 has landed ...
+    __syncthreads();                                        // ... for everybody; tile-2's buffer is free
+#endif
+    const int t2 = min(tile + 2, t_end - 1);
+#if ATTNKV_PIPELINED != 2
+    u32x4 kfr[D + 1], qfr[D + 1];
+    u32x2 vfr[D + 1][2];
+#endif
+    f32x16 s_nxt;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_nxt[r] = 0.f;
+    u32x4 p_cur[2];
+    float mx = 0.f, psum = 0.f, alpha = 1.f;
+    bool need = false;
+#if ATTNKV_PIPELINED == 2
+    // Two phases per iteration: (A) S(tile+1) = K(tile+1).Q^T with the next tile's DMA issue in its gaps (the dependent score
+    // chain has the slack for them), (B) O += V(tile-1).P(tile-1) with the softmax of S(tile) on the vector ALU underneath
+    // (independent accumulators: fillers between those MFMAs are cheap).
+    constexpr int DA = 6, DB = 4;                          // fragment reads run this many slots ahead in each phase
+    u32x4 kfa[DA + 1], qfa[DA + 1];
+    auto fetch_a = [&](auto sc) {
+      constexpr int sl = decltype(sc)::value;
+      if constexpr (sl < 32) {
+        lds_read_b128<(sl >> 3) * 256>(kfa[sl % (DA + 1)], kofs[sl & 7]);
+        if constexpr (sl >= QT_KS) lds_read_b128<(sl - QT_KS) * 1024>(qfa[sl % (DA + 1)], qtail);
+      }
+    };
+    static_for<DA>([&](auto sc) { fetch_a(sc); });
+    static_for<32>([&](auto sc) {
+      constexpr int sl = decltype(sc)::value;
+      fetch_a(std::integral_constant<int, sl + DA>{});
+#ifndef ATTN_ABLATE_NODMA
+      if constexpr ((sl & 3) == 1) issue_piece(std::integral_constant<int, sl / 4>{}, t2, (R + 2) & 3);
+#endif
+      constexpr int hi_s = (sl + DA < 31 ? sl + DA : 31);
+      constexpr int newer = (hi_s - sl) + ((hi_s >= QT_KS ? hi_s - QT_KS + 1 : 0) - (sl >= QT_KS ? sl - QT_KS + 1 : 0));
+      static_assert(newer <= 15, "lgkmcnt is a 4-bit counter");
+      if constexpr (sl >= QT_KS) {
+        lgkm_wait_k<newer>(qfa[sl % (DA + 1)]);             // the Q fragment is the LAST read of its slot: K has landed too
+        lgkm_wait_k<newer>(kfa[sl % (DA + 1)]);
+        s_nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kfa[sl % (DA + 1)]),
+                                                        __builtin_bit_cast(bf16x8, qfa[sl % (DA + 1)]), s_nxt, 0, 0, 0);
+      } else {
+        lgkm_wait_k<newer>(kfa[sl % (DA + 1)]);
+        s_nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kfa[sl % (DA + 1)]), qf[sl < QT_KS ? sl : 0], s_nxt,
+                                                        0, 0, 0);
+      }
+      if constexpr ((sl & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    });
+    u32x2 vfb[DB + 1][2];
+    auto fetch_b = [&](auto sc) {
+      constexpr int sl = decltype(sc)::value;
+      if constexpr (sl < 32) {
+        constexpr int dt = sl >> 1, ks = sl & 1;
+        tr_read_b64<ks * 16384 + (dt >> 2) * 256>(vfb[sl % (DB + 1)][0], vofs[dt & 3][0]);
+        tr_read_b64<ks * 16384 + (dt >> 2) * 256>(vfb[sl % (DB + 1)][1], vofs[dt & 3][1]);
+      }
+    };
+    static_for<DB>([&](auto sc) { fetch_b(sc); });
+    static_for<32>([&](auto sc) {
+      constexpr int sl = decltype(sc)::value;
+      fetch_b(std::integral_constant<int, sl + DB>{});
+      constexpr int hi_s = (sl + DB < 31 ? sl + DB : 31);
+      lgkm_wait_v<2 * (hi_s - sl)>(vfb[sl % (DB + 1)][0], vfb[sl % (DB + 1)][1]);
+      {
+        const u32x2 a0 = vfb[sl % (DB + 1)][0], a1 = vfb[sl % (DB + 1)][1];
+        o[sl >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, u32x4{a0[0], a0[1], a1[0], a1[1]}),
+                                                             __builtin_bit_cast(bf16x8, p_prev[sl & 1]), o[sl >> 1], 0, 0, 0);
+      }
+      // ---- vector-ALU slice of the online softmax of S(tile), one small piece per slot
+#ifdef ATTN_ABLATE_NOSOFTMAX   // timing ablation only: wrong results
+      if constexpr (sl == 0) { asm volatile("" ::"v"(s_cur[0]), "v"(s_cur[15])); p_cur[0] = p_cur[1] = u32x4{0x3d003d00u, 0x3d003d00u, 0x3d003d00u, 0x3d003d00u}; }
+      if constexpr (false) {}
+      else
+#endif
+      if constexpr (sl == 0) mx = fmaxf(fmaxf(s_cur[0], s_cur[1]), s_cur[2]);
+      else if constexpr (sl >= 1 && sl <= 6) mx = fmaxf(fmaxf(mx, s_cur[2 * sl + 1]), s_cur[2 * sl + 2]);
+      else if constexpr (sl == 7) {
+        mx = fmaxf(mx, s_cur[15]);
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        mx = fmaxf(mx, __uint_as_float(hi ? sw[0] : sw[1]));
+      } else if constexpr (sl == 8) {
+        need = __any(mx > m_run + RESCALE_THR);             // wave-uniform; the accumulators are rescaled at the end
+        const float m_new = need ? fmaxf(m_run, mx) : m_run;
+        alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        l_run *= alpha;
+        m_run = m_new;
+      } else if constexpr (sl >= 9 && sl <= 24) {
+        constexpr int r = sl - 9;
+        const float pv = __builtin_amdgcn_exp2f(s_cur[r] - m_run);
+        psum += pv;
+        s_cur[r] = pv;
+        if constexpr (r & 1) p_cur[r >> 3][(r >> 1) & 3] = pack_bf2(s_cur[r - 1], s_cur[r]);
+      } else if constexpr (sl == 25) {
+        l_run += psum;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+#else
+    auto fetch = [&](auto sc) {                            // the LDS reads of slot s, in the order K, V lo, V hi, (Q)
+      constexpr int sl = decltype(sc)::value;
+      if constexpr (sl < 32) {
+        constexpr int dt = sl >> 1, ks = sl & 1;
+        lds_read_b128<KB + (sl >> 3) * 256>(kfr[sl % (D + 1)], kofs[sl & 7]);
+        tr_read_b64<VB + ks * 16384 + (dt >> 2) * 256>(vfr[sl % (D + 1)][0], vofs[dt & 3][0]);
+        tr_read_b64<VB + ks * 16384 + (dt >> 2) * 256>(vfr[sl % (D + 1)][1], vofs[dt & 3][1]);
+        if constexpr (sl >= QT_KS) lds_read_b128<(sl - QT_KS) * 1024>(qfr[sl % (D + 1)], qtail);
+      }
+    };
+    static_for<D>([&](auto sc) { fetch(sc); });
+    static_for<32>([&](auto sc) {
+      constexpr int sl = decltype(sc)::value;
+      fetch(std::integral_constant<int, sl + D>{});
+#ifndef ATTN_ABLATE_NODMA
+#if ATTNKV_DMA_STAGGER == 0      // every wave issues piece j at slot 2j
+      if constexpr ((sl & 1) == 0 && sl < 16) issue_piece(std::integral_constant<int, sl / 2>{}, t2, (R + 2) & 3);
+#elif ATTNKV_DMA_STAGGER == 1    // waves in two groups: piece j at slot 2j + (wave & 1)
+      if constexpr (sl < 16) { if ((wave & 1) == (sl & 1)) issue_piece(std::integral_constant<int, sl / 2>{}, t2, (R + 2) & 3); }
+#elif ATTNKV_DMA_STAGGER == 2    // one wave per slot: piece j at slot 4j + wave
+      if (wave == (sl & 3)) issue_piece(std::integral_constant<int, sl / 4>{}, t2, (R + 2) & 3);
+#elif ATTNKV_DMA_STAGGER == 3    // one wave per slot, first 16 slots twice as dense: pieces 2k, 2k+1 at slot 4k + wave (k < 4)
+      if constexpr (sl < 16) { if (wave == (sl & 3)) { issue_piece(std::integral_constant<int, 2 * (sl / 4)>{}, t2, (R + 2) & 3);
+                                                       issue_piece(std::integral_constant<int, 2 * (sl / 4) + 1>{}, t2, (R + 2) & 3); } }
+#endif
+#endif
+      // newer LDS operations in flight behind slot sl's: slots sl+1 .. min(sl+D, 31)
+      constexpr int hi_s = (sl + D < 31 ? sl + D : 31);
+      constexpr int newer = 3 * (hi_s - sl) + ((hi_s >= QT_KS ? hi_s - QT_KS + 1 : 0) - (sl >= QT_KS ? sl - QT_KS + 1 : 0));
+      static_assert(newer <= 15, "lgkmcnt is a 4-bit counter");
+      bf16x8 qop;
+      if constexpr (sl >= QT_KS) {
+        lgkm_wait_kvq<newer>(kfr[sl % (D + 1)], vfr[sl % (D + 1)][0], vfr[sl % (D + 1)][1], qfr[sl % (D + 1)]);
+        qop = __builtin_bit_cast(bf16x8, qfr[sl % (D + 1)]);
+      } else {
+        lgkm_wait_kv<newer>(kfr[sl % (D + 1)], vfr[sl % (D + 1)][0], vfr[sl % (D + 1)][1]);
+        qop = qf[sl < QT_KS ? sl : 0];
+      }
+      s_nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kfr[sl % (D + 1)]), qop, s_nxt, 0, 0, 0);
+      {
+        const u32x2 a0 = vfr[sl % (D + 1)][0], a1 = vfr[sl % (D + 1)][1];
+        o[sl >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, u32x4{a0[0], a0[1], a1[0], a1[1]}),
+                                                             __builtin_bit_cast(bf16x8, p_prev[sl & 1]), o[sl >> 1], 0, 0, 0);
+      }
+      // ---- vector-ALU slice of the online softmax of S(tile), one small piece per slot
+#ifdef ATTN_ABLATE_NOSOFTMAX   // timing ablation only: wrong results
+      if constexpr (sl == 0) { asm volatile("" ::"v"(s_cur[0]), "v"(s_cur[15])); p_cur[0] = p_cur[1] = u32x4{0x3d003d00u, 0x3d003d00u, 0x3d003d00u, 0x3d003d00u}; }
+      if constexpr (false) {}
+      else
+#endif
+      if constexpr (sl == 0) mx = fmaxf(fmaxf(s_cur[0], s_cur[1]), s_cur[2]);
+      else if constexpr (sl >= 1 && sl <= 6) mx = fmaxf(fmaxf(mx, s_cur[2 * sl + 1]), s_cur[2 * sl + 2]);
+      else if constexpr (sl == 7) {
+        mx = fmaxf(mx, s_cur[15]);
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        mx = fmaxf(mx, __uint_as_float(hi ? sw[0] : sw[1]));
+      } else if constexpr (sl == 8) {
+        need = __any(mx > m_run + RESCALE_THR);             // wave-uniform; the accumulators are rescaled at the end
+        const float m_new = need ? fmaxf(m_run, mx) : m_run;
+        alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        l_run *= alpha;
+        m_run = m_new;
+      } else if constexpr (sl >= 9 && sl <= 24) {
+        constexpr int r = sl - 9;
+        const float pv = __builtin_amdgcn_exp2f(s_cur[r] - m_run);
+        psum += pv;
+        s_cur[r] = pv;
+        if constexpr (r & 1) p_cur[r >> 3][(r >> 1) & 3] = pack_bf2(s_cur[r - 1], s_cur[r]);
+      } else if constexpr (sl == 25) {
+        l_run += psum;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+#endif
+    if (need) {   // rare: every accumulator holds tiles <= tile-1 at the old scale
+#pragma unroll
+      for (int i = 0; i < HD / 32; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float x = o[i][r], tmp;
+          asm volatile("v_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\tv_accvgpr_write_b32 %0, %1"
+                       : "+a"(x), "=&v"(tmp)
+                       : "v"(alpha));
+          o[i][r] = x;
+        }
+    }
+    if (tile + 1 == n_tiles - 1) mask_tail(s_nxt, tile + 1);
+    s_cur = s_nxt;
+    p_prev[0] = p_cur[0];
+    p_prev[1] = p_cur[1];
+    // rotate the fragment addresses to the next iteration's buffers: K (R+1) -> (R+2), V (R+3) -> (R+4), modulo 4
+    constexpr int dk = (((R + 1) & 3) == 3 ? -3 : 1) * KCH * 16, dv = (((R + 3) & 3) == 3 ? -3 : 1) * KCH * 16;
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb) kofs[bb] += dk;
+#pragma unroll
+    for (int dtl = 0; dtl < 4; ++dtl) { vofs[dtl][0] += dv; vofs[dtl][1] += dv; }
+  };
+
+  for (int tile = t_begin; tile < t_end; tile += 4) {
+    iteration(std::integral_constant<int, 0>{}, tile);
+    if (tile + 1 < t_end) iteration(std::integral_constant<int, 1>{}, tile + 1);
+    if (tile + 2 < t_end) iteration(std::integral_constant<int, 2>{}, tile + 2);
+    if (tile + 3 < t_end) iteration(std::integral_constant<int, 3>{}, tile + 3);
+  }
+  // ---- drain: O += V(last).P(last); after the last rotation vofs points at the last tile's buffer
+  {
+    static_for<16>([&](auto dc) {
+      constexpr int dt = decltype(dc)::value;
+      u32x2 a[4];
+      tr_read_b64<(dt >> 2) * 256>(a[0], vofs[dt & 3][0]);
+      tr_read_b64<(dt >> 2) * 256>(a[1], vofs[dt & 3][1]);
+      tr_read_b64<16384 + (dt >> 2) * 256>(a[2], vofs[dt & 3][0]);
+      tr_read_b64<16384 + (dt >> 2) * 256>(a[3], vofs[dt & 3][1]);
+      lgkm_wait_v<0>(a[0], a[1]);
+      lgkm_wait_v<0>(a[2], a[3]);
+      o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, u32x4{a[0][0], a[0][1], a[1][0], a[1][1]}),
+                                                      __builtin_bit_cast(bf16x8, p_prev[0]), o[dt], 0, 0, 0);
+      o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, u32x4{a[2][0], a[2][1], a[3][0], a[3][1]}),
+                                                      __builtin_bit_cast(bf16x8, p_prev[1]), o[dt], 0, 0, 0);
+    });
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  if (p.key_splits > 1) {
+    if (q_ok) {
+      const size_t row = ((size_t)b * p.key_splits + ksplit) * p.N + qrow;
+      float* po = p.part_o + row * HD;
+#pragma unroll
+      for (int dt = 0; dt < HD / 32; ++dt)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const int d = dt * 32 + 8 * rq + 4 * hi;
+          *reinterpret_cast<f32x4*>(po + d) = f32x4{o[dt][4 * rq], o[dt][4 * rq + 1], o[dt][4 * rq + 2], o[dt][4 * rq + 3]};
+        }
+      if (hi == 0) { p.part_ml[row * 2] = m_run; p.part_ml[row * 2 + 1] = l_tot; }
+    }
+    return;
+  }
+  const float inv = 1.0f / l_tot;
+  if (q_ok) {
+    bf16_t* op = p.o + ((size_t)b * p.N + qrow) * p.ldo;
+#pragma unroll
+    for (int dt = 0; dt < HD / 32; ++dt)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int d = dt * 32 + 8 * rq + 4 * hi;
+        u32x2 w = {pack_bf2(o[dt][4 * rq] * inv, o[dt][4 * rq + 1] * inv),
+                   pack_bf2(o[dt][4 * rq + 2] * inv, o[dt][4 * rq + 3] * inv)};
+        *reinterpret_cast<u32x2*>(op + d) = w;
+      }
+  }
+}
+
 // out[q] = sum_s 2^(m_s - m) O_s[q] / sum_s 2^(m_s - m) l_s,  m = max_s m_s: merges the key splits (one wave per query row)
 __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
                                                            bf16_t* __restrict__ out, int ldo, int B, int N, int KS) {
@@ -739,6 +1484,42 @@ extern "C" int glare_attention_d512_splitk_bf16(const void* q, int ldq, const vo
                                                 void* out, int ldo, int B, int N, int key_splits, void* workspace,
                                                 size_t workspace_bytes, glare_stream_t stream) {
   return attn_launch(q, ldq, k, ldk, v_t, v_pitch, out, ldo, B, N, key_splits, workspace, workspace_bytes, stream);
+}
+
+extern "C" int glare_attention_kv512_bf16(const void* q, int ldq, const void* kv, int ldkv, void* out, int ldo, int B, int N,
+                                          int key_splits, void* workspace, size_t workspace_bytes, glare_stream_t stream) {
+  if (!q || !kv || !out || B <= 0 || N <= 0 || key_splits < 1) return GLARE_ERR_INVALID;
+  if (key_splits > (N + BN - 1) / BN) return GLARE_ERR_INVALID;
+  if (((long long)N * ldkv + HD) * 2 >= 0x7ff00000LL) return GLARE_ERR_UNSUPPORTED;   // 32-bit DMA offsets per image
+  if (key_splits > 1 &&
+      ((ldo % 8) || !workspace || workspace_bytes < glare_attention_d512_splitk_workspace_bytes(B, N, key_splits)))
+    return GLARE_ERR_WORKSPACE;
+  if ((ldq % 8) || (ldkv % 8) || (ldo % 4) || ldq < HD || ldkv < HD || ldo < HD) return GLARE_ERR_UNSUPPORTED;
+  AttnParams p;
+  p.q = (const bf16_t*)q; p.k = (const bf16_t*)kv; p.vt = nullptr; p.o = (bf16_t*)out;
+  p.B = B; p.N = N; p.Npad = 0; p.ldq = ldq; p.ldk = ldkv; p.ldo = ldo;
+  p.n_qblocks = (N + BM - 1) / BM;
+  p.key_splits = key_splits;
+  p.part_o = static_cast<float*>(workspace);
+  p.part_ml = p.part_o ? p.part_o + (size_t)B * key_splits * N * HD : nullptr;
+  const long long nb = (long long)B * p.n_qblocks * key_splits;
+  if (nb > 0x7fffffffLL) return GLARE_ERR_INVALID;
+  p.n_blocks = (int)nb;
+#if ATTNKV_PIPELINED != 0
+  const size_t lds = (size_t)4 * KCH * 16 + 4 * 8192;   // 128 KB tile ring + 32 KB Q tail = all 160 KB
+  if (hipFuncSetAttribute((const void*)attn_kv_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return GLARE_ERR_LAUNCH;
+  hipLaunchKernelGGL(attn_kv_pipe_kernel, dim3(p.n_blocks), dim3(AT_THREADS), lds, (hipStream_t)stream, p);
+#else
+  const size_t lds = (size_t)2 * KCH * 16;   // 64 KB: the double-buffered 32-key tile
+  if (hipFuncSetAttribute((const void*)attn_kv_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return GLARE_ERR_LAUNCH;
+  hipLaunchKernelGGL(attn_kv_fwd_kernel, dim3(p.n_blocks), dim3(AT_THREADS), lds, (hipStream_t)stream, p);
+#endif
+  if (key_splits > 1)
+    hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)(((long long)B * N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p.part_o,
+                       p.part_ml, p.o, ldo, B, N, key_splits);
+  return glare_launch_status();
 }
 
 extern "C" int glare_attention_d512_bf16(const void* q, int ldq, const void* k, int ldk, const void* v_t,

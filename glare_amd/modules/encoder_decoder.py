@@ -37,6 +37,9 @@ def conv_t(x, conv, **kw):
 
 SUBPIXEL_UPSAMPLE = True
 FOLD_PROJ_INTO_V = True
+# AttnBlock as attention with shared keys / values (csrc/attn.hip, attn_kv_fwd_kernel): the key projection folded into the
+# query projection, the value projection folded into proj_out.  False: the q | k and v^T projections + the two-tensor kernel.
+SHARED_KV_ATTENTION = True
 
 
 class Upsample(HipModule):
@@ -138,10 +141,29 @@ class AttnBlock(HipModule):
         b = (wp @ self.v.bias.double() + self.proj_out.bias.double()).float()
         return ops.PackedConv(w, b)
 
+    def _q_folded(self):
+        # s_ij = (Wq h_i + bq).(Wk h_j + bk): the terms without j cancel in softmax_j, the rest is (Wk^T (Wq h_i + bq)) . h_j
+        s = float(self.in_channels) ** -0.5 * math.log2(math.e)
+        wq, wk = self.q.weight[:, :, 0, 0].double(), self.k.weight[:, :, 0, 0].double()
+        w = (s * (wk.t() @ wq)).float()[:, :, None, None].contiguous()
+        b = (s * (wk.t() @ self.q.bias.double())).float()
+        return ops.PackedConv(w, b)
+
+    def _out_folded(self):
+        # Wp (sum_j P_ij (Wv h_j + bv)) + bp = (Wp Wv) (sum_j P_ij h_j) + Wp bv + bp   (softmax rows sum to 1)
+        wp, wv = self.proj_out.weight[:, :, 0, 0].double(), self.v.weight[:, :, 0, 0].double()
+        w = (wp @ wv).float()[:, :, None, None].contiguous()
+        b = (wp @ self.v.bias.double() + self.proj_out.bias.double()).float()
+        return ops.PackedConv(w, b)
+
     def forward_nhwc(self, x):
         B, H, W, C = x.shape
         N = H * W
         hn = gn_swish(x, self.norm, swish=False)
+        if SHARED_KV_ATTENTION:
+            q = ops.conv2d(hn, self._packed("q_folded", self._q_folded))
+            a = ops.attention_kv512(q, hn, N)                                    # sum_j softmax_j(q'_i . h_j) h_j
+            return ops.conv2d(a.view(B, H, W, C), self._packed("out_folded", self._out_folded), residual=x, gn_stats=GN_FUSED)
         qk = ops.conv2d(hn, self._packed("qk", self._qk))                       # [B,H,W,1024]: q | k
         npad = (N + 63) // 64 * 64
         if FOLD_PROJ_INTO_V:

@@ -297,6 +297,8 @@ def attention_key_splits(B, N):
 # (rounding), so the batch-invariance test pins both to one configuration.
 ATTENTION_KEY_SPLITS_OVERRIDE = None
 
+ATTENTION_PROFILE_BUFFER = None   # tools/kbench.py KB_PROF=1 (needs a -DATTNKV_PROFILE build)
+
 # Measurement hook (bench.py): when this is a list, every attention launch is bracketed by a pair of events recorded on the
 # stream the kernel is launched on, and (start, end, B, N) is appended.  None (the default) records nothing.
 ATTENTION_LAUNCH_EVENTS = None
@@ -337,6 +339,39 @@ def _attention_d512(q, k, v_t, N, ldq, ldk, out, key_splits):
     check(_lib.lib().glare_attention_d512_bf16(ptr(q), _i(ldq), ptr(k), _i(ldk), ptr(v_t), _ll(v_t.shape[2]), ptr(out),
                                                _i(out.shape[-1]), _i(B), _i(N), stream_handle()),
           "glare_attention_d512_bf16")
+    return out
+
+
+def attention_kv512(q, kv, N, ldq=None, ldkv=None, out=None, key_splits=None):
+    """Attention with SHARED keys / values: out[b,i] = sum_j softmax_j(q_i . kv_j) kv_j.  q, kv: bf16 [B, N, ld] views
+    (d = 512 used; the caller folds 512^-0.5 * log2(e) and the key projection into q -- see AttnBlock); returns bf16 [B, N, 512]."""
+    require_cuda(q, kv, out)
+    assert q.dtype == kv.dtype == torch.bfloat16
+    B = kv.shape[0]
+    ldq = q.shape[-1] if ldq is None else ldq
+    ldkv = kv.shape[-1] if ldkv is None else ldkv
+    if out is None:
+        out = torch.empty(B, N, 512, dtype=torch.bfloat16, device=kv.device)
+    if key_splits is None:
+        key_splits = ATTENTION_KEY_SPLITS_OVERRIDE
+    ks = attention_key_splits(B, N) if key_splits is None else key_splits
+    lib = _lib.lib()
+    ws, nws = None, 0
+    if ATTENTION_PROFILE_BUFFER is not None and ks == 1:   # tools only: a build with -DATTNKV_PROFILE leaves phase cycle sums here
+        ws, nws = ATTENTION_PROFILE_BUFFER, ATTENTION_PROFILE_BUFFER.numel() * ATTENTION_PROFILE_BUFFER.element_size()
+    if ks > 1:
+        lib.glare_attention_d512_splitk_workspace_bytes.restype = _sz
+        nws = lib.glare_attention_d512_splitk_workspace_bytes(_i(B), _i(N), _i(ks))
+        ws = _workspace(nws, kv.device)
+    ev = None
+    if ATTENTION_LAUNCH_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    check(lib.glare_attention_kv512_bf16(ptr(q), _i(ldq), ptr(kv), _i(ldkv), ptr(out), _i(out.shape[-1]), _i(B), _i(N), _i(ks),
+                                         ptr(ws), _sz(nws), stream_handle()), "glare_attention_kv512_bf16")
+    if ev is not None:
+        ev[1].record()
+        ATTENTION_LAUNCH_EVENTS.append((ev[0], ev[1], int(B), int(N)))
     return out
 
 

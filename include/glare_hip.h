@@ -205,6 +205,16 @@ int glare_attention_d512_splitk_bf16(const void* q, int ldq, const void* k, int 
                                      int ldo, int B, int N, int key_splits, void* workspace, size_t workspace_bytes,
                                      glare_stream_t stream);
 
+/* The attention of AttnBlock with keys and values SHARED: out[b, i, :] = sum_j softmax_j(q_i . x_j) x_j.
+ * AttnBlock is single-head self-attention on one tensor h = GroupNorm(x) (encoder_decoder.py:168-188): every term of
+ * (Wq h_i + bq).(Wk h_j + bk) that does not depend on j cancels in softmax_j, so the key projection folds into the query
+ * (q'_i = Wk^T Wq h_i + Wk^T bq, times 512^-0.5 * log2(e)), and since softmax rows sum to 1 the value projection commutes with
+ * the weighted average and folds into proj_out: the N^2 part runs on x = h for BOTH operands -- one tile stream instead of two.
+ * q : bf16 [B][N][ldq];  kv : bf16 [B][N][ldkv] (d = 512 contiguous);  out : bf16 [B][N][ldo].
+ * key_splits > 1: keys split over workgroups as above (workspace of glare_attention_d512_splitk_workspace_bytes); 1: none needed. */
+int glare_attention_kv512_bf16(const void* q, int ldq, const void* kv, int ldkv, void* out, int ldo, int B, int N, int key_splits,
+                               void* workspace, size_t workspace_bytes, glare_stream_t stream);
+
 /* ---- a9: modulated deformable convolution (DCNv2), forward -----------------------------------
  * glare_mdcn_forward_f32 is the drop-in for the pybind function
  *   deform_conv_ext.modulated_deform_conv_forward(input, weight, bias, ones, offset, mask, output,

@@ -225,3 +225,86 @@ def test_groupnorm_and_attention_randomised_sizes():
         out = ops.attention_d512(q, k, vt, N)
         ref = _attn_ref(q, k, v)
         assert torch.allclose(out.float(), ref, rtol=2 ** -6, atol=2 ** -7 * float(ref.abs().max())), "attn case %d: B%d N%d" % (case, B, N)
+
+
+# ---- attention with shared keys / values (attn_kv_fwd_kernel) ---------------------------------------------------------------
+@pytest.mark.parametrize("B,N", [(1, 128), (2, 200), (1, 31), (1, 1), (1, 1000), (3, 33)])
+def test_shared_kv_attention_matches_softmax_reference(B, N):
+    """out_i = sum_j softmax_j(q_i . x_j) x_j against fp32 softmax; x is asymmetric random data, so a transposed or permuted
+    P.V operand (the ds_read_b64_tr_b16 path) cannot pass."""
+    g = torch.Generator().manual_seed(N)
+    q = _bf(torch.randn(B, N, 512, generator=g) * 0.15).cuda()
+    x = _bf(torch.randn(B, N, 512, generator=g) + torch.linspace(-1, 1, 512)).cuda()     # per-channel offsets: d is not symmetric
+    out = ops.attention_kv512(q, x, N, key_splits=1)
+    ref = _attn_ref(q, x, x)
+    assert torch.allclose(out.float(), ref, rtol=2 ** -6, atol=2 ** -7 * float(ref.abs().max()))
+
+
+def test_shared_kv_attention_one_hot_rows_select_exact_tokens():
+    """A query that overwhelmingly prefers ONE key returns that token's row exactly (bf16): checks every (key slot, d) of the
+    transposed tile read -- 64 keys (two tiles), each selected by one query."""
+    N = 64
+    g = torch.Generator().manual_seed(5)
+    x = _bf(torch.randn(1, N, 512, generator=g)).cuda()
+    xn = x.float() / x.float().norm(dim=-1, keepdim=True)
+    q = _bf(xn * 60.0)                                             # q_i . x_i ~ 60 |x_i| >> q_i . x_j
+    out = ops.attention_kv512(q, x, N, key_splits=1)
+    assert torch.allclose(out.float(), x.float(), rtol=2 ** -7, atol=2 ** -7)
+
+
+def test_shared_kv_attention_forced_rescale_and_strided_views():
+    """The deferred-rescale branch (a key far beyond the 2^8 threshold, growing tile by tile; cdna guide rule 26) on strided
+    q / kv views (q | x interleaved in one [B, N, 1024] buffer)."""
+    g = torch.Generator().manual_seed(9)
+    B, N = 1, 320
+    q = torch.randn(B, N, 512, generator=g) * 0.05
+    x = torch.randn(B, N, 512, generator=g)
+    for tile in range(1, 10):
+        x[0, tile * 32 + 3] = q[0, 7] / q[0, 7].norm() * (20.0 * tile)
+    buf = _bf(torch.cat([q, x], dim=-1)).cuda()
+    out = ops.attention_kv512(buf, buf[..., 512:], N, ldq=1024, ldkv=1024, key_splits=1)
+    ref = _attn_ref(buf[..., :512], buf[..., 512:], buf[..., 512:])
+    assert torch.isfinite(out.float()).all()
+    assert torch.allclose(out.float(), ref, rtol=2 ** -6, atol=2 ** -7 * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("N,ks", [(300, 2), (300, 3), (1000, 4), (33, 2)])
+def test_shared_kv_attention_key_splits_agree(N, ks):
+    g = torch.Generator().manual_seed(N + ks)
+    B = 2
+    q = _bf(torch.randn(B, N, 512, generator=g) * 0.2).cuda()
+    x = _bf(torch.randn(B, N, 512, generator=g)).cuda()
+    x[0, N // 2] = x[0, N // 2] * 6.0
+    out = ops.attention_kv512(q, x, N, key_splits=ks)
+    ref = _attn_ref(q, x, x)
+    assert torch.allclose(out.float(), ref, rtol=2 ** -6, atol=2 ** -7 * float(ref.abs().max()))
+    one = ops.attention_kv512(q, x, N, key_splits=1)
+    assert torch.allclose(out.float(), one.float(), rtol=2 ** -6, atol=2 ** -7 * float(ref.abs().max()))
+
+
+def test_attn_block_shared_kv_form_equals_the_projected_form():
+    """AttnBlock through the shared-K/V kernel (key projection folded into q, value projection into proj_out) against the same
+    block through the q | k / v^T projections and the two-tensor kernel, and against the fp32 oracle block."""
+    from glare_amd.modules import encoder_decoder as ED
+    from glare_amd.synthetic import seeded_init_
+    from oracle import torch_ref as O
+
+    ob = seeded_init_(O.AttnBlock(512).eval(), 3)
+    pb = ED.AttnBlock(512).eval()
+    pb.load_state_dict(ob.state_dict(), strict=True)
+    pb.cuda()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 512, 9, 13, generator=g)
+    with torch.no_grad():
+        ref = ob(x)
+        assert ED.SHARED_KV_ATTENTION
+        new = pb(x.cuda()).cpu()
+        ED.SHARED_KV_ATTENTION = False
+        try:
+            pb.invalidate()
+            old = pb(x.cuda()).cpu()
+        finally:
+            ED.SHARED_KV_ATTENTION = True
+    e_new, e_old = float((new - ref).norm() / ref.norm()), float((old - ref).norm() / ref.norm())
+    print("AttnBlock rel err vs fp32 oracle: shared-KV %.2e, projected %.2e" % (e_new, e_old))
+    assert e_new < 4e-3 and e_old < 4e-3
