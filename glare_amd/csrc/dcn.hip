@@ -26,6 +26,7 @@
 #include <atomic>
 
 #include "common.h"
+#include "dcn_generic.h"
 
 namespace {
 
@@ -580,8 +581,6 @@ int launch_dcn(const DcnParams& p, hipStream_t stream) {
   return GLARE_ERR_UNSUPPORTED;
 }
 
-std::atomic<int> g_force_generic{0};
-
 // MT = 1 everywhere: 128-pixel workgroups (MT = 2) halve the weight-fragment traffic but run at occupancy 2 and measured
 // 3.35 ms vs 3.32 ms (C = 128) and 2.95 ms vs 2.42 ms (C = 256) at 8 images -- the kernel needs the waves.
 int launch_dcn_fast(const DcnParams& p, hipStream_t stream) {
@@ -628,7 +627,7 @@ extern "C" int glare_mdcn_forward_nhwc(const void* x, int x_is_bf16, int x_pitch
                                        const float* weight_packed, const float* bias, float* out, int out_planar,
                                        int out_pitch, int out_off, long long out_plane, int B, int C, int H, int W, int Co,
                                        int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int groups, int dg,
-                                       glare_stream_t stream) {
+                                       int flags, glare_stream_t stream) {
   if (!x || !offset || !mask || !weight_packed || !out) return GLARE_ERR_INVALID;
   const int st = dcn_check(B, C, H, W, Co, kh, kw, sh, sw, dh, dw, groups, dg);
   if (st != GLARE_OK) return st;
@@ -656,7 +655,7 @@ extern "C" int glare_mdcn_forward_nhwc(const void* x, int x_is_bf16, int x_pitch
   const long long off_bytes = ((long long)(B - 1) * p.off_bstride + (long long)dg * 2 * kh * kw * p.off_plane) * 4;
   const long long mask_bytes = ((long long)(B - 1) * p.mask_bstride + (long long)dg * kh * kw * p.mask_plane) * 4;
   const long long wt_bytes = (long long)Co * C * kh * kw * 4;
-  const bool generic_only = g_force_generic.load() != 0;
+  const bool generic_only = (flags & GLARE_MDCN_GENERAL_KERNEL) != 0;
   const int taps = kh * kw;
   if (x_is_bf16 && !generic_only && taps % 3 == 0 && x_bytes < LIM && off_bytes < LIM && mask_bytes < LIM && wt_bytes < LIM &&
       p.total_pix < LIM - 256) {
@@ -666,10 +665,6 @@ extern "C" int glare_mdcn_forward_nhwc(const void* x, int x_is_bf16, int x_pitch
   }
   p.x_bytes = p.off_bytes = p.mask_bytes = p.wt_bytes = 0;
   return x_is_bf16 ? launch_dcn<true>(p, (hipStream_t)stream) : launch_dcn<false>(p, (hipStream_t)stream);
-}
-
-extern "C" int glare_mdcn_force_generic(int on) {
-  return g_force_generic.exchange(on ? 1 : 0);
 }
 
 extern "C" size_t glare_mdcn_workspace_bytes(int B, int C, int H, int W, int Co, int kh, int kw) {
@@ -685,6 +680,12 @@ extern "C" int glare_mdcn_forward_f32(const float* x, const float* offset, const
                                       void* workspace, size_t workspace_bytes, glare_stream_t stream) {
   if (!x || !offset || !mask || !weight || !out) return GLARE_ERR_INVALID;
   const int st = dcn_check(B, C, H, W, Co, kh, kw, sh, sw, dh, dw, groups, dg);
+  if (st == GLARE_ERR_UNSUPPORTED) {   // outside the MFMA kernels' configurations: the general fp32 kernel (dcn_generic.hip), no workspace
+    const int gs = glare_mdcn_generic_check(B, C, H, W, Co, kh, kw, sh, sw, dh, dw, groups, dg);
+    if (gs != GLARE_OK) return gs;
+    return glare_mdcn_generic_forward(x, offset, mask, weight, bias_or_null, out, B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, groups,
+                                      dg, (hipStream_t)stream);
+  }
   if (st != GLARE_OK) return st;
   if (!workspace || workspace_bytes < glare_mdcn_workspace_bytes(B, C, H, W, Co, kh, kw)) return GLARE_ERR_WORKSPACE;
   float* x_nhwc = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
@@ -694,5 +695,5 @@ extern "C" int glare_mdcn_forward_f32(const float* x, const float* offset, const
   rc = glare_mdcn_pack_weight_f32(weight, wt, Co, C, kh, kw, dg, stream);
   if (rc != GLARE_OK) return rc;
   return glare_mdcn_forward_nhwc(x_nhwc, 0, C, 0, offset, 0, 0, mask, 0, 0, 0, wt, bias_or_null, out, 1, 0, 0, 0, B, C, H, W, Co,
-                                 kh, kw, sh, sw, ph, pw, dh, dw, groups, dg, stream);
+                                 kh, kw, sh, sw, ph, pw, dh, dw, groups, dg, 0, stream);
 }

@@ -19,6 +19,7 @@
 // The reference accumulates grad_weight / grad_bias into caller-zeroed buffers and assigns the others
 // (deform_conv.py:161-165); same here.  Like the reference, grad_input is order-nondeterministic (atomics).
 #include "common.h"
+#include "dcn_generic.h"
 
 namespace {
 
@@ -373,9 +374,13 @@ extern "C" int glare_mdcn_backward_f32(const float* x, const float* offset, cons
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || Co <= 0 || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 ||
       dg <= 0 || groups <= 0 || C % dg)
     return GLARE_ERR_INVALID;
-  if (groups != 1) return GLARE_ERR_UNSUPPORTED;
   const int cpg = C / dg;
-  if ((cpg != 32 && cpg != 64) || Co % 128 || Co > 256) return GLARE_ERR_UNSUPPORTED;
+  if (groups != 1 || (cpg != 32 && cpg != 64) || Co % 128 || Co > 256) {   // outside the MFMA kernels: general fp32 kernels, no workspace
+    const int gs = glare_mdcn_generic_check(B, C, H, W, Co, kh, kw, sh, sw, dh, dw, groups, dg);
+    if (gs != GLARE_OK) return gs;
+    return glare_mdcn_generic_backward(x, offset, mask, weight, grad_out, grad_input, grad_offset, grad_mask, grad_weight,
+                                       grad_bias_or_null, B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, groups, dg, (hipStream_t)stream_);
+  }
   if (!workspace || workspace_bytes < glare_mdcn_backward_workspace_bytes(B, C, H, W, Co, kh, kw)) return GLARE_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
   const int K = kh * kw;

@@ -94,7 +94,25 @@ __global__ void post_psnr_kernel(const double* __restrict__ mse_partial, long lo
   psnr[b] = mse == 0.0 ? 100.0 : 10.0 * log10(1.0 / mse);
 }
 
+// img_as_ubyte of both images as float planes in [0, 255] (the operands of calculate_ssim, infer_dataset_lol.py:152):
+// restored float in [0,1] -> rint(clip * 255) (skimage's float -> uint8 conversion rounds to nearest even), the GT as is
+__global__ __launch_bounds__(256) void ubyte_planes_kernel(const float* __restrict__ restored, const uint8_t* __restrict__ gt, long long n,
+                                                           float* __restrict__ x255, float* __restrict__ y255) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  x255[i] = rintf(fminf(fmaxf(restored[i], 0.f), 1.f) * 255.f);
+  y255[i] = (float)gt[i];
+}
+
 }  // namespace
+
+extern "C" int glare_harness_ubyte_planes_f32(const float* restored_hwc, const unsigned char* gt_hwc, long long n, float* x255, float* y255,
+                                              glare_stream_t stream) {
+  if (!restored_hwc || !gt_hwc || !x255 || !y255 || n <= 0) return GLARE_ERR_INVALID;
+  hipLaunchKernelGGL(ubyte_planes_kernel, dim3((unsigned)cdivll(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), restored_hwc,
+                     gt_hwc, n, x255, y255);
+  return glare_launch_status();
+}
 
 extern "C" int glare_harness_preprocess_u8(const unsigned char* img_hwc, int B, int H, int W, int pad, float* out_nchw,
                                            glare_stream_t stream) {

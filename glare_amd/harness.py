@@ -51,6 +51,27 @@ def postprocess_device(out_nchw, h, w, gts_u8=None):
     return restored, psnr_t
 
 
+def ssim_device(restored, gts_u8):
+    """SSIM as the reference's evaluation loop computes it (calculate_ssim(img_as_ubyte(target), img_as_ubyte(restored)),
+    utils2.py:42-89 / infer_dataset_lol.py:152): restored float [B,h,w,3] in [0,1] and the uint8 ground truth, both on the device
+    -> float64 [B] (device).  11x11 Gaussian (sigma 1.5) window at the valid positions, per channel, averaged."""
+    from . import _lib
+    from . import train_ops as T
+
+    _lib.require_cuda(restored, gts_u8)
+    assert restored.dtype == torch.float32 and gts_u8.dtype == torch.uint8 and restored.shape == gts_u8.shape
+    restored, gts_u8 = restored.contiguous(), gts_u8.contiguous()
+    B = restored.shape[0]
+    x, y = torch.empty_like(restored), torch.empty_like(restored)
+    _lib.check(_lib.lib().glare_harness_ubyte_planes_f32(_lib.ptr(restored), _lib.ptr(gts_u8), ctypes.c_longlong(restored.numel()),
+                                                         _lib.ptr(x), _lib.ptr(y), _lib.stream_handle()), "glare_harness_ubyte_planes_f32")
+    g = np.exp(-((np.arange(11) - 5.0) ** 2) / (2 * 1.5 ** 2))
+    g = (g / g.sum()).tolist()                                   # cv2.getGaussianKernel(11, 1.5)
+    C1, C2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+    vals = [T.ssim_forward(x[b:b + 1], y[b:b + 1], g, C1, C2)[1][0:1] for b in range(B)]   # mean ssim_map of one image
+    return torch.cat(vals).double()
+
+
 def preprocess(img_u8):
     """uint8 [H,W,3] -> fp32 [1,3,H+20,W+20] in the log domain."""
     img = np.pad(img_u8, [(0, PAD), (PAD, 0), (0, 0)], "reflect")

@@ -41,7 +41,7 @@ def load_lol_pairs(root):
     return lows, gts
 
 
-def run(n_images, batch=8, h=400, w=600, seed=1234, root=None, net_g=None, net_vq=None, pairs=None):
+def run(n_images, batch=8, h=400, w=600, seed=1234, root=None, net_g=None, net_vq=None, pairs=None, with_ssim=False):
     """Synthetic LOL-shaped pairs by default; `root` = a LOL dataset folder (eval15 split), `net_g` / `net_vq` = checkpoint
     files in the reference's format (glare_amd.checkpoint) -- without them the weights are name-seeded; `pairs` = (lows, gts)
     uint8 stacks [n,h,w,3] supplied by the caller."""
@@ -69,7 +69,9 @@ def run(n_images, batch=8, h=400, w=600, seed=1234, root=None, net_g=None, net_v
     def psnr_slice(lo, hi):
         out = enhance_batch(netG, net_vq, lows[lo:hi], device)
         gt = torch.from_numpy(np.ascontiguousarray(gts[lo:hi])).to(device)
-        _, vals = harness.postprocess_device(out, h, w, gt)       # crop, clamp, GT-mean gain, PSNR: all on the device
+        restored, vals = harness.postprocess_device(out, h, w, gt)   # crop, clamp, GT-mean gain, PSNR: all on the device
+        if with_ssim:                                                  # + SSIM (calculate_ssim, infer_dataset_lol.py:152)
+            return torch.stack([vals, harness.ssim_device(restored, gt)], dim=1)
         return vals.view(-1, 1)
 
     psnr_slice(0, min(batch, n_images))                           # warm-up: weight packing, workspace growth
@@ -77,14 +79,16 @@ def run(n_images, batch=8, h=400, w=600, seed=1234, root=None, net_g=None, net_v
     t0 = time.perf_counter()
     local = parallel.run_sharded(n_images, psnr_slice, rank, world, batch=batch, streams=2)
     if local is None:
-        local = torch.zeros(0, 1, dtype=torch.float64, device=device)
+        local = torch.zeros(0, 2 if with_ssim else 1, dtype=torch.float64, device=device)
     torch.cuda.synchronize()
     run.last_seconds = time.perf_counter() - t0                   # host uint8 in -> PSNR on the device, this rank's share
     full = parallel.gather_results(local, n_images, rank, world)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
-    return None if full is None else full.view(-1).cpu().numpy()
+    if full is None:
+        return None
+    return full.cpu().numpy() if with_ssim else full.view(-1).cpu().numpy()   # with_ssim: columns (PSNR, SSIM)
 
 
 def main():
@@ -96,11 +100,14 @@ def main():
     ap.add_argument("--root", default=None, help="LOL dataset folder (uses <root>/eval15/{low,high}/*.png)")
     ap.add_argument("--net-g", default=None, help="net_G checkpoint (reference format)")
     ap.add_argument("--net-vq", default=None, help="VQGAN checkpoint (reference format)")
+    ap.add_argument("--ssim", action="store_true", help="also report SSIM (utils2.calculate_ssim) per image")
     args = ap.parse_args()
-    psnrs = run(args.images, args.batch, args.height, args.width, root=args.root, net_g=args.net_g, net_vq=args.net_vq)
-    if psnrs is not None:
+    res = run(args.images, args.batch, args.height, args.width, root=args.root, net_g=args.net_g, net_vq=args.net_vq, with_ssim=args.ssim)
+    if res is not None:
         world = int(os.environ.get("WORLD_SIZE", "1"))
-        print(json.dumps({"images": int(len(psnrs)), "mean_psnr": float(np.mean(psnrs)), "psnr": [round(float(v), 4) for v in psnrs],
+        psnrs = res[:, 0] if args.ssim else res
+        extra = {"mean_ssim": float(np.mean(res[:, 1])), "ssim": [round(float(v), 5) for v in res[:, 1]]} if args.ssim else {}
+        print(json.dumps({"images": int(len(psnrs)), "mean_psnr": float(np.mean(psnrs)), "psnr": [round(float(v), 4) for v in psnrs], **extra,
                           "images_per_sec_incl_host_transfers": round(len(psnrs) / run.last_seconds, 2), "ranks": world}))
 
 

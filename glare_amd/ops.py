@@ -429,7 +429,10 @@ class PackedDcn:
         self.bias = None if bias is None else bias.detach().float().contiguous()
 
 
-def mdcn_forward_nhwc(x, om, pd, x_off=0, C=None, mask_is_logit=True, padding=1):
+MDCN_GENERAL_KERNEL = 1   # glare_hip.h: pin the general-extent MFMA kernel for this call
+
+
+def mdcn_forward_nhwc(x, om, pd, x_off=0, C=None, mask_is_logit=True, padding=1, flags=0):
     """x: NHWC bf16/fp32 [B,H,W,pitch]; om: planar fp32 [B, 3*dg*K, plane] (offsets then mask logits,
     the conv_offset output); returns NHWC fp32 [B,H,W,Co]."""
     require_cuda(x, om)
@@ -444,7 +447,7 @@ def mdcn_forward_nhwc(x, om, pd, x_off=0, C=None, mask_is_logit=True, padding=1)
                                              _ll(plane), _ll(om.shape[1] * plane), _i(int(mask_is_logit)),
                                              ptr(pd.packed), ptr(pd.bias), ptr(out), _i(0), _i(pd.co), _i(0), _ll(0), _i(B),
                                              _i(C), _i(H), _i(W), _i(pd.co), _i(pd.kh), _i(pd.kw), _i(1), _i(1), _i(padding),
-                                             _i(padding), _i(1), _i(1), _i(1), _i(pd.dg), stream_handle()),
+                                             _i(padding), _i(1), _i(1), _i(1), _i(pd.dg), _i(flags), stream_handle()),
           "glare_mdcn_forward_nhwc")
     return out
 

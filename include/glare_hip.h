@@ -225,8 +225,10 @@ int glare_attention_kv512_bf16(const void* q, int ldq, const void* kv, int ldkv,
  * mask [B][dg*kh*kw][Ho][Wo]; weight [Co][C/groups][kh][kw]), caller-allocated `out`
  * (deform_conv.py:147).  The reference's callee-owned `columns`/`ones` scratch is replaced by a
  * caller-owned workspace of glare_mdcn_workspace_bytes(); bias_or_null == NULL is with_bias=False.
- * Supported: groups == 1, C/dg in {32, 64}, Co % 64 == 0, Co <= 256 (the GLARE warps: C = Co = 256
- * and 128, dg = 4); anything else returns GLARE_ERR_UNSUPPORTED.
+ * Any shape the reference accepts (deform_conv_cuda.cpp:497-516: C % group == 0, Co % group == 0, C % deformable_group == 0):
+ * groups == 1, C/dg in {32, 64}, Co % 64 == 0, Co <= 256 (the GLARE warps: C = Co = 256 and 128, dg = 4) run on the MFMA kernels
+ * (they need the workspace); every other configuration runs on general fp32 kernels (csrc/dcn_generic.hip: any groups /
+ * deformable groups / channels / kernel / stride / padding / dilation; the workspace may then be NULL).
  *
  * glare_mdcn_forward_nhwc is the same operator on the pipeline's native layouts: x NHWC (fp32 or
  * bf16) with pitch/offset, offset/mask planar with explicit plane pitches and per-sample strides in
@@ -248,12 +250,11 @@ int glare_mdcn_forward_nhwc(const void* x, int x_is_bf16, int x_pitch, int x_off
                             long long mask_plane, long long mask_batch_stride, int mask_is_logit,
                             const float* weight_packed, const float* bias, float* out, int out_planar, int out_pitch,
                             int out_off, long long out_plane, int B, int C, int H, int W, int Co, int kh, int kw, int sh,
-                            int sw, int ph, int pw, int dh, int dw, int groups, int dg, glare_stream_t stream);
-
-/* glare_mdcn_forward_nhwc picks between two kernels with the same arithmetic: the general one (any extent, fp32 or bf16 x)
- * and a leaner one for bf16 x when every tensor is < 2 GB and kh*kw % 3 == 0.  Test hook: on != 0 pins the general kernel
- * process-wide (so a test can compare the two on the same input); returns the previous setting. */
-int glare_mdcn_force_generic(int on);
+                            int sw, int ph, int pw, int dh, int dw, int groups, int dg, int flags, glare_stream_t stream);
+/* glare_mdcn_forward_nhwc picks between two MFMA kernels with the same arithmetic: the general-extent one (fp32 or bf16 x) and a
+ * leaner one for bf16 x when every tensor is < 2 GB and kh*kw % 3 == 0.  `flags` & GLARE_MDCN_GENERAL_KERNEL pins the former for
+ * this call (a per-call argument: the library keeps no state; tests compare the two kernels on one input with it). */
+#define GLARE_MDCN_GENERAL_KERNEL 1
 
 /* ---- a10: modulated deformable convolution (DCNv2), backward ----------------------------------
  * Drop-in for the pybind function
@@ -266,7 +267,8 @@ int glare_mdcn_force_generic(int on);
  * grad_offset / grad_mask are overwritten.  grad_input may be NULL (skipped: the GLARE warp input needs
  * no gradient, VQLLFLOWDeformable_arch.py:240-248); grad_bias_or_null NULL = with_bias False.
  * grad_input is summed with fp32 atomics (order-nondeterministic), like the reference (kernel.cu:688).
- * Same shape support as the forward, plus Co % 128 == 0. */
+ * Shapes as the forward: the MFMA kernels additionally need Co % 128 == 0; everything else runs on the general fp32 kernels
+ * (grad_offset / grad_mask / grad_weight deterministic there, grad_input by atomics). */
 size_t glare_mdcn_backward_workspace_bytes(int B, int C, int H, int W, int Co, int kh, int kw);
 int glare_mdcn_backward_f32(const float* x, const float* offset, const float* mask, const float* weight,
                             const float* grad_out, float* grad_input, float* grad_offset, float* grad_mask,
@@ -447,6 +449,12 @@ int glare_l1_clamp_loss_f32(const float* rec_nhwc, const float* gt_nchw, int B, 
  *       0.299 ch2 (:142-144), clip, and psnr[b] = 10 log10(1 / mean((gt/255 - restored)^2)) (utils2.py:32-36). */
 int glare_harness_preprocess_u8(const unsigned char* img_hwc, int B, int H, int W, int pad, float* out_nchw,
                                 glare_stream_t stream);
+/* SSIM of the evaluation scripts (calculate_ssim, code/utils/utils2.py:42-89, called on img_as_ubyte(target) / img_as_ubyte(restored),
+ * infer_dataset_lol.py:152): this entry produces the two uint8-valued operands as fp32 planes in [0, 255] (restored rounded as
+ * skimage's img_as_ubyte does); the windowed statistics are glare_ssim_forward_f32 (11-tap Gaussian sigma 1.5 = cv2.getGaussianKernel,
+ * valid positions only, C1 = (0.01*255)^2, C2 = (0.03*255)^2), one call per image; its ssim mean over positions and channels is the metric. */
+int glare_harness_ubyte_planes_f32(const float* restored_hwc, const unsigned char* gt_hwc, long long n, float* x255, float* y255,
+                                   glare_stream_t stream);
 size_t glare_harness_postprocess_workspace_bytes(int B);
 int glare_harness_postprocess_f32(const float* out_nchw, const unsigned char* gt_hwc_or_null, int B, int h, int w, int Hp,
                                   int Wp, int pad, float* restored_hwc, double* psnr_or_null, void* workspace,

@@ -647,6 +647,29 @@ def gray_mean(img):
     return (0.114 * img[..., 0] + 0.587 * img[..., 1] + 0.299 * img[..., 2]).mean()
 
 
+def ssim_utils2(img1_u8, img2_u8):
+    """calculate_ssim (code/utils/utils2.py:42-89) on HxWx3 uint8 images, float64: per channel, the 11x11 Gaussian window
+    (cv2.getGaussianKernel(11, 1.5) = normalised exp(-(i-5)^2 / (2 * 1.5^2)), cv2's documented formula) at the VALID positions
+    (filter2D(...)[5:-5, 5:-5]), C1 = (0.01*255)^2, C2 = (0.03*255)^2, mean of the map; channels averaged.
+    PARITY UNPINNED BY EXECUTION (cv2 is not in this image); pinned instead to the reference's own pytorch_msssim.ssim, which is
+    the same formula and IS executable here (tests/golden/ssim_metric.npz), and by SSIM(x, x) = 1."""
+    k = np.exp(-((np.arange(11) - 5.0) ** 2) / (2 * 1.5 ** 2))
+    k = k / k.sum()
+    C1, C2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+
+    def filt(a):   # valid separable correlation
+        a = np.stack([np.convolve(r, k, mode="valid") for r in a])                 # along x
+        return np.stack([np.convolve(c, k, mode="valid") for c in a.T]).T          # along y
+
+    vals = []
+    for c in range(3):
+        a, b = img1_u8[:, :, c].astype(np.float64), img2_u8[:, :, c].astype(np.float64)
+        mu1, mu2 = filt(a), filt(b)
+        s1, s2, s12 = filt(a * a) - mu1 ** 2, filt(b * b) - mu2 ** 2, filt(a * b) - mu1 * mu2
+        vals.append((((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1 ** 2 + mu2 ** 2 + C1) * (s1 + s2 + C2))).mean())
+    return float(np.mean(vals))
+
+
 def psnr(a, b):  # utils2.py:32-36
     mse = np.mean((a - b) ** 2)
     return 10 * np.log10(1.0 / mse)

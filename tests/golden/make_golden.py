@@ -167,6 +167,23 @@ def msssim_fixture():
                         cs0=np.float32(cs.item()))
 
 
+def ssim_metric_fixture():
+    """ssim_metric.npz: a seeded uint8 image pair (a 'restored' image and its target) and the per-channel-mean SSIM the
+    REFERENCE's modules/pytorch_msssim.ssim gives for them with val_range=255 (11x11 Gaussian sigma 1.5, valid positions,
+    C1 = (0.01 L)^2, C2 = (0.03 L)^2: the formula of utils2.calculate_ssim, whose own implementation needs cv2)."""
+    R.install()
+    from models.modules import pytorch_msssim as PM
+
+    rng = np.random.RandomState(7)
+    tgt = rng.randint(0, 256, size=(40, 56, 3)).astype(np.uint8)
+    res = np.clip(tgt.astype(np.float64) + rng.randn(40, 56, 3) * 18.0, 0, 255).round().astype(np.uint8)
+    a = torch.from_numpy(tgt.transpose(2, 0, 1)[None].astype(np.float32))
+    b = torch.from_numpy(res.transpose(2, 0, 1)[None].astype(np.float32))
+    with torch.no_grad():
+        val = PM.ssim(a, b, window_size=11, size_average=True, val_range=255)
+    np.savez_compressed(os.path.join(HERE, "ssim_metric.npz"), target=tgt, restored=res, ssim=np.float32(val.item()))
+
+
 def sketch(t, k=8):
     """k seeded Gaussian projections of a tensor (float64): <t, r_i>.  A gradient g with relative error eps reproduces
     them to about eps * |g|."""
@@ -209,6 +226,8 @@ if __name__ == "__main__":
         msssim_fixture()
     elif len(sys.argv) > 1 and sys.argv[1] == "stage2":
         stage2_grads_fixture()
+    elif len(sys.argv) > 1 and sys.argv[1] == "ssim":
+        ssim_metric_fixture()
     elif len(sys.argv) > 1 and sys.argv[1] == "stage2_gtmean":
         stage2_grads_fixture(1.0, "stage2_grads_gtmean.npz")
     else:

@@ -78,11 +78,8 @@ def test_nhwc_bf16_pipeline_entry():
 @pytest.mark.parametrize("B,C,H,W,Co,off_scale", [(2, 128, 8, 10, 128, 0.3), (3, 128, 13, 21, 128, 4.0), (2, 256, 9, 11, 256, 1.5),
                                                    (1, 128, 40, 60, 256, 1.0), (2, 128, 210, 310, 128, 3.0), (4, 256, 210, 310, 256, 1.0)])
 def test_fast_and_general_kernels_agree(B, C, H, W, Co, off_scale):
-    """The bf16 pipeline entry has two kernels with the same arithmetic (glare_hip.h, glare_mdcn_force_generic): the lean
+    """The bf16 pipeline entry has two kernels with the same arithmetic (glare_hip.h, flag GLARE_MDCN_GENERAL_KERNEL): the lean
     one must reproduce the general one on ragged tiles, image boundaries inside a tile and out-of-image samples."""
-    import ctypes
-
-    from glare_amd import _lib
 
     g = torch.Generator().manual_seed(B * 1000 + H)
     x = torch.randn(B, H, W, C, generator=g).to(torch.bfloat16).cuda()
@@ -93,15 +90,10 @@ def test_fast_and_general_kernels_agree(B, C, H, W, Co, off_scale):
     om = om.cuda()
     w = torch.randn(Co, C, 3, 3, generator=g) * 0.05
     pd = ops.PackedDcn(w.cuda(), torch.randn(Co, generator=g).cuda(), 4)
-    lib = _lib.lib()
     fast = ops.mdcn_forward_nhwc(x, om, pd).cpu().numpy()
     for _ in range(3):   # run-to-run identical: the packed-fp32 version of this kernel was not (dcn.hip)
         assert np.array_equal(ops.mdcn_forward_nhwc(x, om, pd).cpu().numpy(), fast)
-    prev = lib.glare_mdcn_force_generic(ctypes.c_int(1))
-    try:
-        general = ops.mdcn_forward_nhwc(x, om, pd).cpu().numpy()
-    finally:
-        lib.glare_mdcn_force_generic(ctypes.c_int(prev))
+    general = ops.mdcn_forward_nhwc(x, om, pd, flags=ops.MDCN_GENERAL_KERNEL).cpu().numpy()   # a per-call flag: no library state
     # same products in the same order per (pixel, tap); only the fp32 accumulation grouping inside the MFMA chain is shared
     np.testing.assert_allclose(fast, general, rtol=0, atol=2e-5 * float(np.abs(general).max()))
 
@@ -214,3 +206,64 @@ def test_dcn_v1_surface_matches_oracle_with_unit_mask():
         deform_conv_ext.deform_conv_forward(x, w, off, x.new_empty(1), e, e, 3, 3, 1, 1, 1, 1, 1, 1, 1, 4, 2)   # CPU input
     pack = DeformConvPack(128, 128, 3, padding=1, deformable_groups=4)
     assert sorted(k for k, _ in pack.named_parameters()) == ["conv_offset.bias", "conv_offset.weight", "weight"]
+
+
+# ---- shapes outside the MFMA kernels' configurations: the general fp32 kernels (csrc/dcn_generic.hip) -----------------------
+GENERIC_CASES = [  # B, C, H, W, Co, k, stride, pad, dil, groups, dg
+    (2, 12, 7, 9, 8, 3, 1, 1, 1, 2, 3),      # conv groups AND deformable groups, channel counts off every tile size
+    (1, 8, 10, 6, 6, 1, 1, 0, 1, 1, 2),      # 1x1 kernel
+    (1, 16, 9, 11, 24, 3, 2, 2, 2, 4, 1),    # stride 2, dilation 2, four conv groups
+    (1, 6, 6, 7, 70, 5, 1, 2, 1, 1, 6),      # 5x5 kernel, more output channels than a workgroup's 64, one channel per deformable group
+    (2, 64, 8, 8, 64, 3, 1, 1, 1, 2, 2),     # MFMA-sized channel counts but groups = 2
+    (1, 128, 6, 5, 96, 3, 1, 1, 1, 1, 4),    # Co not a multiple of 64 with the GLARE input geometry
+]
+
+
+@pytest.mark.parametrize("B,C,H,W,Co,k,stride,pad,dil,groups,dg", GENERIC_CASES)
+def test_general_shapes_forward_and_backward_match_c_oracle(B, C, H, W, Co, k, stride, pad, dil, groups, dg):
+    """deform_conv_ext.modulated_deform_conv_forward / _backward accept any group / deformable_group / channel / kernel /
+    stride / padding / dilation configuration (deform_conv_cuda.cpp:497-516); so does the C ABI (no GLARE_ERR_UNSUPPORTED),
+    through the reference-shaped autograd Function, against oracle/dcn_ref.c: output and all five gradients."""
+    from glare_amd.modules.ops.dcn import modulated_deform_conv
+
+    g = torch.Generator().manual_seed(C * 7 + Co + k)
+    Ho = (H + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+    Wo = (W + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+    x = torch.randn(B, C, H, W, generator=g)
+    off = torch.randn(B, dg * 2 * k * k, Ho, Wo, generator=g) * 1.5
+    m = torch.rand(B, dg * k * k, Ho, Wo, generator=g)
+    w = torch.randn(Co, C // groups, k, k, generator=g) * (1.0 / (C // groups * k * k) ** 0.5)
+    b = torch.randn(Co, generator=g)
+    go = torch.randn(B, Co, Ho, Wo, generator=g)
+    ts = [t.clone().cuda().requires_grad_() for t in (x, off, m, w, b)]
+    out = modulated_deform_conv(ts[0], ts[1], ts[2], ts[3], ts[4], stride, pad, dil, groups, dg)
+    ref = c_ref.dcn_forward(x.numpy(), off.numpy(), m.numpy(), w.numpy(), b.numpy(), stride=stride, padding=pad, dilation=dil,
+                            groups=groups, dg=dg)
+    _close(out.detach().cpu().numpy(), ref)
+    out.backward(go.cuda())
+    gref = c_ref.dcn_backward(x.numpy(), off.numpy(), m.numpy(), w.numpy(), go.numpy(), stride=stride, padding=pad, dilation=dil,
+                              groups=groups, dg=dg)
+    for t, r, name in zip(ts, gref, ("grad_input", "grad_offset", "grad_mask", "grad_weight", "grad_bias")):
+        _close_grad(t.grad.cpu().numpy(), r, name)
+
+
+def test_general_shapes_c_abi_needs_no_workspace_and_rejects_bad_channel_counts():
+    import ctypes
+
+    from glare_amd import _lib
+
+    lib = _lib.lib()
+    B, C, H, W, Co, dg = 1, 12, 5, 6, 10, 3
+    g = torch.Generator().manual_seed(1)
+    x, off, m = torch.randn(B, C, H, W, generator=g).cuda(), torch.randn(B, dg * 18, H, W, generator=g).cuda(), torch.rand(B, dg * 9, H, W, generator=g).cuda()
+    w = torch.randn(Co, C, 3, 3, generator=g).cuda()
+    out = torch.empty(B, Co, H, W, device="cuda")
+    i = ctypes.c_int
+    args = lambda c, groups, dgs: (_lib.ptr(x), _lib.ptr(off), _lib.ptr(m), _lib.ptr(w), ctypes.c_void_p(0), _lib.ptr(out), i(B), i(c), i(H),
+                                   i(W), i(Co), i(3), i(3), i(1), i(1), i(1), i(1), i(1), i(1), i(groups), i(dgs), ctypes.c_void_p(0),
+                                   ctypes.c_size_t(0), _lib.stream_handle())
+    assert lib.glare_mdcn_forward_f32(*args(C, 1, dg)) == 0                 # NULL workspace: the general kernels need none
+    ref = c_ref.dcn_forward(x.cpu().numpy(), off.cpu().numpy(), m.cpu().numpy(), w.cpu().numpy(), None, dg=dg)
+    _close(out.cpu().numpy(), ref)
+    assert lib.glare_mdcn_forward_f32(*args(C, 1, 5)) != 0                  # C % deformable_group != 0 (deform_conv_cuda.cpp:511-516)
+    assert lib.glare_mdcn_forward_f32(*args(C, 5, dg)) != 0                 # C % group != 0

@@ -44,3 +44,27 @@ def test_postprocess_device_gain_and_psnr(B, h, w):
 def test_harness_device_rejects_cpu():
     with pytest.raises(NotImplementedError):
         harness.preprocess_device(torch.zeros(1, 8, 8, 3, dtype=torch.uint8))
+
+
+def test_ssim_metric_on_device(golden):
+    """Row f4: the evaluation loop's SSIM (calculate_ssim on img_as_ubyte images, infer_dataset_lol.py:152) on the device against
+    the reference-generated value (tests/golden/ssim_metric.npz) and the float64 oracle, batched, incl. the rounding of a float
+    restored image to uint8."""
+    import numpy as np
+    import torch
+
+    from glare_amd import harness
+    from oracle import torch_ref as O
+
+    g = golden("ssim_metric")
+    tgt, res = g["target"], g["restored"]
+    rng = np.random.RandomState(3)
+    res2 = np.clip(tgt.astype(np.float64) + rng.randn(*tgt.shape) * 40.0, 0, 255) / 255.0       # a float image: rounded inside
+    restored = torch.from_numpy(np.stack([res / 255.0, res2, tgt / 255.0]).astype(np.float32)).cuda()
+    gts = torch.from_numpy(np.stack([tgt, tgt, tgt])).cuda()
+    got = harness.ssim_device(restored, gts).cpu().numpy()
+    assert abs(got[0] - float(g["ssim"])) < 5e-6
+    assert abs(got[0] - O.ssim_utils2(tgt, res)) < 5e-6
+    res2_u8 = np.rint(np.clip(res2.astype(np.float32), 0, 1) * 255).astype(np.uint8)
+    assert abs(got[1] - O.ssim_utils2(tgt, res2_u8)) < 5e-6
+    assert abs(got[2] - 1.0) < 1e-6

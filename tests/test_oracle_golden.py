@@ -161,3 +161,11 @@ def test_train_gt_ratio_draw_is_one_python_random_call_per_forward():
     assert got == want and 20 < sum(got) < 60
     state = random.getstate()
     assert net._mean_is_gt(True) is True and net._mean_is_gt(False) is False and random.getstate() == state   # forced: no draw
+
+
+def test_ssim_metric_matches_reference_vector(golden):
+    """Row f4: oracle ssim_utils2 (calculate_ssim, utils2.py:42-89) against the value the reference's own pytorch_msssim.ssim
+    (same formula; utils2's implementation needs cv2, absent here) produced, plus SSIM(x, x) = 1."""
+    g = golden("ssim_metric")
+    assert abs(O.ssim_utils2(g["target"], g["restored"]) - float(g["ssim"])) < 2e-6     # the reference value is float32
+    assert abs(O.ssim_utils2(g["target"], g["target"]) - 1.0) < 1e-12

@@ -55,9 +55,7 @@ def main():
         om = torch.randn(B, 108, plane, generator=g).to(DEV)
         pd = ops.PackedDcn((torch.randn(c, c, 3, 3, generator=g) * 0.02).to(DEV), torch.zeros(c, device=DEV), 4)
         total += check("dcn forward C=%d %dx%d" % (c, h, w), lambda: ops.mdcn_forward_nhwc(x, om, pd))
-        _lib.lib().glare_mdcn_force_generic(ctypes.c_int(1))
-        total += check("dcn forward (general kernel) C=%d" % c, lambda: ops.mdcn_forward_nhwc(x, om, pd))
-        _lib.lib().glare_mdcn_force_generic(ctypes.c_int(0))
+        total += check("dcn forward (general kernel) C=%d" % c, lambda: ops.mdcn_forward_nhwc(x, om, pd, flags=ops.MDCN_GENERAL_KERNEL))
     x = torch.randn(B, 420, 620, 128, generator=g).to(torch.bfloat16).to(DEV)
     gm, bt = torch.ones(128, device=DEV), torch.zeros(128, device=DEV)
     total += check("groupnorm 128 420x620", lambda: ops.groupnorm(x, gm, bt))
