@@ -114,9 +114,11 @@ def test_nhwc_bf16_latent_size_against_c_oracle():
 
 
 def test_errors():
-    x, off, m, w, b = _case(6, 1, 24, 4, 4, 64, 4)  # cpg = 6: unsupported, must say so (not crash)
-    with pytest.raises(Exception, match="unsupported"):
-        ops.mdcn_forward(x.cuda(), off.cuda(), m.cuda(), w.cuda(), b.cuda(), 1, 1, 1, 1, 4)
+    x, off, m, w, b = _case(6, 1, 24, 4, 4, 64, 4)  # 6 channels per deformable group: outside the MFMA kernels -> general kernels
+    got = ops.mdcn_forward(x.cuda(), off.cuda(), m.cuda(), w.cuda(), b.cuda(), 1, 1, 1, 1, 4).cpu().numpy()
+    _close(got, c_ref.dcn_forward(x.numpy(), off.numpy(), m.numpy(), w.numpy(), b.numpy(), dg=4))
+    with pytest.raises(Exception, match="invalid"):     # channels not divisible by the deformable groups (deform_conv_cuda.cpp:511-516)
+        ops.mdcn_forward(x.cuda(), off.cuda(), m.cuda(), w.cuda(), b.cuda(), 1, 1, 1, 1, 5)
     with pytest.raises(NotImplementedError):
         ops.mdcn_forward(x, off, m, w, b, 1, 1, 1, 1, 4)  # CPU tensors: no fallback
 
