@@ -12,8 +12,8 @@ collective (weak scaling: 8 images per GPU); at N > 1 every step ends with the o
 path has -- the RCCL gather of the enhanced images to rank 0 (BASELINE configs[2]) -- plus the timing
 barrier / max.  Started as a plain process with --gpus N > 1, bench.py launches the N ranks itself.
 Rank 0 prints ONE JSON line, including
-  roofline     -- the dominant kernel (d=512 blockwise attention) measured live with events on the
-                  launch stream, against the dense bf16 MFMA peak;
+  roofline     -- the dominant kernel (d=512 blockwise attention, shared keys / values) measured live with
+                  events on the launch stream, against the dense bf16 MFMA peak;
   cpu_baseline -- the CPU oracle (a port of the reference's fp32 torch path) timed on this box's host
                   cores on one 400x600 image.
 """
@@ -52,10 +52,10 @@ def build_nets(device):
 
 
 def profiled_traffic(batch):
-    """HBM bytes per launch of the attention kernel from the committed PMC passes (profiles/r01_pmc_traffic.txt: rocprofv3 --pmc
+    """HBM bytes per launch of the attention kernel from the committed PMC passes (profiles/r02_pmc_traffic.txt: rocprofv3 --pmc
     FETCH_SIZE and WRITE_SIZE in separate counter-only runs at B=8; FETCH x2 per the gfx950 note of MI355X_MICROARCH.md).
     Counters cannot be read inside this process, so the figure is the profiled one for the SAME launch shape, else None."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.txt")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.txt")
     if batch != 8 or not os.path.exists(path):
         return None, None
     fetch = write = None
@@ -69,7 +69,7 @@ def profiled_traffic(batch):
             write = float(t[1])
     if fetch is None or write is None:
         return None, None
-    return int((2.0 * fetch + write) * 1024), "profiles/r01_pmc_traffic.txt (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes, KB, FETCH x2)"
+    return int((2.0 * fetch + write) * 1024), "profiles/r02_pmc_traffic.txt (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes, KB, FETCH x2)"
 
 
 def attention_roofline(device, batch, live_events, reps=5):
@@ -81,18 +81,16 @@ def attention_roofline(device, batch, live_events, reps=5):
     N, C = 105 * 155, 512
     live = [s.elapsed_time(e) for s, e, b, n in live_events if b == batch and n == N]
     g = torch.Generator().manual_seed(0)
-    qk = (torch.randn(batch, N, 2 * C, generator=g) * 0.3).to(torch.bfloat16).to(device)
-    npad = (N + 63) // 64 * 64
-    vt = torch.zeros(batch, C, npad, dtype=torch.bfloat16, device=device)
-    vt[:, :, :N] = torch.randn(batch, C, N, generator=g).to(torch.bfloat16).to(device)
+    q = (torch.randn(batch, N, C, generator=g) * 0.3).to(torch.bfloat16).to(device)
+    x = torch.randn(batch, N, C, generator=g).to(torch.bfloat16).to(device)
     out = torch.empty(batch, N, C, dtype=torch.bfloat16, device=device)
     for _ in range(2):
-        ops.attention_d512(qk, qk[..., C:], vt, N, ldq=2 * C, ldk=2 * C, out=out)
+        ops.attention_kv512(q, x, N, out=out, key_splits=1)
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     s.record()
     for _ in range(reps):
-        ops.attention_d512(qk, qk[..., C:], vt, N, ldq=2 * C, ldk=2 * C, out=out)
+        ops.attention_kv512(q, x, N, out=out, key_splits=1)
     e.record()
     torch.cuda.synchronize()
     isolated_ms = s.elapsed_time(e) / reps
@@ -100,9 +98,10 @@ def attention_roofline(device, batch, live_events, reps=5):
     flops = 4.0 * batch * N * N * C  # algorithmic: QK^T + PV, SURVEY.md section 8d
     achieved = flops / (ms * 1e-3) / 1e12
     traffic, source = profiled_traffic(batch)
-    return {"bound": "mfma", "kernel": "attn_fwd_kernel (d=512 blockwise attention)", "achieved": round(achieved, 1),
+    return {"bound": "mfma", "kernel": "attn_kv_fwd_kernel (d=512 blockwise attention with shared keys / values: 4*B*N^2*d FLOP per launch)",
+            "achieved": round(achieved, 1),
             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-            "traffic_unit": "HBM bytes per launch", "traffic_source": source, "algorithmic_bytes": int(4 * 2 * batch * N * C),
+            "traffic_unit": "HBM bytes per launch", "traffic_source": source, "algorithmic_bytes": int(3 * 2 * batch * N * C),
             "ms_per_launch": round(ms, 3), "launches_timed": len(live),
             "timing": "HIP event pairs around every launch inside the timed region" if live else "isolated launches (no live events)",
             "isolated_ms_per_launch": round(isolated_ms, 3), "launch_shape": {"B": batch, "N": N, "d": C}}

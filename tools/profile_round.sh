@@ -1,0 +1,27 @@
+#!/bin/bash
+# One-call profile of a round on the GPU box: the bench line, its rocprofv3 kernel-trace summary, the PMC traffic / SQ counters of
+# the kbench kernels (counters in their own runs, kernel trace only -- never with --sys-trace / hip / hsa domains) and the training
+# steps.  usage: tools/profile_round.sh r02      -> gpurun_out/<tag>_*.txt / .json (copy the ones to keep into profiles/)
+tag=${1:-rXX}
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+python bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench.err
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o b -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_bench_prof.log 2>&1
+python tools/rocpd_stats.py $(ls gpurun_out/prof_$tag/*/b_results.db gpurun_out/prof_$tag/b_results.db 2>/dev/null | head -1) > gpurun_out/${tag}_bench_kernel_stats.txt 2>&1
+{
+  echo "# rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in SEPARATE runs, counters only), MI355X, B=8, $tag"
+  echo "# units: KB per dispatch as reported; gfx950: FETCH_SIZE reports 1/2 of a wide coalesced read stream -> x2 (MI355X_MICROARCH.md)"
+  for k in attn conv gn dcn; do echo "== $k"; bash tools/pmc_traffic.sh ${tag}_$k $k 2>&1 | grep -v "amdgpu.ids"; done
+} > gpurun_out/${tag}_pmc_traffic.txt
+{
+  echo "# rocprofv3 --pmc SQ counters (two passes of 8), kbench kernels at B=8, $tag"
+  for k in attn conv dcn; do echo "== $k"; bash tools/pmc_kernel.sh ${tag}_$k $k 2>&1 | grep -v "amdgpu.ids"; done
+} > gpurun_out/${tag}_pmc_kernels.txt
+python tools/kbench.py > gpurun_out/${tag}_kbench.txt 2>&1
+for st in stage2 stage3; do
+  python tools/train_bench.py $st 10 > gpurun_out/${tag}_train_$st.txt 2>&1
+  rocprofv3 --kernel-trace --stats -d gpurun_out/proft_${tag}_$st -o t -- python tools/train_bench.py $st 5 > /dev/null 2>&1
+  python tools/rocpd_stats.py $(ls gpurun_out/proft_${tag}_$st/*/t_results.db gpurun_out/proft_${tag}_$st/t_results.db 2>/dev/null | head -1) > gpurun_out/${tag}_train_${st}_kernel_stats.txt 2>&1
+done
+rm -rf gpurun_out/prof_$tag gpurun_out/proft_${tag}_* gpurun_out/tr_f_* gpurun_out/tr_w_* gpurun_out/pmc_${tag}_*/ gpurun_out/pmc2_${tag}_*/ 2>/dev/null
+ls -la gpurun_out | grep $tag
