@@ -1,0 +1,314 @@
+// 1x1 convolution as a WEIGHT-STATIONARY GEMM (round 2).
+//
+// Replaces the 1x1 nn.Conv2d's of the path with 128 <= Cin <= 512 and Cout a multiple of 128: AttnBlock's folded query / output
+// projections (encoder_decoder.py:146-165, 22 launches per 8-image step) and the ResnetBlock nin_shortcuts (:104-115).
+//   out[p, co] = act(sum_ci x[p, ci] * w[co, ci] + bias[co]) (+ residual[p, co])
+// The implicit-GEMM conv kernel (conv_igemm.hip, KS = 1) ran these at 0.17-0.18 of the bf16 peak: with K = Cin = 512 a 256 x 128
+// tile is only 16 stages of 16 MFMAs per wave, each with its barrier and 6 LDS-DMA pieces per wave, plus a prologue and an
+// LDS-staged epilogue per tile.  The GEMM is short in K and long in M (130 200 pixels x 512 x 512 at the quarter resolution): it is
+// bound by HBM (x read once, out written once, residual read once: 400 MB = 0.07 ms at 5.7 TB/s), not by the matrix pipe (0.03 ms).
+// So the weights stay put and the pixels stream:
+//   * one persistent workgroup per CU (256 in all); its 128-cout slice of W (128 x Cin bf16 <= 128 KB) is DMA'd into LDS ONCE;
+//   * each of the 4 waves (one per SIMD) walks its own 32-pixel row blocks: A fragments straight from global memory to
+//     registers (32 rows x 32 B per instruction; the four k-steps that share a 128-B line follow each other), B fragments
+//     from the resident LDS tile (XOR-swizzled, conflict-free ds_read_b128), 4 independent accumulators (32 px x 128 co);
+//   * no barrier and no DMA in the steady state: the waves never wait for each other;
+//   * the 128 / Cout... co-tiles of one pixel range run on CUs of the SAME XCD (block -> (xcd, slot)), so x is fetched from
+//     HBM once per range and the other co-tiles hit L2;
+//   * epilogue per row block through a wave-private 8 KB LDS slab: bias, 16-B residual loads, activation, 16-B stores, and the
+//     GroupNorm partial sums of the rounded output (one part per (image, row block)).
+#include <type_traits>
+#ifndef C1_ABL
+#define C1_ABL 0
+#endif
+
+#include "common.h"
+
+namespace {
+
+struct C1Params {
+  const bf16_t* x;
+  const bf16_t* w;       // [Cout][Cin] bf16
+  const float* bias;
+  const bf16_t* res;
+  bf16_t* out;
+  float* gn_part;        // [B][rbi][Cout/4][2] or null
+  int B, N;              // images, pixels per image
+  int Cin, Cout;
+  int xpitch, xoff, opitch, ooff, rpitch, roff;
+  int act, nct, rbi;     // co-tiles (Cout / 128), row blocks per image
+};
+
+template <int ACT>   // compile-time inside the epilogue (a runtime switch per element costs ~3 scalar branches per element)
+__device__ __forceinline__ float act1(float v) {
+  if constexpr (ACT == GLARE_ACT_RELU) return fmaxf(v, 0.f);
+  else if constexpr (ACT == GLARE_ACT_SIGMOID) return sigmoidf_(v);
+  else if constexpr (ACT == GLARE_ACT_SWISH) return swishf_(v);
+  else return v;
+}
+template <typename F>
+__device__ __forceinline__ void with_act1(int act, F&& f) {
+  switch (act) {
+    case GLARE_ACT_RELU: f(std::integral_constant<int, GLARE_ACT_RELU>{}); break;
+    case GLARE_ACT_SIGMOID: f(std::integral_constant<int, GLARE_ACT_SIGMOID>{}); break;
+    case GLARE_ACT_SWISH: f(std::integral_constant<int, GLARE_ACT_SWISH>{}); break;
+    default: f(std::integral_constant<int, GLARE_ACT_NONE>{}); break;
+  }
+}
+
+template <int KSTEPS>   // Cin / 16
+__global__ __launch_bounds__(256, 1) void conv1x1_ws_kernel(const C1Params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ROWB = KSTEPS * 32;              // bytes of one weight row
+  constexpr int CPR = ROWB / 16;                 // 16-B chunks per weight row (16 / 32 / 64)
+  constexpr int RPP = 1024 / ROWB;               // weight rows per 1-KB DMA piece (1, 2 or 4... 8 for Cin = 128)
+  char* const slab_base = smem + 128 * ROWB;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // block -> (xcd, slot): the co-tiles of one pixel range sit on one XCD
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;                 // slot 0..31
+  const int ct = slot % p.nct, rng_in_xcd = slot / p.nct, rpx = 32 / p.nct;
+  const int range = xcd * rpx + rng_in_xcd, n_ranges = 8 * rpx;
+  const int total_rb = p.B * p.rbi;
+  const int rb_lo = (int)((long long)total_rb * range / n_ranges), rb_hi = (int)((long long)total_rb * (range + 1) / n_ranges);
+
+  // ---- weights of this co-tile into LDS, once: row r, chunk c at r * CPR + (c ^ (r & 15)) (source-side swizzle)
+  {
+    const bf16_t* wt = p.w + (size_t)ct * 128 * p.Cin;
+    const int r_in = lane / CPR, c_ph = lane % CPR;
+#pragma unroll 4
+    for (int piece = wave; piece < 128 / RPP; piece += 4) {
+      const int r = piece * RPP + r_in;
+      const int c_src = c_ph ^ (r & 15);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wt + (size_t)r * p.Cin + c_src * 8),
+                                       (__attribute__((address_space(3))) void*)(smem + piece * 1024), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  const int px = lane & 31, khalf = lane >> 5;
+  // The contraction order is free as long as A and B agree: "k-step" v = 4 g + i pairs lane (px, khalf) with the 8 channels
+  // 64 g + 32 khalf + 8 i .. +8, so that a lane's four A loads of a group are 64 CONTIGUOUS bytes and the two half-waves cover
+  // whole 128-B lines (with the natural order 16 v + 8 khalf every load instruction touched a quarter of 32 lines, four times).
+  // B fragment (j, v): row 32 j + px, 16-B chunk 8 g + 4 khalf + i  ->  boff[v & 7] + (v >> 3) * 256 + j * 32 * ROWB
+  int boff[8];
+#pragma unroll
+  for (int bb = 0; bb < 8; ++bb) boff[bb] = px * ROWB + ((((bb >> 2) * 8 + 4 * khalf + (bb & 3)) ^ (px & 15)) * 16);
+  char* const slab = slab_base + wave * 8192;
+
+  const int co0 = ct * 128;
+  float bias_v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bias_v[j] = p.bias ? p.bias[co0 + 32 * j + px] : 0.f;
+
+  // A fragments are fetched one UNIT (16 k-steps = 16 KB per wave) ahead of the MFMAs that consume them: with one wave per SIMD
+  // nothing else hides the memory latency (8 k-steps ahead left the kernel latency-bound at 1.3 TB/s), and two whole row blocks of
+  // fragments (256 registers) spill -- a scratch reload in this loop waits vmcnt(0), i.e. for every prefetch in flight.
+  constexpr int UNIT = KSTEPS < 16 ? KSTEPS : 16, UPB = KSTEPS / UNIT;          // units per row block
+  auto unit_ptr = [&](int q) {                                                   // unit q of this wave: row block + k offset
+    const int rb_ = rb_lo + wave + 4 * (q / UPB), u_ = q % UPB;
+    const int b_ = rb_ / p.rbi, r0_ = (rb_ - b_ * p.rbi) * 32;
+    const int nrows_ = min(32, p.N - r0_);
+    return p.x + ((size_t)b_ * p.N + r0_ + min(px, nrows_ - 1)) * p.xpitch + p.xoff + khalf * 32 + u_ * UNIT * 16;
+  };
+  const int n_rb = rb_hi > rb_lo + wave ? (rb_hi - rb_lo - wave + 3) / 4 : 0, n_units = n_rb * UPB;
+  bf16x8 af[2][UNIT];
+  auto fetch = [&](auto parc, int q) {
+    constexpr int P = decltype(parc)::value;
+    const bf16_t* ap = unit_ptr(q);
+#pragma unroll
+    for (int e = 0; e < UNIT; ++e) {
+#if C1_ABL & 1   // timing ablation: no A loads
+      af[P][e] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)q, (unsigned)e, 0x3f803f80u, 0x3f803f80u});
+      asm volatile("" ::"v"(ap));
+#else
+      af[P][e] = *reinterpret_cast<const bf16x8*>(ap + (e >> 2) * 64 + (e & 3) * 8);
+#endif
+    }
+  };
+  if (n_units > 0) fetch(std::integral_constant<int, 0>{}, 0);
+  f32x16 acc[4];
+  for (int q = 0; q < n_units; ++q) {
+    const int rb = rb_lo + wave + 4 * (q / UPB), u = q % UPB;
+    const int b = rb / p.rbi, r0 = (rb - b * p.rbi) * 32;
+    const int nrows = min(32, p.N - r0);
+    const size_t pix0 = (size_t)b * p.N + r0;
+    if (u == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    }
+    auto body = [&](auto parc) {
+      constexpr int P = decltype(parc)::value;
+      if (q + 1 < n_units) fetch(std::integral_constant<int, P ^ 1>{}, q + 1);
+#pragma unroll
+      for (int e = 0; e < UNIT; ++e) {
+        const int ks = u * UNIT + e;            // u is 0 when UPB == 1; otherwise boff[] only depends on ks & 7 = e & 7
+        bf16x8 bf[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          bf[j] = *reinterpret_cast<const bf16x8*>(smem + boff[e & 7] + (ks >> 3) * 256 + j * 32 * ROWB);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[P][e], bf[j], acc[j], 0, 0, 0);
+      }
+    };
+    if ((q & 1) == 0) body(std::integral_constant<int, 0>{});
+    else body(std::integral_constant<int, 1>{});
+    if (u != UPB - 1) continue;
+#if C1_ABL & 2   // timing ablation: no epilogue
+    asm volatile("" ::"v"(acc[0][0]), "v"(acc[1][5]), "v"(acc[2][9]), "v"(acc[3][15]));
+    continue;
+#endif
+
+    // ---- epilogue: C/D layout col = lane & 31 (co within the 32-tile), row = (r & 3) + 8 (r >> 2) + 4 khalf (pixel).
+    // Phase 1: + bias (+ act when there is no residual) -> bf16; neighbouring lanes (co, co + 1) exchange one value so that each
+    // lane writes one packed 4-B word per register pair; slab row m = 256 B, 16-B chunk c at (c ^ (m & 15)).
+    float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
+    with_act1(p.act, [&](auto actc) {
+    constexpr int ACT = decltype(actc)::value;
+    const bool act_early = p.res == nullptr;
+    const int odd = lane & 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        float a = acc[j][2 * t] + bias_v[j], c = acc[j][2 * t + 1] + bias_v[j];
+        if (act_early) { a = act1<ACT>(a); c = act1<ACT>(c); }
+        const float send = odd ? a : c;
+        const float recv = __shfl_xor(send, 1, 64);
+        const int r = 2 * t + odd;
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        const uint32_t wv = odd ? pack_bf2(recv, c) : pack_bf2(a, recv);
+        const int col = 32 * j + (px & ~1);                               // even channel of the pair, 0..127
+        *reinterpret_cast<uint32_t*>(slab + m * 256 + (((col >> 3) ^ (m & 15)) * 16) + (col & 7) * 2) = wv;
+      }
+    }
+    // Phase 2: 16-B rows out: lane handles chunk ch = lane & 15 of rows (lane >> 4) + 4 it
+    const int ch = lane & 15;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int m = (lane >> 4) + 4 * it;
+      if (m < nrows) {
+        u32x4 v = *reinterpret_cast<const u32x4*>(slab + m * 256 + ((ch ^ (m & 15)) * 16));
+        const size_t pix = pix0 + m;
+        const int co = co0 + ch * 8;
+        if (p.res) {
+          const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + pix * p.rpitch + p.roff + co);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            v[e] = pack_bf2(act1<ACT>(bflo(v[e]) + bflo(rv[e])), act1<ACT>(bfhi(v[e]) + bfhi(rv[e])));
+        }
+        *reinterpret_cast<u32x4*>(p.out + pix * p.opitch + p.ooff + co) = v;
+        if (p.gn_part) {
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const float x0 = bflo(v[e]), x1 = bfhi(v[e]), y0 = bflo(v[2 + e]), y1 = bfhi(v[2 + e]);
+            gs0 += x0 + x1; gq0 += x0 * x0 + x1 * x1;
+            gs1 += y0 + y1; gq1 += y0 * y0 + y1 * y1;
+          }
+        }
+      }
+    }
+    });
+    if (p.gn_part) {   // lanes 16 apart hold the same channel chunk
+#pragma unroll
+      for (int o = 16; o < 64; o <<= 1) {
+        gs0 += __shfl_xor(gs0, o, 64); gq0 += __shfl_xor(gq0, o, 64);
+        gs1 += __shfl_xor(gs1, o, 64); gq1 += __shfl_xor(gq1, o, 64);
+      }
+      if (lane < 16) {
+        float* dst = p.gn_part + (((size_t)b * p.rbi + (rb - b * p.rbi)) * (p.Cout / 4) + (co0 + lane * 8) / 4) * 2;
+        dst[0] = gs0; dst[1] = gq0; dst[2] = gs1; dst[3] = gq1;
+      }
+    }
+  }
+}
+
+// OIHW fp32 [Cout][Cin][1][1] -> bf16 [Cout][Cin]
+__global__ void c1_pack_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = f2bf(w[i]);
+}
+
+// [B][rbi][Cout/4][2] -> [B][1][32][2] (the statistics block gn_apply consumes)
+__global__ __launch_bounds__(256) void c1_gn_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int Cout) {
+  __shared__ float red[2][4];
+  const int b = blockIdx.x / 32, g = blockIdx.x % 32;
+  const int upg = Cout / 128, U = Cout / 4;
+  float s = 0.f, q = 0.f;
+  for (int i = threadIdx.x; i < nparts * upg; i += 256) {
+    const int pt = i / upg, u = g * upg + i % upg;
+    const float* src = part + (((size_t)b * nparts + pt) * U + u) * 2;
+    s += src[0];
+    q += src[1];
+  }
+  s = wave_sum(s);
+  q = wave_sum(q);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[((size_t)b * 32 + g) * 2] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    out[((size_t)b * 32 + g) * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+
+}  // namespace
+
+extern "C" int glare_conv1x1_ws_supported(int Cin, int Cout) {
+  if (Cin != 128 && Cin != 256 && Cin != 512) return 0;
+  if (Cout <= 0 || Cout % 128) return 0;
+  const int nct = Cout / 128;
+  return (nct <= 32 && 32 % nct == 0) ? 1 : 0;
+}
+
+extern "C" int glare_conv1x1_ws_pack_weight(const float* w_oihw, int cout, int cin, void* w_bf16, glare_stream_t stream) {
+  if (!w_oihw || !w_bf16 || cout <= 0 || cin <= 0) return GLARE_ERR_INVALID;
+  const long long n = (long long)cout * cin;
+  hipLaunchKernelGGL(c1_pack_kernel, dim3((unsigned)cdivll(n, 256)), dim3(256), 0, (hipStream_t)stream, w_oihw, (bf16_t*)w_bf16, n);
+  return glare_launch_status();
+}
+
+extern "C" long long glare_conv1x1_ws_gn_partial_elems(int B, long long pixels_per_image, int Cout) {
+  if (B <= 0 || pixels_per_image <= 0 || Cout <= 0) return GLARE_ERR_INVALID;
+  return (long long)B * cdivll(pixels_per_image, 32) * (Cout / 4) * 2;
+}
+
+extern "C" int glare_conv1x1_ws_gn_reduce(const float* gn_partial, float* stats_out, int B, long long pixels_per_image, int Cout,
+                                          glare_stream_t stream) {
+  if (!gn_partial || !stats_out || B <= 0 || Cout % 128) return GLARE_ERR_INVALID;
+  hipLaunchKernelGGL(c1_gn_reduce_kernel, dim3(B * 32), dim3(256), 0, (hipStream_t)stream, gn_partial, stats_out,
+                     (int)cdivll(pixels_per_image, 32), Cout);
+  return glare_launch_status();
+}
+
+extern "C" int glare_conv1x1_ws_bf16(const void* x, int x_pitch, int x_off, const void* w_bf16, const float* bias, const void* residual,
+                                     int res_pitch, int res_off, void* out, int out_pitch, int out_off, int B, long long pixels_per_image,
+                                     int Cin, int Cout, int act, float* gn_partial, glare_stream_t stream) {
+  if (!x || !w_bf16 || !out || B <= 0 || pixels_per_image <= 0) return GLARE_ERR_INVALID;
+  if (!glare_conv1x1_ws_supported(Cin, Cout)) return GLARE_ERR_UNSUPPORTED;
+  if ((x_pitch % 8) || (x_off % 8) || (out_pitch % 8) || (out_off % 8) || x_off + Cin > x_pitch || out_off + Cout > out_pitch)
+    return GLARE_ERR_UNSUPPORTED;
+  if (residual && ((res_pitch % 8) || (res_off % 8) || res_off + Cout > res_pitch)) return GLARE_ERR_UNSUPPORTED;
+  if (pixels_per_image > 0x7fffffffLL || (long long)B * cdivll(pixels_per_image, 32) > 0x7fffffffLL) return GLARE_ERR_INVALID;
+  C1Params p;
+  p.x = (const bf16_t*)x; p.w = (const bf16_t*)w_bf16; p.bias = bias; p.res = (const bf16_t*)residual; p.out = (bf16_t*)out;
+  p.gn_part = gn_partial;
+  p.B = B; p.N = (int)pixels_per_image; p.Cin = Cin; p.Cout = Cout;
+  p.xpitch = x_pitch; p.xoff = x_off; p.opitch = out_pitch; p.ooff = out_off; p.rpitch = res_pitch; p.roff = res_off;
+  p.act = act; p.nct = Cout / 128; p.rbi = (int)cdivll(pixels_per_image, 32);
+  const size_t lds = (size_t)128 * Cin * 2 + 4 * 8192;
+  hipStream_t s = (hipStream_t)stream;
+#define C1_CASE(KS_)                                                                                                       \
+  if (Cin == 16 * KS_) {                                                                                                   \
+    if (hipFuncSetAttribute((const void*)conv1x1_ws_kernel<KS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+      return GLARE_ERR_LAUNCH;                                                                                             \
+    hipLaunchKernelGGL(conv1x1_ws_kernel<KS_>, dim3(256), dim3(256), lds, s, p);                                           \
+    return glare_launch_status();                                                                                          \
+  }
+  C1_CASE(8) C1_CASE(16) C1_CASE(32)
+#undef C1_CASE
+  return GLARE_ERR_UNSUPPORTED;
+}

@@ -71,12 +71,23 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-__device__ __forceinline__ float apply_act(float v, int act) {
+// The activation is a COMPILE-TIME constant inside the epilogues (dispatched once per workgroup, `with_act` below): as a runtime
+// switch per output element it compiled to ~3 scalar branches per element -- 128 elements per thread, several thousand cycles per
+// tile, a quarter of a 128-channel tile's whole MFMA time (found in round 2 with a plain instruction histogram of the ISA).
+template <int ACT>
+__device__ __forceinline__ float apply_act(float v) {
+  if constexpr (ACT == GLARE_ACT_RELU) return fmaxf(v, 0.f);
+  else if constexpr (ACT == GLARE_ACT_SIGMOID) return sigmoidf_(v);
+  else if constexpr (ACT == GLARE_ACT_SWISH) return swishf_(v);
+  else return v;
+}
+template <typename F>
+__device__ __forceinline__ void with_act(int act, F&& f) {
   switch (act) {
-    case GLARE_ACT_RELU: return fmaxf(v, 0.f);
-    case GLARE_ACT_SIGMOID: return sigmoidf_(v);
-    case GLARE_ACT_SWISH: return swishf_(v);
-    default: return v;
+    case GLARE_ACT_RELU: f(std::integral_constant<int, GLARE_ACT_RELU>{}); break;
+    case GLARE_ACT_SIGMOID: f(std::integral_constant<int, GLARE_ACT_SIGMOID>{}); break;
+    case GLARE_ACT_SWISH: f(std::integral_constant<int, GLARE_ACT_SWISH>{}); break;
+    default: f(std::integral_constant<int, GLARE_ACT_NONE>{}); break;
   }
 }
 
@@ -302,6 +313,8 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
     // fused GroupNorm statistics of the tensor being written (the consumer's gn_stats pass would re-read it):
     // per lane the sum / sum of squares of its two 4-channel units over its pixels, from the ROUNDED values
     float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
+    with_act(p.act, [&](auto actc) {
+    constexpr int ACT = decltype(actc)::value;
     static_for<MT / HT>([&](auto hc) {
       constexpr int half = decltype(hc)::value;
       static_for<NT>([&](auto jc) {
@@ -314,7 +327,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
           for (int t = 0; t < 8; ++t) {
             constexpr int i = half * HT + il;
             float a = acc[i][j][2 * t] + bv, c = acc[i][j][2 * t + 1] + bv;
-            if (act_early) { a = apply_act(a, p.act); c = apply_act(c, p.act); }
+            if (act_early) { a = apply_act<ACT>(a); c = apply_act<ACT>(c); }
             const float send = odd ? a : c;
             const float recv = __shfl_xor(send, 1, 64);
             const int r = 2 * t + odd;                                  // the register (row) this lane writes
@@ -339,7 +352,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
             const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + pix * p.rpitch + p.roff + co);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              v[e] = pack_bf2(apply_act(bflo(v[e]) + bflo(rv[e]), p.act), apply_act(bfhi(v[e]) + bfhi(rv[e]), p.act));
+              v[e] = pack_bf2(apply_act<ACT>(bflo(v[e]) + bflo(rv[e])), apply_act<ACT>(bfhi(v[e]) + bfhi(rv[e])));
           }
           *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.out) + pix * p.opitch + p.ooff + co) = v;
           if (p.gn_part) {
@@ -353,6 +366,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    });
     });
     if (p.gn_part) {  // lanes with the same channel chunk are CPR apart: fold them, one lane per chunk writes
 #pragma unroll
@@ -378,6 +392,8 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
   const int ncol = lane & 31, rhalf = lane >> 5;
   // static_for: the accumulator indices must be compile-time constants (a runtime-indexed
   // ext_vector array is demoted to scratch memory)
+  with_act(p.act, [&](auto actc) {
+  constexpr int ACT = decltype(actc)::value;
   static_for<NT>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
     const int co = ct * TN + (wn * NT + j) * 32 + ncol;
@@ -400,7 +416,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
             if (row_ok && co_ok && xb + e < p.OW) {
               float y = v[e];
               if (p.res) y += bf2f(p.res[(pix0 + e) * p.rpitch + p.roff + co]);
-              y = apply_act(y, p.act);
+              y = apply_act<ACT>(y);
               if (p.out_mode == GLARE_OUT_NHWC_BF16)
                 reinterpret_cast<bf16_t*>(p.out)[(pix0 + e) * p.opitch + p.ooff + co] = f2bf(y);
               else
@@ -413,7 +429,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               if (xb + e < p.OW) {
-                const float y = apply_act(v[e], p.act);
+                const float y = apply_act<ACT>(v[e]);
                 if (p.out_mode == GLARE_OUT_PLANAR_F32)
                   reinterpret_cast<float*>(p.out)[base + e] = y;
                 else
@@ -424,6 +440,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
         }
       }
     });
+  });
   });
 }
 

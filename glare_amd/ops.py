@@ -82,6 +82,37 @@ class PackedConv:
             check(lib.glare_conv2d_pack_weight_dgrad(ptr(w), _i(cout), _i(cin), _i(kh), _i(dgrad_pad), ptr(self.packed),
                                                      stream_handle()), "glare_conv2d_pack_weight_dgrad")
         self.bias = None if bias is None else bias.detach().float().contiguous()
+        self.w16 = None
+        if kh == 1 and dgrad_pad is None and lib.glare_conv1x1_ws_supported(_i(cin), _i(cout)):
+            # the weight-stationary 1x1 kernel (csrc/conv1x1.hip) takes the filter as plain bf16 [Cout][Cin]
+            self.w16 = torch.empty(cout, cin, dtype=torch.bfloat16, device=w.device)
+            check(lib.glare_conv1x1_ws_pack_weight(ptr(w), _i(cout), _i(cin), ptr(self.w16), stream_handle()), "glare_conv1x1_ws_pack_weight")
+
+
+CONV1X1_WEIGHT_STATIONARY = True   # False: every 1x1 conv through the implicit-GEMM kernel (conv_igemm.hip, KS = 1)
+
+
+def _conv1x1_ws(x, pc, cin, in_off, act, residual, res_off, out, out_off, gn_stats):
+    B, H, W, pitch = x.shape
+    N = H * W
+    if out is None:
+        out = torch.empty(B, H, W, pc.cout, dtype=torch.bfloat16, device=x.device)
+    lib = _lib.lib()
+    gn_part = None
+    if gn_stats:
+        assert out_off == 0 and out.shape[3] == pc.cout
+        lib.glare_conv1x1_ws_gn_partial_elems.restype = _ll
+        gn_part = torch.empty(lib.glare_conv1x1_ws_gn_partial_elems(_i(B), _ll(N), _i(pc.cout)), dtype=torch.float32, device=x.device)
+    check(lib.glare_conv1x1_ws_bf16(ptr(x), _i(pitch), _i(in_off), ptr(pc.w16), ptr(pc.bias), ptr(residual),
+                                    _i(residual.shape[3] if residual is not None else 0), _i(res_off), ptr(out), _i(out.shape[3]),
+                                    _i(out_off), _i(B), _ll(N), _i(cin), _i(pc.cout), _i(ACT[act]), ptr(gn_part), stream_handle()),
+          "glare_conv1x1_ws_bf16")
+    if gn_stats:
+        stats = torch.empty(B, 1, 32, 2, dtype=torch.float32, device=x.device)
+        check(lib.glare_conv1x1_ws_gn_reduce(ptr(gn_part), ptr(stats), _i(B), _ll(N), _i(pc.cout), stream_handle()),
+              "glare_conv1x1_ws_gn_reduce")
+        out._gn_stats = stats
+    return out
 
 
 def conv2d(x, pc, *, x2=None, cin=None, in_off=0, cin2=None, in2_off=0, stride=1, upsample=False, act="none",
@@ -92,6 +123,13 @@ def conv2d(x, pc, *, x2=None, cin=None, in_off=0, cin2=None, in2_off=0, stride=1
     assert x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous()
     B, H, W, pitch = x.shape
     cin = pitch - in_off if cin is None else cin
+    if (CONV1X1_WEIGHT_STATIONARY and getattr(pc, "w16", None) is not None and x2 is None and stride == 1 and not upsample
+            and out_mode == OUT_NHWC_BF16 and cin == pc.cin and pitch % 8 == 0 and in_off % 8 == 0
+            and (out is None or (out.dtype == torch.bfloat16 and out.shape[3] % 8 == 0 and out_off % 8 == 0))
+            and (residual is None or (residual.shape[3] % 8 == 0 and res_off % 8 == 0)) and (not gn_stats or out is None)):
+        if residual is not None:
+            assert residual.dtype == torch.bfloat16 and residual.is_contiguous()
+        return _conv1x1_ws(x, pc, cin, in_off, act, residual, res_off, out, out_off, gn_stats)
     d = ConvDesc()
     d.in_, d.in2 = x.data_ptr(), (x2.data_ptr() if x2 is not None else None)
     d.B, d.H, d.W = B, H, W

@@ -187,6 +187,23 @@ int glare_flow_tail_f32(float* z_nhwc3, const float* h4, const float* hF, int hF
                         long long n_pixels, const float* M_3x3_host, const float* t_3_host, float eps,
                         glare_stream_t stream);
 
+/* ---- 1x1 convolution, weight-stationary form (csrc/conv1x1.hip) ----------------------------------------------------------
+ * The 1x1 nn.Conv2d's with Cin in {128, 256, 512} and Cout % 128 == 0 (Cout / 128 a divisor of 32): AttnBlock's query / output
+ * projections (encoder_decoder.py:146-165) and ResnetBlock.nin_shortcut (:104-115).  Same arithmetic as glare_conv2d_bf16 with
+ * ksize 1 (bf16 operands, fp32 accumulation, bias, residual add, activation, bf16 NHWC output, optional GroupNorm partial sums
+ * of the rounded output), different schedule: one persistent workgroup per CU keeps its 128-cout slice of the filter in LDS and
+ * streams 32-pixel row blocks through it.  x: bf16 [B][pixels][x_pitch] (channels x_off .. x_off + Cin); w_bf16: [Cout][Cin]
+ * from glare_conv1x1_ws_pack_weight; gn_partial: glare_conv1x1_ws_gn_partial_elems floats (NULL = none), turned into the
+ * [B][1][32][2] statistics block of glare_groupnorm_apply_bf16 by glare_conv1x1_ws_gn_reduce. */
+int glare_conv1x1_ws_supported(int Cin, int Cout);
+int glare_conv1x1_ws_pack_weight(const float* w_oihw, int cout, int cin, void* w_bf16, glare_stream_t stream);
+long long glare_conv1x1_ws_gn_partial_elems(int B, long long pixels_per_image, int Cout);
+int glare_conv1x1_ws_gn_reduce(const float* gn_partial, float* stats_out, int B, long long pixels_per_image, int Cout,
+                               glare_stream_t stream);
+int glare_conv1x1_ws_bf16(const void* x, int x_pitch, int x_off, const void* w_bf16, const float* bias, const void* residual,
+                          int res_pitch, int res_off, void* out, int out_pitch, int out_off, int B, long long pixels_per_image, int Cin,
+                          int Cout, int act, float* gn_partial, glare_stream_t stream);
+
 /* ---- a2: blockwise spatial self-attention, one head, d = 512 ---------------------------------
  * Replaces the bmm / softmax / bmm of AttnBlock.forward (encoder_decoder.py:176-188) without the
  * [B, N, N] score tensor.   out[b, i, :] = sum_j softmax_j(q_i . k_j) v_j

@@ -275,3 +275,66 @@ def test_error_behaviour_of_the_new_entry_points():
     assert lib.glare_conv2d_upsample_packed_weight_elems(ctypes.c_int(0), ctypes.c_int(64)) < 0
     assert lib.glare_add_groupnorm_stats_bf16(None, None, None, ctypes.c_int(1), ctypes.c_longlong(16), ctypes.c_int(64), None,
                                               ctypes.c_size_t(0), None) != 0
+
+
+# ---- 1x1 convolution, weight-stationary kernel (csrc/conv1x1.hip) ----------------------------------------------------------
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 512, 512, 7, 45), (1, 256, 128, 8, 32), (3, 128, 256, 5, 13), (1, 512, 1024, 9, 11),
+                                             (2, 512, 512, 105, 155), (1, 256, 512, 1, 1), (9, 128, 128, 3, 11)])
+def test_conv1x1_weight_stationary_matches_fp32_reference_and_the_igemm_kernel(B, Cin, Cout, H, W):
+    """The persistent weight-stationary 1x1 kernel against F.conv2d (fp32, bf16-rounded operands) and against the implicit-GEMM
+    kernel it replaces (identical products, fp32 accumulation in a different order -> equal up to the output's bf16 rounding);
+    ragged row blocks (H*W not a multiple of 32), more images than pixel ranges, a single pixel."""
+    g = torch.Generator().manual_seed(Cin + Cout + H * W)
+    x = _rand((B, Cin, H, W), g)
+    w = _rand((Cout, Cin, 1, 1), g, 1.0 / Cin ** 0.5)
+    b = _rand((Cout,), g, 0.1)
+    ref = F.conv2d(x.to(torch.bfloat16).float().cuda(), w.to(torch.bfloat16).float().cuda(), b.cuda())
+    pc = ops.PackedConv(w.cuda(), b.cuda())
+    assert pc.w16 is not None
+    xn = _nhwc_bf16(x)
+    out = ops.conv2d(xn, pc)
+    _check(out.permute(0, 3, 1, 2), ref)
+    ops.CONV1X1_WEIGHT_STATIONARY = False
+    try:
+        old = ops.conv2d(xn, pc)
+    finally:
+        ops.CONV1X1_WEIGHT_STATIONARY = True
+    assert torch.allclose(out.float(), old.float(), rtol=2 ** -7, atol=2e-3 * float(ref.abs().max()))
+
+
+def test_conv1x1_weight_stationary_epilogue_residual_act_offsets_and_gn_statistics():
+    """Residual add + activation, channel sub-ranges of wider records on both sides, and the fused GroupNorm statistics: the norm
+    that consumes them must equal the norm that computes its own."""
+    g = torch.Generator().manual_seed(77)
+    B, Cin, Cout, H, W = 2, 256, 256, 9, 21
+    rec = _rand((B, H, W, Cin + 64), g).to(torch.bfloat16).cuda()          # the input lives at channels 64..
+    w = _rand((Cout, Cin, 1, 1), g, 1.0 / Cin ** 0.5)
+    b = _rand((Cout,), g, 0.1)
+    res = _rand((B, H, W, Cout + 8), g).to(torch.bfloat16).cuda()          # residual at channels 8..
+    pc = ops.PackedConv(w.cuda(), b.cuda())
+    out = torch.zeros(B, H, W, Cout + 16, dtype=torch.bfloat16, device="cuda")
+    ops.conv2d(rec, pc, cin=Cin, in_off=64, residual=res, res_off=8, act="relu", out=out, out_off=16)
+    x = rec[..., 64:].float().permute(0, 3, 1, 2)
+    ref = torch.relu(F.conv2d(x, w.to(torch.bfloat16).float().cuda(), b.cuda()).to(torch.bfloat16).float()
+                     + res[..., 8:].float().permute(0, 3, 1, 2))
+    _check(out[..., 16:].permute(0, 3, 1, 2), ref)
+    assert float(out[..., :16].abs().max()) == 0.0                          # nothing outside the channel window
+    # fused statistics
+    xn = rec[..., 64:].contiguous()
+    y = ops.conv2d(xn, pc, gn_stats=True)
+    assert getattr(y, "_gn_stats", None) is not None
+    gamma, beta = (_rand((Cout,), g, 0.3) + 1.0).cuda(), _rand((Cout,), g, 0.2).cuda()
+    n1 = ops.groupnorm(y, gamma, beta, swish=True)
+    n2 = ops.groupnorm(y.clone(), gamma, beta, swish=True)
+    assert torch.allclose(n1.float(), n2.float(), rtol=2 ** -7, atol=2e-3)
+
+
+def test_conv1x1_weight_stationary_is_deterministic_and_falls_back_outside_its_shapes():
+    g = torch.Generator().manual_seed(3)
+    x = _rand((8, 512, 105, 155), g).permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
+    pc = ops.PackedConv((_rand((512, 512, 1, 1), g, 0.05)).cuda(), _rand((512,), g, 0.1).cuda())
+    a = ops.conv2d(x, pc)
+    for _ in range(3):
+        assert torch.equal(ops.conv2d(x, pc), a)
+    assert ops.PackedConv(_rand((1536, 512, 1, 1), g).cuda()).w16 is None        # 12 co-tiles do not divide the 32 slots of an XCD
+    assert ops.PackedConv(_rand((64, 64, 1, 1), g).cuda()).w16 is None           # the flow's 64 -> 64 convs stay on the igemm kernel

@@ -71,6 +71,13 @@ def bench_conv():
         res = torch.randn(B, h, w, co, device=DEV).to(torch.bfloat16)
         ms = timeit(lambda: ops.conv2d(x, pc, out=out, residual=res))
         print("conv  %-22s: %.3f ms  %.0f TFLOP/s  (+residual)" % (name, ms, fl / ms / 1e9))
+        if k == 1 and getattr(pc, "w16", None) is not None:   # the same through the implicit-GEMM kernel, and the HBM roofline
+            ops.CONV1X1_WEIGHT_STATIONARY = False
+            ms_old = timeit(lambda: ops.conv2d(x, pc, out=out))
+            ops.CONV1X1_WEIGHT_STATIONARY = True
+            ms_new = timeit(lambda: ops.conv2d(x, pc, out=out))
+            by = 2.0 * B * h * w * (ci + co)
+            print("conv  %-22s: igemm %.3f ms, weight-stationary %.3f ms = %.0f GB/s algorithmic (x in + out)" % (name, ms_old, ms_new, by / ms_new / 1e6))
 
 
 def bench_gn():
