@@ -61,11 +61,14 @@ def profiled_traffic(batch):
     fetch = write = None
     with open(path) as f:
         block = f.read().split("== attn", 1)[-1].split("==", 1)[0]
+    kernel = ""
     for line in block.splitlines():
         t = line.split()
-        if len(t) >= 2 and t[0] == "FETCH_SIZE":
+        if line[:1] not in (" ", "\t") and t:
+            kernel = t[0]                      # "<kernel name>(<args>)  (<n> dispatches)" heads the counters of that kernel
+        elif kernel.startswith("attn_kv_fwd_kernel") and len(t) >= 2 and t[0] == "FETCH_SIZE":
             fetch = float(t[1])
-        if len(t) >= 2 and t[0] == "WRITE_SIZE":
+        elif kernel.startswith("attn_kv_fwd_kernel") and len(t) >= 2 and t[0] == "WRITE_SIZE":
             write = float(t[1])
     if fetch is None or write is None:
         return None, None

@@ -118,7 +118,7 @@ def test_conv_autograd(cin, cout, k, stride, ups, act, res, bias):
     if bias:
         within(_rel(bd.grad, br.grad), 3.3e-3)   # measured 1.70e-03
     if res:
-        within(_rel(_nchw(rd.grad), rr.grad), 1e-2)
+        within(_rel(_nchw(rd.grad), rr.grad), 1e-6)   # measured 0: the residual's gradient is the incoming one, bit for bit
 
 
 def test_small_conv_autograd():
@@ -139,7 +139,7 @@ def test_small_conv_autograd():
     wd, bd = w.to(_dev()).requires_grad_(True), b.to(_dev()).requires_grad_(True)
     y = A.conv2d_small(x.to(_dev()), wd, bd, layout="nchw")
     y.backward(gy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(_dev()))
-    within(_rel(wd.grad, wr.grad), 6e-3)
+    within(_rel(wd.grad, wr.grad), 3.3e-3)   # measured 1.67e-03
     within(_rel(bd.grad, br.grad), 1e-6)   # measured 5.35e-09 (a plain fp32 sum)
     # sigmoid(conv 3->64) on an NHWC fp32 latent with a data gradient (ConditionEncoder.py:41-43,52-53)
     z = torch.randn(B, 3, H, W, generator=g)
@@ -177,7 +177,7 @@ def test_groupnorm_autograd(C, swish):
     y.backward(_nhwc16(gy))
     within(_rel(_nchw(y), yr.detach()), 3.2e-3)   # measured 1.67e-03
     within(_rel(_nchw(xd.grad), xr.grad), 3.2e-3)   # measured 1.67e-03
-    within(_rel(gd.grad, gr.grad), 6e-3)
+    within(_rel(gd.grad, gr.grad), 1e-6)   # measured 2.73e-07
     within(_rel(bd.grad, br.grad), 1e-6)   # measured 2.35e-07
 
 
