@@ -317,9 +317,7 @@ __global__ __launch_bounds__(GNT) void gn_bwd_reduce_kernel(const bf16_t* __rest
   const long long per = (HW + splits - 1) / splits, q0 = sp * per, q1 = min(HW, q0 + per);
   const bf16_t* xb = x + (size_t)b * HW * pitch + off + chunk * 8;
   const bf16_t* gb = dy + (size_t)b * HW * C + chunk * 8;
-  for (long long p = q0 + pl; p < q1; p += ppi) {
-    const u32x4 xv = *reinterpret_cast<const u32x4*>(xb + (size_t)p * pitch);
-    const u32x4 gv = *reinterpret_cast<const u32x4*>(gb + (size_t)p * C);
+  auto accum = [&](const u32x4& xv, const u32x4& gv) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float xe = (e & 1) ? bfhi(xv[e >> 1]) : bflo(xv[e >> 1]);
@@ -329,7 +327,20 @@ __global__ __launch_bounds__(GNT) void gn_bwd_reduce_kernel(const bf16_t* __rest
       s1[e] += ge;
       s2[e] += ge * xh;
     }
+  };
+  long long p = q0 + pl;
+  for (; p + 3LL * ppi < q1; p += 4LL * ppi) {   // 8 independent 16-B loads in flight per lane; the sums keep the pixel order
+    u32x4 xv[4], gv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      xv[k] = *reinterpret_cast<const u32x4*>(xb + (size_t)(p + (long long)k * ppi) * pitch);
+      gv[k] = *reinterpret_cast<const u32x4*>(gb + (size_t)(p + (long long)k * ppi) * C);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) accum(xv[k], gv[k]);
   }
+  for (; p < q1; p += ppi)
+    accum(*reinterpret_cast<const u32x4*>(xb + (size_t)p * pitch), *reinterpret_cast<const u32x4*>(gb + (size_t)p * C));
 #pragma unroll
   for (int e = 0; e < 8; ++e) { red[threadIdx.x][e] = s1[e]; red[threadIdx.x][8 + e] = s2[e]; }
   __syncthreads();
@@ -343,29 +354,48 @@ __global__ __launch_bounds__(GNT) void gn_bwd_reduce_kernel(const bf16_t* __rest
   }
 }
 
-// per image: sums[b][c][2] (dbeta / dgamma contributions of image b), coef[b][g][2] = (a, q)
+// per (image, block of CB channels): sums[b][c][2] (dbeta / dgamma contributions of image b), coef[b][g][2] = (a, q).
+// Thread (cl, j) adds the splits s = j (mod J) of channel cb*CB + cl in ascending order, the J subtotals are combined in order
+// j = 0..J-1: a fixed summation tree, whatever the launch.  CB is a multiple of the channels per group.
 __global__ __launch_bounds__(GNT) void gn_bwd_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ gamma,
                                                               float* __restrict__ sums, float* __restrict__ coef, long long HW,
-                                                              int C, int splits) {
+                                                              int C, int splits, int CB) {
+  __shared__ float sub[GNT][2];
   __shared__ float g1[2048], g2[2048];
-  const int b = blockIdx.x, cpg = C / GNG;
-  for (int c = threadIdx.x; c < C; c += GNT) {
+  const int b = blockIdx.y, c0 = blockIdx.x * CB, cpg = C / GNG;
+  const int J = CB <= GNT ? GNT / CB : 1;
+  for (int cbase = 0; cbase < CB; cbase += GNT) {   // one turn unless CB > 256
+    const int cl = cbase + (J > 1 ? threadIdx.x % CB : threadIdx.x), j = J > 1 ? threadIdx.x / CB : 0;
     float a = 0.f, q = 0.f;
-    for (int s = 0; s < splits; ++s) {
-      const float* o = partial + (((size_t)b * splits + s) * C + c) * 2;
-      a += o[0]; q += o[1];
+    if (cl < CB && j < J) {
+      for (int sp = j; sp < splits; sp += J) {
+        const float2 o = *reinterpret_cast<const float2*>(partial + (((size_t)b * splits + sp) * C + c0 + cl) * 2);
+        a += o.x; q += o.y;
+      }
     }
-    sums[((size_t)b * 2 + 0) * C + c] = a;   // [b][0][c] = dbeta part, [b][1][c] = dgamma part
-    sums[((size_t)b * 2 + 1) * C + c] = q;
-    g1[c] = a * gamma[c]; g2[c] = q * gamma[c];
+    if (J > 1) {
+      sub[threadIdx.x][0] = a; sub[threadIdx.x][1] = q;
+      __syncthreads();
+      if (j == 0 && cl < CB) {
+        for (int k = 1; k < J; ++k) { a += sub[k * CB + cl][0]; q += sub[k * CB + cl][1]; }
+      }
+    }
+    if (j == 0 && cl < CB) {
+      const int c = c0 + cl;
+      sums[((size_t)b * 2 + 0) * C + c] = a;   // [b][0][c] = dbeta part, [b][1][c] = dgamma part
+      sums[((size_t)b * 2 + 1) * C + c] = q;
+      g1[cl] = a * gamma[c]; g2[cl] = q * gamma[c];
+    }
   }
   __syncthreads();
-  if (threadIdx.x < GNG) {
+  const int gpb = CB / cpg;   // groups of this block
+  if (threadIdx.x < gpb) {
     float a = 0.f, q = 0.f;
     for (int i = 0; i < cpg; ++i) { a += g1[threadIdx.x * cpg + i]; q += g2[threadIdx.x * cpg + i]; }
     const float inv = 1.f / ((float)HW * cpg);
-    coef[((size_t)b * GNG + threadIdx.x) * 2] = a * inv;
-    coef[((size_t)b * GNG + threadIdx.x) * 2 + 1] = q * inv;
+    const int g = c0 / cpg + threadIdx.x;
+    coef[((size_t)b * GNG + g) * 2] = a * inv;
+    coef[((size_t)b * GNG + g) * 2 + 1] = q * inv;
   }
 }
 
@@ -749,8 +779,8 @@ extern "C" int glare_cast_bf16_f32(const void* in, int in_pitch, int in_off, flo
 }
 
 static int gn_bwd_splits(long long HW) {
-  long long s = HW / 256;   // the per-image finalize walks all splits serially: more than 128 costs there what it saves here
-  return (int)(s < 1 ? 1 : (s > 128 ? 128 : s));
+  long long s = HW / 128;   // the per-image finalize walks all splits serially (coalesced over channels)
+  return (int)(s < 1 ? 1 : (s > 512 ? 512 : s));
 }
 
 extern "C" size_t glare_groupnorm_backward_workspace_bytes(int B, long long HW, int C) {
@@ -771,8 +801,9 @@ extern "C" int glare_groupnorm_swish_backward_bf16(const void* x, int in_pitch, 
   float* coef = partial + (size_t)B * splits * C * 2;
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(splits, B), dim3(GNT), 0, ST(stream), static_cast<const bf16_t*>(x), in_pitch, in_off,
                      static_cast<const bf16_t*>(dy), stats, stat_splits, gamma, beta, partial, HW, C, eps, swish, splits);
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(GNT), 0, ST(stream), partial, gamma, dgamma_dbeta_per_image, coef, HW, C,
-                     splits);
+  const int CB = (C % 64 == 0 && 64 % (C / GNG) == 0) ? 64 : C;   // channel block of the finalize: whole groups
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(C / CB, B), dim3(GNT), 0, ST(stream), partial, gamma, dgamma_dbeta_per_image, coef, HW,
+                     C, splits, CB);
   int bpi = (int)((HW * (C / 8) + 16 * GNT - 1) / (16 * GNT));
   if (bpi < 1) bpi = 1;
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)(bpi * B)), dim3(GNT), 0, ST(stream), static_cast<const bf16_t*>(x), in_pitch,

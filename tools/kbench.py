@@ -102,6 +102,20 @@ def bench_dcn():
         print("dcn   C=%d %dx%d: %.3f ms  %.1f TFLOP/s (fp32)" % (c, h, w, ms, fl / ms / 1e9))
 
 
+def bench_wgrad():
+    """Weight gradient of the 3x3 convs at the stage-2 crop (B = 2, 320x320 and its half / quarter resolutions): the whole path
+    (planar transposes + split-K product + reduction) and the product alone."""
+    from glare_amd import train_ops as T
+    for name, cin, cout, H, W in [("128->128 @320", 128, 128, 320, 320), ("256->256 @160", 256, 256, 160, 160),
+                                  ("512->512 @80", 512, 512, 80, 80), ("128->256 @160", 128, 256, 160, 160),
+                                  ("256->512 @80", 256, 512, 80, 80)]:
+        x = torch.randn(2, H, W, cin, device=DEV).to(torch.bfloat16)
+        g = torch.randn(2, H, W, cout, device=DEV).to(torch.bfloat16)
+        ms = timeit(lambda: T.conv3x3_weight_grad_implicit(x, g, cout))
+        fl = 2.0 * 2 * H * W * 9 * cin * cout
+        print("wgrad %-15s: %.3f ms  %.0f TFLOP/s (whole path)" % (name, ms, fl / ms / 1e9))
+
+
 def bench_vq():
     n = B * 105 * 155
     z = torch.randn(n, 3, device=DEV)
@@ -111,6 +125,6 @@ def bench_vq():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["attn", "conv", "gn", "dcn", "vq"]
+    which = sys.argv[1:] or ["attn", "conv", "gn", "dcn", "vq", "wgrad"]
     for w in which:
         globals()["bench_" + w]()
