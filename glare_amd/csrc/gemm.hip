@@ -159,6 +159,28 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restri
   out[i] = accumulate ? out[i] + s : s;
 }
 
+// the same sum for MANY parts of FEW elements (per-workgroup partials of the flow / GroupNorm reductions: S = 256, n = 12..576):
+// one thread per element would walk S dependent loads.  Thread (e, j) adds the parts s = j (mod G) of element e in ascending
+// order, the G subtotals are added in order j = 0..G-1 -- a fixed tree for a given (S, n).
+template <int G>
+__global__ __launch_bounds__(256) void reduce_parts_grouped_kernel(const float* __restrict__ parts, int S, long long n, float scale,
+                                                                    float* __restrict__ out, int accumulate) {
+  constexpr int EL = 256 / G;
+  __shared__ float sub[G][EL];
+  const int e = threadIdx.x % EL, j = threadIdx.x / EL;
+  const long long i = (long long)blockIdx.x * EL + e;
+  float s = 0.f;
+  if (i < n)
+    for (int k = j; k < S; k += G) s += parts[(long long)k * n + i];
+  sub[j][e] = s;
+  __syncthreads();
+  if (j == 0 && i < n) {
+    for (int k = 1; k < G; ++k) s += sub[k][e];
+    s *= scale;
+    out[i] = accumulate ? out[i] + s : s;
+  }
+}
+
 }  // namespace
 
 static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int K, long long lda, long long ldb, long long ldc,
@@ -215,7 +237,11 @@ extern "C" int glare_reduce_parts_f32(const float* parts, int n_parts, long long
   if (n_parts < 0 || n < 0) return GLARE_ERR_INVALID;
   if (n == 0) return GLARE_OK;
   if (!parts || !out) return GLARE_ERR_INVALID;
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdivll(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), parts,
-                     n_parts, n, scale, out, accumulate);
+  if (n_parts >= 32 && n <= 65536)   // many parts of few elements: split the walk over the parts as well
+    hipLaunchKernelGGL(reduce_parts_grouped_kernel<16>, dim3((unsigned)cdivll(n, 16)), dim3(256), 0, static_cast<hipStream_t>(stream), parts,
+                       n_parts, n, scale, out, accumulate);
+  else
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdivll(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), parts,
+                       n_parts, n, scale, out, accumulate);
   return glare_launch_status();
 }

@@ -1,0 +1,286 @@
+// Weight gradient of a 3x3 / stride-1 / pad-1 convolution straight from the NHWC activations (cuDNN wgrad in the reference:
+// `loss.backward()` of LLFlow_model.py:231-236 / VQLLFLOWD_model.py:226-229 over every Conv2d of encoder_decoder.py /
+// deformableDecoder_arch.py):
+//
+//     dW[co][ci][ty][tx] = sum_{b,y,x} g[b][y][x][co] * x[b][y+ty-1][x+tx-1][ci]        db[co] = sum g[b][y][x][co]
+//
+// The contraction runs over PIXELS, the slow axis of both NHWC operands, so both MFMA operands are K-major in memory.  gfx950
+// reads such tiles directly: the [pixel][channel] rows land in LDS by LDS-DMA and `ds_read_b64_tr_b16` hands each lane its
+// 4 pixels x 1 channel column -- no transposed copy of x or g in HBM (the planar transposes this kernel replaces wrote 4x the
+// activation).  One workgroup owns a (64 ci) x (64 co) block of ALL NINE taps, so an x row is fetched once and used by the three
+// tap rows it belongs to, a g row once for nine taps: the nine taps differ only by the LDS address of the A fragment.
+//
+//   grid      : split s = (image, column strip of 16*nks pixels, range of rows) x tile (ci block, co block); the splits of one
+//               tile leave fp32 partials [S][9*Ci + 1][Co] which glare_reduce_parts_f32 sums in a fixed order (deterministic)
+//   LDS       : ring of 4 x rows [16*nks + 2 (+pad) pixels][64 ci] and 2 g rows [16*nks pixels][64 co], 128 B per pixel, the
+//               16-B chunk index XOR-ed with 4*bit1(pixel) (on the DMA source side) so that a transpose read is conflict-free
+//   per row   : vmcnt(0) + one barrier, DMA of the row after next, then nks k-steps x 3 tap rows x 3 MFMA 32x32x16 per wave
+//               (wave = 32 ci x 32 co x 9 taps = 144 accumulators), fragments read one tap row ahead with counted lgkmcnt
+//   borders   : padded / out-of-strip / out-of-range-channel elements carry a DMA offset beyond the buffer descriptor's range,
+//               which the hardware turns into zeros
+#include "common.h"
+
+extern "C" int glare_reduce_parts_f32(const float* parts, int n_parts, long long n, float scale, float* out, int accumulate,
+                                      glare_stream_t stream);
+
+namespace {
+
+constexpr int CB = 64;             // channel block of a workgroup on either side (2 x 2 waves of 32)
+constexpr int PIXB = CB * 2;       // bytes per pixel of a row slot
+constexpr int NX = 4, NG = 2;      // ring slots
+constexpr int MAX_NKS = 6;
+constexpr unsigned OOB = 0x80000000u;
+
+struct WgradParams {
+  const bf16_t* x;
+  const bf16_t* g;
+  float* parts;
+  int B, H, W, xpitch, xoff, Ci, gpitch, Co;
+  int nks, nstrips, ysplits, rps;      // k-steps per strip row, strips per image row, row ranges per strip, rows per range
+  int tiles_ci, tiles_co, n_blocks;
+  int xslot, gslot;                    // bytes of one ring slot
+  int nxi, ngi;                        // DMA instructions per x / g row
+};
+
+template <int N>
+__device__ __forceinline__ void lgkm_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : "memory"); }
+__device__ __forceinline__ void tr_read(u32x2& dst, int addr) { asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst) : "v"(addr)); }
+__device__ __forceinline__ void pin(u32x2& a) { asm volatile("" : "+v"(a)); }   // nothing that reads `a` moves above this point
+
+__device__ __forceinline__ bf16x8 frag(const u32x2& lo, const u32x2& hi) {
+  return __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wci = wave & 1, wco = wave >> 1;
+
+  // consecutive logical ids (the tiles of one split, which read the same rows) on the same XCD
+  int bid = blockIdx.x;
+  {
+    const int n = p.n_blocks, q = n / 8, r = n % 8, xcd = bid % 8, kk = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kk;
+  }
+  const int ntiles = p.tiles_ci * p.tiles_co;
+  const int t = bid % ntiles, s = bid / ntiles;
+  const int tci = t % p.tiles_ci, tco = t / p.tiles_ci;
+  const int ys = s % p.ysplits, strip = (s / p.ysplits) % p.nstrips, b = s / (p.ysplits * p.nstrips);
+  const int ws = 16 * p.nks, x0 = strip * ws;
+  const int y0 = ys * p.rps, y1 = min(p.H, y0 + p.rps);
+  const int ci0 = tci * CB, co0 = tco * CB;
+
+  // ---- DMA geometry: one instruction = 8 pixels x 128 B; lane -> (pixel 8 j + lane / 8, LDS chunk lane % 8), which receives
+  // source chunk (lane % 8) ^ 4 * bit1(pixel)
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(p.x + (size_t)b * p.H * p.W * p.xpitch), 0, (int)((long long)p.H * p.W * p.xpitch * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(p.g + (size_t)b * p.H * p.W * p.gpitch), 0, (int)((long long)p.H * p.W * p.gpitch * 2), 0x00020000);
+  unsigned xvo[4], gvo[3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int px = 8 * (wave + 4 * i) + (lane >> 3), c = (lane & 7) ^ (((px >> 1) & 1) << 2);
+    const int xg = x0 - 1 + px, ch = ci0 + 8 * c;
+    xvo[i] = (xg >= 0 && xg < p.W && px < ws + 2 && ch < p.Ci) ? (unsigned)(xg * p.xpitch + p.xoff + ch) * 2u : OOB;
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int px = 8 * (wave + 4 * i) + (lane >> 3), c = (lane & 7) ^ (((px >> 1) & 1) << 2);
+    const int xg = x0 + px, ch = co0 + 8 * c;
+    gvo[i] = (xg < p.W && px < ws && ch < p.Co) ? (unsigned)(xg * p.gpitch + ch) * 2u : OOB;
+  }
+  const int xrow_bytes = p.W * p.xpitch * 2, grow_bytes = p.W * p.gpitch * 2;
+  auto issue_x = [&](int y) {   // row y of the image (zeros outside it) -> slot (y + 1) & 3
+    const bool rv = y >= 0 && y < p.H;
+    char* dst = smem + ((y + 1) & (NX - 1)) * p.xslot;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = wave + 4 * i;
+      if (j < p.nxi)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, rv ? xvo[i] : OOB,
+                                                 rv ? y * xrow_bytes : 0, 0, 0);
+    }
+  };
+  auto issue_g = [&](int y) {   // row y < H -> slot y & 1
+    char* dst = smem + NX * p.xslot + (y & (NG - 1)) * p.gslot;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int j = wave + 4 * i;
+      if (j < p.ngi)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(gr, (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, gvo[i], y * grow_bytes,
+                                                 0, 0);
+    }
+  };
+
+  // ---- fragment addresses.  Lane i of a 16-lane group supplies the address of 4 consecutive channels of pixel 8 hi + 4 h + (i >> 2)
+  // of the k-step and receives [those 4 pixels][channel 16 g4 + i] of the wave's 32-channel block (h = 0, 1: the two halves of
+  // the lane's 8 k values).  Tap column tx shifts the pixel by tx (slot pixel 0 is image column x0 - 1).
+  const int i16 = lane & 15, g4 = (lane >> 4) & 1, hi = lane >> 5;
+  int abase[3][2], bbase[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int px = 8 * hi + 4 * h + (i16 >> 2);
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx) {
+      const int q = px + tx, chunk = (wci * 4 + 2 * g4 + ((i16 & 3) >> 1)) ^ (((q >> 1) & 1) << 2);
+      abase[tx][h] = q * PIXB + chunk * 16 + (i16 & 1) * 8;
+    }
+    const int chunk = (wco * 4 + 2 * g4 + ((i16 & 3) >> 1)) ^ (((px >> 1) & 1) << 2);
+    bbase[h] = NX * p.xslot + px * PIXB + chunk * 16 + (i16 & 1) * 8;
+  }
+
+  f32x16 acc[9], accb;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    accb[r] = 0.f;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) acc[tp][r] = 0.f;
+  }
+  const bool want_bias = tci == 0 && wci == 0;   // db comes from the ci-block-0 workgroups: one extra MFMA per k-step with A = ones
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
+
+  issue_x(y0 - 1);
+  issue_x(y0);
+  issue_x(y0 + 1);
+  issue_g(y0);
+  for (int y = y0; y < y1; ++y) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // rows y - 1 .. y + 1 and g row y are in LDS; every wave is done with row y - 2 and g row y - 1
+    if (y + 1 < y1) {
+      issue_x(y + 2);
+      issue_g(y + 1);
+    }
+    int xs[3];
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty) xs[ty] = ((y + ty) & (NX - 1)) * p.xslot;   // image row y - 1 + ty
+    const int gs = (y & (NG - 1)) * p.gslot;
+
+    u32x2 af[3][3][2], bn[2];   // A fragments of tap row ty (three tap columns x two halves); the next k-step's B halves
+    bf16x8 bcur;
+    auto load_a = [&](int ks, int ty) {
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) tr_read(af[ty][tx][h], abase[tx][h] + xs[ty] + ks * (16 * PIXB));
+    };
+    auto load_b = [&](int ks) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) tr_read(bn[h], bbase[h] + gs + ks * (16 * PIXB));
+    };
+    auto pin_a = [&](int ty) {
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) pin(af[ty][tx][h]);
+    };
+    auto mma = [&](int ty) {
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx)
+        acc[ty * 3 + tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(af[ty][tx][0], af[ty][tx][1]), bcur, acc[ty * 3 + tx], 0, 0, 0);
+    };
+    load_a(0, 0);
+    load_b(0);
+    for (int ks = 0; ks < p.nks; ++ks) {
+      load_a(ks, 1);                       // 6 reads behind the 8 of (ks, tap row 0) + B
+      lgkm_wait<6>();
+      pin_a(0); pin(bn[0]); pin(bn[1]);
+      bcur = frag(bn[0], bn[1]);
+      mma(0);
+      if (want_bias) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bcur, accb, 0, 0, 0);
+      load_a(ks, 2);
+      lgkm_wait<6>();
+      pin_a(1);
+      mma(1);
+      if (ks + 1 < p.nks) {
+        load_a(ks + 1, 0);
+        load_b(ks + 1);
+        lgkm_wait<8>();
+      } else {
+        lgkm_wait<0>();
+      }
+      pin_a(2);
+      mma(2);
+    }
+  }
+
+  // ---- partial of this split: parts[s][tap * Ci + ci][co], row 9 * Ci = the bias gradient
+  float* out = p.parts + (size_t)s * (9 * p.Ci + 1) * p.Co;
+  const int co = co0 + wco * 32 + (lane & 31);
+  if (co < p.Co) {
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ci0 + wci * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (ci < p.Ci) out[(size_t)(tp * p.Ci + ci) * p.Co + co] = acc[tp][r];
+      }
+    if (want_bias && hi == 0) out[(size_t)9 * p.Ci * p.Co + co] = accb[0];
+  }
+}
+
+struct Plan {
+  int nks, nstrips, ysplits, rps, S;
+};
+
+// strips: the narrowest zero padding of the row, then the fewest strips; row ranges: about 512 workgroups over all tiles, at
+// least 4 rows each (every range re-reads 2 halo rows)
+Plan make_plan(int B, int H, int W, int Ci, int Co) {
+  Plan pl;
+  int best_pad = 1 << 30;
+  pl.nks = 1; pl.nstrips = 1;
+  for (int ns = cdiv(W, 16 * MAX_NKS); ns <= cdiv(W, 16); ++ns) {
+    const int nks = cdiv(cdiv(W, ns), 16);
+    if (nks > MAX_NKS) continue;
+    const int pad = ns * nks * 16 - W;
+    if (pad < best_pad) { best_pad = pad; pl.nks = nks; pl.nstrips = ns; }
+  }
+  const int tiles = cdiv(Ci, CB) * cdiv(Co, CB);
+  int ysplits = cdiv(512, tiles * B * pl.nstrips);
+  ysplits = ysplits < 1 ? 1 : ysplits;
+  if (ysplits > cdiv(H, 4)) ysplits = cdiv(H, 4);
+  pl.rps = cdiv(H, ysplits);
+  pl.ysplits = cdiv(H, pl.rps);
+  pl.S = B * pl.nstrips * pl.ysplits;
+  return pl;
+}
+
+}  // namespace
+
+extern "C" size_t glare_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Co) {
+  if (B <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0) return 0;
+  const Plan pl = make_plan(B, H, W, Ci, Co);
+  return pl.S > 1 ? (size_t)pl.S * (9 * (size_t)Ci + 1) * Co * sizeof(float) : 0;
+}
+
+// dWt[(ty*3 + tx) * Ci + ci][co] and dWt[9 * Ci][co] (= db), fp32 [9 * Ci + 1][Co].  x: bf16 NHWC [B][H][W][xpitch], Ci channels
+// at xoff; g: bf16 NHWC [B][H][W][gpitch], Co channels at 0.  Ci, Co, xoff and both pitches multiples of 8.
+extern "C" int glare_conv3x3_wgrad_bf16(const void* x, int xpitch, int xoff, const void* g, int gpitch, float* dWt, int B, int H, int W,
+                                        int Ci, int Co, void* workspace, size_t workspace_bytes, glare_stream_t stream) {
+  if (!x || !g || !dWt || B <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0) return GLARE_ERR_INVALID;
+  if (Ci % 8 || Co % 8 || xoff % 8 || xpitch % 8 || gpitch % 8 || xoff + Ci > xpitch || Co > gpitch) return GLARE_ERR_INVALID;
+  if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g)) & 15) != 0) return GLARE_ERR_INVALID;
+  if ((long long)H * W * xpitch * 2 >= (1ll << 31) || (long long)H * W * gpitch * 2 >= (1ll << 31)) return GLARE_ERR_UNSUPPORTED;
+  const Plan pl = make_plan(B, H, W, Ci, Co);
+  const size_t need = glare_conv3x3_wgrad_workspace_bytes(B, H, W, Ci, Co);
+  if (need && (!workspace || workspace_bytes < need)) return GLARE_ERR_WORKSPACE;
+  WgradParams p;
+  p.x = static_cast<const bf16_t*>(x);
+  p.g = static_cast<const bf16_t*>(g);
+  p.parts = pl.S > 1 ? static_cast<float*>(workspace) : dWt;
+  p.B = B; p.H = H; p.W = W; p.xpitch = xpitch; p.xoff = xoff; p.Ci = Ci; p.gpitch = gpitch; p.Co = Co;
+  p.nks = pl.nks; p.nstrips = pl.nstrips; p.ysplits = pl.ysplits; p.rps = pl.rps;
+  p.tiles_ci = cdiv(Ci, CB); p.tiles_co = cdiv(Co, CB);
+  const long long nb = (long long)pl.S * p.tiles_ci * p.tiles_co;
+  if (nb > 0x7fffffffLL) return GLARE_ERR_UNSUPPORTED;
+  p.n_blocks = (int)nb;
+  p.nxi = cdiv(16 * pl.nks + 2, 8); p.ngi = 2 * pl.nks;
+  p.xslot = p.nxi * 1024; p.gslot = p.ngi * 1024;
+  const size_t lds = (size_t)NX * p.xslot + (size_t)NG * p.gslot;
+  static const hipError_t attr =
+      hipFuncSetAttribute((const void*)wgrad3x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NX * 13 * 1024 + NG * 12 * 1024);
+  if (attr != hipSuccess) return GLARE_ERR_LAUNCH;
+  hipLaunchKernelGGL(wgrad3x3_kernel, dim3((unsigned)nb), dim3(256), lds, static_cast<hipStream_t>(stream), p);
+  if (pl.S > 1) return glare_reduce_parts_f32(p.parts, pl.S, (long long)(9 * Ci + 1) * Co, 1.0f, dWt, 0, stream);
+  return glare_launch_status();
+}

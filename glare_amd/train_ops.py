@@ -231,6 +231,10 @@ def adam_step_(w, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1
 
 
 # ---- composite backward passes ------------------------------------------------------------------------
+# split-K of the GEMM-form weight gradients (1x1, strided and upsampling convs): about two workgroups per CU, each at least
+# 2048 pixels deep -- more slices cost more in fp32 partials than they gain in occupancy (measured, tools/kbench.py wgrad)
+WGRAD_TARGET_WGS = 512
+WGRAD_MIN_K = 2048
 def conv_weight_grad(x_col_builder, g_bf16, cout, n_rows, out=None):
     """dW|db = gO^T . colT^T by split-K NT GEMM.  x_col_builder(ldp, ones_row) -> colT [n_rows+1, ldp];
     g_bf16: bf16 [B,OH,OW,pitch>=cout] or a 2-D (row-strided) view [P, >=cout].  Returns fp32 [cout, n_rows+1]
@@ -241,7 +245,7 @@ def conv_weight_grad(x_col_builder, g_bf16, cout, n_rows, out=None):
     # the GEMM tile is 256 (m) x 128 (n): put the filter's Cout on the 128 side when it would waste half a 256-row tile
     swap = out is None and cout <= 128 and n_rows + 1 > 128
     tiles = ((n_rows + 256) // 256) * ((cout + 127) // 128) if swap else ((cout + 255) // 256) * ((n_rows + 1 + 127) // 128)
-    S = max(1, min((512 + tiles - 1) // tiles, P // 2048, 64))
+    S = max(1, min((WGRAD_TARGET_WGS + tiles - 1) // tiles, P // WGRAD_MIN_K, 64))
     ldp = _rup(P, 64 * S)
     colT = x_col_builder(ldp, n_rows)
     gT = transpose(g_bf16, ld_out=ldp)[:cout]
@@ -513,6 +517,24 @@ def colsum(g2d, C):
     return out
 
 
+def conv3x3_weight_grad(x, g16, cout, cin=None, in_off=0):
+    """Weight + bias gradient of a 3x3 / stride-1 / pad-1 conv straight from the NHWC operands (csrc/wgrad.hip).  x: bf16 NHWC
+    [B,H,W,pitch] (cin channels at in_off, cin % 8 == 0); g16: bf16 NHWC [B,H,W,>=cout], cout % 8 == 0.  Returns (dW fp32
+    [cout,cin,3,3] (a permuted view), db fp32 [cout])."""
+    require_cuda(x, g16)
+    B, H, W, pitch = x.shape
+    cin = pitch - in_off if cin is None else cin
+    assert g16.shape[:3] == x.shape[:3] and x.is_contiguous() and g16.is_contiguous()
+    lib = _lib.lib()
+    lib.glare_conv3x3_wgrad_workspace_bytes.restype = ctypes.c_size_t
+    nws = lib.glare_conv3x3_wgrad_workspace_bytes(_i(B), _i(H), _i(W), _i(cin), _i(cout))
+    ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=x.device)
+    dwt = torch.empty(9 * cin + 1, cout, dtype=torch.float32, device=x.device)
+    check(lib.glare_conv3x3_wgrad_bf16(ptr(x), _i(pitch), _i(in_off), ptr(g16), _i(g16.shape[-1]), ptr(dwt), _i(B), _i(H), _i(W), _i(cin),
+                                       _i(cout), ptr(ws), _sz(nws), stream_handle()), "glare_conv3x3_wgrad_bf16")
+    return dwt[:9 * cin].view(3, 3, cin, cout).permute(3, 2, 0, 1), dwt[9 * cin]
+
+
 def conv3x3_weight_grad_implicit(x, g16, cout, cin=None, in_off=0):
     """Weight + bias gradient of a 3x3 / stride-1 / pad-1 conv without an im2col matrix.  x: bf16 NHWC [B,H,W,pitch] (cin
     channels at in_off, cin % 16 == 0); g16: bf16 NHWC [B,H,W,>=cout].  Returns (dW fp32 [cout,cin,3,3] (a permuted view),
@@ -525,7 +547,7 @@ def conv3x3_weight_grad_implicit(x, g16, cout, cin=None, in_off=0):
     lib.glare_pad_planar_ld.restype = _ll
     Pp = B * (H + 2) * _rup(W + 2, 8)
     tiles = ((9 * cin + 256) // 256) * ((cout + 127) // 128)
-    S = max(1, min((512 + tiles - 1) // tiles, Pp // 2048, 64))
+    S = max(1, min((WGRAD_TARGET_WGS + tiles - 1) // tiles, Pp // WGRAD_MIN_K, 64))
     ld = int(lib.glare_pad_planar_ld(_i(B), _i(H), _i(W), _i(32 * S)))
     kpb = _rup(Pp, 32 * S) // S
     cop = g16.shape[-1]

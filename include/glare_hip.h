@@ -357,6 +357,14 @@ int glare_pad_planar_t_bf16(const void* x_nhwc, int B, int H, int W, int pitch, 
                             long long ld, int ones_row, glare_stream_t stream);
 int glare_conv3x3_wgrad_implicit_bf16(const void* xT3, const void* gT, float* dWt, int Ci, int Co, int W, long long ld,
                                       int k_per_batch, int batch, glare_stream_t stream);
+/* Weight + bias gradient of a 3x3, stride-1, pad-1 convolution straight from the NHWC operands (csrc/wgrad.hip; cuDNN wgrad in the
+ * reference's loss.backward(), LLFlow_model.py:231-236): dWt[(ty*3+tx)*Ci + ci][co] = sum_{b,y,x} g[b,y,x,co] x[b,y+ty-1,x+tx-1,ci],
+ * row 9*Ci = the bias gradient; fp32 [9*Ci + 1][Co].  x: bf16 NHWC [B][H][W][xpitch] with the Ci channels at xoff, g: bf16 NHWC
+ * [B][H][W][gpitch] with the Co channels at 0; Ci, Co, xoff and the pitches multiples of 8, one image below 2 GB.  Split over
+ * pixel ranges with fp32 partials in `workspace` (glare_conv3x3_wgrad_workspace_bytes), summed in a fixed order. */
+size_t glare_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Co);
+int glare_conv3x3_wgrad_bf16(const void* x, int xpitch, int xoff, const void* g, int gpitch, float* dWt, int B, int H, int W, int Ci,
+                             int Co, void* workspace, size_t workspace_bytes, glare_stream_t stream);
 /* out[c] = sum_p g[p][c] (bias gradient); g bf16 [P][pitch]; workspace >= 256 * C floats */
 int glare_colsum_bf16(const void* g, int pitch, long long P, int C, float* out, void* workspace, size_t workspace_bytes,
                       glare_stream_t stream);
