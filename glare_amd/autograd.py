@@ -73,6 +73,10 @@ class Conv2dFn(torch.autograd.Function):
             else:
                 dw, db = T.conv3x3_weight_grad(x, g16, cout)      # no im2col matrix, no transposed copies
             db = db if has_bias else None
+        elif (ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2])) and k == 1 and stride == 1 and not upsample \
+                and not has_x2 and cin_tot % 8 == 0 and cout % 8 == 0 and IMPLICIT_WGRAD:
+            dw, db = T.conv1x1_weight_grad(x, g16, cout)
+            db = db if has_bias else None
         elif ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             kk = k * k
             c1 = x.shape[-1]

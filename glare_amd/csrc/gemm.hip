@@ -153,6 +153,8 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restri
                                                             float* __restrict__ out, int accumulate) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  parts += (long long)blockIdx.y * S * n;   // blockIdx.y = group: out[grp][i] = sum_s parts[grp][s][i]
+  out += (long long)blockIdx.y * n;
   float s = 0.f;
   for (int k = 0; k < S; ++k) s += parts[(long long)k * n + i];
   s *= scale;
@@ -163,12 +165,14 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restri
 // one thread per element would walk S dependent loads.  Thread (e, j) adds the parts s = j (mod G) of element e in ascending
 // order, the G subtotals are added in order j = 0..G-1 -- a fixed tree for a given (S, n).
 template <int G>
-__global__ __launch_bounds__(256) void reduce_parts_grouped_kernel(const float* __restrict__ parts, int S, long long n, float scale,
+__global__ __launch_bounds__(256) void reduce_many_parts_kernel(const float* __restrict__ parts, int S, long long n, float scale,
                                                                     float* __restrict__ out, int accumulate) {
   constexpr int EL = 256 / G;
   __shared__ float sub[G][EL];
   const int e = threadIdx.x % EL, j = threadIdx.x / EL;
   const long long i = (long long)blockIdx.x * EL + e;
+  parts += (long long)blockIdx.y * S * n;
+  out += (long long)blockIdx.y * n;
   float s = 0.f;
   if (i < n)
     for (int k = j; k < S; k += G) s += parts[(long long)k * n + i];
@@ -232,16 +236,21 @@ static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int 
   return glare_launch_status();
 }
 
-extern "C" int glare_reduce_parts_f32(const float* parts, int n_parts, long long n, float scale, float* out, int accumulate,
-                                      glare_stream_t stream) {
-  if (n_parts < 0 || n < 0) return GLARE_ERR_INVALID;
-  if (n == 0) return GLARE_OK;
+extern "C" int glare_reduce_parts_grouped_f32(const float* parts, int n_groups, int n_parts, long long n, float scale, float* out,
+                                              int accumulate, glare_stream_t stream) {
+  if (n_groups < 0 || n_parts < 0 || n < 0 || n_groups > 65535) return GLARE_ERR_INVALID;
+  if (n == 0 || n_groups == 0) return GLARE_OK;
   if (!parts || !out) return GLARE_ERR_INVALID;
   if (n_parts >= 32 && n <= 65536)   // many parts of few elements: split the walk over the parts as well
-    hipLaunchKernelGGL(reduce_parts_grouped_kernel<16>, dim3((unsigned)cdivll(n, 16)), dim3(256), 0, static_cast<hipStream_t>(stream), parts,
-                       n_parts, n, scale, out, accumulate);
+    hipLaunchKernelGGL(reduce_many_parts_kernel<16>, dim3((unsigned)cdivll(n, 16), n_groups), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       parts, n_parts, n, scale, out, accumulate);
   else
-    hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdivll(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), parts,
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdivll(n, 256), n_groups), dim3(256), 0, static_cast<hipStream_t>(stream), parts,
                        n_parts, n, scale, out, accumulate);
   return glare_launch_status();
+}
+
+extern "C" int glare_reduce_parts_f32(const float* parts, int n_parts, long long n, float scale, float* out, int accumulate,
+                                      glare_stream_t stream) {
+  return glare_reduce_parts_grouped_f32(parts, 1, n_parts, n, scale, out, accumulate, stream);
 }

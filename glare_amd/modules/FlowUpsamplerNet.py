@@ -358,9 +358,6 @@ class FlowNLLFn(torch.autograd.Function):
         ghF = torch.empty(B, H, W, n * 8, dtype=torch.bfloat16, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)
         dMt, dwz = torch.empty(n, 12, **f32), torch.empty(n, 64, 9, **f32)
-        # weight | bias gradients of the per-step convs land in these (GEMM output layout: last column = bias)
-        dc2, dc4 = torch.empty(n, 64, 65, **f32), torch.empty(n, 4, 577, **f32)
-        df2, df4 = torch.empty(n, 64, 65, **f32), torch.empty(n, 6, 577, **f32)
         P = B * H * W
         gh4s = torch.empty(n, B, H, W, 8, dtype=torch.bfloat16, device=dev)     # kept: their filter gradients are batched below
         gh2s = torch.empty(n, B, H, W, 64, dtype=torch.bfloat16, device=dev)
@@ -372,40 +369,29 @@ class FlowNLLFn(torch.autograd.Function):
             T.act_backward_(gftA, h1s[k], "relu", C=64, g_off=64 * k)
             T.flow_h1_backward_(gz, gftA, 64 * k, z_pre[k], wz[k], out=dwz[k])
             T.flow_pre_backward_(gz, z_in[k], hF, 8 * k, gld, None, None, eps, ghF, 8 * k, out=dMt[k], Mt_dev=Mt[k])
-        # filter gradients of the 2 x n coupling convs: ONE transposed-operand pair + ONE batched GEMM per conv type, the
-        # batch index being the step (its pixels are a contiguous K slice of the step-major buffers)
-        if P % 64 == 0:
-            for g_all, x_all, ks, cout, dst in ((gh4s, h2s, 3, 4, dc4), (gh2s, h1s, 1, 64, dc2)):
-                rows = 64 * ks * ks
-                gT = T.transpose(g_all.view(n * P, g_all.shape[-1]), ld_out=n * P)
-                colT = T.im2col_t(x_all.view(n * B, H, W, 64), ks, ldp=n * P, ones_row=rows)
-                T.gemm_nt(gT.as_strided((n, cout, P), (P, n * P, 1)), colT.as_strided((n, rows + 1, P), (P, n * P, 1)), out=dst)
-        else:
-            for k in range(n):
-                T.conv_weight_grad(lambda ldp, ones: T.im2col_t(h2s[k], 3, ldp=ldp, ones_row=ones), gh4s[k], 4, 576, out=dc4[k])
-                T.conv_weight_grad(lambda ldp, ones: T.im2col_t(h1s[k], 1, ldp=ldp, ones_row=ones), gh2s[k], 64, 64, out=dc2[k])
+        # filter gradients of the 2 x n coupling convs: one launch per conv type, the steps being the groups of the NHWC
+        # weight-gradient kernel (step-major tensors: the group stride is a whole step)
+        o4 = T.conv_weight_grad_nhwc(3, h2s, gh4s, 8, 64, groups=n, x_gstride=P * 64, g_gstride=P * 8, shape=(B, H, W))   # [n,577,8]
+        o2 = T.conv_weight_grad_nhwc(1, h1s, gh2s, 64, 64, groups=n, x_gstride=P * 64, g_gstride=P * 64, shape=(B, H, W))  # [n,65,64]
         gh2f, gh1f = torch.empty_like(h1f), torch.empty_like(h1f)
         for s in range(n):                                             # the z-independent feature nets: data gradients
             ops.conv2d(ghF, _wt(f4_w[s], 8), cin=8, in_off=8 * s, out=gh2f, out_off=64 * s)
             T.act_backward_(gh2f, h2f, "relu", C=64, g_off=64 * s, y_off=64 * s)
             ops.conv2d(gh2f, _wt(f2_w[s]), cin=64, in_off=64 * s, out=gh1f, out_off=64 * s)
             T.act_backward_(gh1f, h1f, "relu", C=64, g_off=64 * s, y_off=64 * s)
-        # ... and their filter gradients, batched over the steps: step s owns a row block of both transposed operands
-        Pp = (P + 63) // 64 * 64
-        for g_all, gc, x_all, ks, cout, dst in ((ghF, 8, h2f, 3, 6, df4), (gh2f, 64, h1f, 1, 64, df2)):
-            rows = 64 * ks * ks
-            gT = T.transpose(g_all.view(P, n * gc), ld_out=Pp)                          # [n*gc, Pp]
-            colT = T.im2col_t(x_all, ks, ldp=Pp, ones_row=n * rows)                      # [n*rows + 1, Pp], row = c*k*k + tap
-            a3 = gT.as_strided((n, cout, Pp), (gc * Pp, Pp, 1))
-            T.gemm_nt(a3, colT.as_strided((n, rows, Pp), (rows * Pp, Pp, 1)), out=dst[:, :, :rows])
-            T.gemm_nt(a3, colT[n * rows:].as_strided((n, 1, Pp), (0, Pp, 1)), out=dst[:, :, rows:])   # bias: the row of ones
-        col = lambda ldp, ones: T.im2col_t(ft, 3, ldp=ldp, ones_row=ones)
-        dwb = T.conv_weight_grad(col, gh1f, n * 64, 576)
-        df0w, df0b = dwb[:, :-1].unflatten(1, (64, 3, 3)), dwb[:, -1]
-        dwb = T.conv_weight_grad(col, gftA, n * 64, 576)
-        dftAw, dftAb = dwb[:, :-1].unflatten(1, (64, 3, 3)), dwb[:, -1]
-        dc2w, dc2b, dc4w, dc4b = dc2[:, :, :-1].unflatten(2, (64, 1, 1)), dc2[:, :, -1], dc4[:, :, :-1].unflatten(2, (64, 3, 3)), dc4[:, :, -1]
-        df2w, df2b, df4w, df4b = df2[:, :, :-1].unflatten(2, (64, 1, 1)), df2[:, :, -1], df4[:, :, :-1].unflatten(2, (64, 3, 3)), df4[:, :, -1]
+        # ... and their filter gradients: step s owns a channel block of both tensors (group stride = the block)
+        of4 = T.conv_weight_grad_nhwc(3, h2f, ghF, 8, 64, groups=n, x_gstride=64, g_gstride=8)      # [n,577,8], 6 of 8 used
+        of2 = T.conv_weight_grad_nhwc(1, h1f, gh2f, 64, 64, groups=n, x_gstride=64, g_gstride=64)   # [n,65,64]
+        df0w, df0b = T.conv3x3_weight_grad(ft, gh1f, n * 64)
+        dftAw, dftAb = T.conv3x3_weight_grad(ft, gftA, n * 64)
+
+        def w3(o, co):   # [n, 9*64 + 1, 8] -> ([n, co, 64, 3, 3], [n, co])
+            return o[:, :576, :co].unflatten(1, (3, 3, 64)).permute(0, 4, 3, 1, 2), o[:, 576, :co]
+
+        def w1(o):       # [n, 64 + 1, 64] -> ([n, 64, 64, 1, 1], [n, 64])
+            return o[:, :64].transpose(1, 2).unsqueeze(-1).unsqueeze(-1), o[:, 64]
+
+        (dc4w, dc4b), (dc2w, dc2b), (df4w, df4b), (df2w, df2b) = w3(o4, 4), w1(o2), w3(of4, 6), w1(of2)
         gft = ops.conv2d(gh1f, _wt(f0_w))
         gft = ops.conv2d(gftA, _wt(ftA_w), residual=gft)
         return (gft, gmean, None, None, dMt, dwz, dftAw, dftAb, df0w, df0b, dc2w, dc2b, dc4w, dc4b, df2w, df2b, df4w, df4b)

@@ -517,22 +517,42 @@ def colsum(g2d, C):
     return out
 
 
-def conv3x3_weight_grad(x, g16, cout, cin=None, in_off=0):
-    """Weight + bias gradient of a 3x3 / stride-1 / pad-1 conv straight from the NHWC operands (csrc/wgrad.hip).  x: bf16 NHWC
-    [B,H,W,pitch] (cin channels at in_off, cin % 8 == 0); g16: bf16 NHWC [B,H,W,>=cout], cout % 8 == 0.  Returns (dW fp32
-    [cout,cin,3,3] (a permuted view), db fp32 [cout])."""
-    require_cuda(x, g16)
-    B, H, W, pitch = x.shape
+def conv_weight_grad_nhwc(ksize, x, g16, cout, cin=None, in_off=0, groups=1, x_gstride=0, g_gstride=0, shape=None, out=None):
+    """Weight + bias gradients of `groups` independent ksize x ksize (3 with pad 1, or 1) stride-1 convs straight from the NHWC
+    operands (csrc/wgrad.hip).  x: bf16 NHWC [B,H,W,pitch] (cin channels at in_off, cin % 8 == 0); g16: bf16 NHWC
+    [B,H,W,>=cout], cout % 8 == 0; group k reads x / g16 advanced by k * x_gstride / k * g_gstride elements (`shape` = (B,H,W) of
+    one group when the tensors hold several).  Returns fp32 [groups, ksize^2*cin + 1, cout]: row (ty*ksize+tx)*cin + ci, last
+    row = the bias gradient."""
+    require_cuda(x, g16, out)
+    assert x.dtype == torch.bfloat16 and g16.dtype == torch.bfloat16 and x.is_contiguous() and g16.is_contiguous()
+    B, H, W = x.shape[:3] if shape is None else shape
+    pitch, gpitch = x.shape[-1], g16.shape[-1]
     cin = pitch - in_off if cin is None else cin
-    assert g16.shape[:3] == x.shape[:3] and x.is_contiguous() and g16.is_contiguous()
     lib = _lib.lib()
-    lib.glare_conv3x3_wgrad_workspace_bytes.restype = ctypes.c_size_t
-    nws = lib.glare_conv3x3_wgrad_workspace_bytes(_i(B), _i(H), _i(W), _i(cin), _i(cout))
+    lib.glare_conv_wgrad_workspace_bytes.restype = ctypes.c_size_t
+    nws = lib.glare_conv_wgrad_workspace_bytes(_i(ksize), _i(groups), _i(B), _i(H), _i(W), _i(cin), _i(cout))
     ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=x.device)
-    dwt = torch.empty(9 * cin + 1, cout, dtype=torch.float32, device=x.device)
-    check(lib.glare_conv3x3_wgrad_bf16(ptr(x), _i(pitch), _i(in_off), ptr(g16), _i(g16.shape[-1]), ptr(dwt), _i(B), _i(H), _i(W), _i(cin),
-                                       _i(cout), ptr(ws), _sz(nws), stream_handle()), "glare_conv3x3_wgrad_bf16")
+    if out is None:
+        out = torch.empty(groups, ksize * ksize * cin + 1, cout, dtype=torch.float32, device=x.device)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == groups * (ksize * ksize * cin + 1) * cout
+    check(lib.glare_conv_wgrad_bf16(_i(ksize), ptr(x), _i(pitch), _i(in_off), _ll(x_gstride), ptr(g16), _i(gpitch), _ll(g_gstride), ptr(out),
+                                    _i(groups), _i(B), _i(H), _i(W), _i(cin), _i(cout), ptr(ws), _sz(nws), stream_handle()),
+          "glare_conv_wgrad_bf16")
+    return out
+
+
+def conv3x3_weight_grad(x, g16, cout, cin=None, in_off=0):
+    """-> (dW fp32 [cout,cin,3,3] (a permuted view), db fp32 [cout]) of one 3x3 / stride-1 / pad-1 conv."""
+    cin = x.shape[-1] - in_off if cin is None else cin
+    dwt = conv_weight_grad_nhwc(3, x, g16, cout, cin, in_off)[0]
     return dwt[:9 * cin].view(3, 3, cin, cout).permute(3, 2, 0, 1), dwt[9 * cin]
+
+
+def conv1x1_weight_grad(x, g16, cout, cin=None, in_off=0):
+    """-> (dW fp32 [cout,cin,1,1] (a transposed view), db fp32 [cout]) of one 1x1 conv."""
+    cin = x.shape[-1] - in_off if cin is None else cin
+    dwt = conv_weight_grad_nhwc(1, x, g16, cout, cin, in_off)[0]
+    return dwt[:cin].t().unsqueeze(-1).unsqueeze(-1), dwt[cin]
 
 
 def conv3x3_weight_grad_implicit(x, g16, cout, cin=None, in_off=0):

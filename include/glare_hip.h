@@ -329,6 +329,9 @@ int glare_gemm_nt_bf16(const void* A, const void* B, void* C, int M, int N, int 
 /* out[i] = scale * sum_s parts[s][i] (+ out[i]) -- deterministic second level of split reductions */
 int glare_reduce_parts_f32(const float* parts, int n_parts, long long n, float scale, float* out, int accumulate,
                            glare_stream_t stream);
+/* the same for n_groups independent sums: out[grp][i] = scale * sum_s parts[grp][s][i] */
+int glare_reduce_parts_grouped_f32(const float* parts, int n_groups, int n_parts, long long n, float scale, float* out, int accumulate,
+                                   glare_stream_t stream);
 
 /* K-contiguous operand builders for glare_gemm_nt_bf16.
  * glare_im2col_t_bf16: colT[row_base + c*k*k + tap][p] = x[b, oy*stride+ty-pad, ox*stride+tx-pad, c] (0 outside), p the
@@ -357,14 +360,17 @@ int glare_pad_planar_t_bf16(const void* x_nhwc, int B, int H, int W, int pitch, 
                             long long ld, int ones_row, glare_stream_t stream);
 int glare_conv3x3_wgrad_implicit_bf16(const void* xT3, const void* gT, float* dWt, int Ci, int Co, int W, long long ld,
                                       int k_per_batch, int batch, glare_stream_t stream);
-/* Weight + bias gradient of a 3x3, stride-1, pad-1 convolution straight from the NHWC operands (csrc/wgrad.hip; cuDNN wgrad in the
- * reference's loss.backward(), LLFlow_model.py:231-236): dWt[(ty*3+tx)*Ci + ci][co] = sum_{b,y,x} g[b,y,x,co] x[b,y+ty-1,x+tx-1,ci],
- * row 9*Ci = the bias gradient; fp32 [9*Ci + 1][Co].  x: bf16 NHWC [B][H][W][xpitch] with the Ci channels at xoff, g: bf16 NHWC
- * [B][H][W][gpitch] with the Co channels at 0; Ci, Co, xoff and the pitches multiples of 8, one image below 2 GB.  Split over
- * pixel ranges with fp32 partials in `workspace` (glare_conv3x3_wgrad_workspace_bytes), summed in a fixed order. */
-size_t glare_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Co);
-int glare_conv3x3_wgrad_bf16(const void* x, int xpitch, int xoff, const void* g, int gpitch, float* dWt, int B, int H, int W, int Ci,
-                             int Co, void* workspace, size_t workspace_bytes, glare_stream_t stream);
+/* Weight + bias gradients of `groups` independent ksize x ksize (3: pad 1; or 1), stride-1 convolutions of one shape, straight from
+ * the NHWC operands (csrc/wgrad.hip; cuDNN wgrad in the reference's loss.backward(), LLFlow_model.py:231-236):
+ * dWt[grp][(ty*ksize+tx)*Ci + ci][co] = sum_{b,y,x} g[b,y,x,co] x[b,y+ty-pad,x+tx-pad,ci], row ksize^2*Ci = the bias gradient; fp32
+ * [groups][ksize^2*Ci + 1][Co].  Group grp reads x + grp*x_gstride (bf16 NHWC [B][H][W][xpitch], the Ci channels at xoff) and
+ * g + grp*g_gstride (bf16 NHWC [B][H][W][gpitch], the Co channels at 0), strides in elements: B*H*W*pitch walks step-major tensors,
+ * the channel count walks channel blocks of one tensor.  Ci, Co, xoff, pitches and strides multiples of 8, one image below 2 GB.
+ * Split over pixel ranges with fp32 partials in `workspace` (glare_conv_wgrad_workspace_bytes), summed in a fixed order. */
+size_t glare_conv_wgrad_workspace_bytes(int ksize, int groups, int B, int H, int W, int Ci, int Co);
+int glare_conv_wgrad_bf16(int ksize, const void* x, int xpitch, int xoff, long long x_gstride, const void* g, int gpitch,
+                          long long g_gstride, float* dWt, int groups, int B, int H, int W, int Ci, int Co, void* workspace,
+                          size_t workspace_bytes, glare_stream_t stream);
 /* out[c] = sum_p g[p][c] (bias gradient); g bf16 [P][pitch]; workspace >= 256 * C floats */
 int glare_colsum_bf16(const void* g, int pitch, long long P, int C, float* out, void* workspace, size_t workspace_bytes,
                       glare_stream_t stream);

@@ -666,6 +666,36 @@ def test_conv3x3_weight_gradient_from_nhwc_operands(B, H, W, cin, cout, pitch, o
     within(_rel(db, gr.sum(dim=(0, 2, 3))), 2e-6, tag="db")
     again = T.conv3x3_weight_grad(xw.to(_dev()), gy.to(_dev()), cout, cin=cin, in_off=off)
     assert torch.equal(again[0], dw) and torch.equal(again[1], db)     # fixed summation order: bit-reproducible
+    # the 1x1 filter on the same operands (no halo, one tap)
+    dw1, db1 = T.conv1x1_weight_grad(xw.to(_dev()), gy.to(_dev()), cout, cin=cin, in_off=off)
+    within(_rel(dw1, torch.nn.grad.conv2d_weight(xr, (cout, cin, 1, 1), gr)), 2e-6, tag="dw1")
+    within(_rel(db1, gr.sum(dim=(0, 2, 3))), 2e-6, tag="db1")
+
+
+@pytest.mark.parametrize("ks", [1, 3])
+def test_conv_weight_gradient_groups(ks):
+    """Independent filters in one launch: groups that walk a leading (step) axis and groups that walk channel blocks of one tensor
+    (the two layouts of the flow's per-step convs, FlowUpsamplerNet.py:117-160 of the reference run 2 x n such convs)."""
+    from glare_amd import train_ops as T
+
+    g = torch.Generator().manual_seed(70 + ks)
+    n, B, H, W, cin, cout = 3, 2, 10, 24, 64, 8
+    x = torch.randn(n, B, H, W, cin, generator=g).to(torch.bfloat16)
+    gy = torch.randn(n, B, H, W, cout, generator=g).to(torch.bfloat16)
+    out = T.conv_weight_grad_nhwc(ks, x.to(_dev()), gy.to(_dev()), cout, cin, groups=n, x_gstride=B * H * W * cin, g_gstride=B * H * W * cout,
+                                  shape=(B, H, W))
+    xb = x.permute(1, 2, 3, 0, 4).reshape(B, H, W, n * cin).contiguous()       # the same data as channel blocks
+    gb = gy.permute(1, 2, 3, 0, 4).reshape(B, H, W, n * cout).contiguous()
+    outb = T.conv_weight_grad_nhwc(ks, xb.to(_dev()), gb.to(_dev()), cout, cin, groups=n, x_gstride=cin, g_gstride=cout)
+    for k in range(n):
+        xr = x[k].float().permute(0, 3, 1, 2).contiguous()
+        gr = gy[k].float().permute(0, 3, 1, 2).contiguous()
+        ref = torch.nn.grad.conv2d_weight(xr, (cout, cin, ks, ks), gr, padding=ks // 2)          # [co, ci, ty, tx]
+        ref_t = ref.permute(2, 3, 1, 0).reshape(ks * ks * cin, cout)                            # [(ty, tx, ci), co]
+        for o in (out, outb):
+            within(_rel(o[k, :-1], ref_t), 2e-6)
+            within(_rel(o[k, -1], gr.sum(dim=(0, 2, 3))), 2e-6)
+    assert torch.equal(out, outb)
 
 
 @pytest.mark.parametrize("stage", ["stage2", "stage3"])
