@@ -12,7 +12,6 @@ from . import train_ops as T
 
 
 IMPLICIT_WGRAD = True   # 3x3 stride-1 weight gradients straight from the NHWC operands, csrc/wgrad.hip (False: im2col_t + GEMM)
-PLANAR_WGRAD = False    # A/B only: the planar-transpose + split-K GEMM form the NHWC kernel replaced
 
 
 def _rup(a, b):
@@ -68,10 +67,7 @@ class Conv2dFn(torch.autograd.Function):
         dw = db = dx = dx2 = None
         if (ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2])) and k == 3 and stride == 1 and not upsample \
                 and not has_x2 and cin_tot % 8 == 0 and cout % 8 == 0 and IMPLICIT_WGRAD:
-            if PLANAR_WGRAD and cin_tot % 16 == 0:
-                dw, db = T.conv3x3_weight_grad_implicit(x, g16, cout)
-            else:
-                dw, db = T.conv3x3_weight_grad(x, g16, cout)      # no im2col matrix, no transposed copies
+            dw, db = T.conv3x3_weight_grad(x, g16, cout)      # no im2col matrix, no transposed copies
             db = db if has_bias else None
         elif (ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2])) and k == 1 and stride == 1 and not upsample \
                 and not has_x2 and cin_tot % 8 == 0 and cout % 8 == 0 and IMPLICIT_WGRAD:

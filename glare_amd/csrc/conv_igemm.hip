@@ -448,10 +448,13 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
 // [co_tile][stage][tap][kstep][khalf][TN][8], zero-filled outside Cout / Cin.
 // dgrad != 0: `w` is the FORWARD filter [Cin_real][Cout][KS][KS] of which the data-gradient filter is wanted
 // (w'[co][ci][tap] = w[ci][co][KK-1-tap], input channels ci >= Cin_real zero): no flip/transpose/pad pass on the host.
+// blockIdx.y = filter of a batch of equally shaped filters (consecutive in `w`, consecutive packed images in `out`).
 __global__ void pack_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin, int KS,
                                    int TN, int KSTEPS, int n_stages, long long total, int dgrad, int Cin_real) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
+  w += (size_t)blockIdx.y * (dgrad ? (size_t)Cin_real * Cout : (size_t)Cout * Cin) * KS * KS;
+  out += (size_t)blockIdx.y * total;
   long long t = i;
   const int e = t % 8; t /= 8;
   const int n = t % TN; t /= TN;
@@ -601,6 +604,23 @@ extern "C" int glare_conv2d_pack_weight_upsample(const float* w_oihw, int cout, 
   const Variant v = pick_variant(3, cout);
   hipLaunchKernelGGL(pack_weight_subpix_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      w_oihw, (bf16_t*)packed_bf16, cout, cin_total, v.tn, (cin_total + 15) / 16, (cout + v.tn - 1) / v.tn, total);
+  return glare_launch_status();
+}
+
+extern "C" int glare_conv2d_pack_weight_batched(const float* w_boihw, int batch, int cout, int cin, int ksize, int dgrad_cout_padded,
+                                                void* packed_bf16, glare_stream_t stream) {
+  // `batch` filters of one shape in one launch; dgrad_cout_padded = 0: forward filters (glare_conv2d_pack_weight), > 0: the
+  // data-gradient filters (glare_conv2d_pack_weight_dgrad with that padding); packed images are consecutive
+  if (!w_boihw || !packed_bf16 || batch <= 0 || batch > 65535 || cout <= 0 || cin <= 0) return GLARE_ERR_INVALID;
+  const bool dg = dgrad_cout_padded > 0;
+  if (dg && (dgrad_cout_padded < cout || (dgrad_cout_padded % 8))) return GLARE_ERR_INVALID;
+  const int oc = dg ? cin : cout, ic = dg ? dgrad_cout_padded : cin;   // the packed conv's output / input channels
+  const long long total = glare_conv2d_packed_weight_elems(oc, ic, ksize);
+  if (total <= 0) return GLARE_ERR_UNSUPPORTED;
+  const Variant v = pick_variant(ksize, oc);
+  const int kc = 16 * v.ksteps;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256), batch), dim3(256), 0, (hipStream_t)stream, w_boihw,
+                     (bf16_t*)packed_bf16, oc, ic, ksize, v.tn, v.ksteps, (ic + kc - 1) / kc, total, dg ? 1 : 0, dg ? cout : ic);
   return glare_launch_status();
 }
 

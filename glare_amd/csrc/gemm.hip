@@ -27,10 +27,6 @@ struct GemmParams {
   int tiles_m, tiles_n;
   float alpha;
   int out_bf16, accumulate;
-  // implicit weight-gradient mode (imp_ci > 0): A is the padded planar activation of glare_pad_planar_t_bf16 (3 shifted
-  // copies); logical row m = tap*imp_ci + ci  (tap = ty*3 + tx) is the physical row (tx*imp_ci + ci) read at (ty-1)*imp_wp
-  int imp_ci;
-  long long imp_wp;
 };
 
 __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const GemmParams p) {
@@ -43,43 +39,24 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const GemmParams p) {
   const int tm = blockIdx.x % p.tiles_m, tn = blockIdx.x / p.tiles_m;  // m fastest: neighbours share the B tile in L2
   const int b = blockIdx.y;
   const int row0 = tm * BM, col0 = tn * BN;
-  const bool imp = p.imp_ci > 0;
-  const bf16_t* Ab = p.A + (long long)b * p.sA + (imp ? 0 : (long long)row0 * p.lda);
+  const bf16_t* Ab = p.A + (long long)b * p.sA + (long long)row0 * p.lda;
   const bf16_t* Bb = p.B + (long long)b * p.sB + (long long)col0 * p.ldb;
   const int rowsA = min(p.M - row0, BM), rowsB = min(p.N - col0, BN);
-  // implicit mode: the descriptor spans all three shifted copies (offsets are computed per 16-row group below)
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<bf16_t*>(Ab), 0, imp ? (int)((3LL * p.imp_ci * p.lda + 2 * p.imp_wp + p.K) * 2) : (int)((((long long)rowsA - 1) * p.lda + p.K) * 2),
-      0x00020000);
+      const_cast<bf16_t*>(Ab), 0, (int)((((long long)rowsA - 1) * p.lda + p.K) * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<bf16_t*>(Bb), 0, (int)((((long long)rowsB - 1) * p.ldb + p.K) * 2), 0x00020000);
   // DMA lane geometry: one instruction = 16 rows x 64 B; lane -> (row r, LDS chunk c'), source chunk c' ^ s(r)
   const int dr = lane >> 2, dc = (lane & 3) ^ ((dr >> 2) & 3);
   const int voffA = (int)((dr * p.lda + dc * 8) * 2), voffB = (int)((dr * p.ldb + dc * 8) * 2);
   const int strideA16 = (int)(16 * p.lda * 2), strideB16 = (int)(16 * p.ldb * 2);
-  int baseA[4];   // byte offset of this wave's four 16-row groups of the A tile
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int j = wave * 4 + i;
-    if (imp) {
-      const int m0 = row0 + j * 16, tap = m0 / p.imp_ci, ci0 = m0 % p.imp_ci;     // a group never straddles taps (Ci % 16 == 0)
-      if (tap < 9) {
-        const int ty = tap / 3, tx = tap % 3;
-        baseA[i] = (int)((((long long)tx * p.imp_ci + ci0) * p.lda + (long long)ty * p.imp_wp) * 2);   // (ty-1)*Wp + the Wp margin
-      } else {   // logical row 9*Ci = the row of ones kept after the three copies (bias gradient); anything beyond is masked
-        baseA[i] = (int)(((3LL * p.imp_ci + min(m0 - 9 * p.imp_ci, 0)) * p.lda + p.imp_wp) * 2);
-      }
-    } else {
-      baseA[i] = j * strideA16;
-    }
-  }
   auto issue = [&](int kt, int buf) {
     const int kofs = kt * BK * 2;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {  // 16 A instructions, 4 per wave
       const int j = wave * 4 + i;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(lA + buf * (BM * 4) + j * 64), 16,
-                                               voffA, baseA[i] + kofs, 0, 0);
+                                               voffA, j * strideA16 + kofs, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {  // 8 B instructions, 2 per wave
@@ -189,35 +166,21 @@ __global__ __launch_bounds__(256) void reduce_many_parts_kernel(const float* __r
 
 static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int K, long long lda, long long ldb, long long ldc,
                        int batch, long long strideA, long long strideB, long long strideC, float alpha, int out_bf16, int accumulate,
-                       int imp_ci, long long imp_wp, glare_stream_t stream);
+                       glare_stream_t stream);
 
 extern "C" int glare_gemm_nt_bf16(const void* A, const void* B, void* C, int M, int N, int K, long long lda, long long ldb,
                                   long long ldc, int batch, long long strideA, long long strideB, long long strideC, float alpha,
                                   int out_bf16, int accumulate, glare_stream_t stream) {
-  return gemm_launch(A, B, C, M, N, K, lda, ldb, ldc, batch, strideA, strideB, strideC, alpha, out_bf16, accumulate, 0, 0, stream);
-}
-
-// dWt[b][tap*Ci + ci][co] = sum_k xT3[(tx*Ci + ci)][k + ty*Wp] * gT[co][Wp + k] over the K slice of batch b: the 3x3 stride-1
-// weight gradient straight from the padded planar operands (no im2col matrix); row 9*Ci of the result = the bias gradient (xT3's
-// extra row of ones, ones_row = 3*Ci).  xT3 / gT as glare_pad_planar_t_bf16 writes them
-// (row pitch ld, the same for both); k_per_batch % 32 == 0; Ci % 16 == 0; batch b covers k in [b*k_per_batch, (b+1)*k_per_batch).
-extern "C" int glare_conv3x3_wgrad_implicit_bf16(const void* xT3, const void* gT, float* dWt, int Ci, int Co, int W, long long ld,
-                                                 int k_per_batch, int batch, glare_stream_t stream) {
-  if (Ci <= 0 || Ci % 16 || Co <= 0 || W <= 0) return GLARE_ERR_INVALID;
-  const long long Wp = (W + 2 + 7) / 8 * 8;
-  // gT is read at k + Wp (its margin); the A side adds ty*Wp per group on top of the k offset
-  return gemm_launch(xT3, static_cast<const bf16_t*>(gT) + Wp, dWt, 9 * Ci + 1, Co, k_per_batch, ld, ld, Co, batch, k_per_batch, k_per_batch,
-                     (long long)(9 * Ci + 1) * Co, 1.0f, 0, 0, Ci, Wp, stream);
+  return gemm_launch(A, B, C, M, N, K, lda, ldb, ldc, batch, strideA, strideB, strideC, alpha, out_bf16, accumulate, stream);
 }
 
 static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int K, long long lda, long long ldb, long long ldc,
                        int batch, long long strideA, long long strideB, long long strideC, float alpha, int out_bf16, int accumulate,
-                       int imp_ci, long long imp_wp, glare_stream_t stream) {
+                       glare_stream_t stream) {
   if (M < 0 || N < 0 || K < 0 || batch < 0) return GLARE_ERR_INVALID;
   if (M == 0 || N == 0 || batch == 0) return GLARE_OK;
   if (!A || !B || !C) return GLARE_ERR_INVALID;
   if (K == 0 || K % BK != 0 || lda % 8 != 0 || ldb % 8 != 0 || lda < K || ldb < K || ldc < N) return GLARE_ERR_INVALID;
-  if (imp_ci > 0 && (((3LL * imp_ci + 1) * lda + 2 * imp_wp) * 2 >= (1ll << 31))) return GLARE_ERR_UNSUPPORTED;
   if (strideA % 8 != 0 || strideB % 8 != 0) return GLARE_ERR_INVALID;
   if (((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) != 0) return GLARE_ERR_INVALID;
   if ((BM * lda + K) * 2 >= (1ll << 31) || (BN * ldb + K) * 2 >= (1ll << 31)) return GLARE_ERR_UNSUPPORTED;  // 32-bit DMA offsets
@@ -230,7 +193,6 @@ static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int 
   p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.sA = strideA; p.sB = strideB; p.sC = strideC;
   p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(N, BN);
   p.alpha = alpha; p.out_bf16 = out_bf16; p.accumulate = accumulate;
-  p.imp_ci = imp_ci; p.imp_wp = imp_wp;
   const size_t lds = (size_t)(2 * BM * 4 + 2 * BN * 4) * 16;
   hipLaunchKernelGGL(gemm_nt_kernel, dim3(p.tiles_m * p.tiles_n, batch), dim3(256), lds, static_cast<hipStream_t>(stream), p);
   return glare_launch_status();

@@ -136,63 +136,6 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Operand of the IMPLICIT weight gradient (no im2col matrix): the activation as planar, zero-bordered rows in a padded pixel
-// space p' = b*Hp*Wp + yy*Wp + xx  (Hp = H+2, Wp = roundup(W+2, 8)), one copy per horizontal tap shift:
-//   out[s*C + c][margin + p'] = x[b, yy-1, xx-1 + (s - n_shifts/2), c]   (0 outside the image)
-// A 3x3 tap (ty, tx) of channel c is then the row (tx*C + c) read at the constant offset (ty-1)*Wp -- a 16-B aligned pointer
-// shift, which glare_gemm_nt_bf16's implicit mode applies per 16-row group.  n_shifts = 1 gives the plain zero-bordered
-// transpose (the output-gradient operand: zeros at the border make the padded-space sum exact).
-struct PadTParams {
-  const bf16_t* x;
-  bf16_t* out;
-  long long ld, margin, Pp;
-  int B, H, W, Hp, Wp, pitch, off, C, n_shifts, vec_ok, ones_row;
-};
-
-// grid.x covers the WHOLE row (ld / 64 blocks): margins and tail are written as zeros here, no separate fill
-__global__ __launch_bounds__(256) void pad_shift_t_kernel(const PadTParams p) {
-  __shared__ __attribute__((aligned(16))) bf16_t tile[TT][TT + 8];
-  const int tid = threadIdx.x;
-  const long long e0 = (long long)blockIdx.x * TT, p0 = e0 - p.margin;   // element block of the row / its padded-space pixel
-  const int c0 = blockIdx.y * TT, s = blockIdx.z, dx = s - p.n_shifts / 2;
-  if (p.ones_row >= 0 && blockIdx.y == 0 && s == 0 && tid < TT) p.out[(long long)p.ones_row * p.ld + e0 + tid] = (bf16_t)0x3f80;
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    const int pl = pass * 32 + (tid >> 3), ch = (tid & 7) * 8;
-    const long long pp = p0 + pl;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (pp >= 0 && pp < p.Pp && c0 + ch < p.C) {
-      const int xx = (int)(pp % p.Wp), yy = (int)((pp / p.Wp) % p.Hp), b = (int)(pp / ((long long)p.Wp * p.Hp));
-      const int iy = yy - 1, ix = xx - 1 + dx;
-      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && xx < p.W + 2) {
-        const bf16_t* src = p.x + (((long long)b * p.H + iy) * p.W + ix) * p.pitch + p.off + c0 + ch;
-        if (p.vec_ok && c0 + ch + 8 <= p.C) {
-          v = *reinterpret_cast<const u32x4*>(src);
-        } else {
-          bf16_t e[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) e[i] = (c0 + ch + i < p.C) ? src[i] : (bf16_t)0;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = (uint32_t)e[2 * i] | ((uint32_t)e[2 * i + 1] << 16);
-        }
-      }
-    }
-    *reinterpret_cast<u32x4*>(&tile[pl][ch]) = v;
-  }
-  __syncthreads();
-  const int cl = tid >> 2, sg = tid & 3, c = c0 + cl;
-  if (c < p.C) {
-    u32x4 o[2];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-      o[i >> 2][i & 3] = (uint32_t)tile[sg * 16 + 2 * i][cl] | ((uint32_t)tile[sg * 16 + 2 * i + 1][cl] << 16);
-    bf16_t* dst = p.out + ((long long)s * p.C + c) * p.ld + e0 + sg * 16;
-    *reinterpret_cast<u32x4*>(dst) = o[0];
-    *reinterpret_cast<u32x4*>(dst + 8) = o[1];
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------
 // dilate2: out[b][2oy+1][2ox+1][c] = g[b][oy][ox][c], 0 elsewhere (out: [B][2OH][2OW][C]); a pad-1 3x3 conv of it with
 // the flipped filter is the data gradient of the (0,1,0,1)-padded stride-2 conv (encoder_decoder.py:71-74)
 __global__ __launch_bounds__(256) void dilate2_kernel(const bf16_t* __restrict__ g, bf16_t* __restrict__ out, int B, int OH, int OW,
@@ -702,26 +645,6 @@ extern "C" int glare_transpose_bf16(const void* in, long long ld_in, long long b
   hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)(ld_out / TT), cdiv(cols, TT), batch), dim3(256), 0, ST(stream),
                      static_cast<const bf16_t*>(in), ld_in, batch_stride_in, static_cast<bf16_t*>(out), ld_out, batch_stride_out, rows,
                      cols, vec_ok);
-  return glare_launch_status();
-}
-
-extern "C" long long glare_pad_planar_ld(int B, int H, int W, int k_multiple) {
-  const long long Wp = (W + 2 + 7) / 8 * 8, Pp = (long long)B * (H + 2) * Wp;
-  const long long body = cdivll(Pp, k_multiple) * k_multiple;
-  return cdivll(Wp + body + Wp, TT) * TT;   // leading / trailing margins for the (ty-1)*Wp row shifts, whole 64-element blocks
-}
-
-extern "C" int glare_pad_planar_t_bf16(const void* x_nhwc, int B, int H, int W, int pitch, int off, int C, int n_shifts, void* out,
-                                       long long ld, int ones_row, glare_stream_t stream) {
-  if (!x_nhwc || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (n_shifts != 1 && n_shifts != 3)) return GLARE_ERR_INVALID;
-  PadTParams p;
-  p.Hp = H + 2; p.Wp = (W + 2 + 7) / 8 * 8; p.Pp = (long long)B * p.Hp * p.Wp; p.margin = p.Wp;
-  if (ld % TT || ld < p.margin + p.Pp + p.Wp) return GLARE_ERR_INVALID;
-  p.ones_row = ones_row;
-  p.x = static_cast<const bf16_t*>(x_nhwc); p.out = static_cast<bf16_t*>(out); p.ld = ld;
-  p.B = B; p.H = H; p.W = W; p.pitch = pitch; p.off = off; p.C = C; p.n_shifts = n_shifts;
-  p.vec_ok = (pitch % 8 == 0 && off % 8 == 0 && (reinterpret_cast<uintptr_t>(x_nhwc) & 15) == 0) ? 1 : 0;
-  hipLaunchKernelGGL(pad_shift_t_kernel, dim3((unsigned)(ld / TT), cdiv(C, TT), n_shifts), dim3(256), 0, ST(stream), p);
   return glare_launch_status();
 }
 

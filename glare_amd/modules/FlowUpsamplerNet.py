@@ -319,9 +319,11 @@ class FlowNLLFn(torch.autograd.Function):
         h1f = ops.conv2d(ft, ops.PackedConv(f0_w, f0_b), act="relu")
         h2f = torch.empty_like(h1f)
         hF = torch.zeros(B, H, W, n * 8, dtype=torch.float32, device=dev)
+        f2p, f4p = ops.packed_conv_batch(f2_w, f2_b), ops.packed_conv_batch(f4_w, f4_b)      # one pack launch per conv type
+        c2p, c4p = ops.packed_conv_batch(c2_w, c2_b), ops.packed_conv_batch(c4_w, c4_b)
         for s in range(n):
-            ops.conv2d(h1f, ops.PackedConv(f2_w[s], f2_b[s]), cin=64, in_off=64 * s, act="relu", out=h2f, out_off=64 * s)
-            ops.conv2d(h2f, ops.PackedConv(f4_w[s], f4_b[s]), cin=64, in_off=64 * s, out=hF, out_off=8 * s, out_mode=ops.OUT_NHWC_F32)
+            ops.conv2d(h1f, f2p[s], cin=64, in_off=64 * s, act="relu", out=h2f, out_off=64 * s)
+            ops.conv2d(h2f, f4p[s], cin=64, in_off=64 * s, out=hF, out_off=8 * s, out_mode=ops.OUT_NHWC_F32)
         z = gt.detach().clone().contiguous()
         z_in = torch.empty(n, B, H, W, 3, dtype=torch.float32, device=dev)
         z_pre = torch.empty_like(z_in)
@@ -335,8 +337,8 @@ class FlowNLLFn(torch.autograd.Function):
             ops.flow_fwd_pre(z, hF, 8 * k, None, None, eps, partial[2 * k], Mt_dev=Mt[k])
             z_pre[k].copy_(z)
             ops.flow_h1(z, ftA, 64 * k, wz[k], out=h1s[k])
-            ops.conv2d(h1s[k], ops.PackedConv(c2_w[k], c2_b[k]), act="relu", out=h2s[k])
-            ops.conv2d(h2s[k], ops.PackedConv(c4_w[k], c4_b[k]), out=h4s[k], out_mode=ops.OUT_NHWC_F32)
+            ops.conv2d(h1s[k], c2p[k], act="relu", out=h2s[k])
+            ops.conv2d(h2s[k], c4p[k], out=h4s[k], out_mode=ops.OUT_NHWC_F32)
             ops.flow_fwd_post(z, h4s[k], eps, partial[2 * k + 1])
         mean = mean.contiguous()
         red = ops.flow_nll_reduce(z, mean, partial, 2 * n)
@@ -361,11 +363,13 @@ class FlowNLLFn(torch.autograd.Function):
         P = B * H * W
         gh4s = torch.empty(n, B, H, W, 8, dtype=torch.bfloat16, device=dev)     # kept: their filter gradients are batched below
         gh2s = torch.empty(n, B, H, W, 64, dtype=torch.bfloat16, device=dev)
+        c4t, c2t = ops.packed_conv_batch(c4_w, dgrad_pad=8), ops.packed_conv_batch(c2_w, dgrad_pad=64)   # data-gradient filters
+        f4t, f2t = ops.packed_conv_batch(f4_w, dgrad_pad=8), ops.packed_conv_batch(f2_w, dgrad_pad=64)
         for k in reversed(range(n)):                                   # the sequential adjoint sweep
             T.flow_post_backward_(gz, z_pre[k], h4s[k], gld, eps, out=gh4s[k])
-            ops.conv2d(gh4s[k], _wt(c4_w[k], 8), out=gh2s[k])
+            ops.conv2d(gh4s[k], c4t[k], out=gh2s[k])
             T.act_backward_(gh2s[k], h2s[k], "relu")
-            ops.conv2d(gh2s[k], _wt(c2_w[k]), out=gftA, out_off=64 * k)
+            ops.conv2d(gh2s[k], c2t[k], out=gftA, out_off=64 * k)
             T.act_backward_(gftA, h1s[k], "relu", C=64, g_off=64 * k)
             T.flow_h1_backward_(gz, gftA, 64 * k, z_pre[k], wz[k], out=dwz[k])
             T.flow_pre_backward_(gz, z_in[k], hF, 8 * k, gld, None, None, eps, ghF, 8 * k, out=dMt[k], Mt_dev=Mt[k])
@@ -375,9 +379,9 @@ class FlowNLLFn(torch.autograd.Function):
         o2 = T.conv_weight_grad_nhwc(1, h1s, gh2s, 64, 64, groups=n, x_gstride=P * 64, g_gstride=P * 64, shape=(B, H, W))  # [n,65,64]
         gh2f, gh1f = torch.empty_like(h1f), torch.empty_like(h1f)
         for s in range(n):                                             # the z-independent feature nets: data gradients
-            ops.conv2d(ghF, _wt(f4_w[s], 8), cin=8, in_off=8 * s, out=gh2f, out_off=64 * s)
+            ops.conv2d(ghF, f4t[s], cin=8, in_off=8 * s, out=gh2f, out_off=64 * s)
             T.act_backward_(gh2f, h2f, "relu", C=64, g_off=64 * s, y_off=64 * s)
-            ops.conv2d(gh2f, _wt(f2_w[s]), cin=64, in_off=64 * s, out=gh1f, out_off=64 * s)
+            ops.conv2d(gh2f, f2t[s], cin=64, in_off=64 * s, out=gh1f, out_off=64 * s)
             T.act_backward_(gh1f, h1f, "relu", C=64, g_off=64 * s, y_off=64 * s)
         # ... and their filter gradients: step s owns a channel block of both tensors (group stride = the block)
         of4 = T.conv_weight_grad_nhwc(3, h2f, ghF, 8, 64, groups=n, x_gstride=64, g_gstride=8)      # [n,577,8], 6 of 8 used

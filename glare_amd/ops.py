@@ -89,6 +89,31 @@ class PackedConv:
             check(lib.glare_conv1x1_ws_pack_weight(ptr(w), _i(cout), _i(cin), ptr(self.w16), stream_handle()), "glare_conv1x1_ws_pack_weight")
 
 
+def packed_conv_batch(weights, biases=None, dgrad_pad=None):
+    """weights fp32 [n, cout, cin, k, k] (n filters of one shape) -> n PackedConv whose packed images come from ONE launch.
+    biases: fp32 [n, cout] or None; dgrad_pad as in PackedConv."""
+    require_cuda(weights, biases)
+    w = weights.detach().float().contiguous()
+    n, cout, cin, kh, kw = w.shape
+    assert kh == kw and kh in (1, 3)
+    lib = _lib.lib()
+    lib.glare_conv2d_packed_weight_elems.restype = _ll
+    oc, ic = (cout, cin) if dgrad_pad is None else (cin, dgrad_pad)
+    elems = lib.glare_conv2d_packed_weight_elems(_i(oc), _i(ic), _i(kh))
+    assert elems > 0
+    packed = torch.empty(n, elems, dtype=torch.bfloat16, device=w.device)
+    check(lib.glare_conv2d_pack_weight_batched(ptr(w), _i(n), _i(cout), _i(cin), _i(kh), _i(0 if dgrad_pad is None else dgrad_pad),
+                                               ptr(packed), stream_handle()), "glare_conv2d_pack_weight_batched")
+    b = None if biases is None else biases.detach().float().contiguous()
+    out = []
+    for k in range(n):
+        pc = PackedConv.__new__(PackedConv)
+        pc.ksize, pc.subpixel, pc.cout, pc.cin, pc.packed, pc.w16 = kh, False, oc, ic, packed[k], None
+        pc.bias = None if b is None else b[k]
+        out.append(pc)
+    return out
+
+
 CONV1X1_WEIGHT_STATIONARY = True   # False: every 1x1 conv through the implicit-GEMM kernel (conv_igemm.hip, KS = 1)
 
 

@@ -553,32 +553,3 @@ def conv1x1_weight_grad(x, g16, cout, cin=None, in_off=0):
     cin = x.shape[-1] - in_off if cin is None else cin
     dwt = conv_weight_grad_nhwc(1, x, g16, cout, cin, in_off)[0]
     return dwt[:cin].t().unsqueeze(-1).unsqueeze(-1), dwt[cin]
-
-
-def conv3x3_weight_grad_implicit(x, g16, cout, cin=None, in_off=0):
-    """Weight + bias gradient of a 3x3 / stride-1 / pad-1 conv without an im2col matrix.  x: bf16 NHWC [B,H,W,pitch] (cin
-    channels at in_off, cin % 16 == 0); g16: bf16 NHWC [B,H,W,>=cout].  Returns (dW fp32 [cout,cin,3,3] (a permuted view),
-    db fp32 [cout])."""
-    require_cuda(x, g16)
-    B, H, W, pitch = x.shape
-    cin = pitch - in_off if cin is None else cin
-    assert cin % 16 == 0 and g16.shape[:3] == x.shape[:3]
-    lib = _lib.lib()
-    lib.glare_pad_planar_ld.restype = _ll
-    Pp = B * (H + 2) * _rup(W + 2, 8)
-    tiles = ((9 * cin + 256) // 256) * ((cout + 127) // 128)
-    S = max(1, min((WGRAD_TARGET_WGS + tiles - 1) // tiles, Pp // WGRAD_MIN_K, 64))
-    ld = int(lib.glare_pad_planar_ld(_i(B), _i(H), _i(W), _i(32 * S)))
-    kpb = _rup(Pp, 32 * S) // S
-    cop = g16.shape[-1]
-    xT3 = torch.empty(3 * cin + 1, ld, dtype=torch.bfloat16, device=x.device)      # + the row of ones
-    gT = torch.empty(cop, ld, dtype=torch.bfloat16, device=x.device)
-    check(lib.glare_pad_planar_t_bf16(ptr(x), _i(B), _i(H), _i(W), _i(pitch), _i(in_off), _i(cin), _i(3), ptr(xT3), _ll(ld), _i(3 * cin),
-                                      stream_handle()), "glare_pad_planar_t_bf16")
-    check(lib.glare_pad_planar_t_bf16(ptr(g16), _i(B), _i(H), _i(W), _i(cop), _i(0), _i(cop), _i(1), ptr(gT), _ll(ld), _i(-1),
-                                      stream_handle()), "glare_pad_planar_t_bf16")
-    parts = torch.empty(S, 9 * cin + 1, cout, dtype=torch.float32, device=x.device)
-    check(lib.glare_conv3x3_wgrad_implicit_bf16(ptr(xT3), ptr(gT), ptr(parts), _i(cin), _i(cout), _i(W), _ll(ld), _i(kpb), _i(S),
-                                                stream_handle()), "glare_conv3x3_wgrad_implicit_bf16")
-    dwt = reduce_parts(parts) if S > 1 else parts[0]
-    return dwt[:9 * cin].view(3, 3, cin, cout).permute(3, 2, 0, 1), dwt[9 * cin]

@@ -112,6 +112,11 @@ int glare_conv2d_pack_weight(const float* w_oihw, int cout, int cin_total, int k
  * cout_padded input and cin output channels (glare_conv2d_packed_weight_elems(cin, cout_padded, ksize) elements). */
 int glare_conv2d_pack_weight_dgrad(const float* w_oihw, int cout, int cin, int ksize, int cout_padded, void* packed_bf16,
                                    glare_stream_t stream);
+/* `batch` filters of one shape ([batch][cout][cin][k][k] fp32, consecutive) packed in one launch into consecutive packed images:
+ * dgrad_cout_padded = 0 as glare_conv2d_pack_weight, > 0 as glare_conv2d_pack_weight_dgrad with that padding (the per-step convs
+ * of the flow's coupling nets, FlowAffineCouplingsAblation.py:117-160: 24 steps x 4 convs of two shapes). */
+int glare_conv2d_pack_weight_batched(const float* w_boihw, int batch, int cout, int cin, int ksize, int dgrad_cout_padded,
+                                     void* packed_bf16, glare_stream_t stream);
 /* Sub-pixel filters of "nearest x2 upsample, then 3x3 conv": per output phase (row parity a, column parity b) the 3x3 taps
  * that read the same source pixel are summed in fp32 and rounded to bf16 once (rows a=0: {0},{1,2}; a=1: {0,1},{2}). */
 long long glare_conv2d_upsample_packed_weight_elems(int cout, int cin_total);
@@ -347,19 +352,6 @@ int glare_im2col_t_bf16(const void* x_nhwc, int B, int H, int W, int pitch, int 
 int glare_im2col_t_f32(const float* x, long long stride_b, long long stride_c, long long stride_y, long long stride_x, int B,
                        int H, int W, int Ci, int ksize, int pad, void* colT, long long ldp, int row_base, int ones_row,
                        glare_stream_t stream);
-/* Implicit (im2col-free) weight gradient of a 3x3, stride-1, pad-1 convolution.  glare_pad_planar_t_bf16 writes an NHWC tensor as
- * planar zero-bordered rows in the padded pixel space p' = b*(H+2)*Wp + yy*Wp + xx, Wp = roundup(W+2, 8), after a margin of Wp
- * elements: out[s*C + c][Wp + p'] = x[b, yy-1, xx-1 + (s - n_shifts/2), c]; n_shifts = 3 for the activation (one copy per
- * horizontal tap), 1 for the output gradient.  Whole rows (margins and tail included) are written; pitch ld = glare_pad_planar_ld();
- * ones_row >= 0 additionally fills that row with ones (the activation operand carries it at row 3*C: bias gradient).
- * glare_conv3x3_wgrad_implicit_bf16 then contracts over the padded pixels on the MFMA GEMM, vertical taps being aligned
- * pointer shifts of +-Wp: dWt[b][(ty*3+tx)*Ci + ci][co] plus row 9*Ci = the bias gradient, one [9*Ci+1][Co] partial per K
- * slice b (sum with glare_reduce_parts_f32). */
-long long glare_pad_planar_ld(int B, int H, int W, int k_multiple);
-int glare_pad_planar_t_bf16(const void* x_nhwc, int B, int H, int W, int pitch, int off, int C, int n_shifts, void* out,
-                            long long ld, int ones_row, glare_stream_t stream);
-int glare_conv3x3_wgrad_implicit_bf16(const void* xT3, const void* gT, float* dWt, int Ci, int Co, int W, long long ld,
-                                      int k_per_batch, int batch, glare_stream_t stream);
 /* Weight + bias gradients of `groups` independent ksize x ksize (3: pad 1; or 1), stride-1 convolutions of one shape, straight from
  * the NHWC operands (csrc/wgrad.hip; cuDNN wgrad in the reference's loss.backward(), LLFlow_model.py:231-236):
  * dWt[grp][(ty*ksize+tx)*Ci + ci][co] = sum_{b,y,x} g[b,y,x,co] x[b,y+ty-pad,x+tx-pad,ci], row ksize^2*Ci = the bias gradient; fp32

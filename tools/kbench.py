@@ -103,8 +103,8 @@ def bench_dcn():
 
 
 def bench_wgrad():
-    """Weight gradient of the 3x3 convs at the stage-2 crop (B = 2, 320x320 and its half / quarter resolutions): the whole path
-    (planar transposes + split-K product + reduction) and the product alone."""
+    """Weight gradient of the 3x3 convs at the stage-2 crop (B = 2, 320x320 and its half / quarter resolutions): csrc/wgrad.hip
+    plus the reduction of its split partials."""
     from glare_amd import train_ops as T
     for name, cin, cout, H, W in [("128->128 @320", 128, 128, 320, 320), ("256->256 @160", 256, 256, 160, 160),
                                   ("512->512 @80", 512, 512, 80, 80), ("128->256 @160", 128, 256, 160, 160),
@@ -112,10 +112,8 @@ def bench_wgrad():
         x = torch.randn(2, H, W, cin, device=DEV).to(torch.bfloat16)
         g = torch.randn(2, H, W, cout, device=DEV).to(torch.bfloat16)
         ms = timeit(lambda: T.conv3x3_weight_grad(x, g, cout))
-        ms_old = timeit(lambda: T.conv3x3_weight_grad_implicit(x, g, cout))
         fl = 2.0 * 2 * H * W * 9 * cin * cout
-        print("wgrad %-15s: %.3f ms  %.0f TFLOP/s (NHWC kernel + reduction);  planar transposes + split-K GEMM: %.3f ms"
-              % (name, ms, fl / ms / 1e9, ms_old))
+        print("wgrad %-15s: %.3f ms  %.0f TFLOP/s (NHWC kernel + reduction)" % (name, ms, fl / ms / 1e9))
 
 
 def bench_vq():
