@@ -103,7 +103,6 @@ template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int KSTEPS>
 __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 2)) void conv_igemm_kernel(const ConvParams p) {
   constexpr int TH = WM * MT;       // output tile rows
   constexpr int NW = WM * WN;       // waves per workgroup (4, or 6 for the 12 x 32 x 128 tile)
-  constexpr int NTHREADS = 64 * NW;
   using G = TileGeom<KS, STRIDE, TH>;
   static_assert(NW == 4 || NW == 6 || NW == 8, "wave layout");
   constexpr int TN = WN * NT * 32;
@@ -235,7 +234,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
       // The next stage's DMA pieces are not issued in one burst behind the barrier (12 waves would queue 47 pieces on the
       // CU's address path with the matrix pipe waiting): they are spread over the stage's KS*KSTEPS MFMA groups.
       constexpr int NGRP = KS * KSTEPS;
-      constexpr int B_PG = (B_PER_W + NGRP - 1) / NGRP, A_PG = (A_PER_W + NGRP - 1) / NGRP;
+      [[maybe_unused]] constexpr int B_PG = (B_PER_W + NGRP - 1) / NGRP, A_PG = (A_PER_W + NGRP - 1) / NGRP;
       const bool more_b = bs + 1 < n_bstages, more_a = trow == 0 && chunk + 1 < p.n_stages;
 #if !CONV_DMA_SPREAD
 #ifndef CONV_ABLATE_NODMA

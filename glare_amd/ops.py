@@ -114,6 +114,16 @@ def packed_conv_batch(weights, biases=None, dgrad_pad=None):
     return out
 
 
+# Measurement hook (tools/train_bench.py flops): when a dict, every MFMA launch family adds its algorithmic FLOPs (2 x MACs) to
+# FLOP_COUNTER[family]; None (the default) counts nothing.
+FLOP_COUNTER = None
+
+
+def count_flops(family, flops):
+    if FLOP_COUNTER is not None:
+        FLOP_COUNTER[family] = FLOP_COUNTER.get(family, 0.0) + float(flops)
+
+
 CONV1X1_WEIGHT_STATIONARY = True   # False: every 1x1 conv through the implicit-GEMM kernel (conv_igemm.hip, KS = 1)
 
 
@@ -148,6 +158,9 @@ def conv2d(x, pc, *, x2=None, cin=None, in_off=0, cin2=None, in2_off=0, stride=1
     assert x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous()
     B, H, W, pitch = x.shape
     cin = pitch - in_off if cin is None else cin
+    if FLOP_COUNTER is not None:
+        opix = B * H * W * (4 if upsample else 1) // (stride * stride)
+        count_flops("conv k%d" % pc.ksize, 2.0 * opix * pc.ksize ** 2 * pc.cin * pc.cout)
     if (CONV1X1_WEIGHT_STATIONARY and getattr(pc, "w16", None) is not None and x2 is None and stride == 1 and not upsample
             and out_mode == OUT_NHWC_BF16 and cin == pc.cin and pitch % 8 == 0 and in_off % 8 == 0
             and (out is None or (out.dtype == torch.bfloat16 and out.shape[3] % 8 == 0 and out_off % 8 == 0))

@@ -9,6 +9,8 @@ import torch
 from . import _lib
 from ._lib import check, ptr, require_cuda, stream_handle
 
+from .ops import count_flops as _count_flops
+
 _i = ctypes.c_int
 _ll = ctypes.c_longlong
 _f = ctypes.c_float
@@ -34,6 +36,7 @@ def gemm_nt(a, b, out=None, alpha=1.0, out_dtype=torch.float32, accumulate=False
             out.zero_()
     o3 = out if out.dim() == 3 else out.unsqueeze(0)
     assert o3.stride(-1) == 1 and o3.dtype in (torch.float32, torch.bfloat16)
+    _count_flops("gemm_nt", 2.0 * batch * M * N * K)
     check(_lib.lib().glare_gemm_nt_bf16(ptr(a), ptr(b), ptr(o3), _i(M), _i(N), _i(K), _ll(a.stride(1)), _ll(b.stride(1)),
                                         _ll(o3.stride(1)), _i(batch), _ll(a.stride(0) if batch > 1 else 0),
                                         _ll(b.stride(0) if batch > 1 else 0), _ll(o3.stride(0) if batch > 1 else 0),
@@ -528,6 +531,7 @@ def conv_weight_grad_nhwc(ksize, x, g16, cout, cin=None, in_off=0, groups=1, x_g
     B, H, W = x.shape[:3] if shape is None else shape
     pitch, gpitch = x.shape[-1], g16.shape[-1]
     cin = pitch - in_off if cin is None else cin
+    _count_flops("wgrad k%d" % ksize, 2.0 * groups * B * H * W * ksize * ksize * cin * cout)
     lib = _lib.lib()
     lib.glare_conv_wgrad_workspace_bytes.restype = ctypes.c_size_t
     nws = lib.glare_conv_wgrad_workspace_bytes(_i(ksize), _i(groups), _i(B), _i(H), _i(W), _i(cin), _i(cout))

@@ -19,9 +19,12 @@ python tools/rocpd_stats.py $(ls gpurun_out/prof_$tag/*/b_results.db gpurun_out/
 } > gpurun_out/${tag}_pmc_kernels.txt
 python tools/kbench.py > gpurun_out/${tag}_kbench.txt 2>&1
 for st in stage2 stage3; do
+  python tools/train_bench.py $st 20 graph > gpurun_out/${tag}_train_${st}_graph.txt 2>&1
   python tools/train_bench.py $st 10 > gpurun_out/${tag}_train_$st.txt 2>&1
   rocprofv3 --kernel-trace --stats -d gpurun_out/proft_${tag}_$st -o t -- python tools/train_bench.py $st 5 > /dev/null 2>&1
   python tools/rocpd_stats.py $(ls gpurun_out/proft_${tag}_$st/*/t_results.db gpurun_out/proft_${tag}_$st/t_results.db 2>/dev/null | head -1) > gpurun_out/${tag}_train_${st}_kernel_stats.txt 2>&1
+  python tools/train_bench.py $st 1 flops 2>&1 | grep flops_per_step > gpurun_out/${tag}_train_${st}_flops.txt
+  python tools/train_roofline.py gpurun_out/${tag}_train_${st}_kernel_stats.txt gpurun_out/${tag}_train_${st}_flops.txt 7 > gpurun_out/${tag}_train_${st}_roofline.txt 2>&1
 done
 rm -rf gpurun_out/prof_$tag gpurun_out/proft_${tag}_* gpurun_out/tr_f_* gpurun_out/tr_w_* gpurun_out/pmc_${tag}_*/ gpurun_out/pmc2_${tag}_*/ 2>/dev/null
 ls -la gpurun_out | grep $tag
