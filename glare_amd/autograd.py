@@ -159,6 +159,21 @@ def groupnorm(x, gamma, beta, swish=True, eps=1e-6):
     return GroupNormFn.apply(x, gamma, beta, swish, eps)
 
 
+# Attention backward: "fused" = csrc/attn_bwd.hip (no N^2 tensor), "materialised" = gemm_nt + softmax2_rows + attn_ds with the N^2
+# scores in HBM, "auto" = fused when its grid fills the chip (B * ceil(N / 64) >= 160 workgroups, one per CU: 1.59 vs 1.75 ms at the
+# stage-2 latent, 2 x 6400 tokens) or when the scores of one sample would not fit comfortably (N > 8192: 4 x N^2 x 2-4 B), else
+# materialised (64 workgroups at the stage-3 latent would leave 3/4 of the CUs idle).
+FUSED_ATTENTION_BACKWARD = "auto"
+
+
+def _use_fused_attention_backward(B, N):
+    if FUSED_ATTENTION_BACKWARD in (True, "fused"):
+        return True
+    if FUSED_ATTENTION_BACKWARD in (False, "materialised"):
+        return False
+    return B * ((N + 63) // 64) >= 160 or N > 8192
+
+
 class AttentionFn(torch.autograd.Function):
     """softmax(q k^T) v with q already carrying scale*log2(e) (base-2 logits): q, k, v bf16 [B, N, 512]."""
 
@@ -167,13 +182,16 @@ class AttentionFn(torch.autograd.Function):
         B, N, d = q.shape
         assert d == 512 and q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
         vt = T.transpose(v, _rup(N, 64))
-        o = ops.attention_d512(q, k, vt, N)
-        ctx.save_for_backward(q, k, v, o)
+        lse = torch.empty(B, N, dtype=torch.float32, device=q.device) if _use_fused_attention_backward(B, N) else None
+        o = ops.attention_d512(q, k, vt, N, lse=lse)
+        ctx.save_for_backward(q, k, v, o, lse)
         return o
 
     @staticmethod
     def backward(ctx, go):
-        q, k, v, o = ctx.saved_tensors
+        q, k, v, o, lse = ctx.saved_tensors
+        if lse is not None:
+            return T.attention_backward_fused(q, k, v, o, go.contiguous(), lse)
         return T.attention_backward(q, k, v, o, go.contiguous())
 
 

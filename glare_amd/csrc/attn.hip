@@ -82,6 +82,7 @@ struct AttnParams {
   int key_splits;      // > 1: each workgroup covers 1/key_splits of the keys and leaves an un-normalised partial
   float* part_o;       // [B][key_splits][N][512] fp32
   float* part_ml;      // [B][key_splits][N][2]   (running max in log2 units, sum)
+  float* lse;          // optional [B][N]: log2 sum_j 2^(q_i.k_j) of every query row (what the backward needs); attn_fwd_kernel only
 };
 
 __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParams p) {
@@ -488,6 +489,7 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
     return;
   }
   const float inv = 1.0f / l_tot;
+  if (p.lse && q_ok && hi == 0) p.lse[(size_t)b * p.N + qrow] = m_run + __builtin_amdgcn_logf(l_tot);   // v_log_f32 = log2
   if (q_ok) {
     bf16_t* op = p.o + ((size_t)b * p.N + qrow) * p.ldo;
 #pragma unroll
@@ -1446,7 +1448,8 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_kv_pipe_kernel(const AttnP
 
 // out[q] = sum_s 2^(m_s - m) O_s[q] / sum_s 2^(m_s - m) l_s,  m = max_s m_s: merges the key splits (one wave per query row)
 __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
-                                                           bf16_t* __restrict__ out, int ldo, int B, int N, int KS) {
+                                                           bf16_t* __restrict__ out, int ldo, int B, int N, int KS,
+                                                           float* __restrict__ lse) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // b * N + q
   if (row >= (long long)B * N) return;
   const int lane = threadIdx.x & 63, b = (int)(row / N), q = (int)(row % N);
@@ -1465,6 +1468,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
     for (int e = 0; e < 4; ++e) { acc[e] = fmaf(w, v0[e], acc[e]); acc[4 + e] = fmaf(w, v1[e], acc[4 + e]); }
   }
   const float inv = 1.0f / L;
+  if (lse && lane == 0) lse[row] = m + __builtin_amdgcn_logf(L);
   u32x4 o = {pack_bf2(acc[0] * inv, acc[1] * inv), pack_bf2(acc[2] * inv, acc[3] * inv), pack_bf2(acc[4] * inv, acc[5] * inv),
              pack_bf2(acc[6] * inv, acc[7] * inv)};
   *reinterpret_cast<u32x4*>(out + (size_t)row * ldo + lane * 8) = o;
@@ -1473,7 +1477,14 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
 }  // namespace
 
 static int attn_launch(const void* q, int ldq, const void* k, int ldk, const void* v_t, long long v_pitch, void* out, int ldo, int B,
-                       int N, int key_splits, void* workspace, size_t workspace_bytes, glare_stream_t stream);
+                       int N, int key_splits, void* workspace, size_t workspace_bytes, glare_stream_t stream, float* lse = nullptr);
+
+extern "C" int glare_attention_d512_lse_bf16(const void* q, int ldq, const void* k, int ldk, const void* v_t, long long v_pitch, void* out,
+                                             int ldo, float* lse, int B, int N, int key_splits, void* workspace, size_t workspace_bytes,
+                                             glare_stream_t stream) {
+  if (!lse) return GLARE_ERR_INVALID;
+  return attn_launch(q, ldq, k, ldk, v_t, v_pitch, out, ldo, B, N, key_splits, workspace, workspace_bytes, stream, lse);
+}
 
 extern "C" size_t glare_attention_d512_splitk_workspace_bytes(int B, int N, int key_splits) {
   if (B <= 0 || N <= 0 || key_splits <= 1) return 0;
@@ -1497,7 +1508,7 @@ extern "C" int glare_attention_kv512_bf16(const void* q, int ldq, const void* kv
   if ((ldq % 8) || (ldkv % 8) || (ldo % 4) || ldq < HD || ldkv < HD || ldo < HD) return GLARE_ERR_UNSUPPORTED;
   AttnParams p;
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)kv; p.vt = nullptr; p.o = (bf16_t*)out;
-  p.B = B; p.N = N; p.Npad = 0; p.ldq = ldq; p.ldk = ldkv; p.ldo = ldo;
+  p.B = B; p.N = N; p.Npad = 0; p.ldq = ldq; p.ldk = ldkv; p.ldo = ldo; p.lse = nullptr;
   p.n_qblocks = (N + BM - 1) / BM;
   p.key_splits = key_splits;
   p.part_o = static_cast<float*>(workspace);
@@ -1518,7 +1529,7 @@ extern "C" int glare_attention_kv512_bf16(const void* q, int ldq, const void* kv
 #endif
   if (key_splits > 1)
     hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)(((long long)B * N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p.part_o,
-                       p.part_ml, p.o, ldo, B, N, key_splits);
+                       p.part_ml, p.o, ldo, B, N, key_splits, (float*)nullptr);
   return glare_launch_status();
 }
 
@@ -1528,8 +1539,9 @@ extern "C" int glare_attention_d512_bf16(const void* q, int ldq, const void* k, 
 }
 
 static int attn_launch(const void* q, int ldq, const void* k, int ldk, const void* v_t, long long v_pitch, void* out, int ldo, int B,
-                       int N, int key_splits, void* workspace, size_t workspace_bytes, glare_stream_t stream) {
+                       int N, int key_splits, void* workspace, size_t workspace_bytes, glare_stream_t stream, float* lse) {
   if (!q || !k || !v_t || !out || B <= 0 || N <= 0 || key_splits < 1) return GLARE_ERR_INVALID;
+  if (lse && (ATTN_8WAVES || ATTN_PIPELINED)) return GLARE_ERR_UNSUPPORTED;
   if (key_splits > (N + BN - 1) / BN) return GLARE_ERR_INVALID;   // every split owns at least one key tile
   if (((long long)N * ldk + HD) * 2 >= 0x7ff00000LL || (long long)HD * v_pitch * 2 >= 0x7ff00000LL) return GLARE_ERR_UNSUPPORTED;  // 32-bit DMA offsets per image
   if (key_splits > 1) {
@@ -1540,7 +1552,7 @@ static int attn_launch(const void* q, int ldq, const void* k, int ldk, const voi
   if (v_pitch < (long long)((N + BN - 1) / BN) * BN) return GLARE_ERR_INVALID;  // tiles read whole 32-key groups
   AttnParams p;
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.vt = (const bf16_t*)v_t; p.o = (bf16_t*)out;
-  p.B = B; p.N = N; p.Npad = v_pitch; p.ldq = ldq; p.ldk = ldk; p.ldo = ldo;
+  p.B = B; p.N = N; p.Npad = v_pitch; p.ldq = ldq; p.ldk = ldk; p.ldo = ldo; p.lse = lse;
   p.n_qblocks = (N + BM - 1) / BM;
   p.key_splits = key_splits;
   p.part_o = static_cast<float*>(workspace);
@@ -1560,6 +1572,6 @@ static int attn_launch(const void* q, int ldq, const void* k, int ldk, const voi
 #endif
   if (key_splits > 1)
     hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)(((long long)B * N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p.part_o,
-                       p.part_ml, p.o, ldo, B, N, key_splits);
+                       p.part_ml, p.o, ldo, B, N, key_splits, lse);
   return glare_launch_status();
 }

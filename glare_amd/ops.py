@@ -380,9 +380,13 @@ ATTENTION_PROFILE_BUFFER = None   # tools/kbench.py KB_PROF=1 (needs a -DATTNKV_
 ATTENTION_LAUNCH_EVENTS = None
 
 
-def attention_d512(q, k, v_t, N, ldq=None, ldk=None, out=None, key_splits=None):
-    """q, k: bf16 [B, N, ld] views (d=512 used); v_t: bf16 [B, 512, v_pitch]; returns bf16 [B, N, 512]."""
-    require_cuda(q, k, v_t, out)
+def attention_d512(q, k, v_t, N, ldq=None, ldk=None, out=None, key_splits=None, lse=None):
+    """q, k: bf16 [B, N, ld] views (d=512 used); v_t: bf16 [B, 512, v_pitch]; returns bf16 [B, N, 512].  lse: optional fp32 [B, N]
+    that receives log2 sum_j 2^(q_i . k_j) of every query row (what the fused backward needs)."""
+    require_cuda(q, k, v_t, out, lse)
+    if lse is not None:
+        assert lse.dtype == torch.float32 and lse.is_contiguous() and lse.numel() == v_t.shape[0] * N
+        return _attention_d512(q, k, v_t, N, ldq, ldk, out, key_splits, lse)
     if ATTENTION_LAUNCH_EVENTS is not None:
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         start.record()
@@ -394,7 +398,7 @@ def attention_d512(q, k, v_t, N, ldq=None, ldk=None, out=None, key_splits=None):
     return _attention_d512(q, k, v_t, N, ldq, ldk, out, key_splits)
 
 
-def _attention_d512(q, k, v_t, N, ldq, ldk, out, key_splits):
+def _attention_d512(q, k, v_t, N, ldq, ldk, out, key_splits, lse=None):
     B = v_t.shape[0]
     ldq = q.shape[-1] if ldq is None else ldq
     ldk = k.shape[-1] if ldk is None else ldk
@@ -403,6 +407,15 @@ def _attention_d512(q, k, v_t, N, ldq, ldk, out, key_splits):
     if key_splits is None:
         key_splits = ATTENTION_KEY_SPLITS_OVERRIDE
     ks = attention_key_splits(B, N) if key_splits is None else key_splits
+    if lse is not None:
+        lib = _lib.lib()
+        lib.glare_attention_d512_splitk_workspace_bytes.restype = _sz
+        nws = lib.glare_attention_d512_splitk_workspace_bytes(_i(B), _i(N), _i(ks))
+        ws = _workspace(nws, v_t.device) if nws else None
+        check(lib.glare_attention_d512_lse_bf16(ptr(q), _i(ldq), ptr(k), _i(ldk), ptr(v_t), _ll(v_t.shape[2]), ptr(out), _i(out.shape[-1]),
+                                                ptr(lse), _i(B), _i(N), _i(ks), ptr(ws), _sz(nws), stream_handle()),
+              "glare_attention_d512_lse_bf16")
+        return out
     if ks > 1:
         lib = _lib.lib()
         lib.glare_attention_d512_splitk_workspace_bytes.restype = _sz

@@ -263,6 +263,23 @@ def conv_weight_grad(x_col_builder, g_bf16, cout, n_rows, out=None):
     return reduce_parts(gemm_nt(a3, b3), out=out)
 
 
+def attention_backward_fused(q, k, v, o, do, lse, ln2_scale=0.6931471805599453):
+    """Flash-style backward (csrc/attn_bwd.hip): q (pre-scaled: q.k^T are base-2 logits), k, v, o, do bf16 [B, N, 512] dense, lse fp32
+    [B, N] from the forward -> (dq, dk, dv) bf16.  No N^2 tensor: scores are recomputed per tile in two passes."""
+    require_cuda(q, k, v, o, do, lse)
+    B, N, d = q.shape
+    assert d == 512 and all(t.is_contiguous() and t.dtype == torch.bfloat16 for t in (q, k, v, o, do))
+    assert lse.dtype == torch.float32 and lse.is_contiguous() and lse.numel() == B * N
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    lib = _lib.lib()
+    lib.glare_attention_d512_backward_workspace_bytes.restype = ctypes.c_size_t
+    nws = lib.glare_attention_d512_backward_workspace_bytes(_i(B), _i(N))
+    ws = torch.empty(nws, dtype=torch.uint8, device=q.device)
+    check(lib.glare_attention_d512_backward_bf16(ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(dq), ptr(dk), ptr(dv), _i(B), _i(N),
+                                                 _f(ln2_scale), ptr(ws), _sz(nws), stream_handle()), "glare_attention_d512_backward_bf16")
+    return dq, dk, dv
+
+
 def attention_backward(q, k, v, o, do, ln2_scale=0.6931471805599453):
     """q (pre-scaled so that q.k^T are base-2 logits), k, v, o, do: bf16 [B, N, 512] -> (dq, dk, dv) bf16.
     Materialised form, one sample at a time: N^2 scores live in HBM (82-164 MB at the training crops)."""

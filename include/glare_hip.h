@@ -227,6 +227,17 @@ int glare_attention_d512_splitk_bf16(const void* q, int ldq, const void* k, int 
                                      int ldo, int B, int N, int key_splits, void* workspace, size_t workspace_bytes,
                                      glare_stream_t stream);
 
+/* The forward above (key_splits >= 1) that also leaves lse[b][i] = log2 sum_j 2^(q_i . k_j), fp32 [B][N], and the fused backward of
+ * AttnBlock's two torch.bmm + softmax that consumes it (reference: autograd of encoder_decoder.py:176-188 behind loss.backward(),
+ * LLFlow_model.py:231-236): no N x N tensor; q (pre-scaled: q.k are base-2 logits), k, v, o, d_o and the three gradients are dense
+ * bf16 [B][N][512]; ds = ln2_scale * p * (dp - do.o); workspace of glare_attention_d512_backward_workspace_bytes (B*N floats). */
+int glare_attention_d512_lse_bf16(const void* q, int ldq, const void* k, int ldk, const void* v_t, long long v_pitch, void* out, int ldo,
+                                  float* lse, int B, int N, int key_splits, void* workspace, size_t workspace_bytes,
+                                  glare_stream_t stream);
+size_t glare_attention_d512_backward_workspace_bytes(int B, int N);
+int glare_attention_d512_backward_bf16(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                                       void* dq, void* dk, void* dv, int B, int N, float ln2_scale, void* workspace,
+                                       size_t workspace_bytes, glare_stream_t stream);
 /* The attention of AttnBlock with keys and values SHARED: out[b, i, :] = sum_j softmax_j(q_i . x_j) x_j.
  * AttnBlock is single-head self-attention on one tensor h = GroupNorm(x) (encoder_decoder.py:168-188): every term of
  * (Wq h_i + bq).(Wk h_j + bk) that does not depend on j cancels in softmax_j, so the key projection folds into the query

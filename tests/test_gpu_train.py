@@ -181,12 +181,16 @@ def test_groupnorm_autograd(C, swish):
     within(_rel(bd.grad, br.grad), 1e-6)   # measured 2.35e-07
 
 
-@pytest.mark.parametrize("N", [256, 330])
-def test_attention_autograd(N):
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("N", [256, 330, 1000])
+def test_attention_autograd(N, fused, monkeypatch):
+    """fused: csrc/attn_bwd.hip (scores recomputed per tile from the forward's log-sum-exp; N = 1000 takes the split-key forward, whose
+    merge kernel writes it); not fused: the materialised N^2 form."""
     import math
 
     from glare_amd import autograd as A
 
+    monkeypatch.setattr(A, "FUSED_ATTENTION_BACKWARD", fused)
     g = torch.Generator().manual_seed(N)
     B, d = 2, 512
     q, k, v = [_bf(torch.randn(B, N, d, generator=g) * s) for s in (1.0, 1.0, 1.0)]
@@ -205,6 +209,25 @@ def test_attention_autograd(N):
     within(_rel(qd.grad.float().cpu() * fold, qr.grad), 6.3e-3)  # d/dq = fold * d/dq'   # measured 3.28e-03
     within(_rel(kd.grad, kr.grad), 7.0e-3)   # measured 3.68e-03
     within(_rel(vd.grad, vr.grad), 5.5e-3)   # measured 2.85e-03
+
+
+def test_fused_attention_backward_at_inference_size_matches_the_materialised_form():
+    """One 400x600 image's latent (N = 16 275 tokens, not a multiple of the 32 / 64-row tiles): the fused backward (no N^2 tensor)
+    against the materialised one (1 GB of scores per product), same forward; and it is bit-reproducible."""
+    from glare_amd import ops, train_ops as T
+
+    g = torch.Generator().manual_seed(77)
+    B, N, d = 1, 105 * 155, 512
+    q = (torch.randn(B, N, d, generator=g) * 0.08).to(torch.bfloat16).to(_dev())
+    k, v, do = [torch.randn(B, N, d, generator=g).to(torch.bfloat16).to(_dev()) for _ in range(3)]
+    lse = torch.empty(B, N, dtype=torch.float32, device=_dev())
+    o = ops.attention_d512(q, k, T.transpose(v, (N + 63) // 64 * 64), N, lse=lse)
+    fused = T.attention_backward_fused(q, k, v, o, do, lse)
+    ref = T.attention_backward(q, k, v, o, do)
+    for a, b_, name in zip(fused, ref, ("dq", "dk", "dv")):
+        within(_rel(a, b_), 8e-3, tag=name)      # both round P / dS to bf16; the materialised form also rounds S-derived tiles
+    again = T.attention_backward_fused(q, k, v, o, do, lse)
+    assert all(torch.equal(a, b_) for a, b_ in zip(fused, again))
 
 
 def test_adam_matches_torch():

@@ -116,6 +116,21 @@ def bench_wgrad():
         print("wgrad %-15s: %.3f ms  %.0f TFLOP/s (NHWC kernel + reduction)" % (name, ms, fl / ms / 1e9))
 
 
+def bench_attnbwd():
+    """Attention backward at the stage-2 latent (B = 2, N = 80 x 80 tokens): the fused kernel against the materialised N^2 form."""
+    from glare_amd import train_ops as T
+    Bt, N, C = 2, 6400, 512
+    q = (torch.randn(Bt, N, C, device=DEV) * 0.06).to(torch.bfloat16)
+    k, v, do = [torch.randn(Bt, N, C, device=DEV).to(torch.bfloat16) for _ in range(3)]
+    vt = T.transpose(v, (N + 63) // 64 * 64)
+    lse = torch.empty(Bt, N, dtype=torch.float32, device=DEV)
+    o = ops.attention_d512(q, k, vt, N, lse=lse)
+    fl = 5 * 2.0 * Bt * N * N * C
+    ms = timeit(lambda: T.attention_backward_fused(q, k, v, o, do, lse))
+    ms_old = timeit(lambda: T.attention_backward(q, k, v, o, do))
+    print("attnbwd B=%d N=%d d=512: fused %.3f ms  %.0f TFLOP/s algorithmic (5 products);  materialised %.3f ms" % (Bt, N, ms, fl / ms / 1e9, ms_old))
+
+
 def bench_vq():
     n = B * 105 * 155
     z = torch.randn(n, 3, device=DEV)
@@ -125,6 +140,6 @@ def bench_vq():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["attn", "conv", "gn", "dcn", "vq", "wgrad"]
+    which = sys.argv[1:] or ["attn", "conv", "gn", "dcn", "vq", "wgrad", "attnbwd"]
     for w in which:
         globals()["bench_" + w]()
