@@ -224,8 +224,8 @@ def test_fused_attention_backward_at_inference_size_matches_the_materialised_for
     o = ops.attention_d512(q, k, T.transpose(v, (N + 63) // 64 * 64), N, lse=lse)
     fused = T.attention_backward_fused(q, k, v, o, do, lse)
     ref = T.attention_backward(q, k, v, o, do)
-    for a, b_, name in zip(fused, ref, ("dq", "dk", "dv")):
-        within(_rel(a, b_), 8e-3, tag=name)      # both round P / dS to bf16; the materialised form also rounds S-derived tiles
+    for a, b_, name, tol in zip(fused, ref, ("dq", "dk", "dv"), (7e-3, 7e-3, 5.5e-4)):   # measured 3.57e-03 / 3.56e-03 / 2.79e-04
+        within(_rel(a, b_), tol, tag=name)       # both round P / dS to bf16, in different places
     again = T.attention_backward_fused(q, k, v, o, do, lse)
     assert all(torch.equal(a, b_) for a, b_ in zip(fused, again))
 
