@@ -685,14 +685,14 @@ def test_conv3x3_weight_gradient_from_nhwc_operands(B, H, W, cin, cout, pitch, o
     xr = xw[..., off:off + cin].float().permute(0, 3, 1, 2).contiguous()
     gr = gy.float().permute(0, 3, 1, 2).contiguous()
     ref = torch.nn.grad.conv2d_weight(xr, (cout, cin, 3, 3), gr, padding=1)
-    within(_rel(dw, ref), 2e-6, tag="dw")
-    within(_rel(db, gr.sum(dim=(0, 2, 3))), 2e-6, tag="db")
+    within(_rel(dw, ref), 5.2e-7, tag="dw")                        # measured 2.57e-07 (max over the cases)
+    within(_rel(db, gr.sum(dim=(0, 2, 3))), 8.4e-8, tag="db")      # measured 4.17e-08
     again = T.conv3x3_weight_grad(xw.to(_dev()), gy.to(_dev()), cout, cin=cin, in_off=off)
     assert torch.equal(again[0], dw) and torch.equal(again[1], db)     # fixed summation order: bit-reproducible
     # the 1x1 filter on the same operands (no halo, one tap)
     dw1, db1 = T.conv1x1_weight_grad(xw.to(_dev()), gy.to(_dev()), cout, cin=cin, in_off=off)
-    within(_rel(dw1, torch.nn.grad.conv2d_weight(xr, (cout, cin, 1, 1), gr)), 2e-6, tag="dw1")
-    within(_rel(db1, gr.sum(dim=(0, 2, 3))), 2e-6, tag="db1")
+    within(_rel(dw1, torch.nn.grad.conv2d_weight(xr, (cout, cin, 1, 1), gr)), 3.7e-7, tag="dw1")   # measured 1.83e-07
+    within(_rel(db1, gr.sum(dim=(0, 2, 3))), 8.1e-8, tag="db1")                                     # measured 4.04e-08
 
 
 @pytest.mark.parametrize("ks", [1, 3])
@@ -716,8 +716,8 @@ def test_conv_weight_gradient_groups(ks):
         ref = torch.nn.grad.conv2d_weight(xr, (cout, cin, ks, ks), gr, padding=ks // 2)          # [co, ci, ty, tx]
         ref_t = ref.permute(2, 3, 1, 0).reshape(ks * ks * cin, cout)                            # [(ty, tx, ci), co]
         for o in (out, outb):
-            within(_rel(o[k, :-1], ref_t), 2e-6)
-            within(_rel(o[k, -1], gr.sum(dim=(0, 2, 3))), 2e-6)
+            within(_rel(o[k, :-1], ref_t), 2.4e-7)                        # measured 1.19e-07
+            within(_rel(o[k, -1], gr.sum(dim=(0, 2, 3))), 1e-7)           # measured 0 (one split: the sums are exact here)
     assert torch.equal(out, outb)
 
 
