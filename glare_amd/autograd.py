@@ -35,7 +35,7 @@ def _grad_bf16(g, y, act, cout):
 
 def _data_grad(g16, weight, cout, stride, upsample, out_f32=False):
     """dx of a conv as a stride-1 conv of the (dilated) gradient with the flipped, transposed filter."""
-    pc = ops.PackedConv(weight, dgrad_pad=g16.shape[-1])     # flip / transpose / channel pad happen inside the pack kernel
+    pc = ops.packed_for(weight, dgrad_pad=g16.shape[-1])     # flip / transpose / channel pad happen inside the pack kernel
     mode = ops.OUT_NHWC_F32 if out_f32 else ops.OUT_NHWC_BF16
     if stride == 2:
         return ops.conv2d(T.dilate2(g16), pc, out_mode=mode)
@@ -49,7 +49,7 @@ class Conv2dFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual, x2, stride, upsample, act, out_f32):
-        pc = ops.PackedConv(weight, bias)
+        pc = ops.packed_for(weight, bias)
         y = ops.conv2d(x, pc, x2=x2, stride=stride, upsample=upsample, act=act, residual=residual,
                        out_mode=ops.OUT_NHWC_F32 if out_f32 else ops.OUT_NHWC_BF16)
         ctx.cfg = (stride, upsample, act, bias is not None, residual is not None, x2 is not None)

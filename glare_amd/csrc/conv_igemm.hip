@@ -447,13 +447,8 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
 // [co_tile][stage][tap][kstep][khalf][TN][8], zero-filled outside Cout / Cin.
 // dgrad != 0: `w` is the FORWARD filter [Cin_real][Cout][KS][KS] of which the data-gradient filter is wanted
 // (w'[co][ci][tap] = w[ci][co][KK-1-tap], input channels ci >= Cin_real zero): no flip/transpose/pad pass on the host.
-// blockIdx.y = filter of a batch of equally shaped filters (consecutive in `w`, consecutive packed images in `out`).
-__global__ void pack_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin, int KS,
-                                   int TN, int KSTEPS, int n_stages, long long total, int dgrad, int Cin_real) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  w += (size_t)blockIdx.y * (dgrad ? (size_t)Cin_real * Cout : (size_t)Cout * Cin) * KS * KS;
-  out += (size_t)blockIdx.y * total;
+__device__ __forceinline__ void pack_weight_elem(const float* __restrict__ w, bf16_t* __restrict__ out, long long i, int Cout, int Cin,
+                                                 int KS, int TN, int KSTEPS, int n_stages, int dgrad, int Cin_real) {
   long long t = i;
   const int e = t % 8; t /= 8;
   const int n = t % TN; t /= TN;
@@ -471,6 +466,35 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, bf16_t* __restri
     v = w[((size_t)co * Cin + ci) * KS * KS + tap];
   }
   out[i] = f2bf(v);
+}
+
+// blockIdx.y = filter of a batch of equally shaped filters (consecutive in `w`, consecutive packed images in `out`).
+__global__ void pack_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin, int KS,
+                                   int TN, int KSTEPS, int n_stages, long long total, int dgrad, int Cin_real) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  w += (size_t)blockIdx.y * (dgrad ? (size_t)Cin_real * Cout : (size_t)Cout * Cin) * KS * KS;
+  out += (size_t)blockIdx.y * total;
+  pack_weight_elem(w, out, i, Cout, Cin, KS, TN, KSTEPS, n_stages, dgrad, Cin_real);
+}
+
+// Many filters of DIFFERENT shapes in one launch (the trainable convs of a training step, re-packed after the optimizer update):
+// block b belongs to the last job whose block_begin <= b.
+__global__ void pack_weight_multi_kernel(const glare_pack_job* __restrict__ jobs, int n_jobs) {
+  int lo = 0, hi = n_jobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].block_begin <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const glare_pack_job j = jobs[lo];
+  const long long i = ((long long)blockIdx.x - j.block_begin) * 256 + threadIdx.x;
+  if (i >= j.total) return;
+  if (j.kind == GLARE_PACK_PLAIN_BF16) {
+    static_cast<bf16_t*>(j.out)[i] = f2bf(j.w[i]);
+    return;
+  }
+  pack_weight_elem(j.w, static_cast<bf16_t*>(j.out), i, j.cout, j.cin, j.ksize, j.tn, j.ksteps, j.n_stages, j.kind == GLARE_PACK_DGRAD,
+                   j.cin_real);
 }
 
 // Sub-pixel upsample filters: [phase = a*2+b][co_tile][stage][tap = r*2+c][khalf][TN][8] (KSTEPS = 1), where tap (r, c)
@@ -603,6 +627,34 @@ extern "C" int glare_conv2d_pack_weight_upsample(const float* w_oihw, int cout, 
   const Variant v = pick_variant(3, cout);
   hipLaunchKernelGGL(pack_weight_subpix_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      w_oihw, (bf16_t*)packed_bf16, cout, cin_total, v.tn, (cin_total + 15) / 16, (cout + v.tn - 1) / v.tn, total);
+  return glare_launch_status();
+}
+
+extern "C" int glare_conv2d_pack_job_init(glare_pack_job* job, int kind, const float* w, int cout, int cin, int ksize, int dgrad_cout_padded,
+                                          void* packed) {
+  if (!job || !w || !packed || cout <= 0 || cin <= 0) return GLARE_ERR_INVALID;
+  job->w = w; job->out = packed; job->kind = kind; job->block_begin = 0;
+  if (kind == GLARE_PACK_PLAIN_BF16) {   // the weight-stationary 1x1 kernel's filter: bf16 [cout][cin]
+    job->cout = cout; job->cin = cin; job->ksize = 1; job->tn = job->ksteps = job->n_stages = 0; job->cin_real = cin;
+    job->total = (long long)cout * cin;
+    return GLARE_OK;
+  }
+  const bool dg = kind == GLARE_PACK_DGRAD;
+  if (kind != GLARE_PACK_FORWARD && !dg) return GLARE_ERR_INVALID;
+  if (dg && (dgrad_cout_padded < cout || (dgrad_cout_padded % 8))) return GLARE_ERR_INVALID;
+  const int oc = dg ? cin : cout, ic = dg ? dgrad_cout_padded : cin;   // the packed conv's output / input channels
+  const long long total = glare_conv2d_packed_weight_elems(oc, ic, ksize);
+  if (total <= 0) return GLARE_ERR_UNSUPPORTED;
+  const Variant v = pick_variant(ksize, oc);
+  const int kc = 16 * v.ksteps;
+  job->cout = oc; job->cin = ic; job->ksize = ksize; job->tn = v.tn; job->ksteps = v.ksteps; job->n_stages = (ic + kc - 1) / kc;
+  job->cin_real = dg ? cout : ic; job->total = total;
+  return GLARE_OK;
+}
+
+extern "C" int glare_conv2d_pack_multi(const glare_pack_job* jobs_device, int n_jobs, long long total_blocks, glare_stream_t stream) {
+  if (!jobs_device || n_jobs <= 0 || total_blocks <= 0 || total_blocks > 0x7fffffffLL) return GLARE_ERR_INVALID;
+  hipLaunchKernelGGL(pack_weight_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_device, n_jobs);
   return glare_launch_status();
 }
 

@@ -114,6 +114,84 @@ def packed_conv_batch(weights, biases=None, dgrad_pad=None):
     return out
 
 
+class _PackJob(ctypes.Structure):   # glare_pack_job (include/glare_hip.h)
+    _fields_ = [("w", ctypes.c_void_p), ("out", ctypes.c_void_p), ("total", ctypes.c_longlong), ("block_begin", ctypes.c_longlong),
+                ("cout", ctypes.c_int), ("cin", ctypes.c_int), ("ksize", ctypes.c_int), ("tn", ctypes.c_int), ("ksteps", ctypes.c_int),
+                ("n_stages", ctypes.c_int), ("cin_real", ctypes.c_int), ("kind", ctypes.c_int)]
+
+
+class PackCache:
+    """Packed filters of the TRAINABLE convs kept across training steps.  The autograd conv nodes ask for (weight, dgrad_pad)
+    through packed_for(); a weight that lives in one of `params` (the flat optimizer buffers: stable addresses) is packed on first
+    use into a buffer that stays, and entering the context -- the trainer does at the start of every step's forward, so optimizer
+    updates AND checkpoint loads are both seen -- re-packs ALL of them in ONE launch (glare_conv2d_pack_multi).  Filters derived
+    from parameters on the fly (the flow's folded filters) are not cached: their tensors are new every step."""
+
+    def __init__(self, params):
+        self.ptrs = {p.data_ptr(): tuple(p.shape) for p in params if p.dim() == 4}
+        self.entries = {}          # (data_ptr, dgrad_pad) -> PackedConv
+        self.table = None          # (device job table, n_jobs, total_blocks)
+
+    def __enter__(self):
+        global PACK_CACHE
+        self._prev, PACK_CACHE = PACK_CACHE, self
+        self.refresh()
+        return self
+
+    def __exit__(self, *exc):
+        global PACK_CACHE
+        PACK_CACHE = self._prev
+
+    def get(self, weight, bias, dgrad_pad):
+        key = (weight.data_ptr(), dgrad_pad)
+        pc = self.entries.get(key)
+        if pc is None:
+            if self.ptrs.get(weight.data_ptr()) != tuple(weight.shape) or not weight.is_contiguous() or weight.dtype != torch.float32:
+                return None
+            pc = PackedConv(weight, None, dgrad_pad=dgrad_pad)
+            pc._src = weight.detach()
+            self.entries[key] = pc
+            self.table = None
+        pc.bias = None if bias is None else bias.detach().float().contiguous()
+        return pc
+
+    def refresh(self):
+        if not self.entries:
+            return
+        if self.table is None:
+            lib = _lib.lib()
+            jobs, begin = [], 0
+            for (_, dgrad_pad), pc in self.entries.items():
+                cout, cin, kh, _ = pc._src.shape
+                kinds = [(1, pc.packed)] if dgrad_pad is not None else [(0, pc.packed)] + ([(2, pc.w16)] if pc.w16 is not None else [])
+                for kind, dst in kinds:
+                    j = _PackJob()
+                    check(lib.glare_conv2d_pack_job_init(ctypes.byref(j), _i(kind), ptr(pc._src), _i(cout), _i(cin), _i(kh),
+                                                         _i(dgrad_pad or 0), ptr(dst)), "glare_conv2d_pack_job_init")
+                    j.block_begin = begin
+                    begin += (j.total + 255) // 256
+                    jobs.append(j)
+            arr = (_PackJob * len(jobs))(*jobs)
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            dev = next(iter(self.entries.values())).packed.device
+            self.table = (host.to(dev), len(jobs), begin)
+        tab, n, blocks = self.table
+        check(_lib.lib().glare_conv2d_pack_multi(ptr(tab), _i(n), _ll(blocks), stream_handle()), "glare_conv2d_pack_multi")
+
+
+PACK_CACHE = None   # the PackCache of the training step in progress (None: every packed_for() packs)
+
+
+def packed_for(weight, bias=None, dgrad_pad=None):
+    """The packed image of a conv filter for the autograd nodes: from the step's PackCache when the filter is a trainable parameter
+    it knows, packed on the spot otherwise."""
+    if PACK_CACHE is not None:
+        pc = PACK_CACHE.get(weight, bias, dgrad_pad)
+        if pc is not None:
+            return pc
+    return PackedConv(weight, bias, dgrad_pad=dgrad_pad)
+
+
 # Measurement hook (tools/train_bench.py flops): when a dict, every MFMA launch family adds its algorithmic FLOPs (2 x MACs) to
 # FLOP_COUNTER[family]; None (the default) counts nothing.
 FLOP_COUNTER = None

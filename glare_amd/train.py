@@ -14,6 +14,7 @@ gather through GPU 0 (LLFlow_model.py:72-75).
 import torch
 import torch.distributed as dist
 
+from . import ops
 from . import train_ops as T
 
 
@@ -154,6 +155,7 @@ class Stage2Trainer:
         self.opt = FlatAdam([FlatGroup(other, lr_G, weight_decay_G),
                              FlatGroup(rrdb if train_rrdb else [], lr_G if lr_RRDB is None else lr_RRDB, 1e-5,
                                        device=other[0].device)], device_state=device_state)
+        self.pack_cache = ops.PackCache([p for p in netG.parameters() if p.requires_grad])   # packed filters live across steps
 
     def draw_branch(self):
         """The step's one host-side random decision (LLFlowVQGAN_arch.py:95): is the Gaussian's mean the ground truth?"""
@@ -170,9 +172,10 @@ class Stage2Trainer:
         with torch.no_grad():
             gt_latent = self.net_hq.encode_nhwc(gt_img)            # LLFlow_model.py:200-201
         self.opt.zero_grad()
-        nll = self.netG.train_nll(gt_latent, lr_img, mean_is_gt=flag)   # :215
-        loss = nll.mean()
-        loss.backward()                                            # :236
+        with self.pack_cache:
+            nll = self.netG.train_nll(gt_latent, lr_img, mean_is_gt=flag)   # :215
+            loss = nll.mean()
+            loss.backward()                                        # :236
         self.opt.step()                                            # :240
         self.netG.invalidate()                                     # packed inference weights are stale now
         return loss.detach()
@@ -201,6 +204,7 @@ class Stage3Trainer:
         # conditional encoder is frozen (fix_modules), so its group is empty -- kept for `.state` file compatibility
         self.opt = FlatAdam([FlatGroup(dd, lr_G, weight_decay_G), FlatGroup([], lr_G, 1e-5, device=dd[0].device)],
                             device_state=device_state)
+        self.pack_cache = ops.PackCache(dd)
 
     def step(self, gt_img, lr_img):
         """gt_img: fp32 NCHW in [0,1]; lr_img: fp32 NCHW low-light crop (log domain).  Returns the loss."""
@@ -213,9 +217,10 @@ class Stage3Trainer:
             lat = G.flowUpsamplerNet.decode_nhwc(enc["color_map"], enc["cond_feat"])
             _, _, feats = self.net_hq.decode_nhwc(lat, want_image=False)
         self.opt.zero_grad()
-        rec = G.deformable_decoder.train_nhwc(lat, feats, enc["mid_feat"], whole_batch_mean=True)
-        loss, self.last_terms = stage3_loss(rec, gt_img, self.perceptual, self.use_msssim)
-        loss.backward()
+        with self.pack_cache:
+            rec = G.deformable_decoder.train_nhwc(lat, feats, enc["mid_feat"], whole_batch_mean=True)
+            loss, self.last_terms = stage3_loss(rec, gt_img, self.perceptual, self.use_msssim)
+            loss.backward()
         self.opt.step()
         G.deformable_decoder.invalidate()   # only its packed inference weights went stale; the frozen nets keep theirs
         return loss.detach()

@@ -112,6 +112,24 @@ int glare_conv2d_pack_weight(const float* w_oihw, int cout, int cin_total, int k
  * cout_padded input and cin output channels (glare_conv2d_packed_weight_elems(cin, cout_padded, ksize) elements). */
 int glare_conv2d_pack_weight_dgrad(const float* w_oihw, int cout, int cin, int ksize, int cout_padded, void* packed_bf16,
                                    glare_stream_t stream);
+/* Filters of DIFFERENT shapes packed in ONE launch: the trainable convs of a training step, whose packed images live across steps and
+ * are refreshed after the optimizer update (the reference re-reads its fp32 weights through cuDNN every step; here the MFMA kernels
+ * read stage-ordered bf16 images).  A job = one packed image: glare_conv2d_pack_job_init fills its geometry (kind FORWARD as
+ * glare_conv2d_pack_weight, DGRAD as glare_conv2d_pack_weight_dgrad with dgrad_cout_padded, PLAIN_BF16 as
+ * glare_conv1x1_ws_pack_weight); the caller sets block_begin = sum over the earlier jobs of ceil(total / 256), copies the table to
+ * the device and launches it with the total block count. */
+enum { GLARE_PACK_FORWARD = 0, GLARE_PACK_DGRAD = 1, GLARE_PACK_PLAIN_BF16 = 2 };
+typedef struct glare_pack_job {
+  const float* w;          /* fp32 OIHW filter */
+  void* out;               /* packed bf16 image */
+  long long total;         /* elements of the packed image */
+  long long block_begin;   /* first 256-element block of this job in the launch */
+  int cout, cin, ksize;    /* of the PACKED conv (DGRAD: outputs = the forward conv's inputs) */
+  int tn, ksteps, n_stages, cin_real, kind;
+} glare_pack_job;
+int glare_conv2d_pack_job_init(glare_pack_job* job, int kind, const float* w_oihw, int cout, int cin, int ksize, int dgrad_cout_padded,
+                               void* packed_bf16);
+int glare_conv2d_pack_multi(const glare_pack_job* jobs_device, int n_jobs, long long total_blocks, glare_stream_t stream);
 /* `batch` filters of one shape ([batch][cout][cin][k][k] fp32, consecutive) packed in one launch into consecutive packed images:
  * dgrad_cout_padded = 0 as glare_conv2d_pack_weight, > 0 as glare_conv2d_pack_weight_dgrad with that padding (the per-step convs
  * of the flow's coupling nets, FlowAffineCouplingsAblation.py:117-160: 24 steps x 4 convs of two shapes). */
