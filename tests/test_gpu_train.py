@@ -230,6 +230,30 @@ def test_fused_attention_backward_at_inference_size_matches_the_materialised_for
     assert all(torch.equal(a, b_) for a, b_ in zip(fused, again))
 
 
+def test_pack_cache_repacks_every_kind_of_filter_in_one_launch():
+    """ops.PackCache: forward, data-gradient and weight-stationary 1x1 images of several shapes, refreshed by ONE multi-shape launch
+    after the weights changed, are bit-identical to freshly packed ones; tensors it does not own are packed on the spot."""
+    from glare_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    shapes = [(128, 64, 3), (8, 64, 3), (512, 512, 1), (64, 256, 1), (136, 72, 3)]
+    params = [torch.randn(co, ci, k, k, generator=g).to(_dev()) for co, ci, k in shapes]
+    cache = ops.PackCache(params)
+    with cache:
+        first = [(ops.packed_for(w), ops.packed_for(w, dgrad_pad=(w.shape[0] + 7) // 8 * 8)) for w in params]
+        other = torch.randn(16, 16, 3, 3, generator=g).to(_dev())
+        assert ops.packed_for(other) is not ops.packed_for(other)            # not a registered parameter: no caching
+    for w in params:
+        w.mul_(-0.5).add_(0.25)                                              # "the optimizer step"
+    with cache:                                                              # entering refreshes all images in one launch
+        for w, (pf, pd) in zip(params, first):
+            assert ops.packed_for(w) is pf and ops.packed_for(w, dgrad_pad=(w.shape[0] + 7) // 8 * 8) is pd
+            ref_f, ref_d = ops.PackedConv(w), ops.PackedConv(w, dgrad_pad=(w.shape[0] + 7) // 8 * 8)
+            assert torch.equal(pf.packed, ref_f.packed) and torch.equal(pd.packed, ref_d.packed)
+            assert (pf.w16 is None) == (ref_f.w16 is None) and (pf.w16 is None or torch.equal(pf.w16, ref_f.w16))
+    assert cache.table[1] == sum(2 + (pf.w16 is not None) for pf, _ in first)
+
+
 def test_adam_matches_torch():
     from glare_amd import train_ops as T
 
