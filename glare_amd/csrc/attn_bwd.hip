@@ -33,6 +33,10 @@
 
 #include "common.h"
 
+#ifndef ATTNBWD_ABL
+#define ATTNBWD_ABL 0   // timing ablations only (wrong results): 1 no tile DMA, 2 no score exchange, 4 no exp / statistics, 8 no output product
+#endif
+
 namespace {
 
 constexpr int HD = 512;
@@ -115,15 +119,16 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const BwdParams p) {
   int dvo[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) dvo[i] = (lane ^ ((wave << 2) | i)) * 16;
-  auto issue = [&](int tile, int buf) {
+  auto issue_row = [&](int tile, int buf, int i) {   // row wave + 4 i of both tiles
     char* d1 = smem + buf * 2 * TILE_B;
+    const int row = wave + 4 * i;
+    const int so = (tile * TB + row) * (HD * 2);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (__attribute__((address_space(3))) void*)(d1 + row * 1024), 16, dvo[i & 3], so, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (__attribute__((address_space(3))) void*)(d1 + TILE_B + row * 1024), 16, dvo[i & 3], so, 0, 0);
+  };
+  auto issue = [&](int tile, int buf) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int row = wave + 4 * i;
-      const int so = (tile * TB + row) * (HD * 2);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (__attribute__((address_space(3))) void*)(d1 + row * 1024), 16, dvo[i & 3], so, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (__attribute__((address_space(3))) void*)(d1 + TILE_B + row * 1024), 16, dvo[i & 3], so, 0, 0);
-    }
+    for (int i = 0; i < 8; ++i) issue_row(tile, buf, i);
   };
 
   // ---- fragment addresses
@@ -173,24 +178,40 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const BwdParams p) {
       if (tt + 1 < n_tiles) load_stats(tt + 1);
       __builtin_amdgcn_sched_barrier(0);
     }
+#if !(ATTNBWD_ABL & 1)
+    // all 16 pieces here: spreading them over the MFMA groups of the score loop measured the same (1.46 vs 1.44 ms) -- with one
+    // wave per SIMD at ~30 % of the MFMA rate the wave's in-order issue stream, not the matrix pipe, is what a piece delays
     if (tt + 1 < n_tiles) issue(tt + 1, BUF ^ 1);
+#endif
 
     // ---- partial score tiles over this wave's 256 channels
     f32x16 x, y;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { x[r] = 0.f; y[r] = 0.f; }
+    // fragment reads one group (2 k-steps) ahead of the MFMAs that consume them
+    bf16x8 fa[2][2][2];   // [set][k-step of the group][T1 | T2]
+    auto ldg = [&](int g, bf16x8(&f)[2][2]) {
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      const char* src = smem + BUF * 2 * TILE_B + (ks >> 3) * 256 + kofs[ks & 7];
-      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(src);
-      x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, r1f[ks], x, 0, 0, 0);
-      if (WANT_DS) {
-        const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(src + TILE_B);
-        y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, r2f[ks], y, 0, 0, 0);
+      for (int j = 0; j < 2; ++j) {
+        const int ks = 2 * g + j;
+        const char* src = smem + BUF * 2 * TILE_B + (ks >> 3) * 256 + kofs[ks & 7];
+        f[j][0] = *reinterpret_cast<const bf16x8*>(src);
+        if (WANT_DS) f[j][1] = *reinterpret_cast<const bf16x8*>(src + TILE_B);
       }
-      if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bounds how far ahead the fragment reads are hoisted (registers)
+    };
+    ldg(0, fa[0]);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      if (g + 1 < 8) ldg(g + 1, fa[(g + 1) & 1]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g & 1][j][0], r1f[2 * g + j], x, 0, 0, 0);
+        if (WANT_DS) y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g & 1][j][1], r2f[2 * g + j], y, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     // ---- publish the partial, add the partner's
+#if !(ATTNBWD_ABL & 2)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       xbuf[((wave * 2 + 0) * 4 + i) * 64 + lane] = f32x4{x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3]};
@@ -209,6 +230,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const BwdParams p) {
         for (int e = 0; e < 4; ++e) y[4 * i + e] += yp[e];
       }
     }
+#endif
     // ---- P / dS as bf16 B fragments: k-step e covers registers 8 e .. 8 e + 7 = streamed rows 16 e + 8 hi + 0..7
     bf16x8 pf[2];
 #pragma unroll
@@ -222,11 +244,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const BwdParams p) {
           const int r = 8 * e + 2 * j + u, rr = 2 * j + u;                       // rr: row 0..7 inside the lane's 8-row run
           const int t = tt * TB + 16 * e + 8 * hi + rr;
           float Lq = Lr, Dq = Dr;
-          if (QS) {
+          if (QS && !(ATTNBWD_ABL & 4)) {
             Lq = __shfl(Lm, 16 * e + 8 * hi + rr, 64);
             Dq = WANT_DS ? __shfl(Dm, 16 * e + 8 * hi + rr, 64) : 0.f;
           }
+#if ATTNBWD_ABL & 4
+          const float pe = x[r] - Lq;
+#else
           const float pe = t < p.N ? __builtin_amdgcn_exp2f(x[r] - Lq) : 0.f;
+#endif
           v[u] = WANT_DS ? pe * (y[r] - Dq) * p.ln2 : pe;
         }
         w[j] = pack_bf2(v[0], v[1]);
@@ -242,15 +268,19 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const BwdParams p) {
         for (int h = 0; h < 2; ++h)
           tr_read(f[2 * e + h], tofs[mt & 3][h] + (BUF * 2 * TILE_B + e * 16 * 1024 + (mt >> 2) * 256));
     };
+#if ATTNBWD_ABL & 8
+    asm volatile("" ::"v"(pf[0]), "v"(pf[1]));
+#else
     rd(0, tf[0]);
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
+    for (int mt = 0; mt < 8; ++mt) {   // (two tiles ahead measured the same)
       if (mt + 1 < 8) { rd(mt + 1, tf[(mt + 1) & 1]); lgkm_wait<4>(); } else { lgkm_wait<0>(); }
       u32x2(&f)[4] = tf[mt & 1];
       pin(f[0]); pin(f[1]); pin(f[2]); pin(f[3]);
       o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(f[0], f[1]), pf[0], o[mt], 0, 0, 0);
       o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(f[2], f[3]), pf[1], o[mt], 0, 0, 0);
     }
+#endif
   };
 
   for (int tt = 0; tt < n_tiles; tt += 2) {
