@@ -478,6 +478,7 @@ def attention_d512(q, k, v_t, N, ldq=None, ldk=None, out=None, key_splits=None, 
 
 def _attention_d512(q, k, v_t, N, ldq, ldk, out, key_splits, lse=None):
     B = v_t.shape[0]
+    count_flops("attn fwd", 4.0 * B * N * N * 512)
     ldq = q.shape[-1] if ldq is None else ldq
     ldk = k.shape[-1] if ldk is None else ldk
     if out is None:
@@ -515,6 +516,7 @@ def attention_kv512(q, kv, N, ldq=None, ldkv=None, out=None, key_splits=None):
     require_cuda(q, kv, out)
     assert q.dtype == kv.dtype == torch.bfloat16
     B = kv.shape[0]
+    count_flops("attn fwd", 4.0 * B * N * N * 512)
     ldq = q.shape[-1] if ldq is None else ldq
     ldkv = kv.shape[-1] if ldkv is None else ldkv
     if out is None:

@@ -271,6 +271,7 @@ def attention_backward_fused(q, k, v, o, do, lse, ln2_scale=0.6931471805599453):
     assert d == 512 and all(t.is_contiguous() and t.dtype == torch.bfloat16 for t in (q, k, v, o, do))
     assert lse.dtype == torch.float32 and lse.is_contiguous() and lse.numel() == B * N
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    _count_flops("attn bwd", 10.0 * B * N * N * d)     # the five products of the backward (the kernel recomputes two more)
     lib = _lib.lib()
     lib.glare_attention_d512_backward_workspace_bytes.restype = ctypes.c_size_t
     nws = lib.glare_attention_d512_backward_workspace_bytes(_i(B), _i(N))

@@ -6,7 +6,8 @@ import re
 import sys
 
 PEAK = 2500.0   # dense bf16 MFMA peak, TFLOP/s (MI355X_MICROARCH.md)
-FAMILIES = {"gemm_nt": [r"^gemm_nt_kernel"], "wgrad k3": [r"^wgrad_kernel<3>"], "wgrad k1": [r"^wgrad_kernel<1>"],
+FAMILIES = {"attn fwd": [r"^attn_fwd_kernel", r"^attn_kv_fwd_kernel", r"^attn_combine_kernel"], "attn bwd": [r"^attn_bwd_kernel", r"^attn_bwd_dsum"],
+            "gemm_nt": [r"^gemm_nt_kernel"], "wgrad k3": [r"^wgrad_kernel<3>"], "wgrad k1": [r"^wgrad_kernel<1>"],
             "conv k3": [r"^conv_igemm k3", r"^conv_igemm k2"], "conv k1": [r"^conv_igemm k1", r"^conv1x1_ws_kernel"]}
 
 
