@@ -33,10 +33,19 @@ def _grad_bf16(g, y, act, cout):
     return g
 
 
+def _tile(B, OH, OW, cout, k):
+    """Output-channel tile of a training conv: the crops are small, a 3x3 conv with the default 128-wide tile often has fewer
+    workgroups than the chip has slots (ops.conv_cout_tile); 1x1 convs keep their default (weight-stationary kernel)."""
+    return ops.conv_cout_tile(B, OH, OW, cout) if k == 3 else 0
+
+
 def _data_grad(g16, weight, cout, stride, upsample, out_f32=False):
     """dx of a conv as a stride-1 conv of the (dilated) gradient with the flipped, transposed filter."""
-    pc = ops.packed_for(weight, dgrad_pad=g16.shape[-1])     # flip / transpose / channel pad happen inside the pack kernel
-    mode = ops.OUT_NHWC_F32 if out_f32 else ops.OUT_NHWC_BF16
+    B, gh, gw, _ = g16.shape
+    if stride == 2:
+        gh, gw = 2 * gh, 2 * gw
+    pc = ops.packed_for(weight, dgrad_pad=g16.shape[-1], cout_tile=_tile(B, gh, gw, weight.shape[1], weight.shape[2]))
+    mode = ops.OUT_NHWC_F32 if out_f32 else ops.OUT_NHWC_BF16                # (flip / transpose / channel pad inside the pack kernel)
     if stride == 2:
         return ops.conv2d(T.dilate2(g16), pc, out_mode=mode)
     dx = ops.conv2d(g16, pc, out_mode=mode)
@@ -49,7 +58,11 @@ class Conv2dFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual, x2, stride, upsample, act, out_f32):
-        pc = ops.packed_for(weight, bias)
+        B, H, W, _ = x.shape
+        OH, OW = (2 * H, 2 * W) if upsample else (H, W)
+        if stride == 2:
+            OH, OW = (OH + 1 - 3) // 2 + 1, (OW + 1 - 3) // 2 + 1
+        pc = ops.packed_for(weight, bias, cout_tile=_tile(B, OH, OW, weight.shape[0], weight.shape[2]))
         y = ops.conv2d(x, pc, x2=x2, stride=stride, upsample=upsample, act=act, residual=residual,
                        out_mode=ops.OUT_NHWC_F32 if out_f32 else ops.OUT_NHWC_BF16)
         ctx.cfg = (stride, upsample, act, bias is not None, residual is not None, x2 is not None)

@@ -564,9 +564,10 @@ struct Variant {
 // Measured and dropped: a 256-cout tile for the 1x1 convs (wave 128 px x 128 co, 256 accumulator registers, one workgroup per
 // CU to halve the DMA pieces per MFMA): 250-267 TFLOP/s against 435-444 for the 128-cout tile at 512 -> 512/1024 -- like the
 // 3x3 kernel, the 1x1 lives on the three workgroups per CU that cover its DMA issue stalls.
-Variant pick_variant(int ksize, int cout) {
+Variant pick_variant(int ksize, int cout, int cout_tile = 0) {
   Variant v;
   v.tn = cout > 64 ? 128 : (cout > 32 ? 64 : 32);
+  if ((cout_tile == 32 || cout_tile == 64) && cout_tile < v.tn) v.tn = cout_tile;   // a narrower tile than the default: more workgroups
   v.ksteps = ksize == 1 ? 2 : 1;
   return v;
 }
@@ -593,12 +594,30 @@ int launch(const ConvParams& p_in, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" long long glare_conv2d_packed_weight_elems(int cout, int cin_total, int ksize) {
+extern "C" long long glare_conv2d_packed_weight_elems_tile(int cout, int cin_total, int ksize, int cout_tile) {
   if (cout <= 0 || cin_total <= 0 || (ksize != 1 && ksize != 3)) return GLARE_ERR_INVALID;
-  const Variant v = pick_variant(ksize, cout);
+  const Variant v = pick_variant(ksize, cout, cout_tile);
   const int kc = 16 * v.ksteps;
   const long long stages = (cin_total + kc - 1) / kc, co_tiles = (cout + v.tn - 1) / v.tn;
   return co_tiles * stages * ksize * ksize * v.ksteps * 2 * v.tn * 8;
+}
+
+extern "C" long long glare_conv2d_packed_weight_elems(int cout, int cin_total, int ksize) {
+  return glare_conv2d_packed_weight_elems_tile(cout, cin_total, ksize, 0);
+}
+
+// Workgroups of 8 x 32 output pixels x tile channels.  Measured on MI355X (tools/probes/conv_small_grid.py, 3x3, TFLOP/s with the
+// 128 / 64 / 32 tile): 128->128 @256x256 B=1 610 / 718 / 616; 256->256 @128x128 B=1 426 / 572 / 632; 512->512 @64x64 B=1 254 /
+// 336 / 412; 128->128 @320x320 B=2 800 / 880 / 710; 512->512 @80x80 B=2 669 / 729 / 645: the widest tile that still gives about
+// four workgroups per CU with 128, or 1.5 with 64.
+extern "C" int glare_conv2d_cout_tile(int B, int OH, int OW, int cout) {
+  if (B <= 0 || OH <= 0 || OW <= 0 || cout <= 0) return 0;
+  const int def = cout > 64 ? 128 : (cout > 32 ? 64 : 32);
+  if (def < 128) return def;                       // only the 128-wide default was measured against narrower tiles
+  const long long px = (long long)B * cdiv(OH, 8) * cdiv(OW, 32);
+  if (px * cdiv(cout, 128) >= 1024) return 128;
+  if (px * cdiv(cout, 64) >= 384) return 64;
+  return 32;
 }
 
 extern "C" int glare_conv2d_pack_weight(const float* w_oihw, int cout, int cin_total, int ksize, void* packed_bf16,
@@ -631,7 +650,7 @@ extern "C" int glare_conv2d_pack_weight_upsample(const float* w_oihw, int cout, 
 }
 
 extern "C" int glare_conv2d_pack_job_init(glare_pack_job* job, int kind, const float* w, int cout, int cin, int ksize, int dgrad_cout_padded,
-                                          void* packed) {
+                                          int cout_tile, void* packed) {
   if (!job || !w || !packed || cout <= 0 || cin <= 0) return GLARE_ERR_INVALID;
   job->w = w; job->out = packed; job->kind = kind; job->block_begin = 0;
   if (kind == GLARE_PACK_PLAIN_BF16) {   // the weight-stationary 1x1 kernel's filter: bf16 [cout][cin]
@@ -643,9 +662,9 @@ extern "C" int glare_conv2d_pack_job_init(glare_pack_job* job, int kind, const f
   if (kind != GLARE_PACK_FORWARD && !dg) return GLARE_ERR_INVALID;
   if (dg && (dgrad_cout_padded < cout || (dgrad_cout_padded % 8))) return GLARE_ERR_INVALID;
   const int oc = dg ? cin : cout, ic = dg ? dgrad_cout_padded : cin;   // the packed conv's output / input channels
-  const long long total = glare_conv2d_packed_weight_elems(oc, ic, ksize);
+  const long long total = glare_conv2d_packed_weight_elems_tile(oc, ic, ksize, cout_tile);
   if (total <= 0) return GLARE_ERR_UNSUPPORTED;
-  const Variant v = pick_variant(ksize, oc);
+  const Variant v = pick_variant(ksize, oc, cout_tile);
   const int kc = 16 * v.ksteps;
   job->cout = oc; job->cin = ic; job->ksize = ksize; job->tn = v.tn; job->ksteps = v.ksteps; job->n_stages = (ic + kc - 1) / kc;
   job->cin_real = dg ? cout : ic; job->total = total;
@@ -659,16 +678,16 @@ extern "C" int glare_conv2d_pack_multi(const glare_pack_job* jobs_device, int n_
 }
 
 extern "C" int glare_conv2d_pack_weight_batched(const float* w_boihw, int batch, int cout, int cin, int ksize, int dgrad_cout_padded,
-                                                void* packed_bf16, glare_stream_t stream) {
+                                                int cout_tile, void* packed_bf16, glare_stream_t stream) {
   // `batch` filters of one shape in one launch; dgrad_cout_padded = 0: forward filters (glare_conv2d_pack_weight), > 0: the
   // data-gradient filters (glare_conv2d_pack_weight_dgrad with that padding); packed images are consecutive
   if (!w_boihw || !packed_bf16 || batch <= 0 || batch > 65535 || cout <= 0 || cin <= 0) return GLARE_ERR_INVALID;
   const bool dg = dgrad_cout_padded > 0;
   if (dg && (dgrad_cout_padded < cout || (dgrad_cout_padded % 8))) return GLARE_ERR_INVALID;
   const int oc = dg ? cin : cout, ic = dg ? dgrad_cout_padded : cin;   // the packed conv's output / input channels
-  const long long total = glare_conv2d_packed_weight_elems(oc, ic, ksize);
+  const long long total = glare_conv2d_packed_weight_elems_tile(oc, ic, ksize, cout_tile);
   if (total <= 0) return GLARE_ERR_UNSUPPORTED;
-  const Variant v = pick_variant(ksize, oc);
+  const Variant v = pick_variant(ksize, oc, cout_tile);
   const int kc = 16 * v.ksteps;
   hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256), batch), dim3(256), 0, (hipStream_t)stream, w_boihw,
                      (bf16_t*)packed_bf16, oc, ic, ksize, v.tn, v.ksteps, (ic + kc - 1) / kc, total, dg ? 1 : 0, dg ? cout : ic);
@@ -727,7 +746,9 @@ extern "C" int glare_conv2d_bf16(const glare_conv_desc* d, glare_stream_t stream
   p.upsample = subpix ? 0 : d->upsample; p.act = d->act; p.out_mode = d->out_mode;
   p.plane_pitch = d->plane_pitch > 0 ? d->plane_pitch : (long long)p.OH * p.OW;
   if (p.plane_pitch < (long long)p.OH * p.OW) return GLARE_ERR_INVALID;
-  const Variant v = pick_variant(d->ksize, d->Cout);
+  if (d->cout_tile != 0 && (d->upsample == 2 || (d->cout_tile != 32 && d->cout_tile != 64 && d->cout_tile != 128))) return GLARE_ERR_INVALID;
+  const Variant v = pick_variant(d->ksize, d->Cout, d->cout_tile);
+  if (d->gn_partial && v.tn != 128) return GLARE_ERR_UNSUPPORTED;   // the fused statistics' partial layout is the 128-wide tile's
   const int kc = 16 * v.ksteps;
   // a stage must not straddle the two concatenated sources
   if (p.in1 && (p.Cin0 % kc)) return GLARE_ERR_UNSUPPORTED;

@@ -42,14 +42,16 @@ class ConvDesc(ctypes.Structure):
                 ("Cout", _i), ("out_pitch", _i), ("out_off", _i),
                 ("res_pitch", _i), ("res_off", _i),
                 ("ksize", _i), ("stride", _i), ("upsample", _i), ("act", _i), ("out_mode", _i),
-                ("plane_pitch", _ll), ("gn_partial", ctypes.c_void_p)]
+                ("plane_pitch", _ll), ("gn_partial", ctypes.c_void_p), ("cout_tile", _i)]
 
 
 class PackedConv:
     """A conv filter packed once for the MFMA kernel (weights bf16 stage-ordered, bias fp32)."""
 
-    def __init__(self, weight_oihw, bias=None, dgrad_pad=None, upsample_subpixel=False):
+    def __init__(self, weight_oihw, bias=None, dgrad_pad=None, upsample_subpixel=False, cout_tile=0):
         """dgrad_pad = P: pack the filter of the data-gradient conv (P >= cout input channels, cin outputs) instead.
+        cout_tile: 0 = the default output-channel tile for this cout, or 64 / 32 for launches too small to fill the chip with it
+        (conv_cout_tile(); the packed image is tile-specific and conv2d passes the tile on).
         upsample_subpixel: pack the four 2x2 sub-pixel filters of "nearest x2 upsample, then this 3x3 conv" (conv2d then runs
         desc.upsample = 2: 16 instead of 36 tap-MACs per source pixel)."""
         require_cuda(weight_oihw)
@@ -58,7 +60,12 @@ class PackedConv:
         assert kh == kw and kh in (1, 3)
         self.ksize = kh
         self.subpixel = bool(upsample_subpixel)
+        self.cout_tile = 0
         lib = _lib.lib()
+        if cout_tile and not self.subpixel:
+            one = packed_conv_batch(w.unsqueeze(0), None if bias is None else bias.detach().float().reshape(1, -1), dgrad_pad, cout_tile)[0]
+            self.cout, self.cin, self.packed, self.bias, self.w16, self.cout_tile = one.cout, one.cin, one.packed, one.bias, None, cout_tile
+            return
         if self.subpixel:
             assert kh == 3 and dgrad_pad is None
             self.cout, self.cin = cout, cin
@@ -89,26 +96,26 @@ class PackedConv:
             check(lib.glare_conv1x1_ws_pack_weight(ptr(w), _i(cout), _i(cin), ptr(self.w16), stream_handle()), "glare_conv1x1_ws_pack_weight")
 
 
-def packed_conv_batch(weights, biases=None, dgrad_pad=None):
+def packed_conv_batch(weights, biases=None, dgrad_pad=None, cout_tile=0):
     """weights fp32 [n, cout, cin, k, k] (n filters of one shape) -> n PackedConv whose packed images come from ONE launch.
-    biases: fp32 [n, cout] or None; dgrad_pad as in PackedConv."""
+    biases: fp32 [n, cout] or None; dgrad_pad, cout_tile as in PackedConv."""
     require_cuda(weights, biases)
     w = weights.detach().float().contiguous()
     n, cout, cin, kh, kw = w.shape
     assert kh == kw and kh in (1, 3)
     lib = _lib.lib()
-    lib.glare_conv2d_packed_weight_elems.restype = _ll
+    lib.glare_conv2d_packed_weight_elems_tile.restype = _ll
     oc, ic = (cout, cin) if dgrad_pad is None else (cin, dgrad_pad)
-    elems = lib.glare_conv2d_packed_weight_elems(_i(oc), _i(ic), _i(kh))
+    elems = lib.glare_conv2d_packed_weight_elems_tile(_i(oc), _i(ic), _i(kh), _i(cout_tile))
     assert elems > 0
     packed = torch.empty(n, elems, dtype=torch.bfloat16, device=w.device)
     check(lib.glare_conv2d_pack_weight_batched(ptr(w), _i(n), _i(cout), _i(cin), _i(kh), _i(0 if dgrad_pad is None else dgrad_pad),
-                                               ptr(packed), stream_handle()), "glare_conv2d_pack_weight_batched")
+                                               _i(cout_tile), ptr(packed), stream_handle()), "glare_conv2d_pack_weight_batched")
     b = None if biases is None else biases.detach().float().contiguous()
     out = []
     for k in range(n):
         pc = PackedConv.__new__(PackedConv)
-        pc.ksize, pc.subpixel, pc.cout, pc.cin, pc.packed, pc.w16 = kh, False, oc, ic, packed[k], None
+        pc.ksize, pc.subpixel, pc.cout, pc.cin, pc.packed, pc.w16, pc.cout_tile = kh, False, oc, ic, packed[k], None, cout_tile
         pc.bias = None if b is None else b[k]
         out.append(pc)
     return out
@@ -142,13 +149,13 @@ class PackCache:
         global PACK_CACHE
         PACK_CACHE = self._prev
 
-    def get(self, weight, bias, dgrad_pad):
-        key = (weight.data_ptr(), dgrad_pad)
+    def get(self, weight, bias, dgrad_pad, cout_tile=0):
+        key = (weight.data_ptr(), dgrad_pad, cout_tile)
         pc = self.entries.get(key)
         if pc is None:
             if self.ptrs.get(weight.data_ptr()) != tuple(weight.shape) or not weight.is_contiguous() or weight.dtype != torch.float32:
                 return None
-            pc = PackedConv(weight, None, dgrad_pad=dgrad_pad)
+            pc = PackedConv(weight, None, dgrad_pad=dgrad_pad, cout_tile=cout_tile)
             pc._src = weight.detach()
             self.entries[key] = pc
             self.table = None
@@ -161,13 +168,13 @@ class PackCache:
         if self.table is None:
             lib = _lib.lib()
             jobs, begin = [], 0
-            for (_, dgrad_pad), pc in self.entries.items():
+            for (_, dgrad_pad, cout_tile), pc in self.entries.items():
                 cout, cin, kh, _ = pc._src.shape
                 kinds = [(1, pc.packed)] if dgrad_pad is not None else [(0, pc.packed)] + ([(2, pc.w16)] if pc.w16 is not None else [])
                 for kind, dst in kinds:
                     j = _PackJob()
                     check(lib.glare_conv2d_pack_job_init(ctypes.byref(j), _i(kind), ptr(pc._src), _i(cout), _i(cin), _i(kh),
-                                                         _i(dgrad_pad or 0), ptr(dst)), "glare_conv2d_pack_job_init")
+                                                         _i(dgrad_pad or 0), _i(cout_tile), ptr(dst)), "glare_conv2d_pack_job_init")
                     j.block_begin = begin
                     begin += (j.total + 255) // 256
                     jobs.append(j)
@@ -182,14 +189,20 @@ class PackCache:
 PACK_CACHE = None   # the PackCache of the training step in progress (None: every packed_for() packs)
 
 
-def packed_for(weight, bias=None, dgrad_pad=None):
+def packed_for(weight, bias=None, dgrad_pad=None, cout_tile=0):
     """The packed image of a conv filter for the autograd nodes: from the step's PackCache when the filter is a trainable parameter
     it knows, packed on the spot otherwise."""
     if PACK_CACHE is not None:
-        pc = PACK_CACHE.get(weight, bias, dgrad_pad)
+        pc = PACK_CACHE.get(weight, bias, dgrad_pad, cout_tile)
         if pc is not None:
             return pc
-    return PackedConv(weight, bias, dgrad_pad=dgrad_pad)
+    return PackedConv(weight, bias, dgrad_pad=dgrad_pad, cout_tile=cout_tile)
+
+
+def conv_cout_tile(B, OH, OW, cout):
+    """Output-channel tile (0 = the default) that gives a conv of this output size enough workgroups (glare_conv2d_cout_tile)."""
+    t = _lib.lib().glare_conv2d_cout_tile(_i(B), _i(OH), _i(OW), _i(cout))
+    return 0 if t >= (128 if cout > 64 else (64 if cout > 32 else 32)) else t
 
 
 # Measurement hook (tools/train_bench.py flops): when a dict, every MFMA launch family adds its algorithmic FLOPs (2 x MACs) to
@@ -274,6 +287,7 @@ def conv2d(x, pc, *, x2=None, cin=None, in_off=0, cin2=None, in2_off=0, stride=1
         d.plane_pitch = out.shape[2]
     d.out, d.Cout, d.out_off = out.data_ptr(), pc.cout, out_off
     d.weight_packed = pc.packed.data_ptr()
+    d.cout_tile = getattr(pc, "cout_tile", 0)
     d.bias = pc.bias.data_ptr() if pc.bias is not None else None
     if residual is not None:
         assert residual.dtype == torch.bfloat16 and residual.is_contiguous()

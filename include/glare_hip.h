@@ -100,7 +100,16 @@ typedef struct glare_conv_desc {
   long long plane_pitch;     /* planar modes: elements per plane (>= OH*OW); 0 = OH*OW             */
   float* gn_partial;         /* optional: fused GroupNorm statistics of the OUTPUT (bf16 NHWC, Cout % 128 == 0): */
                              /* glare_conv2d_gn_partial_elems() floats, reduced by glare_conv2d_gn_reduce()       */
+  int cout_tile;             /* 0: the default output-channel tile of the workgroup for this Cout (128 / 64 / 32); else  */
+                             /* the tile the weights were packed for (glare_conv2d_pack_weight_batched's cout_tile):     */
+                             /* small launches (training crops, batch 1) fill the chip better with 64- / 32-wide tiles,  */
+                             /* glare_conv2d_cout_tile() picks                                                            */
 } glare_conv_desc;
+
+/* The output-channel tile (128, 64 or 32) that gives a B x OH x OW x cout conv enough workgroups (8 x 32 output pixels each). */
+int glare_conv2d_cout_tile(int B, int OH, int OW, int cout);
+/* glare_conv2d_packed_weight_elems for an explicit tile (0 = default). */
+long long glare_conv2d_packed_weight_elems_tile(int cout, int cin_total, int ksize, int cout_tile);
 
 /* Number of bf16 elements of the packed weight image for an OIHW [cout][cin_total][k][k] filter. */
 long long glare_conv2d_packed_weight_elems(int cout, int cin_total, int ksize);
@@ -128,13 +137,14 @@ typedef struct glare_pack_job {
   int tn, ksteps, n_stages, cin_real, kind;
 } glare_pack_job;
 int glare_conv2d_pack_job_init(glare_pack_job* job, int kind, const float* w_oihw, int cout, int cin, int ksize, int dgrad_cout_padded,
-                               void* packed_bf16);
+                               int cout_tile, void* packed_bf16);
 int glare_conv2d_pack_multi(const glare_pack_job* jobs_device, int n_jobs, long long total_blocks, glare_stream_t stream);
 /* `batch` filters of one shape ([batch][cout][cin][k][k] fp32, consecutive) packed in one launch into consecutive packed images:
  * dgrad_cout_padded = 0 as glare_conv2d_pack_weight, > 0 as glare_conv2d_pack_weight_dgrad with that padding (the per-step convs
- * of the flow's coupling nets, FlowAffineCouplingsAblation.py:117-160: 24 steps x 4 convs of two shapes). */
+ * of the flow's coupling nets, FlowAffineCouplingsAblation.py:117-160: 24 steps x 4 convs of two shapes); cout_tile = 0 or the
+ * workgroup tile to pack for (glare_conv_desc.cout_tile of the launches that use the image). */
 int glare_conv2d_pack_weight_batched(const float* w_boihw, int batch, int cout, int cin, int ksize, int dgrad_cout_padded,
-                                     void* packed_bf16, glare_stream_t stream);
+                                     int cout_tile, void* packed_bf16, glare_stream_t stream);
 /* Sub-pixel filters of "nearest x2 upsample, then 3x3 conv": per output phase (row parity a, column parity b) the 3x3 taps
  * that read the same source pixel are summed in fp32 and rounded to bf16 once (rows a=0: {0},{1,2}; a=1: {0,1},{2}). */
 long long glare_conv2d_upsample_packed_weight_elems(int cout, int cin_total);

@@ -338,3 +338,33 @@ def test_conv1x1_weight_stationary_is_deterministic_and_falls_back_outside_its_s
         assert torch.equal(ops.conv2d(x, pc), a)
     assert ops.PackedConv(_rand((1536, 512, 1, 1), g).cuda()).w16 is None        # 12 co-tiles do not divide the 32 slots of an XCD
     assert ops.PackedConv(_rand((64, 64, 1, 1), g).cuda()).w16 is None           # the flow's 64 -> 64 convs stay on the igemm kernel
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,k,stride,ups", [(1, 128, 128, 40, 40, 3, 1, False), (2, 64, 256, 24, 36, 3, 1, False),
+                                                          (1, 72, 136, 17, 23, 3, 1, True), (1, 256, 256, 16, 16, 3, 2, False),
+                                                          (1, 128, 192, 20, 20, 1, 1, False)])
+def test_narrower_output_channel_tiles_give_the_same_bits(B, Cin, Cout, H, W, k, stride, ups):
+    """glare_conv_desc.cout_tile: the same conv with 64- and 32-wide workgroup tiles (small launches: more workgroups) -- only the
+    assignment of output channels to workgroups changes, every output's contraction order is the same, so the results are bit-equal;
+    glare_conv2d_cout_tile picks the default for the BASELINE shapes and a narrower tile for the training crops."""
+    from glare_amd import _lib
+    import ctypes
+
+    g = torch.Generator().manual_seed(B + Cin + Cout)
+    x = _nhwc_bf16(_rand((B, Cin, H, W), g))
+    w = _rand((Cout, Cin, k, k), g, (Cin * k * k) ** -0.5).cuda()
+    b = _rand((Cout,), g).cuda()
+    r = _nhwc_bf16(_rand((B, Cout, H, W), g)) if (stride == 1 and not ups) else None
+    ref = ops.conv2d(x, ops.PackedConv(w, b), stride=stride, upsample=ups, act="relu" if r is None else "none", residual=r)
+    for tile in (64, 32):
+        pc = ops.PackedConv(w, b, cout_tile=tile)
+        assert pc.cout_tile == tile and pc.w16 is None
+        got = ops.conv2d(x, pc, stride=stride, upsample=ups, act="relu" if r is None else "none", residual=r)
+        assert torch.equal(got, ref)
+    pick = _lib.lib().glare_conv2d_cout_tile
+    i = ctypes.c_int
+    assert pick(i(8), i(420), i(620), i(128)) == 128 and pick(i(8), i(105), i(155), i(512)) == 128       # the BASELINE batch: default
+    assert pick(i(1), i(256), i(256), i(128)) == 64 and pick(i(1), i(64), i(64), i(512)) == 32          # stage-3 crop
+    assert pick(i(2), i(80), i(80), i(512)) == 64 and pick(i(2), i(80), i(80), i(64)) == 64 and pick(i(1), i(8), i(8), i(16)) == 32
+    with pytest.raises(_lib.GlareError):      # the fused GroupNorm statistics are laid out for the 128-wide tile
+        ops.conv2d(_nhwc_bf16(_rand((1, 128, 16, 32), g)), ops.PackedConv(_rand((128, 128, 3, 3), g).cuda(), cout_tile=64), gn_stats=True)
