@@ -14,25 +14,41 @@ namespace {
 
 constexpr int CS_THREADS = 256;
 
-template <int KS>
+template <int ACT>
+__device__ __forceinline__ float act_apply(float v) {
+  if (ACT == GLARE_ACT_SIGMOID) return sigmoidf_(v);
+  if (ACT == GLARE_ACT_RELU) return fmaxf(v, 0.f);
+  if (ACT == GLARE_ACT_SWISH) return swishf_(v);
+  return v;
+}
+
+// ACT and the store form are compile-time: as a run-time `if` chain per output element they were ~430 branches in the ISA and the
+// kernel ran at 0.78 TB/s of its 4+ TB/s HBM bound (0.71 ms for conv_in 3 -> 128 at 8 x 420 x 620); border pixels are clamped
+// loads + selects instead of branches.
+// (Loading all KS*KS*Cin input rows of a lane up front -- one memory latency per item instead of nine -- was tried: hipcc then
+// preloads every weight as well, 256 registers or hundreds of spills under a register bound; 1.3 - 8.9 ms instead of 0.53.)
+template <int KS, int ACT>
 __global__ __launch_bounds__(CS_THREADS) void conv_small_kernel(
     const float* __restrict__ x, long long sb, long long sc, long long sy, long long sx, const float* __restrict__ w,
     const float* __restrict__ bias, void* __restrict__ out, int B, int H, int W, int Cin, int Cout, int out_pitch,
-    int out_off, int act, int out_f32) {
+    int out_off, int out_f32) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* wl = reinterpret_cast<float*>(smem);  // [KS*KS][Cin][CoutP]
+  float* wl = reinterpret_cast<float*>(smem);  // [KS*KS][Cin][CoutP], then the bias [CoutP]
   const int CoutP = (Cout + 7) & ~7;
   const int taps = KS * KS;
   for (int i = threadIdx.x; i < taps * Cin * CoutP; i += CS_THREADS) {
     const int co = i % CoutP, ci = (i / CoutP) % Cin, t = i / (CoutP * Cin);
     wl[i] = co < Cout ? w[((size_t)co * Cin + ci) * taps + t] : 0.f;
   }
+  float* bl = wl + taps * Cin * CoutP;
+  for (int i = threadIdx.x; i < CoutP; i += CS_THREADS) bl[i] = (bias && i < Cout) ? bias[i] : 0.f;
   __syncthreads();
   // Each lane produces 8 consecutive output channels of PX consecutive pixels of a row: the 8 weights of a (tap, ci) are read
   // from LDS once and reused for PX pixels (the kernel was LDS-read bound at one pixel per lane: 2 ds_read_b128 per 8 FMAs).
   constexpr int PX = 4;
   const int groups = CoutP / 8, WQ = (W + PX - 1) / PX;
   const long long total = (long long)B * H * WQ * groups;
+  const bool vec_store = !out_f32 && ((out_pitch | out_off) % 8) == 0;
   for (long long idx = (long long)blockIdx.x * CS_THREADS + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * CS_THREADS) {
     const int g = idx % groups;
@@ -43,35 +59,50 @@ __global__ __launch_bounds__(CS_THREADS) void conv_small_kernel(
     const int b = t2 / H;
     const int x0 = xq * PX;
     float acc[PX][8];
+    {
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(bl + g * 8), b1 = *reinterpret_cast<const f32x4*>(bl + g * 8 + 4);
 #pragma unroll
-    for (int q = 0; q < PX; ++q)
+      for (int q = 0; q < PX; ++q)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[q][e] = (bias && g * 8 + e < Cout) ? bias[g * 8 + e] : 0.f;
+        for (int e = 0; e < 4; ++e) { acc[q][e] = b0[e]; acc[q][4 + e] = b1[e]; }
+    }
+    // column validity and clamped column offsets of the PX + KS - 1 inputs of a row segment (the same for every row and channel)
+    long long xo[PX + KS - 1];
+    bool xok[PX + KS - 1];
+#pragma unroll
+    for (int k = 0; k < PX + KS - 1; ++k) {
+      const int ix = x0 + k - KS / 2;
+      xok[k] = ix >= 0 && ix < W;
+      xo[k] = (long long)min(max(ix, 0), W - 1) * sx;
+    }
+    auto fma_row = [&](int ty, int ci, const float (&v)[PX + KS - 1]) {
+#pragma unroll
+      for (int tx = 0; tx < KS; ++tx) {
+        const f32x4* wp = reinterpret_cast<const f32x4*>(wl + ((size_t)(ty * KS + tx) * Cin + ci) * CoutP + g * 8);
+        const f32x4 w0 = wp[0], w1 = wp[1];
+#pragma unroll
+        for (int q = 0; q < PX; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc[q][e] = fmaf(v[q + tx], w0[e], acc[q][e]);
+            acc[q][4 + e] = fmaf(v[q + tx], w1[e], acc[q][4 + e]);
+          }
+      }
+    };
 #pragma unroll
     for (int ty = 0; ty < KS; ++ty) {
       const int iy = yh + ty - KS / 2;
-      if (iy < 0 || iy >= H) continue;
+      const bool yok = iy >= 0 && iy < H;
+      const float* xrow = x + b * sb + (long long)min(max(iy, 0), H - 1) * sy;
       for (int ci = 0; ci < Cin; ++ci) {
-        // the PX + KS - 1 inputs of this row segment
         float v[PX + KS - 1];
-        const float* xp = x + b * sb + iy * sy + ci * sc;
+        const float* xp = xrow + ci * sc;
 #pragma unroll
         for (int k = 0; k < PX + KS - 1; ++k) {
-          const int ix = x0 + k - KS / 2;
-          v[k] = (ix >= 0 && ix < W) ? xp[ix * sx] : 0.f;
+          const float t = xp[xo[k]];
+          v[k] = (yok && xok[k]) ? t : 0.f;
         }
-#pragma unroll
-        for (int tx = 0; tx < KS; ++tx) {
-          const f32x4* wp = reinterpret_cast<const f32x4*>(wl + ((size_t)(ty * KS + tx) * Cin + ci) * CoutP + g * 8);
-          const f32x4 w0 = wp[0], w1 = wp[1];
-#pragma unroll
-          for (int q = 0; q < PX; ++q)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              acc[q][e] = fmaf(v[q + tx], w0[e], acc[q][e]);
-              acc[q][4 + e] = fmaf(v[q + tx], w1[e], acc[q][4 + e]);
-            }
-        }
+        fma_row(ty, ci, v);
       }
     }
 #pragma unroll
@@ -80,30 +111,40 @@ __global__ __launch_bounds__(CS_THREADS) void conv_small_kernel(
       if (xw >= W) break;
       const size_t opix = ((size_t)b * H + yh) * W + xw;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        if (act == GLARE_ACT_SIGMOID) acc[q][e] = sigmoidf_(acc[q][e]);
-        else if (act == GLARE_ACT_RELU) acc[q][e] = fmaxf(acc[q][e], 0.f);
-        else if (act == GLARE_ACT_SWISH) acc[q][e] = swishf_(acc[q][e]);
-      }
-      if (out_f32) {
+      for (int e = 0; e < 8; ++e) acc[q][e] = act_apply<ACT>(acc[q][e]);
+      if (vec_store && g * 8 + 8 <= Cout) {
+        bf16_t* o = reinterpret_cast<bf16_t*>(out) + opix * out_pitch + out_off + g * 8;
+        *reinterpret_cast<u32x4*>(o) = u32x4{pack_bf2(acc[q][0], acc[q][1]), pack_bf2(acc[q][2], acc[q][3]), pack_bf2(acc[q][4], acc[q][5]),
+                                             pack_bf2(acc[q][6], acc[q][7])};
+      } else if (out_f32) {
         float* o = reinterpret_cast<float*>(out) + opix * out_pitch + out_off + g * 8;
 #pragma unroll
         for (int e = 0; e < 8; ++e)
           if (g * 8 + e < Cout) o[e] = acc[q][e];
       } else {
         bf16_t* o = reinterpret_cast<bf16_t*>(out) + opix * out_pitch + out_off + g * 8;
-        if (g * 8 + 8 <= Cout && ((out_pitch | out_off) % 8) == 0) {
-          u32x4 vv = {pack_bf2(acc[q][0], acc[q][1]), pack_bf2(acc[q][2], acc[q][3]), pack_bf2(acc[q][4], acc[q][5]),
-                      pack_bf2(acc[q][6], acc[q][7])};
-          *reinterpret_cast<u32x4*>(o) = vv;
-        } else {
 #pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (g * 8 + e < Cout) o[e] = f2bf(acc[q][e]);
-        }
+        for (int e = 0; e < 8; ++e)
+          if (g * 8 + e < Cout) o[e] = f2bf(acc[q][e]);
       }
     }
   }
+}
+
+template <int KS>
+void launch_small(int act, unsigned blocks, size_t lds, hipStream_t st, const float* x, long long sb, long long sc, long long sy,
+                  long long sx, const float* w, const float* bias, void* out, int B, int H, int W, int Cin, int Cout, int out_pitch,
+                  int out_off, int out_f32) {
+#define CS_LAUNCH(A)                                                                                                          \
+  hipLaunchKernelGGL((conv_small_kernel<KS, A>), dim3(blocks), dim3(CS_THREADS), lds, st, x, sb, sc, sy, sx, w, bias, out, B, H, W, \
+                     Cin, Cout, out_pitch, out_off, out_f32)
+  switch (act) {
+    case GLARE_ACT_SIGMOID: CS_LAUNCH(GLARE_ACT_SIGMOID); break;
+    case GLARE_ACT_RELU: CS_LAUNCH(GLARE_ACT_RELU); break;
+    case GLARE_ACT_SWISH: CS_LAUNCH(GLARE_ACT_SWISH); break;
+    default: CS_LAUNCH(GLARE_ACT_NONE);
+  }
+#undef CS_LAUNCH
 }
 
 }  // namespace
@@ -116,18 +157,16 @@ extern "C" int glare_conv2d_smallcin_f32(const float* x, long long stride_b, lon
   if (Cin < 1 || Cin > 4 || (ksize != 1 && ksize != 3)) return GLARE_ERR_UNSUPPORTED;
   if (out_off + Cout > out_pitch) return GLARE_ERR_INVALID;
   const int CoutP = (Cout + 7) & ~7;
-  const size_t lds = (size_t)ksize * ksize * Cin * CoutP * sizeof(float);
+  const size_t lds = ((size_t)ksize * ksize * Cin + 1) * CoutP * sizeof(float);   // weights + bias
   if (lds > 64 * 1024) return GLARE_ERR_UNSUPPORTED;
   const long long total = (long long)B * H * ((W + 3) / 4) * (CoutP / 8);   // 4 pixels per lane
   long long blocks = (total + CS_THREADS - 1) / CS_THREADS;
   if (blocks > 256 * 16) blocks = 256 * 16;
   if (ksize == 3)
-    hipLaunchKernelGGL(conv_small_kernel<3>, dim3((unsigned)blocks), dim3(CS_THREADS), lds, (hipStream_t)stream, x, stride_b,
-                       stride_c, stride_y, stride_x, w_oihw, bias, out, B, H, W, Cin, Cout, out_pitch, out_off, act,
-                       out_is_f32);
+    launch_small<3>(act, (unsigned)blocks, lds, (hipStream_t)stream, x, stride_b, stride_c, stride_y, stride_x, w_oihw, bias, out, B, H, W,
+                    Cin, Cout, out_pitch, out_off, out_is_f32);
   else
-    hipLaunchKernelGGL(conv_small_kernel<1>, dim3((unsigned)blocks), dim3(CS_THREADS), lds, (hipStream_t)stream, x, stride_b,
-                       stride_c, stride_y, stride_x, w_oihw, bias, out, B, H, W, Cin, Cout, out_pitch, out_off, act,
-                       out_is_f32);
+    launch_small<1>(act, (unsigned)blocks, lds, (hipStream_t)stream, x, stride_b, stride_c, stride_y, stride_x, w_oihw, bias, out, B, H, W,
+                    Cin, Cout, out_pitch, out_off, out_is_f32);
   return glare_launch_status();
 }

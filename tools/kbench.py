@@ -131,6 +131,17 @@ def bench_attnbwd():
     print("attnbwd B=%d N=%d d=512: fused %.3f ms  %.0f TFLOP/s algorithmic (5 products);  materialised %.3f ms" % (Bt, N, ms, fl / ms / 1e9, ms_old))
 
 
+def bench_convin():
+    """conv_in 3 -> 128 on the NCHW fp32 image at full resolution (conv_small_kernel): HBM-bound on its bf16 output."""
+    H, W, co = 420, 620, 128
+    x = torch.randn(B, 3, H, W, device=DEV)
+    w = torch.randn(co, 3, 3, 3, device=DEV) * 0.2
+    b = torch.randn(co, device=DEV)
+    out = torch.empty(B, H, W, co, dtype=torch.bfloat16, device=DEV)
+    ms = timeit(lambda: ops.conv2d_smallcin(x, (3 * H * W, H * W, W, 1), (B, H, W), w, b, out=out))
+    print("convin 3->128 3x3 @full: %.3f ms  %.0f GB/s (bf16 output + fp32 input)" % (ms, (out.numel() * 2 + x.numel() * 4) / ms / 1e6))
+
+
 def bench_vq():
     n = B * 105 * 155
     z = torch.randn(n, 3, device=DEV)
