@@ -93,10 +93,12 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16_t* __re
   }
 }
 
+// SWISH is a template parameter: as a run-time flag it compiled to one branch per bf16 pair of the streaming loop
+template <bool SWISH>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ partial,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               bf16_t* __restrict__ y, long long HW, int C, int pitch, int off,
-                                                              int splits, float eps, int swish, int blocks_per_image) {
+                                                              int splits, float eps, int blocks_per_image) {
   __shared__ float mean_s[GN_GROUPS], rstd_s[GN_GROUPS];
   const int b = blockIdx.x / blocks_per_image, blk = blockIdx.x % blocks_per_image;
   const int cpg = C / GN_GROUPS;
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __re
     for (int e = 0; e < 4; ++e) {
       float lo = bflo(v[e]) * sc[2 * e] + sh[2 * e];
       float hi = bfhi(v[e]) * sc[2 * e + 1] + sh[2 * e + 1];
-      if (swish) { lo = swishf_(lo); hi = swishf_(hi); }
+      if (SWISH) { lo = swishf_(lo); hi = swishf_(hi); }
       o[e] = pack_bf2(lo, hi);
     }
     return o;
@@ -190,8 +192,12 @@ extern "C" int glare_groupnorm_swish_bf16(const void* x, int in_pitch, int in_of
                      HW, C, in_pitch, in_off, splits, (const bf16_t*)nullptr, (bf16_t*)nullptr);
   int bpi = (int)((HW * (C / 8) + 16 * GN_THREADS - 1) / (16 * GN_THREADS));  // ~16 chunks per thread
   if (bpi < 1) bpi = 1;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)(bpi * B)), dim3(GN_THREADS), 0, stream, (const bf16_t*)x,
-                     (const float*)workspace, gamma, beta, (bf16_t*)y, HW, C, in_pitch, in_off, splits, eps, swish, bpi);
+  if (swish)
+    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3((unsigned)(bpi * B)), dim3(GN_THREADS), 0, stream, (const bf16_t*)x,
+                       (const float*)workspace, gamma, beta, (bf16_t*)y, HW, C, in_pitch, in_off, splits, eps, bpi);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3((unsigned)(bpi * B)), dim3(GN_THREADS), 0, stream, (const bf16_t*)x,
+                       (const float*)workspace, gamma, beta, (bf16_t*)y, HW, C, in_pitch, in_off, splits, eps, bpi);
   return glare_launch_status();
 }
 
@@ -214,7 +220,11 @@ extern "C" int glare_groupnorm_apply_bf16(const void* x, int in_pitch, int in_of
   if (in_off + C > in_pitch) return GLARE_ERR_INVALID;
   int bpi = (int)((HW * (C / 8) + 16 * GN_THREADS - 1) / (16 * GN_THREADS));
   if (bpi < 1) bpi = 1;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)(bpi * B)), dim3(GN_THREADS), 0, (hipStream_t)stream_, (const bf16_t*)x,
-                     stats, gamma, beta, (bf16_t*)y, HW, C, in_pitch, in_off, splits, eps, swish, bpi);
+  if (swish)
+    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3((unsigned)(bpi * B)), dim3(GN_THREADS), 0, (hipStream_t)stream_, (const bf16_t*)x,
+                       stats, gamma, beta, (bf16_t*)y, HW, C, in_pitch, in_off, splits, eps, bpi);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3((unsigned)(bpi * B)), dim3(GN_THREADS), 0, (hipStream_t)stream_, (const bf16_t*)x,
+                       stats, gamma, beta, (bf16_t*)y, HW, C, in_pitch, in_off, splits, eps, bpi);
   return glare_launch_status();
 }
