@@ -146,7 +146,7 @@ class FlowUpsamplerNet(HipModule):
         ftA = ops.conv2d(ft, P["ftA"], out_mode=ops.OUT_NHWC_F32)                 # [B,h,w,n*64] fp32
         h1f = ops.conv2d(ft, P["f0"], act="relu")                                  # [B,h,w,n*64] bf16
         h2f = torch.empty_like(h1f)
-        hF = torch.zeros(B, H, W, n * 8, dtype=torch.float32, device=z.device)
+        hF = torch.empty(B, H, W, n * 8, dtype=torch.float32, device=z.device)   # 6 of every 8 written and read
         for s, st in enumerate(P["steps"]):                                        # z-independent, batched up front
             ops.conv2d(h1f, st["f2"], cin=64, in_off=64 * s, act="relu", out=h2f, out_off=64 * s)
             ops.conv2d(h2f, st["f4"], cin=64, in_off=64 * s, out=hF, out_off=8 * s, out_mode=ops.OUT_NHWC_F32)
@@ -188,7 +188,7 @@ class FlowUpsamplerNet(HipModule):
         ftA = ops.conv2d(ft, P["ftA"], out_mode=ops.OUT_NHWC_F32)
         h1f = ops.conv2d(ft, P["f0"], act="relu")
         h2f = torch.empty_like(h1f)
-        hF = torch.zeros(B, H, W, n * 8, dtype=torch.float32, device=z.device)
+        hF = torch.empty(B, H, W, n * 8, dtype=torch.float32, device=z.device)   # 6 of every 8 written and read
         for s, st in enumerate(P["steps"]):
             ops.conv2d(h1f, st["f2"], cin=64, in_off=64 * s, act="relu", out=h2f, out_off=64 * s)
             ops.conv2d(h2f, st["f4"], cin=64, in_off=64 * s, out=hF, out_off=8 * s, out_mode=ops.OUT_NHWC_F32)
@@ -318,7 +318,7 @@ class FlowNLLFn(torch.autograd.Function):
         ftA = ops.conv2d(ft, ops.PackedConv(ftA_w, ftA_b), out_mode=ops.OUT_NHWC_F32)
         h1f = ops.conv2d(ft, ops.PackedConv(f0_w, f0_b), act="relu")
         h2f = torch.empty_like(h1f)
-        hF = torch.zeros(B, H, W, n * 8, dtype=torch.float32, device=dev)
+        hF = torch.empty(B, H, W, n * 8, dtype=torch.float32, device=dev)   # 6 of every 8 written and read
         f2p, f4p = ops.packed_conv_batch(f2_w, f2_b), ops.packed_conv_batch(f4_w, f4_b)      # one pack launch per conv type
         c2p, c4p = ops.packed_conv_batch(c2_w, c2_b), ops.packed_conv_batch(c4_w, c4_b)
         for s in range(n):
