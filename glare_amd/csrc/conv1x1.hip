@@ -40,6 +40,8 @@ struct C1Params {
   int Cin, Cout;
   int xpitch, xoff, opitch, ooff, rpitch, roff;
   int act, nct, rbi;     // co-tiles (Cout / 128), row blocks per image
+  long long w_istride;   // 0: one filter for all images; else elements between the filters of consecutive images (a pixel range
+  int b_istride;         // then never straddles two images: (8 * 32 / nct) % B == 0); likewise for the bias
 };
 
 template <int ACT>   // compile-time inside the epilogue (a runtime switch per element costs ~3 scalar branches per element)
@@ -74,11 +76,18 @@ __global__ __launch_bounds__(256, 1) void conv1x1_ws_kernel(const C1Params p) {
   const int ct = slot % p.nct, rng_in_xcd = slot / p.nct, rpx = 32 / p.nct;
   const int range = xcd * rpx + rng_in_xcd, n_ranges = 8 * rpx;
   const int total_rb = p.B * p.rbi;
-  const int rb_lo = (int)((long long)total_rb * range / n_ranges), rb_hi = (int)((long long)total_rb * (range + 1) / n_ranges);
+  int rb_lo = (int)((long long)total_rb * range / n_ranges), rb_hi = (int)((long long)total_rb * (range + 1) / n_ranges);
+  int w_img = 0;
+  if (p.w_istride != 0) {   // per-image filters: ranges are cut per image
+    const int rpi = n_ranges / p.B, sub = range % rpi;
+    w_img = range / rpi;
+    rb_lo = w_img * p.rbi + (int)((long long)p.rbi * sub / rpi);
+    rb_hi = w_img * p.rbi + (int)((long long)p.rbi * (sub + 1) / rpi);
+  }
 
   // ---- weights of this co-tile into LDS, once: row r, chunk c at r * CPR + (c ^ (r & 15)) (source-side swizzle)
   {
-    const bf16_t* wt = p.w + (size_t)ct * 128 * p.Cin;
+    const bf16_t* wt = p.w + (size_t)w_img * p.w_istride + (size_t)ct * 128 * p.Cin;
     const int r_in = lane / CPR, c_ph = lane % CPR;
 #pragma unroll 4
     for (int piece = wave; piece < 128 / RPP; piece += 4) {
@@ -104,7 +113,7 @@ __global__ __launch_bounds__(256, 1) void conv1x1_ws_kernel(const C1Params p) {
   const int co0 = ct * 128;
   float bias_v[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) bias_v[j] = p.bias ? p.bias[co0 + 32 * j + px] : 0.f;
+  for (int j = 0; j < 4; ++j) bias_v[j] = p.bias ? p.bias[(size_t)w_img * p.b_istride + co0 + 32 * j + px] : 0.f;
 
   // A fragments are fetched one UNIT (16 k-steps = 16 KB per wave) ahead of the MFMAs that consume them: with one wave per SIMD
   // nothing else hides the memory latency (8 k-steps ahead left the kernel latency-bound at 1.3 TB/s), and two whole row blocks of
@@ -295,11 +304,12 @@ extern "C" int glare_conv1x1_ws_gn_reduce(const float* gn_partial, float* stats_
   return glare_launch_status();
 }
 
-extern "C" int glare_conv1x1_ws_bf16(const void* x, int x_pitch, int x_off, const void* w_bf16, const float* bias, const void* residual,
-                                     int res_pitch, int res_off, void* out, int out_pitch, int out_off, int B, long long pixels_per_image,
-                                     int Cin, int Cout, int act, float* gn_partial, glare_stream_t stream) {
+static int c1_launch(const void* x, int x_pitch, int x_off, const void* w_bf16, long long w_istride, const float* bias, int b_istride,
+                     const void* residual, int res_pitch, int res_off, void* out, int out_pitch, int out_off, int B,
+                     long long pixels_per_image, int Cin, int Cout, int act, float* gn_partial, glare_stream_t stream) {
   if (!x || !w_bf16 || !out || B <= 0 || pixels_per_image <= 0) return GLARE_ERR_INVALID;
   if (!glare_conv1x1_ws_supported(Cin, Cout)) return GLARE_ERR_UNSUPPORTED;
+  if (w_istride != 0 && ((8 * 32 / (Cout / 128)) % B != 0 || w_istride % 8 != 0 || (bias && b_istride <= 0))) return GLARE_ERR_UNSUPPORTED;
   if ((x_pitch % 8) || (x_off % 8) || (out_pitch % 8) || (out_off % 8) || x_off + Cin > x_pitch || out_off + Cout > out_pitch)
     return GLARE_ERR_UNSUPPORTED;
   if (residual && ((res_pitch % 8) || (res_off % 8) || res_off + Cout > res_pitch)) return GLARE_ERR_UNSUPPORTED;
@@ -310,6 +320,7 @@ extern "C" int glare_conv1x1_ws_bf16(const void* x, int x_pitch, int x_off, cons
   p.B = B; p.N = (int)pixels_per_image; p.Cin = Cin; p.Cout = Cout;
   p.xpitch = x_pitch; p.xoff = x_off; p.opitch = out_pitch; p.ooff = out_off; p.rpitch = res_pitch; p.roff = res_off;
   p.act = act; p.nct = Cout / 128; p.rbi = (int)cdivll(pixels_per_image, 32);
+  p.w_istride = w_istride; p.b_istride = w_istride != 0 ? b_istride : 0;
   const size_t lds = (size_t)128 * Cin * 2 + 4 * 8192;
   hipStream_t s = (hipStream_t)stream;
 #define C1_CASE(KS_)                                                                                                       \
@@ -322,4 +333,23 @@ extern "C" int glare_conv1x1_ws_bf16(const void* x, int x_pitch, int x_off, cons
   C1_CASE(8) C1_CASE(16) C1_CASE(32)
 #undef C1_CASE
   return GLARE_ERR_UNSUPPORTED;
+}
+
+extern "C" int glare_conv1x1_ws_bf16(const void* x, int x_pitch, int x_off, const void* w_bf16, const float* bias, const void* residual,
+                                     int res_pitch, int res_off, void* out, int out_pitch, int out_off, int B, long long pixels_per_image,
+                                     int Cin, int Cout, int act, float* gn_partial, glare_stream_t stream) {
+  return c1_launch(x, x_pitch, x_off, w_bf16, 0, bias, 0, residual, res_pitch, res_off, out, out_pitch, out_off, B, pixels_per_image, Cin,
+                   Cout, act, gn_partial, stream);
+}
+
+// The same with ONE FILTER PER IMAGE: w_bf16 = [B][Cout][Cin] bf16 (w_image_stride elements apart), bias = [B][bias_image_stride].
+// GroupNorm without an activation in front of a 1x1 conv is a per-(image, channel) affine map of the conv's input, i.e. a per-image
+// filter (glare_attn_fold_groupnorm_f32): the normalised tensor is never written.  Needs (8 * 32 / (Cout / 128)) % B == 0.
+extern "C" int glare_conv1x1_ws_image_bf16(const void* x, int x_pitch, int x_off, const void* w_bf16, long long w_image_stride,
+                                           const float* bias, int bias_image_stride, const void* residual, int res_pitch, int res_off,
+                                           void* out, int out_pitch, int out_off, int B, long long pixels_per_image, int Cin, int Cout,
+                                           int act, float* gn_partial, glare_stream_t stream) {
+  if (w_image_stride <= 0) return GLARE_ERR_INVALID;
+  return c1_launch(x, x_pitch, x_off, w_bf16, w_image_stride, bias, bias_image_stride, residual, res_pitch, res_off, out, out_pitch, out_off,
+                   B, pixels_per_image, Cin, Cout, act, gn_partial, stream);
 }

@@ -171,6 +171,59 @@ int gn_splits(long long HW) {
   return (int)(s < 1 ? 1 : (s > 64 ? 64 : s));
 }
 
+// GroupNorm (no activation) in front of 1x1 convs as per-image filters.  With a[b,c] = rstd[b,g(c)] gamma[c] and
+// d[b,c] = beta[c] - mean[b,g(c)] a[b,c], hn = a o x + d, so for AttnBlock on hn = GroupNorm(x) (encoder_decoder.py:146-188, after
+// the key / value folds of AttnBlock._q_folded / _out_folded):
+//   scores   q'_i . hn_j = (a o q'_i) . x_j + const_i  (the constant cancels in softmax_j)   =>  keys   = x
+//   q''_i    = a o (Wq hn_i + bq) = (diag(a) Wq diag(a)) x_i + a o (Wq d + bq)
+//   output   Wo (sum_j p_ij hn_j) + bo = (Wo diag(a)) (sum_j p_ij x_j) + (Wo d + bo)          =>  values = x
+// One block per (output row o, image b) writes row o of both bf16 filters and the two bias entries; the normalised tensor is
+// never materialised (11 GroupNorm apply passes of 133 MB per 8-image step).
+__global__ __launch_bounds__(256) void attn_fold_kernel(const float* __restrict__ stats, int splits, long long HW, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps, const float* __restrict__ wq,
+                                                        const float* __restrict__ bq, const float* __restrict__ wo,
+                                                        const float* __restrict__ bo, bf16_t* __restrict__ wq_out,
+                                                        float* __restrict__ bq_out, bf16_t* __restrict__ wo_out,
+                                                        float* __restrict__ bo_out, int C) {
+  __shared__ float a_s[2048], d_s[2048];
+  __shared__ float red[2][4];
+  const int o = blockIdx.x, b = blockIdx.y, cpg = C / GN_GROUPS;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int g = c / cpg;
+    double s = 0.0, q = 0.0;
+    for (int i = 0; i < splits; ++i) {
+      s += stats[((size_t)b * splits + i) * GN_GROUPS * 2 + g * 2];
+      q += stats[((size_t)b * splits + i) * GN_GROUPS * 2 + g * 2 + 1];
+    }
+    const double n = (double)HW * cpg, m = s / n;
+    double var = q / n - m * m;
+    if (var < 0.0) var = 0.0;
+    const float mean = (float)m, rstd = (float)(1.0 / sqrt(var + (double)eps));   // the two floats gn_apply_kernel uses
+    const float a = rstd * gamma[c];
+    a_s[c] = a;
+    d_s[c] = beta[c] - mean * a;
+  }
+  __syncthreads();
+  const float ao = a_s[o];
+  float dq = 0.f, dv = 0.f;
+  const size_t row = ((size_t)b * C + o) * C;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float wqv = wq[(size_t)o * C + c], wov = wo[(size_t)o * C + c];
+    wq_out[row + c] = f2bf(ao * wqv * a_s[c]);
+    wo_out[row + c] = f2bf(wov * a_s[c]);
+    dq = fmaf(wqv, d_s[c], dq);
+    dv = fmaf(wov, d_s[c], dv);
+  }
+  dq = wave_sum(dq);
+  dv = wave_sum(dv);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = dq; red[1][threadIdx.x >> 6] = dv; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    bq_out[(size_t)b * C + o] = ao * (((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) + bq[o]);
+    bo_out[(size_t)b * C + o] = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) + bo[o];
+  }
+}
+
 }  // namespace
 
 extern "C" size_t glare_groupnorm_workspace_bytes(int B, long long HW) {
@@ -226,5 +279,19 @@ extern "C" int glare_groupnorm_apply_bf16(const void* x, int in_pitch, int in_of
   else
     hipLaunchKernelGGL(gn_apply_kernel<false>, dim3((unsigned)(bpi * B)), dim3(GN_THREADS), 0, (hipStream_t)stream_, (const bf16_t*)x,
                        stats, gamma, beta, (bf16_t*)y, HW, C, in_pitch, in_off, splits, eps, bpi);
+  return glare_launch_status();
+}
+
+// stats: the [B][splits][32][2] (sum, sum of squares) block of the tensor's GroupNorm (from a conv's fused statistics or
+// glare_add_groupnorm_stats_bf16); wq / wo: fp32 [C][C] row-major (out, in), bq / bo fp32 [C]; outputs bf16 [B][C][C] and fp32 [B][C]
+// for glare_conv1x1_ws_image_bf16.  C a multiple of 32, <= 2048.
+extern "C" int glare_attn_fold_groupnorm_f32(const float* stats, int splits, int B, long long HW, int C, const float* gamma,
+                                             const float* beta, float eps, const float* wq, const float* bq, const float* wo,
+                                             const float* bo, void* wq_out, float* bq_out, void* wo_out, float* bo_out,
+                                             glare_stream_t stream) {
+  if (!stats || !gamma || !beta || !wq || !bq || !wo || !bo || !wq_out || !bq_out || !wo_out || !bo_out) return GLARE_ERR_INVALID;
+  if (splits <= 0 || B <= 0 || B > 65535 || HW <= 0 || C <= 0 || C % GN_GROUPS || C > 2048) return GLARE_ERR_INVALID;
+  hipLaunchKernelGGL(attn_fold_kernel, dim3(C, B), dim3(256), 0, (hipStream_t)stream, stats, splits, HW, gamma, beta, eps, wq, bq, wo, bo,
+                     (bf16_t*)wq_out, bq_out, (bf16_t*)wo_out, bo_out, C);
   return glare_launch_status();
 }

@@ -40,6 +40,10 @@ FOLD_PROJ_INTO_V = True
 # AttnBlock as attention with shared keys / values (csrc/attn.hip, attn_kv_fwd_kernel): the key projection folded into the
 # query projection, the value projection folded into proj_out.  False: the q | k and v^T projections + the two-tensor kernel.
 SHARED_KV_ATTENTION = True
+# ... and with the block's GroupNorm folded into the two 1x1 convs as per-image filters (no activation follows that norm): the
+# attention runs on the RAW input as keys / values and the normalised tensor is never written (ops.attn_fold_groupnorm).  Needs the
+# producer's fused GroupNorm statistics on the input and a batch that divides the 1x1 kernel's 64 pixel ranges.
+GN_FOLDED_ATTENTION = True
 
 
 class Upsample(HipModule):
@@ -156,9 +160,24 @@ class AttnBlock(HipModule):
         b = (wp @ self.v.bias.double() + self.proj_out.bias.double()).float()
         return ops.PackedConv(w, b)
 
+    def _fold_mats(self):
+        s = float(self.in_channels) ** -0.5 * math.log2(math.e)
+        wq, wk = self.q.weight[:, :, 0, 0].double(), self.k.weight[:, :, 0, 0].double()
+        wp, wv = self.proj_out.weight[:, :, 0, 0].double(), self.v.weight[:, :, 0, 0].double()
+        return ((s * (wk.t() @ wq)).float().contiguous(), (s * (wk.t() @ self.q.bias.double())).float().contiguous(),
+                (wp @ wv).float().contiguous(), (wp @ self.v.bias.double() + self.proj_out.bias.double()).float().contiguous(),
+                self.norm.weight.detach().float().contiguous(), self.norm.bias.detach().float().contiguous())
+
     def forward_nhwc(self, x):
         B, H, W, C = x.shape
         N = H * W
+        stats = getattr(x, "_gn_stats", None)
+        if SHARED_KV_ATTENTION and GN_FOLDED_ATTENTION and stats is not None and 64 % B == 0:
+            wq, bq, wo, bo, gamma, beta = self._packed("fold_mats", self._fold_mats)
+            wq_b, bq_b, wo_b, bo_b = ops.attn_fold_groupnorm(stats, N, gamma, beta, self.norm.eps, wq, bq, wo, bo)
+            q = ops.conv1x1_per_image(x, wq_b, bq_b)
+            a = ops.attention_kv512(q, x, N)                                     # keys = values = the raw input
+            return ops.conv1x1_per_image(a.view(B, H, W, C), wo_b, bo_b, residual=x, gn_stats=GN_FUSED)
         hn = gn_swish(x, self.norm, swish=False)
         if SHARED_KV_ATTENTION:
             q = ops.conv2d(hn, self._packed("q_folded", self._q_folded))

@@ -241,6 +241,54 @@ def _conv1x1_ws(x, pc, cin, in_off, act, residual, res_off, out, out_off, gn_sta
     return out
 
 
+def conv1x1_per_image(x, w16, bias, residual=None, gn_stats=False):
+    """1x1 conv with ONE FILTER PER IMAGE (csrc/conv1x1.hip): x bf16 NHWC [B,H,W,Cin], w16 bf16 [B,Cout,Cin], bias fp32 [B,Cout],
+    optional residual bf16 [B,H,W,Cout] -> bf16 NHWC [B,H,W,Cout] (+ the fused GroupNorm statistics of the output)."""
+    require_cuda(x, w16, bias, residual)
+    B, H, W, cin = x.shape
+    cout = w16.shape[1]
+    assert x.dtype == w16.dtype == torch.bfloat16 and x.is_contiguous() and w16.is_contiguous() and tuple(w16.shape) == (B, cout, cin)
+    assert bias.dtype == torch.float32 and bias.is_contiguous() and tuple(bias.shape) == (B, cout)
+    N = H * W
+    count_flops("conv k1", 2.0 * B * N * cin * cout)
+    out = torch.empty(B, H, W, cout, dtype=torch.bfloat16, device=x.device)
+    lib = _lib.lib()
+    gn_part = None
+    if gn_stats:
+        lib.glare_conv1x1_ws_gn_partial_elems.restype = _ll
+        gn_part = torch.empty(lib.glare_conv1x1_ws_gn_partial_elems(_i(B), _ll(N), _i(cout)), dtype=torch.float32, device=x.device)
+    if residual is not None:
+        assert residual.dtype == torch.bfloat16 and residual.is_contiguous() and residual.shape == out.shape
+    check(lib.glare_conv1x1_ws_image_bf16(ptr(x), _i(cin), _i(0), ptr(w16), _ll(cout * cin), ptr(bias), _i(cout), ptr(residual),
+                                          _i(cout if residual is not None else 0), _i(0), ptr(out), _i(cout), _i(0), _i(B), _ll(N), _i(cin),
+                                          _i(cout), _i(0), ptr(gn_part), stream_handle()), "glare_conv1x1_ws_image_bf16")
+    if gn_stats:
+        stats = torch.empty(B, 1, 32, 2, dtype=torch.float32, device=x.device)
+        check(lib.glare_conv1x1_ws_gn_reduce(ptr(gn_part), ptr(stats), _i(B), _ll(N), _i(cout), stream_handle()),
+              "glare_conv1x1_ws_gn_reduce")
+        out._gn_stats = stats
+    return out
+
+
+def attn_fold_groupnorm(stats, HW, gamma, beta, eps, wq, bq, wo, bo):
+    """Per-image filters of an AttnBlock whose GroupNorm is folded into its two 1x1 convs (glare_attn_fold_groupnorm_f32):
+    stats fp32 [B, splits, 32, 2]; wq / wo fp32 [C, C], bq / bo fp32 [C] -> (wq_b bf16 [B,C,C], bq_b fp32 [B,C], wo_b, bo_b)."""
+    require_cuda(stats, gamma, beta, wq, bq, wo, bo)
+    B, splits = stats.shape[0], stats.shape[1]
+    C = wq.shape[0]
+    assert stats.dtype == torch.float32 and stats.is_contiguous() and tuple(stats.shape[2:]) == (32, 2)
+    for t in (gamma, beta, wq, bq, wo, bo):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    wq_b = torch.empty(B, C, C, dtype=torch.bfloat16, device=stats.device)
+    wo_b = torch.empty_like(wq_b)
+    bq_b = torch.empty(B, C, dtype=torch.float32, device=stats.device)
+    bo_b = torch.empty_like(bq_b)
+    check(_lib.lib().glare_attn_fold_groupnorm_f32(ptr(stats), _i(splits), _i(B), _ll(HW), _i(C), ptr(gamma), ptr(beta), _f(eps), ptr(wq),
+                                                   ptr(bq), ptr(wo), ptr(bo), ptr(wq_b), ptr(bq_b), ptr(wo_b), ptr(bo_b),
+                                                   stream_handle()), "glare_attn_fold_groupnorm_f32")
+    return wq_b, bq_b, wo_b, bo_b
+
+
 def conv2d(x, pc, *, x2=None, cin=None, in_off=0, cin2=None, in2_off=0, stride=1, upsample=False, act="none",
            residual=None, res_off=0, out=None, out_off=0, out_mode=OUT_NHWC_BF16, plane_pitch=0, gn_stats=False):
     """x: NHWC bf16 [B,H,W,pitch] (channels [in_off, in_off+cin) are used), optional x2 concatenated

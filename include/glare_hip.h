@@ -236,6 +236,20 @@ int glare_conv1x1_ws_gn_reduce(const float* gn_partial, float* stats_out, int B,
 int glare_conv1x1_ws_bf16(const void* x, int x_pitch, int x_off, const void* w_bf16, const float* bias, const void* residual,
                           int res_pitch, int res_off, void* out, int out_pitch, int out_off, int B, long long pixels_per_image, int Cin,
                           int Cout, int act, float* gn_partial, glare_stream_t stream);
+/* The same with ONE FILTER PER IMAGE (w_bf16 [B][Cout][Cin], bias [B][bias_image_stride]; strides in elements): a GroupNorm without
+ * activation in front of a 1x1 conv is a per-(image, channel) affine map of the conv's input, i.e. a per-image filter, and the
+ * normalised tensor need not exist.  (8 * 32 / (Cout / 128)) % B == 0.  glare_attn_fold_groupnorm_f32 builds the two per-image
+ * filters of AttnBlock (norm -> q / k / v 1x1 -> bmm softmax bmm -> proj_out, encoder_decoder.py:146-188) from the tensor's GroupNorm
+ * statistics block [B][splits][32][2] and the folded projections wq = s Wk^T Wq, bq = s Wk^T bq_ref, wo = Wp Wv, bo = Wp bv + bp
+ * (fp32 [C][C] / [C]): with a = rstd gamma, d = beta - mean a:  wq_out = diag(a) wq diag(a), bq_out = a o (wq d + bq),
+ * wo_out = wo diag(a), bo_out = wo d + bo;  attention then runs with keys = values = the RAW tensor. */
+int glare_conv1x1_ws_image_bf16(const void* x, int x_pitch, int x_off, const void* w_bf16, long long w_image_stride, const float* bias,
+                                int bias_image_stride, const void* residual, int res_pitch, int res_off, void* out, int out_pitch,
+                                int out_off, int B, long long pixels_per_image, int Cin, int Cout, int act, float* gn_partial,
+                                glare_stream_t stream);
+int glare_attn_fold_groupnorm_f32(const float* stats, int splits, int B, long long HW, int C, const float* gamma, const float* beta,
+                                  float eps, const float* wq, const float* bq, const float* wo, const float* bo, void* wq_out,
+                                  float* bq_out, void* wo_out, float* bo_out, glare_stream_t stream);
 
 /* ---- a2: blockwise spatial self-attention, one head, d = 512 ---------------------------------
  * Replaces the bmm / softmax / bmm of AttnBlock.forward (encoder_decoder.py:176-188) without the

@@ -308,3 +308,37 @@ def test_attn_block_shared_kv_form_equals_the_projected_form():
     e_new, e_old = float((new - ref).norm() / ref.norm()), float((old - ref).norm() / ref.norm())
     print("AttnBlock rel err vs fp32 oracle: shared-KV %.2e, projected %.2e" % (e_new, e_old))
     assert e_new < 4e-3 and e_old < 4e-3
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 9, 13), (8, 12, 20), (1, 33, 31)])
+def test_attn_block_with_the_groupnorm_folded_into_per_image_filters(B, H, W):
+    """AttnBlock on an input that carries its producer's fused GroupNorm statistics: the norm becomes per-image 1x1 filters
+    (glare_attn_fold_groupnorm_f32 + glare_conv1x1_ws_image_bf16) and the attention's keys / values are the raw input.  Against
+    the fp32 oracle block and against the same block with the normalised tensor materialised; an input with a large per-channel
+    mean (what the dropped softmax constant has to absorb) included."""
+    from glare_amd.modules import encoder_decoder as ED
+    from glare_amd.modules._base import to_nhwc
+    from glare_amd.synthetic import seeded_init_
+    from oracle import torch_ref as O
+
+    ob = seeded_init_(O.AttnBlock(512).eval(), 5)
+    pb = ED.AttnBlock(512).eval()
+    pb.load_state_dict(ob.state_dict(), strict=True)
+    pb.cuda()
+    g = torch.Generator().manual_seed(B * 100 + H)
+    x = torch.randn(B, 512, H, W, generator=g) * (0.5 + torch.rand(1, 512, 1, 1, generator=g)) + torch.randn(1, 512, 1, 1, generator=g) * 2.0
+    x = x.to(torch.bfloat16).float()
+    with torch.no_grad():
+        ref = ob(x)
+        xd = to_nhwc(x.cuda())
+        with_stats = ops.add_bf16(xd, torch.zeros_like(xd), gn_stats=True)       # the same values + the statistics block
+        assert torch.equal(with_stats, xd) and getattr(with_stats, "_gn_stats", None) is not None
+        assert ED.GN_FOLDED_ATTENTION
+        folded = pb.forward_nhwc(with_stats)
+        plain = pb.forward_nhwc(xd)                                              # no statistics on the input: norm materialised
+        assert getattr(folded, "_gn_stats", None) is not None
+    nchw = lambda t: t.float().cpu().permute(0, 3, 1, 2)
+    e_f, e_p = float((nchw(folded) - ref).norm() / ref.norm()), float((nchw(plain) - ref).norm() / ref.norm())
+    print("AttnBlock rel err vs fp32 oracle: GroupNorm folded %.2e, materialised %.2e" % (e_f, e_p))
+    assert e_f < 4e-3 and e_p < 4e-3
+    assert float((folded.float() - plain.float()).norm() / plain.float().norm()) < 4e-3
