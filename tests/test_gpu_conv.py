@@ -368,3 +368,41 @@ def test_narrower_output_channel_tiles_give_the_same_bits(B, Cin, Cout, H, W, k,
     assert pick(i(2), i(80), i(80), i(512)) == 64 and pick(i(2), i(80), i(80), i(64)) == 64 and pick(i(1), i(8), i(8), i(16)) == 32
     with pytest.raises(_lib.GlareError):      # the fused GroupNorm statistics are laid out for the 128-wide tile
         ops.conv2d(_nhwc_bf16(_rand((1, 128, 16, 32), g)), ops.PackedConv(_rand((128, 128, 3, 3), g).cuda(), cout_tile=64), gn_stats=True)
+
+
+def test_groupnorm_fold_builds_the_per_image_filters_and_the_1x1_kernel_applies_them():
+    """glare_attn_fold_groupnorm_f32 against the same algebra in fp64 torch; glare_conv1x1_ws_image_bf16 against eight separate
+    convs with those filters; a batch that does not divide the kernel's 64 pixel ranges is refused (the caller then materialises
+    the norm)."""
+    from glare_amd import _lib
+
+    g = torch.Generator().manual_seed(11)
+    B, H, W, C = 4, 10, 14, 512
+    x = _nhwc_bf16(_rand((B, C, H, W), g) * 1.5 + 0.7)
+    xs = ops.add_bf16(x, torch.zeros_like(x), gn_stats=True)
+    stats = xs._gn_stats
+    gamma, beta = (_rand((C,), g) * 0.3 + 1.0).cuda(), (_rand((C,), g) * 0.2).cuda()
+    wq, wo = (_rand((C, C), g) * C ** -0.5).cuda(), (_rand((C, C), g) * C ** -0.5).cuda()
+    bq, bo = _rand((C,), g).cuda(), _rand((C,), g).cuda()
+    wq_b, bq_b, wo_b, bo_b = ops.attn_fold_groupnorm(stats, H * W, gamma, beta, 1e-6, wq, bq, wo, bo)
+    xf = x.double().view(B, H * W, 32, C // 32)
+    mean, var = xf.mean(dim=(1, 3)), xf.var(dim=(1, 3), unbiased=False)                    # [B, 32]
+    a = (gamma.double().view(32, -1) / torch.sqrt(var + 1e-6).unsqueeze(-1)).reshape(B, C)
+    d = beta.double() - (mean.unsqueeze(-1) * a.view(B, 32, -1)).reshape(B, C)
+    ref_wq = a.unsqueeze(2) * wq.double() * a.unsqueeze(1)
+    ref_bq = a * (torch.einsum("oc,bc->bo", wq.double(), d) + bq.double())
+    ref_wo = wo.double() * a.unsqueeze(1)
+    ref_bo = torch.einsum("oc,bc->bo", wo.double(), d) + bo.double()
+    rel = lambda u, v: float((u.double() - v).norm() / v.norm())
+    assert rel(wq_b, ref_wq) < 3e-3 and rel(wo_b, ref_wo) < 3e-3            # bf16 rounding of the filters (2^-9)
+    assert rel(bq_b, ref_bq) < 1e-5 and rel(bo_b, ref_bo) < 1e-5
+    r = _nhwc_bf16(_rand((B, C, H, W), g))
+    got = ops.conv1x1_per_image(x, wo_b, bo_b, residual=r, gn_stats=True)
+    for b in range(B):
+        pc = ops.PackedConv(wo_b[b].float()[:, :, None, None].contiguous(), bo_b[b])
+        one = ops.conv2d(x[b:b + 1].contiguous(), pc, residual=r[b:b + 1].contiguous())
+        assert torch.equal(got[b:b + 1], one)                                              # same kernel, same contraction order
+    assert getattr(got, "_gn_stats", None) is not None
+    x3 = x[:3].contiguous()
+    with pytest.raises(_lib.GlareError):
+        ops.conv1x1_per_image(x3, wo_b[:3].contiguous(), bo_b[:3].contiguous())            # 64 % 3 != 0
