@@ -748,7 +748,8 @@ extern "C" int glare_conv2d_bf16(const glare_conv_desc* d, glare_stream_t stream
   if (p.plane_pitch < (long long)p.OH * p.OW) return GLARE_ERR_INVALID;
   if (d->cout_tile != 0 && (d->upsample == 2 || (d->cout_tile != 32 && d->cout_tile != 64 && d->cout_tile != 128))) return GLARE_ERR_INVALID;
   const Variant v = pick_variant(d->ksize, d->Cout, d->cout_tile);
-  if (d->gn_partial && v.tn != 128) return GLARE_ERR_UNSUPPORTED;   // the fused statistics' partial layout is the 128-wide tile's
+  if (d->gn_partial && v.tn == 32 && d->Cout > 32) return GLARE_ERR_UNSUPPORTED;   // the fused statistics' parts are per 4-row wave
+                                                                                   // slab: the 32-wide tile's waves cover 2 rows
   const int kc = 16 * v.ksteps;
   // a stage must not straddle the two concatenated sources
   if (p.in1 && (p.Cin0 % kc)) return GLARE_ERR_UNSUPPORTED;

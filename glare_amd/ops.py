@@ -61,6 +61,8 @@ class PackedConv:
         self.ksize = kh
         self.subpixel = bool(upsample_subpixel)
         self.cout_tile = 0
+        self._src = (w, bias, dgrad_pad)     # (no copy for fp32 parameters) for_tile() packs other tiles from it on demand
+        self._tiles = {}
         lib = _lib.lib()
         if cout_tile and not self.subpixel:
             one = packed_conv_batch(w.unsqueeze(0), None if bias is None else bias.detach().float().reshape(1, -1), dgrad_pad, cout_tile)[0]
@@ -156,7 +158,7 @@ class PackCache:
             if self.ptrs.get(weight.data_ptr()) != tuple(weight.shape) or not weight.is_contiguous() or weight.dtype != torch.float32:
                 return None
             pc = PackedConv(weight, None, dgrad_pad=dgrad_pad, cout_tile=cout_tile)
-            pc._src = weight.detach()
+            pc._param = weight.detach()
             self.entries[key] = pc
             self.table = None
         pc.bias = None if bias is None else bias.detach().float().contiguous()
@@ -169,11 +171,11 @@ class PackCache:
             lib = _lib.lib()
             jobs, begin = [], 0
             for (_, dgrad_pad, cout_tile), pc in self.entries.items():
-                cout, cin, kh, _ = pc._src.shape
+                cout, cin, kh, _ = pc._param.shape
                 kinds = [(1, pc.packed)] if dgrad_pad is not None else [(0, pc.packed)] + ([(2, pc.w16)] if pc.w16 is not None else [])
                 for kind, dst in kinds:
                     j = _PackJob()
-                    check(lib.glare_conv2d_pack_job_init(ctypes.byref(j), _i(kind), ptr(pc._src), _i(cout), _i(cin), _i(kh),
+                    check(lib.glare_conv2d_pack_job_init(ctypes.byref(j), _i(kind), ptr(pc._param), _i(cout), _i(cin), _i(kh),
                                                          _i(dgrad_pad or 0), _i(cout_tile), ptr(dst)), "glare_conv2d_pack_job_init")
                     j.block_begin = begin
                     begin += (j.total + 255) // 256
@@ -214,6 +216,32 @@ def count_flops(family, flops):
     if FLOP_COUNTER is not None:
         FLOP_COUNTER[family] = FLOP_COUNTER.get(family, 0.0) + float(flops)
 
+
+def _for_tile(pc, tile):
+    """The same filter packed for a narrower output-channel tile (cached on the PackedConv)."""
+    other = pc._tiles.get(tile)
+    if other is None:
+        w, bias, dgrad_pad = pc._src
+        other = pc._tiles[tile] = PackedConv(w, bias, dgrad_pad=dgrad_pad, cout_tile=tile)
+    return other
+
+
+# 3x3 convs of the cached (inference) filters pick the output-channel tile per launch (conv_cout_tile): a no-op at the BASELINE batch
+# (every launch fills the chip with the 128-wide tile), +20..60 % on the convs of small launches.  OFF by default: with a narrower
+# tile the fused GroupNorm statistics are summed in another fp32 order, and inference promises that a batch of 8 equals eight
+# single-image runs bit for bit (tests/test_gpu_graph.py); the trainers switch it on around their frozen networks
+# (`with ops.auto_cout_tile():`), where the batch is 1 or 2 and nothing is compared across batch sizes.
+AUTO_COUT_TILE = False
+
+
+class auto_cout_tile:
+    def __enter__(self):
+        global AUTO_COUT_TILE
+        self._prev, AUTO_COUT_TILE = AUTO_COUT_TILE, True
+
+    def __exit__(self, *exc):
+        global AUTO_COUT_TILE
+        AUTO_COUT_TILE = self._prev
 
 CONV1X1_WEIGHT_STATIONARY = True   # False: every 1x1 conv through the implicit-GEMM kernel (conv_igemm.hip, KS = 1)
 
@@ -334,6 +362,13 @@ def conv2d(x, pc, *, x2=None, cin=None, in_off=0, cin2=None, in2_off=0, stride=1
         d.out_pitch = out.shape[1]
         d.plane_pitch = out.shape[2]
     d.out, d.Cout, d.out_off = out.data_ptr(), pc.cout, out_off
+    if (AUTO_COUT_TILE and pc.ksize == 3 and pc.cout > 64 and getattr(pc, "cout_tile", 0) == 0 and not getattr(pc, "subpixel", False)
+            and getattr(pc, "_src", None) is not None):
+        tile = conv_cout_tile(B, OH, OW, pc.cout)
+        if tile == 32 and gn_stats:
+            tile = 64          # the fused GroupNorm statistics need 4-row wave slabs (128- and 64-wide tiles)
+        if tile:
+            pc = _for_tile(pc, tile)
     d.weight_packed = pc.packed.data_ptr()
     d.cout_tile = getattr(pc, "cout_tile", 0)
     d.bias = pc.bias.data_ptr() if pc.bias is not None else None

@@ -169,7 +169,7 @@ class Stage2Trainer:
         """The step without any host synchronisation: returns the loss as a device tensor.  mean_is_gt: None = draw with
         probability train_gt_ratio as the reference does; True / False = forced (GraphedStep draws before choosing a graph)."""
         flag = self.draw_branch() if mean_is_gt is None else bool(mean_is_gt)
-        with torch.no_grad():
+        with torch.no_grad(), ops.auto_cout_tile():
             gt_latent = self.net_hq.encode_nhwc(gt_img)            # LLFlow_model.py:200-201
         self.opt.zero_grad()
         with self.pack_cache:
@@ -212,7 +212,7 @@ class Stage3Trainer:
 
     def step_tensor(self, gt_img, lr_img):
         G = self.netG
-        with torch.no_grad():
+        with torch.no_grad(), ops.auto_cout_tile():
             enc = G.RRDB.forward_nhwc(lr_img)
             lat = G.flowUpsamplerNet.decode_nhwc(enc["color_map"], enc["cond_feat"])
             _, _, feats = self.net_hq.decode_nhwc(lat, want_image=False)

@@ -366,8 +366,14 @@ def test_narrower_output_channel_tiles_give_the_same_bits(B, Cin, Cout, H, W, k,
     assert pick(i(8), i(420), i(620), i(128)) == 128 and pick(i(8), i(105), i(155), i(512)) == 128       # the BASELINE batch: default
     assert pick(i(1), i(256), i(256), i(128)) == 64 and pick(i(1), i(64), i(64), i(512)) == 32          # stage-3 crop
     assert pick(i(2), i(80), i(80), i(512)) == 64 and pick(i(2), i(80), i(80), i(64)) == 64 and pick(i(1), i(8), i(8), i(16)) == 32
-    with pytest.raises(_lib.GlareError):      # the fused GroupNorm statistics are laid out for the 128-wide tile
-        ops.conv2d(_nhwc_bf16(_rand((1, 128, 16, 32), g)), ops.PackedConv(_rand((128, 128, 3, 3), g).cuda(), cout_tile=64), gn_stats=True)
+    # fused GroupNorm statistics: the 64-wide tile keeps the 4-row wave slabs of the 128-wide one (same sums, another fp32 order);
+    # the 32-wide tile's waves cover 2 rows each and are refused
+    xs, ws = _nhwc_bf16(_rand((1, 128, 16, 32), g)), _rand((128, 128, 3, 3), g).cuda()
+    s128 = ops.conv2d(xs, ops.PackedConv(ws), gn_stats=True)._gn_stats.double().sum(1)
+    s64 = ops.conv2d(xs, ops.PackedConv(ws, cout_tile=64), gn_stats=True)._gn_stats.double().sum(1)
+    assert float((s128 - s64).abs().max() / s128.abs().max()) < 1e-6
+    with pytest.raises(_lib.GlareError):
+        ops.conv2d(xs, ops.PackedConv(ws, cout_tile=32), gn_stats=True)
 
 
 def test_groupnorm_fold_builds_the_per_image_filters_and_the_1x1_kernel_applies_them():
