@@ -271,13 +271,36 @@ class ConEncoder1(nn.Module):
 # --------------------------------------------------------------------------------------------
 # Normalizing flow              FlowActNorms.py, Permutations.py, flow.py, FlowStep.py, ...
 # --------------------------------------------------------------------------------------------
-class ActNorm2d(nn.Module):  # FlowActNorms.py:10-100 (no data-dependent init: eval / pre-set params)
-    def __init__(self, c):
+class ActNorm2d(nn.Module):  # FlowActNorms.py:10-100
+    def __init__(self, c, scale=1.0):
         super().__init__()
         self.bias = nn.Parameter(torch.zeros(1, c, 1, 1))
         self.logs = nn.Parameter(torch.zeros(1, c, 1, 1))
+        self.scale = float(scale)
+        self.inited = False  # :23
+
+    def initialize_parameters(self, x):  # :32-46: data-dependent init on the first TRAINING forward of an all-zero bias
+        if not self.training:
+            return
+        if (self.bias != 0).any():
+            self.inited = True
+            return
+        with torch.no_grad():
+            def mean(t):  # thops.mean (thops.py:19-33): one dimension at a time, in sorted order
+                for d in (0, 2, 3):
+                    t = t.mean(dim=d, keepdim=True)
+                return t
+
+            bias = mean(x.clone()) * -1.0
+            var = mean((x.clone() + bias) ** 2)
+            logs = torch.log(self.scale / (torch.sqrt(var) + 1e-6))
+            self.bias.data.copy_(bias.data)
+            self.logs.data.copy_(logs.data)
+            self.inited = True
 
     def forward(self, x, logdet=None, reverse=False):
+        if not self.inited:  # :82-83
+            self.initialize_parameters(x)
         pixels = x.shape[2] * x.shape[3]
         if not reverse:
             x = (x + self.bias) * torch.exp(self.logs)
@@ -412,6 +435,11 @@ class FlowUpsamplerNet(nn.Module):  # FlowUpsamplerNet.py:17-326 at confs/LOL.ym
         for layer in self.layers:
             z, logdet = layer(z, logdet, False, ft)
         return z, logdet
+
+    def forward(self, gt=None, rrdbResults=None, z=None, epses=None, logdet=0.0, reverse=False, eps_std=None, y_onehot=None):
+        """The reference's call form (FlowUpsamplerNet.py:216-226)."""
+        ft = rrdbResults["cond_feat"] if isinstance(rrdbResults, dict) else rrdbResults
+        return self.decode(z, ft, logdet) if reverse else self.encode(gt, ft, logdet)
 
     def decode(self, z, ft, logdet=None):  # :290-326
         if logdet is None:

@@ -15,6 +15,7 @@ Fixtures (all float32 unless noted):
   harness.npz   pre-processing (impad + t + log, infer_dataset_lol.py:124-128) and PSNR
                 (utils2.py:32-36) on a seeded uint8 image.
   stage2_grads.npz  the reference's stage-2 objective: nll + per-parameter gradient norms and seeded projections.
+  actnorm_ddi.npz  the data-dependent ActNorm initialisation of a fresh flow's first training forward: all 248 bias / logs, z, nll.
   msssim.npz    msssim(normalize=True) of modules/pytorch_msssim (stage-3 loss term), its gradient, and ssim() level 0.
   graph.npz     end-to-end stage checksums of the full LOL.yml graph A->B->C/D (E needs CUDA in the
                 reference) on a 1x3x24x32 input with seeded weights: outputs only (the 132 M weights
@@ -221,7 +222,35 @@ def stage2_grads_fixture(train_gt_ratio=0.0, fname="stage2_grads.npz"):
                         names=np.array(names), norms=np.array(norms), sketches=np.stack(sk))
 
 
+def actnorm_ddi_fixture():
+    """actnorm_ddi.npz: the REFERENCE's first training forward of a fresh flow (all ActNorms zero, FlowActNorms.py:32-46,82-83) on
+    a seeded 2x3x64x64 batch with name-seeded weights (Conv2dZeros non-zero, so the coupling is not the identity): the bias / logs
+    every one of the 124 ActNorms ends up with, the encoded z and the per-sample nll."""
+    R.install()
+    import models.modules.LLFlowVQGAN_arch as arch
+    from glare_amd.synthetic import reset_actnorms_
+
+    opt = R.load_opt()
+    opt["train_gt_ratio"] = 0.0
+    ref = arch.LLFlowVQGAN2(opt=opt, K=12)
+    seeded_init_(ref, 8)
+    reset_actnorms_(ref)
+    ref.train()
+    g = torch.Generator().manual_seed(9)
+    lr = torch.randn(2, 3, 64, 64, generator=g) * 0.5 - 1.0
+    gt = torch.randn(2, 3, 16, 16, generator=g) * torch.tensor([1.5, 0.6, 2.5]).view(1, 3, 1, 1) + torch.tensor([0.3, -1.0, 2.0]).view(1, 3, 1, 1)
+    z, nll, _ = ref(gt=gt, lr=lr, reverse=False)
+    sd = ref.state_dict()
+    names = [k for k in sd if "actnorm" in k]
+    assert len(names) == 2 * (28 + 4 * 24) and all((sd[k] != 0).any() for k in names)
+    np.savez_compressed(os.path.join(HERE, "actnorm_ddi.npz"), lr=lr.numpy(), gt=gt.numpy(), nll=nll.detach().numpy(),
+                        z=z.detach().numpy(), names=np.array(names), **{"p%03d" % i: sd[k].numpy().reshape(-1) for i, k in enumerate(names)})
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "actnorm":
+        actnorm_ddi_fixture()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "msssim":
         msssim_fixture()
     elif len(sys.argv) > 1 and sys.argv[1] == "stage2":

@@ -169,3 +169,18 @@ def test_ssim_metric_matches_reference_vector(golden):
     g = golden("ssim_metric")
     assert abs(O.ssim_utils2(g["target"], g["restored"]) - float(g["ssim"])) < 2e-6     # the reference value is float32
     assert abs(O.ssim_utils2(g["target"], g["target"]) - 1.0) < 1e-12
+
+
+def test_actnorm_data_dependent_init(golden):
+    """The oracle's first training forward of a fresh flow against what the REFERENCE produced (actnorm_ddi.npz): all 248
+    ActNorm tensors, z and nll (FlowActNorms.py:32-46,82-83)."""
+    from glare_amd.synthetic import reset_actnorms_
+
+    g = golden("actnorm_ddi")
+    m = reset_actnorms_(seeded_init_(O.LLFlowVQGAN2(), 8)).train()
+    z, nll, _ = m.normal_flow(torch.from_numpy(g["gt"]), torch.from_numpy(g["lr"]))
+    sd = m.state_dict()
+    for i, k in enumerate(g["names"]):
+        assert np.array_equal(sd[str(k)].numpy().reshape(-1), g["p%03d" % i]), k
+    assert np.array_equal(z.detach().numpy(), g["z"])
+    np.testing.assert_allclose(nll.detach().numpy(), g["nll"], rtol=1e-6)

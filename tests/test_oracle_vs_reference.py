@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from glare_amd.synthetic import seeded_init_, synthetic_lowlight
+from glare_amd.synthetic import reset_actnorms_, seeded_init_, synthetic_lowlight
 from oracle import refimport as R
 from oracle import torch_ref as O
 
@@ -96,6 +96,46 @@ def test_stage2_normal_flow(nets):
     for n, p in mine.named_parameters():
         if p.grad is not None:
             np.testing.assert_allclose(p.grad.numpy(), gr[n].grad.numpy(), rtol=1e-4, atol=1e-6)
+
+
+def test_actnorm_data_dependent_init_bit_identical(nets):
+    """First TRAINING forward of a flow whose ActNorms are all-zero (FlowActNorms.py:32-46,82-83): every one of the 28 step
+    ActNorms and the 48 + 48 coupling-net ActNorms (flow.py:48-52) takes its bias / logs from the batch, each seeing the layers
+    initialised before it."""
+    import models.modules.LLFlowVQGAN_arch as arch
+
+    opt = R.load_opt()
+    opt["train_gt_ratio"] = 0.0
+    ref = arch.LLFlowVQGAN2(opt=opt, K=12)
+    seeded_init_(ref, 4)
+    mine = O.LLFlowVQGAN2()
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    reset_actnorms_(ref)
+    reset_actnorms_(mine)
+    ref.train()
+    mine.train()
+    g = torch.Generator().manual_seed(7)
+    lr = torch.log(torch.rand(2, 3, 32, 32, generator=g) * 0.3 + 1e-3)
+    gt = torch.randn(2, 3, 8, 8, generator=g) * 1.7 + 0.4
+    z_r, nll_r, _ = ref(gt=gt.clone(), lr=lr.clone(), reverse=False)
+    z_o, nll_o, _ = mine.normal_flow(gt, lr)
+    sr, so = ref.state_dict(), mine.state_dict()
+    n = 0
+    for k in so:
+        if "actnorm" in k:
+            assert torch.equal(sr[k], so[k]), k
+            assert (so[k] != 0).any(), k
+            n += 1
+    assert n == 2 * (28 + 4 * 24)
+    assert torch.equal(z_r, z_o)
+    np.testing.assert_allclose(nll_o.detach().numpy(), nll_r.detach().numpy(), rtol=1e-6)
+    # a second forward leaves the parameters alone (inited), and eval mode never initialises
+    before = {k: v.clone() for k, v in mine.state_dict().items()}
+    mine.normal_flow(gt * 2, lr)
+    assert all(torch.equal(before[k], v) for k, v in mine.state_dict().items())
+    fresh = O.LLFlowVQGAN2().eval()
+    fresh.normal_flow(gt, lr)
+    assert all((m.bias == 0).all() for m in fresh.modules() if isinstance(m, O.ActNorm2d))
 
 
 def test_msssim_bit_identical_to_reference():
