@@ -84,9 +84,9 @@ def attention_roofline(device, batch, live_events, reps=5):
     N, C = 105 * 155, 512
     live = [s.elapsed_time(e) for s, e, b, n in live_events if b == batch and n == N]
     g = torch.Generator().manual_seed(0)
-    q = (torch.randn(batch, N, C, generator=g) * 0.3).to(torch.bfloat16).to(device)
-    x = torch.randn(batch, N, C, generator=g).to(torch.bfloat16).to(device)
-    out = torch.empty(batch, N, C, dtype=torch.bfloat16, device=device)
+    q = (torch.randn(batch, N, C, generator=g) * 0.3).to(ops.act_dtype()).to(device)
+    x = torch.randn(batch, N, C, generator=g).to(ops.act_dtype()).to(device)
+    out = torch.empty(batch, N, C, dtype=ops.act_dtype(), device=device)
     for _ in range(2):
         ops.attention_kv512(q, x, N, out=out, key_splits=1)
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -144,6 +144,10 @@ def main():
                          "roofline's per-launch event timing is the kernel's own duration.  2: consecutive batches overlap (the "
                          "tail of one step's kernels and its latency-bound flow section run under the next step's convs): +3 %% "
                          "throughput, but a launch then shares the GPU and its event-timed duration is no longer a kernel figure")
+    ap.add_argument("--precision", choices=("bf16", "fp16"), default="fp16",
+                    help="16-bit format of activations and filters: fp16 (default: IEEE half, the reference's own autocast dtype and "
+                         "the precision the end-to-end tolerance is met in; libglare_hip_f16.so) or bf16 (libglare_hip.so, +2.7 %% "
+                         "images/s, 8x the rounding per stored tensor).  The JSON line's `dtype` names what ran")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="per-stage timing on stderr")
     args = ap.parse_args()
@@ -171,6 +175,9 @@ def main():
         dist.init_process_group("nccl", device_id=device)  # RCCL on ROCm
         assert dist.get_world_size() == args.gpus and dist.get_backend() == "nccl"
 
+    from glare_amd import ops
+
+    ops.use_precision(args.precision).__enter__()     # for the whole process
     netG, net_vq = build_nets(device)
     lr = build_inputs(args.batch, device, seed=1234 + rank)  # every rank enhances different images
 
@@ -234,7 +241,7 @@ def main():
         res = {
             "metric": "enhanced images/sec (400x600)", "value": round(total_images / dt, 3), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "LOL eval15-shaped 400x600 inference, batch=8 per GPU, full encoder->flow->VQ->decoder->AFT "
                                    "(BASELINE configs[1])", "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "input": "3x400x600 (reflect-padded to 420x620)", "parallelism": "dp%d" % world,

@@ -13,9 +13,16 @@ import torch  # noqa: F401  (must precede the CDLL load, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libglare_hip.so")
+LIB_F16_PATH = os.path.join(_HERE, "libglare_hip_f16.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "glare_hip.h")
 
 _lib = None
+_lib_f16 = None
+# The 16-bit activation / filter format of the kernels in use: "bf16" (libglare_hip.so) or "fp16" (libglare_hip_f16.so).
+# None = not set by any enclosing use_precision(): plain ops (and everything with a tape) then run bf16, the inference entry
+# points (VQLLFLOWDeformable.reverse_flow_nhwc, glare_amd.infer, bench.py) run INFERENCE_PRECISION.
+_PRECISION = None
+INFERENCE_PRECISION = "fp16"
 
 
 class GlareError(RuntimeError):
@@ -30,8 +37,80 @@ def header_symbols():
     return sorted(set(re.findall(r"\b(glare_[a-z0-9_]+)\s*\(", text)))
 
 
+def precision():
+    return _PRECISION or "bf16"
+
+
+def inference_precision(requested=None):
+    """Precision of an inference entry point: the caller's request, else the enclosing use_precision(), else fp16 -- the
+    reference's own autocast dtype (infer_dataset_lol.py:134) and what the end-to-end tolerance needs."""
+    return requested or _PRECISION or INFERENCE_PRECISION
+
+
+def act_dtype():
+    """torch dtype of 16-bit activations / packed filters under the current precision."""
+    return torch.bfloat16 if precision() == "bf16" else torch.float16
+
+
+class use_precision:
+    """`with use_precision("fp16"):` -- ops run the IEEE-half twin of the inference kernels (libglare_hip_f16.so: same kernels,
+    same MFMA rate, 11 instead of 8 mantissa bits in every stored activation and filter: the path's parity mode; the
+    reference's own autocast dtype, infer_dataset_lol.py:134).  None keeps the current one."""
+
+    def __init__(self, name):
+        assert name in (None, "bf16", "fp16"), name
+        self.name = name
+
+    def __enter__(self):
+        global _PRECISION
+        self._prev = _PRECISION
+        if self.name is not None:
+            _PRECISION = self.name
+        return self
+
+    def __exit__(self, *exc):
+        global _PRECISION
+        _PRECISION = self._prev
+
+
+# entry points without any 16-bit tensor in their signature: under "fp16" they resolve to the main library
+_DTYPE_AGNOSTIC = ("glare_vq_", "glare_harness_", "glare_ssim_")
+
+
+class _F16Lib:
+    """libglare_hip_f16.so behind the main library's names: `x_bf16` resolves to its export `x_f16`.  An entry point the half
+    library does not have (training kernels) raises -- it must never silently run a bf16 kernel on fp16 data."""
+
+    def __init__(self, cdll):
+        self._c = cdll
+
+    def __getattr__(self, name):
+        try:
+            return getattr(self._c, name.replace("bf16", "f16"))
+        except AttributeError:
+            if name.startswith(_DTYPE_AGNOSTIC):
+                return getattr(main_lib(), name)
+            raise GlareError("%s is not part of libglare_hip_f16.so (the fp16 precision covers the inference kernels)" % name)
+
+
 def lib():
-    """The loaded CDLL; raises GlareError when the HIP extension has not been built."""
+    """The library of the current precision (use_precision); raises GlareError when the HIP extension has not been built."""
+    if precision() == "fp16":
+        global _lib_f16
+        if _lib_f16 is None:
+            main_lib()
+            if not os.path.exists(LIB_F16_PATH):
+                raise GlareError("libglare_hip_f16.so is not built (%s): run __graft_entry__.build()" % LIB_F16_PATH)
+            c = ctypes.CDLL(LIB_F16_PATH, mode=ctypes.RTLD_LOCAL)
+            c.glare_status_string.restype = ctypes.c_char_p
+            c.glare_status_string.argtypes = [ctypes.c_int]
+            _lib_f16 = _F16Lib(c)
+        return _lib_f16
+    return main_lib()
+
+
+def main_lib():
+    """libglare_hip.so (bf16 activations; every entry point of include/glare_hip.h)."""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
@@ -50,7 +129,7 @@ def lib():
 
 def check(status, what):
     if status != 0:
-        raise GlareError("%s failed: %s (%d)" % (what, lib().glare_status_string(status).decode(), status))
+        raise GlareError("%s failed: %s (%d)" % (what, main_lib().glare_status_string(status).decode(), status))
 
 
 def ptr(t):

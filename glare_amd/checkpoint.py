@@ -31,8 +31,8 @@ def load_network(path_or_state, network, strict=True, submodule=None):
 GRAD_SCALER_STATE = {"scale": 65536.0, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2000, "_growth_tracker": 0}
 """What an enabled torch.cuda.amp.GradScaler.state_dict() holds at its defaults.  The reference creates `GradScaler()`
 (LLFlow_model.py:120, VQLLFLOWD_model.py:126) and its resume path calls `scaler.load_state_dict(state['scaler'])`, which raises on
-an empty dict -- so the saved training state always carries these keys.  This path computes the loss in fp32 and needs no loss
-scaling: on resume the scaler entry is accepted and ignored."""
+an empty dict -- so the saved training state always carries these keys.  FlatAdam keeps the same state on the device (scale and
+growth tracker move as GradScaler.update moves them; a step with inf / NaN gradients is skipped): saved from there, restored on resume."""
 
 
 def adam_state_dict(opt):
@@ -64,11 +64,9 @@ def load_adam_state_dict(opt, sd):
         assert len(sg["params"]) == len(g.params), "parameter count of a group differs"
         g.lr, g.weight_decay = float(sg["lr"]), float(sg.get("weight_decay", 0.0))
         off = 0
-        g.has_grad = []
         for p, pid in zip(g.params, sg["params"]):
             k = p.numel()
-            st = sd["state"].get(pid)
-            g.has_grad.append(st is not None)
+            st = sd["state"].get(pid)      # which parameters Adam updates is static (FlatGroup never_used), not read from the file
             if st is None:               # torch keeps no state for parameters that never received a gradient
                 g.m[off:off + k].zero_()
                 g.v[off:off + k].zero_()
@@ -82,7 +80,8 @@ def load_adam_state_dict(opt, sd):
 
 def save_training_state(path, trainer, epoch, iter_step, schedulers=()):
     torch.save({"epoch": epoch, "iter": iter_step, "schedulers": [s.state_dict() for s in schedulers],
-                "optimizers": [adam_state_dict(trainer.opt)], "scaler": dict(GRAD_SCALER_STATE)}, path)
+                "optimizers": [adam_state_dict(trainer.opt)],
+                "scaler": trainer.opt.scaler_state_dict() if hasattr(trainer.opt, "scaler_state_dict") else dict(GRAD_SCALER_STATE)}, path)
 
 
 def resume_training(path_or_state, trainer, schedulers=()):
@@ -90,6 +89,8 @@ def resume_training(path_or_state, trainer, schedulers=()):
     assert len(st["optimizers"]) == 1, "Wrong lengths of optimizers"
     assert len(st["schedulers"]) == len(schedulers), "Wrong lengths of schedulers"
     load_adam_state_dict(trainer.opt, st["optimizers"][0])
+    if hasattr(trainer.opt, "load_scaler_state_dict"):
+        trainer.opt.load_scaler_state_dict(st.get("scaler"))
     for s, sd in zip(schedulers, st["schedulers"]):
         s.load_state_dict(sd)
     return st["epoch"], st["iter"]

@@ -71,10 +71,10 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 struct AttnParams {
-  const bf16_t* q;
-  const bf16_t* k;
-  const bf16_t* vt;
-  bf16_t* o;
+  const a16_t* q;
+  const a16_t* k;
+  const a16_t* vt;
+  a16_t* o;
   int B, N;
   long long Npad;
   int ldq, ldk, ldo;
@@ -104,14 +104,14 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
   const bool q_ok = qrow < p.N;
 
   // Q^T B-fragments: lane (q, hi) holds Q[q][16*ks + 8*hi .. +8]
-  bf16x8 qf[HD / 16];
+  a16x8 qf[HD / 16];
   {
-    const bf16_t* qp = p.q + ((size_t)b * p.N + (q_ok ? qrow : 0)) * p.ldq + hi * 8;
+    const a16_t* qp = p.q + ((size_t)b * p.N + (q_ok ? qrow : 0)) * p.ldq + hi * 8;
 #pragma unroll
     for (int ks = 0; ks < HD / 16; ++ks) {
       u32x4 v = *reinterpret_cast<const u32x4*>(qp + ks * 16);
       if (!q_ok) v = u32x4{0u, 0u, 0u, 0u};
-      qf[ks] = __builtin_bit_cast(bf16x8, v);
+      qf[ks] = __builtin_bit_cast(a16x8, v);
     }
   }
 
@@ -125,8 +125,8 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
   const int n_tiles = (p.N + BN - 1) / BN;
   // this workgroup's key tiles (all of them unless the keys are split across workgroups to fill the chip at small batch)
   const int t_begin = (int)((long long)n_tiles * ksplit / p.key_splits), t_end = (int)((long long)n_tiles * (ksplit + 1) / p.key_splits);
-  const bf16_t* kbase = p.k + (size_t)b * p.N * p.ldk;
-  const bf16_t* vbase = p.vt + (size_t)b * HD * p.Npad;
+  const a16_t* kbase = p.k + (size_t)b * p.N * p.ldk;
+  const a16_t* vbase = p.vt + (size_t)b * HD * p.Npad;
 
   // DMA source addressing: a wave-uniform 64-bit base (SGPRs: image, tile, row) plus ONE 32-bit per-lane
   // offset.  Per-piece 64-bit pointers kept in VGPRs get spilled around the tile loop, and every
@@ -139,9 +139,9 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
   // tile) plus a 32-bit per-lane offset -- no 64-bit vector add per piece; key rows beyond N fall outside the descriptor's
   // range and arrive as zeros (their scores are masked to -inf below), so no row clamp either.
   const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<bf16_t*>(kbase), 0, (int)((((long long)p.N - 1) * p.ldk + HD) * 2), 0x00020000);
+      const_cast<a16_t*>(kbase), 0, (int)((((long long)p.N - 1) * p.ldk + HD) * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t vrsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vbase), 0, (int)((long long)HD * p.Npad * 2), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<a16_t*>(vbase), 0, (int)((long long)HD * p.Npad * 2), 0x00020000);
   const int lane16 = lane * 16;
   auto issue_piece = [&](auto ic, int tile, int buf) {
     constexpr int i = decltype(ic)::value;
@@ -177,16 +177,16 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
   // serialised) hides in the issue slack of the 32-deep dependent S accumulation.  K and V^T keep separate double buffers
   // with different deadlines: during iteration j the DMA fetches K(j+2) and V^T(j+1).
   const char* const kbuf[2] = {smem, smem + KCH * 16};
-  auto ldk = [&](int ks4, const char* kb, bf16x8(&f)[4]) {   // ks4: compile-time group index
+  auto ldk = [&](int ks4, const char* kb, a16x8(&f)[4]) {   // ks4: compile-time group index
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int ks = 4 * ks4 + e;
-      f[e] = *reinterpret_cast<const bf16x8*>(kb + kofs[ks & 7] + (ks >> 3) * 256);
+      f[e] = *reinterpret_cast<const a16x8*>(kb + kofs[ks & 7] + (ks >> 3) * 256);
     }
   };
-  auto ldv = [&](int g, const char* vb, bf16x8(&f)[4]) {
+  auto ldv = [&](int g, const char* vb, a16x8(&f)[4]) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) f[e] = *reinterpret_cast<const bf16x8*>(vb + vofs[e & 1] + (2 * g + (e >> 1)) * 2048);
+    for (int e = 0; e < 4; ++e) f[e] = *reinterpret_cast<const a16x8*>(vb + vofs[e & 1] + (2 * g + (e >> 1)) * 2048);
   };
   auto issue_k = [&](auto ic, int tile, int buf) {   // piece i of a K tile (8 per wave)
     constexpr int i = decltype(ic)::value;
@@ -212,10 +212,10 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
   // registers it frees hold the second score accumulator of the pipeline.
   char* const qslab = smem + 4 * KCH * 16 + wave * 8192 + lane * 16;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) *reinterpret_cast<bf16x8*>(qslab + i * 1024) = qf[24 + i];
-  auto ldq = [&](int g, bf16x8(&f)[4]) {   // g = 6, 7
+  for (int i = 0; i < 8; ++i) *reinterpret_cast<a16x8*>(qslab + i * 1024) = qf[24 + i];
+  auto ldq = [&](int g, a16x8(&f)[4]) {   // g = 6, 7
 #pragma unroll
-    for (int e = 0; e < 4; ++e) f[e] = *reinterpret_cast<const bf16x8*>(qslab + (4 * (g - 6) + e) * 1024);
+    for (int e = 0; e < 4; ++e) f[e] = *reinterpret_cast<const a16x8*>(qslab + (4 * (g - 6) + e) * 1024);
   };
 
   f32x16 s_cur;
@@ -227,18 +227,18 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 16; ++r) s_cur[r] = 0.f;
-    bf16x8 f0[4];
+    a16x8 f0[4];
     static_for<8>([&](auto gc) {
       constexpr int g = decltype(gc)::value;
       ldk(g, kbuf[0], f0);
       if constexpr (g < 6) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s_cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0[e], qf[4 * g + e], s_cur, 0, 0, 0);
+        for (int e = 0; e < 4; ++e) s_cur = mfma_a16_32x32x16(f0[e], qf[4 * g + e], s_cur, 0, 0, 0);
       } else {
-        bf16x8 q0[4];
+        a16x8 q0[4];
         ldq(g, q0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s_cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0[e], q0[e], s_cur, 0, 0, 0);
+        for (int e = 0; e < 4; ++e) s_cur = mfma_a16_32x32x16(f0[e], q0[e], s_cur, 0, 0, 0);
       }
     });
     if (n_tiles == 1) mask_tail(s_cur, 0);
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
     const int t1 = min(tile + 1, n_tiles - 1), t2 = min(tile + 2, n_tiles - 1);   // clamped: redundant reloads, branch-free
     const char* kb = kbuf[BUF ^ 1];                     // K(tile+1)
     const char* vb = smem + BUF * KCH * 16;             // V^T(tile) (vofs carries the V base)
-    bf16x8 fr[3][4], qt[4];
+    a16x8 fr[3][4], qt[4];
     f32x16 s_nxt;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s_nxt[r] = 0.f;
@@ -273,10 +273,10 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
       if constexpr (g == 5) ldq(6, qt);                 // Q tail for group 6, one group ahead
       if constexpr (g < 6) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s_nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g % 3][e], qf[4 * g + e], s_nxt, 0, 0, 0);
+        for (int e = 0; e < 4; ++e) s_nxt = mfma_a16_32x32x16(fr[g % 3][e], qf[4 * g + e], s_nxt, 0, 0, 0);
       } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s_nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g % 3][e], qt[e], s_nxt, 0, 0, 0);
+        for (int e = 0; e < 4; ++e) s_nxt = mfma_a16_32x32x16(fr[g % 3][e], qt[e], s_nxt, 0, 0, 0);
         if constexpr (g == 6) ldq(7, qt);               // reuses the registers group 6 has just consumed
       }
       if constexpr (g == 0) {
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
           const float p0 = __builtin_amdgcn_exp2f(s_cur[4 * q4 + 2 * e] - m_run);
           const float p1 = __builtin_amdgcn_exp2f(s_cur[4 * q4 + 2 * e + 1] - m_run);
           psum += p0 + p1;
-          w[q4 >> 1][2 * (q4 & 1) + e] = pack_bf2(p0, p1);
+          w[q4 >> 1][2 * (q4 & 1) + e] = pack_a2(p0, p1);
         }
       } else {
         l_run += psum;
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
     // branch-free (a conditional call here costs the register allocator ~60 spills): real tiles mask keys >= N, the redundant
     // tile past the end is masked entirely and never consumed
     mask_tail(s_nxt, tile + 1 < n_tiles ? tile + 1 : n_tiles);
-    const bf16x8 pf[2] = {__builtin_bit_cast(bf16x8, w[0]), __builtin_bit_cast(bf16x8, w[1])};
+    const a16x8 pf[2] = {__builtin_bit_cast(a16x8, w[0]), __builtin_bit_cast(a16x8, w[1])};
     s_cur = s_nxt;
     // ---- phase B: O^T += V^T(tile) . P^T(tile)
     static_for<8>([&](auto gc) {
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
 #endif
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        o[2 * g + (e >> 1)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[(8 + g) % 3][e], pf[e & 1], o[2 * g + (e >> 1)], 0, 0, 0);
+        o[2 * g + (e >> 1)] = mfma_a16_32x32x16(fr[(8 + g) % 3][e], pf[e & 1], o[2 * g + (e >> 1)], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     });
   };
@@ -358,19 +358,19 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
     const int nxt = min(tile + 1, t_end - 1);  // last tile: a redundant reload keeps the loop branch-free
     const char* kb = smem + BUF * KCH * 16;
     const char* vb = smem + BUF * KCH * 16;
-    bf16x8 fr[3][4];
-    auto ldk = [&](auto gc, bf16x8(&f)[4]) {
+    a16x8 fr[3][4];
+    auto ldk = [&](auto gc, a16x8(&f)[4]) {
       constexpr int g = decltype(gc)::value;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int ks = 4 * g + e;
-        f[e] = *reinterpret_cast<const bf16x8*>(kb + kofs[ks & 7] + (ks >> 3) * 256);
+        f[e] = *reinterpret_cast<const a16x8*>(kb + kofs[ks & 7] + (ks >> 3) * 256);
       }
     };
-    auto ldv = [&](auto gc, bf16x8(&f)[4]) {
+    auto ldv = [&](auto gc, a16x8(&f)[4]) {
       constexpr int g = decltype(gc)::value;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) f[e] = *reinterpret_cast<const bf16x8*>(vb + vofs[e & 1] + (2 * g + (e >> 1)) * 2048);
+      for (int e = 0; e < 4; ++e) f[e] = *reinterpret_cast<const a16x8*>(vb + vofs[e & 1] + (2 * g + (e >> 1)) * 2048);
     };
 
     // ---- S^T = K . Q^T  (32 keys x 32 queries, contraction over d = 512)
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
       });
 #endif
 #pragma unroll
-      for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g % 3][e], qf[4 * g + e], s, 0, 0, 0);
+      for (int e = 0; e < 4; ++e) s = mfma_a16_32x32x16(fr[g % 3][e], qf[4 * g + e], s, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     });
     if (tile == n_tiles - 1) {  // mask keys beyond N
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
       m_run = m_new;
     }
     float psum = 0.f;
-    bf16x8 pf[2];
+    a16x8 pf[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       u32x4 w;
@@ -440,9 +440,9 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
         const float p1 = __builtin_amdgcn_exp2f(s[8 * h + 2 * e + 1] - m_run);
 #endif
         psum += p0 + p1;
-        w[e] = pack_bf2(p0, p1);
+        w[e] = pack_a2(p0, p1);
       }
-      pf[h] = __builtin_bit_cast(bf16x8, w);
+      pf[h] = __builtin_bit_cast(a16x8, w);
     }
     l_run += psum;
     __builtin_amdgcn_sched_barrier(0);
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
 #endif
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        o[2 * g + (e >> 1)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[(8 + g) % 3][e], pf[e & 1], o[2 * g + (e >> 1)], 0, 0, 0);
+        o[2 * g + (e >> 1)] = mfma_a16_32x32x16(fr[(8 + g) % 3][e], pf[e & 1], o[2 * g + (e >> 1)], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     });
   };
@@ -491,215 +491,23 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
   const float inv = 1.0f / l_tot;
   if (p.lse && q_ok && hi == 0) p.lse[(size_t)b * p.N + qrow] = m_run + __builtin_amdgcn_logf(l_tot);   // v_log_f32 = log2
   if (q_ok) {
-    bf16_t* op = p.o + ((size_t)b * p.N + qrow) * p.ldo;
+    a16_t* op = p.o + ((size_t)b * p.N + qrow) * p.ldo;
 #pragma unroll
     for (int dt = 0; dt < HD / 32; ++dt)
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
         const int d = dt * 32 + 8 * rq + 4 * hi;
-        u32x2 w = {pack_bf2(o[dt][4 * rq] * inv, o[dt][4 * rq + 1] * inv),
-                   pack_bf2(o[dt][4 * rq + 2] * inv, o[dt][4 * rq + 3] * inv)};
+        u32x2 w = {pack_a2(o[dt][4 * rq] * inv, o[dt][4 * rq + 1] * inv),
+                   pack_a2(o[dt][4 * rq + 2] * inv, o[dt][4 * rq + 3] * inv)};
         *reinterpret_cast<u32x2*>(op + d) = w;
       }
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// 8-wave variant (ATTN_8WAVES): the same 128 query rows and the same LDS images, but 8 waves x 16 rows on
-// v_mfma_f32_16x16x32_bf16: O^T of a wave is 512 x 16 fp32 = 128 registers, Q 64, so TWO waves share a SIMD and cover
-// each other's waits (LDS-DMA issue, fragment reads, the softmax's vector ALU work), and every wave issues half the
-// DMA pieces.  Price: every K / V^T fragment (1 KB) feeds a 16-row MFMA instead of a 32-row one -- twice the LDS read
-// traffic per flop.  Transposed products as above; K rows are fetched in the order key(t, i) = 8*(i>>2) + 4*t + (i&3) so
-// that a lane's two score tiles ARE its P^T B-fragment (keys 8g .. 8g+7 for lane group g = lane>>4).
-typedef __attribute__((ext_vector_type(4))) float f32x4a;
-
-__global__ __launch_bounds__(512, 1) void attn8w_fwd_kernel(const AttnParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  u32x4* lK = reinterpret_cast<u32x4*>(smem);   // [2][KCH]
-  u32x4* lV = lK + 2 * KCH;                     // [2][KCH]
-  int bid = blockIdx.x;
-  {
-    const int n = p.n_blocks, q = n / 8, r = n % 8, xcd = bid % 8, kk = bid / 8;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kk;
-  }
-  const int qb = bid % p.n_qblocks, ksplit = (bid / p.n_qblocks) % p.key_splits, b = bid / (p.n_qblocks * p.key_splits);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int qi = lane & 15, g = lane >> 4;
-  const int qrow = qb * BM + wave * 16 + qi;
-  const bool q_ok = qrow < p.N;
-
-  bf16x8 qf[HD / 32];   // Q^T B-fragments: lane (q, g) holds Q[q][32*ks + 8*g .. +8]
-  {
-    const bf16_t* qp = p.q + ((size_t)b * p.N + (q_ok ? qrow : 0)) * p.ldq + g * 8;
-#pragma unroll
-    for (int ks = 0; ks < HD / 32; ++ks) {
-      u32x4 v = *reinterpret_cast<const u32x4*>(qp + ks * 32);
-      if (!q_ok) v = u32x4{0u, 0u, 0u, 0u};
-      qf[ks] = __builtin_bit_cast(bf16x8, v);
-    }
-  }
-  f32x4a o[HD / 16];
-#pragma unroll
-  for (int i = 0; i < HD / 16; ++i) o[i] = f32x4a{0.f, 0.f, 0.f, 0.f};
-  float m_run = -1e30f, l_run = 0.f;
-
-  const int n_tiles = (p.N + BN - 1) / BN;
-  const int t_begin = (int)((long long)n_tiles * ksplit / p.key_splits), t_end = (int)((long long)n_tiles * (ksplit + 1) / p.key_splits);
-  const bf16_t* kbase = p.k + (size_t)b * p.N * p.ldk;
-  const bf16_t* vbase = p.vt + (size_t)b * HD * p.Npad;
-  const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<bf16_t*>(kbase), 0, (int)((((long long)p.N - 1) * p.ldk + HD) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t vrsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vbase), 0, (int)((long long)HD * p.Npad * 2), 0x00020000);
-  const int lane16 = lane * 16;
-  const unsigned v_lane_off = (unsigned)((lane >> 2) * p.Npad + (((lane & 3) ^ ((lane >> 4) & 3)) * 8)) * 2u;
-  // 64 pieces per tile, 8 per wave: K rows r = wave + 8*i (i < 4), V^T 16-row groups wave + 8*j (j < 4)
-  auto issue_piece = [&](auto ic, int tile, int buf) {
-    constexpr int i = decltype(ic)::value;
-    if constexpr (i < 4) {
-      const int r = wave + 8 * i;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(krsrc, (__attribute__((address_space(3))) void*)(lK + buf * KCH + r * 64), 16,
-                                               lane16 ^ ((r & 15) * 16), (tile * BN + r) * p.ldk * 2, 0, 0);
-    } else {
-      constexpr int j = i - 4;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(vrsrc, (__attribute__((address_space(3))) void*)(lV + buf * KCH + (wave + 8 * j) * 64), 16,
-                                               v_lane_off, (int)(((long long)(wave + 8 * j) * 16 * p.Npad + (long long)tile * BN) * 2), 0, 0);
-    }
-  };
-
-  // fragment addresses: K frag (t, ks): row key(t, qi) of the [32][64 chunks] image, chunk (4*ks + g) ^ (key & 15);
-  //                     V^T frag (dt): row 16*dt + qi of the [512][4 chunks] image, chunk g ^ ((qi >> 2) & 3)
-  int kofs[2][4];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int key = 8 * (qi >> 2) + 4 * t + (qi & 3);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) kofs[t][c] = (key * 64 + (((c << 2) | g) ^ (key & 15))) * 16;
-  }
-  const int vofs = 2 * KCH * 16 + (qi * 4 + (g ^ ((qi >> 2) & 3))) * 16;
-
-  auto tile_body = [&](auto bufc, int tile) {
-    constexpr int BUF = decltype(bufc)::value;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const int nxt = min(tile + 1, t_end - 1);
-    const char* kb = smem + BUF * KCH * 16;
-    // ---- S^T tiles (2 x 16 keys x 16 queries), contraction over d in 16 steps of 32: two independent accumulation chains
-    f32x4a s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-    // fragment reads run one group ahead of the MFMAs through two rotating register sets (fr[set][0..1] = tile-0 rows,
-    // [2..3] = tile-1 rows of two k-steps); the first V^T group is fetched before the softmax
-    bf16x8 fr[2][4];
-    const char* vb = smem + BUF * KCH * 16 + vofs;
-    auto ldk2 = [&](auto gc, bf16x8(&f)[4]) {
-      constexpr int gq = decltype(gc)::value;
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int ks = 2 * gq + e;
-        f[e] = *reinterpret_cast<const bf16x8*>(kb + kofs[0][ks & 3] + (ks >> 2) * 256);
-        f[2 + e] = *reinterpret_cast<const bf16x8*>(kb + kofs[1][ks & 3] + (ks >> 2) * 256);
-      }
-    };
-    auto ldv4 = [&](auto gc, bf16x8(&f)[4]) {
-      constexpr int gq = decltype(gc)::value;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) f[e] = *reinterpret_cast<const bf16x8*>(vb + (4 * gq + e) * 1024);
-    };
-    ldk2(std::integral_constant<int, 0>{}, fr[0]);
-    static_for<8>([&](auto gc) {     // groups of 2 k-steps: 4 fragment reads, 4 MFMAs, 1 DMA piece (register budget: 128 VGPRs)
-      constexpr int gq = decltype(gc)::value;
-      if constexpr (gq + 1 < 8) ldk2(std::integral_constant<int, gq + 1>{}, fr[(gq + 1) & 1]);
-      else ldv4(std::integral_constant<int, 0>{}, fr[(gq + 1) & 1]);
-#ifndef ATTN_ABLATE_NODMA
-      issue_piece(std::integral_constant<int, gq>{}, nxt, BUF ^ 1);
+// The 8-wave variant (ATTN_8WAVES=1; measured 975-995 TFLOP/s against the 4-wave kernel's 1 020-1 050) lives in tools/experiments/.
+#if ATTN_8WAVES
+#include "../../tools/experiments/attn_8waves.inc"
 #endif
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[gq & 1][e], qf[2 * gq + e], s0, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[gq & 1][2 + e], qf[2 * gq + e], s1, 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    if (tile == n_tiles - 1) {   // keys beyond N
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int kv = tile * BN + 8 * g + r;
-        if (kv >= p.N) s0[r] = -__builtin_inff();
-        if (kv + 4 >= p.N) s1[r] = -__builtin_inff();
-      }
-    }
-    // ---- online softmax: a query's 32 keys live in the 4 lanes q, q+16, q+32, q+48
-    float mx = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
-    {
-      const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-      mx = fmaxf(mx, __uint_as_float((g & 1) ? a[0] : a[1]));
-      const auto c = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-      mx = fmaxf(mx, __uint_as_float((g & 2) ? c[0] : c[1]));
-    }
-    if (__any(mx > m_run + RESCALE_THR)) {
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      l_run *= alpha;
-#pragma unroll
-      for (int i = 0; i < HD / 16; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[i][r] *= alpha;   // 128 accumulators: they live in VGPRs here, no AGPR round trip
-      m_run = m_new;
-    }
-    float psum = 0.f;
-    u32x4 w;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const float a0 = __builtin_amdgcn_exp2f(s0[2 * e] - m_run), a1 = __builtin_amdgcn_exp2f(s0[2 * e + 1] - m_run);
-      const float c0 = __builtin_amdgcn_exp2f(s1[2 * e] - m_run), c1 = __builtin_amdgcn_exp2f(s1[2 * e + 1] - m_run);
-      psum += (a0 + a1) + (c0 + c1);
-      w[e] = pack_bf2(a0, a1);
-      w[2 + e] = pack_bf2(c0, c1);
-    }
-    l_run += psum;
-    const bf16x8 pf = __builtin_bit_cast(bf16x8, w);   // P^T B-fragment: keys 8g .. 8g+7 of query qi
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- O^T += V^T . P^T : 32 d-tiles of 16, one 32-key step each
-    static_for<8>([&](auto gc) {     // groups of 4 d-tiles; set parity continues from the S phase (group 8 + gq)
-      constexpr int gq = decltype(gc)::value;
-      if constexpr (gq + 1 < 8) ldv4(std::integral_constant<int, gq + 1>{}, fr[(gq + 1) & 1]);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[4 * gq + e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[gq & 1][e], pf, o[4 * gq + e], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    });
-  };
-
-  static_for<8>([&](auto ic) { issue_piece(ic, t_begin, 0); });
-  for (int tile = t_begin; tile < t_end; tile += 2) {
-    tile_body(std::integral_constant<int, 0>{}, tile);
-    if (tile + 1 < t_end) tile_body(std::integral_constant<int, 1>{}, tile + 1);
-  }
-
-  // ---- epilogue: lane (q, g) holds O[q][16*dt + 4*g + r]
-  float l_tot = l_run;
-  {
-    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(l_tot), __float_as_uint(l_tot), false, false);
-    l_tot += __uint_as_float((g & 1) ? a[0] : a[1]);
-    const auto c = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_tot), __float_as_uint(l_tot), false, false);
-    l_tot += __uint_as_float((g & 2) ? c[0] : c[1]);
-  }
-  if (!q_ok) return;
-  if (p.key_splits > 1) {
-    const size_t row = ((size_t)b * p.key_splits + ksplit) * p.N + qrow;
-    float* po = p.part_o + row * HD;
-#pragma unroll
-    for (int dt = 0; dt < HD / 16; ++dt) *reinterpret_cast<f32x4a*>(po + dt * 16 + 4 * g) = o[dt];
-    if (g == 0) { p.part_ml[row * 2] = m_run; p.part_ml[row * 2 + 1] = l_tot; }
-    return;
-  }
-  const float inv = 1.0f / l_tot;
-  bf16_t* op = p.o + ((size_t)b * p.N + qrow) * p.ldo;
-#pragma unroll
-  for (int dt = 0; dt < HD / 16; ++dt) {
-    u32x2 w2 = {pack_bf2(o[dt][0] * inv, o[dt][1] * inv), pack_bf2(o[dt][2] * inv, o[dt][3] * inv)};
-    *reinterpret_cast<u32x2*>(op + dt * 16 + 4 * g) = w2;
-  }
-}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Shared-K/V form (attn_kv_fwd_kernel): out[i] = sum_j softmax_j(q'_i . x_j) x_j  -- keys AND values are the same tensor x.
@@ -763,14 +571,14 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_kv_fwd_kernel(const AttnPa
   const int qrow = qb * BM + wave * 32 + ql;
   const bool q_ok = qrow < p.N;
 
-  bf16x8 qf[HD / 16];   // Q^T B-fragments: lane (q, hi) holds Q[q][16*ks + 8*hi .. +8]
+  a16x8 qf[HD / 16];   // Q^T B-fragments: lane (q, hi) holds Q[q][16*ks + 8*hi .. +8]
   {
-    const bf16_t* qp = p.q + ((size_t)b * p.N + (q_ok ? qrow : 0)) * p.ldq + hi * 8;
+    const a16_t* qp = p.q + ((size_t)b * p.N + (q_ok ? qrow : 0)) * p.ldq + hi * 8;
 #pragma unroll
     for (int ks = 0; ks < HD / 16; ++ks) {
       u32x4 v = *reinterpret_cast<const u32x4*>(qp + ks * 16);
       if (!q_ok) v = u32x4{0u, 0u, 0u, 0u};
-      qf[ks] = __builtin_bit_cast(bf16x8, v);
+      qf[ks] = __builtin_bit_cast(a16x8, v);
     }
   }
   f32x16 o[HD / 32];
@@ -782,10 +590,10 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_kv_fwd_kernel(const AttnPa
 
   const int n_tiles = (p.N + BN - 1) / BN;
   const int t_begin = (int)((long long)n_tiles * ksplit / p.key_splits), t_end = (int)((long long)n_tiles * (ksplit + 1) / p.key_splits);
-  const bf16_t* kbase = p.k + (size_t)b * p.N * p.ldk;
+  const a16_t* kbase = p.k + (size_t)b * p.N * p.ldk;
   // rows beyond N fall outside the descriptor's range and arrive as zeros: their scores are masked, their values are zero
   const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<bf16_t*>(kbase), 0, (int)((((long long)p.N - 1) * p.ldk + HD) * 2), 0x00020000);
+      const_cast<a16_t*>(kbase), 0, (int)((((long long)p.N - 1) * p.ldk + HD) * 2), 0x00020000);
   // piece i of this wave = key row r = wave + 4*i (1 KB): lane L writes LDS chunk r*64 + L and therefore fetches source chunk
   // L ^ f(r); f(r) = (wave << 2) | (i & 3) for these rows
   const int lane16w = (lane ^ (wave << 2)) * 16;
@@ -835,13 +643,13 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_kv_fwd_kernel(const AttnPa
     PROF_MARK(1);                                  // wait + barrier
     const int nxt = min(tile + 1, t_end - 1);  // last tile: a redundant reload keeps the loop branch-free
     const char* tb = smem + BUF * KCH * 16;
-    bf16x8 fr[3][4];
-    auto ldk = [&](auto gc, bf16x8(&f)[4]) {
+    a16x8 fr[3][4];
+    auto ldk = [&](auto gc, a16x8(&f)[4]) {
       constexpr int g = decltype(gc)::value;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int ks = 4 * g + e;
-        f[e] = *reinterpret_cast<const bf16x8*>(tb + kofs[ks & 7] + (ks >> 3) * 256);
+        f[e] = *reinterpret_cast<const a16x8*>(tb + kofs[ks & 7] + (ks >> 3) * 256);
       }
     };
     // P.V fragments: transpose reads in inline asm.  Through the builtin (__builtin_amdgcn_ds_read_tr16_b64) hipcc cannot tell
@@ -861,7 +669,7 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_kv_fwd_kernel(const AttnPa
       lgkm_wait8<decltype(nc)::value>(f);
     };
     auto vfrag = [&](const u32x2(&f)[8], int e) {
-      return __builtin_bit_cast(bf16x8, u32x4{f[2 * e][0], f[2 * e][1], f[2 * e + 1][0], f[2 * e + 1][1]});
+      return __builtin_bit_cast(a16x8, u32x4{f[2 * e][0], f[2 * e][1], f[2 * e + 1][0], f[2 * e + 1][1]});
     };
 #if ATTNKV_PV_AHEAD == 2
     u32x2 vf[3][8];   // fragments two groups ahead: 16 reads in flight behind the group being consumed, one more than lgkmcnt counts
@@ -882,7 +690,7 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_kv_fwd_kernel(const AttnPa
       issue_piece(gc, nxt, BUF ^ 1);
 #endif
 #pragma unroll
-      for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g % 3][e], qf[4 * g + e], s, 0, 0, 0);
+      for (int e = 0; e < 4; ++e) s = mfma_a16_32x32x16(fr[g % 3][e], qf[4 * g + e], s, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     });
     PROF_MARK(2);                                  // QK^T
@@ -924,7 +732,7 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_kv_fwd_kernel(const AttnPa
     }
 #endif
     float psum = 0.f;
-    bf16x8 pf[2];
+    a16x8 pf[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       u32x4 w;
@@ -940,9 +748,9 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_kv_fwd_kernel(const AttnPa
         const float p1 = __builtin_amdgcn_exp2f(s[8 * h + 2 * e + 1] - m_run);
 #endif
         psum += p0 + p1;
-        w[e] = pack_bf2(p0, p1);
+        w[e] = pack_a2(p0, p1);
       }
-      pf[h] = __builtin_bit_cast(bf16x8, w);
+      pf[h] = __builtin_bit_cast(a16x8, w);
     }
     l_run += psum;
     __builtin_amdgcn_sched_barrier(0);
@@ -975,7 +783,7 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_kv_fwd_kernel(const AttnPa
 #endif
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        o[2 * g + (e >> 1)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(VF_CUR, e), pf[e & 1], o[2 * g + (e >> 1)], 0, 0, 0);
+        o[2 * g + (e >> 1)] = mfma_a16_32x32x16(vfrag(VF_CUR, e), pf[e & 1], o[2 * g + (e >> 1)], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     });
     PROF_MARK(4);                                  // P.V
@@ -1013,442 +821,27 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_kv_fwd_kernel(const AttnPa
   }
   const float inv = 1.0f / l_tot;
   if (q_ok) {
-    bf16_t* op = p.o + ((size_t)b * p.N + qrow) * p.ldo;
+    a16_t* op = p.o + ((size_t)b * p.N + qrow) * p.ldo;
 #pragma unroll
     for (int dt = 0; dt < HD / 32; ++dt)
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
         const int d = dt * 32 + 8 * rq + 4 * hi;
-        u32x2 w = {pack_bf2(o[dt][4 * rq] * inv, o[dt][4 * rq + 1] * inv),
-                   pack_bf2(o[dt][4 * rq + 2] * inv, o[dt][4 * rq + 3] * inv)};
+        u32x2 w = {pack_a2(o[dt][4 * rq] * inv, o[dt][4 * rq + 1] * inv),
+                   pack_a2(o[dt][4 * rq + 2] * inv, o[dt][4 * rq + 3] * inv)};
         *reinterpret_cast<u32x2*>(op + d) = w;
       }
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// attn_kv_pipe_kernel (ATTNKV_PIPELINED = 1 / 2; NOT the default -- a reproducible negative result, see the numbers at the end of
-// this comment): the shared-K/V attention as a THREE-STAGE software pipeline.  In attn_kv_fwd_kernel a tile is
-// QK^T -> softmax -> P.V in sequence: one wave per SIMD means nothing covers the softmax's vector-ALU work (~900 of ~4000
-// cycles per tile, measured) and the 32-deep dependent score accumulation.  Here iteration i runs three INDEPENDENT pieces:
-//     matrix pipe :  S(i+1) = K(i+1).Q^T   interleaved one-for-one with   O += V(i-1).P(i-1)
-//     vector ALU  :  P(i) = softmax-step(S(i))          (in the issue gaps of the 64 MFMAs)
-// so consecutive MFMAs never share an accumulator (the S chain is spaced by a P.V MFMA) and the exponentials, the running
-// max and the bf16 packing hide under the matrix pipe.  Cost: two score tiles and two P tiles live at once (the last quarter
-// of Q moves to a wave-private LDS slab to make room) and four 32-key tiles resident in LDS (i-1: values, i: idle, i+1: keys,
-// i+2: landing) = 128 KB + 32 KB of Q = the whole 160 KB.
-// The deferred rescale is applied at the END of an iteration, when every accumulator holds tiles <= i-1 at the old scale.
-// Every LDS read of the loop is inline asm with hand-counted lgkmcnt (the transpose read forces that, see attn_kv_fwd_kernel;
-// mixing compiler-counted reads into the same phase would make hipcc's own counts wrong): reads are issued in a fixed order,
-// PIPE_D slots ahead of the MFMA pair that consumes them, and retire in order.
-//
-// Measured on MI355X (B = 8, N = 16 275, tools/attn_ablate.sh; same box, TFLOP/s): sequential attn_kv_fwd_kernel 1 127-1 163;
-// three-stage (ATTNKV_PIPELINED=1) 1 035-1 089; two-phase variant with QK^T(i+1) then P.V(i-1) || softmax(i) (=2) 997.
-// The softmax does vanish under the MFMAs (removing it from the pipelined loop changes nothing: 1 024 vs 1 035), but the eight
-// LDS-DMA pieces per tile cost 28-30 % there against 13 % in the sequential kernel (DMA compiled out: 1 326 / 1 291 vs 1 293-
-// 1 315), and staggering the pieces across the waves makes it worse (1 025, 881): with one wave per SIMD every stall of the
-// in-order stream -- DMA issue, the wait at the barrier -- idles the matrix pipe, and the sequential kernel happens to put the
-// DMA issue where the dependent score chain has slack.  What would pay here is a fifth (loader) wave, which 512 registers per
-// wave do not leave room for.
-#ifndef ATTNKV_PIPE_D
-#define ATTNKV_PIPE_D 2
+// The software-pipelined variants (ATTNKV_PIPELINED=1|2; measured 1 035-1 089 / 997 TFLOP/s against 1 127-1 163) live in tools/experiments/.
+#if ATTNKV_PIPELINED != 0
+#include "../../tools/experiments/attn_kv_pipe.inc"
 #endif
-#ifndef ATTNKV_DMA_STAGGER
-#define ATTNKV_DMA_STAGGER 0
-#endif
-
-template <int OFF>
-__device__ __forceinline__ void lds_read_b128(u32x4& dst, int addr) {
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
-}
-template <int N>
-__device__ __forceinline__ void lgkm_wait_kv(u32x4& k, u32x2& v0, u32x2& v1) {
-  asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(k), "+v"(v0), "+v"(v1) : "i"(N));
-}
-template <int N>
-__device__ __forceinline__ void lgkm_wait_kvq(u32x4& k, u32x2& v0, u32x2& v1, u32x4& q) {
-  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(k), "+v"(v0), "+v"(v1), "+v"(q) : "i"(N));
-}
-template <int N>
-__device__ __forceinline__ void lgkm_wait_v(u32x2& v0, u32x2& v1) {
-  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(v0), "+v"(v1) : "i"(N));
-}
-template <int N>
-__device__ __forceinline__ void lgkm_wait_k(u32x4& k) {
-  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(k) : "i"(N));
-}
-
-constexpr int QT_KS = 24;   // k-steps 24..31 of Q live in LDS
-
-__global__ __launch_bounds__(AT_THREADS, 1) void attn_kv_pipe_kernel(const AttnParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  u32x4* lKV = reinterpret_cast<u32x4*>(smem);   // [4][KCH] tile ring, then [4 waves][8 KB] Q tail
-  [[maybe_unused]] constexpr int D = ATTNKV_PIPE_D;
-
-  int bid = blockIdx.x;
-  {
-    const int n = p.n_blocks, q = n / 8, r = n % 8, xcd = bid % 8, kk = bid / 8;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kk;
-  }
-  const int qb = bid % p.n_qblocks, ksplit = (bid / p.n_qblocks) % p.key_splits, b = bid / (p.n_qblocks * p.key_splits);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ql = lane & 31, hi = lane >> 5;
-  const int qrow = qb * BM + wave * 32 + ql;
-  const bool q_ok = qrow < p.N;
-
-  bf16x8 qf[QT_KS];
-  const int qtail = 4 * KCH * 16 + wave * 8192 + lane * 16;   // LDS byte address of this lane's Q-tail fragments
-  {
-    const bf16_t* qp = p.q + ((size_t)b * p.N + (q_ok ? qrow : 0)) * p.ldq + hi * 8;
-#pragma unroll
-    for (int ks = 0; ks < HD / 16; ++ks) {
-      u32x4 v = *reinterpret_cast<const u32x4*>(qp + ks * 16);
-      if (!q_ok) v = u32x4{0u, 0u, 0u, 0u};
-      if (ks < QT_KS) qf[ks] = __builtin_bit_cast(bf16x8, v);
-      else *reinterpret_cast<u32x4*>(smem + qtail + (ks - QT_KS) * 1024) = v;
-    }
-  }
-  f32x16 o[HD / 32];
-#pragma unroll
-  for (int i = 0; i < HD / 32; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
-
-  const int n_tiles = (p.N + BN - 1) / BN;
-  const int t_begin = (int)((long long)n_tiles * ksplit / p.key_splits), t_end = (int)((long long)n_tiles * (ksplit + 1) / p.key_splits);
-  const bf16_t* kbase = p.k + (size_t)b * p.N * p.ldk;
-  const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<bf16_t*>(kbase), 0, (int)((((long long)p.N - 1) * p.ldk + HD) * 2), 0x00020000);
-  const int lane16w = (lane ^ (wave << 2)) * 16;
-  auto issue_piece = [&](auto ic, int tile, int buf) {
-    constexpr int i = decltype(ic)::value;
-    const int r = wave + 4 * i;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(krsrc, (__attribute__((address_space(3))) void*)(lKV + buf * KCH + r * 64), 16,
-                                             lane16w ^ ((i & 3) * 16), (tile * BN + r) * p.ldk * 2, 0, 0);
-  };
-
-  const int krow = (ql & 0x13) | ((ql & 4) << 1) | ((ql & 8) >> 1);
-  const int kf = kv_swz(krow);
-  // fragment addresses INCLUDING the tile buffer's base: the ds offset immediate is 16 bits and the ring spans 128 KB, so the
-  // registers rotate with the ring (kofs -> buffer of K(tile+1), vofs -> buffer of V(tile-1)) instead of the immediates
-  int kofs[8], vofs[4][2];
-#pragma unroll
-  for (int bb = 0; bb < 8; ++bb) kofs[bb] = (krow * 64 + ((2 * bb + hi) ^ kf)) * 16;
-  {
-    const int i16 = lane & 15, g4 = (lane >> 4) & 1;
-#pragma unroll
-    for (int dtl = 0; dtl < 4; ++dtl)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int key = 8 * hi + 4 * h + (i16 >> 2);
-        const int chunk = 4 * dtl + 2 * g4 + ((i16 & 3) >> 1);
-        vofs[dtl][h] = key * 1024 + ((chunk ^ kv_swz(key)) * 16) + (i16 & 1) * 8;
-      }
-  }
-  auto mask_tail = [&](f32x16& sc, int tile) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int kv = tile * BN + 16 * (r >> 3) + 8 * hi + (r & 7);
-      if (kv >= p.N) sc[r] = -__builtin_inff();
-    }
-  };
-
-  // ---- prologue: tiles t_begin (buffer 0) and t_begin + 1 (buffer 1) in flight; buffer 3 stands in for "tile t_begin - 1"
-  // (zeros, multiplied by P = 0 in the first iteration); S(t_begin) computed alone.
-  static_for<8>([&](auto ic) { issue_piece(ic, t_begin, 0); });
-  static_for<8>([&](auto ic) { issue_piece(ic, min(t_begin + 1, t_end - 1), 1); });
-#pragma unroll
-  for (int i = 0; i < 8; ++i) lKV[3 * KCH + wave * 512 + i * 64 + lane] = u32x4{0u, 0u, 0u, 0u};
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __syncthreads();
-  f32x16 s_cur;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) s_cur[r] = 0.f;
-  static_for<HD / 16>([&](auto kc) {
-    constexpr int ks = decltype(kc)::value;
-    u32x4 a;
-    lds_read_b128<(ks >> 3) * 256>(a, kofs[ks & 7]);
-    if constexpr (ks < QT_KS) {
-      lgkm_wait_k<0>(a);
-      s_cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), qf[ks], s_cur, 0, 0, 0);
-    } else {
-      u32x4 qq;
-      lds_read_b128<(ks - QT_KS) * 1024>(qq, qtail);
-      lgkm_wait_k<0>(qq);
-      lgkm_wait_k<0>(a);
-      s_cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, qq), s_cur, 0, 0, 0);
-    }
-  });
-  if (t_begin == n_tiles - 1) mask_tail(s_cur, t_begin);
-  u32x4 p_prev[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
-#pragma unroll
-  for (int bb = 0; bb < 8; ++bb) kofs[bb] += 1 * KCH * 16;          // iteration 0 reads K from buffer 1 ...
-#pragma unroll
-  for (int dtl = 0; dtl < 4; ++dtl) { vofs[dtl][0] += 3 * KCH * 16; vofs[dtl][1] += 3 * KCH * 16; }   // ... and V from buffer 3
-
-  // LDS operations issued for slot s of an iteration: K fragment, two transpose reads, (Q tail fragment)
-  // ops(s) = 3 + (s >= QT_KS); those of slots t+1 .. t+D are in flight behind slot t's when it is consumed
-  auto iteration = [&](auto rc, int tile) {
-    constexpr int R = decltype(rc)::value;                 // (tile - t_begin) % 4: tile in buffer R, K(tile+1) in R+1, V(tile-1) in R+3
-    [[maybe_unused]] constexpr int KB = 0, VB = 0;         // kofs / vofs already point into those buffers
-#ifndef ATTN_ABLATE_NOBARRIER
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // tile+1 has landed ...
-    __syncthreads();                                        // ... for everybody; tile-2's buffer is free
-#endif
-    const int t2 = min(tile + 2, t_end - 1);
-#if ATTNKV_PIPELINED != 2
-    u32x4 kfr[D + 1], qfr[D + 1];
-    u32x2 vfr[D + 1][2];
-#endif
-    f32x16 s_nxt;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s_nxt[r] = 0.f;
-    u32x4 p_cur[2];
-    float mx = 0.f, psum = 0.f, alpha = 1.f;
-    bool need = false;
-#if ATTNKV_PIPELINED == 2
-    // Two phases per iteration: (A) S(tile+1) = K(tile+1).Q^T with the next tile's DMA issue in its gaps (the dependent score
-    // chain has the slack for them), (B) O += V(tile-1).P(tile-1) with the softmax of S(tile) on the vector ALU underneath
-    // (independent accumulators: fillers between those MFMAs are cheap).
-    constexpr int DA = 6, DB = 4;                          // fragment reads run this many slots ahead in each phase
-    u32x4 kfa[DA + 1], qfa[DA + 1];
-    auto fetch_a = [&](auto sc) {
-      constexpr int sl = decltype(sc)::value;
-      if constexpr (sl < 32) {
-        lds_read_b128<(sl >> 3) * 256>(kfa[sl % (DA + 1)], kofs[sl & 7]);
-        if constexpr (sl >= QT_KS) lds_read_b128<(sl - QT_KS) * 1024>(qfa[sl % (DA + 1)], qtail);
-      }
-    };
-    static_for<DA>([&](auto sc) { fetch_a(sc); });
-    static_for<32>([&](auto sc) {
-      constexpr int sl = decltype(sc)::value;
-      fetch_a(std::integral_constant<int, sl + DA>{});
-#ifndef ATTN_ABLATE_NODMA
-      if constexpr ((sl & 3) == 1) issue_piece(std::integral_constant<int, sl / 4>{}, t2, (R + 2) & 3);
-#endif
-      constexpr int hi_s = (sl + DA < 31 ? sl + DA : 31);
-      constexpr int newer = (hi_s - sl) + ((hi_s >= QT_KS ? hi_s - QT_KS + 1 : 0) - (sl >= QT_KS ? sl - QT_KS + 1 : 0));
-      static_assert(newer <= 15, "lgkmcnt is a 4-bit counter");
-      if constexpr (sl >= QT_KS) {
-        lgkm_wait_k<newer>(qfa[sl % (DA + 1)]);             // the Q fragment is the LAST read of its slot: K has landed too
-        lgkm_wait_k<newer>(kfa[sl % (DA + 1)]);
-        s_nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kfa[sl % (DA + 1)]),
-                                                        __builtin_bit_cast(bf16x8, qfa[sl % (DA + 1)]), s_nxt, 0, 0, 0);
-      } else {
-        lgkm_wait_k<newer>(kfa[sl % (DA + 1)]);
-        s_nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kfa[sl % (DA + 1)]), qf[sl < QT_KS ? sl : 0], s_nxt,
-                                                        0, 0, 0);
-      }
-      if constexpr ((sl & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-    });
-    u32x2 vfb[DB + 1][2];
-    auto fetch_b = [&](auto sc) {
-      constexpr int sl = decltype(sc)::value;
-      if constexpr (sl < 32) {
-        constexpr int dt = sl >> 1, ks = sl & 1;
-        tr_read_b64<ks * 16384 + (dt >> 2) * 256>(vfb[sl % (DB + 1)][0], vofs[dt & 3][0]);
-        tr_read_b64<ks * 16384 + (dt >> 2) * 256>(vfb[sl % (DB + 1)][1], vofs[dt & 3][1]);
-      }
-    };
-    static_for<DB>([&](auto sc) { fetch_b(sc); });
-    static_for<32>([&](auto sc) {
-      constexpr int sl = decltype(sc)::value;
-      fetch_b(std::integral_constant<int, sl + DB>{});
-      constexpr int hi_s = (sl + DB < 31 ? sl + DB : 31);
-      lgkm_wait_v<2 * (hi_s - sl)>(vfb[sl % (DB + 1)][0], vfb[sl % (DB + 1)][1]);
-      {
-        const u32x2 a0 = vfb[sl % (DB + 1)][0], a1 = vfb[sl % (DB + 1)][1];
-        o[sl >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, u32x4{a0[0], a0[1], a1[0], a1[1]}),
-                                                             __builtin_bit_cast(bf16x8, p_prev[sl & 1]), o[sl >> 1], 0, 0, 0);
-      }
-      // ---- vector-ALU slice of the online softmax of S(tile), one small piece per slot
-#ifdef ATTN_ABLATE_NOSOFTMAX   // timing ablation only: wrong results
-      if constexpr (sl == 0) { asm volatile("" ::"v"(s_cur[0]), "v"(s_cur[15])); p_cur[0] = p_cur[1] = u32x4{0x3d003d00u, 0x3d003d00u, 0x3d003d00u, 0x3d003d00u}; }
-      if constexpr (false) {}
-      else
-#endif
-      if constexpr (sl == 0) mx = fmaxf(fmaxf(s_cur[0], s_cur[1]), s_cur[2]);
-      else if constexpr (sl >= 1 && sl <= 6) mx = fmaxf(fmaxf(mx, s_cur[2 * sl + 1]), s_cur[2 * sl + 2]);
-      else if constexpr (sl == 7) {
-        mx = fmaxf(mx, s_cur[15]);
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-        mx = fmaxf(mx, __uint_as_float(hi ? sw[0] : sw[1]));
-      } else if constexpr (sl == 8) {
-        need = __any(mx > m_run + RESCALE_THR);             // wave-uniform; the accumulators are rescaled at the end
-        const float m_new = need ? fmaxf(m_run, mx) : m_run;
-        alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        l_run *= alpha;
-        m_run = m_new;
-      } else if constexpr (sl >= 9 && sl <= 24) {
-        constexpr int r = sl - 9;
-        const float pv = __builtin_amdgcn_exp2f(s_cur[r] - m_run);
-        psum += pv;
-        s_cur[r] = pv;
-        if constexpr (r & 1) p_cur[r >> 3][(r >> 1) & 3] = pack_bf2(s_cur[r - 1], s_cur[r]);
-      } else if constexpr (sl == 25) {
-        l_run += psum;
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    });
-#else
-    auto fetch = [&](auto sc) {                            // the LDS reads of slot s, in the order K, V lo, V hi, (Q)
-      constexpr int sl = decltype(sc)::value;
-      if constexpr (sl < 32) {
-        constexpr int dt = sl >> 1, ks = sl & 1;
-        lds_read_b128<KB + (sl >> 3) * 256>(kfr[sl % (D + 1)], kofs[sl & 7]);
-        tr_read_b64<VB + ks * 16384 + (dt >> 2) * 256>(vfr[sl % (D + 1)][0], vofs[dt & 3][0]);
-        tr_read_b64<VB + ks * 16384 + (dt >> 2) * 256>(vfr[sl % (D + 1)][1], vofs[dt & 3][1]);
-        if constexpr (sl >= QT_KS) lds_read_b128<(sl - QT_KS) * 1024>(qfr[sl % (D + 1)], qtail);
-      }
-    };
-    static_for<D>([&](auto sc) { fetch(sc); });
-    static_for<32>([&](auto sc) {
-      constexpr int sl = decltype(sc)::value;
-      fetch(std::integral_constant<int, sl + D>{});
-#ifndef ATTN_ABLATE_NODMA
-#if ATTNKV_DMA_STAGGER == 0      // every wave issues piece j at slot 2j
-      if constexpr ((sl & 1) == 0 && sl < 16) issue_piece(std::integral_constant<int, sl / 2>{}, t2, (R + 2) & 3);
-#elif ATTNKV_DMA_STAGGER == 1    // waves in two groups: piece j at slot 2j + (wave & 1)
-      if constexpr (sl < 16) { if ((wave & 1) == (sl & 1)) issue_piece(std::integral_constant<int, sl / 2>{}, t2, (R + 2) & 3); }
-#elif ATTNKV_DMA_STAGGER == 2    // one wave per slot: piece j at slot 4j + wave
-      if (wave == (sl & 3)) issue_piece(std::integral_constant<int, sl / 4>{}, t2, (R + 2) & 3);
-#elif ATTNKV_DMA_STAGGER == 3    // one wave per slot, first 16 slots twice as dense: pieces 2k, 2k+1 at slot 4k + wave (k < 4)
-      if constexpr (sl < 16) { if (wave == (sl & 3)) { issue_piece(std::integral_constant<int, 2 * (sl / 4)>{}, t2, (R + 2) & 3);
-                                                       issue_piece(std::integral_constant<int, 2 * (sl / 4) + 1>{}, t2, (R + 2) & 3); } }
-#endif
-#endif
-      // newer LDS operations in flight behind slot sl's: slots sl+1 .. min(sl+D, 31)
-      constexpr int hi_s = (sl + D < 31 ? sl + D : 31);
-      constexpr int newer = 3 * (hi_s - sl) + ((hi_s >= QT_KS ? hi_s - QT_KS + 1 : 0) - (sl >= QT_KS ? sl - QT_KS + 1 : 0));
-      static_assert(newer <= 15, "lgkmcnt is a 4-bit counter");
-      bf16x8 qop;
-      if constexpr (sl >= QT_KS) {
-        lgkm_wait_kvq<newer>(kfr[sl % (D + 1)], vfr[sl % (D + 1)][0], vfr[sl % (D + 1)][1], qfr[sl % (D + 1)]);
-        qop = __builtin_bit_cast(bf16x8, qfr[sl % (D + 1)]);
-      } else {
-        lgkm_wait_kv<newer>(kfr[sl % (D + 1)], vfr[sl % (D + 1)][0], vfr[sl % (D + 1)][1]);
-        qop = qf[sl < QT_KS ? sl : 0];
-      }
-      s_nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kfr[sl % (D + 1)]), qop, s_nxt, 0, 0, 0);
-      {
-        const u32x2 a0 = vfr[sl % (D + 1)][0], a1 = vfr[sl % (D + 1)][1];
-        o[sl >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, u32x4{a0[0], a0[1], a1[0], a1[1]}),
-                                                             __builtin_bit_cast(bf16x8, p_prev[sl & 1]), o[sl >> 1], 0, 0, 0);
-      }
-      // ---- vector-ALU slice of the online softmax of S(tile), one small piece per slot
-#ifdef ATTN_ABLATE_NOSOFTMAX   // timing ablation only: wrong results
-      if constexpr (sl == 0) { asm volatile("" ::"v"(s_cur[0]), "v"(s_cur[15])); p_cur[0] = p_cur[1] = u32x4{0x3d003d00u, 0x3d003d00u, 0x3d003d00u, 0x3d003d00u}; }
-      if constexpr (false) {}
-      else
-#endif
-      if constexpr (sl == 0) mx = fmaxf(fmaxf(s_cur[0], s_cur[1]), s_cur[2]);
-      else if constexpr (sl >= 1 && sl <= 6) mx = fmaxf(fmaxf(mx, s_cur[2 * sl + 1]), s_cur[2 * sl + 2]);
-      else if constexpr (sl == 7) {
-        mx = fmaxf(mx, s_cur[15]);
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-        mx = fmaxf(mx, __uint_as_float(hi ? sw[0] : sw[1]));
-      } else if constexpr (sl == 8) {
-        need = __any(mx > m_run + RESCALE_THR);             // wave-uniform; the accumulators are rescaled at the end
-        const float m_new = need ? fmaxf(m_run, mx) : m_run;
-        alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        l_run *= alpha;
-        m_run = m_new;
-      } else if constexpr (sl >= 9 && sl <= 24) {
-        constexpr int r = sl - 9;
-        const float pv = __builtin_amdgcn_exp2f(s_cur[r] - m_run);
-        psum += pv;
-        s_cur[r] = pv;
-        if constexpr (r & 1) p_cur[r >> 3][(r >> 1) & 3] = pack_bf2(s_cur[r - 1], s_cur[r]);
-      } else if constexpr (sl == 25) {
-        l_run += psum;
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    });
-#endif
-    if (need) {   // rare: every accumulator holds tiles <= tile-1 at the old scale
-#pragma unroll
-      for (int i = 0; i < HD / 32; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float x = o[i][r], tmp;
-          asm volatile("v_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\tv_accvgpr_write_b32 %0, %1"
-                       : "+a"(x), "=&v"(tmp)
-                       : "v"(alpha));
-          o[i][r] = x;
-        }
-    }
-    if (tile + 1 == n_tiles - 1) mask_tail(s_nxt, tile + 1);
-    s_cur = s_nxt;
-    p_prev[0] = p_cur[0];
-    p_prev[1] = p_cur[1];
-    // rotate the fragment addresses to the next iteration's buffers: K (R+1) -> (R+2), V (R+3) -> (R+4), modulo 4
-    constexpr int dk = (((R + 1) & 3) == 3 ? -3 : 1) * KCH * 16, dv = (((R + 3) & 3) == 3 ? -3 : 1) * KCH * 16;
-#pragma unroll
-    for (int bb = 0; bb < 8; ++bb) kofs[bb] += dk;
-#pragma unroll
-    for (int dtl = 0; dtl < 4; ++dtl) { vofs[dtl][0] += dv; vofs[dtl][1] += dv; }
-  };
-
-  for (int tile = t_begin; tile < t_end; tile += 4) {
-    iteration(std::integral_constant<int, 0>{}, tile);
-    if (tile + 1 < t_end) iteration(std::integral_constant<int, 1>{}, tile + 1);
-    if (tile + 2 < t_end) iteration(std::integral_constant<int, 2>{}, tile + 2);
-    if (tile + 3 < t_end) iteration(std::integral_constant<int, 3>{}, tile + 3);
-  }
-  // ---- drain: O += V(last).P(last); after the last rotation vofs points at the last tile's buffer
-  {
-    static_for<16>([&](auto dc) {
-      constexpr int dt = decltype(dc)::value;
-      u32x2 a[4];
-      tr_read_b64<(dt >> 2) * 256>(a[0], vofs[dt & 3][0]);
-      tr_read_b64<(dt >> 2) * 256>(a[1], vofs[dt & 3][1]);
-      tr_read_b64<16384 + (dt >> 2) * 256>(a[2], vofs[dt & 3][0]);
-      tr_read_b64<16384 + (dt >> 2) * 256>(a[3], vofs[dt & 3][1]);
-      lgkm_wait_v<0>(a[0], a[1]);
-      lgkm_wait_v<0>(a[2], a[3]);
-      o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, u32x4{a[0][0], a[0][1], a[1][0], a[1][1]}),
-                                                      __builtin_bit_cast(bf16x8, p_prev[0]), o[dt], 0, 0, 0);
-      o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, u32x4{a[2][0], a[2][1], a[3][0], a[3][1]}),
-                                                      __builtin_bit_cast(bf16x8, p_prev[1]), o[dt], 0, 0, 0);
-    });
-  }
-
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  if (p.key_splits > 1) {
-    if (q_ok) {
-      const size_t row = ((size_t)b * p.key_splits + ksplit) * p.N + qrow;
-      float* po = p.part_o + row * HD;
-#pragma unroll
-      for (int dt = 0; dt < HD / 32; ++dt)
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-          const int d = dt * 32 + 8 * rq + 4 * hi;
-          *reinterpret_cast<f32x4*>(po + d) = f32x4{o[dt][4 * rq], o[dt][4 * rq + 1], o[dt][4 * rq + 2], o[dt][4 * rq + 3]};
-        }
-      if (hi == 0) { p.part_ml[row * 2] = m_run; p.part_ml[row * 2 + 1] = l_tot; }
-    }
-    return;
-  }
-  const float inv = 1.0f / l_tot;
-  if (q_ok) {
-    bf16_t* op = p.o + ((size_t)b * p.N + qrow) * p.ldo;
-#pragma unroll
-    for (int dt = 0; dt < HD / 32; ++dt)
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const int d = dt * 32 + 8 * rq + 4 * hi;
-        u32x2 w = {pack_bf2(o[dt][4 * rq] * inv, o[dt][4 * rq + 1] * inv),
-                   pack_bf2(o[dt][4 * rq + 2] * inv, o[dt][4 * rq + 3] * inv)};
-        *reinterpret_cast<u32x2*>(op + d) = w;
-      }
-  }
-}
 
 // out[q] = sum_s 2^(m_s - m) O_s[q] / sum_s 2^(m_s - m) l_s,  m = max_s m_s: merges the key splits (one wave per query row)
 __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
-                                                           bf16_t* __restrict__ out, int ldo, int B, int N, int KS,
+                                                           a16_t* __restrict__ out, int ldo, int B, int N, int KS,
                                                            float* __restrict__ lse) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // b * N + q
   if (row >= (long long)B * N) return;
@@ -1469,8 +862,8 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
   }
   const float inv = 1.0f / L;
   if (lse && lane == 0) lse[row] = m + __builtin_amdgcn_logf(L);
-  u32x4 o = {pack_bf2(acc[0] * inv, acc[1] * inv), pack_bf2(acc[2] * inv, acc[3] * inv), pack_bf2(acc[4] * inv, acc[5] * inv),
-             pack_bf2(acc[6] * inv, acc[7] * inv)};
+  u32x4 o = {pack_a2(acc[0] * inv, acc[1] * inv), pack_a2(acc[2] * inv, acc[3] * inv), pack_a2(acc[4] * inv, acc[5] * inv),
+             pack_a2(acc[6] * inv, acc[7] * inv)};
   *reinterpret_cast<u32x4*>(out + (size_t)row * ldo + lane * 8) = o;
 }
 
@@ -1507,7 +900,7 @@ extern "C" int glare_attention_kv512_bf16(const void* q, int ldq, const void* kv
     return GLARE_ERR_WORKSPACE;
   if ((ldq % 8) || (ldkv % 8) || (ldo % 4) || ldq < HD || ldkv < HD || ldo < HD) return GLARE_ERR_UNSUPPORTED;
   AttnParams p;
-  p.q = (const bf16_t*)q; p.k = (const bf16_t*)kv; p.vt = nullptr; p.o = (bf16_t*)out;
+  p.q = (const a16_t*)q; p.k = (const a16_t*)kv; p.vt = nullptr; p.o = (a16_t*)out;
   p.B = B; p.N = N; p.Npad = 0; p.ldq = ldq; p.ldk = ldkv; p.ldo = ldo; p.lse = nullptr;
   p.n_qblocks = (N + BM - 1) / BM;
   p.key_splits = key_splits;
@@ -1551,7 +944,7 @@ static int attn_launch(const void* q, int ldq, const void* k, int ldk, const voi
   if ((ldq % 8) || (ldk % 8) || (ldo % 4) || (v_pitch % 8) || ldq < HD || ldk < HD || ldo < HD) return GLARE_ERR_UNSUPPORTED;
   if (v_pitch < (long long)((N + BN - 1) / BN) * BN) return GLARE_ERR_INVALID;  // tiles read whole 32-key groups
   AttnParams p;
-  p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.vt = (const bf16_t*)v_t; p.o = (bf16_t*)out;
+  p.q = (const a16_t*)q; p.k = (const a16_t*)k; p.vt = (const a16_t*)v_t; p.o = (a16_t*)out;
   p.B = B; p.N = N; p.Npad = v_pitch; p.ldq = ldq; p.ldk = ldk; p.ldo = ldo; p.lse = lse;
   p.n_qblocks = (N + BM - 1) / BM;
   p.key_splits = key_splits;

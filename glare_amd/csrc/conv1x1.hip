@@ -30,11 +30,11 @@
 namespace {
 
 struct C1Params {
-  const bf16_t* x;
-  const bf16_t* w;       // [Cout][Cin] bf16
+  const a16_t* x;
+  const a16_t* w;       // [Cout][Cin] bf16
   const float* bias;
-  const bf16_t* res;
-  bf16_t* out;
+  const a16_t* res;
+  a16_t* out;
   float* gn_part;        // [B][rbi][Cout/4][2] or null
   int B, N;              // images, pixels per image
   int Cin, Cout;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256, 1) void conv1x1_ws_kernel(const C1Params p) {
 
   // ---- weights of this co-tile into LDS, once: row r, chunk c at r * CPR + (c ^ (r & 15)) (source-side swizzle)
   {
-    const bf16_t* wt = p.w + (size_t)w_img * p.w_istride + (size_t)ct * 128 * p.Cin;
+    const a16_t* wt = p.w + (size_t)w_img * p.w_istride + (size_t)ct * 128 * p.Cin;
     const int r_in = lane / CPR, c_ph = lane % CPR;
 #pragma unroll 4
     for (int piece = wave; piece < 128 / RPP; piece += 4) {
@@ -126,17 +126,17 @@ __global__ __launch_bounds__(256, 1) void conv1x1_ws_kernel(const C1Params p) {
     return p.x + ((size_t)b_ * p.N + r0_ + min(px, nrows_ - 1)) * p.xpitch + p.xoff + khalf * 32 + u_ * UNIT * 16;
   };
   const int n_rb = rb_hi > rb_lo + wave ? (rb_hi - rb_lo - wave + 3) / 4 : 0, n_units = n_rb * UPB;
-  bf16x8 af[2][UNIT];
+  a16x8 af[2][UNIT];
   auto fetch = [&](auto parc, int q) {
     constexpr int P = decltype(parc)::value;
-    const bf16_t* ap = unit_ptr(q);
+    const a16_t* ap = unit_ptr(q);
 #pragma unroll
     for (int e = 0; e < UNIT; ++e) {
 #if C1_ABL & 1   // timing ablation: no A loads
-      af[P][e] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)q, (unsigned)e, 0x3f803f80u, 0x3f803f80u});
+      af[P][e] = __builtin_bit_cast(a16x8, u32x4{(unsigned)q, (unsigned)e, 0x3f803f80u, 0x3f803f80u});
       asm volatile("" ::"v"(ap));
 #else
-      af[P][e] = *reinterpret_cast<const bf16x8*>(ap + (e >> 2) * 64 + (e & 3) * 8);
+      af[P][e] = *reinterpret_cast<const a16x8*>(ap + (e >> 2) * 64 + (e & 3) * 8);
 #endif
     }
   };
@@ -167,12 +167,12 @@ __global__ __launch_bounds__(256, 1) void conv1x1_ws_kernel(const C1Params p) {
 #pragma unroll
       for (int e = 0; e < UNIT; ++e) {
         const int ks = u * UNIT + e;            // u is 0 when UPB == 1; otherwise boff[] only depends on ks & 7 = e & 7
-        bf16x8 bf[4];
+        a16x8 bf[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          bf[j] = *reinterpret_cast<const bf16x8*>(smem + boff[e & 7] + (ks >> 3) * 256 + j * 32 * ROWB);
+          bf[j] = *reinterpret_cast<const a16x8*>(smem + boff[e & 7] + (ks >> 3) * 256 + j * 32 * ROWB);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[P][e], bf[j], acc[j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[j] = mfma_a16_32x32x16(af[P][e], bf[j], acc[j], 0, 0, 0);
       }
     };
     if ((q & 1) == 0) body(std::integral_constant<int, 0>{});
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256, 1) void conv1x1_ws_kernel(const C1Params p) {
         const float recv = __shfl_xor(send, 1, 64);
         const int r = 2 * t + odd;
         const int m = (r & 3) + 8 * (r >> 2) + 4 * khalf;
-        const uint32_t wv = odd ? pack_bf2(recv, c) : pack_bf2(a, recv);
+        const uint32_t wv = odd ? pack_a2(recv, c) : pack_a2(a, recv);
         const int col = 32 * j + (px & ~1);                               // even channel of the pair, 0..127
         *reinterpret_cast<uint32_t*>(slab + m * 256 + (((col >> 3) ^ (m & 15)) * 16) + (col & 7) * 2) = wv;
       }
@@ -219,13 +219,13 @@ __global__ __launch_bounds__(256, 1) void conv1x1_ws_kernel(const C1Params p) {
           const u32x4 rv = resv[it];
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            v[e] = pack_bf2(act1<ACT>(bflo(v[e]) + bflo(rv[e])), act1<ACT>(bfhi(v[e]) + bfhi(rv[e])));
+            v[e] = pack_a2(act1<ACT>(alo(v[e]) + alo(rv[e])), act1<ACT>(ahi(v[e]) + ahi(rv[e])));
         }
         *reinterpret_cast<u32x4*>(p.out + pix * p.opitch + p.ooff + co) = v;
         if (p.gn_part) {
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
-            const float x0 = bflo(v[e]), x1 = bfhi(v[e]), y0 = bflo(v[2 + e]), y1 = bfhi(v[2 + e]);
+            const float x0 = alo(v[e]), x1 = ahi(v[e]), y0 = alo(v[2 + e]), y1 = ahi(v[2 + e]);
             gs0 += x0 + x1; gq0 += x0 * x0 + x1 * x1;
             gs1 += y0 + y1; gq1 += y0 * y0 + y1 * y1;
           }
@@ -248,9 +248,9 @@ __global__ __launch_bounds__(256, 1) void conv1x1_ws_kernel(const C1Params p) {
 }
 
 // OIHW fp32 [Cout][Cin][1][1] -> bf16 [Cout][Cin]
-__global__ void c1_pack_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, long long n) {
+__global__ void c1_pack_kernel(const float* __restrict__ w, a16_t* __restrict__ out, long long n) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) out[i] = f2bf(w[i]);
+  if (i < n) out[i] = f2a(w[i]);
 }
 
 // [B][rbi][Cout/4][2] -> [B][1][32][2] (the statistics block gn_apply consumes)
@@ -287,7 +287,7 @@ extern "C" int glare_conv1x1_ws_supported(int Cin, int Cout) {
 extern "C" int glare_conv1x1_ws_pack_weight(const float* w_oihw, int cout, int cin, void* w_bf16, glare_stream_t stream) {
   if (!w_oihw || !w_bf16 || cout <= 0 || cin <= 0) return GLARE_ERR_INVALID;
   const long long n = (long long)cout * cin;
-  hipLaunchKernelGGL(c1_pack_kernel, dim3((unsigned)cdivll(n, 256)), dim3(256), 0, (hipStream_t)stream, w_oihw, (bf16_t*)w_bf16, n);
+  hipLaunchKernelGGL(c1_pack_kernel, dim3((unsigned)cdivll(n, 256)), dim3(256), 0, (hipStream_t)stream, w_oihw, (a16_t*)w_bf16, n);
   return glare_launch_status();
 }
 
@@ -315,7 +315,7 @@ static int c1_launch(const void* x, int x_pitch, int x_off, const void* w_bf16, 
   if (residual && ((res_pitch % 8) || (res_off % 8) || res_off + Cout > res_pitch)) return GLARE_ERR_UNSUPPORTED;
   if (pixels_per_image > 0x7fffffffLL || (long long)B * cdivll(pixels_per_image, 32) > 0x7fffffffLL) return GLARE_ERR_INVALID;
   C1Params p;
-  p.x = (const bf16_t*)x; p.w = (const bf16_t*)w_bf16; p.bias = bias; p.res = (const bf16_t*)residual; p.out = (bf16_t*)out;
+  p.x = (const a16_t*)x; p.w = (const a16_t*)w_bf16; p.bias = bias; p.res = (const a16_t*)residual; p.out = (a16_t*)out;
   p.gn_part = gn_partial;
   p.B = B; p.N = (int)pixels_per_image; p.Cin = Cin; p.Cout = Cout;
   p.xpitch = x_pitch; p.xoff = x_off; p.opitch = out_pitch; p.ooff = out_off; p.rpitch = res_pitch; p.roff = res_off;

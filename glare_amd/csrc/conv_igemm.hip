@@ -34,11 +34,11 @@ namespace {
 constexpr int TW = 32;   // output tile cols == MFMA M
 
 struct ConvParams {
-  const bf16_t* in0;
-  const bf16_t* in1;
-  const bf16_t* wpk;
+  const a16_t* in0;
+  const a16_t* in1;
+  const a16_t* wpk;
   const float* bias;
-  const bf16_t* res;
+  const a16_t* res;
   void* out;
   int B, H, W;        // source spatial size (before upsample)
   int IHs, IWs;       // conv input size (after upsample)
@@ -179,10 +179,10 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
   }
   const size_t img = (size_t)b * p.H * p.W;
   const __amdgpu_buffer_rsrc_t arsrc0 =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.in0 + img * p.p0), 0, (int)p.in0_bytes, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<a16_t*>(p.in0 + img * p.p0), 0, (int)p.in0_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t arsrc1 = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<bf16_t*>(p.in1 ? p.in1 + img * p.p1 : p.in0), 0, (int)(p.in1 ? p.in1_bytes : p.in0_bytes), 0x00020000);
-  const bf16_t* wbase = p.wpk + ((size_t)phase * p.co_tiles + ct) * p.n_stages * (size_t)(KS * B_CHUNKS) * 8;
+      const_cast<a16_t*>(p.in1 ? p.in1 + img * p.p1 : p.in0), 0, (int)(p.in1 ? p.in1_bytes : p.in0_bytes), 0x00020000);
+  const a16_t* wbase = p.wpk + ((size_t)phase * p.co_tiles + ct) * p.n_stages * (size_t)(KS * B_CHUNKS) * 8;
 
   auto issue_a = [&](int chunk, int buf, int i_lo = 0, int i_hi = 1 << 20) {   // pieces [i_lo, i_hi) of this wave
     const int c0 = chunk * KC;
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
   // Weight stages go through a buffer descriptor: `buffer_load_dwordx4 ... offen lds` takes ONE per-lane
   // 32-bit offset (lane*16, loop-invariant) plus a scalar offset -- no per-instruction 64-bit VALU address.
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<bf16_t*>(wbase), 0, (int)((size_t)p.n_stages * KS * B_CHUNKS * 16), 0x00020000);
+      const_cast<a16_t*>(wbase), 0, (int)((size_t)p.n_stages * KS * B_CHUNKS * 16), 0x00020000);
   const int lane16 = lane * 16;
   auto issue_b = [&](int bstage, int buf, int i_lo = 0, int i_hi = 1 << 20) {
 #pragma unroll
@@ -267,23 +267,23 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
           }
 #endif
 #endif
-          bf16x8 bf[NT], af[MT];
+          a16x8 bf[NT], af[MT];
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
             const int co = (wn * NT + j) * 32 + px;
-            bf[j] = __builtin_bit_cast(bf16x8, cB[((tcol * KSTEPS + ks) * 2 + khalf) * TN + co]);
+            bf[j] = __builtin_bit_cast(a16x8, cB[((tcol * KSTEPS + ks) * 2 + khalf) * TN + co]);
           }
 #pragma unroll
           for (int i = 0; i < MT; ++i) {
             const int row = wm * MT + i;
             const int pos = (row * STRIDE + trow) * G::IW + px * STRIDE + tcol;
-            af[i] = __builtin_bit_cast(bf16x8, cA[(ks * 2 + khalf) * G::NPOS + pos]);
+            af[i] = __builtin_bit_cast(a16x8, cA[(ks * 2 + khalf) * G::NPOS + pos]);
           }
 #pragma unroll
           for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+              acc[i][j] = mfma_a16_32x32x16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
       }
 #ifdef CONV_SETPRIO
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
             const float recv = __shfl_xor(send, 1, 64);
             const int r = 2 * t + odd;                                  // the register (row) this lane writes
             const int m = (r & 3) + 8 * (r >> 2) + 4 * rhalf;            // pixel x within the tile row
-            const uint32_t w = odd ? pack_bf2(recv, c) : pack_bf2(a, recv);
+            const uint32_t w = odd ? pack_a2(recv, c) : pack_a2(a, recv);
             *reinterpret_cast<uint32_t*>(slab + (il * 32 + m) * ROWB + (j * 32 + (ncol & ~1)) * 2) = w;
           }
         });
@@ -351,13 +351,13 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
             const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + pix * p.rpitch + p.roff + co);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              v[e] = pack_bf2(apply_act<ACT>(bflo(v[e]) + bflo(rv[e])), apply_act<ACT>(bfhi(v[e]) + bfhi(rv[e])));
+              v[e] = pack_a2(apply_act<ACT>(alo(v[e]) + alo(rv[e])), apply_act<ACT>(ahi(v[e]) + ahi(rv[e])));
           }
-          *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.out) + pix * p.opitch + p.ooff + co) = v;
+          *reinterpret_cast<u32x4*>(reinterpret_cast<a16_t*>(p.out) + pix * p.opitch + p.ooff + co) = v;
           if (p.gn_part) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-              const float x0 = bflo(v[e]), x1 = bfhi(v[e]), y0 = bflo(v[2 + e]), y1 = bfhi(v[2 + e]);
+              const float x0 = alo(v[e]), x1 = ahi(v[e]), y0 = alo(v[2 + e]), y1 = ahi(v[2 + e]);
               gs0 += x0 + x1; gq0 += x0 * x0 + x1 * x1;
               gs1 += y0 + y1; gq1 += y0 * y0 + y1 * y1;
             }
@@ -414,10 +414,10 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
           for (int e = 0; e < 4; ++e) {
             if (row_ok && co_ok && xb + e < p.OW) {
               float y = v[e];
-              if (p.res) y += bf2f(p.res[(pix0 + e) * p.rpitch + p.roff + co]);
+              if (p.res) y += a2f(p.res[(pix0 + e) * p.rpitch + p.roff + co]);
               y = apply_act<ACT>(y);
               if (p.out_mode == GLARE_OUT_NHWC_BF16)
-                reinterpret_cast<bf16_t*>(p.out)[(pix0 + e) * p.opitch + p.ooff + co] = f2bf(y);
+                reinterpret_cast<a16_t*>(p.out)[(pix0 + e) * p.opitch + p.ooff + co] = f2a(y);
               else
                 reinterpret_cast<float*>(p.out)[(pix0 + e) * p.opitch + p.ooff + co] = y;
             }
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
                 if (p.out_mode == GLARE_OUT_PLANAR_F32)
                   reinterpret_cast<float*>(p.out)[base + e] = y;
                 else
-                  reinterpret_cast<bf16_t*>(p.out)[base + e] = f2bf(y);
+                  reinterpret_cast<a16_t*>(p.out)[base + e] = f2a(y);
               }
             }
           }
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
 // [co_tile][stage][tap][kstep][khalf][TN][8], zero-filled outside Cout / Cin.
 // dgrad != 0: `w` is the FORWARD filter [Cin_real][Cout][KS][KS] of which the data-gradient filter is wanted
 // (w'[co][ci][tap] = w[ci][co][KK-1-tap], input channels ci >= Cin_real zero): no flip/transpose/pad pass on the host.
-__device__ __forceinline__ void pack_weight_elem(const float* __restrict__ w, bf16_t* __restrict__ out, long long i, int Cout, int Cin,
+__device__ __forceinline__ void pack_weight_elem(const float* __restrict__ w, a16_t* __restrict__ out, long long i, int Cout, int Cin,
                                                  int KS, int TN, int KSTEPS, int n_stages, int dgrad, int Cin_real) {
   long long t = i;
   const int e = t % 8; t /= 8;
@@ -465,11 +465,11 @@ __device__ __forceinline__ void pack_weight_elem(const float* __restrict__ w, bf
   } else if (co < Cout && ci < Cin) {
     v = w[((size_t)co * Cin + ci) * KS * KS + tap];
   }
-  out[i] = f2bf(v);
+  out[i] = f2a(v);
 }
 
 // blockIdx.y = filter of a batch of equally shaped filters (consecutive in `w`, consecutive packed images in `out`).
-__global__ void pack_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin, int KS,
+__global__ void pack_weight_kernel(const float* __restrict__ w, a16_t* __restrict__ out, int Cout, int Cin, int KS,
                                    int TN, int KSTEPS, int n_stages, long long total, int dgrad, int Cin_real) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
@@ -490,17 +490,17 @@ __global__ void pack_weight_multi_kernel(const glare_pack_job* __restrict__ jobs
   const long long i = ((long long)blockIdx.x - j.block_begin) * 256 + threadIdx.x;
   if (i >= j.total) return;
   if (j.kind == GLARE_PACK_PLAIN_BF16) {
-    static_cast<bf16_t*>(j.out)[i] = f2bf(j.w[i]);
+    static_cast<a16_t*>(j.out)[i] = f2a(j.w[i]);
     return;
   }
-  pack_weight_elem(j.w, static_cast<bf16_t*>(j.out), i, j.cout, j.cin, j.ksize, j.tn, j.ksteps, j.n_stages, j.kind == GLARE_PACK_DGRAD,
+  pack_weight_elem(j.w, static_cast<a16_t*>(j.out), i, j.cout, j.cin, j.ksize, j.tn, j.ksteps, j.n_stages, j.kind == GLARE_PACK_DGRAD,
                    j.cin_real);
 }
 
 // Sub-pixel upsample filters: [phase = a*2+b][co_tile][stage][tap = r*2+c][khalf][TN][8] (KSTEPS = 1), where tap (r, c)
 // of phase (a, b) is the sum of the 3x3 taps (ky, kx) that read the same source pixel: rows a=0: r=0 <- {0}, r=1 <- {1,2};
 // a=1: r=0 <- {0,1}, r=1 <- {2}; columns alike with b.
-__global__ void pack_weight_subpix_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin, int TN,
+__global__ void pack_weight_subpix_kernel(const float* __restrict__ w, a16_t* __restrict__ out, int Cout, int Cin, int TN,
                                           int n_stages, int co_tiles, long long total) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
@@ -523,7 +523,7 @@ __global__ void pack_weight_subpix_kernel(const float* __restrict__ w, bf16_t* _
     for (int ky = ky0; ky <= ky1; ++ky)
       for (int kx = kx0; kx <= kx1; ++kx) v += wp[ky * 3 + kx];
   }
-  out[i] = f2bf(v);
+  out[i] = f2a(v);
 }
 
 // GroupNorm partial reduction: [b][part][Cout/4][2] -> the [B][1][32][2] partial format gn_apply consumes
@@ -628,7 +628,7 @@ extern "C" int glare_conv2d_pack_weight(const float* w_oihw, int cout, int cin_t
   const int kc = 16 * v.ksteps;
   const int stages = (cin_total + kc - 1) / kc;
   hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     w_oihw, (bf16_t*)packed_bf16, cout, cin_total, ksize, v.tn, v.ksteps, stages, total, 0, cin_total);
+                     w_oihw, (a16_t*)packed_bf16, cout, cin_total, ksize, v.tn, v.ksteps, stages, total, 0, cin_total);
   return glare_launch_status();
 }
 
@@ -645,7 +645,7 @@ extern "C" int glare_conv2d_pack_weight_upsample(const float* w_oihw, int cout, 
   if (total < 0 || !w_oihw || !packed_bf16) return GLARE_ERR_INVALID;
   const Variant v = pick_variant(3, cout);
   hipLaunchKernelGGL(pack_weight_subpix_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     w_oihw, (bf16_t*)packed_bf16, cout, cin_total, v.tn, (cin_total + 15) / 16, (cout + v.tn - 1) / v.tn, total);
+                     w_oihw, (a16_t*)packed_bf16, cout, cin_total, v.tn, (cin_total + 15) / 16, (cout + v.tn - 1) / v.tn, total);
   return glare_launch_status();
 }
 
@@ -690,7 +690,7 @@ extern "C" int glare_conv2d_pack_weight_batched(const float* w_boihw, int batch,
   const Variant v = pick_variant(ksize, oc, cout_tile);
   const int kc = 16 * v.ksteps;
   hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256), batch), dim3(256), 0, (hipStream_t)stream, w_boihw,
-                     (bf16_t*)packed_bf16, oc, ic, ksize, v.tn, v.ksteps, (ic + kc - 1) / kc, total, dg ? 1 : 0, dg ? cout : ic);
+                     (a16_t*)packed_bf16, oc, ic, ksize, v.tn, v.ksteps, (ic + kc - 1) / kc, total, dg ? 1 : 0, dg ? cout : ic);
   return glare_launch_status();
 }
 
@@ -704,7 +704,7 @@ extern "C" int glare_conv2d_pack_weight_dgrad(const float* w_oihw, int cout, int
   const int kc = 16 * v.ksteps;
   const int stages = (cout_padded + kc - 1) / kc;
   hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_oihw,
-                     (bf16_t*)packed_bf16, cin, cout_padded, ksize, v.tn, v.ksteps, stages, total, 1, cout);
+                     (a16_t*)packed_bf16, cin, cout_padded, ksize, v.tn, v.ksteps, stages, total, 1, cout);
   return glare_launch_status();
 }
 
@@ -724,11 +724,11 @@ extern "C" int glare_conv2d_bf16(const glare_conv_desc* d, glare_stream_t stream
   if (d->in_off + d->Cin > d->in_pitch || d->out_off + d->Cout > d->out_pitch) return GLARE_ERR_INVALID;
 
   ConvParams p;
-  p.in0 = (const bf16_t*)d->in;
-  p.in1 = (const bf16_t*)d->in2;
-  p.wpk = (const bf16_t*)d->weight_packed;
+  p.in0 = (const a16_t*)d->in;
+  p.in1 = (const a16_t*)d->in2;
+  p.wpk = (const a16_t*)d->weight_packed;
   p.bias = d->bias;
-  p.res = (const bf16_t*)d->residual;
+  p.res = (const a16_t*)d->residual;
   p.out = d->out;
   p.B = d->B; p.H = d->H; p.W = d->W;
   p.IHs = (d->upsample && !subpix) ? 2 * d->H : d->H;   // sub-pixel form: the kernel works on the source grid

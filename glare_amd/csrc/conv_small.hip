@@ -113,19 +113,19 @@ __global__ __launch_bounds__(CS_THREADS) void conv_small_kernel(
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[q][e] = act_apply<ACT>(acc[q][e]);
       if (vec_store && g * 8 + 8 <= Cout) {
-        bf16_t* o = reinterpret_cast<bf16_t*>(out) + opix * out_pitch + out_off + g * 8;
-        *reinterpret_cast<u32x4*>(o) = u32x4{pack_bf2(acc[q][0], acc[q][1]), pack_bf2(acc[q][2], acc[q][3]), pack_bf2(acc[q][4], acc[q][5]),
-                                             pack_bf2(acc[q][6], acc[q][7])};
+        a16_t* o = reinterpret_cast<a16_t*>(out) + opix * out_pitch + out_off + g * 8;
+        *reinterpret_cast<u32x4*>(o) = u32x4{pack_a2(acc[q][0], acc[q][1]), pack_a2(acc[q][2], acc[q][3]), pack_a2(acc[q][4], acc[q][5]),
+                                             pack_a2(acc[q][6], acc[q][7])};
       } else if (out_f32) {
         float* o = reinterpret_cast<float*>(out) + opix * out_pitch + out_off + g * 8;
 #pragma unroll
         for (int e = 0; e < 8; ++e)
           if (g * 8 + e < Cout) o[e] = acc[q][e];
       } else {
-        bf16_t* o = reinterpret_cast<bf16_t*>(out) + opix * out_pitch + out_off + g * 8;
+        a16_t* o = reinterpret_cast<a16_t*>(out) + opix * out_pitch + out_off + g * 8;
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-          if (g * 8 + e < Cout) o[e] = f2bf(acc[q][e]);
+          if (g * 8 + e < Cout) o[e] = f2a(acc[q][e]);
       }
     }
   }

@@ -62,7 +62,7 @@ template <bool XBF16>
 __device__ __forceinline__ void load8(const void* base, long long elem_off, bool ok, Corner<XBF16>& c) {
   const u32x4 z = {0u, 0u, 0u, 0u};
   if (XBF16) {
-    c.v0 = ok ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(base) + elem_off) : z;
+    c.v0 = ok ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const a16_t*>(base) + elem_off) : z;
   } else {
     const float* p = reinterpret_cast<const float*>(base) + elem_off;
     c.v0 = ok ? *reinterpret_cast<const u32x4*>(p) : z;
@@ -72,7 +72,7 @@ __device__ __forceinline__ void load8(const void* base, long long elem_off, bool
 
 template <bool XBF16>
 __device__ __forceinline__ float elem(const Corner<XBF16>& c, int e) {
-  if (XBF16) return (e & 1) ? bfhi(c.v0[e >> 1]) : bflo(c.v0[e >> 1]);
+  if (XBF16) return (e & 1) ? ahi(c.v0[e >> 1]) : alo(c.v0[e >> 1]);   // x: the build's 16-bit activation format
   return __uint_as_float(e < 4 ? c.v0[e] : c.v1[e - 4]);
 }
 
@@ -423,10 +423,10 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_fast_kernel(const DcnParam
       for (int e = 0; e < 4; ++e) {
         // reference order: (w1*v1 + w2*v2 + w3*v3 + w4*v4) * mask   (kernel.cu:493-496,625), on (even, odd) channel pairs.
         // SCALAR fp32 on purpose, see the note on packed fp32 in the kernel's header comment.
-        float v0 = bflo(cr[i][0][e]) * cw[i][0], v1 = bfhi(cr[i][0][e]) * cw[i][0];
-        v0 = __builtin_fmaf(bflo(cr[i][1][e]), cw[i][1], v0); v1 = __builtin_fmaf(bfhi(cr[i][1][e]), cw[i][1], v1);
-        v0 = __builtin_fmaf(bflo(cr[i][2][e]), cw[i][2], v0); v1 = __builtin_fmaf(bfhi(cr[i][2][e]), cw[i][2], v1);
-        v0 = __builtin_fmaf(bflo(cr[i][3][e]), cw[i][3], v0); v1 = __builtin_fmaf(bfhi(cr[i][3][e]), cw[i][3], v1);
+        float v0 = alo(cr[i][0][e]) * cw[i][0], v1 = ahi(cr[i][0][e]) * cw[i][0];
+        v0 = __builtin_fmaf(alo(cr[i][1][e]), cw[i][1], v0); v1 = __builtin_fmaf(ahi(cr[i][1][e]), cw[i][1], v1);
+        v0 = __builtin_fmaf(alo(cr[i][2][e]), cw[i][2], v0); v1 = __builtin_fmaf(ahi(cr[i][2][e]), cw[i][2], v1);
+        v0 = __builtin_fmaf(alo(cr[i][3][e]), cw[i][3], v0); v1 = __builtin_fmaf(ahi(cr[i][3][e]), cw[i][3], v1);
         v0 *= m; v1 *= m;
         asm volatile("" : "+v"(v0), "+v"(v1));   // keeps the pair out of the vectoriser's hands
         hi[e] = pack_bf2(v0, v1);

@@ -10,9 +10,9 @@ namespace {
 
 constexpr int EW_THREADS = 256;
 
-__global__ __launch_bounds__(EW_THREADS) void mix_kernel(const bf16_t* __restrict__ a, int a_pitch, int a_off,
-                                                         const bf16_t* __restrict__ b, int b_pitch, int b_off,
-                                                         bf16_t* __restrict__ out, int o_pitch, int o_off, long long npix,
+__global__ __launch_bounds__(EW_THREADS) void mix_kernel(const a16_t* __restrict__ a, int a_pitch, int a_off,
+                                                         const a16_t* __restrict__ b, int b_pitch, int b_off,
+                                                         a16_t* __restrict__ out, int o_pitch, int o_off, long long npix,
                                                          int C, float f, const float* __restrict__ w_dev) {
   if (w_dev) f = 1.0f / (1.0f + expf(-w_dev[0]));   // the mixing logit read on the device: no host round trip
   const int CP = C / 8;
@@ -25,13 +25,13 @@ __global__ __launch_bounds__(EW_THREADS) void mix_kernel(const bf16_t* __restric
     u32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-      o[e] = pack_bf2(bflo(va[e]) * f + bflo(vb[e]) * (1.f - f), bfhi(va[e]) * f + bfhi(vb[e]) * (1.f - f));
+      o[e] = pack_a2(alo(va[e]) * f + alo(vb[e]) * (1.f - f), ahi(va[e]) * f + ahi(vb[e]) * (1.f - f));
     *reinterpret_cast<u32x4*>(out + p * o_pitch + o_off + c) = o;
   }
 }
 
 // partial[b][blk][2]: sum(h), sum(xw) over this block's slice of sample b
-__global__ __launch_bounds__(EW_THREADS) void rescale_sum_kernel(const bf16_t* __restrict__ h, const float* __restrict__ xw,
+__global__ __launch_bounds__(EW_THREADS) void rescale_sum_kernel(const a16_t* __restrict__ h, const float* __restrict__ xw,
                                                                  float* __restrict__ partial, long long n_per_sample,
                                                                  int blocks_per_sample) {
   __shared__ float red[2][EW_THREADS / 64];
@@ -39,14 +39,14 @@ __global__ __launch_bounds__(EW_THREADS) void rescale_sum_kernel(const bf16_t* _
   const long long nvec = n_per_sample / 8;
   const long long per = (nvec + blocks_per_sample - 1) / blocks_per_sample;
   const long long v0 = blk * per, v1 = min(nvec, v0 + per);
-  const bf16_t* hb = h + (size_t)b * n_per_sample;
+  const a16_t* hb = h + (size_t)b * n_per_sample;
   const float* xb = xw + (size_t)b * n_per_sample;
   float sh = 0.f, sx = 0.f;
   for (long long v = v0 + threadIdx.x; v < v1; v += EW_THREADS) {
     const u32x4 hv = *reinterpret_cast<const u32x4*>(hb + v * 8);
     const f32x4 x0 = *reinterpret_cast<const f32x4*>(xb + v * 8), x1 = *reinterpret_cast<const f32x4*>(xb + v * 8 + 4);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) sh += bflo(hv[e]) + bfhi(hv[e]);
+    for (int e = 0; e < 4; ++e) sh += alo(hv[e]) + ahi(hv[e]);
     sx += (x0[0] + x0[1]) + (x0[2] + x0[3]) + (x1[0] + x1[1]) + (x1[2] + x1[3]);
   }
   sh = wave_sum(sh);
@@ -61,8 +61,8 @@ __global__ __launch_bounds__(EW_THREADS) void rescale_sum_kernel(const bf16_t* _
   }
 }
 
-__global__ __launch_bounds__(EW_THREADS) void rescale_apply_kernel(const bf16_t* __restrict__ h, const float* __restrict__ xw,
-                                                                   const float* __restrict__ partial, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(EW_THREADS) void rescale_apply_kernel(const a16_t* __restrict__ h, const float* __restrict__ xw,
+                                                                   const float* __restrict__ partial, a16_t* __restrict__ out,
                                                                    long long n_per_sample, int blocks_per_sample, int B,
                                                                    int whole_batch) {
   __shared__ float ratio_s;
@@ -78,17 +78,17 @@ __global__ __launch_bounds__(EW_THREADS) void rescale_apply_kernel(const bf16_t*
   const long long nvec = n_per_sample / 8;
   const long long per = (nvec + blocks_per_sample - 1) / blocks_per_sample;
   const long long v0 = blk * per, v1 = min(nvec, v0 + per);
-  const bf16_t* hb = h + (size_t)b * n_per_sample;
+  const a16_t* hb = h + (size_t)b * n_per_sample;
   const float* xb = xw + (size_t)b * n_per_sample;
-  bf16_t* ob = out + (size_t)b * n_per_sample;
+  a16_t* ob = out + (size_t)b * n_per_sample;
   for (long long v = v0 + threadIdx.x; v < v1; v += EW_THREADS) {
     const u32x4 hv = *reinterpret_cast<const u32x4*>(hb + v * 8);
     const f32x4 x0 = *reinterpret_cast<const f32x4*>(xb + v * 8), x1 = *reinterpret_cast<const f32x4*>(xb + v * 8 + 4);
     u32x4 o;
-    o[0] = pack_bf2(bflo(hv[0]) + x0[0] * r, bfhi(hv[0]) + x0[1] * r);
-    o[1] = pack_bf2(bflo(hv[1]) + x0[2] * r, bfhi(hv[1]) + x0[3] * r);
-    o[2] = pack_bf2(bflo(hv[2]) + x1[0] * r, bfhi(hv[2]) + x1[1] * r);
-    o[3] = pack_bf2(bflo(hv[3]) + x1[2] * r, bfhi(hv[3]) + x1[3] * r);
+    o[0] = pack_a2(alo(hv[0]) + x0[0] * r, ahi(hv[0]) + x0[1] * r);
+    o[1] = pack_a2(alo(hv[1]) + x0[2] * r, ahi(hv[1]) + x0[3] * r);
+    o[2] = pack_a2(alo(hv[2]) + x1[0] * r, ahi(hv[2]) + x1[1] * r);
+    o[3] = pack_a2(alo(hv[3]) + x1[2] * r, ahi(hv[3]) + x1[3] * r);
     *reinterpret_cast<u32x4*>(ob + v * 8) = o;
   }
 }
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void layout_kernel(const void* __restrict__ sr
       const int c = c0 + tx;
       if (c < C && p < HW) {
         const size_t o = ((size_t)b * HW + p) * pitch + off + c;
-        if (BF16) reinterpret_cast<bf16_t*>(dst)[o] = f2bf(tile[tx][ty + 8 * k]);
+        if (BF16) reinterpret_cast<a16_t*>(dst)[o] = f2a(tile[tx][ty + 8 * k]);
         else reinterpret_cast<float*>(dst)[o] = tile[tx][ty + 8 * k];
       }
     }
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void layout_kernel(const void* __restrict__ sr
       float v = 0.f;
       if (c < C && p < HW) {
         const size_t o = ((size_t)b * HW + p) * pitch + off + c;
-        v = BF16 ? bf2f(reinterpret_cast<const bf16_t*>(src)[o]) : reinterpret_cast<const float*>(src)[o];
+        v = BF16 ? a2f(reinterpret_cast<const a16_t*>(src)[o]) : reinterpret_cast<const float*>(src)[o];
       }
       tile[ty + 8 * k][tx] = v;
     }
@@ -162,7 +162,7 @@ extern "C" int glare_mix_bf16(const void* a, int a_pitch, int a_off, const void*
   if ((C | a_pitch | a_off | b_pitch | b_off | out_pitch | out_off) % 8) return GLARE_ERR_UNSUPPORTED;
   const float f = 1.0f / (1.0f + expf(-mix_w));
   hipLaunchKernelGGL(mix_kernel, dim3(ew_blocks(n_pixels * (C / 8))), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                     (const bf16_t*)a, a_pitch, a_off, (const bf16_t*)b, b_pitch, b_off, (bf16_t*)out, out_pitch, out_off,
+                     (const a16_t*)a, a_pitch, a_off, (const a16_t*)b, b_pitch, b_off, (a16_t*)out, out_pitch, out_off,
                      n_pixels, C, f, (const float*)nullptr);
   return glare_launch_status();
 }
@@ -173,7 +173,7 @@ extern "C" int glare_mix_dev_bf16(const void* a, int a_pitch, int a_off, const v
   if (!a || !b || !out || !mix_w_device || n_pixels <= 0 || C <= 0) return GLARE_ERR_INVALID;
   if ((C | a_pitch | a_off | b_pitch | b_off | out_pitch | out_off) % 8) return GLARE_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(mix_kernel, dim3(ew_blocks(n_pixels * (C / 8))), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                     (const bf16_t*)a, a_pitch, a_off, (const bf16_t*)b, b_pitch, b_off, (bf16_t*)out, out_pitch, out_off,
+                     (const a16_t*)a, a_pitch, a_off, (const a16_t*)b, b_pitch, b_off, (a16_t*)out, out_pitch, out_off,
                      n_pixels, C, 0.f, mix_w_device);
   return glare_launch_status();
 }
@@ -191,10 +191,10 @@ extern "C" int glare_mean_rescale_bf16(const void* h, const float* xw, void* out
   if (!workspace || workspace_bytes < glare_mean_rescale_workspace_bytes(B, n_per_sample)) return GLARE_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
   const int bps = rescale_bps(n_per_sample);
-  hipLaunchKernelGGL(rescale_sum_kernel, dim3(B * bps), dim3(EW_THREADS), 0, stream, (const bf16_t*)h, xw, (float*)workspace,
+  hipLaunchKernelGGL(rescale_sum_kernel, dim3(B * bps), dim3(EW_THREADS), 0, stream, (const a16_t*)h, xw, (float*)workspace,
                      n_per_sample, bps);
-  hipLaunchKernelGGL(rescale_apply_kernel, dim3(B * bps), dim3(EW_THREADS), 0, stream, (const bf16_t*)h, xw,
-                     (const float*)workspace, (bf16_t*)out, n_per_sample, bps, B, whole_batch_mean);
+  hipLaunchKernelGGL(rescale_apply_kernel, dim3(B * bps), dim3(EW_THREADS), 0, stream, (const a16_t*)h, xw,
+                     (const float*)workspace, (a16_t*)out, n_per_sample, bps, B, whole_batch_mean);
   return glare_launch_status();
 }
 

@@ -23,9 +23,16 @@ constexpr int FL_THREADS = 256;
 
 __device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+struct TailParams {
+  float M[9];
+  float t[3];
+};
+
+// RAW: the pre-activation sum itself in fp32 (what fAffine[0]'s ActNorm sees at its data-dependent initialisation)
+template <bool RAW>
 __global__ __launch_bounds__(FL_THREADS) void flow_h1_kernel(const float* __restrict__ z, const float* __restrict__ ftA,
                                                              int a_pitch, int a_off, const float* __restrict__ wz,
-                                                             bf16_t* __restrict__ h1, int B, int H, int W) {
+                                                             a16_t* __restrict__ h1, float* __restrict__ raw, int B, int H, int W) {
   __shared__ float wl[9][64];
   for (int i = threadIdx.x; i < 576; i += FL_THREADS) wl[i % 9][i / 9] = wz[i];  // wz is [64][9]
   __syncthreads();
@@ -46,17 +53,72 @@ __global__ __launch_bounds__(FL_THREADS) void flow_h1_kernel(const float* __rest
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] = fmaf(v, wl[t][g * 8 + e], acc[e]);
     }
-    u32x4 o;
+    if (RAW) {
+      *reinterpret_cast<f32x4*>(raw + pix * 64 + g * 8) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+      *reinterpret_cast<f32x4*>(raw + pix * 64 + g * 8 + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+    } else {
+      u32x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = pack_bf2(fmaxf(acc[2 * e], 0.f), fmaxf(acc[2 * e + 1], 0.f));
-    *reinterpret_cast<u32x4*>(h1 + pix * 64 + g * 8) = o;
+      for (int e = 0; e < 4; ++e) o[e] = pack_a2(fmaxf(acc[2 * e], 0.f), fmaxf(acc[2 * e + 1], 0.f));
+      *reinterpret_cast<u32x4*>(h1 + pix * 64 + g * 8) = o;
+    }
   }
 }
 
-struct TailParams {
-  float M[9];
-  float t[3];
-};
+// z = M z + t alone (a coupling-free step, FlowStep.py:83-88 with flow_coupling == "noCoupling")
+__global__ __launch_bounds__(FL_THREADS) void flow_affine3_kernel(float* __restrict__ z, long long npix, TailParams tp) {
+  for (long long p = (long long)blockIdx.x * FL_THREADS + threadIdx.x; p < npix; p += (long long)gridDim.x * FL_THREADS) {
+    const float a0 = z[p * 3], a1 = z[p * 3 + 1], a2 = z[p * 3 + 2];
+    z[p * 3] = fmaf(tp.M[0], a0, fmaf(tp.M[1], a1, fmaf(tp.M[2], a2, tp.t[0])));
+    z[p * 3 + 1] = fmaf(tp.M[3], a0, fmaf(tp.M[4], a1, fmaf(tp.M[5], a2, tp.t[1])));
+    z[p * 3 + 2] = fmaf(tp.M[6], a0, fmaf(tp.M[7], a1, fmaf(tp.M[8], a2, tp.t[2])));
+  }
+}
+
+// ---- ActNorm data-dependent initialisation (FlowActNorms.py:32-46) -----------------------------------------------------------
+//   bias = -mean(x);  logs = log(scale / (sqrt(mean((x + bias)^2)) + 1e-6))      per channel over (B, H, W)
+// Two passes of one kernel over x fp32 [P][pitch] (the mean, then the centred second moment: the reference's own two-pass
+// form), each block a fixed slice of the pixels, fp64 partials, a final single-block reduction in a fixed order:
+// deterministic, no atomics.  C <= 64.
+constexpr int AN_MAXC = 64;
+__global__ __launch_bounds__(FL_THREADS) void actnorm_partial_kernel(const float* __restrict__ x, int pitch, int off, int C, long long P,
+                                                                     const double* __restrict__ mean, double* __restrict__ partial) {
+  __shared__ double red[FL_THREADS];
+  const int lanes_per_pix = C <= 4 ? 4 : (C <= 16 ? 16 : 64);      // threads along the channel axis
+  const int c = threadIdx.x % lanes_per_pix, pl = threadIdx.x / lanes_per_pix, ppi = FL_THREADS / lanes_per_pix;
+  const long long per = (P + gridDim.x - 1) / gridDim.x;
+  const long long p0 = (long long)blockIdx.x * per, p1 = min(P, p0 + per);
+  const double mu = (mean && c < C) ? mean[c] : 0.0;
+  double acc = 0.0;
+  if (c < C)
+    for (long long p = p0 + pl; p < p1; p += ppi) {
+      const double v = (double)x[p * pitch + off + c] - mu;
+      acc += mean ? v * v : v;
+    }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < lanes_per_pix && threadIdx.x < C) {
+    double a = 0.0;
+    for (int r = 0; r < ppi; ++r) a += red[r * lanes_per_pix + threadIdx.x];
+    partial[(size_t)blockIdx.x * AN_MAXC + threadIdx.x] = a;
+  }
+}
+
+// stage 0: mean[c] = sum / P.   stage 1: bias = -mean, logs = log(scale / (sqrt(sum / P) + 1e-6))
+__global__ void actnorm_final_kernel(const double* __restrict__ partial, int nblocks, int C, long long P, int stage, float scale,
+                                     double* __restrict__ mean, float* __restrict__ bias, float* __restrict__ logs) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0;
+  for (int b = 0; b < nblocks; ++b) a += partial[(size_t)b * AN_MAXC + c];
+  a /= (double)P;
+  if (stage == 0) {
+    mean[c] = a;
+  } else {
+    bias[c] = (float)(-mean[c]);
+    logs[c] = logf(scale / (sqrtf((float)a) + 1e-6f));
+  }
+}
 
 __global__ __launch_bounds__(FL_THREADS) void flow_tail_kernel(float* __restrict__ z, const float* __restrict__ h4,
                                                                const float* __restrict__ hF, int f_pitch, int f_off,
@@ -183,8 +245,52 @@ extern "C" int glare_flow_h1_f32(const float* z_nhwc3, const float* ftA, int ftA
                                  const float* wz_64x9, void* h1_bf16, int B, int H, int W, glare_stream_t stream) {
   if (!z_nhwc3 || !ftA || !wz_64x9 || !h1_bf16 || B <= 0 || H <= 0 || W <= 0) return GLARE_ERR_INVALID;
   if ((ftA_pitch % 4) || (ftA_off % 4) || ftA_off + 64 > ftA_pitch) return GLARE_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(flow_h1_kernel, dim3(fl_blocks((long long)B * H * W * 8)), dim3(FL_THREADS), 0, (hipStream_t)stream,
-                     z_nhwc3, ftA, ftA_pitch, ftA_off, wz_64x9, (bf16_t*)h1_bf16, B, H, W);
+  hipLaunchKernelGGL(flow_h1_kernel<false>, dim3(fl_blocks((long long)B * H * W * 8)), dim3(FL_THREADS), 0, (hipStream_t)stream,
+                     z_nhwc3, ftA, ftA_pitch, ftA_off, wz_64x9, (a16_t*)h1_bf16, (float*)nullptr, B, H, W);
+  return glare_launch_status();
+}
+
+extern "C" int glare_flow_h1_raw_f32(const float* z_nhwc3, const float* ftA, int ftA_pitch, int ftA_off, const float* wz_64x9,
+                                     float* raw_f32, int B, int H, int W, glare_stream_t stream) {
+  if (!z_nhwc3 || !ftA || !wz_64x9 || !raw_f32 || B <= 0 || H <= 0 || W <= 0) return GLARE_ERR_INVALID;
+  if ((ftA_pitch % 4) || (ftA_off % 4) || ftA_off + 64 > ftA_pitch) return GLARE_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(flow_h1_kernel<true>, dim3(fl_blocks((long long)B * H * W * 8)), dim3(FL_THREADS), 0, (hipStream_t)stream,
+                     z_nhwc3, ftA, ftA_pitch, ftA_off, wz_64x9, (a16_t*)nullptr, raw_f32, B, H, W);
+  return glare_launch_status();
+}
+
+extern "C" int glare_flow_affine3_f32(float* z_nhwc3, long long n_pixels, const float* M_3x3_host, const float* t_3_host,
+                                      glare_stream_t stream) {
+  if (!z_nhwc3 || !M_3x3_host || !t_3_host || n_pixels <= 0) return GLARE_ERR_INVALID;
+  TailParams tp;
+  for (int i = 0; i < 9; ++i) tp.M[i] = M_3x3_host[i];
+  for (int i = 0; i < 3; ++i) tp.t[i] = t_3_host[i];
+  hipLaunchKernelGGL(flow_affine3_kernel, dim3(fl_blocks(n_pixels)), dim3(FL_THREADS), 0, (hipStream_t)stream, z_nhwc3, n_pixels, tp);
+  return glare_launch_status();
+}
+
+static int an_blocks(long long P) {
+  long long b = P / 512;
+  return (int)(b < 1 ? 1 : (b > 256 ? 256 : b));
+}
+
+extern "C" size_t glare_actnorm_init_workspace_bytes(long long n_pixels) {
+  return n_pixels <= 0 ? 0 : ((size_t)an_blocks(n_pixels) * AN_MAXC + AN_MAXC) * sizeof(double);
+}
+
+extern "C" int glare_actnorm_init_f32(const float* x, int pitch, int off, int C, long long n_pixels, float scale, float* bias_out,
+                                      float* logs_out, void* workspace, size_t workspace_bytes, glare_stream_t stream) {
+  if (!x || !bias_out || !logs_out || n_pixels <= 0 || C <= 0 || pitch <= 0 || off < 0 || off + C > pitch) return GLARE_ERR_INVALID;
+  if (C > AN_MAXC) return GLARE_ERR_UNSUPPORTED;
+  if (!workspace || workspace_bytes < glare_actnorm_init_workspace_bytes(n_pixels)) return GLARE_ERR_WORKSPACE;
+  const int nb = an_blocks(n_pixels);
+  double* partial = static_cast<double*>(workspace);
+  double* mean = partial + (size_t)nb * AN_MAXC;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(actnorm_partial_kernel, dim3(nb), dim3(FL_THREADS), 0, st, x, pitch, off, C, n_pixels, (const double*)nullptr, partial);
+  hipLaunchKernelGGL(actnorm_final_kernel, dim3(1), dim3(AN_MAXC), 0, st, partial, nb, C, n_pixels, 0, scale, mean, bias_out, logs_out);
+  hipLaunchKernelGGL(actnorm_partial_kernel, dim3(nb), dim3(FL_THREADS), 0, st, x, pitch, off, C, n_pixels, (const double*)mean, partial);
+  hipLaunchKernelGGL(actnorm_final_kernel, dim3(1), dim3(AN_MAXC), 0, st, partial, nb, C, n_pixels, 1, scale, mean, bias_out, logs_out);
   return glare_launch_status();
 }
 

@@ -20,9 +20,9 @@ constexpr int GN_GROUPS = 32;
 // ADD: y = x + addend (dense, pitch C) is formed, rounded to bf16, stored to `sum_out`, and the statistics are those of y --
 // the residual add that is left of AttnBlock once proj_out is folded into v, fused with the next norm's statistics pass.
 template <bool ADD>
-__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ partial,
+__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const a16_t* __restrict__ x, float* __restrict__ partial,
                                                               long long HW, int C, int pitch, int off, int splits,
-                                                              const bf16_t* __restrict__ addend, bf16_t* __restrict__ sum_out) {
+                                                              const a16_t* __restrict__ addend, a16_t* __restrict__ sum_out) {
   // deterministic block reduction (no float atomics: the statistics, and everything downstream, must not depend on
   // the order in which waves happen to arrive): per-thread sums -> per-channel sums -> per-group sums, fixed order
   __shared__ float vals[GN_THREADS][17];
@@ -37,13 +37,13 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16_t* __re
 #pragma unroll
   for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
   {
-    const bf16_t* base = x + (size_t)b * HW * pitch + off + chunk * 8;
-    const bf16_t* abase = ADD ? addend + (size_t)b * HW * C + chunk * 8 : nullptr;
-    bf16_t* obase = ADD ? sum_out + (size_t)b * HW * C + chunk * 8 : nullptr;
+    const a16_t* base = x + (size_t)b * HW * pitch + off + chunk * 8;
+    const a16_t* abase = ADD ? addend + (size_t)b * HW * C + chunk * 8 : nullptr;
+    a16_t* obase = ADD ? sum_out + (size_t)b * HW * C + chunk * 8 : nullptr;
     auto accum = [&](const u32x4& v) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float lo = bflo(v[e]), hi = bfhi(v[e]);
+        const float lo = alo(v[e]), hi = ahi(v[e]);
         s[2 * e] += lo; q[2 * e] += lo * lo;
         s[2 * e + 1] += hi; q[2 * e + 1] += hi * hi;
       }
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16_t* __re
         const u32x4 c = *reinterpret_cast<const u32x4*>(abase + (size_t)q * C);
         u32x4 y;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = pack_bf2(bflo(a[e]) + bflo(c[e]), bfhi(a[e]) + bfhi(c[e]));
+        for (int e = 0; e < 4; ++e) y[e] = pack_a2(alo(a[e]) + alo(c[e]), ahi(a[e]) + ahi(c[e]));
         *reinterpret_cast<u32x4*>(obase + (size_t)q * C) = y;
         return y;
       };
@@ -95,9 +95,9 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16_t* __re
 
 // SWISH is a template parameter: as a run-time flag it compiled to one branch per bf16 pair of the streaming loop
 template <bool SWISH>
-__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ partial,
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const a16_t* __restrict__ x, const float* __restrict__ partial,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                              bf16_t* __restrict__ y, long long HW, int C, int pitch, int off,
+                                                              a16_t* __restrict__ y, long long HW, int C, int pitch, int off,
                                                               int splits, float eps, int blocks_per_image) {
   __shared__ float mean_s[GN_GROUPS], rstd_s[GN_GROUPS];
   const int b = blockIdx.x / blocks_per_image, blk = blockIdx.x % blocks_per_image;
@@ -129,16 +129,16 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __re
   }
   const long long per = (HW + blocks_per_image - 1) / blocks_per_image;
   const long long p0 = blk * per, p1 = min(HW, p0 + per);
-  const bf16_t* xb = x + (size_t)b * HW * pitch + off + chunk * 8;
-  bf16_t* yb = y + (size_t)b * HW * C + chunk * 8;
+  const a16_t* xb = x + (size_t)b * HW * pitch + off + chunk * 8;
+  a16_t* yb = y + (size_t)b * HW * C + chunk * 8;
   auto apply = [&](const u32x4& v) {
     u32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      float lo = bflo(v[e]) * sc[2 * e] + sh[2 * e];
-      float hi = bfhi(v[e]) * sc[2 * e + 1] + sh[2 * e + 1];
+      float lo = alo(v[e]) * sc[2 * e] + sh[2 * e];
+      float hi = ahi(v[e]) * sc[2 * e + 1] + sh[2 * e + 1];
       if (SWISH) { lo = swishf_(lo); hi = swishf_(hi); }
-      o[e] = pack_bf2(lo, hi);
+      o[e] = pack_a2(lo, hi);
     }
     return o;
   };
@@ -182,8 +182,8 @@ int gn_splits(long long HW) {
 __global__ __launch_bounds__(256) void attn_fold_kernel(const float* __restrict__ stats, int splits, long long HW, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, const float* __restrict__ wq,
                                                         const float* __restrict__ bq, const float* __restrict__ wo,
-                                                        const float* __restrict__ bo, bf16_t* __restrict__ wq_out,
-                                                        float* __restrict__ bq_out, bf16_t* __restrict__ wo_out,
+                                                        const float* __restrict__ bo, a16_t* __restrict__ wq_out,
+                                                        float* __restrict__ bq_out, a16_t* __restrict__ wo_out,
                                                         float* __restrict__ bo_out, int C) {
   __shared__ float a_s[2048], d_s[2048];
   __shared__ float red[2][4];
@@ -209,8 +209,8 @@ __global__ __launch_bounds__(256) void attn_fold_kernel(const float* __restrict_
   const size_t row = ((size_t)b * C + o) * C;
   for (int c = threadIdx.x; c < C; c += 256) {
     const float wqv = wq[(size_t)o * C + c], wov = wo[(size_t)o * C + c];
-    wq_out[row + c] = f2bf(ao * wqv * a_s[c]);
-    wo_out[row + c] = f2bf(wov * a_s[c]);
+    wq_out[row + c] = f2a(ao * wqv * a_s[c]);
+    wo_out[row + c] = f2a(wov * a_s[c]);
     dq = fmaf(wqv, d_s[c], dq);
     dv = fmaf(wov, d_s[c], dv);
   }
@@ -241,16 +241,16 @@ extern "C" int glare_groupnorm_swish_bf16(const void* x, int in_pitch, int in_of
   if (!workspace || workspace_bytes < glare_groupnorm_workspace_bytes(B, HW)) return GLARE_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
   const int splits = gn_splits(HW);
-  hipLaunchKernelGGL(gn_stats_kernel<false>, dim3(splits, B), dim3(GN_THREADS), 0, stream, (const bf16_t*)x, (float*)workspace,
-                     HW, C, in_pitch, in_off, splits, (const bf16_t*)nullptr, (bf16_t*)nullptr);
+  hipLaunchKernelGGL(gn_stats_kernel<false>, dim3(splits, B), dim3(GN_THREADS), 0, stream, (const a16_t*)x, (float*)workspace,
+                     HW, C, in_pitch, in_off, splits, (const a16_t*)nullptr, (a16_t*)nullptr);
   int bpi = (int)((HW * (C / 8) + 16 * GN_THREADS - 1) / (16 * GN_THREADS));  // ~16 chunks per thread
   if (bpi < 1) bpi = 1;
   if (swish)
-    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3((unsigned)(bpi * B)), dim3(GN_THREADS), 0, stream, (const bf16_t*)x,
-                       (const float*)workspace, gamma, beta, (bf16_t*)y, HW, C, in_pitch, in_off, splits, eps, bpi);
+    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3((unsigned)(bpi * B)), dim3(GN_THREADS), 0, stream, (const a16_t*)x,
+                       (const float*)workspace, gamma, beta, (a16_t*)y, HW, C, in_pitch, in_off, splits, eps, bpi);
   else
-    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3((unsigned)(bpi * B)), dim3(GN_THREADS), 0, stream, (const bf16_t*)x,
-                       (const float*)workspace, gamma, beta, (bf16_t*)y, HW, C, in_pitch, in_off, splits, eps, bpi);
+    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3((unsigned)(bpi * B)), dim3(GN_THREADS), 0, stream, (const a16_t*)x,
+                       (const float*)workspace, gamma, beta, (a16_t*)y, HW, C, in_pitch, in_off, splits, eps, bpi);
   return glare_launch_status();
 }
 
@@ -260,8 +260,8 @@ extern "C" int glare_add_groupnorm_stats_bf16(const void* a, const void* b, void
   if (C % 32 || C > 2048 || (GN_THREADS % (C / 8))) return GLARE_ERR_UNSUPPORTED;
   if (stats_bytes < glare_groupnorm_workspace_bytes(B, HW)) return GLARE_ERR_WORKSPACE;
   const int splits = gn_splits(HW);
-  hipLaunchKernelGGL(gn_stats_kernel<true>, dim3(splits, B), dim3(GN_THREADS), 0, (hipStream_t)stream_, (const bf16_t*)a,
-                     (float*)stats, HW, C, C, 0, splits, (const bf16_t*)b, (bf16_t*)out);
+  hipLaunchKernelGGL(gn_stats_kernel<true>, dim3(splits, B), dim3(GN_THREADS), 0, (hipStream_t)stream_, (const a16_t*)a,
+                     (float*)stats, HW, C, C, 0, splits, (const a16_t*)b, (a16_t*)out);
   return glare_launch_status();
 }
 
@@ -274,11 +274,11 @@ extern "C" int glare_groupnorm_apply_bf16(const void* x, int in_pitch, int in_of
   int bpi = (int)((HW * (C / 8) + 16 * GN_THREADS - 1) / (16 * GN_THREADS));
   if (bpi < 1) bpi = 1;
   if (swish)
-    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3((unsigned)(bpi * B)), dim3(GN_THREADS), 0, (hipStream_t)stream_, (const bf16_t*)x,
-                       stats, gamma, beta, (bf16_t*)y, HW, C, in_pitch, in_off, splits, eps, bpi);
+    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3((unsigned)(bpi * B)), dim3(GN_THREADS), 0, (hipStream_t)stream_, (const a16_t*)x,
+                       stats, gamma, beta, (a16_t*)y, HW, C, in_pitch, in_off, splits, eps, bpi);
   else
-    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3((unsigned)(bpi * B)), dim3(GN_THREADS), 0, (hipStream_t)stream_, (const bf16_t*)x,
-                       stats, gamma, beta, (bf16_t*)y, HW, C, in_pitch, in_off, splits, eps, bpi);
+    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3((unsigned)(bpi * B)), dim3(GN_THREADS), 0, (hipStream_t)stream_, (const a16_t*)x,
+                       stats, gamma, beta, (a16_t*)y, HW, C, in_pitch, in_off, splits, eps, bpi);
   return glare_launch_status();
 }
 
@@ -292,6 +292,6 @@ extern "C" int glare_attn_fold_groupnorm_f32(const float* stats, int splits, int
   if (!stats || !gamma || !beta || !wq || !bq || !wo || !bo || !wq_out || !bq_out || !wo_out || !bo_out) return GLARE_ERR_INVALID;
   if (splits <= 0 || B <= 0 || B > 65535 || HW <= 0 || C <= 0 || C % GN_GROUPS || C > 2048) return GLARE_ERR_INVALID;
   hipLaunchKernelGGL(attn_fold_kernel, dim3(C, B), dim3(256), 0, (hipStream_t)stream, stats, splits, HW, gamma, beta, eps, wq, bq, wo, bo,
-                     (bf16_t*)wq_out, bq_out, (bf16_t*)wo_out, bo_out, C);
+                     (a16_t*)wq_out, bq_out, (a16_t*)wo_out, bo_out, C);
   return glare_launch_status();
 }

@@ -575,8 +575,10 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
 // torch.optim.Adam (no amsgrad, no weight decay unless wd != 0 -> L2 added to the gradient as torch does)
 // step counter and bias corrections kept on the device, so that an optimizer step has no host-side state and the whole
 // training step can be replayed from a hipGraph: state = {bc1, sqrt(bc2), lr multiplier}, step_dev = the 1-based step count
-__global__ void adam_prepare_kernel(int* __restrict__ step_dev, float* __restrict__ state, float b1, float b2) {
+__global__ void adam_prepare_kernel(int* __restrict__ step_dev, float* __restrict__ state, float b1, float b2,
+                                    const int* __restrict__ skip) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (skip && *skip) return;
   const int t = step_dev[0] + 1;
   step_dev[0] = t;
   state[0] = (float)(1.0 - pow((double)b1, t));
@@ -586,9 +588,10 @@ __global__ void adam_prepare_kernel(int* __restrict__ step_dev, float* __restric
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
                                                    float wd, float bc1, float bc2_sqrt, float grad_scale,
-                                                   const float* __restrict__ state_dev) {
+                                                   const float* __restrict__ state_dev, const int* __restrict__ skip) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  if (skip && *skip) return;   // GradScaler.step: inf / NaN somewhere in this step's gradients (wave-uniform scalar load)
   if (state_dev) { bc1 = state_dev[0]; bc2_sqrt = state_dev[1]; lr *= state_dev[2]; }
   float gi = g[i] * grad_scale;
   if (wd != 0.f) gi += wd * w[i];
@@ -597,6 +600,26 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const 
   m[i] = mi; v[i] = vi;
   const float denom = sqrtf(vi) / bc2_sqrt + eps;   // torch: (sqrt(v) / sqrt(bias_correction2)) + eps
   w[i] -= (lr / bc1) * (mi / denom);
+}
+
+// found |= any(!isfinite(g)): exponent all ones.  One atomicOr per block that saw one (OR: order-independent).
+__global__ __launch_bounds__(256) void nonfinite_kernel(const float* __restrict__ g, long long n, int* __restrict__ found) {
+  bool bad = false;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    bad |= (__float_as_uint(g[i]) & 0x7f800000u) == 0x7f800000u;
+  if (__syncthreads_or(bad) && threadIdx.x == 0) atomicOr(found, 1);
+}
+
+__global__ void gradscaler_update_kernel(float* __restrict__ scale, int* __restrict__ tracker, const int* __restrict__ found,
+                                         float growth, float backoff, int interval) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (*found) {
+    *scale *= backoff;
+    *tracker = 0;
+  } else {
+    const int t = *tracker + 1;
+    if (t == interval) { *scale *= growth; *tracker = 0; } else { *tracker = t; }
+  }
 }
 
 }  // namespace
@@ -849,23 +872,53 @@ extern "C" int glare_adam_step_f32(float* w, const float* grad, float* exp_avg, 
   if (!w || !grad || !exp_avg || !exp_avg_sq) return GLARE_ERR_INVALID;
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)cdivll(n, 256)), dim3(256), 0, ST(stream), w, grad, exp_avg, exp_avg_sq, n, lr, beta1,
-                     beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale, (const float*)nullptr);
+                     beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale, (const float*)nullptr, (const int*)nullptr);
+  return glare_launch_status();
+}
+
+extern "C" int glare_adam_prepare_guarded(int* step_device, float* state3_device, float beta1, float beta2,
+                                          const int* skip_if_nonzero_device, glare_stream_t stream) {
+  if (!step_device || !state3_device) return GLARE_ERR_INVALID;
+  hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(64), 0, ST(stream), step_device, state3_device, beta1, beta2,
+                     skip_if_nonzero_device);
   return glare_launch_status();
 }
 
 extern "C" int glare_adam_prepare(int* step_device, float* state3_device, float beta1, float beta2, glare_stream_t stream) {
-  if (!step_device || !state3_device) return GLARE_ERR_INVALID;
-  hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(64), 0, ST(stream), step_device, state3_device, beta1, beta2);
+  return glare_adam_prepare_guarded(step_device, state3_device, beta1, beta2, nullptr, stream);
+}
+
+extern "C" int glare_grad_nonfinite_f32(const float* grad, long long n, int* found_device, glare_stream_t stream) {
+  if (n < 0 || !found_device) return GLARE_ERR_INVALID;
+  if (n == 0) return GLARE_OK;
+  if (!grad) return GLARE_ERR_INVALID;
+  const long long blocks = cdivll(n, 256 * 16);
+  hipLaunchKernelGGL(nonfinite_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, ST(stream), grad, n, found_device);
+  return glare_launch_status();
+}
+
+extern "C" int glare_gradscaler_update(float* scale_device, int* growth_tracker_device, const int* found_device, float growth_factor,
+                                       float backoff_factor, int growth_interval, glare_stream_t stream) {
+  if (!scale_device || !growth_tracker_device || !found_device || growth_interval < 1) return GLARE_ERR_INVALID;
+  hipLaunchKernelGGL(gradscaler_update_kernel, dim3(1), dim3(64), 0, ST(stream), scale_device, growth_tracker_device, found_device,
+                     growth_factor, backoff_factor, growth_interval);
+  return glare_launch_status();
+}
+
+extern "C" int glare_adam_step_dev_guarded_f32(float* w, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
+                                               float beta1, float beta2, float eps, float weight_decay, const float* state3_device,
+                                               float grad_scale, const int* skip_if_nonzero_device, glare_stream_t stream) {
+  if (n < 0) return GLARE_ERR_INVALID;
+  if (n == 0) return GLARE_OK;
+  if (!w || !grad || !exp_avg || !exp_avg_sq || !state3_device) return GLARE_ERR_INVALID;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)cdivll(n, 256)), dim3(256), 0, ST(stream), w, grad, exp_avg, exp_avg_sq, n, lr, beta1,
+                     beta2, eps, weight_decay, 1.f, 1.f, grad_scale, state3_device, skip_if_nonzero_device);
   return glare_launch_status();
 }
 
 extern "C" int glare_adam_step_dev_f32(float* w, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1,
                                        float beta2, float eps, float weight_decay, const float* state3_device, float grad_scale,
                                        glare_stream_t stream) {
-  if (n < 0) return GLARE_ERR_INVALID;
-  if (n == 0) return GLARE_OK;
-  if (!w || !grad || !exp_avg || !exp_avg_sq || !state3_device) return GLARE_ERR_INVALID;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)cdivll(n, 256)), dim3(256), 0, ST(stream), w, grad, exp_avg, exp_avg_sq, n, lr, beta1,
-                     beta2, eps, weight_decay, 1.f, 1.f, grad_scale, state3_device);
-  return glare_launch_status();
+  return glare_adam_step_dev_guarded_f32(w, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, state3_device, grad_scale,
+                                         nullptr, stream);
 }

@@ -150,7 +150,7 @@ class FlowUpsamplerNet(HipModule):
         for s, st in enumerate(P["steps"]):                                        # z-independent, batched up front
             ops.conv2d(h1f, st["f2"], cin=64, in_off=64 * s, act="relu", out=h2f, out_off=64 * s)
             ops.conv2d(h2f, st["f4"], cin=64, in_off=64 * s, out=hF, out_off=8 * s, out_mode=ops.OUT_NHWC_F32)
-        h1 = torch.empty(B, H, W, 64, dtype=torch.bfloat16, device=z.device)
+        h1 = torch.empty(B, H, W, 64, dtype=ops.act_dtype(), device=z.device)
         h2 = torch.empty_like(h1)
         h4 = torch.empty(B, H, W, 4, dtype=torch.float32, device=z.device)
         for s, st in enumerate(P["steps"]):                                        # the sequential part
@@ -159,6 +159,85 @@ class FlowUpsamplerNet(HipModule):
             ops.conv2d(h2, st["c4"], out=h4, out_mode=ops.OUT_NHWC_F32)
             ops.flow_tail(z, h4, hF, 8 * s, st["M"], st["t"], st["eps"])
         return z
+
+    # ---- ActNorm data-dependent initialisation (row a12: the first training forward of a fresh flow) ----------------
+    def actnorms(self):
+        """Every ActNorm2d in the order a training forward reaches them (FlowStep.normal_flow, FlowStep.py:75-98: the step's
+        own, then fFeatures', then fAffine's, FlowAffineCouplingsAblation.py:55-77)."""
+        out = []
+        for layer in self.layers:
+            out.append(layer.actnorm)
+            if layer.flow_coupling != "noCoupling":
+                f, a = layer.affine.fFeatures, layer.affine.fAffine
+                out += [f[0].actnorm, f[2].actnorm, a[0].actnorm, a[2].actnorm]
+        return out
+
+    def needs_actnorm_init(self):
+        return self.training and any(not m.inited for m in self.actnorms())
+
+    @torch.no_grad()
+    def initialize_actnorms_nhwc(self, gt, ft):
+        """_ActNorm.initialize_parameters (FlowActNorms.py:32-46) for every ActNorm a training forward has not seen yet, in the
+        reference's order: layer by layer through the normal direction, each ActNorm taking `bias = -mean`, `logs =
+        log(scale / (std + 1e-6))` of ITS input over (B, H, W) as produced by the layers already initialised before it.  An
+        ActNorm whose bias is not all-zero is only marked initialised (:36-38: a loaded checkpoint).  One-off (the first
+        training step), so the pass is plain: raw conv (no bias, fp32 out) -> statistics kernel -> the folded conv the
+        training forward itself runs.  gt: fp32 NHWC [B,h,w,3]; ft: 16-bit NHWC [B,h,w,64] (cond_feat)."""
+        pending = [m for m in self.actnorms() if not m.inited]
+        if not pending:
+            return
+        nonzero = torch.stack([(m.bias != 0).any() for m in pending]).cpu().tolist()     # the one host read of the pass
+        need = {id(m) for m, nz in zip(pending, nonzero) if not nz}
+        for m in pending:
+            m.inited = True
+        if not need:
+            return
+        B, H, W, _ = gt.shape
+        F32 = ops.OUT_NHWC_F32
+        ft = ft.contiguous()
+        z = gt.detach().clone().contiguous()
+        eye, zero3 = [1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0], [0.0, 0.0, 0.0]
+        bps = ops.flow_blocks_per_sample(H * W)
+        partial = torch.zeros(B * bps, dtype=torch.float32, device=z.device)
+        hF = torch.zeros(B, H, W, 8, dtype=torch.float32, device=z.device)
+        h4 = torch.zeros(B, H, W, 4, dtype=torch.float32, device=z.device)
+
+        def init(an, x, C):
+            if id(an) in need:
+                T.actnorm_init_(x, C, an.bias.data, an.logs.data, scale=an.scale)
+
+        def tail(net, h1):   # conv 1x1 (+ActNorm) -> relu -> Conv2dZeros of a coupling net, given its first layer's output
+            if id(net[2].actnorm) in need:
+                init(net[2].actnorm, ops.conv2d(h1, ops.PackedConv(net[2].weight), out_mode=F32), 64)
+            h2 = ops.conv2d(h1, ops.PackedConv(*net[2].folded()), act="relu")
+            return h2
+
+        for layer in self.layers:
+            init(layer.actnorm, z, 3)
+            A, c, _ = layer.forward_affine_fp64()            # actnorm . invconv of this step with the fresh parameters
+            T.flow_affine3_(z, A.float().flatten().tolist(), c.float().tolist())
+            if layer.flow_coupling == "noCoupling":
+                continue
+            aff = layer.affine
+            f, a = aff.fFeatures, aff.fAffine
+            eps = float(aff.affine_eps)
+            # feature-conditional affine (FlowAffineCouplingsAblation.py:55-59)
+            if id(f[0].actnorm) in need:
+                init(f[0].actnorm, ops.conv2d(ft, ops.PackedConv(f[0].weight), out_mode=F32), 64)
+            h1 = ops.conv2d(ft, ops.PackedConv(*f[0].folded()), act="relu")
+            ops.conv2d(tail(f, h1), ops.PackedConv(*f[4].folded()), out=hF, out_off=0, out_mode=F32)
+            ops.flow_fwd_pre(z, hF, 0, eye, zero3, eps, partial)
+            # self-conditional affine (:62-77): the first conv sees cat[z1, ft]
+            w0 = a[0].weight.detach()
+            if id(a[0].actnorm) in need:
+                raw = ops.conv2d(ft, ops.PackedConv(w0[:, 1:].contiguous()), out_mode=F32)
+                init(a[0].actnorm, T.flow_h1_raw(z, raw, 0, w0[:, 0].reshape(64, 9).float().contiguous()), 64)
+            w0f, b0f = a[0].folded()
+            ftA = ops.conv2d(ft, ops.PackedConv(w0f[:, 1:].contiguous(), b0f), out_mode=F32)
+            h1 = ops.flow_h1(z, ftA, 0, w0f[:, 0].reshape(64, 9).float().contiguous())
+            ops.conv2d(tail(a, h1), ops.PackedConv(*a[4].folded()), out=h4, out_off=0, out_mode=F32)
+            ops.flow_fwd_post(z, h4, eps, partial)
+        self.invalidate()
 
     def _prepare_forward(self):
         """Host-side composition for the normal direction: per coupling step the affine map of its own
@@ -178,6 +257,8 @@ class FlowUpsamplerNet(HipModule):
     def encode_nhwc(self, gt, ft, mean=None):
         """Normal direction.  gt: fp32 NHWC latent [B,h,w,3]; ft: bf16 NHWC cond_feat.  Returns (z fp32 NHWC,
         logdet fp64 [B], logp fp64 [B] or None): FlowUpsamplerNet.encode (:228-274) + GaussianDiag.logp."""
+        if self.needs_actnorm_init():                # a fresh flow in train mode: FlowActNorms.py:82-83
+            self.initialize_actnorms_nhwc(gt, ft)
         P = self._packed("flow", self._prepare)      # packed convs are shared with the reverse direction
         F_ = self._packed("flow_fwd", self._prepare_forward)
         rev = {id(st["layer"]): st for st in P["steps"]}
@@ -194,7 +275,7 @@ class FlowUpsamplerNet(HipModule):
             ops.conv2d(h2f, st["f4"], cin=64, in_off=64 * s, out=hF, out_off=8 * s, out_mode=ops.OUT_NHWC_F32)
         bps = ops.flow_blocks_per_sample(H * W)
         partial = torch.zeros(2 * n, B * bps, dtype=torch.float32, device=z.device)
-        h1 = torch.empty(B, H, W, 64, dtype=torch.bfloat16, device=z.device)
+        h1 = torch.empty(B, H, W, 64, dtype=ops.act_dtype(), device=z.device)
         h2 = torch.empty_like(h1)
         h4 = torch.empty(B, H, W, 4, dtype=torch.float32, device=z.device)
         for k, fs in enumerate(F_["steps"]):

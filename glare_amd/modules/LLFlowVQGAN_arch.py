@@ -46,6 +46,10 @@ class LLFlowVQGAN2(HipModule):
         """Per-sample NLL (float64 [B]) with a tape through the conditional encoder and the flow: what
         LLFlowModel.optimize_parameters differentiates (LLFlow_model.py:215-236).  mean_is_gt: None = draw as the reference
         does (train_gt_ratio), True / False = forced."""
+        if self.flowUpsamplerNet.needs_actnorm_init():          # first training step of a fresh flow (FlowActNorms.py:82-83):
+            with torch.no_grad():                                # the ActNorms take their statistics from this batch, untaped
+                enc0 = self.RRDB.forward_nhwc(lr)
+                self.flowUpsamplerNet.initialize_actnorms_nhwc(gt_latent.detach(), enc0["cond_feat"])
         flow_params = self.flowUpsamplerNet._train_params()     # first: see train_nll_terms
         enc = self.RRDB.train_nhwc(lr)
         mean = gt_latent.detach() if self._mean_is_gt(mean_is_gt) else enc["color_map"]

@@ -8,6 +8,7 @@ import torch
 import torch.nn as nn
 
 from .. import autograd as A
+from .. import ops
 from ._base import HipModule, to_nchw
 from .ConditionEncoder import ConEncoder1
 from .deformableDecoder_arch import MultiScaleDecoder2
@@ -28,12 +29,16 @@ class VQLLFLOWDeformable(HipModule):
                 for p in getattr(self, name).parameters():
                     p.requires_grad = False
 
-    def reverse_flow_nhwc(self, net_vq, lr):
-        """lr: fp32 NCHW log-domain image batch.  Every intermediate stays NHWC on device."""
-        enc = self.RRDB.forward_nhwc(lr)
-        latent = self.flowUpsamplerNet.decode_nhwc(enc["color_map"], enc["cond_feat"])
-        idx, _, code_feats = net_vq.decode_nhwc(latent, want_image=False)
-        out = self.deformable_decoder.forward_nhwc(latent, code_feats, enc["mid_feat"])
+    def reverse_flow_nhwc(self, net_vq, lr, precision=None):
+        """lr: fp32 NCHW log-domain image batch.  Every intermediate stays NHWC on device.
+        precision: the 16-bit format of activations and filters -- "fp16" (IEEE half, the reference's own autocast dtype:
+        8x less rounding per stored tensor than bf16 at the same MFMA rate; what the end-to-end tolerance needs, DESIGN.md
+        section 4) or "bf16" (fp32 range; +2.7 % images/s); None = the enclosing `ops.use_precision`, else fp16."""
+        with ops.use_precision(ops.inference_precision(precision)):
+            enc = self.RRDB.forward_nhwc(lr)
+            latent = self.flowUpsamplerNet.decode_nhwc(enc["color_map"], enc["cond_feat"])
+            idx, _, code_feats = net_vq.decode_nhwc(latent, want_image=False)
+            out = self.deformable_decoder.forward_nhwc(latent, code_feats, enc["mid_feat"])
         return {"out": out, "latent": latent, "indices": idx, "enc": enc, "code_feats": code_feats}
 
     def reverse_flow_train_nhwc(self, net_vq, lr, whole_batch_mean=True):

@@ -9,6 +9,7 @@ class HipModule(nn.Module):
     """Caches kernel-ready (packed) weights; `invalidate()` after changing parameters."""
 
     def _packed(self, key, builder):
+        key = (key, ops.act_dtype())          # packed filters are in the 16-bit format of the precision in use
         cache = self.__dict__.setdefault("_hip_cache", {})
         if key not in cache:
             with torch.no_grad():

@@ -12,7 +12,9 @@ class ActNorm2d(nn.Module):
         super().__init__()
         self.bias = nn.Parameter(torch.zeros(1, num_features, 1, 1))
         self.logs = nn.Parameter(torch.zeros(1, num_features, 1, 1))
-        self.num_features, self.scale, self.inited = num_features, float(scale), True
+        self.num_features, self.scale = num_features, float(scale)
+        self.inited = False   # FlowActNorms.py:23: the first TRAINING forward initialises an all-zero ActNorm from its batch
+                              # (FlowUpsamplerNet.initialize_actnorms_nhwc; eval / inference never does, :34-35)
 
 
 class InvertibleConv1x1(nn.Module):

@@ -6,7 +6,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import check, ptr, require_cuda, stream_handle
+from ._lib import act_dtype, check, inference_precision, precision, ptr, require_cuda, stream_handle, use_precision  # noqa: F401
 
 _i = ctypes.c_int
 _ll = ctypes.c_longlong
@@ -74,7 +74,7 @@ class PackedConv:
             lib.glare_conv2d_upsample_packed_weight_elems.restype = _ll
             n = lib.glare_conv2d_upsample_packed_weight_elems(_i(cout), _i(cin))
             assert n > 0
-            self.packed = torch.empty(n, dtype=torch.bfloat16, device=w.device)
+            self.packed = torch.empty(n, dtype=act_dtype(), device=w.device)
             check(lib.glare_conv2d_pack_weight_upsample(ptr(w), _i(cout), _i(cin), ptr(self.packed), stream_handle()),
                   "glare_conv2d_pack_weight_upsample")
             self.bias = None if bias is None else bias.detach().float().contiguous()
@@ -83,7 +83,7 @@ class PackedConv:
         self.cout, self.cin = (cout, cin) if dgrad_pad is None else (cin, dgrad_pad)
         n = lib.glare_conv2d_packed_weight_elems(_i(self.cout), _i(self.cin), _i(kh))
         assert n > 0
-        self.packed = torch.empty(n, dtype=torch.bfloat16, device=w.device)
+        self.packed = torch.empty(n, dtype=act_dtype(), device=w.device)
         if dgrad_pad is None:
             check(lib.glare_conv2d_pack_weight(ptr(w), _i(cout), _i(cin), _i(kh), ptr(self.packed), stream_handle()),
                   "glare_conv2d_pack_weight")
@@ -94,7 +94,7 @@ class PackedConv:
         self.w16 = None
         if kh == 1 and dgrad_pad is None and lib.glare_conv1x1_ws_supported(_i(cin), _i(cout)):
             # the weight-stationary 1x1 kernel (csrc/conv1x1.hip) takes the filter as plain bf16 [Cout][Cin]
-            self.w16 = torch.empty(cout, cin, dtype=torch.bfloat16, device=w.device)
+            self.w16 = torch.empty(cout, cin, dtype=act_dtype(), device=w.device)
             check(lib.glare_conv1x1_ws_pack_weight(ptr(w), _i(cout), _i(cin), ptr(self.w16), stream_handle()), "glare_conv1x1_ws_pack_weight")
 
 
@@ -110,7 +110,7 @@ def packed_conv_batch(weights, biases=None, dgrad_pad=None, cout_tile=0):
     oc, ic = (cout, cin) if dgrad_pad is None else (cin, dgrad_pad)
     elems = lib.glare_conv2d_packed_weight_elems_tile(_i(oc), _i(ic), _i(kh), _i(cout_tile))
     assert elems > 0
-    packed = torch.empty(n, elems, dtype=torch.bfloat16, device=w.device)
+    packed = torch.empty(n, elems, dtype=act_dtype(), device=w.device)
     check(lib.glare_conv2d_pack_weight_batched(ptr(w), _i(n), _i(cout), _i(cin), _i(kh), _i(0 if dgrad_pad is None else dgrad_pad),
                                                _i(cout_tile), ptr(packed), stream_handle()), "glare_conv2d_pack_weight_batched")
     b = None if biases is None else biases.detach().float().contiguous()
@@ -250,7 +250,7 @@ def _conv1x1_ws(x, pc, cin, in_off, act, residual, res_off, out, out_off, gn_sta
     B, H, W, pitch = x.shape
     N = H * W
     if out is None:
-        out = torch.empty(B, H, W, pc.cout, dtype=torch.bfloat16, device=x.device)
+        out = torch.empty(B, H, W, pc.cout, dtype=act_dtype(), device=x.device)
     lib = _lib.lib()
     gn_part = None
     if gn_stats:
@@ -275,18 +275,18 @@ def conv1x1_per_image(x, w16, bias, residual=None, gn_stats=False):
     require_cuda(x, w16, bias, residual)
     B, H, W, cin = x.shape
     cout = w16.shape[1]
-    assert x.dtype == w16.dtype == torch.bfloat16 and x.is_contiguous() and w16.is_contiguous() and tuple(w16.shape) == (B, cout, cin)
+    assert x.dtype == w16.dtype == act_dtype() and x.is_contiguous() and w16.is_contiguous() and tuple(w16.shape) == (B, cout, cin)
     assert bias.dtype == torch.float32 and bias.is_contiguous() and tuple(bias.shape) == (B, cout)
     N = H * W
     count_flops("conv k1", 2.0 * B * N * cin * cout)
-    out = torch.empty(B, H, W, cout, dtype=torch.bfloat16, device=x.device)
+    out = torch.empty(B, H, W, cout, dtype=act_dtype(), device=x.device)
     lib = _lib.lib()
     gn_part = None
     if gn_stats:
         lib.glare_conv1x1_ws_gn_partial_elems.restype = _ll
         gn_part = torch.empty(lib.glare_conv1x1_ws_gn_partial_elems(_i(B), _ll(N), _i(cout)), dtype=torch.float32, device=x.device)
     if residual is not None:
-        assert residual.dtype == torch.bfloat16 and residual.is_contiguous() and residual.shape == out.shape
+        assert residual.dtype == act_dtype() and residual.is_contiguous() and residual.shape == out.shape
     check(lib.glare_conv1x1_ws_image_bf16(ptr(x), _i(cin), _i(0), ptr(w16), _ll(cout * cin), ptr(bias), _i(cout), ptr(residual),
                                           _i(cout if residual is not None else 0), _i(0), ptr(out), _i(cout), _i(0), _i(B), _ll(N), _i(cin),
                                           _i(cout), _i(0), ptr(gn_part), stream_handle()), "glare_conv1x1_ws_image_bf16")
@@ -307,7 +307,7 @@ def attn_fold_groupnorm(stats, HW, gamma, beta, eps, wq, bq, wo, bo):
     assert stats.dtype == torch.float32 and stats.is_contiguous() and tuple(stats.shape[2:]) == (32, 2)
     for t in (gamma, beta, wq, bq, wo, bo):
         assert t.dtype == torch.float32 and t.is_contiguous()
-    wq_b = torch.empty(B, C, C, dtype=torch.bfloat16, device=stats.device)
+    wq_b = torch.empty(B, C, C, dtype=act_dtype(), device=stats.device)
     wo_b = torch.empty_like(wq_b)
     bq_b = torch.empty(B, C, dtype=torch.float32, device=stats.device)
     bo_b = torch.empty_like(bq_b)
@@ -322,7 +322,8 @@ def conv2d(x, pc, *, x2=None, cin=None, in_off=0, cin2=None, in2_off=0, stride=1
     """x: NHWC bf16 [B,H,W,pitch] (channels [in_off, in_off+cin) are used), optional x2 concatenated
     after it.  Returns (or fills `out`) per out_mode; planar outputs are [B, planes, plane_pitch]."""
     require_cuda(x, x2, residual, out)
-    assert x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous()
+    assert x.dtype == act_dtype() and x.dim() == 4 and x.is_contiguous(), (x.dtype, act_dtype())
+    assert pc.packed.dtype == x.dtype, "filter packed under another precision"
     B, H, W, pitch = x.shape
     cin = pitch - in_off if cin is None else cin
     if FLOP_COUNTER is not None:
@@ -330,17 +331,17 @@ def conv2d(x, pc, *, x2=None, cin=None, in_off=0, cin2=None, in2_off=0, stride=1
         count_flops("conv k%d" % pc.ksize, 2.0 * opix * pc.ksize ** 2 * pc.cin * pc.cout)
     if (CONV1X1_WEIGHT_STATIONARY and getattr(pc, "w16", None) is not None and x2 is None and stride == 1 and not upsample
             and out_mode == OUT_NHWC_BF16 and cin == pc.cin and pitch % 8 == 0 and in_off % 8 == 0
-            and (out is None or (out.dtype == torch.bfloat16 and out.shape[3] % 8 == 0 and out_off % 8 == 0))
+            and (out is None or (out.dtype == act_dtype() and out.shape[3] % 8 == 0 and out_off % 8 == 0))
             and (residual is None or (residual.shape[3] % 8 == 0 and res_off % 8 == 0)) and (not gn_stats or out is None)):
         if residual is not None:
-            assert residual.dtype == torch.bfloat16 and residual.is_contiguous()
+            assert residual.dtype == act_dtype() and residual.is_contiguous()
         return _conv1x1_ws(x, pc, cin, in_off, act, residual, res_off, out, out_off, gn_stats)
     d = ConvDesc()
     d.in_, d.in2 = x.data_ptr(), (x2.data_ptr() if x2 is not None else None)
     d.B, d.H, d.W = B, H, W
     d.Cin, d.in_pitch, d.in_off = cin, pitch, in_off
     if x2 is not None:
-        assert x2.dtype == torch.bfloat16 and x2.is_contiguous() and x2.shape[:3] == x.shape[:3]
+        assert x2.dtype == act_dtype() and x2.is_contiguous() and x2.shape[:3] == x.shape[:3]
         d.Cin2 = x2.shape[3] - in2_off if cin2 is None else cin2
         d.in2_pitch, d.in2_off = x2.shape[3], in2_off
     assert pc.cin == d.Cin + d.Cin2, (pc.cin, d.Cin, d.Cin2)
@@ -348,12 +349,12 @@ def conv2d(x, pc, *, x2=None, cin=None, in_off=0, cin2=None, in2_off=0, stride=1
     OH, OW = ((IH + 1 - 3) // 2 + 1, (IW + 1 - 3) // 2 + 1) if stride == 2 else (IH, IW)
     if out is None:
         if out_mode == OUT_NHWC_BF16:
-            out = torch.empty(B, OH, OW, pc.cout, dtype=torch.bfloat16, device=x.device)
+            out = torch.empty(B, OH, OW, pc.cout, dtype=act_dtype(), device=x.device)
         elif out_mode == OUT_NHWC_F32:
             out = torch.empty(B, OH, OW, pc.cout, dtype=torch.float32, device=x.device)
         else:
             pp = plane_pitch or OH * OW
-            dt = torch.float32 if out_mode == OUT_PLANAR_F32 else torch.bfloat16
+            dt = torch.float32 if out_mode == OUT_PLANAR_F32 else act_dtype()
             out = torch.zeros(B, pc.cout, pp, dtype=dt, device=x.device)
     assert out.is_contiguous()
     if out_mode in (OUT_NHWC_BF16, OUT_NHWC_F32):
@@ -373,7 +374,7 @@ def conv2d(x, pc, *, x2=None, cin=None, in_off=0, cin2=None, in2_off=0, stride=1
     d.cout_tile = getattr(pc, "cout_tile", 0)
     d.bias = pc.bias.data_ptr() if pc.bias is not None else None
     if residual is not None:
-        assert residual.dtype == torch.bfloat16 and residual.is_contiguous()
+        assert residual.dtype == act_dtype() and residual.is_contiguous()
         d.residual, d.res_pitch, d.res_off = residual.data_ptr(), residual.shape[3], res_off
     subpixel = getattr(pc, "subpixel", False)
     assert not subpixel or upsample, "a sub-pixel packed filter only implements the upsample conv"
@@ -421,7 +422,7 @@ def conv2d_smallcin(x, strides, shape_bhw, weight, bias=None, act="none", out=No
     cout, cin, k, _ = w.shape
     b = None if bias is None else bias.detach().float().contiguous()
     if out is None:
-        out = torch.empty(B, H, W, cout, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+        out = torch.empty(B, H, W, cout, dtype=torch.float32 if out_f32 else act_dtype(), device=x.device)
     sb, sc, sy, sx = strides
     check(_lib.lib().glare_conv2d_smallcin_f32(ptr(x), _ll(sb), _ll(sc), _ll(sy), _ll(sx), ptr(w), ptr(b), ptr(out),
                                                _i(B), _i(H), _i(W), _i(cin), _i(cout), _i(k), _i(out.shape[3]),
@@ -434,13 +435,13 @@ def groupnorm(x, gamma, beta, swish=True, eps=1e-6, cin=None, in_off=0):
     """x: bf16 NHWC [B,H,W,pitch]; returns dense bf16 NHWC [B,H,W,C].  If the producing conv left its fused
     statistics on the tensor (conv2d(..., gn_stats=True)), only the apply pass runs."""
     require_cuda(x, gamma, beta)
-    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    assert x.dtype == act_dtype() and x.is_contiguous()
     B, H, W, pitch = x.shape
     C = pitch - in_off if cin is None else cin
     lib = _lib.lib()
     stats = getattr(x, "_gn_stats", None)
     if stats is not None and in_off == 0 and C == pitch:
-        y = torch.empty(B, H, W, C, dtype=torch.bfloat16, device=x.device)
+        y = torch.empty(B, H, W, C, dtype=act_dtype(), device=x.device)
         check(lib.glare_groupnorm_apply_bf16(ptr(x), _i(pitch), _i(0), ptr(gamma), ptr(beta), ptr(y), _i(B), _ll(H * W), _i(C),
                                              _f(eps), _i(int(swish)), ptr(stats), _i(int(stats.shape[1])), stream_handle()),
               "glare_groupnorm_apply_bf16")
@@ -448,7 +449,7 @@ def groupnorm(x, gamma, beta, swish=True, eps=1e-6, cin=None, in_off=0):
     lib.glare_groupnorm_workspace_bytes.restype = _sz
     nws = lib.glare_groupnorm_workspace_bytes(_i(B), _ll(H * W))
     ws = _workspace(nws, x.device)
-    y = torch.empty(B, H, W, C, dtype=torch.bfloat16, device=x.device)
+    y = torch.empty(B, H, W, C, dtype=act_dtype(), device=x.device)
     check(lib.glare_groupnorm_swish_bf16(ptr(x), _i(pitch), _i(in_off), ptr(gamma), ptr(beta), ptr(y), _i(B), _ll(H * W),
                                          _i(C), _f(eps), _i(int(swish)), ptr(ws), _sz(ws.numel()), stream_handle()),
           "glare_groupnorm_swish_bf16")
@@ -457,11 +458,11 @@ def groupnorm(x, gamma, beta, swish=True, eps=1e-6, cin=None, in_off=0):
 
 def mix(a, b, w, out=None, out_off=0, a_off=0, b_off=0, C=None):
     require_cuda(a, b, out)
-    assert a.dtype == b.dtype == torch.bfloat16
+    assert a.dtype == b.dtype == act_dtype()
     C = a.shape[-1] - a_off if C is None else C
     npix = a.numel() // a.shape[-1]
     if out is None:
-        out = torch.empty(a.shape[:-1] + (C,), dtype=torch.bfloat16, device=a.device)
+        out = torch.empty(a.shape[:-1] + (C,), dtype=act_dtype(), device=a.device)
     if torch.is_tensor(w):   # device scalar: read by the kernel, no .item() synchronisation
         require_cuda(w)
         w32 = w.detach().float().reshape(1)
@@ -478,7 +479,7 @@ def mix(a, b, w, out=None, out_off=0, a_off=0, b_off=0, C=None):
 def mean_rescale(h, xw, whole_batch=False):
     """h bf16 [B,...], xw fp32 same shape -> h + xw * (mean(h)/mean(xw)) (bf16)."""
     require_cuda(h, xw)
-    assert h.dtype == torch.bfloat16 and xw.dtype == torch.float32 and h.shape == xw.shape
+    assert h.dtype == act_dtype() and xw.dtype == torch.float32 and h.shape == xw.shape
     B = h.shape[0]
     n = h.numel() // B
     lib = _lib.lib()
@@ -495,20 +496,20 @@ def nchw_to_nhwc(x, bf16=True, out=None, out_off=0):
     x = x.float().contiguous()
     B, C, H, W = x.shape
     if out is None:
-        out = torch.empty(B, H, W, C, dtype=torch.bfloat16 if bf16 else torch.float32, device=x.device)
+        out = torch.empty(B, H, W, C, dtype=act_dtype() if bf16 else torch.float32, device=x.device)
     check(_lib.lib().glare_nchw_to_nhwc(ptr(x), ptr(out), _i(B), _i(C), _ll(H * W), _i(out.shape[3]), _i(out_off),
-                                        _i(int(out.dtype == torch.bfloat16)), stream_handle()), "glare_nchw_to_nhwc")
+                                        _i(int(out.dtype != torch.float32)), stream_handle()), "glare_nchw_to_nhwc")
     return out
 
 
 def nhwc_to_nchw(x, C=None, off=0):
     require_cuda(x)
-    assert x.is_contiguous()
+    assert x.is_contiguous() and x.dtype in (torch.float32, act_dtype()), (x.dtype, act_dtype())
     B, H, W, pitch = x.shape
     C = pitch - off if C is None else C
     out = torch.empty(B, C, H, W, dtype=torch.float32, device=x.device)
     check(_lib.lib().glare_nhwc_to_nchw(ptr(x), ptr(out), _i(B), _i(C), _ll(H * W), _i(pitch), _i(off),
-                                        _i(int(x.dtype == torch.bfloat16)), stream_handle()), "glare_nhwc_to_nchw")
+                                        _i(int(x.dtype != torch.float32)), stream_handle()), "glare_nhwc_to_nchw")
     return out
 
 
@@ -518,7 +519,7 @@ def flow_h1(z, ftA, ftA_off, wz, out=None):
     require_cuda(z, ftA, wz, out)
     B, H, W, _ = z.shape
     if out is None:
-        out = torch.empty(B, H, W, 64, dtype=torch.bfloat16, device=z.device)
+        out = torch.empty(B, H, W, 64, dtype=act_dtype(), device=z.device)
     check(_lib.lib().glare_flow_h1_f32(ptr(z), ptr(ftA), _i(ftA.shape[3]), _i(ftA_off), ptr(wz), ptr(out), _i(B), _i(H),
                                        _i(W), stream_handle()), "glare_flow_h1_f32")
     return out
@@ -579,7 +580,7 @@ def _attention_d512(q, k, v_t, N, ldq, ldk, out, key_splits, lse=None):
     ldq = q.shape[-1] if ldq is None else ldq
     ldk = k.shape[-1] if ldk is None else ldk
     if out is None:
-        out = torch.empty(B, N, 512, dtype=torch.bfloat16, device=v_t.device)
+        out = torch.empty(B, N, 512, dtype=act_dtype(), device=v_t.device)
     if key_splits is None:
         key_splits = ATTENTION_KEY_SPLITS_OVERRIDE
     ks = attention_key_splits(B, N) if key_splits is None else key_splits
@@ -611,13 +612,13 @@ def attention_kv512(q, kv, N, ldq=None, ldkv=None, out=None, key_splits=None):
     """Attention with SHARED keys / values: out[b,i] = sum_j softmax_j(q_i . kv_j) kv_j.  q, kv: bf16 [B, N, ld] views
     (d = 512 used; the caller folds 512^-0.5 * log2(e) and the key projection into q -- see AttnBlock); returns bf16 [B, N, 512]."""
     require_cuda(q, kv, out)
-    assert q.dtype == kv.dtype == torch.bfloat16
+    assert q.dtype == kv.dtype == act_dtype()
     B = kv.shape[0]
     count_flops("attn fwd", 4.0 * B * N * N * 512)
     ldq = q.shape[-1] if ldq is None else ldq
     ldkv = kv.shape[-1] if ldkv is None else ldkv
     if out is None:
-        out = torch.empty(B, N, 512, dtype=torch.bfloat16, device=kv.device)
+        out = torch.empty(B, N, 512, dtype=act_dtype(), device=kv.device)
     if key_splits is None:
         key_splits = ATTENTION_KEY_SPLITS_OVERRIDE
     ks = attention_key_splits(B, N) if key_splits is None else key_splits
@@ -645,7 +646,7 @@ def add_bf16(a, b, out=None, gn_stats=False):
     """out = a + b on bf16 NHWC tensors of one shape (the residual add left of AttnBlock's folded output projection); with
     gn_stats the GroupNorm statistics of the sum ride along (consumed by groupnorm(), which then only runs its apply pass)."""
     require_cuda(a, b, out)
-    assert a.dtype == b.dtype == torch.bfloat16 and a.shape == b.shape and a.is_contiguous() and b.is_contiguous()
+    assert a.dtype == b.dtype == act_dtype() and a.shape == b.shape and a.is_contiguous() and b.is_contiguous()
     if out is None:
         out = torch.empty_like(a)
     lib = _lib.lib()
@@ -702,13 +703,14 @@ def mdcn_forward_nhwc(x, om, pd, x_off=0, C=None, mask_is_logit=True, padding=1,
     """x: NHWC bf16/fp32 [B,H,W,pitch]; om: planar fp32 [B, 3*dg*K, plane] (offsets then mask logits,
     the conv_offset output); returns NHWC fp32 [B,H,W,Co]."""
     require_cuda(x, om)
+    assert x.dtype in (torch.float32, act_dtype()), (x.dtype, act_dtype())
     B, H, W, pitch = x.shape
     C = pd.c if C is None else C
     K = pd.kh * pd.kw
     plane = om.shape[2]
     out = torch.empty(B, H, W, pd.co, dtype=torch.float32, device=x.device)
     mask = om[:, 2 * pd.dg * K:]
-    check(_lib.lib().glare_mdcn_forward_nhwc(ptr(x), _i(int(x.dtype == torch.bfloat16)), _i(pitch), _i(x_off), ptr(om),
+    check(_lib.lib().glare_mdcn_forward_nhwc(ptr(x), _i(int(x.dtype != torch.float32)), _i(pitch), _i(x_off), ptr(om),
                                              _ll(plane), _ll(om.shape[1] * plane), ctypes.c_void_p(mask.data_ptr()),
                                              _ll(plane), _ll(om.shape[1] * plane), _i(int(mask_is_logit)),
                                              ptr(pd.packed), ptr(pd.bias), ptr(out), _i(0), _i(pd.co), _i(0), _ll(0), _i(B),

@@ -4,7 +4,10 @@ plumbing both stages share.
 Reference: LLFlowModel.optimize_parameters (code/models/LLFlow_model.py:181-250) with its optimizer setup (:90-122):
 torch.optim.Adam over two parameter groups -- the flow ("other", lr_G, weight_decay_G) and the conditional encoder
 (names containing '.RRDB.', lr_RRDB or lr_G, weight decay 1e-5); the `beta1` / `beta2` keys it passes are not Adam's
-`betas`, so torch's defaults (0.9, 0.999) apply.  GradScaler is a no-op without fp16 and is not reproduced.
+`betas`, so torch's defaults (0.9, 0.999) apply.  `scaler.scale(loss).backward(); scaler.step(opt); scaler.update()`
+(:236-241): bf16 activations keep fp32's range, so the loss is not scaled -- but GradScaler's other job is: a step whose
+gradients hold an inf / NaN is skipped, decided on the device (FlatAdam.step), and the scale / growth tracker are kept as the
+reference's scaler would keep them.
 
 MI355X design: parameters, gradients and both Adam moments of a group live in four flat fp32 buffers (module parameters
 and their .grad are views), so the optimizer is ONE kernel launch per group and the data-parallel gradient mean is ONE
@@ -21,8 +24,16 @@ from . import train_ops as T
 class FlatGroup:
     """Flat fp32 storage for a parameter group: w / grad / exp_avg / exp_avg_sq; parameters become views."""
 
-    def __init__(self, params, lr, weight_decay=0.0, device=None):
+    def __init__(self, params, lr, weight_decay=0.0, device=None, never_used=()):
+        """never_used: parameters the training graph never reaches (they never get a gradient: torch.optim.Adam keeps no
+        state for them and applies no weight decay).  Declared STATICALLY so that the set of parameters Adam updates is
+        the same on every rank and every step: a rank-local `p.grad is None` test is not -- stage 2's `train_gt_ratio`
+        branch leaves `RRDB.color_conv` without a gradient on the ranks that drew `mean = gt`, and those ranks would skip an
+        update the others apply to the all-reduced gradient.  (With nn.DataParallel the reference sums the replicas'
+        gradients on one device: a parameter moves whenever any replica used it -- the same rule.)"""
         self.params = [p for p in params if p.requires_grad]
+        skip = {id(p) for p in never_used}
+        self.has_grad = [id(p) not in skip for p in self.params]
         self.lr, self.weight_decay = float(lr), float(weight_decay)
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else torch.device(device or "cpu")
@@ -44,10 +55,10 @@ class FlatGroup:
             p.grad = None
 
     def active_ranges(self):
-        """[lo, hi) element ranges of the flat buffer whose parameters have EVER received a gradient.  torch.optim.Adam (the
-        reference's optimizer) skips a parameter whose .grad is None -- no moment update, no weight decay, no state entry:
-        the parameters the graph never uses (flowUpsamplerNet.f, deformable_decoder.{scale,bias,enc,conv_out}) must not
-        move under weight decay.  Merged, these are 1-3 ranges, i.e. 1-3 Adam launches per group."""
+        """[lo, hi) element ranges of the flat buffer that Adam updates: everything but the `never_used` parameters.
+        torch.optim.Adam (the reference's optimizer) skips a parameter whose .grad is None -- no moment update, no weight
+        decay, no state entry: the parameters the graph never uses (flowUpsamplerNet.f, deformable_decoder.{scale,bias,enc,
+        conv_out}) must not move under weight decay.  Merged, these are 1-3 ranges, i.e. 1-3 Adam launches per group."""
         out, off = [], 0
         for p, used in zip(self.params, self.has_grad):
             k = p.numel()
@@ -60,11 +71,9 @@ class FlatGroup:
         return [(a, b) for a, b in out]
 
     def collect(self, chunk=64):
-        if not hasattr(self, "has_grad"):
-            self.has_grad = [False] * len(self.params)
         for i, p in enumerate(self.params):
-            if p.grad is not None:
-                self.has_grad[i] = True
+            if p.grad is not None and not self.has_grad[i]:
+                raise RuntimeError("a parameter declared never_used received a gradient (index %d, shape %s)" % (i, tuple(p.shape)))
         off = 0
         for i in range(0, len(self.params), chunk):
             ps = self.params[i:i + chunk]
@@ -95,8 +104,14 @@ class FlatAdam:
     def __init__(self, groups, betas=(0.9, 0.999), eps=1e-8, device_state=False):
         self.groups, self.betas, self.eps, self._t = groups, betas, eps, 0
         self.device_state = device_state
+        dev = next(g.w.device for g in groups if g.w.numel())
+        # GradScaler's state (torch.cuda.amp.GradScaler defaults, LLFlow_model.py:120): found_inf of the step in progress, the
+        # scale and the growth tracker -- all on the device, so a skipped step costs no host synchronisation
+        self.found_inf = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.scale = torch.full((1,), 65536.0, dtype=torch.float32, device=dev)
+        self.growth_tracker = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.growth_factor, self.backoff_factor, self.growth_interval = 2.0, 0.5, 2000
         if device_state:
-            dev = next(g.w.device for g in groups if g.w.numel())
             self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
             self.state3 = torch.tensor([1.0, 1.0, 1.0], dtype=torch.float32, device=dev)   # bc1, sqrt(bc2), lr multiplier
 
@@ -119,21 +134,62 @@ class FlatAdam:
             g.zero_grad()
 
     def step(self):
-        if self.device_state:
-            T.adam_prepare_(self.step_dev, self.state3, self.betas)
-        else:
-            self._t += 1
+        """scaler.step(optimizer); scaler.update() (LLFlow_model.py:240-241): gather + all-reduce the gradients, then ONE Adam
+        step over every group -- unless an inf / NaN sits anywhere in them (checked AFTER the all-reduce, so every rank
+        decides alike): then nothing moves, the step count stays and the scale backs off.  Returns nothing; `last_step_skipped()`
+        reads the flag (a host synchronisation) for callers that want to log it."""
+        self.found_inf.zero_()
+        worlds = []
         for g in self.groups:
             if g.w.numel() == 0:
+                worlds.append(1)
                 continue
             g.collect()
-            world = g.all_reduce()
-            for lo, hi in g.active_ranges():       # parameters that never had a gradient are skipped, as torch.optim.Adam does
+            worlds.append(g.all_reduce())
+            T.grad_nonfinite_(g.g, self.found_inf)
+        skipped_on_host = False
+        if self.device_state:
+            T.adam_prepare_guarded_(self.step_dev, self.state3, self.betas, self.found_inf)
+        else:
+            skipped_on_host = bool(int(self.found_inf.item()))     # host-state mode: the step count lives here
+            if not skipped_on_host:
+                self._t += 1
+        for g, world in zip(self.groups, worlds):
+            if g.w.numel() == 0 or skipped_on_host:
+                continue
+            for lo, hi in g.active_ranges():       # never-used parameters are skipped, as torch.optim.Adam does
                 w, gr, m, v = g.w[lo:hi], g.g[lo:hi], g.m[lo:hi], g.v[lo:hi]
                 if self.device_state:
-                    T.adam_step_dev_(w, gr, m, v, self.state3, g.lr, self.betas, self.eps, g.weight_decay, grad_scale=1.0 / world)
+                    T.adam_step_dev_guarded_(w, gr, m, v, self.state3, g.lr, self.betas, self.eps, g.weight_decay, 1.0 / world,
+                                             self.found_inf)
                 else:
                     T.adam_step_(w, gr, m, v, self._t, g.lr, self.betas, self.eps, g.weight_decay, grad_scale=1.0 / world)
+        T.gradscaler_update_(self.scale, self.growth_tracker, self.found_inf, self.growth_factor, self.backoff_factor,
+                             self.growth_interval)
+
+    def last_step_skipped(self):
+        return bool(int(self.found_inf.item()))
+
+    def scaler_state_dict(self):
+        """What torch.cuda.amp.GradScaler.state_dict() holds (checkpoint.save_training_state)."""
+        return {"scale": float(self.scale.item()), "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
+                "growth_interval": self.growth_interval, "_growth_tracker": int(self.growth_tracker.item())}
+
+    def load_scaler_state_dict(self, sd):
+        if not sd:
+            return
+        self.scale.fill_(float(sd.get("scale", 65536.0)))
+        self.growth_tracker.fill_(int(sd.get("_growth_tracker", 0)))
+        self.growth_factor = float(sd.get("growth_factor", 2.0))
+        self.backoff_factor = float(sd.get("backoff_factor", 0.5))
+        self.growth_interval = int(sd.get("growth_interval", 2000))
+
+
+# Parameters the reference constructs but its graphs never call (they never receive a gradient, so torch.optim.Adam never
+# touches them): the 320 -> 384 conv of FlowUpsamplerNet (FlowUpsamplerNet.py:113-116) and, in MultiScaleDecoder2, the
+# fuse / scale / shift layers of the unused gating path and its own conv_out (deformableDecoder_arch.py:490-523).
+STAGE2_NEVER_USED = ("flowUpsamplerNet.f.",)
+STAGE3_NEVER_USED = ("deformable_decoder.scale.", "deformable_decoder.bias.", "deformable_decoder.enc.", "deformable_decoder.conv_out.")
 
 
 class Stage2Trainer:
@@ -152,7 +208,8 @@ class Stage2Trainer:
         # always the reference's two groups [other, RRDB] (LLFlow_model.py:110-118); the RRDB group is EMPTY while the
         # conditional encoder is frozen (train_RRDB: false / before train_RRDB_delay), exactly as in the reference's
         # optimizer -- so `.state` files are interchangeable (glare_amd/checkpoint.py)
-        self.opt = FlatAdam([FlatGroup(other, lr_G, weight_decay_G),
+        never = [p for n, p in netG.named_parameters() if n.startswith(STAGE2_NEVER_USED)]
+        self.opt = FlatAdam([FlatGroup(other, lr_G, weight_decay_G, never_used=never),
                              FlatGroup(rrdb if train_rrdb else [], lr_G if lr_RRDB is None else lr_RRDB, 1e-5,
                                        device=other[0].device)], device_state=device_state)
         self.pack_cache = ops.PackCache([p for p in netG.parameters() if p.requires_grad])   # packed filters live across steps
@@ -202,7 +259,8 @@ class Stage3Trainer:
         dd = [p for n, p in netG.named_parameters() if n.startswith("deformable_decoder.")]
         # the reference's optimizer always has the two groups [other, RRDB] (VQLLFLOWD_model.py:113-121); at stage 3 the
         # conditional encoder is frozen (fix_modules), so its group is empty -- kept for `.state` file compatibility
-        self.opt = FlatAdam([FlatGroup(dd, lr_G, weight_decay_G), FlatGroup([], lr_G, 1e-5, device=dd[0].device)],
+        never = [p for n, p in netG.named_parameters() if n.startswith(STAGE3_NEVER_USED)]
+        self.opt = FlatAdam([FlatGroup(dd, lr_G, weight_decay_G, never_used=never), FlatGroup([], lr_G, 1e-5, device=dd[0].device)],
                             device_state=device_state)
         self.pack_cache = ops.PackCache(dd)
 

@@ -517,6 +517,69 @@ def adam_step_dev_(w, grad, exp_avg, exp_avg_sq, state3, lr, betas=(0.9, 0.999),
     return w
 
 
+def grad_nonfinite_(grad, found):
+    """found (int32 [1], device) |= any(grad is inf / NaN): GradScaler's found_inf without a host read."""
+    require_cuda(grad, found)
+    assert grad.dtype == torch.float32 and grad.is_contiguous() and found.dtype == torch.int32
+    check(_lib.lib().glare_grad_nonfinite_f32(ptr(grad), _ll(grad.numel()), ptr(found), stream_handle()), "glare_grad_nonfinite_f32")
+
+
+def adam_prepare_guarded_(step_dev, state3, betas, skip):
+    require_cuda(step_dev, state3, skip)
+    check(_lib.lib().glare_adam_prepare_guarded(ptr(step_dev), ptr(state3), _f(betas[0]), _f(betas[1]), ptr(skip), stream_handle()),
+          "glare_adam_prepare_guarded")
+
+
+def adam_step_dev_guarded_(w, grad, exp_avg, exp_avg_sq, state3, lr, betas, eps, weight_decay, grad_scale, skip):
+    require_cuda(w, grad, exp_avg, exp_avg_sq, state3, skip)
+    check(_lib.lib().glare_adam_step_dev_guarded_f32(ptr(w), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), _ll(w.numel()), _f(lr),
+                                                     _f(betas[0]), _f(betas[1]), _f(eps), _f(weight_decay), ptr(state3), _f(grad_scale),
+                                                     ptr(skip), stream_handle()), "glare_adam_step_dev_guarded_f32")
+    return w
+
+
+def gradscaler_update_(scale, tracker, found, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+    require_cuda(scale, tracker, found)
+    assert scale.dtype == torch.float32 and tracker.dtype == torch.int32 and found.dtype == torch.int32
+    check(_lib.lib().glare_gradscaler_update(ptr(scale), ptr(tracker), ptr(found), _f(growth_factor), _f(backoff_factor),
+                                             _i(growth_interval), stream_handle()), "glare_gradscaler_update")
+
+
+def actnorm_init_(x, C, bias, logs, off=0, scale=1.0):
+    """ActNorm's data-dependent initialisation (FlowActNorms.py:32-46) from x fp32 [..., pitch] (channels [off, off + C)):
+    writes bias / logs (fp32, C elements, any shape) in place."""
+    require_cuda(x, bias, logs)
+    assert x.dtype == torch.float32 and x.is_contiguous() and bias.dtype == logs.dtype == torch.float32
+    assert bias.is_contiguous() and logs.is_contiguous() and bias.numel() == logs.numel() == C
+    pitch = x.shape[-1]
+    P = x.numel() // pitch
+    lib = _lib.lib()
+    lib.glare_actnorm_init_workspace_bytes.restype = ctypes.c_size_t
+    nws = lib.glare_actnorm_init_workspace_bytes(_ll(P))
+    ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
+    check(lib.glare_actnorm_init_f32(ptr(x), _i(pitch), _i(off), _i(C), _ll(P), _f(scale), ptr(bias), ptr(logs), ptr(ws),
+                                     ctypes.c_size_t(nws), stream_handle()), "glare_actnorm_init_f32")
+
+
+def flow_h1_raw(z, ftA, ftA_off, wz):
+    """The pre-activation of fAffine's first conv: ftA[:, off:off+64] + conv3x3(z[:, 0] -> 64), fp32 [B,H,W,64]."""
+    require_cuda(z, ftA, wz)
+    B, H, W, _ = z.shape
+    out = torch.empty(B, H, W, 64, dtype=torch.float32, device=z.device)
+    check(_lib.lib().glare_flow_h1_raw_f32(ptr(z), ptr(ftA), _i(ftA.shape[3]), _i(ftA_off), ptr(wz), ptr(out), _i(B), _i(H), _i(W),
+                                           stream_handle()), "glare_flow_h1_raw_f32")
+    return out
+
+
+def flow_affine3_(z, M, t):
+    """z = M z + t in place (fp32 [.., 3]); M (9 floats, row-major) and t (3 floats) are host sequences."""
+    require_cuda(z)
+    Ma = (ctypes.c_float * 9)(*[float(v) for v in M])
+    ta = (ctypes.c_float * 3)(*[float(v) for v in t])
+    check(_lib.lib().glare_flow_affine3_f32(ptr(z), _ll(z.numel() // 3), Ma, ta, stream_handle()), "glare_flow_affine3_f32")
+    return z
+
+
 def add_bf16(a, b, c=None):
     require_cuda(a, b, c)
     a, b = a.contiguous(), b.contiguous()

@@ -220,6 +220,22 @@ int glare_flow_tail_f32(float* z_nhwc3, const float* h4, const float* hF, int hF
                         long long n_pixels, const float* M_3x3_host, const float* t_3_host, float eps,
                         glare_stream_t stream);
 
+/* ---- ActNorm data-dependent initialisation (a12: the first training forward of a fresh flow) ----------------------------
+ * Replaces _ActNorm.initialize_parameters (FlowActNorms.py:32-46), reached from _ActNorm.forward (:82-83) for the 28 step
+ * ActNorms and, through flow.Conv2d.forward (flow.py:48-52), the 96 coupling-net ActNorms:
+ *   bias[c] = -mean_p x[p][c];  logs[c] = log(scale / (sqrt(mean_p (x[p][c] + bias[c])^2) + 1e-6))     over all B*H*W pixels.
+ * x: fp32 [n_pixels][pitch], channels [off, off + C), C <= 64.  Two-pass, fp64 partials, fixed reduction order (deterministic).
+ * glare_flow_h1_raw_f32: the PRE-activation of fAffine's first conv, fp32 [pixel][64] (glare_flow_h1_f32 without the relu / the
+ *   16-bit rounding) -- what that conv's ActNorm is initialised from.
+ * glare_flow_affine3_f32: z = M z + t in place, one coupling-free step (FlowStep.py:83-88). */
+size_t glare_actnorm_init_workspace_bytes(long long n_pixels);
+int glare_actnorm_init_f32(const float* x, int pitch, int off, int C, long long n_pixels, float scale, float* bias_out,
+                           float* logs_out, void* workspace, size_t workspace_bytes, glare_stream_t stream);
+int glare_flow_h1_raw_f32(const float* z_nhwc3, const float* ftA, int ftA_pitch, int ftA_off, const float* wz_64x9,
+                          float* raw_f32, int B, int H, int W, glare_stream_t stream);
+int glare_flow_affine3_f32(float* z_nhwc3, long long n_pixels, const float* M_3x3_host, const float* t_3_host,
+                           glare_stream_t stream);
+
 /* ---- 1x1 convolution, weight-stationary form (csrc/conv1x1.hip) ----------------------------------------------------------
  * The 1x1 nn.Conv2d's with Cin in {128, 256, 512} and Cout % 128 == 0 (Cout / 128 a divisor of 32): AttnBlock's query / output
  * projections (encoder_decoder.py:146-165) and ResnetBlock.nin_shortcut (:104-115).  Same arithmetic as glare_conv2d_bf16 with
@@ -462,6 +478,23 @@ int glare_attention_ds_bf16(const void* P, long long ldp, const float* dP, long 
  * 1-based step count, grad_scale multiplies the gradient first (1/world for the data-parallel mean). */
 int glare_adam_step_f32(float* w, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1,
                         float beta2, float eps, float weight_decay, int step, float grad_scale, glare_stream_t stream);
+/* GradScaler.step / .update (LLFlow_model.py:236-241, VQLLFLOWD_model.py:226-228): a step whose gradients hold an inf or a
+ * NaN is SKIPPED -- no moment update, no weight decay, no step count -- and the loss scale backs off.
+ * glare_grad_nonfinite_f32 ORs "some grad[i] is not finite" into *found_device (int32; the caller zeroes it before the first
+ *   buffer of a step; OR is order-independent, so the flag is deterministic).
+ * glare_adam_prepare_guarded / glare_adam_step_dev_guarded_f32 are the device-state Adam entry points below made no-ops when
+ *   *skip_if_nonzero_device != 0 (the whole step stays one capturable launch sequence: no host read of the flag).
+ * glare_gradscaler_update: GradScaler.update on device state -- found: scale *= backoff, tracker = 0; else tracker += 1 and,
+ *   at growth_interval, scale *= growth and tracker = 0.  (bf16 activations keep fp32's range: the scale is bookkeeping for
+ *   `.state` file parity, it multiplies nothing.) */
+int glare_grad_nonfinite_f32(const float* grad, long long n, int* found_device, glare_stream_t stream);
+int glare_adam_prepare_guarded(int* step_device, float* state3_device, float beta1, float beta2, const int* skip_if_nonzero_device,
+                               glare_stream_t stream);
+int glare_adam_step_dev_guarded_f32(float* w, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1,
+                                    float beta2, float eps, float weight_decay, const float* state3_device, float grad_scale,
+                                    const int* skip_if_nonzero_device, glare_stream_t stream);
+int glare_gradscaler_update(float* scale_device, int* growth_tracker_device, const int* found_device, float growth_factor,
+                            float backoff_factor, int growth_interval, glare_stream_t stream);
 /* The same step with ALL optimizer state on the device, so that a whole training step replays from a hipGraph:
  * glare_adam_prepare increments *step_device and writes state3 = {1 - beta1^t, sqrt(1 - beta2^t), (unchanged) lr multiplier};
  * glare_adam_step_dev_f32 reads the bias corrections and the lr multiplier from state3 (lr_effective = lr * state3[2]). */

@@ -43,3 +43,30 @@ def test_product_refuses_cpu_tensors():
     cb = torch.zeros(16, 3)
     with pytest.raises(NotImplementedError):
         ops.vq_nearest(z, cb)
+
+
+def test_half_library_exports_the_inference_entry_points():
+    """libglare_hip_f16.so (IEEE-half activations / filters): its exports are declared in the header -- a *_bf16 entry point under
+    the name *_f16, identical signature -- and it is a subset (the inference kernels), never a superset."""
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_F16_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r"\bT (glare_[a-z0-9_]+)", out))
+    declared = set(_lib.header_symbols())
+    as_f16 = {n.replace("bf16", "f16") for n in declared}
+    assert exported <= as_f16, sorted(exported - as_f16)
+    for must in ("glare_conv2d_f16", "glare_conv1x1_ws_f16", "glare_attention_kv512_f16", "glare_groupnorm_apply_f16",
+                 "glare_mdcn_forward_nhwc", "glare_flow_h1_f32", "glare_flow_tail_f32", "glare_conv2d_smallcin_f32", "glare_mix_f16"):
+        assert must in exported, must
+    assert not any("bf16" in n for n in exported)
+    data = open(_lib.LIB_F16_PATH, "rb").read()
+    assert b"gfx950" in data and b"gfx942" not in data
+    # the precision switch resolves names through it, and refuses what it does not have
+    from glare_amd import ops
+
+    with ops.use_precision("fp16"):
+        assert ops.act_dtype() == torch.float16
+        assert _lib.lib().glare_conv2d_bf16 is not None          # -> glare_conv2d_f16
+        with pytest.raises(_lib.GlareError):
+            _lib.lib().glare_wgrad_nhwc_bf16
+        assert _lib.lib().glare_vq_nearest_f32 is not None       # dtype-agnostic: the main library's
+    assert ops.act_dtype() == torch.bfloat16
+    assert ops.inference_precision() == "fp16" and ops.inference_precision("bf16") == "bf16"

@@ -25,6 +25,15 @@ pytestmark = pytest.mark.gpu
 from tolerances import TOL, within  # noqa: E402  (tests/tolerances.py: per-stage bounds, <= 2x measured)
 
 
+@pytest.fixture(autouse=True)
+def bf16_precision():
+    """This module is the bf16 suite: every tolerance below was measured with bf16 activations and filters.  The inference entry
+    points default to fp16 (ops.inference_precision); tests/test_gpu_precision.py is the fp16 suite and holds the end-to-end
+    table of both precisions in both weight regimes."""
+    with ops.use_precision("bf16"):
+        yield
+
+
 def rel(a, b):
     a, b = a.float().cpu(), b.float().cpu()
     return float((a - b).norm() / (b.norm() + 1e-12))

@@ -879,3 +879,115 @@ def test_adam_skips_parameters_without_gradient_and_graph_replay_invalidates():
     gs.step(gt_img, lr_img)                                            # ... which the next replay must drop
     assert "_hip_cache" not in netG.deformable_decoder.mid.block_1.__dict__
     assert "_hip_cache" in netG.RRDB.encoder.mid.block_1.__dict__       # the frozen nets keep theirs
+
+
+def test_actnorm_data_dependent_init_matches_reference_vectors(golden, capsys):
+    """Row a12: the first training forward of a FRESH flow (every ActNorm all-zero) initialises the 28 step ActNorms and the 96
+    coupling-net ActNorms from the batch (FlowActNorms.py:32-46,82-83; flow.py:48-52).  Fixture: what the REFERENCE's 124 bias /
+    logs tensors, z and nll are after that forward on a seeded batch (tests/golden/actnorm_ddi.npz)."""
+    from glare_amd import modules as M
+    from glare_amd.synthetic import reset_actnorms_, seeded_init_
+
+    g = golden("actnorm_ddi")
+    m = reset_actnorms_(seeded_init_(M.LLFlowVQGAN2(), 8)).train().to(_dev())
+    gt, lr = torch.from_numpy(g["gt"]).to(_dev()), torch.from_numpy(g["lr"]).to(_dev())
+    assert m.flowUpsamplerNet.needs_actnorm_init()
+    z, nll, _ = m(gt=gt, lr=lr, reverse=False)            # the reference-shaped, taped entry point (LLFlow_model.py:215)
+    assert nll.requires_grad and not m.flowUpsamplerNet.needs_actnorm_init()
+    sd = m.state_dict()
+    worst = {"bias3": 0.0, "logs3": 0.0, "bias64": 0.0, "logs64": 0.0}
+    for i, k in enumerate(g["names"]):
+        got, ref = sd[str(k)].reshape(-1).double().cpu(), torch.from_numpy(g["p%03d" % i]).double()
+        assert (got != 0).any(), k
+        kind = ("logs" if str(k).endswith("logs") else "bias") + str(ref.numel())
+        # bias = -mean: compare against the channel's scale (std = scale / e^logs), logs: absolute (a log of a std ratio)
+        err = float((got - ref).abs().max()) if kind.startswith("logs") else float((got - ref).norm() / ref.norm().clamp_min(1e-3))
+        worst[kind] = max(worst[kind], err)
+    with capsys.disabled():
+        print("\n[actnorm ddi] worst deviation from the reference's parameters:", {k: round(v, 5) for k, v in worst.items()},
+              "| nll", nll.detach().cpu().numpy(), "ref", g["nll"])
+    within(worst["logs3"], 4.2e-3)     # measured 2.08e-03 (bf16 conditional encoder + coupling nets against the fp32 reference)
+    within(worst["logs64"], 2.9e-2)    # measured 1.44e-02
+    within(worst["bias3"], 2.2e-2)     # measured 1.12e-02
+    within(worst["bias64"], 5.4e-2)    # measured 2.70e-02
+    within(_rel(z, torch.from_numpy(g["z"])), 4.9e-2)   # measured 2.44e-02
+    within(float((nll.detach().cpu() - torch.from_numpy(g["nll"])).abs().max()), 1.4e-2)   # measured 6.7e-03 of 13.5
+    # the statistics do what they are for: every ActNorm's output has zero mean / unit variance on this batch (checked on z's
+    # first step through the oracle-free identity: bias = -mean, logs = -log(std))
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    m(gt=gt * 2, lr=lr, reverse=False)                    # initialised: a second forward leaves the parameters alone
+    assert all(torch.equal(before[k], v) for k, v in m.state_dict().items())
+    fresh = reset_actnorms_(seeded_init_(M.LLFlowVQGAN2(), 8)).eval().to(_dev())
+    with torch.no_grad():
+        fresh(gt=gt, lr=lr, reverse=False)                # eval never initialises (:34-35)
+    assert all((a.bias == 0).all() for a in fresh.flowUpsamplerNet.actnorms())
+    loaded = seeded_init_(M.LLFlowVQGAN2(), 8).train().to(_dev())    # non-zero biases (a checkpoint): marked, not re-initialised
+    keep = {k: v.clone() for k, v in loaded.state_dict().items()}
+    loaded(gt=gt, lr=lr, reverse=False)
+    assert all(torch.equal(keep[k], v) for k, v in loaded.state_dict().items()) and not loaded.flowUpsamplerNet.needs_actnorm_init()
+
+
+def test_actnorm_init_kernel_matches_torch():
+    from glare_amd import train_ops as T
+
+    g = torch.Generator().manual_seed(4)
+    for C, pitch, off, P in ((3, 3, 0, 2 * 80 * 80), (64, 64, 0, 700), (6, 8, 2, 33)):
+        x = (torch.randn(P, pitch, generator=g) * torch.rand(pitch, generator=g) * 3 + torch.randn(pitch, generator=g)).to(_dev())
+        bias, logs = torch.zeros(1, C, 1, 1, device=_dev()), torch.zeros(1, C, 1, 1, device=_dev())
+        T.actnorm_init_(x, C, bias, logs, off=off)
+        xs = x[:, off:off + C].double().cpu()
+        rb = -xs.mean(0)
+        rl = torch.log(1.0 / (torch.sqrt(((xs + rb) ** 2).mean(0)) + 1e-6))
+        assert torch.allclose(bias.reshape(-1).double().cpu(), rb, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(logs.reshape(-1).double().cpu(), rl, rtol=1e-5, atol=1e-6)
+        b2, l2 = torch.zeros_like(bias), torch.zeros_like(logs)
+        T.actnorm_init_(x, C, b2, l2, off=off)
+        assert torch.equal(b2, bias) and torch.equal(l2, logs)       # deterministic
+
+
+@pytest.mark.parametrize("device_state", [False, True])
+def test_step_with_nonfinite_gradients_is_skipped(device_state):
+    """GradScaler.step / update (LLFlow_model.py:236-241): inf / NaN anywhere in the step's gradients => no parameter, moment or
+    step-count change, the scale backs off; the next finite step proceeds and the growth tracker counts it."""
+    from glare_amd.train import FlatAdam, FlatGroup
+
+    torch.manual_seed(0)
+    a = torch.nn.Parameter(torch.randn(1000, device=_dev()))
+    b = torch.nn.Parameter(torch.randn(37, 5, device=_dev()))
+    opt = FlatAdam([FlatGroup([a], 1e-2, 0.1), FlatGroup([b], 1e-2, 1e-5)], device_state=device_state)
+    ref = torch.optim.Adam([{"params": [torch.nn.Parameter(a.detach().clone())], "lr": 1e-2, "weight_decay": 0.1},
+                            {"params": [torch.nn.Parameter(b.detach().clone())], "lr": 1e-2, "weight_decay": 1e-5}])
+    rp = [g["params"][0] for g in ref.param_groups]
+
+    def grads(poison=None):
+        ga, gb = torch.randn_like(a), torch.randn_like(b)
+        if poison is not None:
+            gb[3, 2] = poison
+        return ga, gb
+
+    for it, poison in enumerate([None, float("nan"), float("inf"), None, None]):
+        ga, gb = grads(poison)
+        opt.zero_grad()
+        a.grad, b.grad = ga.clone(), gb.clone()
+        w0 = (a.detach().clone(), b.detach().clone(), opt.groups[0].m.clone(), opt.groups[1].v.clone(), opt.t)
+        opt.step()
+        if poison is None:
+            rp[0].grad, rp[1].grad = ga.clone(), gb.clone()
+            ref.step()
+            assert not opt.last_step_skipped()
+        else:
+            assert opt.last_step_skipped()
+            assert torch.equal(a.detach(), w0[0]) and torch.equal(b.detach(), w0[1])
+            assert torch.equal(opt.groups[0].m, w0[2]) and torch.equal(opt.groups[1].v, w0[3]) and opt.t == w0[4]
+        assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    assert opt.t == 3
+    within(_rel(a, rp[0]), 1e-5)
+    within(_rel(b, rp[1]), 1e-5)
+    sd = opt.scaler_state_dict()
+    assert sd["scale"] == 65536.0 * 0.25 and sd["_growth_tracker"] == 2, sd   # two back-offs, then two good steps
+    opt.growth_interval = 3
+    for _ in range(1):
+        ga, gb = grads()
+        a.grad, b.grad = ga, gb
+        opt.step()
+    assert opt.scaler_state_dict() == {**sd, "scale": sd["scale"] * 2, "_growth_tracker": 0, "growth_interval": 3}

@@ -96,3 +96,61 @@ def test_flat_gradient_all_reduce_two_ranks():
     assert w0 == w1 == 2
     assert float(l0.abs().sum()) > 0 and not torch.equal(l0, l1)
     assert torch.allclose(s0, l0 + l1) and torch.equal(s0, s1)
+
+
+def _branch_worker(rank, world, port, q):
+    """Two ranks draw DIFFERENT stage-2 branches (LLFlowVQGAN_arch.py:95): rank 1's graph does not reach the last layer's
+    bias (stands in for RRDB.color_conv under mean = gt).  The set of parameters Adam updates must not depend on that."""
+    from glare_amd.train import FlatGroup
+
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    parallel.init_from_env(backend="gloo")
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.Linear(4, 3))
+    unused = torch.nn.Parameter(torch.ones(7))                       # a parameter no graph ever reaches (flowUpsamplerNet.f)
+    grp = FlatGroup(list(net.parameters()) + [unused], lr=1e-3, never_used=[unused])
+    grp.zero_grad()
+    x = torch.full((2, 5), float(rank + 1))
+    h = net[0](x)
+    out = h @ net[1].weight.t() + (net[1].bias if rank == 0 else 0.0)   # rank 1: no gradient for net[1].bias
+    out.sum().backward()
+    assert (net[1].bias.grad is None) == (rank == 1)
+    grp.collect()
+    grp.all_reduce()
+    q.put((rank, grp.active_ranges(), grp.g.clone(), [p.grad is None for p in grp.params]))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_active_parameter_set_is_rank_invariant():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_branch_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, r0, g0, n0), (_, r1, g1, n1) = got
+    assert r0 == r1 == [(0, 5 * 4 + 4 + 4 * 3 + 3)], (r0, r1)        # both ranks update everything but the never-used tail
+    assert torch.equal(g0, g1)                                         # ... with the same all-reduced gradient
+    assert n0 == n1 == [False, False, False, False, True]              # .grad stays None only for the never-used parameter
+    assert float(g0[-10:-7].abs().sum()) > 0                           # the bias gradient of the rank that had one arrived
+
+
+def test_never_used_parameter_with_a_gradient_is_an_error():
+    import pytest
+
+    from glare_amd.train import FlatGroup
+
+    p = torch.nn.Parameter(torch.ones(3))
+    grp = FlatGroup([p], lr=1e-3, never_used=[p])
+    (p * 2).sum().backward()
+    with pytest.raises(RuntimeError):
+        grp.collect()

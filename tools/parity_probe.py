@@ -8,7 +8,7 @@
     a chosen PSNR) -- the form of "output PSNR within 0.05 dB of the reference" that can actually fail,
   * the budget: the same figures with the product's stages swapped in one at a time from the back.
 
-    python tools/parity_probe.py [h w] [seed]
+    python tools/parity_probe.py [h w] [seed] [precision: bf16|fp16] [regime: adversarial|representative]
 """
 import json
 import os
@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 
 from glare_amd import modules as M  # noqa: E402
 from glare_amd import ops  # noqa: E402
-from glare_amd.synthetic import seeded_init_, synthetic_lowlight  # noqa: E402
+from glare_amd.synthetic import representative_init_, seeded_init_, synthetic_lowlight, synthetic_pair  # noqa: E402
 from oracle import torch_ref as O  # noqa: E402
 
 
@@ -59,19 +59,26 @@ def main():
     h = int(sys.argv[1]) if len(sys.argv) > 2 else 400
     w = int(sys.argv[2]) if len(sys.argv) > 2 else 600
     seed = int(sys.argv[3]) if len(sys.argv) > 3 else 11
+    precision = sys.argv[4] if len(sys.argv) > 4 else "bf16"
+    regime = sys.argv[5] if len(sys.argv) > 5 else "adversarial"
     torch.manual_seed(0)
-    og = seeded_init_(O.VQLLFLOWDeformable(per_sample_mean=True).eval(), 0)
-    ov = seeded_init_(O.VQModel().eval(), 1)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    if regime == "representative":
+        og, ov = representative_init_(O.VQLLFLOWDeformable(per_sample_mean=True).eval(), O.VQModel().eval(), 0)
+    else:
+        og = seeded_init_(O.VQLLFLOWDeformable(per_sample_mean=True).eval(), 0)
+        ov = seeded_init_(O.VQModel().eval(), 1)
+    ops.use_precision(precision).__enter__()
     pg, pv = M.VQLLFLOWDeformable().eval(), M.VQModel().eval()
     pg.load_state_dict(og.state_dict(), strict=True)
     pv.load_state_dict(ov.state_dict(), strict=True)
     pg.cuda()
     pv.cuda()
-    lr = O.preprocess(synthetic_lowlight(1, h, w, seed=seed)[0])
-    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    lr = O.preprocess(synthetic_pair(1, h, w, seed=seed)[0][0] if regime == "representative" else synthetic_lowlight(1, h, w, seed=seed)[0])
     with torch.no_grad():
         ref = og.stages(ov, lr)
-    R = {"h": h, "w": w, "seed": seed}
+    R = {"h": h, "w": w, "seed": seed, "precision": precision, "regime": regime}
+    print("== %dx%d precision %s, %s regime" % (h, w, precision, regime), flush=True)
     with torch.no_grad():
         # ---- stage-isolated (oracle inputs) --------------------------------------------------
         enc = pg.RRDB.forward_nhwc(lr.cuda())
@@ -134,7 +141,7 @@ def main():
     print(json.dumps(R["stage_isolated"], indent=1))
     print({k: R[k] for k in ("latent_rel_e2e", "flipped_tokens", "fused_equals_staged") if k in R})
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "parity_probe_%dx%d.json" % (h, w)), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "parity_probe_%dx%d_%s_%s.json" % (h, w, precision, regime)), "w") as f:
         json.dump(R, f, indent=1)
 
 
