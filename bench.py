@@ -28,7 +28,8 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-PEAK_BF16_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 = dense fp16, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_TBS = 8.0
 H_IMG, W_IMG, PAD = 400, 600, 20
 
 
@@ -110,6 +111,86 @@ def attention_roofline(device, batch, live_events, reps=5):
             "isolated_ms_per_launch": round(isolated_ms, 3), "launch_shape": {"B": batch, "N": N, "d": C}}
 
 
+def family_rooflines(events, steps):
+    """`rooflines`: the other kernel families of the step, timed the same way (event pairs on the launch stream around every
+    launch inside the timed region, ops.LAUNCH_EVENTS): the 3x3 implicit-GEMM convs (MFMA-bound) and the two DCNv2 warps
+    (gather: HBM / L2; contraction: split-bf16 MFMA -- reported against both peaks)."""
+    out = []
+    conv = events.get("conv3x3") or []
+    if conv:
+        ms = sum(s.elapsed_time(e) for s, e, _, _ in conv)
+        fl = sum(f for _, _, f, _ in conv)
+        ach = fl / (ms * 1e-3) / 1e12
+        out.append({"kernel": "conv_igemm_kernel, 3x3 / sub-pixel family (2*B*Ho*Wo*Cin*Cout*9 FLOP per launch)", "bound": "mfma",
+                    "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                    "launches_timed": len(conv), "launches_per_step": len(conv) // max(steps, 1), "ms_per_step": round(ms / max(steps, 1), 3),
+                    "algorithmic_tflop_per_step": round(fl / max(steps, 1) / 1e12, 3), "traffic": None,
+                    "timing": "HIP event pairs around every launch inside the timed region"})
+    dcn = events.get("dcn") or []
+    shapes = {}
+    for s_, e_, f, nb in dcn:
+        shapes.setdefault((f, nb), []).append(s_.elapsed_time(e_))
+    for (f, nb), ts in sorted(shapes.items(), key=lambda kv: -kv[0][1]):
+        ms = sum(ts) / len(ts)
+        tbs = nb / (ms * 1e-3) / 1e12
+        out.append({"kernel": "dcn_fwd_fast_kernel (DCNv2 warp: bilinear gather + 9-tap contraction, %.0f MB algorithmic)" % (nb / 1e6),
+                    "bound": "hbm", "achieved": round(tbs * 1e3, 1), "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s", "frac": round(tbs / PEAK_HBM_TBS, 4),
+                    "mfma_equivalent_tflops": round(f / (ms * 1e-3) / 1e12, 1), "ms_per_launch": round(ms, 3), "launches_timed": len(ts),
+                    "traffic": None, "timing": "HIP event pairs around every launch inside the timed region"})
+    return out
+
+
+def train_block(device, rank, world, steps=8, warmup=3):
+    """`train`: one stage-2 and one stage-3 optimisation step at the reference's per-GPU crops (BASELINE configs[3] / [4]: 2 x
+    3x320x320 and 1 x 3x256x256 per GPU), measured after the inference region.  N = 1: the step replayed from a hipGraph when
+    that is the faster form (stage 2), else eager.  N > 1: eager, with the ONE RCCL all-reduce per parameter group over the
+    flat fp32 gradient buffer inside every step (106 MB / 176 MB)."""
+    import torch.distributed as dist
+
+    from glare_amd import modules as M
+    from glare_amd.synthetic import seeded_init_
+    from glare_amd.train import GraphedStep, Stage2Trainer, Stage3Trainer
+
+    res = {"steps": steps, "warmup": warmup, "world": world,
+           "exchange": "none (1 GPU)" if world == 1 else "RCCL all-reduce of the flat fp32 gradient buffer per parameter group, every step"}
+    g = torch.Generator().manual_seed(10 + rank)
+    net_hq = seeded_init_(M.VQModel().eval(), 1).to(device)
+    for name, B, S in (("stage2", 2, 320), ("stage3", 1, 256)):
+        graph = world == 1 and name == "stage2"
+        if name == "stage2":
+            tr = Stage2Trainer(seeded_init_(M.LLFlowVQGAN2().train(), 2).to(device), net_hq, device_state=graph)
+        else:
+            tr = Stage3Trainer(seeded_init_(M.VQLLFLOWDeformable().train(), 0).to(device), net_hq, device_state=graph)
+        gt = torch.rand(B, 3, S, S, generator=g).to(device)
+        lr = (torch.randn(B, 3, S, S, generator=g) * 0.5 - 1.0).to(device)
+        runner = GraphedStep(tr, gt, lr) if graph else tr
+        for _ in range(warmup):
+            loss = runner.step_tensor(gt, lr)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = runner.step_tensor(gt, lr)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        assert bool(torch.isfinite(loss).all())
+        res["%s_ms_per_step" % name] = round(dt / steps * 1e3, 2)
+        res["%s_samples_per_sec" % name] = round(B * world * steps / dt, 2)
+        res["%s_graph" % name] = graph
+        res["%s_crop" % name] = "%d x 3x%dx%d per GPU" % (B, S, S)
+        del tr, runner
+        torch.cuda.empty_cache()
+    res["graph"] = res["stage2_graph"]
+    return res
+
+
 def cpu_baseline():
     """The CPU oracle on one 400x600 image (fp32, all host cores).  Test infrastructure used as the
     reported baseline only -- never on the product path."""
@@ -149,6 +230,8 @@ def main():
                          "the precision the end-to-end tolerance is met in; libglare_hip_f16.so) or bf16 (libglare_hip.so, +2.7 %% "
                          "images/s, 8x the rounding per stored tensor).  The JSON line's `dtype` names what ran")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the `train` block (stage-2 / stage-3 ms per step, measured after "
+                                                            "the inference region)")
     ap.add_argument("--breakdown", action="store_true", help="per-stage timing on stderr")
     args = ap.parse_args()
 
@@ -190,13 +273,13 @@ def main():
         # the one exchange of the inference path (no data-path collective).  N = 1 has nothing to gather.
         from glare_amd import harness, parallel
 
-        gatherer = parallel.RankGather(torch.empty(args.batch, H_IMG, W_IMG, 3, device=device), rank, world)
+        gatherer = parallel.RankGather(torch.empty(args.batch, H_IMG, W_IMG, 3, dtype=torch.uint8, device=device), rank, world)
 
     def enhance():
         out = netG.reverse_flow_nhwc(net_vq, lr)["out"]
         if gatherer is not None:
             restored, _ = harness.postprocess_device(out, H_IMG, W_IMG)
-            gatherer.gather(restored)
+            gatherer.gather(harness.to_ubyte_device(restored))      # img_as_ubyte: 5.8 MB per rank and step instead of 23 MB
         return out
 
     def step(i=0):
@@ -218,6 +301,7 @@ def main():
 
         if rank == 0:
             ops.ATTENTION_LAUNCH_EVENTS = []     # roofline: the dominant kernel's launches are timed where they run
+            ops.LAUNCH_EVENTS = {"conv3x3": [], "dcn": []}     # ... and the next two families (`rooflines`)
         t0 = time.perf_counter()
         for i in range(args.steps):
             out = step(i)
@@ -227,6 +311,7 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         live_events, ops.ATTENTION_LAUNCH_EVENTS = ops.ATTENTION_LAUNCH_EVENTS or [], None
+        family_events, ops.LAUNCH_EVENTS = ops.LAUNCH_EVENTS or {}, None
     assert bool(torch.isfinite(out).all())
     if dist is not None:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -235,6 +320,11 @@ def main():
 
     if args.breakdown and rank == 0:
         stage_breakdown(netG, net_vq, lr)
+
+    train = None
+    if not args.no_train:
+        with ops.use_precision("bf16"):       # the training kernels' format (fp32 range for gradients)
+            train = train_block(device, rank, world)
 
     if rank == 0:
         total_images = args.batch * world * args.steps
@@ -246,10 +336,12 @@ def main():
                                    "(BASELINE configs[1])", "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "input": "3x400x600 (reflect-padded to 420x620)", "parallelism": "dp%d" % world,
                        "streams_per_gpu": args.streams,
-                       "exchange": "none (1 GPU)" if world == 1 else "per step: crop/clamp on device + RCCL gather of the "
-                                   "enhanced [B,400,600,3] fp32 batches to rank 0 (inside the timed region)",
+                       "exchange": "none (1 GPU)" if world == 1 else "per step: crop/clamp/uint8 on device + RCCL gather of the "
+                                   "enhanced [B,400,600,3] uint8 batches to rank 0 (inside the timed region)",
                        "weights": "random, name-seeded (no checkpoints offline)"},
             "roofline": attention_roofline(device, args.batch, live_events),
+            "rooflines": family_rooflines(family_events, args.steps),
+            "train": train,
         }
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             res["cpu_baseline"] = cpu_baseline()

@@ -32,35 +32,54 @@ struct GParams {
   int cchunk;           // input channels sampled per LDS pass (forward)
 };
 
-// dmcn_im2col_bilinear (deform_conv_cuda_kernel.cu:468-497)
-__device__ __forceinline__ float bilinear(const float* im, int H, int W, float h, float w) {
-  const int hl = (int)floorf(h), wl = (int)floorf(w), hh = hl + 1, wh = wl + 1;
-  const float lh = h - hl, lw = w - wl, uh = 1.f - lh, uw = 1.f - lw;
-  float v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
-  if (hl >= 0 && wl >= 0) v1 = im[hl * W + wl];
-  if (hl >= 0 && wh <= W - 1) v2 = im[hl * W + wh];
-  if (hh <= H - 1 && wl >= 0) v3 = im[hh * W + wl];
-  if (hh <= H - 1 && wh <= W - 1) v4 = im[hh * W + wh];
-  return uh * uw * v1 + uh * lw * v2 + lh * uw * v3 + lh * lw * v4;
+// A sampling point (h, w) of a plane H x W as the kernels of dcn.hip see it: the linear index of its top-left corner, the two
+// fractional parts and a validity predicate per corner (a corner outside the plane contributes zero: the per-corner zeroing
+// of the reference's sampler, deform_conv_cuda_kernel.cu:468-497).  The interpolated value is sum_c wgt_c v_c with the four
+// products of (1 - fy, fy) x (1 - fx, fx); its derivative along y (x) replaces the y (x) factor by (-1, +1) -- the reference
+// tabulates the same two sums corner by corner in dmcn_get_coordinate_weight (:528-568).
+struct Corners {
+  int base;            // y0 * W + x0 (may be negative: only dereferenced where ok[] holds)
+  float fy, fx;
+  bool ok[4];          // (y0,x0) (y0,x1) (y1,x0) (y1,x1)
+};
+
+__device__ __forceinline__ Corners corners_at(int H, int W, float h, float w) {
+  Corners c;
+  const float y0f = floorf(h), x0f = floorf(w);
+  const int y0 = (int)y0f, x0 = (int)x0f;
+  c.base = y0 * W + x0;
+  c.fy = h - y0f;
+  c.fx = w - x0f;
+  const bool top = y0 >= 0, bot = y0 + 1 < H, lef = x0 >= 0, rig = x0 + 1 < W;
+  c.ok[0] = top && lef; c.ok[1] = top && rig; c.ok[2] = bot && lef; c.ok[3] = bot && rig;
+  return c;
 }
 
-// dmcn_get_coordinate_weight (deform_conv_cuda_kernel.cu:528-568); dir 0 = d/dh, 1 = d/dw
+__device__ __forceinline__ void corner_values(const float* im, int W, const Corners& c, float (&v)[4]) {
+  v[0] = c.ok[0] ? im[c.base] : 0.f;
+  v[1] = c.ok[1] ? im[c.base + 1] : 0.f;
+  v[2] = c.ok[2] ? im[c.base + W] : 0.f;
+  v[3] = c.ok[3] ? im[c.base + W + 1] : 0.f;
+}
+
+__device__ __forceinline__ float bilinear(const float* im, int H, int W, float h, float w) {
+  const Corners c = corners_at(H, W, h, w);
+  float v[4];
+  corner_values(im, W, c, v);
+  const float ty = 1.f - c.fy, tx = 1.f - c.fx;
+  return ty * tx * v[0] + ty * c.fx * v[1] + c.fy * tx * v[2] + c.fy * c.fx * v[3];
+}
+
+// d(sample)/d(coordinate): dir 0 = along y, 1 = along x; zero outside the open interval the forward samples in
 __device__ __forceinline__ float coordinate_weight(const float* im, int H, int W, float ah, float aw, int dir) {
-  if (ah <= -1.f || ah >= (float)H || aw <= -1.f || aw >= (float)W) return 0.f;
-  const int hl = (int)floorf(ah), wl = (int)floorf(aw), hh = hl + 1, wh = wl + 1;
-  float wgt = 0.f;
-  if (dir == 0) {
-    if (hl >= 0 && wl >= 0) wgt += -1.f * (wl + 1 - aw) * im[hl * W + wl];
-    if (hl >= 0 && wh <= W - 1) wgt += -1.f * (aw - wl) * im[hl * W + wh];
-    if (hh <= H - 1 && wl >= 0) wgt += (wl + 1 - aw) * im[hh * W + wl];
-    if (hh <= H - 1 && wh <= W - 1) wgt += (aw - wl) * im[hh * W + wh];
-  } else {
-    if (hl >= 0 && wl >= 0) wgt += -1.f * (hl + 1 - ah) * im[hl * W + wl];
-    if (hl >= 0 && wh <= W - 1) wgt += (hl + 1 - ah) * im[hl * W + wh];
-    if (hh <= H - 1 && wl >= 0) wgt += -1.f * (ah - hl) * im[hh * W + wl];
-    if (hh <= H - 1 && wh <= W - 1) wgt += (ah - hl) * im[hh * W + wh];
-  }
-  return wgt;
+  if (!(ah > -1.f && ah < (float)H && aw > -1.f && aw < (float)W)) return 0.f;
+  const Corners c = corners_at(H, W, ah, aw);
+  float v[4];
+  corner_values(im, W, c, v);
+  const float tx = 1.f - c.fx, ty = 1.f - c.fy;
+  // accumulated in the corner order (y0,x0), (y0,x1), (y1,x0), (y1,x1)
+  if (dir == 0) return ((-tx * v[0] - c.fx * v[1]) + tx * v[2]) + c.fx * v[3];
+  return ((-ty * v[0] + ty * v[1]) - c.fy * v[2]) + c.fy * v[3];
 }
 
 constexpr int GP = 64;    // output pixels per workgroup

@@ -106,6 +106,18 @@ __global__ __launch_bounds__(256) void ubyte_planes_kernel(const float* __restri
 
 }  // namespace
 
+// restored float in [0,1] -> uint8 = rint(clip * 255): img_as_ubyte(restored), the image the reference's loop hands to imwrite
+__global__ __launch_bounds__(256) void to_ubyte_kernel(const float* __restrict__ restored, long long n, uint8_t* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = (uint8_t)rintf(fminf(fmaxf(restored[i], 0.f), 1.f) * 255.f);
+}
+
+extern "C" int glare_harness_to_ubyte(const float* restored_hwc, long long n, unsigned char* out_u8, glare_stream_t stream) {
+  if (!restored_hwc || !out_u8 || n <= 0) return GLARE_ERR_INVALID;
+  hipLaunchKernelGGL(to_ubyte_kernel, dim3((unsigned)cdivll(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), restored_hwc, n, out_u8);
+  return glare_launch_status();
+}
+
 extern "C" int glare_harness_ubyte_planes_f32(const float* restored_hwc, const unsigned char* gt_hwc, long long n, float* x255, float* y255,
                                               glare_stream_t stream) {
   if (!restored_hwc || !gt_hwc || !x255 || !y255 || n <= 0) return GLARE_ERR_INVALID;

@@ -51,6 +51,18 @@ def postprocess_device(out_nchw, h, w, gts_u8=None):
     return restored, psnr_t
 
 
+def to_ubyte_device(restored):
+    """restored float [..] in [0,1] (device) -> uint8 of the same shape: img_as_ubyte, the image the reference's loop saves."""
+    from . import _lib
+
+    _lib.require_cuda(restored)
+    restored = restored.float().contiguous()
+    out = torch.empty(restored.shape, dtype=torch.uint8, device=restored.device)
+    _lib.check(_lib.main_lib().glare_harness_to_ubyte(_lib.ptr(restored), ctypes.c_longlong(restored.numel()), _lib.ptr(out),
+                                                      _lib.stream_handle()), "glare_harness_to_ubyte")
+    return out
+
+
 def ssim_device(restored, gts_u8):
     """SSIM as the reference's evaluation loop computes it (calculate_ssim(img_as_ubyte(target), img_as_ubyte(restored)),
     utils2.py:42-89 / infer_dataset_lol.py:152): restored float [B,h,w,3] in [0,1] and the uint8 ground truth, both on the device

@@ -251,6 +251,29 @@ class DeformConv(nn.Module):  # deform_conv.py:191-245
         return deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups, self.deformable_groups)
 
 
+def _offset_conv(conv, x):
+    """`conv_offset(x)` of the two Pack modules on the HIP kernels: the MFMA conv for the configuration every user on the GLARE
+    path has (3x3 / 1x1, stride 1, 'same' padding, no dilation, Cin % 8 == 0); any other nn.Conv2d configuration as what a conv
+    IS in this file's terms -- a modulated deformable conv with zero offsets and a unit mask (the general-shape DCN kernel takes
+    every stride / padding / dilation the reference's extension takes).  NCHW fp32 in and out."""
+    from .... import ops
+
+    ops.require_cuda(x)
+    k, st, pd, dl = conv.kernel_size, conv.stride, conv.padding, conv.dilation
+    taped = torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad)   # the DCN form below carries the tape
+    if (not taped and k[0] == k[1] and k[0] in (1, 3) and st == (1, 1) and dl == (1, 1) and pd == (k[0] // 2, k[0] // 2) and conv.groups == 1
+            and conv.in_channels % 8 == 0):
+        y = ops.conv2d(ops.nchw_to_nhwc(x.float()), ops.PackedConv(conv.weight, conv.bias), out_mode=ops.OUT_NHWC_F32)
+        return ops.nhwc_to_nchw(y)
+    B, _, H, W = x.shape
+    Ho = (H + 2 * pd[0] - (dl[0] * (k[0] - 1) + 1)) // st[0] + 1
+    Wo = (W + 2 * pd[1] - (dl[1] * (k[1] - 1) + 1)) // st[1] + 1
+    K = k[0] * k[1]
+    zero = torch.zeros(B, 2 * K, Ho, Wo, dtype=torch.float32, device=x.device)
+    one = torch.ones(B, K, Ho, Wo, dtype=torch.float32, device=x.device)
+    return modulated_deform_conv(x.float(), zero, one, conv.weight, conv.bias, st, pd, dl, conv.groups, 1)
+
+
 class DeformConvPack(DeformConv):  # deform_conv.py:248-286
     _version = 2
 
@@ -263,7 +286,7 @@ class DeformConvPack(DeformConv):  # deform_conv.py:248-286
         self.conv_offset.bias.data.zero_()
 
     def forward(self, x):
-        return deform_conv(x, self.conv_offset(x), self.weight, self.stride, self.padding, self.dilation, self.groups,
+        return deform_conv(x, _offset_conv(self.conv_offset, x), self.weight, self.stride, self.padding, self.dilation, self.groups,
                            self.deformable_groups)
 
 
@@ -315,7 +338,7 @@ class ModulatedDeformConvPack(ModulatedDeformConv):
             self.conv_offset.bias.data.zero_()
 
     def forward(self, x):
-        out = self.conv_offset(x)
+        out = _offset_conv(self.conv_offset, x)
         o1, o2, mask = torch.chunk(out, 3, dim=1)
         offset = torch.cat((o1, o2), dim=1)
         return modulated_deform_conv(x, offset, torch.sigmoid(mask), self.weight, self.bias, self.stride, self.padding,

@@ -61,7 +61,10 @@ class PackedConv:
         self.ksize = kh
         self.subpixel = bool(upsample_subpixel)
         self.cout_tile = 0
-        self._src = (w, bias, dgrad_pad)     # (no copy for fp32 parameters) for_tile() packs other tiles from it on demand
+        # for_tile() re-packs a 3x3 filter with more than 64 output channels for a narrower tile on demand: only then is the fp32
+        # source kept (for filters built on the fly -- AttnBlock's folded 1x1s, 9.4 MB sub-pixel upsample filters, the per-step
+        # filters of training -- it would otherwise stay resident for the model's lifetime)
+        self._src = (w, bias, dgrad_pad) if (kh == 3 and not upsample_subpixel and (cout if dgrad_pad is None else cin) > 64) else None
         self._tiles = {}
         lib = _lib.lib()
         if cout_tile and not self.subpixel:
@@ -205,6 +208,28 @@ def conv_cout_tile(B, OH, OW, cout):
     """Output-channel tile (0 = the default) that gives a conv of this output size enough workgroups (glare_conv2d_cout_tile)."""
     t = _lib.lib().glare_conv2d_cout_tile(_i(B), _i(OH), _i(OW), _i(cout))
     return 0 if t >= (128 if cout > 64 else (64 if cout > 32 else 32)) else t
+
+
+# Measurement hook (bench.py `rooflines`): when a dict {family: list}, launches of that family are bracketed by a pair of events
+# recorded on the stream the kernel is launched on, and (start, end, algorithmic FLOPs, algorithmic bytes) is appended.
+# Families: "conv3x3" (the 3x3 / sub-pixel implicit-GEMM launches), "dcn" (DCNv2 forward).  None (default) records nothing.
+LAUNCH_EVENTS = None
+
+
+class _timed_launch:
+    def __init__(self, family, flops, nbytes):
+        self.rec = LAUNCH_EVENTS.get(family) if LAUNCH_EVENTS is not None else None
+        self.flops, self.nbytes = flops, nbytes
+
+    def __enter__(self):
+        if self.rec is not None:
+            self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.ev[0].record()
+
+    def __exit__(self, *exc):
+        if self.rec is not None:
+            self.ev[1].record()
+            self.rec.append((self.ev[0], self.ev[1], float(self.flops), float(self.nbytes)))
 
 
 # Measurement hook (tools/train_bench.py flops): when a dict, every MFMA launch family adds its algorithmic FLOPs (2 x MACs) to
@@ -391,7 +416,14 @@ def conv2d(x, pc, *, x2=None, cin=None, in_off=0, cin2=None, in2_off=0, stride=1
             n = lib.glare_conv2d_gn_partial_elems(_i(B), _i(OH), _i(OW), _i(pc.cout))
         gn_part = torch.empty(n, dtype=torch.float32, device=x.device)
         d.gn_partial = gn_part.data_ptr()
-    check(lib.glare_conv2d_bf16(ctypes.byref(d), stream_handle()), "glare_conv2d_bf16")
+    if LAUNCH_EVENTS is not None and pc.ksize == 3:
+        opix = B * OH * OW
+        esz = 2 if out_mode in (OUT_NHWC_BF16, OUT_PLANAR_BF16) else 4
+        with _timed_launch("conv3x3", 2.0 * opix * 9 * pc.cin * pc.cout,     # 2*B*Ho*Wo*Cin*Cout*k^2; bytes in + out + filter
+                           2.0 * B * H * W * pc.cin + esz * opix * pc.cout + 2.0 * 9 * pc.cin * pc.cout):
+            check(lib.glare_conv2d_bf16(ctypes.byref(d), stream_handle()), "glare_conv2d_bf16")
+    else:
+        check(lib.glare_conv2d_bf16(ctypes.byref(d), stream_handle()), "glare_conv2d_bf16")
     if gn_stats:
         stats = torch.empty(B, 1, 32, 2, dtype=torch.float32, device=x.device)
         if subpixel:
@@ -710,6 +742,13 @@ def mdcn_forward_nhwc(x, om, pd, x_off=0, C=None, mask_is_logit=True, padding=1,
     plane = om.shape[2]
     out = torch.empty(B, H, W, pd.co, dtype=torch.float32, device=x.device)
     mask = om[:, 2 * pd.dg * K:]
+    with _timed_launch("dcn", 2.0 * B * H * W * C * pd.co * K + 8.0 * K * B * H * W * C,      # contraction + sampling
+                       (2.0 if x.dtype != torch.float32 else 4.0) * B * H * W * C + 4.0 * B * H * W * (3 * pd.dg * K + pd.co) + 4.0 * pd.co * C * K):
+        _mdcn_forward_nhwc_launch(x, om, pd, out, mask, pitch, x_off, plane, mask_is_logit, B, C, H, W, padding, flags)
+    return out
+
+
+def _mdcn_forward_nhwc_launch(x, om, pd, out, mask, pitch, x_off, plane, mask_is_logit, B, C, H, W, padding, flags):
     check(_lib.lib().glare_mdcn_forward_nhwc(ptr(x), _i(int(x.dtype != torch.float32)), _i(pitch), _i(x_off), ptr(om),
                                              _ll(plane), _ll(om.shape[1] * plane), ctypes.c_void_p(mask.data_ptr()),
                                              _ll(plane), _ll(om.shape[1] * plane), _i(int(mask_is_logit)),

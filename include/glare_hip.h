@@ -564,6 +564,8 @@ int glare_harness_preprocess_u8(const unsigned char* img_hwc, int B, int H, int 
  * valid positions only, C1 = (0.01*255)^2, C2 = (0.03*255)^2), one call per image; its ssim mean over positions and channels is the metric. */
 int glare_harness_ubyte_planes_f32(const float* restored_hwc, const unsigned char* gt_hwc, long long n, float* x255, float* y255,
                                    glare_stream_t stream);
+/* img_as_ubyte(restored) (infer_dataset_lol.py:146-150, the image the loop saves): uint8 = rint(clip(x, 0, 1) * 255), n elements. */
+int glare_harness_to_ubyte(const float* restored_hwc, long long n, unsigned char* out_u8, glare_stream_t stream);
 size_t glare_harness_postprocess_workspace_bytes(int B);
 int glare_harness_postprocess_f32(const float* out_nchw, const unsigned char* gt_hwc_or_null, int B, int h, int w, int Hp,
                                   int Wp, int pad, float* restored_hwc, double* psnr_or_null, void* workspace,

@@ -269,3 +269,36 @@ def test_general_shapes_c_abi_needs_no_workspace_and_rejects_bad_channel_counts(
     _close(out.cpu().numpy(), ref)
     assert lib.glare_mdcn_forward_f32(*args(C, 1, 5)) != 0                  # C % deformable_group != 0 (deform_conv_cuda.cpp:511-516)
     assert lib.glare_mdcn_forward_f32(*args(C, 5, dg)) != 0                 # C % group != 0
+
+
+def test_pack_modules_run_conv_offset_on_the_hip_kernels(monkeypatch):
+    """ModulatedDeformConvPack / DeformConvPack .forward: `conv_offset` no longer goes through nn.Conv2d (MIOpen) -- the MFMA conv
+    for the 3x3 'same' configuration, the general DCN kernel with zero offsets / unit mask for any other (stride 2 here)."""
+    import torch.nn.functional as F
+
+    from glare_amd.modules.ops.dcn import ModulatedDeformConvPack
+    import importlib
+
+    dc = importlib.import_module("glare_amd.modules.ops.dcn.deform_conv")   # the module (the package re-exports a function of that name)
+
+    def boom(*a, **k):
+        raise AssertionError("conv_offset ran through nn.Conv2d")
+
+    monkeypatch.setattr(torch.nn.Conv2d, "forward", boom)
+    g = torch.Generator().manual_seed(2)
+    for stride in (1, 2):
+        m = ModulatedDeformConvPack(16, 24, 3, stride=stride, padding=1, deformable_groups=2).cuda()
+        with torch.no_grad():
+            m.conv_offset.weight.copy_(torch.randn(m.conv_offset.weight.shape, generator=g) * 0.05)
+            m.conv_offset.bias.copy_(torch.randn(m.conv_offset.bias.shape, generator=g) * 0.5)
+        x = torch.randn(2, 16, 12, 14, generator=g).cuda()
+        with torch.no_grad():
+            got_off = dc._offset_conv(m.conv_offset, x)
+            ref_off = F.conv2d(x, m.conv_offset.weight, m.conv_offset.bias, stride, 1)
+            tol = 2e-2 if stride == 1 else 1e-4          # stride 1: the bf16 MFMA conv; stride 2: the fp32 general kernel
+            assert float((got_off - ref_off).norm() / ref_off.norm()) < tol
+            y = m(x)
+        assert y.shape == (2, 24, 12 // stride, 14 // stride) and torch.isfinite(y).all()
+        y2 = m(x.requires_grad_(True))                     # with a tape: the DCN form, gradients reach conv_offset
+        y2.sum().backward()
+        assert m.conv_offset.weight.grad is not None and float(m.conv_offset.weight.grad.abs().sum()) > 0
