@@ -206,12 +206,15 @@ def cpu_baseline():
     lr = O.preprocess(synthetic_lowlight(1, H_IMG, W_IMG)[0])
     with torch.no_grad():
         og(ov, O.preprocess(synthetic_lowlight(1, 100, 152)[0]))    # warm-up at 1/16 of the pixels: thread pool, primitive caches
-        t0 = time.time()
-        og(ov, lr)
-    dt = time.time() - t0
-    return {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+        runs = []
+        for _ in range(2):                                           # two timed runs of the bounded sample (~20 s each): best + both
+            t0 = time.time()
+            og(ov, lr)
+            runs.append(time.time() - t0)
+    dt = min(runs)
+    return {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port", "runs_s": [round(r, 2) for r in runs],
             "sample": "1 image 400x600 (420x620 padded), fp32 torch CPU oracle on %d threads of %d host cores (more threads are slower "
-                      "on this graph), one timed run of %.1f s after a 100x152 warm-up run" % (cores, os.cpu_count() or 1, dt)}
+                      "on this graph), best of two timed runs (%.1f s, %.1f s) after a 100x152 warm-up run" % (cores, os.cpu_count() or 1, runs[0], runs[1])}
 
 
 def main():
@@ -323,8 +326,13 @@ def main():
 
     train = None
     if not args.no_train:
-        with ops.use_precision("bf16"):       # the training kernels' format (fp32 range for gradients)
-            train = train_block(device, rank, world)
+        # after the timed inference region; never allowed to take the headline line down with it (the all-reduce leg has only
+        # ever run under gloo on CPU before a driver's N > 1 run): a failure is reported inside the block
+        try:
+            with ops.use_precision("bf16"):       # the training kernels' format (fp32 range for gradients)
+                train = train_block(device, rank, world)
+        except Exception as e:  # noqa: BLE001
+            train = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
 
     if rank == 0:
         total_images = args.batch * world * args.steps

@@ -586,6 +586,10 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_kv_fwd_kernel(const AttnPa
   for (int i = 0; i < HD / 32; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  // Round 3, measured and NOT kept (alternated A/B on one box, tools/attn_ab.sh): (1) starting the score accumulator at -m_run
+  // (written among the previous tile's last P.V MFMAs) so that the softmax needs no subtraction -- bit-correct, but 16 registers
+  // carried across the loop in a register file that is exactly full (O 256 + Q 128) became 1036 B/lane of scratch: 21.4 ms
+  // instead of 3.8; (2) the 16-score maximum as 7 v_max3_f32 + 1 v_max_f32 instead of hipcc's 15 v_max_f32: 3.82 vs 3.82 ms.
   float m_run = -1e30f, l_run = 0.f;
 
   const int n_tiles = (p.N + BN - 1) / BN;

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(FL_THREADS) void flow_tail_kernel(float* __restrict
 // post: z[1:] = (z[1:] + shift) * scale                                      (:74-77)
 // Both add sum(log scale) of their pixels to a per-(sample, block) partial; the data-independent
 // parts of the log-determinant (actnorm logs, slogdet W) are added on the host in fp64.
-__global__ __launch_bounds__(FL_THREADS) void flow_fwd_pre_kernel(float* __restrict__ z, const float* __restrict__ hF, int f_pitch,
+__global__ __launch_bounds__(FL_THREADS) void flow_fwd_pre_kernel(const float* zin, float* z, const float* __restrict__ hF, int f_pitch,
                                                                   int f_off, long long pix_per_sample, int blocks_per_sample,
                                                                   TailParams tp, const float* __restrict__ mt_dev, float eps,
                                                                   float* __restrict__ ld_partial) {
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(FL_THREADS) void flow_fwd_pre_kernel(float* __restr
   float acc = 0.f;
   for (long long q = (long long)blk * FL_THREADS + threadIdx.x; q < pix_per_sample; q += (long long)blocks_per_sample * FL_THREADS) {
     const long long p = (long long)b * pix_per_sample + q;
-    const float a0 = z[p * 3], a1 = z[p * 3 + 1], a2 = z[p * 3 + 2];
+    const float a0 = zin[p * 3], a1 = zin[p * 3 + 1], a2 = zin[p * 3 + 2];   // zin == z: in place (no __restrict__ on the pair)
     float z0 = fmaf(tp.M[0], a0, fmaf(tp.M[1], a1, fmaf(tp.M[2], a2, tp.t[0])));
     float z1 = fmaf(tp.M[3], a0, fmaf(tp.M[4], a1, fmaf(tp.M[5], a2, tp.t[1])));
     float z2 = fmaf(tp.M[6], a0, fmaf(tp.M[7], a1, fmaf(tp.M[8], a2, tp.t[2])));
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(FL_THREADS) void flow_fwd_pre_kernel(float* __restr
   if (threadIdx.x == 0) ld_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ __launch_bounds__(FL_THREADS) void flow_fwd_post_kernel(float* __restrict__ z, const float* __restrict__ h4,
+__global__ __launch_bounds__(FL_THREADS) void flow_fwd_post_kernel(const float* zin, float* z, const float* __restrict__ h4,
                                                                    long long pix_per_sample, int blocks_per_sample, float eps,
                                                                    float* __restrict__ ld_partial) {
   __shared__ float red[FL_THREADS / 64];
@@ -194,8 +194,10 @@ __global__ __launch_bounds__(FL_THREADS) void flow_fwd_post_kernel(float* __rest
     const long long p = (long long)b * pix_per_sample + q;
     const f32x4 h = *reinterpret_cast<const f32x4*>(h4 + p * 4);
     const float s1 = sigmoid_acc(h[1] + 2.f) + eps, s2 = sigmoid_acc(h[3] + 2.f) + eps;
-    z[p * 3 + 1] = (z[p * 3 + 1] + h[0]) * s1;
-    z[p * 3 + 2] = (z[p * 3 + 2] + h[2]) * s2;
+    const float c0 = zin[p * 3], c1 = zin[p * 3 + 1], c2 = zin[p * 3 + 2];
+    if (zin != z) z[p * 3] = c0;                // out of place: the pass-through channel travels too
+    z[p * 3 + 1] = (c1 + h[0]) * s1;
+    z[p * 3 + 2] = (c2 + h[2]) * s2;
     acc += logf(s1) + logf(s2);
   }
   acc = wave_sum(acc);
@@ -321,30 +323,42 @@ extern "C" int glare_flow_fwd_pre_f32(float* z_nhwc3, const float* hF, int hF_pi
   for (int i = 0; i < 9; ++i) tp.M[i] = M_3x3_host[i];
   for (int i = 0; i < 3; ++i) tp.t[i] = t_3_host[i];
   const int bps = glare_flow_blocks_per_sample(pixels_per_sample);
-  hipLaunchKernelGGL(flow_fwd_pre_kernel, dim3(B * bps), dim3(FL_THREADS), 0, (hipStream_t)stream, z_nhwc3, hF, hF_pitch, hF_off,
-                     pixels_per_sample, bps, tp, (const float*)nullptr, eps, logdet_partial);
+  hipLaunchKernelGGL(flow_fwd_pre_kernel, dim3(B * bps), dim3(FL_THREADS), 0, (hipStream_t)stream, (const float*)z_nhwc3, z_nhwc3, hF,
+                     hF_pitch, hF_off, pixels_per_sample, bps, tp, (const float*)nullptr, eps, logdet_partial);
+  return glare_launch_status();
+}
+
+extern "C" int glare_flow_fwd_pre_dev_io_f32(const float* z_in, float* z_out, const float* hF, int hF_pitch, int hF_off, int B,
+                                             long long pixels_per_sample, const float* Mt_12_device, float eps, float* logdet_partial,
+                                             glare_stream_t stream) {
+  if (!z_in || !z_out || !hF || !Mt_12_device || !logdet_partial || B <= 0 || pixels_per_sample <= 0) return GLARE_ERR_INVALID;
+  if ((hF_pitch % 4) || (hF_off % 4) || hF_off + 6 > hF_pitch) return GLARE_ERR_UNSUPPORTED;
+  TailParams tp = {};
+  const int bps = glare_flow_blocks_per_sample(pixels_per_sample);
+  hipLaunchKernelGGL(flow_fwd_pre_kernel, dim3(B * bps), dim3(FL_THREADS), 0, (hipStream_t)stream, z_in, z_out, hF, hF_pitch, hF_off,
+                     pixels_per_sample, bps, tp, Mt_12_device, eps, logdet_partial);
   return glare_launch_status();
 }
 
 extern "C" int glare_flow_fwd_pre_dev_f32(float* z_nhwc3, const float* hF, int hF_pitch, int hF_off, int B,
                                           long long pixels_per_sample, const float* Mt_12_device, float eps, float* logdet_partial,
                                           glare_stream_t stream) {
-  if (!z_nhwc3 || !hF || !Mt_12_device || !logdet_partial || B <= 0 || pixels_per_sample <= 0) return GLARE_ERR_INVALID;
-  if ((hF_pitch % 4) || (hF_off % 4) || hF_off + 6 > hF_pitch) return GLARE_ERR_UNSUPPORTED;
-  TailParams tp = {};
+  return glare_flow_fwd_pre_dev_io_f32(z_nhwc3, z_nhwc3, hF, hF_pitch, hF_off, B, pixels_per_sample, Mt_12_device, eps, logdet_partial,
+                                       stream);
+}
+
+extern "C" int glare_flow_fwd_post_io_f32(const float* z_in, float* z_out, const float* h4, int B, long long pixels_per_sample, float eps,
+                                          float* logdet_partial, glare_stream_t stream) {
+  if (!z_in || !z_out || !h4 || !logdet_partial || B <= 0 || pixels_per_sample <= 0) return GLARE_ERR_INVALID;
   const int bps = glare_flow_blocks_per_sample(pixels_per_sample);
-  hipLaunchKernelGGL(flow_fwd_pre_kernel, dim3(B * bps), dim3(FL_THREADS), 0, (hipStream_t)stream, z_nhwc3, hF, hF_pitch, hF_off,
-                     pixels_per_sample, bps, tp, Mt_12_device, eps, logdet_partial);
+  hipLaunchKernelGGL(flow_fwd_post_kernel, dim3(B * bps), dim3(FL_THREADS), 0, (hipStream_t)stream, z_in, z_out, h4,
+                     pixels_per_sample, bps, eps, logdet_partial);
   return glare_launch_status();
 }
 
 extern "C" int glare_flow_fwd_post_f32(float* z_nhwc3, const float* h4, int B, long long pixels_per_sample, float eps,
                                        float* logdet_partial, glare_stream_t stream) {
-  if (!z_nhwc3 || !h4 || !logdet_partial || B <= 0 || pixels_per_sample <= 0) return GLARE_ERR_INVALID;
-  const int bps = glare_flow_blocks_per_sample(pixels_per_sample);
-  hipLaunchKernelGGL(flow_fwd_post_kernel, dim3(B * bps), dim3(FL_THREADS), 0, (hipStream_t)stream, z_nhwc3, h4,
-                     pixels_per_sample, bps, eps, logdet_partial);
-  return glare_launch_status();
+  return glare_flow_fwd_post_io_f32(z_nhwc3, z_nhwc3, h4, B, pixels_per_sample, eps, logdet_partial, stream);
 }
 
 extern "C" int glare_flow_nll_reduce_f32(const float* z_nhwc3, const float* mean_nhwc3, const float* logdet_partial,

@@ -405,22 +405,23 @@ class FlowNLLFn(torch.autograd.Function):
         for s in range(n):
             ops.conv2d(h1f, f2p[s], cin=64, in_off=64 * s, act="relu", out=h2f, out_off=64 * s)
             ops.conv2d(h2f, f4p[s], cin=64, in_off=64 * s, out=hF, out_off=8 * s, out_mode=ops.OUT_NHWC_F32)
-        z = gt.detach().clone().contiguous()
-        z_in = torch.empty(n, B, H, W, 3, dtype=torch.float32, device=dev)
-        z_pre = torch.empty_like(z_in)
+        # every step's input and mid-step latent are kept for the backward: the kernels write them in place of copies --
+        # z_in[k] -pre-> z_pre[k] -post-> z_in[k + 1]; slot n of z_in is the encoded latent
+        z_in = torch.empty(n + 1, B, H, W, 3, dtype=torch.float32, device=dev)
+        z_in[0].copy_(gt.detach())
+        z_pre = torch.empty(n, B, H, W, 3, dtype=torch.float32, device=dev)
         h1s = torch.empty(n, B, H, W, 64, dtype=torch.bfloat16, device=dev)
         h2s = torch.empty_like(h1s)
         h4s = torch.empty(n, B, H, W, 4, dtype=torch.float32, device=dev)
         bps = ops.flow_blocks_per_sample(H * W)
         partial = torch.zeros(2 * n, B * bps, dtype=torch.float32, device=dev)
         for k in range(n):
-            z_in[k].copy_(z)
-            ops.flow_fwd_pre(z, hF, 8 * k, None, None, eps, partial[2 * k], Mt_dev=Mt[k])
-            z_pre[k].copy_(z)
-            ops.flow_h1(z, ftA, 64 * k, wz[k], out=h1s[k])
+            ops.flow_fwd_pre(z_in[k], hF, 8 * k, None, None, eps, partial[2 * k], Mt_dev=Mt[k], out=z_pre[k])
+            ops.flow_h1(z_pre[k], ftA, 64 * k, wz[k], out=h1s[k])
             ops.conv2d(h1s[k], c2p[k], act="relu", out=h2s[k])
             ops.conv2d(h2s[k], c4p[k], out=h4s[k], out_mode=ops.OUT_NHWC_F32)
-            ops.flow_fwd_post(z, h4s[k], eps, partial[2 * k + 1])
+            ops.flow_fwd_post(z_pre[k], h4s[k], eps, partial[2 * k + 1], out=z_in[k + 1])
+        z = z_in[n]
         mean = mean.contiguous()
         red = ops.flow_nll_reduce(z, mean, partial, 2 * n)
         ctx.eps = eps
@@ -433,7 +434,7 @@ class FlowNLLFn(torch.autograd.Function):
     def backward(ctx, g_logdet, g_logp, _g_z=None):
         ft, mean, z, h1f, h2f, hF, z_in, z_pre, h1s, h2s, h4s, wz, ftA_w, f0_w, c2_w, c4_w, f2_w, f4_w, Mt = ctx.saved_tensors
         eps = ctx.eps
-        n, B, H, W, _ = z_in.shape
+        n, B, H, W, _ = z_pre.shape
         dev = z.device
         gld = g_logdet.float().contiguous()
         gz, gmean = T.flow_nll_backward(z, mean, g_logp.float().contiguous())

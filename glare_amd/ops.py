@@ -763,26 +763,33 @@ def flow_blocks_per_sample(pixels_per_sample):
     return int(_lib.lib().glare_flow_blocks_per_sample(_ll(pixels_per_sample)))
 
 
-def flow_fwd_pre(z, hF, hF_off, M, t, eps, partial_row, Mt_dev=None):
-    """M, t: host sequences -- or Mt_dev: fp32 device tensor [12] (3x3 row-major, then the offset), no host round trip."""
-    require_cuda(z, hF, partial_row, Mt_dev)
+def flow_fwd_pre(z, hF, hF_off, M, t, eps, partial_row, Mt_dev=None, out=None):
+    """M, t: host sequences -- or Mt_dev: fp32 device tensor [12] (3x3 row-major, then the offset), no host round trip.
+    out (with Mt_dev): write the result there instead of over z."""
+    require_cuda(z, hF, partial_row, Mt_dev, out)
     B = z.shape[0]
     if Mt_dev is not None:
         assert Mt_dev.dtype == torch.float32 and Mt_dev.numel() == 12 and Mt_dev.is_contiguous()
-        check(_lib.lib().glare_flow_fwd_pre_dev_f32(ptr(z), ptr(hF), _i(hF.shape[3]), _i(hF_off), _i(B), _ll(z.numel() // 3 // B),
-                                                    ptr(Mt_dev), _f(eps), ptr(partial_row), stream_handle()), "glare_flow_fwd_pre_dev_f32")
+        dst = z if out is None else out
+        assert dst.is_contiguous() and z.is_contiguous() and dst.shape == z.shape
+        check(_lib.lib().glare_flow_fwd_pre_dev_io_f32(ptr(z), ptr(dst), ptr(hF), _i(hF.shape[3]), _i(hF_off), _i(B),
+                                                       _ll(z.numel() // 3 // B), ptr(Mt_dev), _f(eps), ptr(partial_row), stream_handle()),
+              "glare_flow_fwd_pre_dev_io_f32")
         return
+    assert out is None
     Ma = (ctypes.c_float * 9)(*[float(v) for v in M])
     ta = (ctypes.c_float * 3)(*[float(v) for v in t])
     check(_lib.lib().glare_flow_fwd_pre_f32(ptr(z), ptr(hF), _i(hF.shape[3]), _i(hF_off), _i(B), _ll(z.numel() // 3 // B), Ma, ta,
                                             _f(eps), ptr(partial_row), stream_handle()), "glare_flow_fwd_pre_f32")
 
 
-def flow_fwd_post(z, h4, eps, partial_row):
-    require_cuda(z, h4, partial_row)
+def flow_fwd_post(z, h4, eps, partial_row, out=None):
+    require_cuda(z, h4, partial_row, out)
     B = z.shape[0]
-    check(_lib.lib().glare_flow_fwd_post_f32(ptr(z), ptr(h4), _i(B), _ll(z.numel() // 3 // B), _f(eps), ptr(partial_row),
-                                             stream_handle()), "glare_flow_fwd_post_f32")
+    dst = z if out is None else out
+    assert dst.is_contiguous() and z.is_contiguous() and dst.shape == z.shape
+    check(_lib.lib().glare_flow_fwd_post_io_f32(ptr(z), ptr(dst), ptr(h4), _i(B), _ll(z.numel() // 3 // B), _f(eps), ptr(partial_row),
+                                                stream_handle()), "glare_flow_fwd_post_io_f32")
 
 
 def flow_nll_reduce(z, mean, partial, n_rows):

@@ -386,6 +386,13 @@ int glare_flow_fwd_pre_dev_f32(float* z_nhwc3, const float* hF, int hF_pitch, in
                                const float* Mt_12_device, float eps, float* logdet_partial, glare_stream_t stream);
 int glare_flow_fwd_post_f32(float* z_nhwc3, const float* h4, int B, long long pixels_per_sample, float eps,
                             float* logdet_partial, glare_stream_t stream);
+/* out-of-place forms (z_in -> z_out; z_in == z_out is the in-place call): the training forward keeps every step's input and
+ * mid-step latent for the backward, so each kernel writes straight into the step-major buffer instead of being followed by a copy */
+int glare_flow_fwd_pre_dev_io_f32(const float* z_in, float* z_out, const float* hF, int hF_pitch, int hF_off, int B,
+                                  long long pixels_per_sample, const float* Mt_12_device, float eps, float* logdet_partial,
+                                  glare_stream_t stream);
+int glare_flow_fwd_post_io_f32(const float* z_in, float* z_out, const float* h4, int B, long long pixels_per_sample, float eps,
+                               float* logdet_partial, glare_stream_t stream);
 int glare_flow_nll_reduce_f32(const float* z_nhwc3, const float* mean_nhwc3, const float* logdet_partial,
                               int n_partial_rows, int B, long long pixels_per_sample, double* out_2_per_sample,
                               glare_stream_t stream);

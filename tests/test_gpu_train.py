@@ -991,3 +991,67 @@ def test_step_with_nonfinite_gradients_is_skipped(device_state):
         a.grad, b.grad = ga, gb
         opt.step()
     assert opt.scaler_state_dict() == {**sd, "scale": sd["scale"] * 2, "_growth_tracker": 0, "growth_interval": 3}
+
+
+def _two_rank_stage2_worker(rank, world, port, q):
+    import os
+
+    import torch.distributed as dist
+
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from glare_amd import modules as M
+    from glare_amd.synthetic import seeded_init_
+    from glare_amd.train import Stage2Trainer
+
+    dev = torch.device("cuda", 0)
+    netG = seeded_init_(M.LLFlowVQGAN2().train(), 2).to(dev)
+    net_hq = seeded_init_(M.VQModel().eval(), 1).to(dev)
+    tr = Stage2Trainer(netG, net_hq, lr_G=1e-4)
+    g = torch.Generator().manual_seed(100 + rank)                     # every rank trains on its own crops
+    gt = torch.rand(1, 3, 64, 64, generator=g).to(dev)
+    lr = (torch.randn(1, 3, 64, 64, generator=g) * 0.5 - 1.0).to(dev)
+    cc0 = netG.RRDB.color_conv.weight.detach().clone()
+    losses = []
+    for it in range(3):
+        # step 0: the ranks draw DIFFERENT branches of LLFlowVQGAN_arch.py:95 (rank 1: mean = gt, no gradient reaches color_conv);
+        # step 1: both draw mean = gt (no rank has one); step 2: both color_map
+        flag = (rank == 1) if it == 0 else (it == 1)
+        losses.append(float(tr.step(gt, lr, mean_is_gt=flag)))
+    sd = netG.state_dict()
+    digest = {k: float(v.double().sum()) for k, v in sd.items() if v.is_floating_point()}
+    q.put((rank, losses, digest, float((netG.RRDB.color_conv.weight.detach() - cc0).abs().sum()), tr.opt.t))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_stage2_steps_keep_the_replicas_identical():
+    """BASELINE configs[3] on real kernels with world_size 2 (both ranks on this one GPU, gloo carrying the exchange -- RCCL cannot
+    put two ranks on one device; the code path is FlatGroup.all_reduce either way): different crops AND different `train_gt_ratio`
+    branches per rank, three steps -- the replicas must hold bit-identical parameters afterwards (every rank applies the same
+    all-reduced gradient to the same static parameter set), and color_conv must have moved on both."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_stage2_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, l0, d0, moved0, t0), (_, l1, d1, moved1, t1) = got
+    assert t0 == t1 == 3
+    assert all(l == l for l in l0 + l1)                              # finite
+    assert l0 != l1                                                  # different data
+    diff = [k for k in d0 if d0[k] != d1[k]]
+    assert not diff, "replicas diverged in %d tensors, e.g. %s" % (len(diff), diff[:3])
+    assert moved0 > 0 and moved0 == moved1

@@ -24,6 +24,8 @@ with torch.no_grad():
         print("%-10s %s" % (name, ", ".join("%s x%d" % (k[6:], v) for k, v in c.most_common(14))))
         return r
 
+    from glare_amd import ops
+    ops.use_precision(ops.inference_precision()).__enter__()   # the stages below under the entry point's precision (cached filters)
     enc = run("encoder", lambda: netG.RRDB.forward_nhwc(lr))
     lat = run("flow", lambda: netG.flowUpsamplerNet.decode_nhwc(enc["color_map"], enc["cond_feat"]))
     idx, _, feats = run("vq+dec", lambda: net_vq.decode_nhwc(lat, want_image=False))
