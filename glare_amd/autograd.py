@@ -7,7 +7,7 @@ The reference gets these gradients from `loss.backward()` over cuDNN / ATen (LLF
 VQLLFLOWD_model.py:226-229); activations here are NHWC bf16, parameters and their gradients fp32.
 """
 import torch
-from . import ops
+from . import _lib, ops
 from . import train_ops as T
 
 
@@ -78,15 +78,21 @@ class Conv2dFn(torch.autograd.Function):
         g16 = _grad_bf16(gy, y, act, cout)
         dres = g16 if (has_res and ctx.needs_input_grad[3]) else None
         dw = db = dx = dx2 = None
-        if (ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2])) and k == 3 and stride == 1 and not upsample \
-                and not has_x2 and cin_tot % 8 == 0 and cout % 8 == 0 and IMPLICIT_WGRAD:
-            dw, db = T.conv3x3_weight_grad(x, g16, cout)      # no im2col matrix, no transposed copies
-            db = db if has_bias else None
-        elif (ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2])) and k == 1 and stride == 1 and not upsample \
-                and not has_x2 and cin_tot % 8 == 0 and cout % 8 == 0 and IMPLICIT_WGRAD:
-            dw, db = T.conv1x1_weight_grad(x, g16, cout)
-            db = db if has_bias else None
-        elif ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+        want_w = ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2])
+        implicit = (want_w and k in (1, 3) and stride == 1 and not upsample and not has_x2 and cin_tot % 8 == 0 and cout % 8 == 0
+                    and IMPLICIT_WGRAD)
+        if implicit:
+            # the NHWC weight-gradient kernel (no im2col matrix, no transposed copies).  Its fp32 partials grow with the number of
+            # (image, strip, row range) splits and one image must stay below 2 GB: beyond either limit it reports
+            # GLARE_ERR_UNSUPPORTED / needs a workspace past WGRAD_MAX_WORKSPACE, and the im2col + GEMM form below takes over
+            try:
+                dw, db = (T.conv3x3_weight_grad if k == 3 else T.conv1x1_weight_grad)(x, g16, cout)
+                db = db if has_bias else None
+            except _lib.GlareError:
+                implicit = False
+        if implicit:
+            pass
+        elif want_w:
             kk = k * k
             c1 = x.shape[-1]
 

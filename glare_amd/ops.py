@@ -143,6 +143,7 @@ class PackCache:
         self.ptrs = {p.data_ptr(): tuple(p.shape) for p in params if p.dim() == 4}
         self.entries = {}          # (data_ptr, dgrad_pad) -> PackedConv
         self.table = None          # (device job table, n_jobs, total_blocks)
+        self._retired = []         # superseded job tables, kept alive
 
     def __enter__(self):
         global PACK_CACHE
@@ -163,7 +164,9 @@ class PackCache:
             pc = PackedConv(weight, None, dgrad_pad=dgrad_pad, cout_tile=cout_tile)
             pc._param = weight.detach()
             self.entries[key] = pc
-            self.table = None
+            if self.table is not None:
+                self._retired.append(self.table)   # a captured hipGraph may still launch the multi-shape pack from the old job
+            self.table = None                      # table: it stays allocated (and correct for ITS entries) for the cache's lifetime
         pc.bias = None if bias is None else bias.detach().float().contiguous()
         return pc
 

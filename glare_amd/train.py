@@ -316,21 +316,35 @@ class GraphedStep:
 
     A stage-2 step has one host-side random decision (mean = ground truth with probability train_gt_ratio,
     LLFlowVQGAN_arch.py:95) that changes the captured kernel sequence: the decision is drawn on the host BEFORE the replay
-    and selects one of two graphs (the second is captured the first time its branch is drawn)."""
+    and selects one of two graphs, both captured up front (capture_all)."""
 
     def __init__(self, trainer, gt_img, lr_img, warmup=3):
         assert trainer.opt.device_state, "build the trainer with device_state=True"
         self.trainer = trainer
         self.branching = hasattr(trainer, "draw_branch")
         self.gt, self.lr = gt_img.clone(), lr_img.clone()
+        self.warmup = warmup
+        self.graphs = {}
+        self.capture_all()
+
+    def capture_all(self):
+        """Warm up and capture EVERY branch now (stage 2: mean = color_map and mean = gt), never lazily mid-training: a capture
+        bakes in host state of that moment -- the packed-filter job table of the PackCache (a branch that packs a filter the
+        other never touched must have done so BEFORE any graph holds the table), allocator pools, lazily built folds.  Call again
+        after `resume_training` / loading weights: the old graphs are dropped."""
+        self.graphs = {}
+        # the mean = gt branch exists only when it can be drawn (train_gt_ratio > 0: 0.2 in confs/train_stage2_LOL.yml, 0 in LOL.yml)
+        both = self.branching and float(getattr(self.trainer.netG, "train_gt_ratio", 0.0)) > 0.0
+        flags = (False, True) if both else (False,)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(warmup):                 # allocator / lazy-init warm-up outside the capture
-                self._eager(False)
+            for _ in range(self.warmup):            # allocator / lazy-init warm-up outside the capture, every branch
+                for f in flags:
+                    self._eager(f)
         torch.cuda.current_stream().wait_stream(side)
-        self.graphs = {}
-        self._capture(False)
+        for f in flags:
+            self._capture(f)
 
     def _eager(self, flag):
         return self.trainer.step_tensor(self.gt, self.lr, flag) if self.branching else self.trainer.step_tensor(self.gt, self.lr)
@@ -355,8 +369,8 @@ class GraphedStep:
             flag = self.trainer.draw_branch() if mean_is_gt is None else bool(mean_is_gt)
         self.gt.copy_(gt_img)
         self.lr.copy_(lr_img)
-        if flag not in self.graphs:
-            self._capture(flag)
+        if flag not in self.graphs:      # a forced branch the configuration itself cannot draw (tests): captured on first use --
+            self._capture(flag)          # safe, the PackCache keeps superseded job tables alive for the graphs that hold them
         g, loss = self.graphs[flag]
         g.replay()
         self._invalidate()

@@ -601,6 +601,9 @@ def colsum(g2d, C):
     return out
 
 
+WGRAD_MAX_WORKSPACE = 2 << 30   # bytes of fp32 partials the NHWC weight-gradient kernel may ask for before callers fall back
+
+
 def conv_weight_grad_nhwc(ksize, x, g16, cout, cin=None, in_off=0, groups=1, x_gstride=0, g_gstride=0, shape=None, out=None):
     """Weight + bias gradients of `groups` independent ksize x ksize (3 with pad 1, or 1) stride-1 convs straight from the NHWC
     operands (csrc/wgrad.hip).  x: bf16 NHWC [B,H,W,pitch] (cin channels at in_off, cin % 8 == 0); g16: bf16 NHWC
@@ -616,6 +619,8 @@ def conv_weight_grad_nhwc(ksize, x, g16, cout, cin=None, in_off=0, groups=1, x_g
     lib = _lib.lib()
     lib.glare_conv_wgrad_workspace_bytes.restype = ctypes.c_size_t
     nws = lib.glare_conv_wgrad_workspace_bytes(_i(ksize), _i(groups), _i(B), _i(H), _i(W), _i(cin), _i(cout))
+    if nws > WGRAD_MAX_WORKSPACE:     # the split count grows with the batch (one workgroup per image, strip and row range)
+        raise _lib.GlareError("glare_conv_wgrad_bf16: %.1f GB of fp32 partials (limit %.1f GB)" % (nws / 2 ** 30, WGRAD_MAX_WORKSPACE / 2 ** 30))
     ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=x.device)
     if out is None:
         out = torch.empty(groups, ksize * ksize * cin + 1, cout, dtype=torch.float32, device=x.device)

@@ -1055,3 +1055,26 @@ def test_two_rank_stage2_steps_keep_the_replicas_identical():
     diff = [k for k in d0 if d0[k] != d1[k]]
     assert not diff, "replicas diverged in %d tensors, e.g. %s" % (len(diff), diff[:3])
     assert moved0 > 0 and moved0 == moved1
+
+
+def test_implicit_weight_gradient_falls_back_when_its_workspace_would_be_too_large(monkeypatch):
+    """the NHWC weight-gradient kernel's fp32 partials grow with the batch; past the cap (or the 2 GB-per-image limit)
+    Conv2dFn.backward must degrade to the im2col + GEMM form instead of raising."""
+    from glare_amd import autograd as A
+    from glare_amd import train_ops as T
+
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 20, 24, 64, generator=g).to(torch.bfloat16).to(_dev()).requires_grad_(True)
+    w = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).to(_dev()).requires_grad_(True)
+    b = torch.zeros(64, device=_dev(), requires_grad=True)
+
+    def grads():
+        w.grad = b.grad = None
+        A.conv2d(x, w, b).float().square().sum().backward()
+        return w.grad.clone(), b.grad.clone()
+
+    ref_w, ref_b = grads()
+    monkeypatch.setattr(T, "WGRAD_MAX_WORKSPACE", 0)       # every split launch now exceeds the cap
+    fb_w, fb_b = grads()
+    within(_rel(fb_w, ref_w), 2e-3)
+    within(_rel(fb_b, ref_b), 2e-3)

@@ -6,7 +6,7 @@ tag=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 python bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench.err
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o b -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_bench_prof.log 2>&1
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o b -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train > gpurun_out/${tag}_bench_prof.log 2>&1
 python tools/rocpd_stats.py $(ls gpurun_out/prof_$tag/*/b_results.db gpurun_out/prof_$tag/b_results.db 2>/dev/null | head -1) > gpurun_out/${tag}_bench_kernel_stats.txt 2>&1
 {
   echo "# rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in SEPARATE runs, counters only), MI355X, B=8, $tag"
@@ -18,6 +18,11 @@ python tools/rocpd_stats.py $(ls gpurun_out/prof_$tag/*/b_results.db gpurun_out/
   for k in attn conv dcn; do echo "== $k"; bash tools/pmc_kernel.sh ${tag}_$k $k 2>&1 | grep -v "amdgpu.ids"; done
 } > gpurun_out/${tag}_pmc_kernels.txt
 python tools/kbench.py > gpurun_out/${tag}_kbench.txt 2>&1
+# end-to-end parity table: both precisions, both weight regimes, 400x600 (one ~30 s oracle run each) + two more seeds of the default
+for prec in bf16 fp16; do for reg in adversarial representative; do
+  python tools/parity_probe.py 400 600 11 $prec $reg 2>&1 | grep -v Warn | grep "==\|full path\|ORACLE\|latent_rel" 
+done; done > gpurun_out/${tag}_parity_table.txt 2>&1
+for seed in 12 13; do python tools/parity_probe.py 400 600 $seed fp16 representative 2>&1 | grep -v Warn | grep "==\|full path\|ORACLE\|latent_rel"; done >> gpurun_out/${tag}_parity_table.txt 2>&1
 for st in stage2 stage3; do
   python tools/train_bench.py $st 20 graph > gpurun_out/${tag}_train_${st}_graph.txt 2>&1
   python tools/train_bench.py $st 10 > gpurun_out/${tag}_train_$st.txt 2>&1
