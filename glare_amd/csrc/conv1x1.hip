@@ -34,7 +34,9 @@ struct C1Params {
   const a16_t* w;       // [Cout][Cin] bf16
   const float* bias;
   const a16_t* res;
+  const a16_t* res_lo;   // hi / lo form (conv_igemm.hip's HILO epilogue): remainder halves of the residual and of the output
   a16_t* out;
+  a16_t* out_lo;
   float* gn_part;        // [B][rbi][Cout/4][2] or null
   int B, N;              // images, pixels per image
   int Cin, Cout;
@@ -61,7 +63,7 @@ __device__ __forceinline__ void with_act1(int act, F&& f) {
   }
 }
 
-template <int KSTEPS>   // Cin / 16
+template <int KSTEPS, bool HILO = false>   // Cin / 16
 __global__ __launch_bounds__(256, 1) void conv1x1_ws_kernel(const C1Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ROWB = KSTEPS * 32;              // bytes of one weight row
@@ -143,6 +145,7 @@ __global__ __launch_bounds__(256, 1) void conv1x1_ws_kernel(const C1Params p) {
   if (n_units > 0) fetch(std::integral_constant<int, 0>{}, 0);
   f32x16 acc[4];
   u32x4 resv[8];
+  [[maybe_unused]] u32x4 resl[8];
   for (int q = 0; q < n_units; ++q) {
     const int rb = rb_lo + wave + 4 * (q / UPB), u = q % UPB;
     const int b = rb / p.rbi, r0 = (rb - b * p.rbi) * 32;
@@ -156,8 +159,12 @@ __global__ __launch_bounds__(256, 1) void conv1x1_ws_kernel(const C1Params p) {
       if (p.res) {   // the residual rows of this block, fetched NOW: they land under the MFMAs instead of stalling the epilogue
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
-          const int m = min((lane >> 4) + 4 * it, nrows - 1);
-          resv[it] = *reinterpret_cast<const u32x4*>(p.res + (pix0 + m) * p.rpitch + p.roff + co0 + (lane & 15) * 8);
+          // hi / lo form: the epilogue runs in two 64-channel halves, item it = 4 * half + t is row (lane >> 3) + 8 t, chunk 8 half + (lane & 7)
+          const int m = HILO ? min((lane >> 3) + 8 * (it & 3), nrows - 1) : min((lane >> 4) + 4 * it, nrows - 1);
+          const int chn = HILO ? 8 * (it >> 2) + (lane & 7) : (lane & 15);
+          resv[it] = *reinterpret_cast<const u32x4*>(p.res + (pix0 + m) * p.rpitch + p.roff + co0 + chn * 8);
+          if constexpr (HILO)
+            resl[it] = p.res_lo ? *reinterpret_cast<const u32x4*>(p.res_lo + (pix0 + m) * p.rpitch + p.roff + co0 + chn * 8) : u32x4{0u, 0u, 0u, 0u};
         }
       }
     }
@@ -187,6 +194,66 @@ __global__ __launch_bounds__(256, 1) void conv1x1_ws_kernel(const C1Params p) {
     // Phase 1: + bias (+ act when there is no residual) -> bf16; neighbouring lanes (co, co + 1) exchange one value so that each
     // lane writes one packed 4-B word per register pair; slab row m = 256 B, 16-B chunk c at (c ^ (m & 15)).
     float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
+    if constexpr (HILO) {
+      // hi / lo epilogue (see conv_igemm.hip): fp32 through the 8 KB slab, 64 output channels at a time (row = 64 floats, 16-B
+      // chunk c at c ^ (m & 15)); v = acc + bias + residual_hi + residual_lo, hi = round16(v), lo = round16(v - hi)
+      with_act1(p.act, [&](auto actc) {
+      constexpr int ACT = decltype(actc)::value;
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int j = 2 * hf + jj;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            const int col = 32 * jj + px;                                      // 0..63 within the half
+            *reinterpret_cast<float*>(slab + m * 256 + (((col >> 2) ^ (m & 15)) * 16) + (col & 3) * 4) = acc[j][r] + bias_v[j];
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int m = (lane >> 3) + 8 * t, c8 = lane & 7;
+          if (m < nrows) {
+            const f32x4 f0 = *reinterpret_cast<const f32x4*>(slab + m * 256 + (((2 * c8) ^ (m & 15)) * 16));
+            const f32x4 f1 = *reinterpret_cast<const f32x4*>(slab + m * 256 + (((2 * c8 + 1) ^ (m & 15)) * 16));
+            float v[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+            if (p.res) {
+              const u32x4 rv = resv[4 * hf + t], rl = resl[4 * hf + t];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { v[2 * e] += alo(rv[e]) + alo(rl[e]); v[2 * e + 1] += ahi(rv[e]) + ahi(rl[e]); }
+            }
+            u32x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float a = act1<ACT>(v[2 * e]), c = act1<ACT>(v[2 * e + 1]);
+              hi[e] = pack_a2(a, c);
+              lo[e] = pack_a2(a - alo(hi[e]), c - ahi(hi[e]));
+              if (e < 2) { gs0 += a + c; gq0 += a * a + c * c; } else { gs1 += a + c; gq1 += a * a + c * c; }
+            }
+            const size_t o = (pix0 + m) * p.opitch + p.ooff + co0 + (8 * hf + c8) * 8;
+            *reinterpret_cast<u32x4*>(p.out + o) = hi;
+            *reinterpret_cast<u32x4*>(p.out_lo + o) = lo;
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (p.gn_part) {   // lanes 8 apart hold the same channel chunk of this half
+#pragma unroll
+          for (int o = 8; o < 64; o <<= 1) {
+            gs0 += __shfl_xor(gs0, o, 64); gq0 += __shfl_xor(gq0, o, 64);
+            gs1 += __shfl_xor(gs1, o, 64); gq1 += __shfl_xor(gq1, o, 64);
+          }
+          if (lane < 8) {
+            float* dst = p.gn_part + (((size_t)b * p.rbi + (rb - b * p.rbi)) * (p.Cout / 4) + (co0 + (8 * hf + lane) * 8) / 4) * 2;
+            dst[0] = gs0; dst[1] = gq0; dst[2] = gs1; dst[3] = gq1;
+          }
+          gs0 = gq0 = gs1 = gq1 = 0.f;
+        }
+      }
+      });
+      continue;
+    }
     with_act1(p.act, [&](auto actc) {
     constexpr int ACT = decltype(actc)::value;
     const bool act_early = p.res == nullptr;
@@ -306,7 +373,8 @@ extern "C" int glare_conv1x1_ws_gn_reduce(const float* gn_partial, float* stats_
 
 static int c1_launch(const void* x, int x_pitch, int x_off, const void* w_bf16, long long w_istride, const float* bias, int b_istride,
                      const void* residual, int res_pitch, int res_off, void* out, int out_pitch, int out_off, int B,
-                     long long pixels_per_image, int Cin, int Cout, int act, float* gn_partial, glare_stream_t stream) {
+                     long long pixels_per_image, int Cin, int Cout, int act, float* gn_partial, glare_stream_t stream,
+                     const void* residual_lo = nullptr, void* out_lo = nullptr) {
   if (!x || !w_bf16 || !out || B <= 0 || pixels_per_image <= 0) return GLARE_ERR_INVALID;
   if (!glare_conv1x1_ws_supported(Cin, Cout)) return GLARE_ERR_UNSUPPORTED;
   if (w_istride != 0 && ((8 * 32 / (Cout / 128)) % B != 0 || w_istride % 8 != 0 || (bias && b_istride <= 0))) return GLARE_ERR_UNSUPPORTED;
@@ -317,20 +385,22 @@ static int c1_launch(const void* x, int x_pitch, int x_off, const void* w_bf16, 
   C1Params p;
   p.x = (const a16_t*)x; p.w = (const a16_t*)w_bf16; p.bias = bias; p.res = (const a16_t*)residual; p.out = (a16_t*)out;
   p.gn_part = gn_partial;
+  p.res_lo = (const a16_t*)residual_lo; p.out_lo = (a16_t*)out_lo;
+  if (residual_lo && !(residual && out_lo)) return GLARE_ERR_INVALID;
   p.B = B; p.N = (int)pixels_per_image; p.Cin = Cin; p.Cout = Cout;
   p.xpitch = x_pitch; p.xoff = x_off; p.opitch = out_pitch; p.ooff = out_off; p.rpitch = res_pitch; p.roff = res_off;
   p.act = act; p.nct = Cout / 128; p.rbi = (int)cdivll(pixels_per_image, 32);
   p.w_istride = w_istride; p.b_istride = w_istride != 0 ? b_istride : 0;
   const size_t lds = (size_t)128 * Cin * 2 + 4 * 8192;
   hipStream_t s = (hipStream_t)stream;
-#define C1_CASE(KS_)                                                                                                       \
-  if (Cin == 16 * KS_) {                                                                                                   \
-    if (hipFuncSetAttribute((const void*)conv1x1_ws_kernel<KS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+#define C1_CASE(KS_, HL_)                                                                                                  \
+  if (Cin == 16 * KS_ && (out_lo != nullptr) == HL_) {                                                                     \
+    if (hipFuncSetAttribute((const void*)conv1x1_ws_kernel<KS_, HL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
       return GLARE_ERR_LAUNCH;                                                                                             \
-    hipLaunchKernelGGL(conv1x1_ws_kernel<KS_>, dim3(256), dim3(256), lds, s, p);                                           \
+    hipLaunchKernelGGL((conv1x1_ws_kernel<KS_, HL_>), dim3(256), dim3(256), lds, s, p);                                    \
     return glare_launch_status();                                                                                          \
   }
-  C1_CASE(8) C1_CASE(16) C1_CASE(32)
+  C1_CASE(8, false) C1_CASE(16, false) C1_CASE(32, false) C1_CASE(8, true) C1_CASE(16, true) C1_CASE(32, true)
 #undef C1_CASE
   return GLARE_ERR_UNSUPPORTED;
 }
@@ -352,4 +422,18 @@ extern "C" int glare_conv1x1_ws_image_bf16(const void* x, int x_pitch, int x_off
   if (w_image_stride <= 0) return GLARE_ERR_INVALID;
   return c1_launch(x, x_pitch, x_off, w_bf16, w_image_stride, bias, bias_image_stride, residual, res_pitch, res_off, out, out_pitch, out_off,
                    B, pixels_per_image, Cin, Cout, act, gn_partial, stream);
+}
+
+// hi / lo form of both entry points above (w_image_stride = 0: one filter for all images): the output leaves as hi = round16(v) in
+// `out` and lo = round16(v - hi) in `out_lo` (same pitch / offset) of v = acc + bias + residual + residual_lo, nothing rounded before
+// the residual add; the fused GroupNorm statistics are those of v.  The residual stream of the conditional encoder (nin_shortcut,
+// AttnBlock's output projection) in the fp16 precision -- see glare_conv_desc.out_lo.
+extern "C" int glare_conv1x1_ws_hilo_bf16(const void* x, int x_pitch, int x_off, const void* w_bf16, long long w_image_stride,
+                                          const float* bias, int bias_image_stride, const void* residual, const void* residual_lo,
+                                          int res_pitch, int res_off, void* out, void* out_lo, int out_pitch, int out_off, int B,
+                                          long long pixels_per_image, int Cin, int Cout, int act, float* gn_partial,
+                                          glare_stream_t stream) {
+  if (!out_lo || w_image_stride < 0) return GLARE_ERR_INVALID;
+  return c1_launch(x, x_pitch, x_off, w_bf16, w_image_stride, bias, bias_image_stride, residual, res_pitch, res_off, out, out_pitch, out_off,
+                   B, pixels_per_image, Cin, Cout, act, gn_partial, stream, residual_lo, out_lo);
 }

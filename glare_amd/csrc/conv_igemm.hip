@@ -53,6 +53,8 @@ struct ConvParams {
   unsigned in0_bytes, in1_bytes;   // bytes of ONE image of each source (range of the halo DMA's buffer descriptors)
   float* gn_part;   // optional GroupNorm partial sums of the OUTPUT: [b][part][Cout/4][2], part = tile*WM + wm
   int gn_nparts;
+  const a16_t* res_lo;   // hi / lo epilogue (HILO instantiations): remainder halves of the residual and of the output
+  a16_t* out_lo;
 };
 
 template <int KS, int STRIDE, int TH>
@@ -99,7 +101,7 @@ __device__ __forceinline__ void with_act(int act, F&& f) {
 // "B stages" (one tap row each: KS taps x KSTEPS k-steps of weights).  Both images are
 // double-buffered in LDS and filled by LDS-DMA (global_load_lds_dwordx4), issued one B stage
 // ahead, right after the barrier that retires the buffer they overwrite; one barrier per B stage.
-template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int KSTEPS>
+template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int KSTEPS, bool HILO = false>
 __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 2)) void conv_igemm_kernel(const ConvParams p) {
   constexpr int TH = WM * MT;       // output tile rows
   constexpr int NW = WM * WN;       // waves per workgroup (4, or 6 for the 12 x 32 x 128 tile)
@@ -290,6 +292,89 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
       __builtin_amdgcn_s_setprio(0);
 #endif
     }
+  }
+
+  // ---- hi / lo epilogue: the output keeps 22 mantissa bits as two 16-bit tensors (the residual stream of the conditional
+  // encoder in the fp16 precision).  The accumulators go through a wave-private fp32 slab, one tile row
+  // (32 pixels x NT*32 couts) at a time; v = acc + bias + residual_hi + residual_lo in fp32, then hi = round16(v) and
+  // lo = round16(v - hi) leave as two 16-B stores per lane.  Unlike the plain epilogue nothing is rounded before the residual add.
+  if constexpr (HILO) {
+    constexpr int ROWF = NT * 128 + 16;                  // slab row pitch in bytes (pad: bank spread between rows)
+    constexpr int CPR = NT * 4;                          // 8-channel chunks per slab row
+    static_assert(NW * 32 * ROWF <= (2 * A_SLOTS + 2 * B_CHUNKS) * 16, "hi/lo epilogue slab fits the pipeline LDS");
+    static_assert(KS != 2, "the sub-pixel form has no hi/lo epilogue");
+    __syncthreads();  // every wave is done reading the pipeline buffers
+    char* slab = smem + wave * (32 * ROWF);
+    const int ncol = lane & 31, rhalf = lane >> 5;
+    float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
+    with_act(p.act, [&](auto actc) {
+    constexpr int ACT = decltype(actc)::value;
+    static_for<MT>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      static_for<NT>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const int co = ct * TN + (wn * NT + j) * 32 + ncol;
+        const float bv = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = (r & 3) + 8 * (r >> 2) + 4 * rhalf;           // pixel x within the tile row
+          *reinterpret_cast<float*>(slab + m * ROWF + (j * 32 + ncol) * 4) = acc[i][j][r] + bv;
+        }
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < 32 * CPR / 64; ++it) {
+        const int idx = lane + 64 * it;
+        const int row = idx / CPR, ch = idx % CPR;
+        const int oy = oy0 + wm * MT + i, ox = ox0 + row;
+        const int co = ct * TN + wn * NT * 32 + ch * 8;
+        if (oy < p.OH && ox < p.OW && co < p.Cout) {
+          const f32x4 f0 = *reinterpret_cast<const f32x4*>(slab + row * ROWF + ch * 32);
+          const f32x4 f1 = *reinterpret_cast<const f32x4*>(slab + row * ROWF + ch * 32 + 16);
+          float v[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+          const size_t pix = ((size_t)b * p.OH + oy) * p.OW + ox;
+          if (p.res) {
+            const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + pix * p.rpitch + p.roff + co);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] += alo(rv[e]); v[2 * e + 1] += ahi(rv[e]); }
+            if (p.res_lo) {
+              const u32x4 rl = *reinterpret_cast<const u32x4*>(p.res_lo + pix * p.rpitch + p.roff + co);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { v[2 * e] += alo(rl[e]); v[2 * e + 1] += ahi(rl[e]); }
+            }
+          }
+          u32x4 hi, lo;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float a = apply_act<ACT>(v[2 * e]), c = apply_act<ACT>(v[2 * e + 1]);
+            hi[e] = pack_a2(a, c);
+            lo[e] = pack_a2(a - alo(hi[e]), c - ahi(hi[e]));
+            if (e < 2) { gs0 += a + c; gq0 += a * a + c * c; } else { gs1 += a + c; gq1 += a * a + c * c; }
+          }
+          *reinterpret_cast<u32x4*>(reinterpret_cast<a16_t*>(p.out) + pix * p.opitch + p.ooff + co) = hi;
+          *reinterpret_cast<u32x4*>(p.out_lo + pix * p.opitch + p.ooff + co) = lo;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    });
+    });
+    if (p.gn_part) {  // lanes with the same channel chunk are CPR apart: fold them, one lane per chunk writes
+#pragma unroll
+      for (int o = CPR; o < 64; o <<= 1) {
+        gs0 += __shfl_xor(gs0, o, 64); gq0 += __shfl_xor(gq0, o, 64);
+        gs1 += __shfl_xor(gs1, o, 64); gq1 += __shfl_xor(gq1, o, 64);
+      }
+      const int co = ct * TN + wn * NT * 32 + lane * 8;
+      if (lane < CPR && co < p.Cout) {
+        const int row0 = oy0 + wm * MT;
+        const int part = ((phase * ((p.OH + 7) / 8) + row0 / 8) * p.tiles_x + tx) * 2 + ((row0 / 4) & 1);
+        if (part < p.gn_nparts) {
+          float* dst = p.gn_part + (((size_t)b * p.gn_nparts + part) * (p.Cout / 4) + co / 4) * 2;
+          dst[0] = gs0; dst[1] = gq0; dst[2] = gs1; dst[3] = gq1;
+        }
+      }
+    }
+    return;
   }
 
   // ---- fast epilogue (bf16 NHWC output, 16-B aligned records): the accumulators go through LDS so
@@ -572,7 +657,7 @@ Variant pick_variant(int ksize, int cout, int cout_tile = 0) {
   return v;
 }
 
-template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int KSTEPS>
+template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int KSTEPS, bool HILO = false>
 int launch(const ConvParams& p_in, hipStream_t stream) {
   using G = TileGeom<KS, STRIDE, WM * MT>;
   constexpr int TN = WN * NT * 32;
@@ -584,7 +669,7 @@ int launch(const ConvParams& p_in, hipStream_t stream) {
   p.gn_nparts = p.tiles_x * cdiv(p.OH, 8) * 2 * (KS == 2 ? 4 : 1);  // the 8 x 32 grid, 2 wave rows (4 rows each) per block
   if (p.gn_part && !(p.fast_epilogue && p.Cout % 32 == 0)) return GLARE_ERR_UNSUPPORTED;
   const size_t lds = (size_t)(2 * (((KSTEPS * 2 * G::NPOS + 63) / 64) * 64) + 2 * KS * KSTEPS * 2 * TN) * 16;
-  auto kern = conv_igemm_kernel<KS, STRIDE, MT, NT, WM, WN, KSTEPS>;
+  auto kern = conv_igemm_kernel<KS, STRIDE, MT, NT, WM, WN, KSTEPS, HILO>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GLARE_ERR_LAUNCH;
@@ -764,6 +849,9 @@ extern "C" int glare_conv2d_bf16(const glare_conv_desc* d, glare_stream_t stream
   p.n_blocks = 0;
   p.gn_part = d->gn_partial;
   p.gn_nparts = 0;
+  p.res_lo = (const a16_t*)d->residual_lo;
+  p.out_lo = (a16_t*)d->out_lo;
+  if (p.res_lo && !(p.res && p.out_lo)) return GLARE_ERR_INVALID;
   // 16-B records everywhere -> LDS-staged epilogue
   p.fast_epilogue = (d->out_mode == GLARE_OUT_NHWC_BF16) && !(p.Cout % 8) && !(p.opitch % 8) && !(p.ooff % 8) &&
                     (!p.res || (!(p.rpitch % 8) && !(p.roff % 8)));
@@ -782,6 +870,11 @@ extern "C" int glare_conv2d_bf16(const glare_conv_desc* d, glare_stream_t stream
     return launch<KS_, ST_, 2, 1, 4, 1, KST>(p, stream);                                  \
   } while (0)
 
+  if (p.out_lo) {   // hi / lo output: the 3x3 convs of the conditional encoder's residual stream (128-wide tile, 16-B records)
+    if (d->ksize != 3 || subpix || d->upsample || v.tn != 128 || !p.fast_epilogue || CONV_TILE16) return GLARE_ERR_UNSUPPORTED;
+    if (d->stride == 2) return launch<3, 2, 4, 2, 2, 2, 1, true>(p, stream);
+    return launch<3, 1, 4, 2, 2, 2, 1, true>(p, stream);
+  }
   if (subpix) {   // interleaved scatter lives in the LDS-staged epilogue only
     if (!p.fast_epilogue) return GLARE_ERR_UNSUPPORTED;
     GLARE_CONV_DISPATCH(2, 1);

@@ -31,7 +31,7 @@ template <int KS, int ACT>
 __global__ __launch_bounds__(CS_THREADS) void conv_small_kernel(
     const float* __restrict__ x, long long sb, long long sc, long long sy, long long sx, const float* __restrict__ w,
     const float* __restrict__ bias, void* __restrict__ out, int B, int H, int W, int Cin, int Cout, int out_pitch,
-    int out_off, int out_f32) {
+    int out_off, int out_f32, a16_t* __restrict__ out_lo) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* wl = reinterpret_cast<float*>(smem);  // [KS*KS][Cin][CoutP], then the bias [CoutP]
   const int CoutP = (Cout + 7) & ~7;
@@ -114,8 +114,15 @@ __global__ __launch_bounds__(CS_THREADS) void conv_small_kernel(
       for (int e = 0; e < 8; ++e) acc[q][e] = act_apply<ACT>(acc[q][e]);
       if (vec_store && g * 8 + 8 <= Cout) {
         a16_t* o = reinterpret_cast<a16_t*>(out) + opix * out_pitch + out_off + g * 8;
-        *reinterpret_cast<u32x4*>(o) = u32x4{pack_a2(acc[q][0], acc[q][1]), pack_a2(acc[q][2], acc[q][3]), pack_a2(acc[q][4], acc[q][5]),
-                                             pack_a2(acc[q][6], acc[q][7])};
+        const u32x4 hi = u32x4{pack_a2(acc[q][0], acc[q][1]), pack_a2(acc[q][2], acc[q][3]), pack_a2(acc[q][4], acc[q][5]),
+                               pack_a2(acc[q][6], acc[q][7])};
+        *reinterpret_cast<u32x4*>(o) = hi;
+        if (out_lo) {   // hi / lo pair (glare_conv_desc.out_lo): the remainder of the 16-bit rounding, same pitch / offset
+          u32x4 lo;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) lo[e] = pack_a2(acc[q][2 * e] - alo(hi[e]), acc[q][2 * e + 1] - ahi(hi[e]));
+          *reinterpret_cast<u32x4*>(out_lo + opix * out_pitch + out_off + g * 8) = lo;
+        }
       } else if (out_f32) {
         float* o = reinterpret_cast<float*>(out) + opix * out_pitch + out_off + g * 8;
 #pragma unroll
@@ -134,10 +141,10 @@ __global__ __launch_bounds__(CS_THREADS) void conv_small_kernel(
 template <int KS>
 void launch_small(int act, unsigned blocks, size_t lds, hipStream_t st, const float* x, long long sb, long long sc, long long sy,
                   long long sx, const float* w, const float* bias, void* out, int B, int H, int W, int Cin, int Cout, int out_pitch,
-                  int out_off, int out_f32) {
+                  int out_off, int out_f32, a16_t* out_lo) {
 #define CS_LAUNCH(A)                                                                                                          \
   hipLaunchKernelGGL((conv_small_kernel<KS, A>), dim3(blocks), dim3(CS_THREADS), lds, st, x, sb, sc, sy, sx, w, bias, out, B, H, W, \
-                     Cin, Cout, out_pitch, out_off, out_f32)
+                     Cin, Cout, out_pitch, out_off, out_f32, out_lo)
   switch (act) {
     case GLARE_ACT_SIGMOID: CS_LAUNCH(GLARE_ACT_SIGMOID); break;
     case GLARE_ACT_RELU: CS_LAUNCH(GLARE_ACT_RELU); break;
@@ -149,11 +156,11 @@ void launch_small(int act, unsigned blocks, size_t lds, hipStream_t st, const fl
 
 }  // namespace
 
-extern "C" int glare_conv2d_smallcin_f32(const float* x, long long stride_b, long long stride_c, long long stride_y,
-                                         long long stride_x, const float* w_oihw, const float* bias, void* out, int B,
-                                         int H, int W, int Cin, int Cout, int ksize, int out_pitch, int out_off, int act,
-                                         int out_is_f32, glare_stream_t stream) {
+static int smallcin_launch(const float* x, long long stride_b, long long stride_c, long long stride_y, long long stride_x,
+                           const float* w_oihw, const float* bias, void* out, int B, int H, int W, int Cin, int Cout, int ksize,
+                           int out_pitch, int out_off, int act, int out_is_f32, void* out_lo, glare_stream_t stream) {
   if (!x || !w_oihw || !out || B <= 0 || H <= 0 || W <= 0 || Cout <= 0) return GLARE_ERR_INVALID;
+  if (out_lo && (out_is_f32 || (out_pitch % 8) || (out_off % 8) || (Cout % 8))) return GLARE_ERR_UNSUPPORTED;
   if (Cin < 1 || Cin > 4 || (ksize != 1 && ksize != 3)) return GLARE_ERR_UNSUPPORTED;
   if (out_off + Cout > out_pitch) return GLARE_ERR_INVALID;
   const int CoutP = (Cout + 7) & ~7;
@@ -164,9 +171,28 @@ extern "C" int glare_conv2d_smallcin_f32(const float* x, long long stride_b, lon
   if (blocks > 256 * 16) blocks = 256 * 16;
   if (ksize == 3)
     launch_small<3>(act, (unsigned)blocks, lds, (hipStream_t)stream, x, stride_b, stride_c, stride_y, stride_x, w_oihw, bias, out, B, H, W,
-                    Cin, Cout, out_pitch, out_off, out_is_f32);
+                    Cin, Cout, out_pitch, out_off, out_is_f32, (a16_t*)out_lo);
   else
     launch_small<1>(act, (unsigned)blocks, lds, (hipStream_t)stream, x, stride_b, stride_c, stride_y, stride_x, w_oihw, bias, out, B, H, W,
-                    Cin, Cout, out_pitch, out_off, out_is_f32);
+                    Cin, Cout, out_pitch, out_off, out_is_f32, (a16_t*)out_lo);
   return glare_launch_status();
+}
+
+extern "C" int glare_conv2d_smallcin_f32(const float* x, long long stride_b, long long stride_c, long long stride_y,
+                                         long long stride_x, const float* w_oihw, const float* bias, void* out, int B,
+                                         int H, int W, int Cin, int Cout, int ksize, int out_pitch, int out_off, int act,
+                                         int out_is_f32, glare_stream_t stream) {
+  return smallcin_launch(x, stride_b, stride_c, stride_y, stride_x, w_oihw, bias, out, B, H, W, Cin, Cout, ksize, out_pitch, out_off, act,
+                         out_is_f32, nullptr, stream);
+}
+
+// The same with the output as a hi / lo pair (16-bit NHWC, Cout / pitch / offset multiples of 8; glare_conv_desc.out_lo): conv_in
+// of the conditional encoder opens the 22-bit residual stream straight from its fp32 accumulators.
+extern "C" int glare_conv2d_smallcin_hilo_f32(const float* x, long long stride_b, long long stride_c, long long stride_y,
+                                              long long stride_x, const float* w_oihw, const float* bias, void* out_hi, void* out_lo,
+                                              int B, int H, int W, int Cin, int Cout, int ksize, int out_pitch, int out_off, int act,
+                                              glare_stream_t stream) {
+  if (!out_lo) return GLARE_ERR_INVALID;
+  return smallcin_launch(x, stride_b, stride_c, stride_y, stride_x, w_oihw, bias, out_hi, B, H, W, Cin, Cout, ksize, out_pitch, out_off, act,
+                         0, out_lo, stream);
 }

@@ -154,7 +154,31 @@ int rescale_bps(long long n_per_sample) {
   return (int)(b < 1 ? 1 : (b > 512 ? 512 : b));
 }
 
+// fp32 -> hi / lo pair: hi = round16(v), lo = round16(v - hi)  (the conv_in output opening the encoder's residual stream)
+__global__ __launch_bounds__(EW_THREADS) void split_hilo_kernel(const float* __restrict__ src, long long n8, a16_t* __restrict__ hi,
+                                                                a16_t* __restrict__ lo) {
+  for (long long i = (long long)blockIdx.x * EW_THREADS + threadIdx.x; i < n8; i += (long long)gridDim.x * EW_THREADS) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(src + i * 8), c = *reinterpret_cast<const f32x4*>(src + i * 8 + 4);
+    const float v[8] = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+    u32x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      h[e] = pack_a2(v[2 * e], v[2 * e + 1]);
+      l[e] = pack_a2(v[2 * e] - alo(h[e]), v[2 * e + 1] - ahi(h[e]));
+    }
+    *reinterpret_cast<u32x4*>(hi + i * 8) = h;
+    *reinterpret_cast<u32x4*>(lo + i * 8) = l;
+  }
+}
+
 }  // namespace
+
+extern "C" int glare_split_hilo_f32(const float* src, long long n, void* hi_bf16, void* lo_bf16, glare_stream_t stream) {
+  if (!src || !hi_bf16 || !lo_bf16 || n <= 0 || (n % 8)) return GLARE_ERR_INVALID;
+  hipLaunchKernelGGL(split_hilo_kernel, dim3(ew_blocks(n / 8)), dim3(EW_THREADS), 0, (hipStream_t)stream, src, n / 8, (a16_t*)hi_bf16,
+                     (a16_t*)lo_bf16);
+  return glare_launch_status();
+}
 
 extern "C" int glare_mix_bf16(const void* a, int a_pitch, int a_off, const void* b, int b_pitch, int b_off, void* out,
                               int out_pitch, int out_off, long long n_pixels, int C, float mix_w, glare_stream_t stream) {

@@ -19,10 +19,12 @@ constexpr int GN_GROUPS = 32;
 // partial layout: [B][splits][32][2] fp32
 // ADD: y = x + addend (dense, pitch C) is formed, rounded to bf16, stored to `sum_out`, and the statistics are those of y --
 // the residual add that is left of AttnBlock once proj_out is folded into v, fused with the next norm's statistics pass.
-template <bool ADD>
+// LO: x is the hi half of a hi / lo pair (value = hi + lo, 22 mantissa bits; glare_conv_desc.out_lo), `xlo` its remainder half
+template <bool ADD, bool LO = false>
 __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const a16_t* __restrict__ x, float* __restrict__ partial,
                                                               long long HW, int C, int pitch, int off, int splits,
-                                                              const a16_t* __restrict__ addend, a16_t* __restrict__ sum_out) {
+                                                              const a16_t* __restrict__ addend, a16_t* __restrict__ sum_out,
+                                                              const a16_t* __restrict__ xlo = nullptr) {
   // deterministic block reduction (no float atomics: the statistics, and everything downstream, must not depend on
   // the order in which waves happen to arrive): per-thread sums -> per-channel sums -> per-group sums, fixed order
   __shared__ float vals[GN_THREADS][17];
@@ -65,6 +67,24 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const a16_t* __res
       }
       for (; p < p1; p += ppi) accum(add_store(p));
     } else {
+      if constexpr (LO) {
+        const a16_t* lbase = xlo + (size_t)b * HW * pitch + off + chunk * 8;
+        auto acc2 = [&](const u32x4& vh, const u32x4& vl) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float lo = alo(vh[e]) + alo(vl[e]), hi = ahi(vh[e]) + ahi(vl[e]);
+            s[2 * e] += lo; q[2 * e] += lo * lo;
+            s[2 * e + 1] += hi; q[2 * e + 1] += hi * hi;
+          }
+        };
+        for (; p + ppi < p1; p += 2LL * ppi) {   // two pixels (four 16-B loads) in flight per lane
+          const u32x4 h0 = *reinterpret_cast<const u32x4*>(base + (size_t)p * pitch), l0 = *reinterpret_cast<const u32x4*>(lbase + (size_t)p * pitch);
+          const u32x4 h1 = *reinterpret_cast<const u32x4*>(base + (size_t)(p + ppi) * pitch), l1 = *reinterpret_cast<const u32x4*>(lbase + (size_t)(p + ppi) * pitch);
+          acc2(h0, l0); acc2(h1, l1);
+        }
+        for (; p < p1; p += ppi)
+          acc2(*reinterpret_cast<const u32x4*>(base + (size_t)p * pitch), *reinterpret_cast<const u32x4*>(lbase + (size_t)p * pitch));
+      }
       for (; p + 3LL * ppi < p1; p += 4LL * ppi) {  // 4 independent 16-B loads in flight per lane
         const u32x4 v0 = *reinterpret_cast<const u32x4*>(base + (size_t)p * pitch);
         const u32x4 v1 = *reinterpret_cast<const u32x4*>(base + (size_t)(p + ppi) * pitch);
@@ -94,11 +114,12 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const a16_t* __res
 }
 
 // SWISH is a template parameter: as a run-time flag it compiled to one branch per bf16 pair of the streaming loop
-template <bool SWISH>
+template <bool SWISH, bool LO = false>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const a16_t* __restrict__ x, const float* __restrict__ partial,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               a16_t* __restrict__ y, long long HW, int C, int pitch, int off,
-                                                              int splits, float eps, int blocks_per_image) {
+                                                              int splits, float eps, int blocks_per_image,
+                                                              const a16_t* __restrict__ xlo = nullptr) {
   __shared__ float mean_s[GN_GROUPS], rstd_s[GN_GROUPS];
   const int b = blockIdx.x / blocks_per_image, blk = blockIdx.x % blocks_per_image;
   const int cpg = C / GN_GROUPS;
@@ -143,6 +164,30 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const a16_t* __res
     return o;
   };
   long long p = p0 + pl;
+  if constexpr (LO) {     // hi / lo input: the normalised value is formed from hi + lo, rounded once on the way out
+    const a16_t* lb = xlo + (size_t)b * HW * pitch + off + chunk * 8;
+    auto apply2 = [&](const u32x4& vh, const u32x4& vl) {
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float lo = (alo(vh[e]) + alo(vl[e])) * sc[2 * e] + sh[2 * e];
+        float hi = (ahi(vh[e]) + ahi(vl[e])) * sc[2 * e + 1] + sh[2 * e + 1];
+        if (SWISH) { lo = swishf_(lo); hi = swishf_(hi); }
+        o[e] = pack_a2(lo, hi);
+      }
+      return o;
+    };
+    for (; p + ppi < p1; p += 2LL * ppi) {   // two pixels (four 16-B loads) in flight per lane
+      const u32x4 h0 = *reinterpret_cast<const u32x4*>(xb + (size_t)p * pitch), l0 = *reinterpret_cast<const u32x4*>(lb + (size_t)p * pitch);
+      const u32x4 h1 = *reinterpret_cast<const u32x4*>(xb + (size_t)(p + ppi) * pitch), l1 = *reinterpret_cast<const u32x4*>(lb + (size_t)(p + ppi) * pitch);
+      __builtin_nontemporal_store(apply2(h0, l0), reinterpret_cast<u32x4*>(yb + (size_t)p * C));
+      __builtin_nontemporal_store(apply2(h1, l1), reinterpret_cast<u32x4*>(yb + (size_t)(p + ppi) * C));
+    }
+    for (; p < p1; p += ppi)
+      __builtin_nontemporal_store(apply2(*reinterpret_cast<const u32x4*>(xb + (size_t)p * pitch), *reinterpret_cast<const u32x4*>(lb + (size_t)p * pitch)),
+                                  reinterpret_cast<u32x4*>(yb + (size_t)p * C));
+    return;
+  }
 #ifndef GN_APPLY_DEPTH
 #define GN_APPLY_DEPTH 4
 #endif
@@ -279,6 +324,36 @@ extern "C" int glare_groupnorm_apply_bf16(const void* x, int in_pitch, int in_of
   else
     hipLaunchKernelGGL(gn_apply_kernel<false>, dim3((unsigned)(bpi * B)), dim3(GN_THREADS), 0, (hipStream_t)stream_, (const a16_t*)x,
                        stats, gamma, beta, (a16_t*)y, HW, C, in_pitch, in_off, splits, eps, bpi);
+  return glare_launch_status();
+}
+
+// GroupNorm of a hi / lo pair (value = x_hi + x_lo, same pitch / offset; glare_conv_desc.out_lo): statistics and normalisation from
+// the 22-bit value, one rounding on the way out.  stats != NULL: apply only (statistics from the producer's epilogue); stats == NULL:
+// statistics pass first (workspace as glare_groupnorm_swish_bf16).
+extern "C" int glare_groupnorm_hilo_bf16(const void* x_hi, const void* x_lo, int in_pitch, int in_off, const float* gamma,
+                                         const float* beta, void* y, int B, long long HW, int C, float eps, int swish, const float* stats,
+                                         int splits, void* workspace, size_t workspace_bytes, glare_stream_t stream_) {
+  if (!x_hi || !x_lo || !gamma || !beta || !y || B <= 0 || HW <= 0 || C <= 0) return GLARE_ERR_INVALID;
+  if (C % 32 || C % 8 || C > 2048 || (GN_THREADS % (C / 8)) || in_pitch % 8 || in_off % 8) return GLARE_ERR_UNSUPPORTED;
+  if (in_off + C > in_pitch) return GLARE_ERR_INVALID;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!stats) {
+    if (!workspace || workspace_bytes < glare_groupnorm_workspace_bytes(B, HW)) return GLARE_ERR_WORKSPACE;
+    splits = gn_splits(HW);
+    hipLaunchKernelGGL((gn_stats_kernel<false, true>), dim3(splits, B), dim3(GN_THREADS), 0, stream, (const a16_t*)x_hi, (float*)workspace,
+                       HW, C, in_pitch, in_off, splits, (const a16_t*)nullptr, (a16_t*)nullptr, (const a16_t*)x_lo);
+    stats = (const float*)workspace;
+  } else if (splits <= 0) {
+    return GLARE_ERR_INVALID;
+  }
+  int bpi = (int)((HW * (C / 8) + 16 * GN_THREADS - 1) / (16 * GN_THREADS));
+  if (bpi < 1) bpi = 1;
+  if (swish)
+    hipLaunchKernelGGL((gn_apply_kernel<true, true>), dim3((unsigned)(bpi * B)), dim3(GN_THREADS), 0, stream, (const a16_t*)x_hi, stats,
+                       gamma, beta, (a16_t*)y, HW, C, in_pitch, in_off, splits, eps, bpi, (const a16_t*)x_lo);
+  else
+    hipLaunchKernelGGL((gn_apply_kernel<false, true>), dim3((unsigned)(bpi * B)), dim3(GN_THREADS), 0, stream, (const a16_t*)x_hi, stats,
+                       gamma, beta, (a16_t*)y, HW, C, in_pitch, in_off, splits, eps, bpi, (const a16_t*)x_lo);
   return glare_launch_status();
 }
 

@@ -38,7 +38,9 @@ __global__ __launch_bounds__(256) void post_crop_kernel(const float* __restrict_
     float r[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      r[c] = fminf(fmaxf(out[(((long long)b * 3 + c) * Hp + y) * Wp + x + pad], 0.f), 1.f);
+      const float v = out[(((long long)b * 3 + c) * Hp + y) * Wp + x + pad];
+      r[c] = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);     // torch.clamp (infer_dataset_lol.py:138): a NaN stays a NaN -- fminf / fmaxf
+                                                      // would turn it into 0 and hide a broken image behind a finite PSNR
       restored[((long long)b * npix + p) * 3 + c] = r[c];
     }
     sr += (double)(0.114f * r[0] + 0.587f * r[1] + 0.299f * r[2]);
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256) void post_gain_kernel(float* __restrict__ rest
   double acc = 0.0;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)HB * 256) {
     float r = restored[(long long)b * n + i];
-    if (apply_gain) r = fminf(fmaxf(r * gain, 0.f), 1.f);
+    if (apply_gain) { r *= gain; r = r < 0.f ? 0.f : (r > 1.f ? 1.f : r); }   // np.clip: NaN propagates
     restored[(long long)b * n + i] = r;
     if (gt) {
       const double d = gt[(long long)b * n + i] / 255.0 - (double)r;

@@ -22,12 +22,13 @@ from . import modules as M
 from .synthetic import seeded_init_, synthetic_gt, synthetic_lowlight
 
 
-def enhance_batch(netG, net_vq, imgs_u8, device):
+def enhance_batch(netG, net_vq, imgs_u8, device, precision=None):
     """uint8 [n,H,W,3] (host) -> network outputs [n,3,H+20,W+20] on the device (before the GT gain), via the fused NHWC
-    graph.  The images cross PCIe once, as uint8; padding / log transform run on the device (csrc/harness.hip)."""
+    graph.  The images cross PCIe once, as uint8; padding / log transform run on the device (csrc/harness.hip).
+    precision: None = the entry point's default (fp16), or "bf16" / "fp16"."""
     lr = harness.preprocess_device(torch.from_numpy(np.ascontiguousarray(imgs_u8)).to(device))
     with torch.no_grad():
-        out = netG.reverse_flow_nhwc(net_vq, lr)["out"]
+        out = netG.reverse_flow_nhwc(net_vq, lr, precision=precision)["out"]
     return out
 
 
@@ -41,7 +42,7 @@ def load_lol_pairs(root):
     return lows, gts
 
 
-def run(n_images, batch=8, h=400, w=600, seed=1234, root=None, net_g=None, net_vq=None, pairs=None, with_ssim=False):
+def run(n_images, batch=8, h=400, w=600, seed=1234, root=None, net_g=None, net_vq=None, pairs=None, with_ssim=False, precision=None):
     """Synthetic LOL-shaped pairs by default; `root` = a LOL dataset folder (eval15 split), `net_g` / `net_vq` = checkpoint
     files in the reference's format (glare_amd.checkpoint) -- without them the weights are name-seeded; `pairs` = (lows, gts)
     uint8 stacks [n,h,w,3] supplied by the caller."""
@@ -66,8 +67,8 @@ def run(n_images, batch=8, h=400, w=600, seed=1234, root=None, net_g=None, net_v
         lows = synthetic_lowlight(n_images, h, w, seed=seed)
         gts = synthetic_gt(n_images, h, w, seed=seed + 1)
 
-    def psnr_slice(lo, hi):
-        out = enhance_batch(netG, net_vq, lows[lo:hi], device)
+    def psnr_slice(lo, hi, prec=precision):
+        out = enhance_batch(netG, net_vq, lows[lo:hi], device, prec)
         gt = torch.from_numpy(np.ascontiguousarray(gts[lo:hi])).to(device)
         restored, vals = harness.postprocess_device(out, h, w, gt)   # crop, clamp, GT-mean gain, PSNR: all on the device
         if with_ssim:                                                  # + SSIM (calculate_ssim, infer_dataset_lol.py:152)
@@ -80,6 +81,14 @@ def run(n_images, batch=8, h=400, w=600, seed=1234, root=None, net_g=None, net_v
     local = parallel.run_sharded(n_images, psnr_slice, rank, world, batch=batch, streams=2)
     if local is None:
         local = torch.zeros(0, 2 if with_ssim else 1, dtype=torch.float64, device=device)
+    # fp16 (the default) has fp16's range: a checkpoint whose activations pass 65504 yields inf / NaN where bf16 would not.  The
+    # PSNRs come back to the host anyway; an image whose value is not finite is enhanced again in bf16 (fp32 range, same kernels)
+    run.bf16_reruns = 0
+    if precision != "bf16" and local.numel() and not bool(torch.isfinite(local[:, 0]).all()):
+        lo0, _ = parallel.shard_range(n_images, rank, world)
+        for j in (~torch.isfinite(local[:, 0])).nonzero().flatten().tolist():
+            local[j] = psnr_slice(lo0 + j, lo0 + j + 1, "bf16")[0]
+            run.bf16_reruns += 1
     torch.cuda.synchronize()
     run.last_seconds = time.perf_counter() - t0                   # host uint8 in -> PSNR on the device, this rank's share
     full = parallel.gather_results(local, n_images, rank, world)
@@ -101,8 +110,11 @@ def main():
     ap.add_argument("--net-g", default=None, help="net_G checkpoint (reference format)")
     ap.add_argument("--net-vq", default=None, help="VQGAN checkpoint (reference format)")
     ap.add_argument("--ssim", action="store_true", help="also report SSIM (utils2.calculate_ssim) per image")
+    ap.add_argument("--precision", choices=("fp16", "bf16"), default=None,
+                    help="16-bit format of activations and filters (default fp16, the reference's autocast dtype; images whose fp16 "
+                         "result is not finite are re-run in bf16)")
     args = ap.parse_args()
-    res = run(args.images, args.batch, args.height, args.width, root=args.root, net_g=args.net_g, net_vq=args.net_vq, with_ssim=args.ssim)
+    res = run(args.images, args.batch, args.height, args.width, root=args.root, net_g=args.net_g, net_vq=args.net_vq, with_ssim=args.ssim, precision=args.precision)
     if res is not None:
         world = int(os.environ.get("WORLD_SIZE", "1"))
         psnrs = res[:, 0] if args.ssim else res

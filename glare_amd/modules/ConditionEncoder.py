@@ -15,6 +15,7 @@ class ConEncoder1(HipModule):
         self.encoder = Encoder(ch, out_ch, ch_mult=ch_mult, num_res_blocks=num_res_blocks,
                                attn_resolutions=attn_resolutions, in_channels=in_channels, resolution=resolution,
                                z_channels=z_channels, double_z=double_z)
+        self.encoder.hilo_stream = True     # inference in fp16: the residual stream as hi / lo pairs (encoder_decoder.is_hilo)
         self.color_conv = nn.Conv2d(3, 3, 3, 1, 1)
         self.cond_conv = nn.Sequential(nn.Conv2d(3, 64, 3, 1, 1), nn.Sigmoid())
 

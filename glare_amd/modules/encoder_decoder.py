@@ -5,6 +5,7 @@ Mirrors code/models/modules/encoder_decoder.py (ResnetBlock :78-137, AttnBlock :
 signatures (NCHW fp32 in/out).  Internally activations are NHWC bf16; `forward_nhwc` chains modules
 without layout conversions and is what the fused graphs use."""
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -25,6 +26,12 @@ def gn_swish(x, norm, swish=True):
     return ops.groupnorm(x, norm.weight.detach().float(), norm.bias.detach().float(), swish=swish, eps=norm.eps)
 
 
+def is_hilo(x):
+    """Is this activation the hi half of a hi / lo pair (its remainder in `x._lo`)?  Encoder.hilo_stream starts the residual
+    stream that way; every block then adds into it at 22 bits and hands the pair on (ops.conv2d(hilo=True))."""
+    return getattr(x, "_lo", None) is not None
+
+
 # Training mode (`train_nhwc` methods): the same graph through glare_amd.autograd, i.e. HIP forward + HIP backward
 # with parameters taken live (packed per call) -- what `loss.backward()` differentiates in the reference.
 def gn_swish_t(x, norm, swish=True):
@@ -35,6 +42,9 @@ def conv_t(x, conv, **kw):
     return A.conv2d(x, conv.weight, conv.bias, **kw)
 
 
+# The conditional encoder's residual stream as hi / lo pairs under fp16 (Encoder.hilo_stream; GLARE_HILO_STREAM=0 switches it off for
+# A/B measurements: the stream tensors are then plain 16-bit, as in every other network of the path).
+HILO_STREAM = os.environ.get("GLARE_HILO_STREAM", "1") != "0"
 SUBPIXEL_UPSAMPLE = True
 FOLD_PROJ_INTO_V = True
 # AttnBlock as attention with shared keys / values (csrc/attn.hip, attn_kv_fwd_kernel): the key projection folded into the
@@ -79,7 +89,7 @@ class Downsample(HipModule):
 
     def forward_nhwc(self, x):
         return ops.conv2d(x, packed_conv(self, self.conv), stride=2,  # pad (0,1,0,1) fused in the loader
-                          gn_stats=GN_FUSED and self.conv.out_channels % 128 == 0)
+                          gn_stats=GN_FUSED and self.conv.out_channels % 128 == 0, hilo=is_hilo(x))
 
     def train_nhwc(self, x):
         return conv_t(x, self.conv, stride=2)
@@ -103,12 +113,13 @@ class ResnetBlock(HipModule):
 
     def forward_nhwc(self, x, out=None, out_off=0):
         fuse = GN_FUSED and self.out_channels % 128 == 0
+        hl = is_hilo(x)      # the residual stream as a hi / lo pair (conditional encoder, fp16): x + h is added in 22 bits
         h = ops.conv2d(gn_swish(x, self.norm1), packed_conv(self, self.conv1), gn_stats=fuse)  # stats for norm2
         h = gn_swish(h, self.norm2)
-        res = x if self.in_channels == self.out_channels else ops.conv2d(x, packed_conv(self, self.nin_shortcut))
+        res = x if self.in_channels == self.out_channels else ops.conv2d(x, packed_conv(self, self.nin_shortcut), hilo=hl)
         # the block output feeds the next block's / attention's norm: its statistics ride along too
         return ops.conv2d(h, packed_conv(self, self.conv2), residual=res, out=out, out_off=out_off,
-                          gn_stats=fuse and out is None)
+                          gn_stats=fuse and out is None, hilo=hl)
 
     def train_nhwc(self, x):
         x, xr = A.fork(x)                                         # x feeds the block body and the shortcut
@@ -177,12 +188,13 @@ class AttnBlock(HipModule):
             wq_b, bq_b, wo_b, bo_b = ops.attn_fold_groupnorm(stats, N, gamma, beta, self.norm.eps, wq, bq, wo, bo)
             q = ops.conv1x1_per_image(x, wq_b, bq_b)
             a = ops.attention_kv512(q, x, N)                                     # keys = values = the raw input
-            return ops.conv1x1_per_image(a.view(B, H, W, C), wo_b, bo_b, residual=x, gn_stats=GN_FUSED)
+            return ops.conv1x1_per_image(a.view(B, H, W, C), wo_b, bo_b, residual=x, gn_stats=GN_FUSED, hilo=is_hilo(x))
         hn = gn_swish(x, self.norm, swish=False)
         if SHARED_KV_ATTENTION:
             q = ops.conv2d(hn, self._packed("q_folded", self._q_folded))
             a = ops.attention_kv512(q, hn, N)                                    # sum_j softmax_j(q'_i . h_j) h_j
-            return ops.conv2d(a.view(B, H, W, C), self._packed("out_folded", self._out_folded), residual=x, gn_stats=GN_FUSED)
+            return ops.conv2d(a.view(B, H, W, C), self._packed("out_folded", self._out_folded), residual=x, gn_stats=GN_FUSED,
+                              hilo=is_hilo(x))
         qk = ops.conv2d(hn, self._packed("qk", self._qk))                       # [B,H,W,1024]: q | k
         npad = (N + 63) // 64 * 64
         if FOLD_PROJ_INTO_V:
@@ -249,7 +261,12 @@ class Encoder(HipModule):
         """x_nchw: fp32 NCHW image (read in place).  Returns (latent fp32 NHWC [B,h,w,zc], enc_feat list)."""
         x = x_nchw.float().contiguous()
         B, C, H, W = x.shape
-        h = ops.conv2d_smallcin(x, (C * H * W, H * W, W, 1), (B, H, W), self.conv_in.weight, self.conv_in.bias)
+        if getattr(self, "hilo_stream", False) and HILO_STREAM and ops.precision() == "fp16":
+            # the residual stream as hi / lo pairs (22 mantissa bits): its rounding at every block output is the largest single
+            # term of the latent error in fp16 (DESIGN.md section 4); everything that READS the stream (convs, attention) reads hi
+            h = ops.conv2d_smallcin(x, (C * H * W, H * W, W, 1), (B, H, W), self.conv_in.weight, self.conv_in.bias, hilo=True)
+        else:
+            h = ops.conv2d_smallcin(x, (C * H * W, H * W, W, 1), (B, H, W), self.conv_in.weight, self.conv_in.bias)
         feats = []
         for i_level in range(self.num_resolutions):
             lvl = self.down[i_level]

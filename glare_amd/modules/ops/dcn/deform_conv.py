@@ -265,13 +265,15 @@ def _offset_conv(conv, x):
             and conv.in_channels % 8 == 0):
         y = ops.conv2d(ops.nchw_to_nhwc(x.float()), ops.PackedConv(conv.weight, conv.bias), out_mode=ops.OUT_NHWC_F32)
         return ops.nhwc_to_nchw(y)
+    if st[0] != st[1] or pd[0] != pd[1] or dl[0] != dl[1]:
+        raise NotImplementedError("conv_offset with different vertical / horizontal stride, padding or dilation")
     B, _, H, W = x.shape
     Ho = (H + 2 * pd[0] - (dl[0] * (k[0] - 1) + 1)) // st[0] + 1
     Wo = (W + 2 * pd[1] - (dl[1] * (k[1] - 1) + 1)) // st[1] + 1
     K = k[0] * k[1]
     zero = torch.zeros(B, 2 * K, Ho, Wo, dtype=torch.float32, device=x.device)
     one = torch.ones(B, K, Ho, Wo, dtype=torch.float32, device=x.device)
-    return modulated_deform_conv(x.float(), zero, one, conv.weight, conv.bias, st, pd, dl, conv.groups, 1)
+    return modulated_deform_conv(x.float(), zero, one, conv.weight, conv.bias, st[0], pd[0], dl[0], conv.groups, 1)
 
 
 class DeformConvPack(DeformConv):  # deform_conv.py:248-286

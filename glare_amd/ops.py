@@ -42,7 +42,8 @@ class ConvDesc(ctypes.Structure):
                 ("Cout", _i), ("out_pitch", _i), ("out_off", _i),
                 ("res_pitch", _i), ("res_off", _i),
                 ("ksize", _i), ("stride", _i), ("upsample", _i), ("act", _i), ("out_mode", _i),
-                ("plane_pitch", _ll), ("gn_partial", ctypes.c_void_p), ("cout_tile", _i)]
+                ("plane_pitch", _ll), ("gn_partial", ctypes.c_void_p), ("cout_tile", _i),
+                ("residual_lo", ctypes.c_void_p), ("out_lo", ctypes.c_void_p)]
 
 
 class PackedConv:
@@ -274,7 +275,7 @@ class auto_cout_tile:
 CONV1X1_WEIGHT_STATIONARY = True   # False: every 1x1 conv through the implicit-GEMM kernel (conv_igemm.hip, KS = 1)
 
 
-def _conv1x1_ws(x, pc, cin, in_off, act, residual, res_off, out, out_off, gn_stats):
+def _conv1x1_ws(x, pc, cin, in_off, act, residual, res_off, out, out_off, gn_stats, hilo=False):
     B, H, W, pitch = x.shape
     N = H * W
     if out is None:
@@ -285,10 +286,16 @@ def _conv1x1_ws(x, pc, cin, in_off, act, residual, res_off, out, out_off, gn_sta
         assert out_off == 0 and out.shape[3] == pc.cout
         lib.glare_conv1x1_ws_gn_partial_elems.restype = _ll
         gn_part = torch.empty(lib.glare_conv1x1_ws_gn_partial_elems(_i(B), _ll(N), _i(pc.cout)), dtype=torch.float32, device=x.device)
-    check(lib.glare_conv1x1_ws_bf16(ptr(x), _i(pitch), _i(in_off), ptr(pc.w16), ptr(pc.bias), ptr(residual),
-                                    _i(residual.shape[3] if residual is not None else 0), _i(res_off), ptr(out), _i(out.shape[3]),
-                                    _i(out_off), _i(B), _ll(N), _i(cin), _i(pc.cout), _i(ACT[act]), ptr(gn_part), stream_handle()),
-          "glare_conv1x1_ws_bf16")
+    if hilo:
+        out_lo = torch.empty_like(out)
+        rlo = getattr(residual, "_lo", None) if residual is not None else None
+        check(lib.glare_conv1x1_ws_hilo_bf16(ptr(x), _i(pitch), _i(in_off), ptr(pc.w16), _ll(0), ptr(pc.bias), _i(0), ptr(residual), ptr(rlo),
+                                             _i(residual.shape[3] if residual is not None else 0), _i(res_off), ptr(out), ptr(out_lo),
+                                             _i(out.shape[3]), _i(out_off), _i(B), _ll(N), _i(cin), _i(pc.cout), _i(ACT[act]), ptr(gn_part),
+                                             stream_handle()), "glare_conv1x1_ws_hilo_bf16")
+        out._lo = out_lo
+    else:
+        _conv1x1_ws_plain(lib, x, pitch, in_off, pc, residual, res_off, out, out_off, B, N, cin, act, gn_part)
     if gn_stats:
         stats = torch.empty(B, 1, 32, 2, dtype=torch.float32, device=x.device)
         check(lib.glare_conv1x1_ws_gn_reduce(ptr(gn_part), ptr(stats), _i(B), _ll(N), _i(pc.cout), stream_handle()),
@@ -297,9 +304,17 @@ def _conv1x1_ws(x, pc, cin, in_off, act, residual, res_off, out, out_off, gn_sta
     return out
 
 
-def conv1x1_per_image(x, w16, bias, residual=None, gn_stats=False):
+def _conv1x1_ws_plain(lib, x, pitch, in_off, pc, residual, res_off, out, out_off, B, N, cin, act, gn_part):
+    check(lib.glare_conv1x1_ws_bf16(ptr(x), _i(pitch), _i(in_off), ptr(pc.w16), ptr(pc.bias), ptr(residual),
+                                    _i(residual.shape[3] if residual is not None else 0), _i(res_off), ptr(out), _i(out.shape[3]),
+                                    _i(out_off), _i(B), _ll(N), _i(cin), _i(pc.cout), _i(ACT[act]), ptr(gn_part), stream_handle()),
+          "glare_conv1x1_ws_bf16")
+
+
+def conv1x1_per_image(x, w16, bias, residual=None, gn_stats=False, hilo=False):
     """1x1 conv with ONE FILTER PER IMAGE (csrc/conv1x1.hip): x bf16 NHWC [B,H,W,Cin], w16 bf16 [B,Cout,Cin], bias fp32 [B,Cout],
-    optional residual bf16 [B,H,W,Cout] -> bf16 NHWC [B,H,W,Cout] (+ the fused GroupNorm statistics of the output)."""
+    optional residual bf16 [B,H,W,Cout] -> bf16 NHWC [B,H,W,Cout] (+ the fused GroupNorm statistics of the output).
+    hilo: as conv2d(hilo=True) -- the result's remainder half rides along as `._lo`, the residual's `._lo` is added."""
     require_cuda(x, w16, bias, residual)
     B, H, W, cin = x.shape
     cout = w16.shape[1]
@@ -315,9 +330,17 @@ def conv1x1_per_image(x, w16, bias, residual=None, gn_stats=False):
         gn_part = torch.empty(lib.glare_conv1x1_ws_gn_partial_elems(_i(B), _ll(N), _i(cout)), dtype=torch.float32, device=x.device)
     if residual is not None:
         assert residual.dtype == act_dtype() and residual.is_contiguous() and residual.shape == out.shape
-    check(lib.glare_conv1x1_ws_image_bf16(ptr(x), _i(cin), _i(0), ptr(w16), _ll(cout * cin), ptr(bias), _i(cout), ptr(residual),
-                                          _i(cout if residual is not None else 0), _i(0), ptr(out), _i(cout), _i(0), _i(B), _ll(N), _i(cin),
-                                          _i(cout), _i(0), ptr(gn_part), stream_handle()), "glare_conv1x1_ws_image_bf16")
+    if hilo:
+        out_lo = torch.empty_like(out)
+        rlo = getattr(residual, "_lo", None) if residual is not None else None
+        check(lib.glare_conv1x1_ws_hilo_bf16(ptr(x), _i(cin), _i(0), ptr(w16), _ll(cout * cin), ptr(bias), _i(cout), ptr(residual), ptr(rlo),
+                                             _i(cout if residual is not None else 0), _i(0), ptr(out), ptr(out_lo), _i(cout), _i(0), _i(B),
+                                             _ll(N), _i(cin), _i(cout), _i(0), ptr(gn_part), stream_handle()), "glare_conv1x1_ws_hilo_bf16")
+        out._lo = out_lo
+    else:
+        check(lib.glare_conv1x1_ws_image_bf16(ptr(x), _i(cin), _i(0), ptr(w16), _ll(cout * cin), ptr(bias), _i(cout), ptr(residual),
+                                              _i(cout if residual is not None else 0), _i(0), ptr(out), _i(cout), _i(0), _i(B), _ll(N),
+                                              _i(cin), _i(cout), _i(0), ptr(gn_part), stream_handle()), "glare_conv1x1_ws_image_bf16")
     if gn_stats:
         stats = torch.empty(B, 1, 32, 2, dtype=torch.float32, device=x.device)
         check(lib.glare_conv1x1_ws_gn_reduce(ptr(gn_part), ptr(stats), _i(B), _ll(N), _i(cout), stream_handle()),
@@ -346,9 +369,11 @@ def attn_fold_groupnorm(stats, HW, gamma, beta, eps, wq, bq, wo, bo):
 
 
 def conv2d(x, pc, *, x2=None, cin=None, in_off=0, cin2=None, in2_off=0, stride=1, upsample=False, act="none",
-           residual=None, res_off=0, out=None, out_off=0, out_mode=OUT_NHWC_BF16, plane_pitch=0, gn_stats=False):
+           residual=None, res_off=0, out=None, out_off=0, out_mode=OUT_NHWC_BF16, plane_pitch=0, gn_stats=False, hilo=False):
     """x: NHWC bf16 [B,H,W,pitch] (channels [in_off, in_off+cin) are used), optional x2 concatenated
-    after it.  Returns (or fills `out`) per out_mode; planar outputs are [B, planes, plane_pitch]."""
+    after it.  Returns (or fills `out`) per out_mode; planar outputs are [B, planes, plane_pitch].
+    hilo: the output keeps 22 mantissa bits as a hi / lo pair -- the returned tensor is `hi` (what every consumer reads), its
+    remainder rides along as `out._lo`; a `residual` carrying `._lo` is added with it (glare_conv_desc.out_lo)."""
     require_cuda(x, x2, residual, out)
     assert x.dtype == act_dtype() and x.dim() == 4 and x.is_contiguous(), (x.dtype, act_dtype())
     assert pc.packed.dtype == x.dtype, "filter packed under another precision"
@@ -357,6 +382,9 @@ def conv2d(x, pc, *, x2=None, cin=None, in_off=0, cin2=None, in2_off=0, stride=1
     if FLOP_COUNTER is not None:
         opix = B * H * W * (4 if upsample else 1) // (stride * stride)
         count_flops("conv k%d" % pc.ksize, 2.0 * opix * pc.ksize ** 2 * pc.cin * pc.cout)
+    if hilo and pc.ksize == 1:
+        assert x2 is None and stride == 1 and not upsample and out is None and cin == pc.cin and getattr(pc, "w16", None) is not None
+        return _conv1x1_ws(x, pc, cin, in_off, act, residual, res_off, None, 0, gn_stats, hilo=True)
     if (CONV1X1_WEIGHT_STATIONARY and getattr(pc, "w16", None) is not None and x2 is None and stride == 1 and not upsample
             and out_mode == OUT_NHWC_BF16 and cin == pc.cin and pitch % 8 == 0 and in_off % 8 == 0
             and (out is None or (out.dtype == act_dtype() and out.shape[3] % 8 == 0 and out_off % 8 == 0))
@@ -404,6 +432,15 @@ def conv2d(x, pc, *, x2=None, cin=None, in_off=0, cin2=None, in2_off=0, stride=1
     if residual is not None:
         assert residual.dtype == act_dtype() and residual.is_contiguous()
         d.residual, d.res_pitch, d.res_off = residual.data_ptr(), residual.shape[3], res_off
+    out_lo = None
+    if hilo:
+        assert out_mode == OUT_NHWC_BF16 and out_off == 0 and out.shape[3] == pc.cout
+        out_lo = torch.empty_like(out)
+        d.out_lo = out_lo.data_ptr()
+        rlo = getattr(residual, "_lo", None) if residual is not None else None
+        if rlo is not None:
+            assert rlo.shape == residual.shape and rlo.dtype == residual.dtype and rlo.is_contiguous()
+            d.residual_lo = rlo.data_ptr()
     subpixel = getattr(pc, "subpixel", False)
     assert not subpixel or upsample, "a sub-pixel packed filter only implements the upsample conv"
     d.ksize, d.stride, d.upsample, d.act, d.out_mode = pc.ksize, stride, (2 if subpixel else int(bool(upsample))), ACT[act], out_mode
@@ -436,6 +473,8 @@ def conv2d(x, pc, *, x2=None, cin=None, in_off=0, cin2=None, in2_off=0, stride=1
             check(lib.glare_conv2d_gn_reduce(ptr(gn_part), ptr(stats), _i(B), _i(OH), _i(OW), _i(pc.cout), stream_handle()),
                   "glare_conv2d_gn_reduce")
         out._gn_stats = stats  # consumed by groupnorm(); plain Python attribute, not a tensor property
+    if out_lo is not None:
+        out._lo = out_lo
     return out
 
 
@@ -448,14 +487,24 @@ def _workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
-def conv2d_smallcin(x, strides, shape_bhw, weight, bias=None, act="none", out=None, out_off=0, out_f32=False):
+def conv2d_smallcin(x, strides, shape_bhw, weight, bias=None, act="none", out=None, out_off=0, out_f32=False, hilo=False):
     """Direct conv for Cin <= 4.  x: fp32 device tensor read through explicit element strides
-    (sb, sc, sy, sx); shape_bhw = (B, H, W).  Returns NHWC [B,H,W,Cout] bf16 (or fp32)."""
+    (sb, sc, sy, sx); shape_bhw = (B, H, W).  Returns NHWC [B,H,W,Cout] bf16 (or fp32); hilo: a hi / lo pair (`._lo`)."""
     require_cuda(x, weight, bias, out)
     B, H, W = shape_bhw
     w = weight.detach().float().contiguous()
     cout, cin, k, _ = w.shape
     b = None if bias is None else bias.detach().float().contiguous()
+    if hilo:
+        assert out is None and not out_f32
+        hi = torch.empty(B, H, W, cout, dtype=act_dtype(), device=x.device)
+        lo = torch.empty_like(hi)
+        sb, sc, sy, sx = strides
+        check(_lib.lib().glare_conv2d_smallcin_hilo_f32(ptr(x), _ll(sb), _ll(sc), _ll(sy), _ll(sx), ptr(w), ptr(b), ptr(hi), ptr(lo),
+                                                        _i(B), _i(H), _i(W), _i(cin), _i(cout), _i(k), _i(cout), _i(0), _i(ACT[act]),
+                                                        stream_handle()), "glare_conv2d_smallcin_hilo_f32")
+        hi._lo = lo
+        return hi
     if out is None:
         out = torch.empty(B, H, W, cout, dtype=torch.float32 if out_f32 else act_dtype(), device=x.device)
     sb, sc, sy, sx = strides
@@ -475,6 +524,19 @@ def groupnorm(x, gamma, beta, swish=True, eps=1e-6, cin=None, in_off=0):
     C = pitch - in_off if cin is None else cin
     lib = _lib.lib()
     stats = getattr(x, "_gn_stats", None)
+    xlo = getattr(x, "_lo", None)
+    if xlo is not None:      # a hi / lo pair (the conditional encoder's residual stream in fp16): normalise the 22-bit value
+        assert in_off == 0 and C == pitch and xlo.shape == x.shape and xlo.is_contiguous()
+        y = torch.empty(B, H, W, C, dtype=act_dtype(), device=x.device)
+        ws, nws = None, 0
+        if stats is None:
+            lib.glare_groupnorm_workspace_bytes.restype = _sz
+            nws = lib.glare_groupnorm_workspace_bytes(_i(B), _ll(H * W))
+            ws = _workspace(nws, x.device)
+        check(lib.glare_groupnorm_hilo_bf16(ptr(x), ptr(xlo), _i(pitch), _i(0), ptr(gamma), ptr(beta), ptr(y), _i(B), _ll(H * W), _i(C),
+                                            _f(eps), _i(int(swish)), ptr(stats), _i(int(stats.shape[1]) if stats is not None else 0),
+                                            ptr(ws), _sz(nws), stream_handle()), "glare_groupnorm_hilo_bf16")
+        return y
     if stats is not None and in_off == 0 and C == pitch:
         y = torch.empty(B, H, W, C, dtype=act_dtype(), device=x.device)
         check(lib.glare_groupnorm_apply_bf16(ptr(x), _i(pitch), _i(0), ptr(gamma), ptr(beta), ptr(y), _i(B), _ll(H * W), _i(C),
@@ -489,6 +551,17 @@ def groupnorm(x, gamma, beta, swish=True, eps=1e-6, cin=None, in_off=0):
                                          _i(C), _f(eps), _i(int(swish)), ptr(ws), _sz(ws.numel()), stream_handle()),
           "glare_groupnorm_swish_bf16")
     return y
+
+
+def split_hilo(x32):
+    """fp32 [..., C] (numel % 8 == 0) -> the 16-bit tensor hi = round16(x) with its remainder lo = round16(x - hi) as `hi._lo`."""
+    require_cuda(x32)
+    assert x32.dtype == torch.float32 and x32.is_contiguous() and x32.numel() % 8 == 0
+    hi = torch.empty(x32.shape, dtype=act_dtype(), device=x32.device)
+    lo = torch.empty_like(hi)
+    check(_lib.lib().glare_split_hilo_f32(ptr(x32), _ll(x32.numel()), ptr(hi), ptr(lo), stream_handle()), "glare_split_hilo_f32")
+    hi._lo = lo
+    return hi
 
 
 def mix(a, b, w, out=None, out_off=0, a_off=0, b_off=0, C=None):

@@ -104,6 +104,14 @@ typedef struct glare_conv_desc {
                              /* the tile the weights were packed for (glare_conv2d_pack_weight_batched's cout_tile):     */
                              /* small launches (training crops, batch 1) fill the chip better with 64- / 32-wide tiles,  */
                              /* glare_conv2d_cout_tile() picks                                                            */
+  /* ---- hi / lo output (round 3; zero-initialise the struct if unused) -----------------------------------------------------
+   * The residual stream of the conditional encoder kept to 22 mantissa bits in two 16-bit tensors: value = hi + lo, `hi` the
+   * ordinary activation tensor every consumer reads (convs, attention), `lo` the rounding remainder that only residual adds and
+   * GroupNorm read back.  out_lo != NULL (GLARE_OUT_NHWC_BF16, 3x3, Cout tile 128, stride 1 or 2): `out` receives
+   * hi = round16(v), out_lo (same pitch / offset) lo = round16(v - hi) of v = acc + bias (+ residual + residual_lo) after `act`,
+   * without the intermediate 16-bit rounding of acc + bias the plain epilogue has; the fused GroupNorm statistics are those of v. */
+  const void* residual_lo;   /* optional lo half of `residual` (same pitch / offset), or NULL      */
+  void* out_lo;              /* optional: see above                                                */
 } glare_conv_desc;
 
 /* The output-channel tile (128, 64 or 32) that gives a B x OH x OW x cout conv enough workgroups (8 x 32 output pixels each). */
@@ -170,6 +178,10 @@ int glare_conv2d_smallcin_f32(const float* x, long long stride_b, long long stri
                               long long stride_x, const float* w_oihw, const float* bias, void* out, int B, int H,
                               int W, int Cin, int Cout, int ksize, int out_pitch, int out_off, int act,
                               int out_is_f32, glare_stream_t stream);
+/* ... with the output as a hi / lo pair (16-bit NHWC; Cout, out_pitch, out_off multiples of 8; see glare_conv_desc.out_lo). */
+int glare_conv2d_smallcin_hilo_f32(const float* x, long long stride_b, long long stride_c, long long stride_y, long long stride_x,
+                                   const float* w_oihw, const float* bias, void* out_hi, void* out_lo, int B, int H, int W, int Cin,
+                                   int Cout, int ksize, int out_pitch, int out_off, int act, glare_stream_t stream);
 
 /* ---- GroupNorm(32, C, eps) [+ swish] --------------------------------------------------------
  * Replaces Normalize() + nonlinearity() (encoder_decoder.py:29-35,119-120,126-127,170,436-437).
@@ -186,6 +198,14 @@ int glare_add_groupnorm_stats_bf16(const void* a, const void* b, void* out, int 
 int glare_groupnorm_apply_bf16(const void* x, int in_pitch, int in_off, const float* gamma, const float* beta, void* y,
                                int B, long long HW, int C, float eps, int swish, const float* stats, int splits,
                                glare_stream_t stream);
+/* GroupNorm of a hi / lo pair (value = x_hi + x_lo, same pitch / offset; see glare_conv_desc.out_lo): statistics and normalisation
+ * from the 22-bit value, one rounding on the way out.  stats != NULL ([B][splits][32][2], from the producer's epilogue): apply only;
+ * stats == NULL: the statistics pass runs first (workspace as glare_groupnorm_swish_bf16).
+ * glare_split_hilo_f32: fp32 [n] (n % 8 == 0) -> hi = round16(v), lo = round16(v - hi): how conv_in's output opens the stream. */
+int glare_groupnorm_hilo_bf16(const void* x_hi, const void* x_lo, int in_pitch, int in_off, const float* gamma, const float* beta,
+                              void* y, int B, long long HW, int C, float eps, int swish, const float* stats, int splits,
+                              void* workspace, size_t workspace_bytes, glare_stream_t stream);
+int glare_split_hilo_f32(const float* src, long long n, void* hi_bf16, void* lo_bf16, glare_stream_t stream);
 int glare_groupnorm_swish_bf16(const void* x, int in_pitch, int in_off, const float* gamma, const float* beta,
                                void* y, int B, long long HW, int C, float eps, int swish, void* workspace,
                                size_t workspace_bytes, glare_stream_t stream);
@@ -263,6 +283,13 @@ int glare_conv1x1_ws_image_bf16(const void* x, int x_pitch, int x_off, const voi
                                 int bias_image_stride, const void* residual, int res_pitch, int res_off, void* out, int out_pitch,
                                 int out_off, int B, long long pixels_per_image, int Cin, int Cout, int act, float* gn_partial,
                                 glare_stream_t stream);
+/* hi / lo form of the two entry points above (w_image_stride = 0: one filter for all images; see glare_conv_desc.out_lo): `out`
+ * receives hi = round16(v), `out_lo` lo = round16(v - hi) of v = acc + bias + residual + residual_lo (residual_lo optional),
+ * nothing rounded before the residual add; the fused GroupNorm statistics are those of v. */
+int glare_conv1x1_ws_hilo_bf16(const void* x, int x_pitch, int x_off, const void* w_bf16, long long w_image_stride,
+                               const float* bias, int bias_image_stride, const void* residual, const void* residual_lo,
+                               int res_pitch, int res_off, void* out, void* out_lo, int out_pitch, int out_off, int B,
+                               long long pixels_per_image, int Cin, int Cout, int act, float* gn_partial, glare_stream_t stream);
 int glare_attn_fold_groupnorm_f32(const float* stats, int splits, int B, long long HW, int C, const float* gamma, const float* beta,
                                   float eps, const float* wq, const float* bq, const float* wo, const float* bo, void* wq_out,
                                   float* bq_out, void* wo_out, float* bo_out, glare_stream_t stream);

@@ -151,3 +151,24 @@ def test_msssim_bit_identical_to_reference():
     vr.backward()
     vo.backward()
     assert torch.equal(ar.grad, ao.grad)
+
+
+def test_representative_regime_recipe_on_the_reference_itself():
+    """synthetic.representative_init_ (the trained-like weight regime of the end-to-end parity table) uses nothing but the modules'
+    own forward passes -- so it runs on the REFERENCE's modules unchanged, and must leave them in exactly the state it leaves the
+    oracle in (codebook from the reference's VQ encoder, ActNorms from the reference's own data-dependent initialisation)."""
+    from glare_amd.synthetic import representative_init_
+
+    torch.manual_seed(0)
+    np.random.seed(0)
+    netG, opt = R.build_netG()
+    net_vq, _ = R.build_vqgan(opt)
+    oG, oV = O.VQLLFLOWDeformable().eval(), O.VQModel().eval()
+    with R.cpu_only():
+        representative_init_(netG.eval(), net_vq.eval(), 3, batch=4, size=192)   # 4 x 48 x 48 = 9216 tokens >= the 8192 codes
+    representative_init_(oG, oV, 3, batch=4, size=192)
+    a, b = netG.state_dict(), oG.state_dict()
+    assert all(torch.equal(a[k], b[k]) for k in b), [k for k in b if not torch.equal(a[k], b[k])][:4]
+    av, bv = net_vq.state_dict(), oV.state_dict()
+    assert all(torch.equal(av[k], bv[k]) for k in bv)
+    assert all((m.bias != 0).any() for m in oG.flowUpsamplerNet.modules() if isinstance(m, O.ActNorm2d))
