@@ -1,0 +1,544 @@
+// Shared by the translation units of the implicit-GEMM convolution (conv_igemm.hip: C ABI, packing, dispatch;
+// conv_igemm_k3s1.hip / _k3s2.hip / _k1k2.hip: the kernel instantiations, split so that they compile in parallel -- one file
+// with all of them was 4.5 minutes of the build's critical path).  The kernel itself is documented at the top of conv_igemm.hip.
+#pragma once
+#include <type_traits>
+
+#include "common.h"
+
+#ifndef CONV_DMA_SPREAD
+#define CONV_DMA_SPREAD 1
+#endif
+#ifndef CONV_TILE16
+#define CONV_TILE16 0
+#endif
+
+
+struct ConvParams {
+  const a16_t* in0;
+  const a16_t* in1;
+  const a16_t* wpk;
+  const float* bias;
+  const a16_t* res;
+  void* out;
+  int B, H, W;        // source spatial size (before upsample)
+  int IHs, IWs;       // conv input size (after upsample)
+  int OH, OW;
+  int Cin0, Cin1, CinTot;
+  int p0, o0, p1, o1; // pitch / channel offset of the two sources
+  int Cout, opitch, ooff, rpitch, roff;
+  int upsample, act, out_mode;
+  long long plane_pitch;
+  int tiles_x, tiles_y, co_tiles, n_blocks, n_stages;
+  int fast_epilogue;
+  unsigned in0_bytes, in1_bytes;   // bytes of ONE image of each source (range of the halo DMA's buffer descriptors)
+  float* gn_part;   // optional GroupNorm partial sums of the OUTPUT: [b][part][Cout/4][2], part = tile*WM + wm
+  int gn_nparts;
+  const a16_t* res_lo;   // hi / lo epilogue (HILO instantiations): remainder halves of the residual and of the output
+  a16_t* out_lo;
+};
+
+// kernel-family dispatchers, one per translation unit: tn = the output-channel tile (128 / 64 / 32); hilo = the hi / lo epilogue
+int glare_conv_launch_k3s1(const ConvParams& p, int tn, bool hilo, hipStream_t stream);
+int glare_conv_launch_k3s2(const ConvParams& p, int tn, bool hilo, hipStream_t stream);
+int glare_conv_launch_k1(const ConvParams& p, int tn, hipStream_t stream);
+int glare_conv_launch_k2(const ConvParams& p, int tn, hipStream_t stream);   // sub-pixel upsample form
+
+namespace {
+
+constexpr int TW = 32;   // output tile cols == MFMA M
+
+
+
+template <int KS, int STRIDE, int TH>
+struct TileGeom {
+  static constexpr int IH = (TH - 1) * STRIDE + KS;
+  static constexpr int IW = (TW - 1) * STRIDE + KS;
+  static constexpr int NPOS = IH * IW;
+  static constexpr int PAD = (KS == 3 && STRIDE == 1) ? 1 : 0;  // stride 2: pad (0,1,0,1) only
+};
+
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+// The activation is a COMPILE-TIME constant inside the epilogues (dispatched once per workgroup, `with_act` below): as a runtime
+// switch per output element it compiled to ~3 scalar branches per element -- 128 elements per thread, several thousand cycles per
+// tile, a quarter of a 128-channel tile's whole MFMA time (found in round 2 with a plain instruction histogram of the ISA).
+template <int ACT>
+__device__ __forceinline__ float apply_act(float v) {
+  if constexpr (ACT == GLARE_ACT_RELU) return fmaxf(v, 0.f);
+  else if constexpr (ACT == GLARE_ACT_SIGMOID) return sigmoidf_(v);
+  else if constexpr (ACT == GLARE_ACT_SWISH) return swishf_(v);
+  else return v;
+}
+template <typename F>
+__device__ __forceinline__ void with_act(int act, F&& f) {
+  switch (act) {
+    case GLARE_ACT_RELU: f(std::integral_constant<int, GLARE_ACT_RELU>{}); break;
+    case GLARE_ACT_SIGMOID: f(std::integral_constant<int, GLARE_ACT_SIGMOID>{}); break;
+    case GLARE_ACT_SWISH: f(std::integral_constant<int, GLARE_ACT_SWISH>{}); break;
+    default: f(std::integral_constant<int, GLARE_ACT_NONE>{}); break;
+  }
+}
+
+
+// KS kernel size, STRIDE, MT/NT 32x32 MFMA tiles per wave along pixel rows / couts,
+// WM x WN waves (WM*MT == 8 rows), KSTEPS 16-channel k-steps per input stage.
+//
+// Pipeline: an "A stage" is KC = 16*KSTEPS channels of the halo tile; it is consumed in KS
+// "B stages" (one tap row each: KS taps x KSTEPS k-steps of weights).  Both images are
+// double-buffered in LDS and filled by LDS-DMA (global_load_lds_dwordx4), issued one B stage
+// ahead, right after the barrier that retires the buffer they overwrite; one barrier per B stage.
+template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int KSTEPS, bool HILO = false>
+__global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 2)) void conv_igemm_kernel(const ConvParams p) {
+  constexpr int TH = WM * MT;       // output tile rows
+  constexpr int NW = WM * WN;       // waves per workgroup (4, or 6 for the 12 x 32 x 128 tile)
+  using G = TileGeom<KS, STRIDE, TH>;
+  static_assert(NW == 4 || NW == 6 || NW == 8, "wave layout");
+  constexpr int TN = WN * NT * 32;
+  constexpr int A_CHUNKS = KSTEPS * 2 * G::NPOS;           // 16-B chunks of one A stage
+  constexpr int A_INSTR = (A_CHUNKS + 63) / 64;            // wave-level DMA instructions per A stage
+  constexpr int A_SLOTS = A_INSTR * 64;
+  constexpr int A_PER_W = (A_INSTR + NW - 1) / NW;
+  constexpr int B_CHUNKS = KS * KSTEPS * 2 * TN;           // 16-B chunks of one B stage (one tap row)
+  static_assert(B_CHUNKS % 64 == 0, "B stage is a whole number of wave DMAs");
+  constexpr int B_INSTR = B_CHUNKS / 64;
+  constexpr int B_PER_W = (B_INSTR + NW - 1) / NW;
+  constexpr int KC = 16 * KSTEPS;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  u32x4* lA = reinterpret_cast<u32x4*>(smem);              // [2][A_SLOTS]
+  u32x4* lB = lA + 2 * A_SLOTS;                            // [2][B_CHUNKS]
+
+  // XCD-aware order: consecutive logical tiles (same pixels, different couts; then neighbouring
+  // pixels) run on one XCD and share its L2 (dispatch is round-robin over the 8 XCDs).
+  int bid = blockIdx.x;
+  {
+    const int n = p.n_blocks, q = n / 8, r = n % 8, xcd = bid % 8, k = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int ct = bid % p.co_tiles;
+  int t = bid / p.co_tiles;
+  int phase = 0;
+  if (KS == 2) { phase = t & 3; t >>= 2; }
+  const int pa = phase >> 1, pb = phase & 1;   // output row / column parity of this sub-pixel phase
+  const int tx = t % p.tiles_x;
+  t /= p.tiles_x;
+  const int ty = t % p.tiles_y;
+  const int b = t / p.tiles_y;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int iy0 = oy0 * STRIDE - G::PAD - (KS == 2 ? 1 - pa : 0), ix0 = ox0 * STRIDE - G::PAD - (KS == 2 ? 1 - pb : 0);
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // per-lane invariant part of the A addressing: this wave issues DMA instructions j = wave + NW*i; lane handles chunk
+  // c = j*64 + lane = (kstep*2 + khalf)*NPOS + pos.  The halo goes through buffer descriptors based at THIS IMAGE (32-bit byte
+  // offsets: one image of one source stays below 2 GB): a loop-invariant offset per lane and piece (pixel, 8-channel half)
+  // plus the stage's channel offset as the scalar offset; padded positions, slots beyond the tile and channels beyond Cin
+  // carry an offset beyond the descriptor's range, which the hardware turns into zeros -- no 64-bit address arithmetic, no
+  // divergent branches and no zero source in the issue sequence.
+  constexpr unsigned A_OOB = 0x80000000u;
+  unsigned a_vo0[A_PER_W], a_vo1[A_PER_W];
+  int a_ck[A_PER_W];         // channel offset inside the stage: kstep*16 + khalf*8
+#pragma unroll
+  for (int i = 0; i < A_PER_W; ++i) {
+    const int c = (wave + NW * i) * 64 + lane;
+    a_vo0[i] = a_vo1[i] = A_OOB;
+    a_ck[i] = 0;
+    if (c < A_CHUNKS) {
+      const int pos = c % G::NPOS, kk = c / G::NPOS;
+      a_ck[i] = kk * 8;
+      const int iy = iy0 + pos / G::IW, ix = ix0 + pos % G::IW;
+      if (iy >= 0 && iy < p.IHs && ix >= 0 && ix < p.IWs) {
+        const int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
+        const unsigned pix = (unsigned)(sy * p.W + sx);
+        a_vo0[i] = (pix * (unsigned)p.p0 + (unsigned)(p.o0 + kk * 8)) * 2u;
+        a_vo1[i] = (pix * (unsigned)p.p1 + (unsigned)(p.o1 + kk * 8)) * 2u;
+      }
+    }
+  }
+  const size_t img = (size_t)b * p.H * p.W;
+  const __amdgpu_buffer_rsrc_t arsrc0 =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<a16_t*>(p.in0 + img * p.p0), 0, (int)p.in0_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t arsrc1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<a16_t*>(p.in1 ? p.in1 + img * p.p1 : p.in0), 0, (int)(p.in1 ? p.in1_bytes : p.in0_bytes), 0x00020000);
+  const a16_t* wbase = p.wpk + ((size_t)phase * p.co_tiles + ct) * p.n_stages * (size_t)(KS * B_CHUNKS) * 8;
+
+  auto issue_a = [&](int chunk, int buf, int i_lo = 0, int i_hi = 1 << 20) {   // pieces [i_lo, i_hi) of this wave
+    const int c0 = chunk * KC;
+    const bool src0 = c0 < p.Cin0;                       // uniform: a stage never straddles the two concatenated sources
+    const int cbase = src0 ? c0 : c0 - p.Cin0, climit = src0 ? p.Cin0 : p.Cin1;
+#pragma unroll
+    for (int i = 0; i < A_PER_W; ++i) {
+      const int j = wave + NW * i;
+      if (i >= i_lo && i < i_hi && j < A_INSTR) {
+        unsigned vo = src0 ? a_vo0[i] : a_vo1[i];
+        if (cbase + a_ck[i] >= climit) vo = A_OOB;       // channels beyond Cin (last stage only): v_cndmask, not a branch
+        if (src0)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc0, (__attribute__((address_space(3))) void*)(lA + buf * A_SLOTS + j * 64), 16, vo,
+                                                   cbase * 2, 0, 0);
+        else
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc1, (__attribute__((address_space(3))) void*)(lA + buf * A_SLOTS + j * 64), 16, vo,
+                                                   cbase * 2, 0, 0);
+      }
+    }
+  };
+  // Weight stages go through a buffer descriptor: `buffer_load_dwordx4 ... offen lds` takes ONE per-lane
+  // 32-bit offset (lane*16, loop-invariant) plus a scalar offset -- no per-instruction 64-bit VALU address.
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<a16_t*>(wbase), 0, (int)((size_t)p.n_stages * KS * B_CHUNKS * 16), 0x00020000);
+  const int lane16 = lane * 16;
+  auto issue_b = [&](int bstage, int buf, int i_lo = 0, int i_hi = 1 << 20) {
+#pragma unroll
+    for (int i = 0; i < B_PER_W; ++i) {
+      const int j = wave + NW * i;
+      if (i >= i_lo && i < i_hi && j < B_INSTR)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(lB + buf * B_CHUNKS + j * 64),
+                                                 16, lane16, (bstage * B_CHUNKS + j * 64) * 16, 0, 0);
+    }
+  };
+
+  const int khalf = lane >> 5, px = lane & 31;
+  const int n_bstages = p.n_stages * KS;
+  issue_a(0, 0);
+  issue_b(0, 0);
+  int bs = 0;
+  for (int chunk = 0; chunk < p.n_stages; ++chunk) {
+    const u32x4* cA = lA + (chunk & 1) * A_SLOTS;
+#pragma unroll
+    for (int trow = 0; trow < KS; ++trow, ++bs) {
+#ifndef CONV_ABLATE_NOBARRIER  // timing ablations only (tools/ablate.sh): wrong results
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
+      __syncthreads();                                   // ... and everybody else's; stage bs-1 retired
+#endif
+      // The next stage's DMA pieces are not issued in one burst behind the barrier (12 waves would queue 47 pieces on the
+      // CU's address path with the matrix pipe waiting): they are spread over the stage's KS*KSTEPS MFMA groups.
+      constexpr int NGRP = KS * KSTEPS;
+      [[maybe_unused]] constexpr int B_PG = (B_PER_W + NGRP - 1) / NGRP, A_PG = (A_PER_W + NGRP - 1) / NGRP;
+      const bool more_b = bs + 1 < n_bstages, more_a = trow == 0 && chunk + 1 < p.n_stages;
+#if !CONV_DMA_SPREAD
+#ifndef CONV_ABLATE_NODMA
+#ifndef CONV_ABLATE_NODMA_B
+      if (more_b) issue_b(bs + 1, (bs + 1) & 1);
+#endif
+#ifndef CONV_ABLATE_NODMA_A
+      if (more_a) issue_a(chunk + 1, (chunk + 1) & 1);
+#endif
+#endif
+#endif
+      const u32x4* cB = lB + (bs & 1) * B_CHUNKS;
+#ifdef CONV_SETPRIO
+      __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+      for (int tcol = 0; tcol < KS; ++tcol) {
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+#if CONV_DMA_SPREAD
+#ifndef CONV_ABLATE_NODMA
+          {
+            const int grp = tcol * KSTEPS + ks;
+#ifndef CONV_ABLATE_NODMA_B
+            if (more_b) issue_b(bs + 1, (bs + 1) & 1, grp * B_PG, (grp + 1) * B_PG);
+#endif
+#ifndef CONV_ABLATE_NODMA_A
+            if (more_a) issue_a(chunk + 1, (chunk + 1) & 1, grp * A_PG, (grp + 1) * A_PG);
+#endif
+          }
+#endif
+#endif
+          a16x8 bf[NT], af[MT];
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const int co = (wn * NT + j) * 32 + px;
+            bf[j] = __builtin_bit_cast(a16x8, cB[((tcol * KSTEPS + ks) * 2 + khalf) * TN + co]);
+          }
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            const int row = wm * MT + i;
+            const int pos = (row * STRIDE + trow) * G::IW + px * STRIDE + tcol;
+            af[i] = __builtin_bit_cast(a16x8, cA[(ks * 2 + khalf) * G::NPOS + pos]);
+          }
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[i][j] = mfma_a16_32x32x16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+      }
+#ifdef CONV_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
+    }
+  }
+
+  // ---- hi / lo epilogue: the output keeps 22 mantissa bits as two 16-bit tensors (the residual stream of the conditional
+  // encoder in the fp16 precision).  The accumulators go through a wave-private fp32 slab, one tile row
+  // (32 pixels x NT*32 couts) at a time; v = acc + bias + residual_hi + residual_lo in fp32, then hi = round16(v) and
+  // lo = round16(v - hi) leave as two 16-B stores per lane.  Unlike the plain epilogue nothing is rounded before the residual add.
+  if constexpr (HILO) {
+    constexpr int ROWF = NT * 128 + 16;                  // slab row pitch in bytes (pad: bank spread between rows)
+    constexpr int CPR = NT * 4;                          // 8-channel chunks per slab row
+    static_assert(NW * 32 * ROWF <= (2 * A_SLOTS + 2 * B_CHUNKS) * 16, "hi/lo epilogue slab fits the pipeline LDS");
+    static_assert(KS != 2, "the sub-pixel form has no hi/lo epilogue");
+    __syncthreads();  // every wave is done reading the pipeline buffers
+    char* slab = smem + wave * (32 * ROWF);
+    const int ncol = lane & 31, rhalf = lane >> 5;
+    float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
+    with_act(p.act, [&](auto actc) {
+    constexpr int ACT = decltype(actc)::value;
+    static_for<MT>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      static_for<NT>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const int co = ct * TN + (wn * NT + j) * 32 + ncol;
+        const float bv = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = (r & 3) + 8 * (r >> 2) + 4 * rhalf;           // pixel x within the tile row
+          *reinterpret_cast<float*>(slab + m * ROWF + (j * 32 + ncol) * 4) = acc[i][j][r] + bv;
+        }
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < 32 * CPR / 64; ++it) {
+        const int idx = lane + 64 * it;
+        const int row = idx / CPR, ch = idx % CPR;
+        const int oy = oy0 + wm * MT + i, ox = ox0 + row;
+        const int co = ct * TN + wn * NT * 32 + ch * 8;
+        if (oy < p.OH && ox < p.OW && co < p.Cout) {
+          const f32x4 f0 = *reinterpret_cast<const f32x4*>(slab + row * ROWF + ch * 32);
+          const f32x4 f1 = *reinterpret_cast<const f32x4*>(slab + row * ROWF + ch * 32 + 16);
+          float v[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+          const size_t pix = ((size_t)b * p.OH + oy) * p.OW + ox;
+          if (p.res) {
+            const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + pix * p.rpitch + p.roff + co);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] += alo(rv[e]); v[2 * e + 1] += ahi(rv[e]); }
+            if (p.res_lo) {
+              const u32x4 rl = *reinterpret_cast<const u32x4*>(p.res_lo + pix * p.rpitch + p.roff + co);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { v[2 * e] += alo(rl[e]); v[2 * e + 1] += ahi(rl[e]); }
+            }
+          }
+          u32x4 hi, lo;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float a = apply_act<ACT>(v[2 * e]), c = apply_act<ACT>(v[2 * e + 1]);
+            hi[e] = pack_a2(a, c);
+            lo[e] = pack_a2(a - alo(hi[e]), c - ahi(hi[e]));
+            if (e < 2) { gs0 += a + c; gq0 += a * a + c * c; } else { gs1 += a + c; gq1 += a * a + c * c; }
+          }
+          *reinterpret_cast<u32x4*>(reinterpret_cast<a16_t*>(p.out) + pix * p.opitch + p.ooff + co) = hi;
+          *reinterpret_cast<u32x4*>(p.out_lo + pix * p.opitch + p.ooff + co) = lo;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    });
+    });
+    if (p.gn_part) {  // lanes with the same channel chunk are CPR apart: fold them, one lane per chunk writes
+#pragma unroll
+      for (int o = CPR; o < 64; o <<= 1) {
+        gs0 += __shfl_xor(gs0, o, 64); gq0 += __shfl_xor(gq0, o, 64);
+        gs1 += __shfl_xor(gs1, o, 64); gq1 += __shfl_xor(gq1, o, 64);
+      }
+      const int co = ct * TN + wn * NT * 32 + lane * 8;
+      if (lane < CPR && co < p.Cout) {
+        const int row0 = oy0 + wm * MT;
+        const int part = ((phase * ((p.OH + 7) / 8) + row0 / 8) * p.tiles_x + tx) * 2 + ((row0 / 4) & 1);
+        if (part < p.gn_nparts) {
+          float* dst = p.gn_part + (((size_t)b * p.gn_nparts + part) * (p.Cout / 4) + co / 4) * 2;
+          dst[0] = gs0; dst[1] = gq0; dst[2] = gs1; dst[3] = gq1;
+        }
+      }
+    }
+    return;
+  }
+
+  // ---- fast epilogue (bf16 NHWC output, 16-B aligned records): the accumulators go through LDS so
+  // that the residual read and the output write are 16 B per lane, 128 contiguous bytes per pixel
+  // (the direct C/D layout would store 2 B per lane).  Each wave stages its own 64-row slab (wave-
+  // private region: no workgroup barrier inside), two slabs of MT/2 tile rows per wave.
+  //   phase 1: acc + bias (+act when there is no residual) -> bf16; neighbouring lanes (co n, n+1) swap one
+  //            value so every lane writes one packed 4-B word: even lanes row m(2t), odd lanes row m(2t+1)
+  //   phase 2: 16-B LDS reads, + residual (16-B global load, fp32 add), act, 16-B global store
+  if (p.out_mode == GLARE_OUT_NHWC_BF16 && p.fast_epilogue) {
+    constexpr int HT = (NW == 8 || MT < 2) ? 1 : MT / 2;  // tile rows per slab (smaller slabs when 8 waves share the LDS)
+    constexpr int HROWS = HT * 32;                       // slab rows
+    constexpr int ROWB = NT * 64 + 16;                   // slab row pitch in bytes (pad: bank spread)
+    constexpr int CPR = NT * 4;                          // 16-B chunks per slab row
+    static_assert(NW * HROWS * ROWB <= (2 * A_SLOTS + 2 * B_CHUNKS) * 16, "epilogue slab fits the pipeline LDS");
+    __syncthreads();  // every wave is done reading the pipeline buffers
+    char* slab = smem + wave * (HROWS * ROWB);
+    const int ncol = lane & 31, rhalf = lane >> 5, odd = lane & 1;
+    const bool act_early = p.res == nullptr;
+    // fused GroupNorm statistics of the tensor being written (the consumer's gn_stats pass would re-read it):
+    // per lane the sum / sum of squares of its two 4-channel units over its pixels, from the ROUNDED values
+    float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
+    with_act(p.act, [&](auto actc) {
+    constexpr int ACT = decltype(actc)::value;
+    static_for<MT / HT>([&](auto hc) {
+      constexpr int half = decltype(hc)::value;
+      static_for<NT>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const int co = ct * TN + (wn * NT + j) * 32 + ncol;
+        const float bv = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+        static_for<HT>([&](auto ic) {
+          constexpr int il = decltype(ic)::value;
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            constexpr int i = half * HT + il;
+            float a = acc[i][j][2 * t] + bv, c = acc[i][j][2 * t + 1] + bv;
+            if (act_early) { a = apply_act<ACT>(a); c = apply_act<ACT>(c); }
+            const float send = odd ? a : c;
+            const float recv = __shfl_xor(send, 1, 64);
+            const int r = 2 * t + odd;                                  // the register (row) this lane writes
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * rhalf;            // pixel x within the tile row
+            const uint32_t w = odd ? pack_a2(recv, c) : pack_a2(a, recv);
+            *reinterpret_cast<uint32_t*>(slab + (il * 32 + m) * ROWB + (j * 32 + (ncol & ~1)) * 2) = w;
+          }
+        });
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < HROWS * CPR / 64; ++it) {
+        const int idx = lane + 64 * it;
+        const int row = idx / CPR, ch = idx % CPR;
+        const int oy = oy0 + wm * MT + half * HT + row / 32, ox = ox0 + (row & 31);
+        const int co = ct * TN + wn * NT * 32 + ch * 8;
+        if (oy < p.OH && ox < p.OW && co < p.Cout) {
+          u32x4 v = *reinterpret_cast<const u32x4*>(slab + row * ROWB + ch * 16);
+          const size_t pix = KS == 2 ? ((size_t)b * (2 * p.OH) + 2 * oy + pa) * (size_t)(2 * p.OW) + 2 * ox + pb
+                                     : ((size_t)b * p.OH + oy) * p.OW + ox;
+          if (p.res) {
+            const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + pix * p.rpitch + p.roff + co);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              v[e] = pack_a2(apply_act<ACT>(alo(v[e]) + alo(rv[e])), apply_act<ACT>(ahi(v[e]) + ahi(rv[e])));
+          }
+          *reinterpret_cast<u32x4*>(reinterpret_cast<a16_t*>(p.out) + pix * p.opitch + p.ooff + co) = v;
+          if (p.gn_part) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const float x0 = alo(v[e]), x1 = ahi(v[e]), y0 = alo(v[2 + e]), y1 = ahi(v[2 + e]);
+              gs0 += x0 + x1; gq0 += x0 * x0 + x1 * x1;
+              gs1 += y0 + y1; gq1 += y0 * y0 + y1 * y1;
+            }
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    });
+    });
+    if (p.gn_part) {  // lanes with the same channel chunk are CPR apart: fold them, one lane per chunk writes
+#pragma unroll
+      for (int o = CPR; o < 64; o <<= 1) {
+        gs0 += __shfl_xor(gs0, o, 64); gq0 += __shfl_xor(gq0, o, 64);
+        gs1 += __shfl_xor(gs1, o, 64); gq1 += __shfl_xor(gq1, o, 64);
+      }
+      const int co = ct * TN + wn * NT * 32 + lane * 8;
+      if (lane < CPR && co < p.Cout) {
+        // parts live on the 8-row x 32-col grid whatever the tile: (8-row block, column tile, wave row within the block)
+        const int row0 = oy0 + wm * MT;
+        const int part = ((phase * ((p.OH + 7) / 8) + row0 / 8) * p.tiles_x + tx) * 2 + ((row0 / 4) & 1);
+        if (part < p.gn_nparts) {
+          float* dst = p.gn_part + (((size_t)b * p.gn_nparts + part) * (p.Cout / 4) + co / 4) * 2;
+          dst[0] = gs0; dst[1] = gq0; dst[2] = gs1; dst[3] = gq1;
+        }
+      }
+    }
+    return;
+  }
+
+  // ---- epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int ncol = lane & 31, rhalf = lane >> 5;
+  // static_for: the accumulator indices must be compile-time constants (a runtime-indexed
+  // ext_vector array is demoted to scratch memory)
+  with_act(p.act, [&](auto actc) {
+  constexpr int ACT = decltype(actc)::value;
+  static_for<NT>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const int co = ct * TN + (wn * NT + j) * 32 + ncol;
+    const bool co_ok = co < p.Cout;
+    const float bv = (co_ok && p.bias) ? p.bias[co] : 0.f;
+    static_for<MT>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const int oy = oy0 + wm * MT + i;
+      const bool row_ok = oy < p.OH;
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int xb = ox0 + 8 * rq + 4 * rhalf;  // 4 consecutive x: xb .. xb+3
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rq * 4 + e] + bv;
+        const size_t pix0 = ((size_t)b * p.OH + oy) * p.OW + xb;
+        if (p.out_mode == GLARE_OUT_NHWC_BF16 || p.out_mode == GLARE_OUT_NHWC_F32) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (row_ok && co_ok && xb + e < p.OW) {
+              float y = v[e];
+              if (p.res) y += a2f(p.res[(pix0 + e) * p.rpitch + p.roff + co]);
+              y = apply_act<ACT>(y);
+              if (p.out_mode == GLARE_OUT_NHWC_BF16)
+                reinterpret_cast<a16_t*>(p.out)[(pix0 + e) * p.opitch + p.ooff + co] = f2a(y);
+              else
+                reinterpret_cast<float*>(p.out)[(pix0 + e) * p.opitch + p.ooff + co] = y;
+            }
+          }
+        } else {  // planar: [b][co][plane_pitch], pixel index y*OW + x
+          if (co_ok && row_ok) {
+            const size_t base = ((size_t)b * p.opitch + p.ooff + co) * (size_t)p.plane_pitch + (size_t)oy * p.OW + xb;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (xb + e < p.OW) {
+                const float y = apply_act<ACT>(v[e]);
+                if (p.out_mode == GLARE_OUT_PLANAR_F32)
+                  reinterpret_cast<float*>(p.out)[base + e] = y;
+                else
+                  reinterpret_cast<a16_t*>(p.out)[base + e] = f2a(y);
+              }
+            }
+          }
+        }
+      }
+    });
+  });
+  });
+}
+
+template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int KSTEPS, bool HILO = false>
+int launch(const ConvParams& p_in, hipStream_t stream) {
+  using G = TileGeom<KS, STRIDE, WM * MT>;
+  constexpr int TN = WN * NT * 32;
+  ConvParams p = p_in;
+  p.tiles_y = cdiv(p.OH, WM * MT);
+  const long long nb = (long long)p.B * p.tiles_x * p.tiles_y * p.co_tiles * (KS == 2 ? 4 : 1);
+  if (nb > 0x7fffffffLL) return GLARE_ERR_INVALID;
+  p.n_blocks = (int)nb;
+  p.gn_nparts = p.tiles_x * cdiv(p.OH, 8) * 2 * (KS == 2 ? 4 : 1);  // the 8 x 32 grid, 2 wave rows (4 rows each) per block
+  if (p.gn_part && !(p.fast_epilogue && p.Cout % 32 == 0)) return GLARE_ERR_UNSUPPORTED;
+  const size_t lds = (size_t)(2 * (((KSTEPS * 2 * G::NPOS + 63) / 64) * 64) + 2 * KS * KSTEPS * 2 * TN) * 16;
+  auto kern = conv_igemm_kernel<KS, STRIDE, MT, NT, WM, WN, KSTEPS, HILO>;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return GLARE_ERR_LAUNCH;
+  hipLaunchKernelGGL(kern, dim3(p.n_blocks), dim3(64 * WM * WN), lds, stream, p);
+  return glare_launch_status();
+}
+
+}  // namespace
