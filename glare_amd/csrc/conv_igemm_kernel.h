@@ -291,6 +291,8 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
   // encoder in the fp16 precision).  The accumulators go through a wave-private fp32 slab, one tile row
   // (32 pixels x NT*32 couts) at a time; v = acc + bias + residual_hi + residual_lo in fp32, then hi = round16(v) and
   // lo = round16(v - hi) leave as two 16-B stores per lane.  Unlike the plain epilogue nothing is rounded before the residual add.
+  // (Requesting a tile row's residual halves BEFORE its pass through the slab -- 32 more registers next to the 128 accumulators at
+  // 168 -- spilled: 196 B/lane of scratch, 892 instead of 823 us per launch on the path's eight launches; kept out.)
   if constexpr (HILO) {
     constexpr int ROWF = NT * 128 + 16;                  // slab row pitch in bytes (pad: bank spread between rows)
     constexpr int CPR = NT * 4;                          // 8-channel chunks per slab row

@@ -13,10 +13,10 @@ import sys
 def short(name):
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"^void ", "", name)
-    m = re.match(r"conv_igemm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>", name)
+    m = re.match(r"conv_igemm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (true|false))?>", name)
     if m:
-        ks, st, mt, nt, wm, wn, kst = map(int, m.groups())
-        return "conv_igemm k%d s%d TN%d" % (ks, st, wn * nt * 32)
+        ks, st, mt, nt, wm, wn, kst = map(int, m.groups()[:7])
+        return "conv_igemm k%d s%d TN%d%s" % (ks, st, wn * nt * 32, " hi/lo" if m.group(8) == "true" else "")
     name = re.sub(r"\(.*\)$", "", name)
     return name[:90]
 
