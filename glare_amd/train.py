@@ -104,35 +104,34 @@ class FlatGroup:
 
 
 class FlatAdam:
-    """device_state=True keeps the step count, the bias corrections and an lr multiplier in device memory (no host-side optimizer
-    state inside a step): required for replaying the training step from a hipGraph (GraphedStep)."""
+    """torch.optim.Adam over flat groups with ALL optimizer state on the device -- step count, bias corrections, an lr multiplier,
+    GradScaler's found_inf / scale / growth tracker: a step has no host-side state and no host synchronisation (the Python launch
+    loop runs ahead of the GPU; the whole step replays from a hipGraph, GraphedStep).  `device_state` is accepted for
+    compatibility with round 2's two modes; the host-state mode is gone (its inf / NaN check would have cost a sync per step)."""
 
-    def __init__(self, groups, betas=(0.9, 0.999), eps=1e-8, device_state=False):
-        self.groups, self.betas, self.eps, self._t = groups, betas, eps, 0
-        self.device_state = device_state
+    def __init__(self, groups, betas=(0.9, 0.999), eps=1e-8, device_state=True):
+        self.groups, self.betas, self.eps = groups, betas, eps
+        self.device_state = True
         dev = next(g.w.device for g in groups if g.w.numel())
         # GradScaler's state (torch.cuda.amp.GradScaler defaults, LLFlow_model.py:120): found_inf of the step in progress, the
-        # scale and the growth tracker -- all on the device, so a skipped step costs no host synchronisation
+        # scale and the growth tracker
         self.found_inf = torch.zeros(1, dtype=torch.int32, device=dev)
         self.scale = torch.full((1,), 65536.0, dtype=torch.float32, device=dev)
         self.growth_tracker = torch.zeros(1, dtype=torch.int32, device=dev)
         self.growth_factor, self.backoff_factor, self.growth_interval = 2.0, 0.5, 2000
-        if device_state:
-            self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
-            self.state3 = torch.tensor([1.0, 1.0, 1.0], dtype=torch.float32, device=dev)   # bc1, sqrt(bc2), lr multiplier
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.state3 = torch.tensor([1.0, 1.0, 1.0], dtype=torch.float32, device=dev)   # bc1, sqrt(bc2), lr multiplier
 
     @property
     def t(self):
-        return int(self.step_dev.item()) if self.device_state else self._t
+        return int(self.step_dev.item())       # a host read: for checkpoints / tests, never inside a step
 
     @t.setter
     def t(self, v):
-        if self.device_state:
-            self.step_dev.fill_(int(v))
-        self._t = int(v)
+        self.step_dev.fill_(int(v))
 
     def set_lr_scale(self, s):
-        """Scheduler hook for the device-state mode: lr_effective = group lr * s (a device scalar the graph reads)."""
+        """Scheduler hook: lr_effective = group lr * s (a device scalar the kernels read)."""
         self.state3[2] = float(s)
 
     def zero_grad(self):
@@ -142,8 +141,8 @@ class FlatAdam:
     def step(self):
         """scaler.step(optimizer); scaler.update() (LLFlow_model.py:240-241): gather + all-reduce the gradients, then ONE Adam
         step over every group -- unless an inf / NaN sits anywhere in them (checked AFTER the all-reduce, so every rank
-        decides alike): then nothing moves, the step count stays and the scale backs off.  Returns nothing; `last_step_skipped()`
-        reads the flag (a host synchronisation) for callers that want to log it."""
+        decides alike): then nothing moves, the step count stays and the scale backs off.  `last_step_skipped()` reads the flag
+        (a host synchronisation) for callers that want to log it."""
         self.found_inf.zero_()
         worlds = []
         for g in self.groups:
@@ -153,23 +152,13 @@ class FlatAdam:
             g.collect()
             worlds.append(g.all_reduce())
             T.grad_nonfinite_(g.g, self.found_inf)
-        skipped_on_host = False
-        if self.device_state:
-            T.adam_prepare_guarded_(self.step_dev, self.state3, self.betas, self.found_inf)
-        else:
-            skipped_on_host = bool(int(self.found_inf.item()))     # host-state mode: the step count lives here
-            if not skipped_on_host:
-                self._t += 1
+        T.adam_prepare_guarded_(self.step_dev, self.state3, self.betas, self.found_inf)
         for g, world in zip(self.groups, worlds):
-            if g.w.numel() == 0 or skipped_on_host:
+            if g.w.numel() == 0:
                 continue
             for lo, hi in g.active_ranges():       # never-used parameters are skipped, as torch.optim.Adam does
-                w, gr, m, v = g.w[lo:hi], g.g[lo:hi], g.m[lo:hi], g.v[lo:hi]
-                if self.device_state:
-                    T.adam_step_dev_guarded_(w, gr, m, v, self.state3, g.lr, self.betas, self.eps, g.weight_decay, 1.0 / world,
-                                             self.found_inf)
-                else:
-                    T.adam_step_(w, gr, m, v, self._t, g.lr, self.betas, self.eps, g.weight_decay, grad_scale=1.0 / world)
+                T.adam_step_dev_guarded_(g.w[lo:hi], g.g[lo:hi], g.m[lo:hi], g.v[lo:hi], self.state3, g.lr, self.betas, self.eps,
+                                         g.weight_decay, 1.0 / world, self.found_inf)
         T.gradscaler_update_(self.scale, self.growth_tracker, self.found_inf, self.growth_factor, self.backoff_factor,
                              self.growth_interval)
 
@@ -319,7 +308,6 @@ class GraphedStep:
     and selects one of two graphs, both captured up front (capture_all)."""
 
     def __init__(self, trainer, gt_img, lr_img, warmup=3):
-        assert trainer.opt.device_state, "build the trainer with device_state=True"
         self.trainer = trainer
         self.branching = hasattr(trainer, "draw_branch")
         self.gt, self.lr = gt_img.clone(), lr_img.clone()

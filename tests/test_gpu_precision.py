@@ -194,28 +194,41 @@ def setup(regime, h, w, seed):
     return _CACHE[key]
 
 
+# relative L2 error of each stage on the oracle's inputs under fp16 (incl. the hi / lo residual stream of stage A); bound = 2x measured
+TOL16 = {"cond_feat": 4.9e-4,    # 2.45e-4
+         "color_map": 1.58e-3,   # 7.88e-4
+         "mid_feat0": 4.7e-4,    # 2.34e-4
+         "mid_feat1": 1.13e-3,   # 5.65e-4
+         "latent": 6.9e-4,       # 3.46e-4
+         "code_feat0": 2.58e-3,  # 1.29e-3
+         "code_feat1": 3.97e-3,  # 1.99e-3
+         "vq_rec": 4.17e-3,      # 2.09e-3
+         "aft_out": 3.0e-3}      # 1.50e-3
+
+
 def test_fp16_stage_parity_against_oracle():
-    """Every stage on the oracle's inputs under fp16 (20x36 image): bounds = the bf16 suite's TOL / 8 (measured: TOL / 16)."""
+    """Every stage on the oracle's inputs under fp16 (20x36 image): 8x less rounding than bf16 measures as 8-16x less error
+    (tests/tolerances.py TOL holds the bf16 bounds)."""
     og, ov, pg, pv, lr, ref = setup("adversarial", 20, 36, 7)
     nhwc = lambda t, a16=True: ops.nchw_to_nhwc(t.cuda(), bf16=a16)
     nchw = lambda t: ops.nhwc_to_nchw(t).cpu()
     with torch.no_grad(), ops.use_precision("fp16"):
         enc = pg.RRDB.forward_nhwc(lr.cuda())
         assert enc["cond_feat"].dtype == torch.float16
-        within(rel(nchw(enc["cond_feat"]), ref["enc"]["cond_feat"]), TOL["cond_feat"] / 8)
-        within(rel(nchw(enc["color_map"]), ref["enc"]["color_map"]), TOL["color_map"] / 8)
+        within(rel(nchw(enc["cond_feat"]), ref["enc"]["cond_feat"]), TOL16["cond_feat"])
+        within(rel(nchw(enc["color_map"]), ref["enc"]["color_map"]), TOL16["color_map"])
         for i, (a, b) in enumerate(zip(enc["mid_feat"], ref["enc"]["mid_feat"])):
-            within(rel(nchw(a), b), TOL["mid_feat%d" % i] / 8, tag=i)
+            within(rel(nchw(a), b), TOL16["mid_feat%d" % i], tag=i)
         z = pg.flowUpsamplerNet.decode_nhwc(nhwc(ref["enc"]["color_map"], False), nhwc(ref["enc"]["cond_feat"]))
-        within(rel(nchw(z), ref["latent"]), TOL["latent"] / 8)
+        within(rel(nchw(z), ref["latent"]), TOL16["latent"])
         idx, img, feats = pv.decode_nhwc(nhwc(ref["latent"], False), want_image=True)
         assert torch.equal(idx.cpu(), ref["indices"])
         for i, (a, b) in enumerate(zip(feats, ref["code_feats"])):
-            within(rel(nchw(a), b), TOL["code_feat%d" % i] / 8, tag=i)
-        within(rel(img.cpu(), ref["vq_rec"]), TOL["vq_rec"] / 8)
+            within(rel(nchw(a), b), TOL16["code_feat%d" % i], tag=i)
+        within(rel(img.cpu(), ref["vq_rec"]), TOL16["vq_rec"])
         out = pg.deformable_decoder.forward_nhwc(nhwc(ref["latent"], False), [nhwc(f) for f in ref["code_feats"]],
                                                  [nhwc(f) for f in ref["enc"]["mid_feat"]])
-        within(rel(out.cpu(), ref["out"]), TOL["aft_out"] / 8)
+        within(rel(out.cpu(), ref["out"]), TOL16["aft_out"])
 
 
 def correlated_gt(ref_img, db=27.0, seed=5):

@@ -981,8 +981,8 @@ def test_step_with_nonfinite_gradients_is_skipped(device_state):
             assert torch.equal(opt.groups[0].m, w0[2]) and torch.equal(opt.groups[1].v, w0[3]) and opt.t == w0[4]
         assert torch.isfinite(a).all() and torch.isfinite(b).all()
     assert opt.t == 3
-    within(_rel(a, rp[0]), 1e-5)
-    within(_rel(b, rp[1]), 1e-5)
+    within(_rel(a, rp[0]), 1e-6)     # measured 1.1e-08 (fp32 Adam against torch's)
+    within(_rel(b, rp[1]), 1e-6)     # measured 2.8e-09
     sd = opt.scaler_state_dict()
     assert sd["scale"] == 65536.0 * 0.25 and sd["_growth_tracker"] == 2, sd   # two back-offs, then two good steps
     opt.growth_interval = 3
@@ -1076,5 +1076,5 @@ def test_implicit_weight_gradient_falls_back_when_its_workspace_would_be_too_lar
     ref_w, ref_b = grads()
     monkeypatch.setattr(T, "WGRAD_MAX_WORKSPACE", 0)       # every split launch now exceeds the cap
     fb_w, fb_b = grads()
-    within(_rel(fb_w, ref_w), 2e-3)
-    within(_rel(fb_b, ref_b), 2e-3)
+    within(_rel(fb_w, ref_w), 1e-6)     # measured 1.7e-07: two fp32 summation orders of the same bf16 products
+    within(_rel(fb_b, ref_b), 1e-6)     # measured 1.3e-08
