@@ -325,6 +325,15 @@ extern "C" int glare_conv2d_bf16(const glare_conv_desc* d, glare_stream_t stream
   p.gn_nparts = 0;
   p.res_lo = (const a16_t*)d->residual_lo;
   p.out_lo = (a16_t*)d->out_lo;
+  p.groups = d->groups > 1 ? d->groups : 1;
+  p.g_in_step = d->group_in_step; p.g_out_step = d->group_out_step; p.g_bias_step = d->Cout; p.g_w_elems = 0;
+  if (p.groups > 1) {
+    if (d->in2 || d->residual || d->gn_partial || d->out_lo || subpix || p.groups > 65535) return GLARE_ERR_UNSUPPORTED;
+    if ((d->group_in_step % 8) || d->in_off + (long long)(p.groups - 1) * d->group_in_step + d->Cin > d->in_pitch ||
+        d->out_off + (long long)(p.groups - 1) * d->group_out_step + d->Cout > d->out_pitch || d->group_out_step < 0 || d->group_in_step < 0)
+      return GLARE_ERR_INVALID;
+    p.g_w_elems = glare_conv2d_packed_weight_elems_tile(d->Cout, d->Cin, d->ksize, d->cout_tile);
+  }
   if (p.res_lo && !(p.res && p.out_lo)) return GLARE_ERR_INVALID;
   // 16-B records everywhere -> LDS-staged epilogue
   p.fast_epilogue = (d->out_mode == GLARE_OUT_NHWC_BF16) && !(p.Cout % 8) && !(p.opitch % 8) && !(p.ooff % 8) &&

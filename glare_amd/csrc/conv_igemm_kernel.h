@@ -36,6 +36,11 @@ struct ConvParams {
   int gn_nparts;
   const a16_t* res_lo;   // hi / lo epilogue (HILO instantiations): remainder halves of the residual and of the output
   a16_t* out_lo;
+  // grouped launch (blockIdx.y = group): `groups` independent filters of one shape on channel slices of one tensor -- the flow's
+  // 24 z-independent coupling nets, FlowAffineCouplingsAblation.py:143-151.  Group g reads input channels o0 + g * g_in_step,
+  // writes output channels ooff + g * g_out_step, with the g-th packed filter / bias.
+  int groups, g_in_step, g_out_step, g_bias_step;
+  long long g_w_elems;
 };
 
 // kernel-family dispatchers, one per translation unit: tn = the output-channel tile (128 / 64 / 32); hilo = the hi / lo epilogue
@@ -95,7 +100,15 @@ __device__ __forceinline__ void with_act(int act, F&& f) {
 // double-buffered in LDS and filled by LDS-DMA (global_load_lds_dwordx4), issued one B stage
 // ahead, right after the barrier that retires the buffer they overwrite; one barrier per B stage.
 template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int KSTEPS, bool HILO = false>
-__global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 2)) void conv_igemm_kernel(const ConvParams p) {
+__global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 2)) void conv_igemm_kernel(const ConvParams p_in) {
+  ConvParams p = p_in;
+  if (p.groups > 1) {               // uniform (scalar) adjustments: this workgroup's group
+    const int g = blockIdx.y;
+    p.o0 += g * p.g_in_step;
+    p.ooff += g * p.g_out_step;
+    p.wpk += (size_t)g * p.g_w_elems;
+    if (p.bias) p.bias += g * p.g_bias_step;
+  }
   constexpr int TH = WM * MT;       // output tile rows
   constexpr int NW = WM * WN;       // waves per workgroup (4, or 6 for the 12 x 32 x 128 tile)
   using G = TileGeom<KS, STRIDE, TH>;
@@ -467,6 +480,59 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
     return;
   }
 
+  // ---- planar fp32 output through LDS (the DCN's offset / mask-logit planes, conv_offset: deform_conv.py:357-364).  In the C/D
+  // layout a lane holds ONE output channel, so a direct planar store is 64 scattered 4-B words per instruction (32 planes x 2); via
+  // a wave-private fp32 slab (one 32-pixel tile row at a time) each lane stores 4 consecutive pixels of one plane and 8 consecutive
+  // lanes cover the 128 contiguous bytes of the row.  128 -> 108 at 8 x 420 x 620: 1.31 -> 0.83 ms; 256 -> 108 at half size: 0.45 -> 0.32 ms.
+  if constexpr (!HILO && KS == 3 && STRIDE == 1 && NW == 4) {
+    if (p.out_mode == GLARE_OUT_PLANAR_F32 && !p.res) {
+      constexpr int ROWD = NT * 32 + 1;                 // slab row pitch in dwords (odd: column reads spread over the banks)
+      static_assert(NW * 32 * ROWD * 4 <= (2 * A_SLOTS + 2 * B_CHUNKS) * 16, "planar epilogue slab fits the pipeline LDS");
+      typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+      __syncthreads();  // every wave is done reading the pipeline buffers
+      float* slab = reinterpret_cast<float*>(smem) + wave * (32 * ROWD);
+      const int ncol = lane & 31, rhalf = lane >> 5;
+      with_act(p.act, [&](auto actc) {
+      constexpr int ACT = decltype(actc)::value;
+      static_for<MT>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        static_for<NT>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          const int co = ct * TN + (wn * NT + j) * 32 + ncol;
+          const float bv = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * rhalf;
+            slab[m * ROWD + j * 32 + ncol] = apply_act<ACT>(acc[i][j][r] + bv);
+          }
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int oy = oy0 + wm * MT + i;
+#pragma unroll
+        for (int it = 0; it < 8 * NT * 32 / 64; ++it) {
+          const int idx = lane + 64 * it;
+          const int q = idx & 7, cl = idx >> 3;                  // 4-pixel group of the tile row, channel within the wave's NT*32
+          const int co = ct * TN + wn * NT * 32 + cl, x0 = ox0 + 4 * q;
+          if (oy < p.OH && co < p.Cout && x0 < p.OW) {
+            const f32x4u v = {slab[(4 * q) * ROWD + cl], slab[(4 * q + 1) * ROWD + cl], slab[(4 * q + 2) * ROWD + cl],
+                              slab[(4 * q + 3) * ROWD + cl]};
+            float* dst = reinterpret_cast<float*>(p.out) + ((size_t)b * p.opitch + p.ooff + co) * (size_t)p.plane_pitch + (size_t)oy * p.OW + x0;
+            if (x0 + 3 < p.OW) {
+              *reinterpret_cast<f32x4u*>(dst) = v;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (x0 + e < p.OW) dst[e] = v[e];
+            }
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      });
+      });
+      return;
+    }
+  }
+
   // ---- epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int ncol = lane & 31, rhalf = lane >> 5;
   // static_for: the accumulator indices must be compile-time constants (a runtime-indexed
@@ -539,7 +605,7 @@ int launch(const ConvParams& p_in, hipStream_t stream) {
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GLARE_ERR_LAUNCH;
-  hipLaunchKernelGGL(kern, dim3(p.n_blocks), dim3(64 * WM * WN), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3(p.n_blocks, p.groups > 1 ? p.groups : 1), dim3(64 * WM * WN), lds, stream, p);
   return glare_launch_status();
 }
 

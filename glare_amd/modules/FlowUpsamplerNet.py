@@ -131,11 +131,14 @@ class FlowUpsamplerNet(HipModule):
             f0w, f0b = aff.fFeatures[0].folded()
             wf0.append(f0w)
             bf0.append(f0b)
-            st["f2"] = ops.PackedConv(*aff.fFeatures[2].folded())
-            st["f4"] = ops.PackedConv(*aff.fFeatures[4].folded())
             st["eps"] = float(aff.affine_eps)
+        # the z-independent second and third layers of all n feature nets: ONE grouped launch each (ops.conv2d_grouped)
+        f2 = [st["layer"].affine.fFeatures[2].folded() for st in steps]
+        f4 = [st["layer"].affine.fFeatures[4].folded() for st in steps]
         return {"steps": steps, "n": n, "ftA": ops.PackedConv(torch.cat(wa_ft, 0), torch.cat(ba_ft, 0)),
-                "f0": ops.PackedConv(torch.cat(wf0, 0), torch.cat(bf0, 0)), "dev": dev}
+                "f0": ops.PackedConv(torch.cat(wf0, 0), torch.cat(bf0, 0)), "dev": dev,
+                "f2": ops.packed_conv_batch(torch.stack([w for w, _ in f2]), torch.stack([b for _, b in f2])),
+                "f4": ops.packed_conv_batch(torch.stack([w for w, _ in f4]), torch.stack([b for _, b in f4]))}
 
     def decode_nhwc(self, z, ft):
         """z: fp32 NHWC [B,h,w,3] (color_map); ft: bf16 NHWC [B,h,w,64] (cond_feat) -> latent fp32 NHWC."""
@@ -147,9 +150,9 @@ class FlowUpsamplerNet(HipModule):
         h1f = ops.conv2d(ft, P["f0"], act="relu")                                  # [B,h,w,n*64] bf16
         h2f = torch.empty_like(h1f)
         hF = torch.empty(B, H, W, n * 8, dtype=torch.float32, device=z.device)   # 6 of every 8 written and read
-        for s, st in enumerate(P["steps"]):                                        # z-independent, batched up front
-            ops.conv2d(h1f, st["f2"], cin=64, in_off=64 * s, act="relu", out=h2f, out_off=64 * s)
-            ops.conv2d(h2f, st["f4"], cin=64, in_off=64 * s, out=hF, out_off=8 * s, out_mode=ops.OUT_NHWC_F32)
+        # z-independent, batched up front: the n second layers, then the n third layers, one grouped launch each
+        ops.conv2d_grouped(h1f, P["f2"], cin=64, in_step=64, out=h2f, out_step=64, act="relu")
+        ops.conv2d_grouped(h2f, P["f4"], cin=64, in_step=64, out=hF, out_step=8, out_mode=ops.OUT_NHWC_F32)
         h1 = torch.empty(B, H, W, 64, dtype=ops.act_dtype(), device=z.device)
         h2 = torch.empty_like(h1)
         h4 = torch.empty(B, H, W, 4, dtype=torch.float32, device=z.device)
@@ -270,9 +273,8 @@ class FlowUpsamplerNet(HipModule):
         h1f = ops.conv2d(ft, P["f0"], act="relu")
         h2f = torch.empty_like(h1f)
         hF = torch.empty(B, H, W, n * 8, dtype=torch.float32, device=z.device)   # 6 of every 8 written and read
-        for s, st in enumerate(P["steps"]):
-            ops.conv2d(h1f, st["f2"], cin=64, in_off=64 * s, act="relu", out=h2f, out_off=64 * s)
-            ops.conv2d(h2f, st["f4"], cin=64, in_off=64 * s, out=hF, out_off=8 * s, out_mode=ops.OUT_NHWC_F32)
+        ops.conv2d_grouped(h1f, P["f2"], cin=64, in_step=64, out=h2f, out_step=64, act="relu")
+        ops.conv2d_grouped(h2f, P["f4"], cin=64, in_step=64, out=hF, out_step=8, out_mode=ops.OUT_NHWC_F32)
         bps = ops.flow_blocks_per_sample(H * W)
         partial = torch.zeros(2 * n, B * bps, dtype=torch.float32, device=z.device)
         h1 = torch.empty(B, H, W, 64, dtype=ops.act_dtype(), device=z.device)

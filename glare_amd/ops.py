@@ -43,7 +43,8 @@ class ConvDesc(ctypes.Structure):
                 ("res_pitch", _i), ("res_off", _i),
                 ("ksize", _i), ("stride", _i), ("upsample", _i), ("act", _i), ("out_mode", _i),
                 ("plane_pitch", _ll), ("gn_partial", ctypes.c_void_p), ("cout_tile", _i),
-                ("residual_lo", ctypes.c_void_p), ("out_lo", ctypes.c_void_p)]
+                ("residual_lo", ctypes.c_void_p), ("out_lo", ctypes.c_void_p),
+                ("groups", _i), ("group_in_step", _i), ("group_out_step", _i)]
 
 
 class PackedConv:
@@ -368,6 +369,34 @@ def attn_fold_groupnorm(stats, HW, gamma, beta, eps, wq, bq, wo, bo):
     return wq_b, bq_b, wo_b, bo_b
 
 
+def conv2d_grouped(x, pcs, *, cin, in_step, out, out_step, in_off=0, out_off=0, act="none", out_mode=OUT_NHWC_BF16):
+    """len(pcs) independent convs of ONE shape in a single launch (glare_conv_desc.groups): conv g reads channels
+    [in_off + g * in_step, + cin) of x and writes channels [out_off + g * out_step, + cout) of `out`.  pcs: the PackedConvs that
+    packed_conv_batch() returned for them (consecutive packed images, consecutive biases)."""
+    require_cuda(x, out)
+    G = len(pcs)
+    p0 = pcs[0]
+    assert x.dtype == act_dtype() and x.is_contiguous() and out.is_contiguous() and p0.packed.dtype == x.dtype
+    stride_w = p0.packed.numel()
+    assert all(pc.packed.data_ptr() == p0.packed.data_ptr() + g * stride_w * p0.packed.element_size() for g, pc in enumerate(pcs)), \
+        "grouped conv: filters must come from one packed_conv_batch()"
+    if p0.bias is not None:
+        assert all(pc.bias.data_ptr() == p0.bias.data_ptr() + g * p0.cout * 4 for g, pc in enumerate(pcs))
+    B, H, W, pitch = x.shape
+    d = ConvDesc()
+    d.in_, d.B, d.H, d.W = x.data_ptr(), B, H, W
+    d.Cin, d.in_pitch, d.in_off = cin, pitch, in_off
+    d.out, d.Cout, d.out_pitch, d.out_off = out.data_ptr(), p0.cout, out.shape[3], out_off
+    d.weight_packed = p0.packed.data_ptr()
+    d.bias = p0.bias.data_ptr() if p0.bias is not None else None
+    d.cout_tile = getattr(p0, "cout_tile", 0)
+    d.ksize, d.stride, d.upsample, d.act, d.out_mode = p0.ksize, 1, 0, ACT[act], out_mode
+    d.groups, d.group_in_step, d.group_out_step = G, in_step, out_step
+    count_flops("conv k%d" % p0.ksize, 2.0 * G * B * H * W * p0.ksize ** 2 * p0.cin * p0.cout)
+    check(_lib.lib().glare_conv2d_bf16(ctypes.byref(d), stream_handle()), "glare_conv2d_bf16")
+    return out
+
+
 def conv2d(x, pc, *, x2=None, cin=None, in_off=0, cin2=None, in2_off=0, stride=1, upsample=False, act="none",
            residual=None, res_off=0, out=None, out_off=0, out_mode=OUT_NHWC_BF16, plane_pitch=0, gn_stats=False, hilo=False):
     """x: NHWC bf16 [B,H,W,pitch] (channels [in_off, in_off+cin) are used), optional x2 concatenated
@@ -411,7 +440,10 @@ def conv2d(x, pc, *, x2=None, cin=None, in_off=0, cin2=None, in2_off=0, stride=1
         else:
             pp = plane_pitch or OH * OW
             dt = torch.float32 if out_mode == OUT_PLANAR_F32 else act_dtype()
-            out = torch.zeros(B, pc.cout, pp, dtype=dt, device=x.device)
+            out = torch.empty(B, pc.cout, pp, dtype=dt, device=x.device)   # the conv writes every valid pixel of every plane;
+            if pp > OH * OW:                                                # only the padding behind them is cleared (V^T of the
+                out[:, :, OH * OW:].zero_()                                 # two-tensor attention reads whole 32-key groups): the
+                                                                            # full 900 MB fill of the DCN's offset planes cost 0.1 ms
     assert out.is_contiguous()
     if out_mode in (OUT_NHWC_BF16, OUT_NHWC_F32):
         d.out_pitch = out.shape[3]

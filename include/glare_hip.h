@@ -112,6 +112,11 @@ typedef struct glare_conv_desc {
    * without the intermediate 16-bit rounding of acc + bias the plain epilogue has; the fused GroupNorm statistics are those of v. */
   const void* residual_lo;   /* optional lo half of `residual` (same pitch / offset), or NULL      */
   void* out_lo;              /* optional: see above                                                */
+  /* ---- grouped launch (round 3; zero = one filter): `groups` independent filters of ONE shape applied to channel slices of one
+   * tensor in a single launch -- group g reads input channels [in_off + g * group_in_step, + Cin), writes output channels
+   * [out_off + g * group_out_step, + Cout), with the g-th of `groups` consecutive packed filters in weight_packed
+   * (glare_conv2d_pack_weight_batched) and the g-th Cout-vector of bias.  No second source, residual, fused statistics or hi / lo. */
+  int groups, group_in_step, group_out_step;
 } glare_conv_desc;
 
 /* The output-channel tile (128, 64 or 32) that gives a B x OH x OW x cout conv enough workgroups (8 x 32 output pixels each). */

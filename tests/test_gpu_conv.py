@@ -412,3 +412,30 @@ def test_groupnorm_fold_builds_the_per_image_filters_and_the_1x1_kernel_applies_
     x3 = x[:3].contiguous()
     with pytest.raises(_lib.GlareError):
         ops.conv1x1_per_image(x3, wo_b[:3].contiguous(), bo_b[:3].contiguous())            # 64 % 3 != 0
+
+
+@pytest.mark.parametrize("k,cout,out_step,f32", [(1, 64, 64, False), (3, 6, 8, True), (3, 64, 64, False)])
+def test_grouped_launch_gives_the_bits_of_the_per_group_launches(k, cout, out_step, f32):
+    """glare_conv_desc.groups: n filters of one shape on channel slices of one tensor in ONE launch (the flow's z-independent
+    coupling nets) == the n separate launches, bit for bit; untouched output channels stay untouched."""
+    g = torch.Generator().manual_seed(77 + k + cout)
+    G, B, H, W, cin = 5, 2, 13, 37, 64
+    x = _nhwc_bf16(_rand((B, G * cin, H, W), g))
+    w = _rand((G, cout, cin, k, k), g, 1.0 / (cin * k * k) ** 0.5).cuda()
+    b = _rand((G, cout), g, 0.1).cuda()
+    pcs = ops.packed_conv_batch(w, b)
+    mode = ops.OUT_NHWC_F32 if f32 else ops.OUT_NHWC_BF16
+    dt = torch.float32 if f32 else torch.bfloat16
+    one = torch.full((B, H, W, G * out_step), 7.0, dtype=dt, device="cuda")
+    sep = one.clone()
+    ops.conv2d_grouped(x, pcs, cin=cin, in_step=cin, out=one, out_step=out_step, act="relu", out_mode=mode)
+    for s in range(G):
+        ops.conv2d(x, pcs[s], cin=cin, in_off=cin * s, act="relu", out=sep, out_off=out_step * s, out_mode=mode)
+    assert torch.equal(one, sep)
+    if out_step > cout:
+        assert bool((one.view(B, H, W, G, out_step)[..., cout:] == 7.0).all())
+    ref = F.conv2d(x[..., cin:2 * cin].permute(0, 3, 1, 2).float(), w[1].to(torch.bfloat16).float(), b[1], 1, k // 2).relu()
+    _check(one[..., out_step:out_step + cout].permute(0, 3, 1, 2), ref, bf16_out=not f32)
+    # refusals: channel slices past the pitch; fusions the grouped launch does not carry
+    with pytest.raises(RuntimeError):
+        ops.conv2d_grouped(x, pcs, cin=cin, in_step=cin, in_off=8, out=one, out_step=out_step, out_mode=mode)
