@@ -251,8 +251,13 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_kernel(const DcnParams p) 
 #ifndef DCN_ABL
 #define DCN_ABL 0   // timing ablations only (tools/ablate.sh): 1 no weight loads, 2 no corner loads, 4 no MFMA, 8 no offset loads
 #endif
-template <int NT, int NCH, int MT>
+//
+// SINGLE = true (GLARE_MDCN_SINGLE_PASS): the blended sample and the filter are rounded ONCE to the library's 16-bit activation
+// format and contracted by one MFMA per product -- the arithmetic of every other convolution on the path (16-bit operands, fp32
+// accumulation) instead of the split form's 3 MFMAs; half the sample tile in LDS, half the fragment reads and weight loads.
+template <int NT, int NCH, int MT, bool SINGLE = false>
 __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_fast_kernel(const DcnParams p) {
+  constexpr int HL = SINGLE ? 1 : 2;                // 16-bit planes of the sample tile (hi | lo, or the one rounded value)
   constexpr int PIX = 64 * MT;
   constexpr int ITEMS = PIX * NCH / DC_THREADS;
   constexpr int KSN = NCH / 2;                      // 16-channel MFMA k-steps per stage
@@ -260,10 +265,10 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_fast_kernel(const DcnParam
   constexpr int NPASS = (CT * PIX + DC_THREADS - 1) / DC_THREADS;
   constexpr unsigned OOB = 0x80000000u;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  u32x4* colH = reinterpret_cast<u32x4*>(smem);                    // [2 buffers][hi|lo][NCH][PIX] 16-B chunks
+  u32x4* colH = reinterpret_cast<u32x4*>(smem);                    // [2 buffers][HL: hi|lo][NCH][PIX] 16-B chunks
   // sampling plan, [2 buffers] x { corner offsets u32x4 [CT][PIX] | corner weights f32x4 [CT][PIX] | mask f32 [CT][PIX] }
   constexpr int PLAN_BYTES = CT * PIX * 36;
-  char* plan = smem + (size_t)2 * 2 * NCH * PIX * 16;
+  char* plan = smem + (size_t)2 * HL * NCH * PIX * 16;
   const int K = p.kh * p.kw;
   const int n_stages = p.dg * K, n_chunks = n_stages / CT;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -414,7 +419,7 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_fast_kernel(const DcnParam
     const u32x4 (&cr)[ITEMS][4] = cs.cr;
     const f32x4 (&cw)[ITEMS] = cs.cw;
     const float (&cm)[ITEMS] = cs.cm;
-    u32x4* dst = colH + (size_t)buf * 2 * NCH * PIX;
+    u32x4* dst = colH + (size_t)buf * HL * NCH * PIX;
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
       const float m = cm[i];
@@ -429,34 +434,53 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_fast_kernel(const DcnParam
         v0 = __builtin_fmaf(alo(cr[i][3][e]), cw[i][3], v0); v1 = __builtin_fmaf(ahi(cr[i][3][e]), cw[i][3], v1);
         v0 *= m; v1 *= m;
         asm volatile("" : "+v"(v0), "+v"(v1));   // keeps the pair out of the vectoriser's hands
-        hi[e] = pack_bf2(v0, v1);
-        float r0 = v0 - bflo(hi[e]), r1 = v1 - bfhi(hi[e]);
-        asm volatile("" : "+v"(r0), "+v"(r1));
-        lo[e] = pack_bf2(r0, r1);
+        if constexpr (SINGLE) {
+          hi[e] = pack_a2(v0, v1);
+        } else {
+          hi[e] = pack_bf2(v0, v1);
+          float r0 = v0 - bflo(hi[e]), r1 = v1 - bfhi(hi[e]);
+          asm volatile("" : "+v"(r0), "+v"(r1));
+          lo[e] = pack_bf2(r0, r1);
+        }
       }
       dst[it_lds[i]] = hi;
-      dst[NCH * PIX + it_lds[i]] = lo;
+      if constexpr (!SINGLE) dst[NCH * PIX + it_lds[i]] = lo;
     }
   };
 
   // ---- weight fragments: [stage][c/8][Co][hi 16 B | lo 16 B], one (hi, lo) pair per (k-step, N tile) ----
+  // (SINGLE: [stage][c/8][Co][16 B], one fragment per (k-step, N tile))
   const int khalf = lane >> 5;
-  const unsigned wvo = (unsigned)(khalf * p.Co + wn * NT * 32 + (lane & 31)) * 32u;
-  auto load_b = [&](int s, int ks, u32x4 (&dst)[NT][2]) {
-    const unsigned ws = (unsigned)((s * NCH + 2 * ks) * p.Co) * 32u;
+  constexpr unsigned WB = SINGLE ? 16u : 32u;       // bytes per (8 channels, output channel) record of the packed filter
+  const unsigned wvo = (unsigned)(khalf * p.Co + wn * NT * 32 + (lane & 31)) * WB;
+  auto load_b = [&](int s, int ks, u32x4 (&dst)[NT][HL]) {
+    const unsigned ws = (unsigned)((s * NCH + 2 * ks) * p.Co) * WB;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
 #if DCN_ABL & 1
       dst[j][0] = u32x4{wvo + j, ws, wvo, ws};
-      dst[j][1] = u32x4{wvo, ws + j, ws, wvo};
+      if constexpr (!SINGLE) dst[j][HL - 1] = u32x4{wvo, ws + j, ws, wvo};
 #else
-      dst[j][0] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvo + j * 1024, ws, 0);
-      dst[j][1] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvo + j * 1024 + 16, ws, 0);
+      dst[j][0] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvo + j * (32 * WB), ws, 0);
+      if constexpr (!SINGLE) dst[j][HL - 1] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvo + j * 1024 + 16, ws, 0);
 #endif
     }
   };
-  auto mfma_step = [&](const u32x4* a_src, int ks, const u32x4 (&b)[NT][2]) {
+  auto mfma_step = [&](const u32x4* a_src, int ks, const u32x4 (&b)[NT][HL]) {
     const int kk = 2 * ks + khalf;
+    if constexpr (SINGLE) {
+      a16x8 a[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int sw = ((lane & 31) ^ (kk * (16 / NCH))) - (lane & 31);
+        a[m] = __builtin_bit_cast(a16x8, a_src[kk * PIX + 32 * m + sw]);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          acc[m][j] = mfma_a16_32x32x16(a[m], __builtin_bit_cast(a16x8, b[j][0]), acc[m][j], 0, 0, 0);
+    } else {
     bf16x8 ah[MT], al[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -467,7 +491,7 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_fast_kernel(const DcnParam
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const bf16x8 bh = __builtin_bit_cast(bf16x8, b[j][0]);
-      const bf16x8 bl = __builtin_bit_cast(bf16x8, b[j][1]);
+      const bf16x8 bl = __builtin_bit_cast(bf16x8, b[j][HL - 1]);
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
 #if DCN_ABL & 4
@@ -479,9 +503,10 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_fast_kernel(const DcnParam
 #endif
       }
     }
+    }
   };
 
-  u32x4 bA[NT][2], bB[NT][2];
+  u32x4 bA[NT][HL], bB[NT][HL];
 
   // one stage: barrier; the gather of stage s+1 is issued; the MFMAs of stage s (the weight fragments of the next
   // k-step always in flight); the samples of stage s+1 are blended into the other tile.  Measured and dropped: weight
@@ -493,7 +518,7 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_fast_kernel(const DcnParam
     const int c = s / CT, tl = s - c * CT;
     if (more) gather_issue(s + 1, cs0);
     if (tl == 0 && c + 1 < n_chunks) plan_load(c + 1);
-    const u32x4* a_src = colH + (size_t)(s & 1) * 2 * NCH * PIX + (lane & 31) + 32 * MT * wm;
+    const u32x4* a_src = colH + (size_t)(s & 1) * HL * NCH * PIX + (lane & 31) + 32 * MT * wm;
     // KSN is even: the k-steps alternate between the two register sets and every stage starts on bA
 #pragma unroll
     for (int ks = 0; ks < KSN; ks += 2) {
@@ -565,6 +590,22 @@ __global__ void dcn_pack_weight_kernel(const float* __restrict__ w, bf16_t* __re
   wt[base + 8 + e] = f2bf(v - bf2f(hi));
 }
 
+// the single-pass image: [stage][c/8][Co][8 x a16], the filter rounded once to the library's activation format
+__global__ void dcn_pack_weight_single_kernel(const float* __restrict__ w, a16_t* __restrict__ wt, int Co, int C, int K, int dg) {
+  const long long total = (long long)Co * C * K;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int cpg = C / dg, nch = cpg / 8;
+  const int e = (int)(i % 8);
+  long long t = i / 8;
+  const int co = (int)(t % Co);
+  t /= Co;
+  const int kk = (int)(t % nch);
+  const int s = (int)(t / nch);
+  const int g = s / K, tap = s % K;
+  wt[(((size_t)s * nch + kk) * Co + co) * 8 + e] = f2a(w[((size_t)co * C + g * cpg + kk * 8 + e) * K + tap]);
+}
+
 template <bool XBF16>
 int launch_dcn(const DcnParams& p, hipStream_t stream) {
   const int nt = p.Co / 64;           // 2 waves along Co
@@ -583,14 +624,27 @@ int launch_dcn(const DcnParams& p, hipStream_t stream) {
 
 // MT = 1 everywhere: 128-pixel workgroups (MT = 2) halve the weight-fragment traffic but run at occupancy 2 and measured
 // 3.35 ms vs 3.32 ms (C = 128) and 2.95 ms vs 2.42 ms (C = 256) at 8 images -- the kernel needs the waves.
-int launch_dcn_fast(const DcnParams& p, hipStream_t stream) {
+int launch_dcn_fast(const DcnParams& p, bool single, hipStream_t stream) {
   const int nt = p.Co / 64, nch = p.cpg / 8;
+  if (single && nt == 2 && nch == 4) {
+    // 128-pixel workgroups (MT = 2) for the single-pass form at C = Co = 128: half the weight-fragment loads per pixel at 140
+    // VGPRs (3 waves / SIMD): 2.13 -> 1.94 ms at 8 x 420 x 620.  Not at C = 256 (1.59 -> 2.15 ms: occupancy 1), and not for the
+    // split form (measured in round 2, see above launch_dcn_fast).
+    const int pix2 = 128;
+    const size_t lds2 = (size_t)2 * nch * pix2 * 16 + (size_t)2 * 3 * pix2 * 36;
+    hipLaunchKernelGGL((dcn_fwd_fast_kernel<2, 4, 2, true>), dim3((unsigned)((p.total_pix + pix2 - 1) / pix2)), dim3(DC_THREADS), lds2,
+                       stream, p);
+    return glare_launch_status();
+  }
   const int pix = 64;
-  const size_t lds = (size_t)2 * 2 * nch * pix * 16 + (size_t)2 * 3 * pix * 36;   // sample tiles + sampling plan
+  const size_t lds = (size_t)2 * (single ? 1 : 2) * nch * pix * 16 + (size_t)2 * 3 * pix * 36;   // sample tiles + sampling plan
   const unsigned blocks = (unsigned)((p.total_pix + pix - 1) / pix);
 #define DCN_FAST(NT_, NCH_)                                                                                  \
   if (nt == NT_ && nch == NCH_) {                                                                            \
-    hipLaunchKernelGGL((dcn_fwd_fast_kernel<NT_, NCH_, 1>), dim3(blocks), dim3(DC_THREADS), lds, stream, p); \
+    if (single)                                                                                              \
+      hipLaunchKernelGGL((dcn_fwd_fast_kernel<NT_, NCH_, 1, true>), dim3(blocks), dim3(DC_THREADS), lds, stream, p); \
+    else                                                                                                     \
+      hipLaunchKernelGGL((dcn_fwd_fast_kernel<NT_, NCH_, 1>), dim3(blocks), dim3(DC_THREADS), lds, stream, p); \
     return glare_launch_status();                                                                            \
   }
   DCN_FAST(1, 4) DCN_FAST(2, 4) DCN_FAST(4, 4) DCN_FAST(1, 8) DCN_FAST(2, 8) DCN_FAST(4, 8)
@@ -618,6 +672,15 @@ extern "C" int glare_mdcn_pack_weight_f32(const float* weight_oihw, float* packe
   const long long total = (long long)Co * C * kh * kw;
   hipLaunchKernelGGL(dcn_pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      weight_oihw, reinterpret_cast<bf16_t*>(packed), Co, C, kh * kw, dg);
+  return glare_launch_status();
+}
+
+extern "C" int glare_mdcn_pack_weight_single_f32(const float* weight_oihw, void* packed, int Co, int C, int kh, int kw, int dg,
+                                                 glare_stream_t stream) {
+  if (!weight_oihw || !packed || Co <= 0 || C <= 0 || kh <= 0 || kw <= 0 || dg <= 0 || C % dg || (C / dg) % 8) return GLARE_ERR_INVALID;
+  const long long total = (long long)Co * C * kh * kw;
+  hipLaunchKernelGGL(dcn_pack_weight_single_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     weight_oihw, reinterpret_cast<a16_t*>(packed), Co, C, kh * kw, dg);
   return glare_launch_status();
 }
 
@@ -655,14 +718,16 @@ extern "C" int glare_mdcn_forward_nhwc(const void* x, int x_is_bf16, int x_pitch
   const long long off_bytes = ((long long)(B - 1) * p.off_bstride + (long long)dg * 2 * kh * kw * p.off_plane) * 4;
   const long long mask_bytes = ((long long)(B - 1) * p.mask_bstride + (long long)dg * kh * kw * p.mask_plane) * 4;
   const long long wt_bytes = (long long)Co * C * kh * kw * 4;
-  const bool generic_only = (flags & GLARE_MDCN_GENERAL_KERNEL) != 0;
+  const bool generic_only = (flags & GLARE_MDCN_GENERAL_KERNEL) != 0, single = (flags & GLARE_MDCN_SINGLE_PASS) != 0;
+  if (single && generic_only) return GLARE_ERR_INVALID;
   const int taps = kh * kw;
   if (x_is_bf16 && !generic_only && taps % 3 == 0 && x_bytes < LIM && off_bytes < LIM && mask_bytes < LIM && wt_bytes < LIM &&
       p.total_pix < LIM - 256) {
     p.x_bytes = (unsigned)x_bytes; p.off_bytes = (unsigned)off_bytes; p.mask_bytes = (unsigned)mask_bytes;
-    p.wt_bytes = (unsigned)wt_bytes;
-    return launch_dcn_fast(p, (hipStream_t)stream);
+    p.wt_bytes = (unsigned)(single ? wt_bytes / 2 : wt_bytes);
+    return launch_dcn_fast(p, single, (hipStream_t)stream);
   }
+  if (single) return GLARE_ERR_UNSUPPORTED;   // the single-pass form exists on the fast path only (16-bit x, 3 | kh * kw, < 2 GB tensors)
   p.x_bytes = p.off_bytes = p.mask_bytes = p.wt_bytes = 0;
   return x_is_bf16 ? launch_dcn<true>(p, (hipStream_t)stream) : launch_dcn<false>(p, (hipStream_t)stream);
 }

@@ -306,21 +306,35 @@ class FlowUpsamplerNet(HipModule):
         bias = torch.stack([l.actnorm.bias.reshape(-1) for l in self.layers]).double()
         A2 = Wm * torch.exp(logs).unsqueeze(1)
         c2 = (A2 @ bias.unsqueeze(-1)).squeeze(-1)
-        det = (Wm[:, 0, 0] * (Wm[:, 1, 1] * Wm[:, 2, 2] - Wm[:, 1, 2] * Wm[:, 2, 1])
-               - Wm[:, 0, 1] * (Wm[:, 1, 0] * Wm[:, 2, 2] - Wm[:, 1, 2] * Wm[:, 2, 0])
-               + Wm[:, 0, 2] * (Wm[:, 1, 0] * Wm[:, 2, 1] - Wm[:, 1, 1] * Wm[:, 2, 0]))
+        w = Wm.reshape(-1, 9).unbind(1)          # one unbind (backward: one stack) instead of 18 selects
+        det = w[0] * (w[4] * w[8] - w[5] * w[7]) - w[1] * (w[3] * w[8] - w[5] * w[6]) + w[2] * (w[3] * w[7] - w[4] * w[6])
         const_ld = logs.sum() + torch.log(det.abs()).sum()
-        Mts, steps, pend = [], [], None
-        for i, layer in enumerate(self.layers):          # only the coupling-free layers before a coupling step need composing
+        # One row [A | c] per coupling step.  A coupling layer that directly follows another one takes its own row of `rows`
+        # unchanged: runs of such layers are SLICES of it (one slice / one slice_backward per run, not a select + cat per layer --
+        # a per-layer formulation put ~400 filter-sized kernels into every training step); only a coupling layer behind
+        # coupling-free layers (2 of the 24 steps) needs the composition with what is pending.
+        rows = torch.cat([A2.reshape(-1, 9), c2], 1)                                       # [L, 12]
+        pieces, steps, pend, run = [], [], None, None
+        for i, layer in enumerate(self.layers):
+            coupling = layer.flow_coupling != "noCoupling"
+            if coupling and pend is None:
+                run = [i, i + 1] if run is None else [run[0], i + 1]
+                steps.append(layer.affine)
+                continue
+            if run is not None:
+                pieces.append(rows[run[0]:run[1]])
+                run = None
             A, c = A2[i], c2[i]
             if pend is not None:
                 A, c = A @ pend[0], A @ pend[1] + c
-            if layer.flow_coupling == "noCoupling":
-                pend = (A, c)
-            else:
-                Mts.append(torch.cat([A.reshape(9), c]))
+            if coupling:
+                pieces.append(torch.cat([A.reshape(9), c]).unsqueeze(0))
                 steps.append(layer.affine)
                 pend = None
+            else:
+                pend = (A, c)
+        if run is not None:
+            pieces.append(rows[run[0]:run[1]])
         assert self.layers[len(self.layers) - 1].flow_coupling != "noCoupling"
 
         # batched folds: stack the raw parameters of all coupling steps once, then ONE op per fold for all steps
@@ -340,7 +354,7 @@ class FlowUpsamplerNet(HipModule):
         c4w, c4b = fold([a.fAffine[4] for a in steps])
         f2w, f2b = fold([a.fFeatures[2] for a in steps])
         f4w, f4b = fold([a.fFeatures[4] for a in steps])
-        P = {"Mt": torch.stack(Mts).float(),
+        P = {"Mt": torch.cat(pieces).float(),
              "wz": a0w[:, :, 0].reshape(len(steps), 64, 9),
              "ftA_w": a0w[:, :, 1:].reshape(-1, 64, 3, 3), "ftA_b": a0b.reshape(-1),
              "f0_w": f0w.reshape(-1, 64, 3, 3), "f0_b": f0b.reshape(-1),
@@ -404,9 +418,8 @@ class FlowNLLFn(torch.autograd.Function):
         hF = torch.empty(B, H, W, n * 8, dtype=torch.float32, device=dev)   # 6 of every 8 written and read
         f2p, f4p = ops.packed_conv_batch(f2_w, f2_b), ops.packed_conv_batch(f4_w, f4_b)      # one pack launch per conv type
         c2p, c4p = ops.packed_conv_batch(c2_w, c2_b), ops.packed_conv_batch(c4_w, c4_b)
-        for s in range(n):
-            ops.conv2d(h1f, f2p[s], cin=64, in_off=64 * s, act="relu", out=h2f, out_off=64 * s)
-            ops.conv2d(h2f, f4p[s], cin=64, in_off=64 * s, out=hF, out_off=8 * s, out_mode=ops.OUT_NHWC_F32)
+        ops.conv2d_grouped(h1f, f2p, cin=64, in_step=64, out=h2f, out_step=64, act="relu")     # the n z-independent nets: one
+        ops.conv2d_grouped(h2f, f4p, cin=64, in_step=64, out=hF, out_step=8, out_mode=ops.OUT_NHWC_F32)   # grouped launch per layer
         # every step's input and mid-step latent are kept for the backward: the kernels write them in place of copies --
         # z_in[k] -pre-> z_pre[k] -post-> z_in[k + 1]; slot n of z_in is the encoded latent
         z_in = torch.empty(n + 1, B, H, W, 3, dtype=torch.float32, device=dev)
@@ -462,11 +475,11 @@ class FlowNLLFn(torch.autograd.Function):
         o4 = T.conv_weight_grad_nhwc(3, h2s, gh4s, 8, 64, groups=n, x_gstride=P * 64, g_gstride=P * 8, shape=(B, H, W))   # [n,577,8]
         o2 = T.conv_weight_grad_nhwc(1, h1s, gh2s, 64, 64, groups=n, x_gstride=P * 64, g_gstride=P * 64, shape=(B, H, W))  # [n,65,64]
         gh2f, gh1f = torch.empty_like(h1f), torch.empty_like(h1f)
-        for s in range(n):                                             # the z-independent feature nets: data gradients
-            ops.conv2d(ghF, f4t[s], cin=8, in_off=8 * s, out=gh2f, out_off=64 * s)
-            T.act_backward_(gh2f, h2f, "relu", C=64, g_off=64 * s, y_off=64 * s)
-            ops.conv2d(gh2f, f2t[s], cin=64, in_off=64 * s, out=gh1f, out_off=64 * s)
-            T.act_backward_(gh1f, h1f, "relu", C=64, g_off=64 * s, y_off=64 * s)
+        # the z-independent feature nets: data gradients, the n nets as the groups of one launch per layer
+        ops.conv2d_grouped(ghF, f4t, cin=8, in_step=8, out=gh2f, out_step=64)
+        T.act_backward_(gh2f, h2f, "relu")
+        ops.conv2d_grouped(gh2f, f2t, cin=64, in_step=64, out=gh1f, out_step=64)
+        T.act_backward_(gh1f, h1f, "relu")
         # ... and their filter gradients: step s owns a channel block of both tensors (group stride = the block)
         of4 = T.conv_weight_grad_nhwc(3, h2f, ghF, 8, 64, groups=n, x_gstride=64, g_gstride=8)      # [n,577,8], 6 of 8 used
         of2 = T.conv_weight_grad_nhwc(1, h1f, gh2f, 64, 64, groups=n, x_gstride=64, g_gstride=64)   # [n,65,64]

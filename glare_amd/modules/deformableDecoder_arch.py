@@ -13,6 +13,14 @@ from .encoder_decoder import build_decoder_trunk, conv_t, decoder_stem, gn_swish
 from .ops.dcn import ModulatedDeformConvPack, modulated_deform_conv
 
 
+import os
+
+# Inference under the fp16 precision: the DCN contraction as ONE half-precision MFMA per product (GLARE_MDCN_SINGLE_PASS) -- the
+# arithmetic of every other convolution of the decoder -- instead of the split fp32-class form.  GLARE_DCN_SINGLE_PASS=0 keeps the
+# split form everywhere; bf16 inference (8 mantissa bits), the op-level API and training always use the split form.
+DCN_SINGLE_PASS = os.environ.get("GLARE_DCN_SINGLE_PASS", "1") != "0"
+
+
 class DCNv2Pack(ModulatedDeformConvPack, HipModule):
     """Offsets and masks come from a second feature map (deformableDecoder_arch.py:141-152)."""
 
@@ -29,7 +37,8 @@ class DCNv2Pack(ModulatedDeformConvPack, HipModule):
         B, H, W, _ = feat.shape
         plane = (H * W + 63) // 64 * 64
         om = ops.conv2d(feat, packed_conv(self, self.conv_offset), out_mode=ops.OUT_PLANAR_F32, plane_pitch=plane)
-        pd = self._packed("dcn", lambda: ops.PackedDcn(self.weight, self.bias, self.deformable_groups))
+        single = DCN_SINGLE_PASS and ops.precision() == "fp16" and x.dtype == torch.float16
+        pd = self._packed("dcn1" if single else "dcn", lambda: ops.PackedDcn(self.weight, self.bias, self.deformable_groups, single=single))
         return ops.mdcn_forward_nhwc(x, om, pd, x_off=x_off, C=self.in_channels, mask_is_logit=True, padding=self.padding)
 
     def train_nhwc(self, x, feat):

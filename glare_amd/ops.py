@@ -825,18 +825,28 @@ def mdcn_forward(x, offset, mask, weight, bias, stride=1, padding=1, dilation=1,
 
 
 class PackedDcn:
-    def __init__(self, weight_oihw, bias, deformable_groups):
+    """single=False: the split form (two 16-bit halves per operand, fp32-class).  single=True: the filter rounded once to the
+    current precision's 16-bit format for GLARE_MDCN_SINGLE_PASS (mdcn_forward_nhwc passes the flag by itself)."""
+
+    def __init__(self, weight_oihw, bias, deformable_groups, single=False):
         require_cuda(weight_oihw)
         w = weight_oihw.detach().float().contiguous()
         self.co, self.c, self.kh, self.kw = w.shape
         self.dg = deformable_groups
-        self.packed = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
-        check(_lib.lib().glare_mdcn_pack_weight_f32(ptr(w), ptr(self.packed), _i(self.co), _i(self.c), _i(self.kh),
-                                                     _i(self.kw), _i(self.dg), stream_handle()), "glare_mdcn_pack_weight_f32")
+        self.single = bool(single)
+        if self.single:
+            self.packed = torch.empty(w.numel(), dtype=act_dtype(), device=w.device)
+            check(_lib.lib().glare_mdcn_pack_weight_single_f32(ptr(w), ptr(self.packed), _i(self.co), _i(self.c), _i(self.kh),
+                                                                _i(self.kw), _i(self.dg), stream_handle()), "glare_mdcn_pack_weight_single_f32")
+        else:
+            self.packed = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
+            check(_lib.lib().glare_mdcn_pack_weight_f32(ptr(w), ptr(self.packed), _i(self.co), _i(self.c), _i(self.kh),
+                                                         _i(self.kw), _i(self.dg), stream_handle()), "glare_mdcn_pack_weight_f32")
         self.bias = None if bias is None else bias.detach().float().contiguous()
 
 
 MDCN_GENERAL_KERNEL = 1   # glare_hip.h: pin the general-extent MFMA kernel for this call
+MDCN_SINGLE_PASS = 2      # glare_hip.h: one MFMA per product on 16-bit operands (PackedDcn(single=True))
 
 
 def mdcn_forward_nhwc(x, om, pd, x_off=0, C=None, mask_is_logit=True, padding=1, flags=0):
@@ -850,6 +860,9 @@ def mdcn_forward_nhwc(x, om, pd, x_off=0, C=None, mask_is_logit=True, padding=1,
     plane = om.shape[2]
     out = torch.empty(B, H, W, pd.co, dtype=torch.float32, device=x.device)
     mask = om[:, 2 * pd.dg * K:]
+    if getattr(pd, "single", False):
+        assert pd.packed.dtype == act_dtype() == x.dtype, "single-pass DCN: filter and x in the current precision's 16-bit format"
+        flags |= MDCN_SINGLE_PASS
     with _timed_launch("dcn", 2.0 * B * H * W * C * pd.co * K + 8.0 * K * B * H * W * C,      # contraction + sampling
                        (2.0 if x.dtype != torch.float32 else 4.0) * B * H * W * C + 4.0 * B * H * W * (3 * pd.dg * K + pd.co) + 4.0 * pd.co * C * K):
         _mdcn_forward_nhwc_launch(x, om, pd, out, mask, pitch, x_off, plane, mask_is_logit, B, C, H, W, padding, flags)

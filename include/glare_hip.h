@@ -378,6 +378,14 @@ int glare_mdcn_forward_nhwc(const void* x, int x_is_bf16, int x_pitch, int x_off
  * leaner one for bf16 x when every tensor is < 2 GB and kh*kw % 3 == 0.  `flags` & GLARE_MDCN_GENERAL_KERNEL pins the former for
  * this call (a per-call argument: the library keeps no state; tests compare the two kernels on one input with it). */
 #define GLARE_MDCN_GENERAL_KERNEL 1
+/* `flags` & GLARE_MDCN_SINGLE_PASS (round 3): the blended, modulated sample and the filter are each rounded ONCE to the library's
+ * 16-bit activation format (bf16 in libglare_hip.so, IEEE half in libglare_hip_f16.so) and contracted by one MFMA per product with
+ * fp32 accumulation -- the arithmetic of every other convolution on the path -- instead of the split form (two 16-bit halves per
+ * operand, three MFMAs per product, fp32-class).  `weight_packed` must then come from glare_mdcn_pack_weight_single_f32 (half the
+ * bytes: Co*C*kh*kw 16-bit values).  Only where the leaner kernel applies (16-bit x, 3 | kh*kw, tensors < 2 GB), else UNSUPPORTED. */
+#define GLARE_MDCN_SINGLE_PASS 2
+int glare_mdcn_pack_weight_single_f32(const float* weight_oihw, void* packed, int Co, int C, int kh, int kw, int dg,
+                                      glare_stream_t stream);
 
 /* ---- a10: modulated deformable convolution (DCNv2), backward ----------------------------------
  * Drop-in for the pybind function

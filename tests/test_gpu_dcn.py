@@ -98,6 +98,45 @@ def test_fast_and_general_kernels_agree(B, C, H, W, Co, off_scale):
     np.testing.assert_allclose(fast, general, rtol=0, atol=2e-5 * float(np.abs(general).max()))
 
 
+@pytest.mark.parametrize("precision,tol", [("fp16", 1e-3), ("bf16", 8e-3)])
+@pytest.mark.parametrize("B,C,H,W,Co,off_scale", [(2, 128, 13, 21, 128, 3.0), (1, 256, 9, 11, 256, 1.5), (2, 128, 105, 155, 128, 2.0),
+                                                   (1, 256, 105, 155, 256, 1.0)])
+def test_single_pass_form_against_the_split_form(precision, tol, B, C, H, W, Co, off_scale):
+    """GLARE_MDCN_SINGLE_PASS: sample and filter rounded once to the precision's 16-bit format, one MFMA per product.  Against the
+    split (fp32-class) form on the same 16-bit x: the difference is the rounding of the 9 * C products' operands (2^-11 each in
+    half, 2^-8 in bf16), bounded here relative to max|ref|; run-to-run identical; and against the C oracle at the small size."""
+    g = torch.Generator().manual_seed(B * 100 + C + H)
+    with ops.use_precision(precision):
+        dt = ops.act_dtype()
+        x = torch.randn(B, H, W, C, generator=g).to(dt)
+        plane = (H * W + 63) // 64 * 64
+        off = torch.randn(B, 72, H * W, generator=g) * off_scale
+        logit = torch.randn(B, 36, H * W, generator=g)
+        om = torch.zeros(B, 108, plane)
+        om[:, :72, :H * W] = off
+        om[:, 72:, :H * W] = logit
+        w = torch.randn(Co, C, 3, 3, generator=g) * (1.0 / (C * 9) ** 0.5)
+        b = torch.randn(Co, generator=g)
+        split = ops.mdcn_forward_nhwc(x.cuda(), om.cuda(), ops.PackedDcn(w.cuda(), b.cuda(), 4))
+        pd1 = ops.PackedDcn(w.cuda(), b.cuda(), 4, single=True)
+        assert pd1.packed.dtype == dt and pd1.packed.numel() == w.numel()
+        one = ops.mdcn_forward_nhwc(x.cuda(), om.cuda(), pd1)
+        for _ in range(2):
+            assert torch.equal(ops.mdcn_forward_nhwc(x.cuda(), om.cuda(), pd1), one)
+        ref = split.cpu().numpy()
+        err = float(np.abs(one.cpu().numpy() - ref).max()) / float(np.abs(ref).max())
+        print("\n[dcn single pass %s %dx%dx%d] max err / max|ref| = %.2e (bound %.0e)" % (precision, H, W, C, err, tol))
+        assert err <= tol
+        if H * W < 1000:
+            cref = c_ref.dcn_forward(x.float().permute(0, 3, 1, 2).contiguous().numpy(), off.reshape(B, 72, H, W).numpy(),
+                                     torch.sigmoid(logit).reshape(B, 36, H, W).numpy(), w.numpy(), b.numpy(), dg=4)
+            got = one.permute(0, 3, 1, 2).cpu().numpy()
+            assert float(np.abs(got - cref).max()) <= tol * float(np.abs(cref).max())
+        # refusals: the flag needs the leaner kernel (16-bit x) and excludes the general-kernel flag
+        with pytest.raises(RuntimeError):
+            ops.mdcn_forward_nhwc(x.cuda(), om.cuda(), pd1, flags=ops.MDCN_GENERAL_KERNEL)
+
+
 def test_nhwc_bf16_latent_size_against_c_oracle():
     """The pipeline entry at the latent resolution (105 x 155, 254 workgroups in flight) with scattered samples against the
     plain-C oracle: the small cases above fit in a handful of workgroups and cannot see a fault that depends on timing."""
