@@ -318,6 +318,10 @@ extern "C" int glare_conv2d_bf16(const glare_conv_desc* d, glare_stream_t stream
     if (b0 >= 0x7ff00000LL || b1 >= 0x7ff00000LL) return GLARE_ERR_UNSUPPORTED;
     p.in0_bytes = (unsigned)b0;
     p.in1_bytes = (unsigned)b1;
+    const long long br = d->residual ? (long long)p.OH * p.OW * p.rpitch * 2 : 0;   // one image of the residual (the L2 prefetch)
+    p.res_bytes = (br > 0 && br < 0x7ff00000LL && !subpix) ? (unsigned)br : 0u;
+    static const bool no_prefetch = getenv("GLARE_CONV_NO_RES_PREFETCH") != nullptr;
+    if (no_prefetch) p.res_bytes = 0;
   }
   p.tiles_x = cdiv(p.OW, TW); p.tiles_y = 0; p.co_tiles = cdiv(p.Cout, v.tn);  // tiles_y / n_blocks: per variant, in launch()
   p.n_blocks = 0;
