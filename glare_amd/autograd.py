@@ -79,14 +79,18 @@ class Conv2dFn(torch.autograd.Function):
         dres = g16 if (has_res and ctx.needs_input_grad[3]) else None
         dw = db = dx = dx2 = None
         want_w = ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2])
-        implicit = (want_w and k in (1, 3) and stride == 1 and not upsample and not has_x2 and cin_tot % 8 == 0 and cout % 8 == 0
-                    and IMPLICIT_WGRAD)
+        c1 = x.shape[-1]
+        implicit = (want_w and k in (1, 3) and stride == 1 and not upsample and cin_tot % 8 == 0 and cout % 8 == 0 and IMPLICIT_WGRAD
+                    and (not has_x2 or (c1 % 8 == 0 and x2.shape[-1] % 8 == 0)))
         if implicit:
             # the NHWC weight-gradient kernel (no im2col matrix, no transposed copies).  Its fp32 partials grow with the number of
             # (image, strip, row range) splits and one image must stay below 2 GB: beyond either limit it reports
             # GLARE_ERR_UNSUPPORTED / needs a workspace past WGRAD_MAX_WORKSPACE, and the im2col + GEMM form below takes over
             try:
-                dw, db = (T.conv3x3_weight_grad if k == 3 else T.conv1x1_weight_grad)(x, g16, cout)
+                wgrad = T.conv3x3_weight_grad if k == 3 else T.conv1x1_weight_grad
+                dw, db = wgrad(x, g16, cout)
+                if has_x2:      # torch.cat((x, x2), 1) as the conv's input: the filter's input-channel blocks, one launch per source
+                    dw = torch.cat([dw, wgrad(x2, g16, cout)[0]], 1)
                 db = db if has_bias else None
             except _lib.GlareError:
                 implicit = False
@@ -94,7 +98,6 @@ class Conv2dFn(torch.autograd.Function):
             pass
         elif want_w:
             kk = k * k
-            c1 = x.shape[-1]
 
             def build(ldp, ones_row):
                 col = T.im2col_t(x, k, stride, upsample=upsample, ldp=ldp, ones_row=ones_row, rows=cin_tot * kk + 1)

@@ -121,6 +121,43 @@ def test_conv_autograd(cin, cout, k, stride, ups, act, res, bias):
         within(_rel(_nchw(rd.grad), rr.grad), 1e-6)   # measured 0: the residual's gradient is the incoming one, bit for bit
 
 
+@pytest.mark.parametrize("c1,c2,cout,k", [(64, 64, 128, 3), (128, 64, 64, 3), (64, 128, 64, 1)])
+def test_conv_autograd_two_sources(c1, c2, cout, k):
+    """conv(torch.cat((x, x2), 1)) with the concatenation fused into the conv (WarpBlock.offset, deformableDecoder_arch.py:283-288):
+    both data gradients and the filter gradient -- from the NHWC weight-gradient kernel, one launch per source -- against torch
+    fp32 autograd on the same bf16-rounded operands."""
+    import torch.nn.functional as F
+
+    from glare_amd import autograd as A
+
+    g = torch.Generator().manual_seed(c1 + 2 * c2 + k)
+    B, H, W = 2, 18, 28
+    x, x2 = _bf(torch.randn(B, c1, H, W, generator=g)), _bf(torch.randn(B, c2, H, W, generator=g))
+    w = torch.randn(cout, c1 + c2, k, k, generator=g) / ((c1 + c2) * k * k) ** 0.5
+    b = torch.randn(cout, generator=g)
+    xr, x2r = x.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+    wr, br = _bf(w).clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(torch.cat((xr, x2r), 1), wr, br, padding=k // 2)
+    gy = _bf(torch.randn(yr.shape, generator=g))
+    yr.backward(gy)
+    xd, x2d = _nhwc16(x).requires_grad_(True), _nhwc16(x2).requires_grad_(True)
+    wd, bd = w.to(_dev()).requires_grad_(True), b.to(_dev()).requires_grad_(True)
+    for implicit in (True, False):     # the NHWC weight-gradient kernel, then the im2col + GEMM form it replaces
+        for t in (xd, x2d, wd, bd):
+            t.grad = None
+        A.IMPLICIT_WGRAD = implicit
+        try:
+            y = A.conv2d(xd, wd, bd, x2=x2d)
+            y.backward(gy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(_dev()))
+        finally:
+            A.IMPLICIT_WGRAD = True
+        within(_rel(_nchw(y), yr.detach()), 4.3e-3)
+        within(_rel(_nchw(xd.grad), xr.grad), 5.8e-3)
+        within(_rel(_nchw(x2d.grad), x2r.grad), 5.8e-3)
+        within(_rel(wd.grad, wr.grad), 4.7e-3)
+        within(_rel(bd.grad, br.grad), 3.3e-3)
+
+
 def test_small_conv_autograd():
     import torch.nn.functional as F
 
