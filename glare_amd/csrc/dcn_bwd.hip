@@ -189,9 +189,27 @@ __global__ __launch_bounds__(DB_THREADS) void dcn_bwd_data_kernel(const DcnBwdPa
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const float* a_src = goT + (size_t)k0 * DB_PITCH + mt * 32 + l31;
     const float* b_src = p.wtb + ((size_t)s * p.Co + k0) * cpg + nt * 32 + l31;
-    for (int ks = 0; ks < k_len / 2; ++ks) {
-      const int kk = 2 * ks + khalf;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_src[kk * DB_PITCH], b_src[(size_t)kk * cpg], acc, 0, 0, 0);
+    // The B operand comes straight from global memory (L2): eight k-steps are requested together and the next eight while these
+    // are contracted -- issued one by one in front of their MFMA, each of the Co / 2 steps exposed a full L2 round trip
+    // (the loop was ~90 % of the kernel: 1.33 -> see DESIGN.md section 3).
+    constexpr int KB = 8;
+    float bq[2][KB];
+#pragma unroll
+    for (int u = 0; u < KB; ++u) bq[0][u] = b_src[(size_t)(2 * u + khalf) * cpg];
+    for (int ks0 = 0; ks0 < k_len / 2; ks0 += 2 * KB) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int base = ks0 + h * KB;
+        if (base + KB < k_len / 2) {
+#pragma unroll
+          for (int u = 0; u < KB; ++u) bq[h ^ 1][u] = b_src[(size_t)(2 * (base + KB + u) + khalf) * cpg];
+        }
+        float aq[KB];
+#pragma unroll
+        for (int u = 0; u < KB; ++u) aq[u] = a_src[(2 * (base + u) + khalf) * DB_PITCH];
+#pragma unroll
+        for (int u = 0; u < KB; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[u], bq[h][u], acc, 0, 0, 0);
+      }
     }
     float* dst = cgT + (size_t)kpart * cpg * DB_PITCH + (nt * 32 + l31) * DB_PITCH + mt * 32;
 #pragma unroll
@@ -270,12 +288,19 @@ __global__ __launch_bounds__(DB_THREADS) void dcn_bwd_weight_kernel(const DcnBwd
     G.set_pixels(p, pix0, p_end);
     G.issue(p, s);
     __syncthreads();  // previous tile's MFMAs are done with goT / colP
-    for (int i = tid; i < p.Co * DB_PIX; i += DB_THREADS) {
-      const int co = i / DB_PIX, px = i % DB_PIX;
+    {  // gO tile -> LDS: a thread's pixel column is fixed (DB_THREADS % DB_PIX == 0), its rows are requested eight at a time
+      const int px = tid % DB_PIX;
       const long long gp = pix0 + px;
-      float v = 0.f;
-      if (gp < p_end) v = p.gout[((gp / hw_out) * p.Co + co) * p.gout_plane + gp % hw_out];
-      goT[co * DB_PITCH + px] = v;
+      const bool ok = gp < p_end;
+      const float* src = p.gout + ((ok ? gp / hw_out : 0) * p.Co) * p.gout_plane + (ok ? gp % hw_out : 0);
+      constexpr int CSTEP = DB_THREADS / DB_PIX;     // output channels between a thread's consecutive rows
+      for (int co0 = tid / DB_PIX; co0 < p.Co; co0 += 8 * CSTEP) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = ok ? src[(size_t)(co0 + u * CSTEP) * p.gout_plane] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) goT[(co0 + u * CSTEP) * DB_PITCH + px] = v[u];
+      }
     }
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {

@@ -102,6 +102,25 @@ def bench_dcn():
         print("dcn   C=%d %dx%d: %.3f ms  %.1f TFLOP/s (fp32)" % (c, h, w, ms, fl / ms / 1e9))
 
 
+def bench_dcnbwd():
+    """DCNv2 backward at the stage-3 crop (B = 1, 256x256 and its half resolution), through the drop-in of
+    modulated_deform_conv_backward; with and without grad_input (in stage 3 the sampled feature is frozen: no scatter)."""
+    from glare_amd.modules.ops.dcn.deform_conv import deform_conv_ext
+    for c, h, w in ((128, 256, 256), (256, 128, 128)):
+        x = torch.randn(1, c, h, w, device=DEV)
+        off = torch.randn(1, 72, h, w, device=DEV) * 2
+        m = torch.rand(1, 36, h, w, device=DEV)
+        wt = torch.randn(c, c, 3, 3, device=DEV) * 0.02
+        b = torch.zeros(c, device=DEV)
+        go = torch.randn(1, c, h, w, device=DEV)
+        for want_gx in (False, True):
+            gin = torch.zeros_like(x) if want_gx else None
+            goff, gm, gw, gb = torch.zeros_like(off), torch.zeros_like(m), torch.zeros_like(wt), torch.zeros_like(b)
+            ms = timeit(lambda: deform_conv_ext.modulated_deform_conv_backward(x, wt, b, x.new_empty(0), off, m, x.new_empty(0), gin, gw, gb,
+                                                                               goff, gm, go, 3, 3, 1, 1, 1, 1, 1, 1, 1, 4, True))
+            print("dcnbwd C=%d %dx%d grad_input=%d: %.3f ms" % (c, h, w, want_gx, ms))
+
+
 def bench_wgrad():
     """Weight gradient of the 3x3 convs at the stage-2 crop (B = 2, 320x320 and its half / quarter resolutions): csrc/wgrad.hip
     plus the reduction of its split partials."""

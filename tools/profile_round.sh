@@ -22,7 +22,7 @@ python tools/kbench.py > gpurun_out/${tag}_kbench.txt 2>&1
 for prec in bf16 fp16; do for reg in adversarial representative; do
   python tools/parity_probe.py 400 600 11 $prec $reg 2>&1 | grep -v Warn | grep "==\|full path\|ORACLE\|latent_rel" 
 done; done > gpurun_out/${tag}_parity_table.txt 2>&1
-for seed in 12 13; do python tools/parity_probe.py 400 600 $seed fp16 representative 2>&1 | grep -v Warn | grep "==\|full path\|ORACLE\|latent_rel"; done >> gpurun_out/${tag}_parity_table.txt 2>&1
+for seed in 12 13 14 15 16; do python tools/parity_probe.py 400 600 $seed fp16 representative 2>&1 | grep -v Warn | grep "==\|full path\|ORACLE\|latent_rel"; done >> gpurun_out/${tag}_parity_table.txt 2>&1
 for st in stage2 stage3; do
   python tools/train_bench.py $st 20 graph > gpurun_out/${tag}_train_${st}_graph.txt 2>&1
   python tools/train_bench.py $st 10 > gpurun_out/${tag}_train_$st.txt 2>&1
