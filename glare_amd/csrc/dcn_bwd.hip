@@ -191,7 +191,7 @@ __global__ __launch_bounds__(DB_THREADS) void dcn_bwd_data_kernel(const DcnBwdPa
     const float* b_src = p.wtb + ((size_t)s * p.Co + k0) * cpg + nt * 32 + l31;
     // The B operand comes straight from global memory (L2): eight k-steps are requested together and the next eight while these
     // are contracted -- issued one by one in front of their MFMA, each of the Co / 2 steps exposed a full L2 round trip
-    // (the loop was ~90 % of the kernel: 1.33 -> see DESIGN.md section 3).
+    // (1.33 -> 0.41 ms at 1 x 128 x 128 x 256, 0.96 -> 0.39 ms at 1 x 256 x 256 x 128).
     constexpr int KB = 8;
     float bq[2][KB];
 #pragma unroll
@@ -289,6 +289,7 @@ __global__ __launch_bounds__(DB_THREADS) void dcn_bwd_weight_kernel(const DcnBwd
     G.issue(p, s);
     __syncthreads();  // previous tile's MFMAs are done with goT / colP
     {  // gO tile -> LDS: a thread's pixel column is fixed (DB_THREADS % DB_PIX == 0), its rows are requested eight at a time
+       // (one load per loop trip before: 1.28 -> 0.53 ms and 1.01 -> 0.42 ms for the two stage-3 shapes)
       const int px = tid % DB_PIX;
       const long long gp = pix0 + px;
       const bool ok = gp < p_end;
