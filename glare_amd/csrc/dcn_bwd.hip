@@ -346,7 +346,15 @@ __global__ void dcn_bwd_reduce_kernel(const float* __restrict__ partial, float* 
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float s = 0.f;
-  for (int k = 0; k < splits; ++k) s += partial[(size_t)k * n + i];
+  int k = 0;
+  for (; k + 7 < splits; k += 8) {   // eight loads in flight, added in order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(k + u) * n + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; k < splits; ++k) s += partial[(size_t)k * n + i];
   gw[i] += s;  // accumulates into the caller's (zeroed) buffer, as the reference's addmm_ does
 }
 

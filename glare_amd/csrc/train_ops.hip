@@ -468,11 +468,26 @@ __global__ __launch_bounds__(256) void rescale_bwd_reduce_kernel(const bf16_t* _
   const int b = blockIdx.y;
   float d = 0.f, sh = 0.f, sx = 0.f;
   const long long base = (long long)b * n_per_sample;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_per_sample; i += (long long)blocks * 256) {
-    const float x = xw[base + i];
-    d += bf2f(g[base + i]) * x;
-    sh += bf2f(h[base + i]);
-    sx += x;
+  if ((n_per_sample & 7) == 0 && (base & 7) == 0) {   // 8 elements per lane and trip: 16-B loads of g / h, 2 x 16 B of xw
+    const long long n8 = n_per_sample >> 3;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)blocks * 256) {
+      const u32x4 gv = *reinterpret_cast<const u32x4*>(g + base + i * 8), hv = *reinterpret_cast<const u32x4*>(h + base + i * 8);
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(xw + base + i * 8), x1 = *reinterpret_cast<const f32x4*>(xw + base + i * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xa = e < 2 ? x0[2 * e] : x1[2 * e - 4], xb = e < 2 ? x0[2 * e + 1] : x1[2 * e - 3];
+        d += bflo(gv[e]) * xa + bfhi(gv[e]) * xb;
+        sh += bflo(hv[e]) + bfhi(hv[e]);
+        sx += xa + xb;
+      }
+    }
+  } else {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_per_sample; i += (long long)blocks * 256) {
+      const float x = xw[base + i];
+      d += bf2f(g[base + i]) * x;
+      sh += bf2f(h[base + i]);
+      sx += x;
+    }
   }
   d = wave_sum(d); sh = wave_sum(sh); sx = wave_sum(sx);
   if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = d; red[1][threadIdx.x >> 6] = sh; red[2][threadIdx.x >> 6] = sx; }
@@ -482,22 +497,30 @@ __global__ __launch_bounds__(256) void rescale_bwd_reduce_kernel(const bf16_t* _
         (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
 
+// one wave: lane l adds the slices k = l (mod 64) in ascending order, the 64 subtotals are folded by a fixed butterfly
 __global__ void rescale_bwd_finalize_kernel(const float* __restrict__ partial, int B, int blocks, int whole_batch,
                                             float* __restrict__ coef) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (threadIdx.x >= 64 || blockIdx.x != 0) return;
+  const int lane = threadIdx.x;
   double D = 0, Sh = 0, Sx = 0;
   for (int b = 0; b < B; ++b) {
-    if (!whole_batch) D = Sh = Sx = 0;
-    for (int k = 0; k < blocks; ++k) {
-      D += partial[((size_t)b * blocks + k) * 3];
-      Sh += partial[((size_t)b * blocks + k) * 3 + 1];
-      Sx += partial[((size_t)b * blocks + k) * 3 + 2];
+    double d = 0, sh = 0, sx = 0;
+    for (int k = lane; k < blocks; k += 64) {
+      d += partial[((size_t)b * blocks + k) * 3];
+      sh += partial[((size_t)b * blocks + k) * 3 + 1];
+      sx += partial[((size_t)b * blocks + k) * 3 + 2];
     }
-    if (!whole_batch) {
-      coef[b * 3] = (float)(D / Sx); coef[b * 3 + 1] = (float)(Sh / Sx); coef[b * 3 + 2] = (float)(D * Sh / (Sx * Sx));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      d += __shfl_xor(d, o, 64); sh += __shfl_xor(sh, o, 64); sx += __shfl_xor(sx, o, 64);
+    }
+    if (whole_batch) {
+      D += d; Sh += sh; Sx += sx;
+    } else if (lane == 0) {
+      coef[b * 3] = (float)(d / sx); coef[b * 3 + 1] = (float)(sh / sx); coef[b * 3 + 2] = (float)(d * sh / (sx * sx));
     }
   }
-  if (whole_batch)
+  if (whole_batch && lane == 0)
     for (int b = 0; b < B; ++b) {
       coef[b * 3] = (float)(D / Sx); coef[b * 3 + 1] = (float)(Sh / Sx); coef[b * 3 + 2] = (float)(D * Sh / (Sx * Sx));
     }
@@ -805,9 +828,11 @@ extern "C" int glare_mix_backward_dev_bf16(const void* g, const void* a, const v
   return glare_reduce_parts_f32(static_cast<const float*>(workspace), blocks, 1, 1.f, dw_out, 0, stream);
 }
 
+constexpr int RESCALE_BWD_BLOCKS = 512;   // slices per sample of the mean-rescale backward's sums (fixed: the order of the sums is)
+
 extern "C" size_t glare_mean_rescale_backward_workspace_bytes(int B, long long n_per_sample) {
   if (B <= 0 || n_per_sample <= 0) return 0;
-  return ((size_t)B * 64 * 3 + (size_t)B * 3) * sizeof(float);
+  return ((size_t)B * RESCALE_BWD_BLOCKS * 3 + (size_t)B * 3) * sizeof(float);
 }
 
 extern "C" int glare_mean_rescale_backward_bf16(const void* g, const void* h, const float* xw, void* gh, float* gxw, int B,
@@ -816,10 +841,10 @@ extern "C" int glare_mean_rescale_backward_bf16(const void* g, const void* h, co
   if (!g || !h || !xw || !gh || !gxw || B <= 0 || n_per_sample <= 0) return GLARE_ERR_INVALID;
   if (!workspace || workspace_bytes < glare_mean_rescale_backward_workspace_bytes(B, n_per_sample)) return GLARE_ERR_WORKSPACE;
   float* partial = static_cast<float*>(workspace);
-  float* coef = partial + (size_t)B * 64 * 3;
-  hipLaunchKernelGGL(rescale_bwd_reduce_kernel, dim3(64, B), dim3(256), 0, ST(stream), static_cast<const bf16_t*>(g),
-                     static_cast<const bf16_t*>(h), xw, n_per_sample, 64, partial);
-  hipLaunchKernelGGL(rescale_bwd_finalize_kernel, dim3(1), dim3(64), 0, ST(stream), partial, B, 64, whole_batch_mean, coef);
+  float* coef = partial + (size_t)B * RESCALE_BWD_BLOCKS * 3;
+  hipLaunchKernelGGL(rescale_bwd_reduce_kernel, dim3(RESCALE_BWD_BLOCKS, B), dim3(256), 0, ST(stream), static_cast<const bf16_t*>(g),
+                     static_cast<const bf16_t*>(h), xw, n_per_sample, RESCALE_BWD_BLOCKS, partial);
+  hipLaunchKernelGGL(rescale_bwd_finalize_kernel, dim3(1), dim3(64), 0, ST(stream), partial, B, RESCALE_BWD_BLOCKS, whole_batch_mean, coef);
   const long long total = (long long)B * n_per_sample;
   hipLaunchKernelGGL(rescale_bwd_apply_kernel, dim3((unsigned)cdivll(total, 256)), dim3(256), 0, ST(stream), static_cast<const bf16_t*>(g),
                      coef, n_per_sample, total, static_cast<bf16_t*>(gh), gxw);
