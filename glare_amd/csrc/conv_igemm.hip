@@ -33,35 +33,46 @@ namespace {
 // [co_tile][stage][tap][kstep][khalf][TN][8], zero-filled outside Cout / Cin.
 // dgrad != 0: `w` is the FORWARD filter [Cin_real][Cout][KS][KS] of which the data-gradient filter is wanted
 // (w'[co][ci][tap] = w[ci][co][KK-1-tap], input channels ci >= Cin_real zero): no flip/transpose/pad pass on the host.
-__device__ __forceinline__ void pack_weight_elem(const float* __restrict__ w, a16_t* __restrict__ out, long long i, int Cout, int Cin,
-                                                 int KS, int TN, int KSTEPS, int n_stages, int dgrad, int Cin_real) {
-  long long t = i;
-  const int e = t % 8; t /= 8;
+// One thread = one 16-B chunk (8 consecutive input channels of one (tap, output channel)): the index arithmetic once per chunk.
+__device__ __forceinline__ void pack_weight_chunk(const float* __restrict__ w, a16_t* __restrict__ out, long long chunk, int Cout, int Cin,
+                                                  int KS, int TN, int KSTEPS, int n_stages, int dgrad, int Cin_real) {
+  long long t = chunk;
   const int n = t % TN; t /= TN;
   const int khalf = t % 2; t /= 2;
   const int ks = t % KSTEPS; t /= KSTEPS;
-  const int tap = t % (KS * KS); t /= (KS * KS);
+  const int KK = KS * KS;
+  const int tap = t % KK; t /= KK;
   const int s = t % n_stages; t /= n_stages;
   const int ct = (int)t;
   const int co = ct * TN + n;
-  const int ci = (s * KSTEPS + ks) * 16 + khalf * 8 + e;
-  float v = 0.f;
-  if (dgrad) {
-    if (co < Cout && ci < Cin_real) v = w[((size_t)ci * Cout + co) * KS * KS + (KS * KS - 1 - tap)];
-  } else if (co < Cout && ci < Cin) {
-    v = w[((size_t)co * Cin + ci) * KS * KS + tap];
+  const int ci0 = (s * KSTEPS + ks) * 16 + khalf * 8;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ci = ci0 + e;
+    v[e] = 0.f;
+    if (dgrad) {
+      if (co < Cout && ci < Cin_real) v[e] = w[((size_t)ci * Cout + co) * KK + (KK - 1 - tap)];
+    } else if (co < Cout && ci < Cin) {
+      v[e] = w[((size_t)co * Cin + ci) * KK + tap];
+    }
   }
-  out[i] = f2a(v);
+  u32x4 pk;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) pk[e] = pack_a2(v[2 * e], v[2 * e + 1]);
+  *reinterpret_cast<u32x4*>(out + chunk * 8) = pk;
 }
+
+constexpr int PACK_BLOCK_ELEMS = 2048;   // packed elements per 256-thread block (glare_pack_job.block_begin counts these)
 
 // blockIdx.y = filter of a batch of equally shaped filters (consecutive in `w`, consecutive packed images in `out`).
 __global__ void pack_weight_kernel(const float* __restrict__ w, a16_t* __restrict__ out, int Cout, int Cin, int KS,
                                    int TN, int KSTEPS, int n_stages, long long total, int dgrad, int Cin_real) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
+  const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c * 8 >= total) return;
   w += (size_t)blockIdx.y * (dgrad ? (size_t)Cin_real * Cout : (size_t)Cout * Cin) * KS * KS;
   out += (size_t)blockIdx.y * total;
-  pack_weight_elem(w, out, i, Cout, Cin, KS, TN, KSTEPS, n_stages, dgrad, Cin_real);
+  pack_weight_chunk(w, out, c, Cout, Cin, KS, TN, KSTEPS, n_stages, dgrad, Cin_real);
 }
 
 // Many filters of DIFFERENT shapes in one launch (the trainable convs of a training step, re-packed after the optimizer update):
@@ -73,14 +84,15 @@ __global__ void pack_weight_multi_kernel(const glare_pack_job* __restrict__ jobs
     if (jobs[mid].block_begin <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
   }
   const glare_pack_job j = jobs[lo];
-  const long long i = ((long long)blockIdx.x - j.block_begin) * 256 + threadIdx.x;
-  if (i >= j.total) return;
+  const long long c = ((long long)blockIdx.x - j.block_begin) * 256 + threadIdx.x;   // 16-B chunk of this job
+  if (c * 8 >= j.total) return;
   if (j.kind == GLARE_PACK_PLAIN_BF16) {
-    static_cast<a16_t*>(j.out)[i] = f2a(j.w[i]);
+    a16_t* o = static_cast<a16_t*>(j.out);
+    for (long long i = c * 8; i < min(j.total, c * 8 + 8); ++i) o[i] = f2a(j.w[i]);
     return;
   }
-  pack_weight_elem(j.w, static_cast<a16_t*>(j.out), i, j.cout, j.cin, j.ksize, j.tn, j.ksteps, j.n_stages, j.kind == GLARE_PACK_DGRAD,
-                   j.cin_real);
+  pack_weight_chunk(j.w, static_cast<a16_t*>(j.out), c, j.cout, j.cin, j.ksize, j.tn, j.ksteps, j.n_stages, j.kind == GLARE_PACK_DGRAD,
+                    j.cin_real);
 }
 
 // Sub-pixel upsample filters: [phase = a*2+b][co_tile][stage][tap = r*2+c][khalf][TN][8] (KSTEPS = 1), where tap (r, c)
@@ -186,7 +198,7 @@ extern "C" int glare_conv2d_pack_weight(const float* w_oihw, int cout, int cin_t
   const Variant v = pick_variant(ksize, cout);
   const int kc = 16 * v.ksteps;
   const int stages = (cin_total + kc - 1) / kc;
-  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + PACK_BLOCK_ELEMS - 1) / PACK_BLOCK_ELEMS)), dim3(256), 0, (hipStream_t)stream,
                      w_oihw, (a16_t*)packed_bf16, cout, cin_total, ksize, v.tn, v.ksteps, stages, total, 0, cin_total);
   return glare_launch_status();
 }
@@ -248,7 +260,7 @@ extern "C" int glare_conv2d_pack_weight_batched(const float* w_boihw, int batch,
   if (total <= 0) return GLARE_ERR_UNSUPPORTED;
   const Variant v = pick_variant(ksize, oc, cout_tile);
   const int kc = 16 * v.ksteps;
-  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256), batch), dim3(256), 0, (hipStream_t)stream, w_boihw,
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + PACK_BLOCK_ELEMS - 1) / PACK_BLOCK_ELEMS), batch), dim3(256), 0, (hipStream_t)stream, w_boihw,
                      (a16_t*)packed_bf16, oc, ic, ksize, v.tn, v.ksteps, (ic + kc - 1) / kc, total, dg ? 1 : 0, dg ? cout : ic);
   return glare_launch_status();
 }
@@ -262,7 +274,7 @@ extern "C" int glare_conv2d_pack_weight_dgrad(const float* w_oihw, int cout, int
   const Variant v = pick_variant(ksize, cin);
   const int kc = 16 * v.ksteps;
   const int stages = (cout_padded + kc - 1) / kc;
-  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_oihw,
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + PACK_BLOCK_ELEMS - 1) / PACK_BLOCK_ELEMS)), dim3(256), 0, (hipStream_t)stream, w_oihw,
                      (a16_t*)packed_bf16, cin, cout_padded, ksize, v.tn, v.ksteps, stages, total, 1, cout);
   return glare_launch_status();
 }

@@ -128,6 +128,9 @@ def packed_conv_batch(weights, biases=None, dgrad_pad=None, cout_tile=0):
     return out
 
 
+PACK_BLOCK_ELEMS = 2048   # GLARE_PACK_BLOCK_ELEMS (include/glare_hip.h)
+
+
 class _PackJob(ctypes.Structure):   # glare_pack_job (include/glare_hip.h)
     _fields_ = [("w", ctypes.c_void_p), ("out", ctypes.c_void_p), ("total", ctypes.c_longlong), ("block_begin", ctypes.c_longlong),
                 ("cout", ctypes.c_int), ("cin", ctypes.c_int), ("ksize", ctypes.c_int), ("tn", ctypes.c_int), ("ksteps", ctypes.c_int),
@@ -186,7 +189,7 @@ class PackCache:
                     check(lib.glare_conv2d_pack_job_init(ctypes.byref(j), _i(kind), ptr(pc._param), _i(cout), _i(cin), _i(kh),
                                                          _i(dgrad_pad or 0), _i(cout_tile), ptr(dst)), "glare_conv2d_pack_job_init")
                     j.block_begin = begin
-                    begin += (j.total + 255) // 256
+                    begin += (j.total + PACK_BLOCK_ELEMS - 1) // PACK_BLOCK_ELEMS
                     jobs.append(j)
             arr = (_PackJob * len(jobs))(*jobs)
             host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)

@@ -138,14 +138,15 @@ int glare_conv2d_pack_weight_dgrad(const float* w_oihw, int cout, int cin, int k
  * are refreshed after the optimizer update (the reference re-reads its fp32 weights through cuDNN every step; here the MFMA kernels
  * read stage-ordered bf16 images).  A job = one packed image: glare_conv2d_pack_job_init fills its geometry (kind FORWARD as
  * glare_conv2d_pack_weight, DGRAD as glare_conv2d_pack_weight_dgrad with dgrad_cout_padded, PLAIN_BF16 as
- * glare_conv1x1_ws_pack_weight); the caller sets block_begin = sum over the earlier jobs of ceil(total / 256), copies the table to
+ * glare_conv1x1_ws_pack_weight); the caller sets block_begin = sum over the earlier jobs of ceil(total / GLARE_PACK_BLOCK_ELEMS), copies the table to
  * the device and launches it with the total block count. */
 enum { GLARE_PACK_FORWARD = 0, GLARE_PACK_DGRAD = 1, GLARE_PACK_PLAIN_BF16 = 2 };
+#define GLARE_PACK_BLOCK_ELEMS 2048   /* packed elements per block of glare_conv2d_pack_multi (8 per thread: one 16-B chunk) */
 typedef struct glare_pack_job {
   const float* w;          /* fp32 OIHW filter */
   void* out;               /* packed bf16 image */
   long long total;         /* elements of the packed image */
-  long long block_begin;   /* first 256-element block of this job in the launch */
+  long long block_begin;   /* first block (of GLARE_PACK_BLOCK_ELEMS packed elements) of this job in the launch */
   int cout, cin, ksize;    /* of the PACKED conv (DGRAD: outputs = the forward conv's inputs) */
   int tn, ksteps, n_stages, cin_real, kind;
 } glare_pack_job;
