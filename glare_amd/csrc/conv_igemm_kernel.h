@@ -13,7 +13,7 @@
 #define CONV_TILE16 0
 #endif
 #ifndef CONV_ABL_EPI
-#define CONV_ABL_EPI 0   // timing ablations only (tools/ablate.sh; wrong results): 1 residual add -> one xor, 4 no output stores, 8 no epilogue at all
+#define CONV_ABL_EPI 0   // timing ablations only (tools/ablate.sh; wrong results): 1 residual add -> one xor, 2 phase 1 as a transposed layout would have it, 4 no output stores, 8 no epilogue at all
 #endif
 
 
@@ -453,6 +453,17 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
         const float bv = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
         static_for<HT>([&](auto ic) {
           constexpr int il = decltype(ic)::value;
+#if CONV_ABL_EPI & 2   // timing only: what a transposed accumulator layout would leave of phase 1 (4 x 8-B LDS writes per tile, no swaps)
+          {
+            constexpr int i2 = half * HT + il;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+              const u32x2 w2 = {pack_a2(acc[i2][j][4 * q4], acc[i2][j][4 * q4 + 1]), pack_a2(acc[i2][j][4 * q4 + 2], acc[i2][j][4 * q4 + 3])};
+              *reinterpret_cast<u32x2*>(slab + (il * 32 + ncol) * ROWB + (j * 32 + 8 * q4 + 4 * rhalf) * 2) = w2;
+            }
+          }
+          if (bv == 12345.f)
+#endif
 #pragma unroll
           for (int t = 0; t < 8; ++t) {
             constexpr int i = half * HT + il;
