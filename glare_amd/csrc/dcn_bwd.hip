@@ -150,6 +150,9 @@ __global__ __launch_bounds__(DB_THREADS) void dcn_bwd_data_kernel(const DcnBwdPa
   float* goT = reinterpret_cast<float*>(smem);               // [Co][DB_PITCH]
   float* cgT = goT + (size_t)p.Co * DB_PITCH;                // [KSPLIT][cpg][DB_PITCH]
   const int cpg = p.cpg, K = p.kh * p.kw, n_stages = p.dg * K;
+  // grad_input scatter plan of the stage: per pixel the 4 corner pixels (-1: dropped) and corner weight x modulation
+  long long* scat_pix = reinterpret_cast<long long*>(cgT + (size_t)KSPLIT * cpg * DB_PITCH + (((size_t)KSPLIT * cpg * DB_PITCH) & 1));
+  float* scat_w = reinterpret_cast<float*>(scat_pix + DB_PIX * 4);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // XCD-aware tile order (dcn.hip): XCD j takes the j-th contiguous eighth of the pixel tiles, so the rows a tile gathers from
@@ -232,13 +235,13 @@ __global__ __launch_bounds__(DB_THREADS) void dcn_bwd_data_kernel(const DcnBwdPa
         const float top = cg * q.m;
         goh += (q.hw * (v3 - v1) + q.lw * (v4 - v2)) * top;   // d/dh: kernel.cu:543-553
         gow += (q.hh * (v2 - v1) + q.lh * (v4 - v3)) * top;   // d/dw: kernel.cu:554-564
-        if (p.gx) {  // grad_input is dense NHWC [pixel][C]
-          if (q.ok[0]) atomicAdd(p.gx + q.pix[0] * p.C + q.cb + e, w1 * top);
-          if (q.ok[1]) atomicAdd(p.gx + q.pix[1] * p.C + q.cb + e, w2 * top);
-          if (q.ok[2]) atomicAdd(p.gx + q.pix[2] * p.C + q.cb + e, w3 * top);
-          if (q.ok[3]) atomicAdd(p.gx + q.pix[3] * p.C + q.cb + e, w4 * top);
-        }
       }
+      if (p.gx && G.ch[i] == 0) {   // the scatter plan of this pixel (one lane per pixel writes it)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) scat_pix[G.px[i] * 4 + c] = (G.valid[i] && q.ok[c]) ? q.pix[c] : -1;
+        scat_w[G.px[i] * 4] = w1 * q.m; scat_w[G.px[i] * 4 + 1] = w2 * q.m; scat_w[G.px[i] * 4 + 2] = w3 * q.m; scat_w[G.px[i] * 4 + 3] = w4 * q.m;
+      }
+      {
       // reduce over the nch channel chunks of this pixel (adjacent lanes)
       for (int o = 1; o < nch; o <<= 1) {
         mval += __shfl_xor(mval, o, 64);
@@ -252,6 +255,27 @@ __global__ __launch_bounds__(DB_THREADS) void dcn_bwd_data_kernel(const DcnBwdPa
         go[0] = goh;
         go[hw_out] = gow;
         p.gmask[((long long)G.b[i] * p.dg * K + (long long)g * K + tap) * hw_out + pin] = mval;
+      }
+      }
+    }
+    if (p.gx) {
+      // grad_input (kernel.cu:677-691), channel-major: lane = channel of the group, so one atomic instruction adds whole
+      // 128-B / 256-B runs of one or two corner pixels.  (Issued from the gather layout -- a lane = 8 channels of a pixel, one
+      // channel per instruction -- every instruction touched 16 pixels x 4 scattered dwords: 7.96 ms at 1 x 256 x 256 x 128 and
+      // 4.57 ms at 1 x 128 x 128 x 256 for the whole backward with grad_input, against 0.91 / 0.96 ms without.)
+      __syncthreads();                       // the scatter plan and every wave's cg tile are complete
+      const int ppi = 64 / cpg;              // pixels per wave instruction (cpg = 32: 2, cpg = 64: 1)
+      const int ch = lane % cpg, g = s / K;
+      float* gxc = p.gx + (size_t)g * cpg + ch;
+      for (int it = 0; it < DB_PIX / (4 * ppi); ++it) {
+        const int px = (it * 4 + wave) * ppi + lane / cpg;
+        float cg = cgT[ch * DB_PITCH + px];
+        if (KSPLIT == 2) cg += cgT[(cpg + ch) * DB_PITCH + px];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const long long pc = scat_pix[px * 4 + c];
+          if (pc >= 0) atomicAdd(gxc + pc * p.C, scat_w[px * 4 + c] * cg);
+        }
       }
     }
     __syncthreads();
@@ -446,7 +470,8 @@ extern "C" int glare_mdcn_backward_f32(const float* x, const float* offset, cons
   hipLaunchKernelGGL(dcn_bwd_pack_kernel, dim3((unsigned)((ws + 255) / 256)), dim3(256), 0, stream, weight, wtb, Co, C, K, dg);
 
   const unsigned blocks = (unsigned)((p.total_pix + DB_PIX - 1) / DB_PIX);
-  const size_t lds_data = ((size_t)Co * DB_PITCH + (size_t)(cpg == 32 ? 2 : 1) * cpg * DB_PITCH) * sizeof(float);
+  const size_t lds_data = ((size_t)Co * DB_PITCH + (size_t)(cpg == 32 ? 2 : 1) * cpg * DB_PITCH + 2) * sizeof(float) +
+                          (size_t)DB_PIX * 4 * (sizeof(long long) + sizeof(float));   // + the grad_input scatter plan
   const size_t lds_w = ((size_t)Co * DB_PITCH + (size_t)DB_PIX * (cpg + 1)) * sizeof(float);
   const dim3 wgrid(dg * K, DB_SPLITS);
 #define DB_ATTR(k, bytes)                                                                                              \
