@@ -18,18 +18,26 @@
 
 namespace {
 
-constexpr int VQ_THREADS = 256;
+constexpr int VQ_THREADS = 1024;   // 16 waves: 4 per SIMD hide the broadcast-read latency of the scan (one wave per SIMD ran 100
+                                   // cycles per code for ~40 cycles of arithmetic)
 constexpr int VQ_TPT = 2;          // tokens per lane
 constexpr int VQ_CHUNK = 8192;     // codes resident in LDS at once (x 16 B = 128 KB)
 
+// A workgroup = `slots` token lanes (a multiple of 64, TPT tokens each) x `parts` = VQ_THREADS / slots code ranges: thread
+// (part, slot) scans the part-th share of every resident chunk for its tokens, first minimum wins inside its (ascending) sequence,
+// and the parts are merged by (distance, index) -- the smaller index wins a tie, which is the sequential scan's "first minimum
+// wins" whatever the order of the merge.  Few tokens (the training crops: 4 096 - 12 800) take few slots and many parts, so the
+// launch still fills the chip: the scan of one workgroup was 394 us whether it served 130 200 tokens or 4 096.
 template <int TPT>
 __global__ __launch_bounds__(VQ_THREADS, 1) void vq_nearest_kernel(
     const float* __restrict__ z, const float* __restrict__ codebook, long long n_tokens,
-    int n_codes, long long* __restrict__ idx_out, float* __restrict__ zq_out) {
+    int n_codes, long long* __restrict__ idx_out, float* __restrict__ zq_out, int slots) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x4* cb = reinterpret_cast<f32x4*>(smem);
 
-  const long long t0 = ((long long)blockIdx.x * VQ_THREADS + threadIdx.x) * TPT;
+  const int parts = VQ_THREADS / slots;
+  const int part = threadIdx.x / slots, slot = threadIdx.x % slots;   // part is wave-uniform (slots % 64 == 0)
+  const long long t0 = ((long long)blockIdx.x * slots + slot) * TPT;
   float z0[TPT], z1[TPT], z2[TPT], zz[TPT], best[TPT];
   int bidx[TPT];
 #pragma unroll
@@ -42,7 +50,7 @@ __global__ __launch_bounds__(VQ_THREADS, 1) void vq_nearest_kernel(
     zz[t] = __fadd_rn(__fadd_rn(__fmul_rn(z0[t], z0[t]), __fmul_rn(z1[t], z1[t])),
                       __fmul_rn(z2[t], z2[t]));
     best[t] = __builtin_inff();
-    bidx[t] = 0;
+    bidx[t] = 0x7fffffff;
   }
 
   for (int c0 = 0; c0 < n_codes; c0 += VQ_CHUNK) {
@@ -57,8 +65,9 @@ __global__ __launch_bounds__(VQ_THREADS, 1) void vq_nearest_kernel(
       cb[c] = v;
     }
     __syncthreads();
+    const int cb0 = (int)((long long)nc * part / parts), cb1 = (int)((long long)nc * (part + 1) / parts);
 #pragma unroll 4
-    for (int c = 0; c < nc; ++c) {
+    for (int c = cb0; c < cb1; ++c) {
       const f32x4 e = cb[c];  // wave-uniform address: one broadcast ds_read_b128
 #pragma unroll
       for (int t = 0; t < TPT; ++t) {
@@ -72,13 +81,34 @@ __global__ __launch_bounds__(VQ_THREADS, 1) void vq_nearest_kernel(
     }
   }
 
+  if (parts > 1) {   // merge the parts' candidates: smaller distance, then smaller index
+    __syncthreads();                                   // every scan is done with the codebook image: its LDS becomes the exchange
+    float* xb = reinterpret_cast<float*>(smem);        // [part][t][slot] distances, then the indices
+    int* xi = reinterpret_cast<int*>(smem) + VQ_THREADS * TPT;
+#pragma unroll
+    for (int t = 0; t < TPT; ++t) {
+      xb[(part * TPT + t) * slots + slot] = best[t];
+      xi[(part * TPT + t) * slots + slot] = bidx[t];
+    }
+    __syncthreads();
+    if (part != 0) return;
+#pragma unroll
+    for (int t = 0; t < TPT; ++t)
+      for (int k = 1; k < parts; ++k) {
+        const float d = xb[(k * TPT + t) * slots + slot];
+        const int i = xi[(k * TPT + t) * slots + slot];
+        if (d < best[t] || (d == best[t] && i < bidx[t])) { best[t] = d; bidx[t] = i; }
+      }
+  }
+
 #pragma unroll
   for (int t = 0; t < TPT; ++t) {
     const long long tok = t0 + t;
     if (tok < n_tokens) {
-      idx_out[tok] = (long long)bidx[t];
+      const int bi = bidx[t] == 0x7fffffff ? 0 : bidx[t];   // no distance compared below +inf (all NaN): index 0, as the one-range scan gave
+      idx_out[tok] = (long long)bi;
       if (zq_out) {
-        const float* e = codebook + (long long)bidx[t] * 3;
+        const float* e = codebook + (long long)bi * 3;
         zq_out[tok * 3 + 0] = e[0];
         zq_out[tok * 3 + 1] = e[1];
         zq_out[tok * 3 + 2] = e[2];
@@ -97,14 +127,20 @@ extern "C" int glare_vq_nearest_f32(const float* z_nhwc, const float* codebook, 
   if (n_tokens == 0) return GLARE_OK;          // empty batch: nothing to do, pointers may be NULL
   if (!z_nhwc || !codebook || !idx_i64) return GLARE_ERR_INVALID;
   const size_t lds = (size_t)VQ_CHUNK * sizeof(f32x4);
+  // token lanes per workgroup: as many as fill the chip's 256 CUs once, between one wave and a quarter of the workgroup (so that
+  // at least 4 code ranges keep 4 waves on every SIMD)
+  long long lanes = (n_tokens + VQ_TPT - 1) / VQ_TPT;
+  int slots = (int)(((lanes + 255) / 256 + 63) / 64 * 64);
+  if (slots < 64) slots = 64;
+  if (slots > VQ_THREADS / 4) slots = VQ_THREADS / 4;
   // per call, not cached: the attribute is per device and the library keeps no state
   if (hipFuncSetAttribute((const void*)vq_nearest_kernel<VQ_TPT>,
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GLARE_ERR_LAUNCH;
-  const long long per_block = (long long)VQ_THREADS * VQ_TPT;
+  const long long per_block = (long long)slots * VQ_TPT;
   const long long blocks = (n_tokens + per_block - 1) / per_block;
   if (blocks > 0x7fffffffLL) return GLARE_ERR_INVALID;
   hipLaunchKernelGGL(vq_nearest_kernel<VQ_TPT>, dim3((unsigned)blocks), dim3(VQ_THREADS), lds,
-                     (hipStream_t)stream, z_nhwc, codebook, n_tokens, n_codes, idx_i64, zq_nhwc);
+                     (hipStream_t)stream, z_nhwc, codebook, n_tokens, n_codes, idx_i64, zq_nhwc, slots);
   return glare_launch_status();
 }
