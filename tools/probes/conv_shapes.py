@@ -7,13 +7,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 
 import bench
-from glare_amd import ops, _lib
+from glare_amd import ops
 
 dev = torch.device("cuda", 0)
 netG, net_vq = bench.build_nets(dev)
 lr = bench.build_inputs(8, dev)
 recs = []
-real = _lib._F16Lib.__getattr__ if hasattr(_lib, "_F16Lib") else None
 orig_conv2d = ops.conv2d
 
 
@@ -36,7 +35,6 @@ with torch.no_grad():
         netG.reverse_flow_nhwc(net_vq, lr)
     torch.cuda.synchronize()
     ops.conv2d = conv2d
-    import glare_amd.modules.encoder_decoder as ed
     for it in range(5):
         netG.reverse_flow_nhwc(net_vq, lr)
     torch.cuda.synchronize()
