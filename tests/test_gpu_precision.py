@@ -252,7 +252,7 @@ BOUNDS = {
     (400, "adversarial", "bf16"): (0.970, 27.6, 3.4),        # 0.98415, 30.60 dB, 1.70 dB
     (400, "adversarial", "fp16"): (0.9970, 37.5, 0.43),      # 0.99853, 40.57 dB, 0.22 dB
     (400, "representative", "bf16"): (0.30, 32.2, 1.07),     # 0.47637, 35.19 dB, 0.53 dB
-    (400, "representative", "fp16"): (0.880, 43.1, 0.05),    # 0.94015, 46.11 dB, 0.041 dB (seeds 12 / 13: 0.041 / 0.036): BASELINE's 0.05
+    (400, "representative", "fp16"): (0.880, 43.1, 0.05),    # 0.94015, 46.16 dB, 0.041 dB: BASELINE's 0.05 (other scenes: the next test)
     (100, "adversarial", "bf16"): (0.950, 25.5, 5.1),        # 0.97576, 28.48 dB, 2.54 dB
     (100, "adversarial", "fp16"): (0.9969, 35.1, 0.71),      # 0.99848, 38.12 dB, 0.35 dB
     (100, "representative", "bf16"): (0.30, 33.4, 0.76),     # 0.51742, 36.47 dB, 0.38 dB
@@ -305,6 +305,29 @@ def test_end_to_end_mid_size_both_precisions(regime, capsys):
 def test_end_to_end_full_size_both_precisions(regime, capsys):
     """BASELINE shape (400x600, N = 16275 tokens): one ~30 s oracle run per regime."""
     check_e2e(regime, 400, 600, 11, capsys)
+
+
+@pytest.mark.parametrize("seed,measured", [(13, 0.0544), (15, 0.0655)])
+def test_end_to_end_full_size_scenes_that_miss_the_tolerance(seed, measured, capsys):
+    """What the 0.05 dB of the test above is worth: over six scenes (tools/parity_probe.py, seeds 11-16, profiles/r03_parity_table.txt)
+    the default path's full-path |dPSNR vs GT| is 0.033-0.066 dB, mean 0.048 -- AT BASELINE.json's tolerance, not inside it.  These
+    are the two scenes of the six that miss it; they are held to 1.3x what they measure, the token agreement and the post-VQ half
+    (the oracle's indices: every scene <= 0.003 dB) to the bounds of the asserted scene."""
+    og, ov, pg, pv, lr, ref = setup("representative", 400, 600, seed)
+    with torch.no_grad():
+        r = pg.reverse_flow_nhwc(pv, lr.cuda(), precision="fp16")
+        with ops.use_precision("fp16"):
+            _, _, feats_i = pv.decode_nhwc(ops.nchw_to_nhwc(ref["latent"].cuda(), bf16=False), want_image=False)
+            out_i = pg.deformable_decoder.forward_nhwc(r["latent"], feats_i, r["enc"]["mid_feat"]).cpu()
+    agree = float((r["indices"].cpu() == ref["indices"]).float().mean())
+    full, forced = e2e_metrics(r["out"].cpu(), ref["out"], 400), e2e_metrics(out_i, ref["out"], 400)
+    with capsys.disabled():
+        print("\n[e2e 400x600 representative fp16 seed %d] index agreement %.5f | full path: PSNR(ours,oracle) %.2f dB, |dPSNR vs GT| %.4f dB"
+              " (recorded %.4f) | oracle's indices: %.2f dB, %.4f dB" % (seed, agree, full["psnr_vs_oracle"], full["delta"], measured,
+                                                                          forced["psnr_vs_oracle"], forced["delta"]))
+    assert agree >= 0.880 and full["psnr_vs_oracle"] >= 43.1
+    assert full["delta"] <= 1.3 * measured, full
+    assert forced["delta"] <= 0.05 and forced["psnr_vs_oracle"] >= 60.0, forced
 
 
 def test_fp16_batch_of_8_equals_eight_single_runs():
