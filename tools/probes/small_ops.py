@@ -46,6 +46,8 @@ class Spy(TorchDispatchMode):
                 if "glare_amd" in fr.filename and "probes" not in fr.filename:
                     where = "%s:%d %s" % (fr.filename.split("glare_amd/")[-1], fr.lineno, fr.name)
                     break
+            if where == "<autograd>" and name in ("copy_", "mul", "add") and args and torch.is_tensor(args[0]):
+                where = "<autograd> %s %s" % (tuple(args[0].shape), str(args[0].dtype).replace("torch.", ""))
             agg[(name, where)] += 1
         return func(*args, **(kwargs or {}))
 
