@@ -56,6 +56,15 @@ def main():
         pd = ops.PackedDcn((torch.randn(c, c, 3, 3, generator=g) * 0.02).to(DEV), torch.zeros(c, device=DEV), 4)
         total += check("dcn forward C=%d %dx%d" % (c, h, w), lambda: ops.mdcn_forward_nhwc(x, om, pd))
         total += check("dcn forward (general kernel) C=%d" % c, lambda: ops.mdcn_forward_nhwc(x, om, pd, flags=ops.MDCN_GENERAL_KERNEL))
+        with ops.use_precision("fp16"):     # the single-pass form of the fp16 inference precision (128-pixel workgroups at C = 128)
+            xh = x.to(torch.float16)
+            pd1 = ops.PackedDcn((torch.randn(c, c, 3, 3, generator=g) * 0.02).to(DEV), torch.zeros(c, device=DEV), 4, single=True)
+            total += check("dcn forward single pass fp16 C=%d" % c, lambda: ops.mdcn_forward_nhwc(xh, om, pd1))
+    # the flow's grouped launch: 24 filters of one shape on channel slices of one tensor
+    xg = torch.randn(B, 105, 155, 1536, generator=g).to(torch.bfloat16).to(DEV)
+    pcs = ops.packed_conv_batch((torch.randn(24, 64, 64, 1, 1, generator=g) * 0.1).to(DEV), torch.randn(24, 64, generator=g).to(DEV))
+    og = torch.empty_like(xg)
+    total += check("grouped conv 24 x (64->64 1x1)", lambda: ops.conv2d_grouped(xg, pcs, cin=64, in_step=64, out=og, out_step=64, act="relu").clone())
     x = torch.randn(B, 420, 620, 128, generator=g).to(torch.bfloat16).to(DEV)
     gm, bt = torch.ones(128, device=DEV), torch.zeros(128, device=DEV)
     total += check("groupnorm 128 420x620", lambda: ops.groupnorm(x, gm, bt))
