@@ -8,6 +8,7 @@ streams are then shared between torch and the kernels.
 import ctypes
 import os
 import re
+import threading
 
 import torch  # noqa: F401  (must precede the CDLL load, see module docstring)
 
@@ -19,10 +20,16 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "glare_hip.h")
 _lib = None
 _lib_f16 = None
 # The 16-bit activation / filter format of the kernels in use: "bf16" (libglare_hip.so) or "fp16" (libglare_hip_f16.so).
-# None = not set by any enclosing use_precision(): plain ops (and everything with a tape) then run bf16, the inference entry
+# None = not set by any enclosing use_precision() of THIS thread: plain ops (and everything with a tape) then run bf16, the inference entry
 # points (VQLLFLOWDeformable.reverse_flow_nhwc, glare_amd.infer, bench.py) run INFERENCE_PRECISION.
-_PRECISION = None
+# Thread-local: the reference boundary is entered from one thread per GPU under nn.DataParallel, and a precision
+# switched by one thread's context manager must not leak into another's launches.
+_TLS = threading.local()
 INFERENCE_PRECISION = "fp16"
+
+
+def _current():
+    return getattr(_TLS, "precision", None)
 
 
 class GlareError(RuntimeError):
@@ -38,13 +45,13 @@ def header_symbols():
 
 
 def precision():
-    return _PRECISION or "bf16"
+    return _current() or "bf16"
 
 
 def inference_precision(requested=None):
     """Precision of an inference entry point: the caller's request, else the enclosing use_precision(), else fp16 -- the
     reference's own autocast dtype (infer_dataset_lol.py:134) and what the end-to-end tolerance needs."""
-    return requested or _PRECISION or INFERENCE_PRECISION
+    return requested or _current() or INFERENCE_PRECISION
 
 
 def act_dtype():
@@ -62,15 +69,13 @@ class use_precision:
         self.name = name
 
     def __enter__(self):
-        global _PRECISION
-        self._prev = _PRECISION
+        self._prev = _current()
         if self.name is not None:
-            _PRECISION = self.name
+            _TLS.precision = self.name
         return self
 
     def __exit__(self, *exc):
-        global _PRECISION
-        _PRECISION = self._prev
+        _TLS.precision = self._prev
 
 
 # entry points without any 16-bit tensor in their signature: under "fp16" they resolve to the main library

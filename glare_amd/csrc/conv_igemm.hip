@@ -310,7 +310,8 @@ extern "C" int glare_conv2d_bf16(const glare_conv_desc* d, glare_stream_t stream
   } else {
     p.OH = p.IHs; p.OW = p.IWs;
   }
-  p.Cin0 = d->Cin; p.Cin1 = d->in2 ? d->Cin2 : 0; p.CinTot = p.Cin0 + p.Cin1;
+  p.k_wrap = d->k_wrap != 0;
+  p.Cin0 = d->Cin; p.Cin1 = d->in2 ? d->Cin2 : 0; p.CinTot = p.Cin0 + p.Cin1 + (p.k_wrap ? p.Cin0 : 0);
   p.p0 = d->in_pitch; p.o0 = d->in_off; p.p1 = d->in2_pitch; p.o1 = d->in2_off;
   p.Cout = d->Cout; p.opitch = d->out_pitch; p.ooff = d->out_off;
   p.rpitch = d->res_pitch; p.roff = d->res_off;
@@ -323,7 +324,9 @@ extern "C" int glare_conv2d_bf16(const glare_conv_desc* d, glare_stream_t stream
                                                                                    // slab: the 32-wide tile's waves cover 2 rows
   const int kc = 16 * v.ksteps;
   // a stage must not straddle the two concatenated sources
-  if (p.in1 && (p.Cin0 % kc)) return GLARE_ERR_UNSUPPORTED;
+  if ((p.in1 || p.k_wrap) && (p.Cin0 % kc)) return GLARE_ERR_UNSUPPORTED;
+  if (p.k_wrap && (p.Cin1 % kc)) return GLARE_ERR_UNSUPPORTED;
+  if (p.k_wrap && (subpix || d->upsample)) return GLARE_ERR_UNSUPPORTED;
   p.n_stages = (p.CinTot + kc - 1) / kc;
   {  // halo DMA through per-image buffer descriptors: 32-bit byte offsets inside one image of one source
     const long long b0 = (long long)p.H * p.W * p.p0 * 2, b1 = p.in1 ? (long long)p.H * p.W * p.p1 * 2 : 0;
@@ -344,11 +347,13 @@ extern "C" int glare_conv2d_bf16(const glare_conv_desc* d, glare_stream_t stream
   p.groups = d->groups > 1 ? d->groups : 1;
   p.g_in_step = d->group_in_step; p.g_out_step = d->group_out_step; p.g_bias_step = d->Cout; p.g_w_elems = 0;
   if (p.groups > 1) {
-    if (d->in2 || d->residual || d->gn_partial || d->out_lo || subpix || p.groups > 65535) return GLARE_ERR_UNSUPPORTED;
+    if ((d->in2 && !(p.k_wrap && d->in2_pitch == d->in_pitch && d->Cin2 == d->Cin)) || d->residual || d->gn_partial || subpix || p.groups > 65535)
+      return GLARE_ERR_UNSUPPORTED;
     if ((d->group_in_step % 8) || d->in_off + (long long)(p.groups - 1) * d->group_in_step + d->Cin > d->in_pitch ||
         d->out_off + (long long)(p.groups - 1) * d->group_out_step + d->Cout > d->out_pitch || d->group_out_step < 0 || d->group_in_step < 0)
       return GLARE_ERR_INVALID;
-    p.g_w_elems = glare_conv2d_packed_weight_elems_tile(d->Cout, d->Cin, d->ksize, d->cout_tile);
+    p.g_w_elems = glare_conv2d_packed_weight_elems_tile(d->Cout, p.CinTot, d->ksize, d->cout_tile);
+    if (d->in2 && d->in2_off + (long long)(p.groups - 1) * d->group_in_step + d->Cin2 > d->in2_pitch) return GLARE_ERR_INVALID;
   }
   if (p.res_lo && !(p.res && p.out_lo)) return GLARE_ERR_INVALID;
   // 16-B records everywhere -> LDS-staged epilogue
@@ -356,15 +361,17 @@ extern "C" int glare_conv2d_bf16(const glare_conv_desc* d, glare_stream_t stream
                     (!p.res || (!(p.rpitch % 8) && !(p.roff % 8)));
   hipStream_t stream = (hipStream_t)stream_;
 
-  if (p.out_lo) {   // hi / lo output: the 3x3 convs of the conditional encoder's residual stream (128-wide tile, 16-B records)
-    if (d->ksize != 3 || subpix || d->upsample || !p.fast_epilogue) return GLARE_ERR_UNSUPPORTED;
+  if (p.out_lo) {   // hi / lo output (16-B records): the conditional encoder's residual stream, and every stored activation of the
+                    // fp32-class convs (3x3: 128-wide tile; 1x1: 128- and 64-wide)
+    if (subpix || d->upsample || !p.fast_epilogue) return GLARE_ERR_UNSUPPORTED;
+    if (d->ksize == 1) return glare_conv_launch_k1(p, v.tn, true, stream);
     return d->stride == 2 ? glare_conv_launch_k3s2(p, v.tn, true, stream) : glare_conv_launch_k3s1(p, v.tn, true, stream);
   }
   if (subpix) {   // interleaved scatter lives in the LDS-staged epilogue only
     if (!p.fast_epilogue) return GLARE_ERR_UNSUPPORTED;
     return glare_conv_launch_k2(p, v.tn, stream);
   }
-  if (d->ksize == 1) return glare_conv_launch_k1(p, v.tn, stream);
+  if (d->ksize == 1) return glare_conv_launch_k1(p, v.tn, false, stream);
   if (d->stride == 2) return glare_conv_launch_k3s2(p, v.tn, false, stream);
   return glare_conv_launch_k3s1(p, v.tn, false, stream);
 }

@@ -45,12 +45,13 @@ struct ConvParams {
   // writes output channels ooff + g * g_out_step, with the g-th packed filter / bias.
   int groups, g_in_step, g_out_step, g_bias_step;
   long long g_w_elems;
+  int k_wrap;            // K segments [in0 | in1 | in0 again]: the fp32-class contraction on hi / lo operand pairs (glare_conv_desc.k_wrap)
 };
 
 // kernel-family dispatchers, one per translation unit: tn = the output-channel tile (128 / 64 / 32); hilo = the hi / lo epilogue
 int glare_conv_launch_k3s1(const ConvParams& p, int tn, bool hilo, hipStream_t stream);
 int glare_conv_launch_k3s2(const ConvParams& p, int tn, bool hilo, hipStream_t stream);
-int glare_conv_launch_k1(const ConvParams& p, int tn, hipStream_t stream);
+int glare_conv_launch_k1(const ConvParams& p, int tn, bool hilo, hipStream_t stream);
 int glare_conv_launch_k2(const ConvParams& p, int tn, hipStream_t stream);   // sub-pixel upsample form
 
 namespace {
@@ -109,6 +110,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
   if (p.groups > 1) {               // uniform (scalar) adjustments: this workgroup's group
     const int g = blockIdx.y;
     p.o0 += g * p.g_in_step;
+    p.o1 += g * p.g_in_step;
     p.ooff += g * p.g_out_step;
     p.wpk += (size_t)g * p.g_w_elems;
     if (p.bias) p.bias += g * p.g_bias_step;
@@ -198,8 +200,9 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
 
   auto issue_a = [&](int chunk, int buf, int i_lo = 0, int i_hi = 1 << 20) {   // pieces [i_lo, i_hi) of this wave
     const int c0 = chunk * KC;
-    const bool src0 = c0 < p.Cin0;                       // uniform: a stage never straddles the two concatenated sources
-    const int cbase = src0 ? c0 : c0 - p.Cin0, climit = src0 ? p.Cin0 : p.Cin1;
+    // uniform: a stage never straddles two K segments -- [in0 | in1] and, with k_wrap, in0 once more behind them
+    const bool src0 = c0 < p.Cin0 || c0 >= p.Cin0 + p.Cin1;
+    const int cbase = c0 < p.Cin0 ? c0 : (src0 ? c0 - p.Cin0 - p.Cin1 : c0 - p.Cin0), climit = src0 ? p.Cin0 : p.Cin1;
 #pragma unroll
     for (int i = 0; i < A_PER_W; ++i) {
       const int j = wave + NW * i;

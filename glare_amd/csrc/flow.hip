@@ -32,7 +32,8 @@ struct TailParams {
 template <bool RAW>
 __global__ __launch_bounds__(FL_THREADS) void flow_h1_kernel(const float* __restrict__ z, const float* __restrict__ ftA,
                                                              int a_pitch, int a_off, const float* __restrict__ wz,
-                                                             a16_t* __restrict__ h1, float* __restrict__ raw, int B, int H, int W) {
+                                                             a16_t* __restrict__ h1, float* __restrict__ raw, int B, int H, int W,
+                                                             a16_t* __restrict__ h1_lo = nullptr) {
   __shared__ float wl[9][64];
   for (int i = threadIdx.x; i < 576; i += FL_THREADS) wl[i % 9][i / 9] = wz[i];  // wz is [64][9]
   __syncthreads();
@@ -61,6 +62,12 @@ __global__ __launch_bounds__(FL_THREADS) void flow_h1_kernel(const float* __rest
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = pack_a2(fmaxf(acc[2 * e], 0.f), fmaxf(acc[2 * e + 1], 0.f));
       *reinterpret_cast<u32x4*>(h1 + pix * 64 + g * 8) = o;
+      if (h1_lo) {   // the remainder half: h1 as the operand pair of an fp32-class 1x1 conv (glare_conv_desc.k_wrap)
+        u32x4 l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) l[e] = pack_a2(fmaxf(acc[2 * e], 0.f) - alo(o[e]), fmaxf(acc[2 * e + 1], 0.f) - ahi(o[e]));
+        *reinterpret_cast<u32x4*>(h1_lo + pix * 64 + g * 8) = l;
+      }
     }
   }
 }
@@ -249,6 +256,15 @@ extern "C" int glare_flow_h1_f32(const float* z_nhwc3, const float* ftA, int ftA
   if ((ftA_pitch % 4) || (ftA_off % 4) || ftA_off + 64 > ftA_pitch) return GLARE_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(flow_h1_kernel<false>, dim3(fl_blocks((long long)B * H * W * 8)), dim3(FL_THREADS), 0, (hipStream_t)stream,
                      z_nhwc3, ftA, ftA_pitch, ftA_off, wz_64x9, (a16_t*)h1_bf16, (float*)nullptr, B, H, W);
+  return glare_launch_status();
+}
+
+extern "C" int glare_flow_h1_pair_f32(const float* z_nhwc3, const float* ftA, int ftA_pitch, int ftA_off, const float* wz_64x9,
+                                      void* h1_hi, void* h1_lo, int B, int H, int W, glare_stream_t stream) {
+  if (!z_nhwc3 || !ftA || !wz_64x9 || !h1_hi || !h1_lo || B <= 0 || H <= 0 || W <= 0) return GLARE_ERR_INVALID;
+  if ((ftA_pitch % 4) || (ftA_off % 4) || ftA_off + 64 > ftA_pitch) return GLARE_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(flow_h1_kernel<false>, dim3(fl_blocks((long long)B * H * W * 8)), dim3(FL_THREADS), 0, (hipStream_t)stream,
+                     z_nhwc3, ftA, ftA_pitch, ftA_off, wz_64x9, (a16_t*)h1_hi, (float*)nullptr, B, H, W, (a16_t*)h1_lo);
   return glare_launch_status();
 }
 

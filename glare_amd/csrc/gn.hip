@@ -119,7 +119,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const a16_t* __res
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               a16_t* __restrict__ y, long long HW, int C, int pitch, int off,
                                                               int splits, float eps, int blocks_per_image,
-                                                              const a16_t* __restrict__ xlo = nullptr) {
+                                                              const a16_t* __restrict__ xlo = nullptr, a16_t* __restrict__ ylo = nullptr) {
   __shared__ float mean_s[GN_GROUPS], rstd_s[GN_GROUPS];
   const int b = blockIdx.x / blocks_per_image, blk = blockIdx.x % blocks_per_image;
   const int cpg = C / GN_GROUPS;
@@ -166,26 +166,28 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const a16_t* __res
   long long p = p0 + pl;
   if constexpr (LO) {     // hi / lo input: the normalised value is formed from hi + lo, rounded once on the way out
     const a16_t* lb = xlo + (size_t)b * HW * pitch + off + chunk * 8;
-    auto apply2 = [&](const u32x4& vh, const u32x4& vl) {
-      u32x4 o;
+    a16_t* ylb = ylo ? ylo + (size_t)b * HW * C + chunk * 8 : nullptr;   // hi / lo OUTPUT too: the operand pair of an fp32-class conv
+    auto apply2 = [&](const u32x4& vh, const u32x4& vl, long long pix) {
+      u32x4 o, ol;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float lo = (alo(vh[e]) + alo(vl[e])) * sc[2 * e] + sh[2 * e];
         float hi = (ahi(vh[e]) + ahi(vl[e])) * sc[2 * e + 1] + sh[2 * e + 1];
         if (SWISH) { lo = swishf_(lo); hi = swishf_(hi); }
         o[e] = pack_a2(lo, hi);
+        ol[e] = pack_a2(lo - alo(o[e]), hi - ahi(o[e]));
       }
-      return o;
+      __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(yb + (size_t)pix * C));
+      if (ylb) __builtin_nontemporal_store(ol, reinterpret_cast<u32x4*>(ylb + (size_t)pix * C));
     };
     for (; p + ppi < p1; p += 2LL * ppi) {   // two pixels (four 16-B loads) in flight per lane
       const u32x4 h0 = *reinterpret_cast<const u32x4*>(xb + (size_t)p * pitch), l0 = *reinterpret_cast<const u32x4*>(lb + (size_t)p * pitch);
       const u32x4 h1 = *reinterpret_cast<const u32x4*>(xb + (size_t)(p + ppi) * pitch), l1 = *reinterpret_cast<const u32x4*>(lb + (size_t)(p + ppi) * pitch);
-      __builtin_nontemporal_store(apply2(h0, l0), reinterpret_cast<u32x4*>(yb + (size_t)p * C));
-      __builtin_nontemporal_store(apply2(h1, l1), reinterpret_cast<u32x4*>(yb + (size_t)(p + ppi) * C));
+      apply2(h0, l0, p);
+      apply2(h1, l1, p + ppi);
     }
     for (; p < p1; p += ppi)
-      __builtin_nontemporal_store(apply2(*reinterpret_cast<const u32x4*>(xb + (size_t)p * pitch), *reinterpret_cast<const u32x4*>(lb + (size_t)p * pitch)),
-                                  reinterpret_cast<u32x4*>(yb + (size_t)p * C));
+      apply2(*reinterpret_cast<const u32x4*>(xb + (size_t)p * pitch), *reinterpret_cast<const u32x4*>(lb + (size_t)p * pitch), p);
     return;
   }
 #ifndef GN_APPLY_DEPTH
@@ -333,6 +335,16 @@ extern "C" int glare_groupnorm_apply_bf16(const void* x, int in_pitch, int in_of
 extern "C" int glare_groupnorm_hilo_bf16(const void* x_hi, const void* x_lo, int in_pitch, int in_off, const float* gamma,
                                          const float* beta, void* y, int B, long long HW, int C, float eps, int swish, const float* stats,
                                          int splits, void* workspace, size_t workspace_bytes, glare_stream_t stream_) {
+  return glare_groupnorm_hilo_pair_bf16(x_hi, x_lo, in_pitch, in_off, gamma, beta, y, nullptr, B, HW, C, eps, swish, stats, splits, workspace,
+                                        workspace_bytes, stream_);
+}
+
+// ... with the OUTPUT as a hi / lo pair as well (y_lo != NULL: dense [B][HW][C] like y): the activation operand pair of an fp32-class
+// conv (glare_conv_desc.k_wrap).
+extern "C" int glare_groupnorm_hilo_pair_bf16(const void* x_hi, const void* x_lo, int in_pitch, int in_off, const float* gamma,
+                                              const float* beta, void* y, void* y_lo, int B, long long HW, int C, float eps, int swish,
+                                              const float* stats, int splits, void* workspace, size_t workspace_bytes,
+                                              glare_stream_t stream_) {
   if (!x_hi || !x_lo || !gamma || !beta || !y || B <= 0 || HW <= 0 || C <= 0) return GLARE_ERR_INVALID;
   if (C % 32 || C % 8 || C > 2048 || (GN_THREADS % (C / 8)) || in_pitch % 8 || in_off % 8) return GLARE_ERR_UNSUPPORTED;
   if (in_off + C > in_pitch) return GLARE_ERR_INVALID;
@@ -350,10 +362,10 @@ extern "C" int glare_groupnorm_hilo_bf16(const void* x_hi, const void* x_lo, int
   if (bpi < 1) bpi = 1;
   if (swish)
     hipLaunchKernelGGL((gn_apply_kernel<true, true>), dim3((unsigned)(bpi * B)), dim3(GN_THREADS), 0, stream, (const a16_t*)x_hi, stats,
-                       gamma, beta, (a16_t*)y, HW, C, in_pitch, in_off, splits, eps, bpi, (const a16_t*)x_lo);
+                       gamma, beta, (a16_t*)y, HW, C, in_pitch, in_off, splits, eps, bpi, (const a16_t*)x_lo, (a16_t*)y_lo);
   else
     hipLaunchKernelGGL((gn_apply_kernel<false, true>), dim3((unsigned)(bpi * B)), dim3(GN_THREADS), 0, stream, (const a16_t*)x_hi, stats,
-                       gamma, beta, (a16_t*)y, HW, C, in_pitch, in_off, splits, eps, bpi, (const a16_t*)x_lo);
+                       gamma, beta, (a16_t*)y, HW, C, in_pitch, in_off, splits, eps, bpi, (const a16_t*)x_lo, (a16_t*)y_lo);
   return glare_launch_status();
 }
 

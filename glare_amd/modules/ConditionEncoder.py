@@ -24,7 +24,9 @@ class ConEncoder1(HipModule):
         enc, feats = self.encoder.forward_nhwc(x_nchw)
         B, H, W, C = enc.shape
         st = (H * W * C, 1, W * C, C)
-        cond = ops.conv2d_smallcin(enc, st, (B, H, W), self.cond_conv[0].weight, self.cond_conv[0].bias, act="sigmoid")
+        # fp32-class mode (encoder_decoder.FP32_CLASS): cond_feat as a hi / lo pair -- it is an MFMA operand of all 48 coupling nets
+        cond = ops.conv2d_smallcin(enc, st, (B, H, W), self.cond_conv[0].weight, self.cond_conv[0].bias, act="sigmoid",
+                                   hilo=getattr(enc, "_fp32_class", False))
         color = ops.conv2d_smallcin(enc, st, (B, H, W), self.color_conv.weight, self.color_conv.bias, out_f32=True)
         return {"cond_feat": cond, "color_map": color, "mid_feat": feats}
 

@@ -102,7 +102,9 @@ class FlowUpsamplerNet(HipModule):
         self.f = nn.Sequential(nn.Conv2d(affine_in, 2 * 3 * 64, 3, 1, 1))  # built, never called (:113-116)
 
     # ---- host-side preparation (once per weight set) --------------------------------------------
-    def _prepare(self):
+    def _prepare(self, split=0):
+        """split = 3: every MFMA conv of the coupling nets in the fp32-class form (ops.PackedConv(split=3): the conditional
+        feature and the hidden activations are hi / lo pairs then, decode_nhwc)."""
         dev = self.layers[0].actnorm.bias.device
         order = list(reversed(range(len(self.layers))))
         steps = []  # one entry per coupling step, in execution (reverse) order
@@ -126,8 +128,8 @@ class FlowUpsamplerNet(HipModule):
             wa_ft.append(w0[:, 1:])
             ba_ft.append(b0)
             st["wz"] = w0[:, 0].reshape(64, 9).float().contiguous()
-            st["c2"] = ops.PackedConv(*aff.fAffine[2].folded())
-            st["c4"] = ops.PackedConv(*aff.fAffine[4].folded())
+            st["c2"] = ops.PackedConv(*aff.fAffine[2].folded(), split=split)
+            st["c4"] = ops.PackedConv(*aff.fAffine[4].folded(), split=split)
             f0w, f0b = aff.fFeatures[0].folded()
             wf0.append(f0w)
             bf0.append(f0b)
@@ -135,30 +137,37 @@ class FlowUpsamplerNet(HipModule):
         # the z-independent second and third layers of all n feature nets: ONE grouped launch each (ops.conv2d_grouped)
         f2 = [st["layer"].affine.fFeatures[2].folded() for st in steps]
         f4 = [st["layer"].affine.fFeatures[4].folded() for st in steps]
-        return {"steps": steps, "n": n, "ftA": ops.PackedConv(torch.cat(wa_ft, 0), torch.cat(ba_ft, 0)),
-                "f0": ops.PackedConv(torch.cat(wf0, 0), torch.cat(bf0, 0)), "dev": dev,
-                "f2": ops.packed_conv_batch(torch.stack([w for w, _ in f2]), torch.stack([b for _, b in f2])),
-                "f4": ops.packed_conv_batch(torch.stack([w for w, _ in f4]), torch.stack([b for _, b in f4]))}
+        return {"steps": steps, "n": n, "ftA": ops.PackedConv(torch.cat(wa_ft, 0), torch.cat(ba_ft, 0), split=split),
+                "f0": ops.PackedConv(torch.cat(wf0, 0), torch.cat(bf0, 0), split=split), "dev": dev,
+                "f2": ops.packed_conv_batch(torch.stack([w for w, _ in f2]), torch.stack([b for _, b in f2]), split=split),
+                "f4": ops.packed_conv_batch(torch.stack([w for w, _ in f4]), torch.stack([b for _, b in f4]), split=split)}
 
     def decode_nhwc(self, z, ft):
         """z: fp32 NHWC [B,h,w,3] (color_map); ft: bf16 NHWC [B,h,w,64] (cond_feat) -> latent fp32 NHWC."""
-        P = self._packed("flow", self._prepare)
+        # a cond_feat that arrives as a hi / lo pair (ConEncoder1 in fp32-class mode) selects the fp32-class form of every conv here:
+        # cond_feat, h1f / h2f and the per-step h1 / h2 are pairs, the filters [w_hi | w_hi | w_lo] (tools/precision_sites.py: the
+        # 16-bit cond_feat alone is 6.5e-4 of latent error, the nets' first-layer filters 5.8e-4)
+        pair = getattr(ft, "_lo", None) is not None
+        split = 3 if pair else 0
+        P = self._packed(("flow", split), lambda: self._prepare(split)) if split else self._packed("flow", self._prepare)
         n = P["n"]
         B, H, W, _ = z.shape
         z = z.clone()
         ftA = ops.conv2d(ft, P["ftA"], out_mode=ops.OUT_NHWC_F32)                 # [B,h,w,n*64] fp32
-        h1f = ops.conv2d(ft, P["f0"], act="relu")                                  # [B,h,w,n*64] bf16
+        h1f = ops.conv2d(ft, P["f0"], act="relu", hilo=pair)                       # [B,h,w,n*64] bf16
         h2f = torch.empty_like(h1f)
         hF = torch.empty(B, H, W, n * 8, dtype=torch.float32, device=z.device)   # 6 of every 8 written and read
         # z-independent, batched up front: the n second layers, then the n third layers, one grouped launch each
-        ops.conv2d_grouped(h1f, P["f2"], cin=64, in_step=64, out=h2f, out_step=64, act="relu")
+        ops.conv2d_grouped(h1f, P["f2"], cin=64, in_step=64, out=h2f, out_step=64, act="relu", out_lo=torch.empty_like(h2f) if pair else None)
         ops.conv2d_grouped(h2f, P["f4"], cin=64, in_step=64, out=hF, out_step=8, out_mode=ops.OUT_NHWC_F32)
         h1 = torch.empty(B, H, W, 64, dtype=ops.act_dtype(), device=z.device)
         h2 = torch.empty_like(h1)
+        if pair:
+            h1._lo, h2._lo = torch.empty_like(h1), torch.empty_like(h2)
         h4 = torch.empty(B, H, W, 4, dtype=torch.float32, device=z.device)
         for s, st in enumerate(P["steps"]):                                        # the sequential part
             ops.flow_h1(z, ftA, 64 * s, st["wz"], out=h1)
-            ops.conv2d(h1, st["c2"], act="relu", out=h2)
+            ops.conv2d(h1, st["c2"], act="relu", out=h2, hilo=pair)
             ops.conv2d(h2, st["c4"], out=h4, out_mode=ops.OUT_NHWC_F32)
             ops.flow_tail(z, h4, hF, 8 * s, st["M"], st["t"], st["eps"])
         return z

@@ -22,8 +22,8 @@ def Normalize(in_channels):  # encoder_decoder.py:34-35
     return nn.GroupNorm(num_groups=32, num_channels=in_channels, eps=1e-6, affine=True)
 
 
-def gn_swish(x, norm, swish=True):
-    return ops.groupnorm(x, norm.weight.detach().float(), norm.bias.detach().float(), swish=swish, eps=norm.eps)
+def gn_swish(x, norm, swish=True, pair=False):
+    return ops.groupnorm(x, norm.weight.detach().float(), norm.bias.detach().float(), swish=swish, eps=norm.eps, pair=pair)
 
 
 def is_hilo(x):
@@ -45,6 +45,13 @@ def conv_t(x, conv, **kw):
 # The conditional encoder's residual stream as hi / lo pairs under fp16 (Encoder.hilo_stream; GLARE_HILO_STREAM=0 switches it off for
 # A/B measurements: the stream tensors are then plain 16-bit, as in every other network of the path).
 HILO_STREAM = os.environ.get("GLARE_HILO_STREAM", "1") != "0"
+# ... and, on top of the hi / lo stream, every MFMA contraction of the conditional encoder in the fp32-class form (round 4): the
+# activation operand AND the filter as hi / lo pairs, x . w = x_hi . w_hi + x_lo . w_hi + x_hi . w_lo in one accumulation over three
+# K segments (glare_conv_desc.k_wrap), every stored activation a hi / lo pair.  The reference runs these convs under fp16 autocast
+# but is judged against its fp32 self (BASELINE: PSNR within 0.05 dB, indices bit-exact): tools/precision_sites.py shows the
+# codebook search needs the latent to ~1e-4, which 11-bit MFMA operands miss 20-fold.  GLARE_FP32_CLASS=0:
+# round 3's single-pass convs (A/B measurements).
+FP32_CLASS = os.environ.get("GLARE_FP32_CLASS", "1") != "0"
 SUBPIXEL_UPSAMPLE = True
 FOLD_PROJ_INTO_V = True
 # AttnBlock as attention with shared keys / values (csrc/attn.hip, attn_kv_fwd_kernel): the key projection folded into the
@@ -87,8 +94,8 @@ class Downsample(HipModule):
         self.with_conv = with_conv
         self.conv = nn.Conv2d(in_channels, in_channels, 3, 2, 0)
 
-    def forward_nhwc(self, x):
-        return ops.conv2d(x, packed_conv(self, self.conv), stride=2,  # pad (0,1,0,1) fused in the loader
+    def forward_nhwc(self, x, split=0):
+        return ops.conv2d(x, packed_conv(self, self.conv, split=split), stride=2,  # pad (0,1,0,1) fused in the loader
                           gn_stats=GN_FUSED and self.conv.out_channels % 128 == 0, hilo=is_hilo(x))
 
     def train_nhwc(self, x):
@@ -111,9 +118,15 @@ class ResnetBlock(HipModule):
         if in_channels != out_channels:
             self.nin_shortcut = nn.Conv2d(in_channels, out_channels, 1, 1, 0)
 
-    def forward_nhwc(self, x, out=None, out_off=0):
+    def forward_nhwc(self, x, out=None, out_off=0, split=0):
         fuse = GN_FUSED and self.out_channels % 128 == 0
         hl = is_hilo(x)      # the residual stream as a hi / lo pair (conditional encoder, fp16): x + h is added in 22 bits
+        if split:            # fp32-class (FP32_CLASS): every operand and every stored activation of the block a hi / lo pair
+            assert hl and out is None and split == 3
+            h = ops.conv2d(gn_swish(x, self.norm1, pair=True), packed_conv(self, self.conv1, split=3), gn_stats=fuse, hilo=True)
+            h = gn_swish(h, self.norm2, pair=True)
+            res = x if self.in_channels == self.out_channels else ops.conv2d(x, packed_conv(self, self.nin_shortcut, split=3), hilo=True)
+            return ops.conv2d(h, packed_conv(self, self.conv2, split=3), residual=res, gn_stats=fuse, hilo=True)
         h = ops.conv2d(gn_swish(x, self.norm1), packed_conv(self, self.conv1), gn_stats=fuse)  # stats for norm2
         h = gn_swish(h, self.norm2)
         res = x if self.in_channels == self.out_channels else ops.conv2d(x, packed_conv(self, self.nin_shortcut), hilo=hl)
@@ -261,25 +274,29 @@ class Encoder(HipModule):
         """x_nchw: fp32 NCHW image (read in place).  Returns (latent fp32 NHWC [B,h,w,zc], enc_feat list)."""
         x = x_nchw.float().contiguous()
         B, C, H, W = x.shape
+        split = 0
         if getattr(self, "hilo_stream", False) and HILO_STREAM and ops.precision() == "fp16":
             # the residual stream as hi / lo pairs (22 mantissa bits): its rounding at every block output is the largest single
             # term of the latent error in fp16 (DESIGN.md section 4); everything that READS the stream (convs, attention) reads hi
             h = ops.conv2d_smallcin(x, (C * H * W, H * W, W, 1), (B, H, W), self.conv_in.weight, self.conv_in.bias, hilo=True)
+            split = 3 if FP32_CLASS else 0      # ... and with FP32_CLASS the convs contract hi / lo pairs (three K segments)
         else:
             h = ops.conv2d_smallcin(x, (C * H * W, H * W, W, 1), (B, H, W), self.conv_in.weight, self.conv_in.bias)
+        kw = {"split": split} if split else {}
         feats = []
         for i_level in range(self.num_resolutions):
             lvl = self.down[i_level]
             for i_block in range(self.num_res_blocks):
-                h = lvl.block[i_block].forward_nhwc(h)
+                h = lvl.block[i_block].forward_nhwc(h, **kw)
                 if len(lvl.attn) > 0:
                     h = lvl.attn[i_block].forward_nhwc(h)
             if i_level != self.num_resolutions - 1:
                 feats.append(h)
-                h = lvl.downsample.forward_nhwc(h)
-        h = self.mid.block_2.forward_nhwc(self.mid.attn_1.forward_nhwc(self.mid.block_1.forward_nhwc(h)))
-        h = gn_swish(h, self.norm_out)
-        z = ops.conv2d(h, packed_conv(self, self.conv_out), out_mode=ops.OUT_NHWC_F32)
+                h = lvl.downsample.forward_nhwc(h, **kw)
+        h = self.mid.block_2.forward_nhwc(self.mid.attn_1.forward_nhwc(self.mid.block_1.forward_nhwc(h, **kw)), **kw)
+        h = gn_swish(h, self.norm_out, pair=bool(split))
+        z = ops.conv2d(h, packed_conv(self, self.conv_out, split=split), out_mode=ops.OUT_NHWC_F32)
+        z._fp32_class = bool(split)          # ConEncoder1 hands cond_feat to the flow as a hi / lo pair then
         return z, feats
 
     def train_nhwc(self, x_nchw):

@@ -44,13 +44,25 @@ class ConvDesc(ctypes.Structure):
                 ("ksize", _i), ("stride", _i), ("upsample", _i), ("act", _i), ("out_mode", _i),
                 ("plane_pitch", _ll), ("gn_partial", ctypes.c_void_p), ("cout_tile", _i),
                 ("residual_lo", ctypes.c_void_p), ("out_lo", ctypes.c_void_p),
-                ("groups", _i), ("group_in_step", _i), ("group_out_step", _i)]
+                ("groups", _i), ("group_in_step", _i), ("group_out_step", _i), ("k_wrap", _i)]
+
+
+def split_filter(w, split):
+    """K segments of an fp32-class conv (glare_conv_desc.k_wrap), along the input channels of an fp32 [..., cout, cin, k, k] filter:
+    split = 3: [w_hi | w_hi | w_lo] for the operand segments [x_hi | x_lo | x_hi]; split = 2: [w_hi | w_lo] for [x_hi | x_hi]
+    (a 16-bit activation against a 22-bit filter).  w_hi = round16(w) is what the pack kernel makes of the first segments by
+    itself; w_lo = round16(w - w_hi)."""
+    if not split:
+        return w
+    assert split in (2, 3)
+    lo = w - w.to(act_dtype()).float()
+    return torch.cat([w, w, lo] if split == 3 else [w, lo], dim=-3).contiguous()
 
 
 class PackedConv:
     """A conv filter packed once for the MFMA kernel (weights bf16 stage-ordered, bias fp32)."""
 
-    def __init__(self, weight_oihw, bias=None, dgrad_pad=None, upsample_subpixel=False, cout_tile=0):
+    def __init__(self, weight_oihw, bias=None, dgrad_pad=None, upsample_subpixel=False, cout_tile=0, split=0):
         """dgrad_pad = P: pack the filter of the data-gradient conv (P >= cout input channels, cin outputs) instead.
         cout_tile: 0 = the default output-channel tile for this cout, or 64 / 32 for launches too small to fill the chip with it
         (conv_cout_tile(); the packed image is tile-specific and conv2d passes the tile on).
@@ -58,6 +70,10 @@ class PackedConv:
         desc.upsample = 2: 16 instead of 36 tap-MACs per source pixel)."""
         require_cuda(weight_oihw)
         w = weight_oihw.detach().float().contiguous()
+        self.split = int(split)
+        if split:       # the fp32-class form: conv2d() reads the activation's hi / lo pair against [w_hi | w_hi | w_lo]
+            assert dgrad_pad is None and not upsample_subpixel and not cout_tile
+            w = split_filter(w, split)
         cout, cin, kh, kw = w.shape
         assert kh == kw and kh in (1, 3)
         self.ksize = kh
@@ -66,7 +82,7 @@ class PackedConv:
         # for_tile() re-packs a 3x3 filter with more than 64 output channels for a narrower tile on demand: only then is the fp32
         # source kept (for filters built on the fly -- AttnBlock's folded 1x1s, 9.4 MB sub-pixel upsample filters, the per-step
         # filters of training -- it would otherwise stay resident for the model's lifetime)
-        self._src = (w, bias, dgrad_pad) if (kh == 3 and not upsample_subpixel and (cout if dgrad_pad is None else cin) > 64) else None
+        self._src = (w, bias, dgrad_pad) if (kh == 3 and not upsample_subpixel and not split and (cout if dgrad_pad is None else cin) > 64) else None
         self._tiles = {}
         lib = _lib.lib()
         if cout_tile and not self.subpixel:
@@ -97,17 +113,22 @@ class PackedConv:
                                                      stream_handle()), "glare_conv2d_pack_weight_dgrad")
         self.bias = None if bias is None else bias.detach().float().contiguous()
         self.w16 = None
-        if kh == 1 and dgrad_pad is None and lib.glare_conv1x1_ws_supported(_i(cin), _i(cout)):
+        if split:
+            self.cin = cin // split          # the conv's own input channels; the packed image holds `split` K segments of them
+        if kh == 1 and dgrad_pad is None and not split and lib.glare_conv1x1_ws_supported(_i(cin), _i(cout)):
             # the weight-stationary 1x1 kernel (csrc/conv1x1.hip) takes the filter as plain bf16 [Cout][Cin]
             self.w16 = torch.empty(cout, cin, dtype=act_dtype(), device=w.device)
             check(lib.glare_conv1x1_ws_pack_weight(ptr(w), _i(cout), _i(cin), ptr(self.w16), stream_handle()), "glare_conv1x1_ws_pack_weight")
 
 
-def packed_conv_batch(weights, biases=None, dgrad_pad=None, cout_tile=0):
+def packed_conv_batch(weights, biases=None, dgrad_pad=None, cout_tile=0, split=0):
     """weights fp32 [n, cout, cin, k, k] (n filters of one shape) -> n PackedConv whose packed images come from ONE launch.
-    biases: fp32 [n, cout] or None; dgrad_pad, cout_tile as in PackedConv."""
+    biases: fp32 [n, cout] or None; dgrad_pad, cout_tile, split as in PackedConv."""
     require_cuda(weights, biases)
     w = weights.detach().float().contiguous()
+    if split:
+        assert dgrad_pad is None
+        w = split_filter(w, split)
     n, cout, cin, kh, kw = w.shape
     assert kh == kw and kh in (1, 3)
     lib = _lib.lib()
@@ -122,7 +143,8 @@ def packed_conv_batch(weights, biases=None, dgrad_pad=None, cout_tile=0):
     out = []
     for k in range(n):
         pc = PackedConv.__new__(PackedConv)
-        pc.ksize, pc.subpixel, pc.cout, pc.cin, pc.packed, pc.w16, pc.cout_tile = kh, False, oc, ic, packed[k], None, cout_tile
+        pc.ksize, pc.subpixel, pc.cout, pc.cin, pc.packed, pc.w16, pc.cout_tile = kh, False, oc, ic // (split or 1), packed[k], None, cout_tile
+        pc.split = int(split)
         pc.bias = None if b is None else b[k]
         out.append(pc)
     return out
@@ -372,7 +394,7 @@ def attn_fold_groupnorm(stats, HW, gamma, beta, eps, wq, bq, wo, bo):
     return wq_b, bq_b, wo_b, bo_b
 
 
-def conv2d_grouped(x, pcs, *, cin, in_step, out, out_step, in_off=0, out_off=0, act="none", out_mode=OUT_NHWC_BF16):
+def conv2d_grouped(x, pcs, *, cin, in_step, out, out_step, in_off=0, out_off=0, act="none", out_mode=OUT_NHWC_BF16, out_lo=None):
     """len(pcs) independent convs of ONE shape in a single launch (glare_conv_desc.groups): conv g reads channels
     [in_off + g * in_step, + cin) of x and writes channels [out_off + g * out_step, + cout) of `out`.  pcs: the PackedConvs that
     packed_conv_batch() returned for them (consecutive packed images, consecutive biases)."""
@@ -395,7 +417,18 @@ def conv2d_grouped(x, pcs, *, cin, in_step, out, out_step, in_off=0, out_off=0, 
     d.cout_tile = getattr(p0, "cout_tile", 0)
     d.ksize, d.stride, d.upsample, d.act, d.out_mode = p0.ksize, 1, 0, ACT[act], out_mode
     d.groups, d.group_in_step, d.group_out_step = G, in_step, out_step
-    count_flops("conv k%d" % p0.ksize, 2.0 * G * B * H * W * p0.ksize ** 2 * p0.cin * p0.cout)
+    split = getattr(p0, "split", 0)
+    if split:                                  # fp32-class: the hi / lo operand pair against [w_hi | w_hi | w_lo] (k_wrap)
+        d.k_wrap = 1
+        if split == 3:
+            xlo = getattr(x, "_lo", None)
+            assert xlo is not None and xlo.shape == x.shape and xlo.dtype == x.dtype and xlo.is_contiguous(), "split-3 filter: x needs its lo half"
+            d.in2, d.Cin2, d.in2_pitch, d.in2_off = xlo.data_ptr(), cin, pitch, in_off
+    if out_lo is not None:
+        assert out_mode == OUT_NHWC_BF16 and out_lo.shape == out.shape and out_lo.dtype == out.dtype and out_lo.is_contiguous()
+        d.out_lo = out_lo.data_ptr()
+        out._lo = out_lo
+    count_flops("conv k%d" % p0.ksize, 2.0 * G * B * H * W * p0.ksize ** 2 * p0.cin * p0.cout * (split or 1))
     check(_lib.lib().glare_conv2d_bf16(ctypes.byref(d), stream_handle()), "glare_conv2d_bf16")
     return out
 
@@ -411,10 +444,11 @@ def conv2d(x, pc, *, x2=None, cin=None, in_off=0, cin2=None, in2_off=0, stride=1
     assert pc.packed.dtype == x.dtype, "filter packed under another precision"
     B, H, W, pitch = x.shape
     cin = pitch - in_off if cin is None else cin
+    split = getattr(pc, "split", 0)
     if FLOP_COUNTER is not None:
         opix = B * H * W * (4 if upsample else 1) // (stride * stride)
-        count_flops("conv k%d" % pc.ksize, 2.0 * opix * pc.ksize ** 2 * pc.cin * pc.cout)
-    if hilo and pc.ksize == 1:
+        count_flops("conv k%d" % pc.ksize, 2.0 * opix * pc.ksize ** 2 * pc.cin * pc.cout * (split or 1))
+    if hilo and pc.ksize == 1 and not split:
         assert x2 is None and stride == 1 and not upsample and out is None and cin == pc.cin and getattr(pc, "w16", None) is not None
         return _conv1x1_ws(x, pc, cin, in_off, act, residual, res_off, None, 0, gn_stats, hilo=True)
     if (CONV1X1_WEIGHT_STATIONARY and getattr(pc, "w16", None) is not None and x2 is None and stride == 1 and not upsample
@@ -428,11 +462,19 @@ def conv2d(x, pc, *, x2=None, cin=None, in_off=0, cin2=None, in2_off=0, stride=1
     d.in_, d.in2 = x.data_ptr(), (x2.data_ptr() if x2 is not None else None)
     d.B, d.H, d.W = B, H, W
     d.Cin, d.in_pitch, d.in_off = cin, pitch, in_off
+    if split:      # fp32-class: K segments [x_hi | x_lo | x_hi] against the filter packed as [w_hi | w_hi | w_lo] (k_wrap)
+        assert x2 is None and not upsample and cin == pc.cin, (cin, pc.cin)
+        d.k_wrap = 1
+        if split == 3:
+            x2 = getattr(x, "_lo", None)
+            assert x2 is not None and x2.shape == x.shape, "a split-3 filter contracts the activation's hi / lo pair: x._lo is missing"
+            cin2, in2_off = cin, in_off
     if x2 is not None:
         assert x2.dtype == act_dtype() and x2.is_contiguous() and x2.shape[:3] == x.shape[:3]
+        d.in2 = x2.data_ptr()
         d.Cin2 = x2.shape[3] - in2_off if cin2 is None else cin2
         d.in2_pitch, d.in2_off = x2.shape[3], in2_off
-    assert pc.cin == d.Cin + d.Cin2, (pc.cin, d.Cin, d.Cin2)
+    assert pc.cin == d.Cin + (0 if split else d.Cin2), (pc.cin, d.Cin, d.Cin2)
     IH, IW = (2 * H, 2 * W) if upsample else (H, W)
     OH, OW = ((IH + 1 - 3) // 2 + 1, (IW + 1 - 3) // 2 + 1) if stride == 2 else (IH, IW)
     if out is None:
@@ -470,7 +512,9 @@ def conv2d(x, pc, *, x2=None, cin=None, in_off=0, cin2=None, in2_off=0, stride=1
     out_lo = None
     if hilo:
         assert out_mode == OUT_NHWC_BF16 and out_off == 0 and out.shape[3] == pc.cout
-        out_lo = torch.empty_like(out)
+        out_lo = getattr(out, "_lo", None)          # a caller-provided pair (out=...) keeps its lo half
+        if out_lo is None:
+            out_lo = torch.empty_like(out)
         d.out_lo = out_lo.data_ptr()
         rlo = getattr(residual, "_lo", None) if residual is not None else None
         if rlo is not None:
@@ -494,8 +538,11 @@ def conv2d(x, pc, *, x2=None, cin=None, in_off=0, cin2=None, in2_off=0, stride=1
     if LAUNCH_EVENTS is not None and pc.ksize == 3:
         opix = B * OH * OW
         esz = 2 if out_mode in (OUT_NHWC_BF16, OUT_PLANAR_BF16) else 4
-        with _timed_launch("conv3x3", 2.0 * opix * 9 * pc.cin * pc.cout,     # 2*B*Ho*Wo*Cin*Cout*k^2; bytes in + out + filter
-                           2.0 * B * H * W * pc.cin + esz * opix * pc.cout + 2.0 * 9 * pc.cin * pc.cout):
+        # 2*B*Ho*Wo*Cin*Cout*k^2 (an fp32-class launch counts ONCE -- its 3 MFMA passes are this kernel's way of doing
+        # the reference's fp32 conv, not more algorithmic work); bytes in + out + filter
+        with _timed_launch("conv3x3_split" if split else "conv3x3", 2.0 * opix * 9 * pc.cin * pc.cout,
+                           2.0 * B * H * W * pc.cin * (2 if split == 3 else 1) + esz * opix * pc.cout * (2 if hilo else 1)
+                           + 2.0 * 9 * pc.cin * pc.cout * (split or 1)):
             check(lib.glare_conv2d_bf16(ctypes.byref(d), stream_handle()), "glare_conv2d_bf16")
     else:
         check(lib.glare_conv2d_bf16(ctypes.byref(d), stream_handle()), "glare_conv2d_bf16")
@@ -550,7 +597,7 @@ def conv2d_smallcin(x, strides, shape_bhw, weight, bias=None, act="none", out=No
     return out
 
 
-def groupnorm(x, gamma, beta, swish=True, eps=1e-6, cin=None, in_off=0):
+def groupnorm(x, gamma, beta, swish=True, eps=1e-6, cin=None, in_off=0, pair=False):
     """x: bf16 NHWC [B,H,W,pitch]; returns dense bf16 NHWC [B,H,W,C].  If the producing conv left its fused
     statistics on the tensor (conv2d(..., gn_stats=True)), only the apply pass runs."""
     require_cuda(x, gamma, beta)
@@ -563,15 +610,20 @@ def groupnorm(x, gamma, beta, swish=True, eps=1e-6, cin=None, in_off=0):
     if xlo is not None:      # a hi / lo pair (the conditional encoder's residual stream in fp16): normalise the 22-bit value
         assert in_off == 0 and C == pitch and xlo.shape == x.shape and xlo.is_contiguous()
         y = torch.empty(B, H, W, C, dtype=act_dtype(), device=x.device)
+        ylo = torch.empty_like(y) if pair else None      # pair: the output as a hi / lo pair too (operand of an fp32-class conv)
         ws, nws = None, 0
         if stats is None:
             lib.glare_groupnorm_workspace_bytes.restype = _sz
             nws = lib.glare_groupnorm_workspace_bytes(_i(B), _ll(H * W))
             ws = _workspace(nws, x.device)
-        check(lib.glare_groupnorm_hilo_bf16(ptr(x), ptr(xlo), _i(pitch), _i(0), ptr(gamma), ptr(beta), ptr(y), _i(B), _ll(H * W), _i(C),
-                                            _f(eps), _i(int(swish)), ptr(stats), _i(int(stats.shape[1]) if stats is not None else 0),
-                                            ptr(ws), _sz(nws), stream_handle()), "glare_groupnorm_hilo_bf16")
+        check(lib.glare_groupnorm_hilo_pair_bf16(ptr(x), ptr(xlo), _i(pitch), _i(0), ptr(gamma), ptr(beta), ptr(y), ptr(ylo), _i(B),
+                                                 _ll(H * W), _i(C), _f(eps), _i(int(swish)), ptr(stats),
+                                                 _i(int(stats.shape[1]) if stats is not None else 0), ptr(ws), _sz(nws), stream_handle()),
+              "glare_groupnorm_hilo_pair_bf16")
+        if pair:
+            y._lo = ylo
         return y
+    assert not pair, "groupnorm(pair=True) normalises a hi / lo pair (x._lo)"
     if stats is not None and in_off == 0 and C == pitch:
         y = torch.empty(B, H, W, C, dtype=act_dtype(), device=x.device)
         check(lib.glare_groupnorm_apply_bf16(ptr(x), _i(pitch), _i(0), ptr(gamma), ptr(beta), ptr(y), _i(B), _ll(H * W), _i(C),
@@ -663,6 +715,11 @@ def flow_h1(z, ftA, ftA_off, wz, out=None):
     B, H, W, _ = z.shape
     if out is None:
         out = torch.empty(B, H, W, 64, dtype=act_dtype(), device=z.device)
+    olo = getattr(out, "_lo", None)
+    if olo is not None:        # h1 as a hi / lo pair: the operand of the fp32-class 1x1 conv that follows
+        check(_lib.lib().glare_flow_h1_pair_f32(ptr(z), ptr(ftA), _i(ftA.shape[3]), _i(ftA_off), ptr(wz), ptr(out), ptr(olo), _i(B), _i(H),
+                                                _i(W), stream_handle()), "glare_flow_h1_pair_f32")
+        return out
     check(_lib.lib().glare_flow_h1_f32(ptr(z), ptr(ftA), _i(ftA.shape[3]), _i(ftA_off), ptr(wz), ptr(out), _i(B), _i(H),
                                        _i(W), stream_handle()), "glare_flow_h1_f32")
     return out

@@ -115,8 +115,18 @@ typedef struct glare_conv_desc {
   /* ---- grouped launch (round 3; zero = one filter): `groups` independent filters of ONE shape applied to channel slices of one
    * tensor in a single launch -- group g reads input channels [in_off + g * group_in_step, + Cin), writes output channels
    * [out_off + g * group_out_step, + Cout), with the g-th of `groups` consecutive packed filters in weight_packed
-   * (glare_conv2d_pack_weight_batched) and the g-th Cout-vector of bias.  No second source, residual, fused statistics or hi / lo. */
+   * (glare_conv2d_pack_weight_batched) and the g-th Cout-vector of bias.  No residual or fused statistics; a second source only as the
+   * lo half of a k_wrap launch (shifted like the first); out_lo follows out. */
   int groups, group_in_step, group_out_step;
+  /* ---- fp32-class contraction on the 16-bit MFMA (round 4; zero = plain): with the activation and the filter each a hi / lo pair
+   * (22 mantissa bits), x . w = x_hi . w_hi + x_lo . w_hi + x_hi . w_lo up to 2^-22, i.e. ONE accumulation over three K segments.
+   * k_wrap != 0: after the concatenated sources (`in`, then `in2`) the FIRST source is read again, so that with in = x_hi,
+   * in2 = x_lo (same geometry, Cin2 = Cin) and weight_packed = the pack of [w_hi | w_hi | w_lo] along the input channels (3 Cin) the
+   * launch computes exactly that sum; with in2 = NULL it is x_hi . (w_hi + w_lo) on a filter packed as [w_hi | w_lo] (2 Cin).
+   * The packed filter's input-channel count must be Cin + Cin2 + Cin; Cin (and Cin2) multiples of the kernel's 16-channel (3x3) /
+   * 32-channel (1x1) stage.  Grouped launches shift both sources by group_in_step.  Where the reference contracts in fp32 and the
+   * codebook search downstream needs it (the conditional encoder and the flow's nets under the fp16 inference precision). */
+  int k_wrap;
 } glare_conv_desc;
 
 /* The output-channel tile (128, 64 or 32) that gives a B x OH x OW x cout conv enough workgroups (8 x 32 output pixels each). */
@@ -211,6 +221,11 @@ int glare_groupnorm_apply_bf16(const void* x, int in_pitch, int in_off, const fl
 int glare_groupnorm_hilo_bf16(const void* x_hi, const void* x_lo, int in_pitch, int in_off, const float* gamma, const float* beta,
                               void* y, int B, long long HW, int C, float eps, int swish, const float* stats, int splits,
                               void* workspace, size_t workspace_bytes, glare_stream_t stream);
+/* ... with the output a hi / lo pair too (y_lo dense like y, or NULL = glare_groupnorm_hilo_bf16): the activation operand pair of an
+ * fp32-class conv (glare_conv_desc.k_wrap). */
+int glare_groupnorm_hilo_pair_bf16(const void* x_hi, const void* x_lo, int in_pitch, int in_off, const float* gamma, const float* beta,
+                                   void* y, void* y_lo, int B, long long HW, int C, float eps, int swish, const float* stats, int splits,
+                                   void* workspace, size_t workspace_bytes, glare_stream_t stream);
 int glare_split_hilo_f32(const float* src, long long n, void* hi_bf16, void* lo_bf16, glare_stream_t stream);
 int glare_groupnorm_swish_bf16(const void* x, int in_pitch, int in_off, const float* gamma, const float* beta,
                                void* y, int B, long long HW, int C, float eps, int swish, void* workspace,
@@ -242,6 +257,9 @@ int glare_nhwc_to_nchw(const void* src_nhwc, float* dst_nchw, int B, int C, long
  *                      hF[pixel][pitch] (6 used at hF_off), then z = M z + t (host 3x3 / 3). */
 int glare_flow_h1_f32(const float* z_nhwc3, const float* ftA, int ftA_pitch, int ftA_off, const float* wz_64x9,
                       void* h1_bf16, int B, int H, int W, glare_stream_t stream);
+/* ... h1 as a hi / lo pair (two 16-bit [pixel][64] tensors, value = hi + lo): the operand of an fp32-class 1x1 conv (k_wrap). */
+int glare_flow_h1_pair_f32(const float* z_nhwc3, const float* ftA, int ftA_pitch, int ftA_off, const float* wz_64x9,
+                           void* h1_hi, void* h1_lo, int B, int H, int W, glare_stream_t stream);
 int glare_flow_tail_f32(float* z_nhwc3, const float* h4, const float* hF, int hF_pitch, int hF_off,
                         long long n_pixels, const float* M_3x3_host, const float* t_3_host, float eps,
                         glare_stream_t stream);

@@ -1,0 +1,146 @@
+"""GPU: the fp32-class form of the MFMA convolution (glare_conv_desc.k_wrap, ops.PackedConv(split=3)): activation and filter
+each a hi / lo pair of 16-bit tensors (22 mantissa bits), contracted as x_hi.w_hi + x_lo.w_hi + x_hi.w_lo in ONE accumulation
+over three K segments -- against F.conv2d in fp32 on the UNROUNDED fp32 operands (what the reference's fp32 nn.Conv2d computes,
+encoder_decoder.py:88-115).  Tolerance: the dropped x_lo.w_lo term (2^-22) + fp32 summation order: 2e-5 of max|ref| asserted
+(measured ~3e-6); the single-pass kernel on the same data is asserted to be >= 30x worse, so the test cannot pass on a launch
+that silently ignored the lo halves."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from glare_amd import ops
+from tolerances import within
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(x_nchw):
+    """fp32 NCHW (cpu) -> the hi / lo pair in NHWC on the device (ops.split_hilo)."""
+    x = x_nchw.permute(0, 2, 3, 1).contiguous().cuda()
+    return ops.split_hilo(x)
+
+
+def _val(t):
+    lo = getattr(t, "_lo", None)
+    return t.float() if lo is None else t.float() + lo.float()
+
+
+def _err(got_nhwc, ref_nchw):
+    ref = ref_nchw.permute(0, 2, 3, 1)
+    return float((got_nhwc - ref).abs().max() / ref.abs().max())
+
+
+CASES = [  # B, Cin, Cout, H, W, k, stride
+    (1, 128, 128, 16, 40, 3, 1),
+    (2, 64, 256, 9, 33, 3, 1),
+    (1, 256, 128, 8, 32, 1, 1),      # nin_shortcut-like
+    (1, 128, 128, 17, 35, 3, 2),     # Downsample
+    (1, 512, 3, 12, 31, 3, 1),       # conv_out
+    (1, 64, 64, 11, 35, 1, 1),       # the flow's 1x1 (64-wide tile)
+    (1, 64, 4, 10, 37, 3, 1),        # the flow's last conv
+]
+
+
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+@pytest.mark.parametrize("B,Cin,Cout,H,W,k,stride", CASES)
+def test_split3_conv_matches_the_fp32_conv(prec, B, Cin, Cout, H, W, k, stride):
+    g = torch.Generator().manual_seed(B * 1000 + Cin + Cout + H + k)
+    x = torch.randn((B, Cin, H, W), generator=g)
+    w = torch.randn((Cout, Cin, k, k), generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn((Cout,), generator=g) * 0.1
+    if stride == 2:   # pad (0,1,0,1) then valid 3x3 stride 2 (encoder_decoder.py:71-73)
+        ref = F.conv2d(F.pad(x.cuda(), (0, 1, 0, 1)), w.cuda(), b.cuda(), 2, 0)
+    else:
+        ref = F.conv2d(x.cuda(), w.cuda(), b.cuda(), 1, k // 2)
+    with ops.use_precision(prec):
+        xp = _pair(x)
+        out = ops.conv2d(xp, ops.PackedConv(w.cuda(), b.cuda(), split=3), stride=stride, out_mode=ops.OUT_NHWC_F32)
+        plain = ops.conv2d(xp, ops.PackedConv(w.cuda(), b.cuda()), stride=stride, out_mode=ops.OUT_NHWC_F32)
+    e3, e1 = _err(out, ref), _err(plain, ref)
+    bits = 11 if prec == "fp16" else 8
+    within(e3, 8.0 * 2.0 ** (-2 * bits), prec)           # fp16: 1.9e-6 ... measured ~5e-7; bf16: 1.2e-4
+    assert e1 > 30 * e3, (e1, e3)
+
+
+def test_split3_hilo_output_residual_and_statistics():
+    """The ResnetBlock tail in fp32-class form: conv2(n2) + residual with every tensor a pair, GroupNorm statistics fused."""
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn((2, 128, 12, 40), generator=g)
+    r = torch.randn((2, 128, 12, 40), generator=g)
+    w = torch.randn((128, 128, 3, 3), generator=g) * 0.03
+    b = torch.randn((128,), generator=g) * 0.1
+    ref = F.conv2d(x.cuda(), w.cuda(), b.cuda(), 1, 1) + r.cuda()
+    with ops.use_precision("fp16"):
+        out = ops.conv2d(_pair(x), ops.PackedConv(w.cuda(), b.cuda(), split=3), residual=_pair(r), hilo=True, gn_stats=True)
+        within(_err(_val(out), ref), 4e-6)
+        # GroupNorm of the pair, output as a pair
+        gamma, beta = torch.rand(128, generator=g).cuda() + 0.5, torch.randn(128, generator=g).cuda() * 0.1
+        y = ops.groupnorm(out, gamma, beta, swish=True, pair=True)
+        yref = F.silu(F.group_norm(ref, 32, gamma, beta, 1e-6))
+        within(_err(_val(y), yref), 1e-5)
+        assert float((y._lo.float().abs().max())) > 0
+
+
+def test_split3_1x1_hilo_output_both_tiles():
+    g = torch.Generator().manual_seed(12)
+    for cin, cout in ((128, 256), (64, 64)):
+        x = torch.randn((1, cin, 9, 37), generator=g)
+        w = torch.randn((cout, cin, 1, 1), generator=g) / cin ** 0.5
+        b = torch.randn((cout,), generator=g) * 0.1
+        ref = F.relu(F.conv2d(x.cuda(), w.cuda(), b.cuda()))
+        with ops.use_precision("fp16"):
+            out = ops.conv2d(_pair(x), ops.PackedConv(w.cuda(), b.cuda(), split=3), act="relu", hilo=True)
+        within(_err(_val(out), ref), 4e-6, cout)
+
+
+def test_split3_grouped_launch_equals_per_group_launches():
+    """The flow's z-independent nets: n filters of one shape on channel slices of one pair, one launch (blockIdx.y = group)."""
+    g = torch.Generator().manual_seed(13)
+    n = 3
+    x = torch.randn((1, n * 64, 10, 33), generator=g)
+    for k, cout, step, f32 in ((1, 64, 64, False), (3, 6, 8, True)):
+        w = torch.randn((n, cout, 64, k, k), generator=g) / (64 * k * k) ** 0.5
+        b = torch.randn((n, cout), generator=g) * 0.1
+        with ops.use_precision("fp16"):
+            xp = _pair(x)
+            pcs = ops.packed_conv_batch(w.cuda(), b.cuda(), split=3)
+            if f32:
+                out = torch.zeros(1, 10, 33, n * step, dtype=torch.float32, device="cuda")
+                ops.conv2d_grouped(xp, pcs, cin=64, in_step=64, out=out, out_step=step, out_mode=ops.OUT_NHWC_F32)
+                got = out
+            else:
+                out = torch.zeros(1, 10, 33, n * step, dtype=torch.float16, device="cuda")
+                ops.conv2d_grouped(xp, pcs, cin=64, in_step=64, out=out, out_step=step, out_lo=torch.zeros_like(out), act="relu")
+                got = _val(out)
+        for i in range(n):
+            ref = F.conv2d(x[:, 64 * i:64 * i + 64].cuda(), w[i].cuda(), b[i].cuda(), 1, k // 2)
+            if not f32:
+                ref = F.relu(ref)
+            within(_err(got[..., step * i:step * i + cout], ref), 4e-6, "%d/%d" % (k, i))
+
+
+def test_split2_filter_remainder_only():
+    """A 16-bit activation against a 22-bit filter (K segments [x | x] . [w_hi | w_lo]): exact in the filter, x as stored."""
+    g = torch.Generator().manual_seed(14)
+    x = torch.randn((1, 128, 9, 35), generator=g).half().float()
+    w = torch.randn((128, 128, 3, 3), generator=g) * 0.03
+    ref = F.conv2d(x.cuda(), w.cuda(), None, 1, 1)
+    with ops.use_precision("fp16"):
+        xh = x.permute(0, 2, 3, 1).contiguous().cuda().half()
+        out = ops.conv2d(xh, ops.PackedConv(w.cuda(), None, split=2), out_mode=ops.OUT_NHWC_F32)
+    within(_err(out, ref), 4e-6)
+
+
+def test_flow_h1_pair():
+    g = torch.Generator().manual_seed(15)
+    z = torch.randn((1, 9, 21, 3), generator=g).cuda()
+    ftA = torch.randn((1, 9, 21, 128), generator=g).cuda()
+    wz = torch.randn((64, 9), generator=g).cuda() * 0.2
+    with ops.use_precision("fp16"):
+        h1 = torch.empty(1, 9, 21, 64, dtype=torch.float16, device="cuda")
+        h1._lo = torch.empty_like(h1)
+        ops.flow_h1(z, ftA, 64, wz, out=h1)
+        plain = ops.flow_h1(z, ftA, 64, wz)
+    ref = F.relu(ftA[..., 64:] + F.conv2d(z[..., :1].permute(0, 3, 1, 2), wz.view(64, 1, 3, 3), None, 1, 1).permute(0, 2, 3, 1))
+    assert torch.equal(h1, plain)
+    within(float((_val(h1) - ref).abs().max() / ref.abs().max()), 2e-6)

@@ -1,0 +1,67 @@
+#!/usr/bin/env python
+"""The full-path parity table over MANY scenes (test-side tool, imports oracle/): for every seed one 400x600 synthetic scene through
+the fp32 CPU oracle and through the HIP path (representative weights, default inference precision, the path's OWN codebook
+indices), printing latent error, index agreement, PSNR(ours, oracle) and |dPSNR vs GT| (GT = oracle output + 27 dB noise) -- and
+the same with the oracle's indices forced.  The table profiles/r0N_parity_table.txt and the bounds of
+tests/test_gpu_precision.py::test_end_to_end_full_size_scenes come from this.
+
+    python tools/parity_scenes.py [h w] [seed ...]          (GLARE_FP32_CLASS=0 / GLARE_HILO_STREAM=0: the earlier precisions)
+"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from glare_amd import modules as M  # noqa: E402
+from glare_amd import ops  # noqa: E402
+from glare_amd.synthetic import representative_init_, synthetic_pair  # noqa: E402
+from oracle import torch_ref as O  # noqa: E402
+from test_gpu_precision import e2e_metrics, rel  # noqa: E402
+
+
+def main():
+    args = [int(a) for a in sys.argv[1:]]
+    h, w = (args[0], args[1]) if len(args) >= 2 else (400, 600)
+    seeds = args[2:] or list(range(11, 23))
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    og, ov = representative_init_(O.VQLLFLOWDeformable(per_sample_mean=True).eval(), O.VQModel().eval(), 0)
+    pg, pv = M.VQLLFLOWDeformable().eval(), M.VQModel().eval()
+    pg.load_state_dict(og.state_dict())
+    pv.load_state_dict(ov.state_dict())
+    pg.cuda()
+    pv.cuda()
+    prec = os.environ.get("PARITY_PRECISION") or None
+    print("== %dx%d, representative weights, precision %s, GLARE_FP32_CLASS=%s GLARE_HILO_STREAM=%s GLARE_DCN_SINGLE_PASS=%s"
+          % (h, w, prec or "default", os.environ.get("GLARE_FP32_CLASS", "1"), os.environ.get("GLARE_HILO_STREAM", "1"),
+             os.environ.get("GLARE_DCN_SINGLE_PASS", "default")))
+    rows = []
+    for s in seeds:
+        lr = O.preprocess(synthetic_pair(1, h, w, seed=s)[0][0])
+        t0 = time.time()
+        with torch.no_grad():
+            ref = og.stages(ov, lr)
+        t1 = time.time()
+        with torch.no_grad():
+            r = pg.reverse_flow_nhwc(pv, lr.cuda(), precision=prec)
+            with ops.use_precision(ops.inference_precision(prec)):
+                _, _, feats_i = pv.decode_nhwc(ops.nchw_to_nhwc(ref["latent"].cuda(), bf16=False), want_image=False)
+                out_i = pg.deformable_decoder.forward_nhwc(r["latent"], feats_i, r["enc"]["mid_feat"]).cpu()
+        agree = float((r["indices"].cpu() == ref["indices"]).float().mean())
+        full, forced = e2e_metrics(r["out"].cpu(), ref["out"], h), e2e_metrics(out_i, ref["out"], h)
+        lat = rel(ops.nhwc_to_nchw(r["latent"]).cpu(), ref["latent"])
+        rows.append((s, lat, agree, full["psnr_vs_oracle"], full["delta"], forced["psnr_vs_oracle"], forced["delta"]))
+        print("seed %3d  latent rel %.3e  idx agree %.5f  full path: PSNR(ours,oracle) %6.2f dB  |dPSNR vs GT| %.4f dB   oracle's indices: %6.2f dB  %.4f dB   (oracle %.0f s)"
+              % (rows[-1] + (t1 - t0,)), flush=True)
+    n = len(rows)
+    print("-- %d scenes: latent rel mean %.3e | agreement min %.5f mean %.5f | PSNR(ours,oracle) min %.2f | |dPSNR vs GT| max %.4f mean %.4f | forced max %.4f"
+          % (n, sum(r[1] for r in rows) / n, min(r[2] for r in rows), sum(r[2] for r in rows) / n, min(r[3] for r in rows),
+             max(r[4] for r in rows), sum(r[4] for r in rows) / n, max(r[6] for r in rows)))
+
+
+if __name__ == "__main__":
+    main()
