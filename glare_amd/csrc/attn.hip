@@ -83,6 +83,7 @@ struct AttnParams {
   float* part_o;       // [B][key_splits][N][512] fp32
   float* part_ml;      // [B][key_splits][N][2]   (running max in log2 units, sum)
   float* lse;          // optional [B][N]: log2 sum_j 2^(q_i.k_j) of every query row (what the backward needs); attn_fwd_kernel only
+  a16_t* o_lo;         // optional remainder half of the output (value = o + o_lo, same ldo): attn_kv_fwd_kernel / attn_combine_kernel
 };
 
 __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParams p) {
@@ -506,7 +507,10 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
 
 // The 8-wave variant (ATTN_8WAVES=1; measured 975-995 TFLOP/s against the 4-wave kernel's 1 020-1 050) lives in tools/experiments/.
 #if ATTN_8WAVES
-#include "../../tools/experiments/attn_8waves.inc"
+#ifndef GLARE_ABLATE
+#error "ATTN_8WAVES is an experiment: build with GLARE_DEFS='-DGLARE_ABLATE -DATTN_8WAVES=1' (build.py then adds -I tools/experiments)"
+#endif
+#include "attn_8waves.inc"   // found through -I tools/experiments, which only a GLARE_ABLATE build passes: the product build never reads tools/
 #endif
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -555,6 +559,9 @@ __device__ __forceinline__ void lgkm_wait8(u32x2 (&f)[8]) {   // ties the wait t
                : "i"(N));
 }
 
+// PAIR: the output leaves as a hi / lo pair (p.o_lo); its own instantiation so that the plain kernel's register allocation -- the
+// file is exactly full -- does not change
+template <bool PAIR>
 __global__ __launch_bounds__(AT_THREADS, 1) void attn_kv_fwd_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   u32x4* lKV = reinterpret_cast<u32x4*>(smem);   // [2][KCH]: tile image [32 keys][64 chunks], chunk c of key r at r*64 + (c ^ f(r))
@@ -834,19 +841,27 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_kv_fwd_kernel(const AttnPa
         u32x2 w = {pack_a2(o[dt][4 * rq] * inv, o[dt][4 * rq + 1] * inv),
                    pack_a2(o[dt][4 * rq + 2] * inv, o[dt][4 * rq + 3] * inv)};
         *reinterpret_cast<u32x2*>(op + d) = w;
+        if constexpr (PAIR) {   // the output as a hi / lo pair: the operand of the fp32-class output projection (glare_conv_desc.k_wrap)
+          const u32x2 l = {pack_a2(o[dt][4 * rq] * inv - alo(w[0]), o[dt][4 * rq + 1] * inv - ahi(w[0])),
+                           pack_a2(o[dt][4 * rq + 2] * inv - alo(w[1]), o[dt][4 * rq + 3] * inv - ahi(w[1]))};
+          *reinterpret_cast<u32x2*>(p.o_lo + ((size_t)b * p.N + qrow) * p.ldo + d) = l;
+        }
       }
   }
 }
 
 // The software-pipelined variants (ATTNKV_PIPELINED=1|2; measured 1 035-1 089 / 997 TFLOP/s against 1 127-1 163) live in tools/experiments/.
 #if ATTNKV_PIPELINED != 0
-#include "../../tools/experiments/attn_kv_pipe.inc"
+#ifndef GLARE_ABLATE
+#error "ATTNKV_PIPELINED is an experiment: build with GLARE_DEFS='-DGLARE_ABLATE -DATTNKV_PIPELINED=1'"
+#endif
+#include "attn_kv_pipe.inc"
 #endif
 
 // out[q] = sum_s 2^(m_s - m) O_s[q] / sum_s 2^(m_s - m) l_s,  m = max_s m_s: merges the key splits (one wave per query row)
 __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
                                                            a16_t* __restrict__ out, int ldo, int B, int N, int KS,
-                                                           float* __restrict__ lse) {
+                                                           float* __restrict__ lse, a16_t* __restrict__ out_lo = nullptr) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // b * N + q
   if (row >= (long long)B * N) return;
   const int lane = threadIdx.x & 63, b = (int)(row / N), q = (int)(row % N);
@@ -869,6 +884,12 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
   u32x4 o = {pack_a2(acc[0] * inv, acc[1] * inv), pack_a2(acc[2] * inv, acc[3] * inv), pack_a2(acc[4] * inv, acc[5] * inv),
              pack_a2(acc[6] * inv, acc[7] * inv)};
   *reinterpret_cast<u32x4*>(out + (size_t)row * ldo + lane * 8) = o;
+  if (out_lo) {
+    u32x4 l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) l[e] = pack_a2(acc[2 * e] * inv - alo(o[e]), acc[2 * e + 1] * inv - ahi(o[e]));
+    *reinterpret_cast<u32x4*>(out_lo + (size_t)row * ldo + lane * 8) = l;
+  }
 }
 
 }  // namespace
@@ -896,6 +917,11 @@ extern "C" int glare_attention_d512_splitk_bf16(const void* q, int ldq, const vo
 
 extern "C" int glare_attention_kv512_bf16(const void* q, int ldq, const void* kv, int ldkv, void* out, int ldo, int B, int N,
                                           int key_splits, void* workspace, size_t workspace_bytes, glare_stream_t stream) {
+  return glare_attention_kv512_pair_bf16(q, ldq, kv, ldkv, out, nullptr, ldo, B, N, key_splits, workspace, workspace_bytes, stream);
+}
+
+extern "C" int glare_attention_kv512_pair_bf16(const void* q, int ldq, const void* kv, int ldkv, void* out, void* out_lo, int ldo, int B,
+                                               int N, int key_splits, void* workspace, size_t workspace_bytes, glare_stream_t stream) {
   if (!q || !kv || !out || B <= 0 || N <= 0 || key_splits < 1) return GLARE_ERR_INVALID;
   if (key_splits > (N + BN - 1) / BN) return GLARE_ERR_INVALID;
   if (((long long)N * ldkv + HD) * 2 >= 0x7ff00000LL) return GLARE_ERR_UNSUPPORTED;   // 32-bit DMA offsets per image
@@ -904,7 +930,7 @@ extern "C" int glare_attention_kv512_bf16(const void* q, int ldq, const void* kv
     return GLARE_ERR_WORKSPACE;
   if ((ldq % 8) || (ldkv % 8) || (ldo % 4) || ldq < HD || ldkv < HD || ldo < HD) return GLARE_ERR_UNSUPPORTED;
   AttnParams p;
-  p.q = (const a16_t*)q; p.k = (const a16_t*)kv; p.vt = nullptr; p.o = (a16_t*)out;
+  p.q = (const a16_t*)q; p.k = (const a16_t*)kv; p.vt = nullptr; p.o = (a16_t*)out; p.o_lo = (a16_t*)out_lo;
   p.B = B; p.N = N; p.Npad = 0; p.ldq = ldq; p.ldk = ldkv; p.ldo = ldo; p.lse = nullptr;
   p.n_qblocks = (N + BM - 1) / BM;
   p.key_splits = key_splits;
@@ -920,13 +946,14 @@ extern "C" int glare_attention_kv512_bf16(const void* q, int ldq, const void* kv
   hipLaunchKernelGGL(attn_kv_pipe_kernel, dim3(p.n_blocks), dim3(AT_THREADS), lds, (hipStream_t)stream, p);
 #else
   const size_t lds = (size_t)2 * KCH * 16;   // 64 KB: the double-buffered 32-key tile
-  if (hipFuncSetAttribute((const void*)attn_kv_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+  auto kern = (out_lo && key_splits == 1) ? attn_kv_fwd_kernel<true> : attn_kv_fwd_kernel<false>;   // with key splits the combine kernel writes the pair
+  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GLARE_ERR_LAUNCH;
-  hipLaunchKernelGGL(attn_kv_fwd_kernel, dim3(p.n_blocks), dim3(AT_THREADS), lds, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(kern, dim3(p.n_blocks), dim3(AT_THREADS), lds, (hipStream_t)stream, p);
 #endif
   if (key_splits > 1)
     hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)(((long long)B * N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p.part_o,
-                       p.part_ml, p.o, ldo, B, N, key_splits, (float*)nullptr);
+                       p.part_ml, p.o, ldo, B, N, key_splits, (float*)nullptr, p.o_lo);
   return glare_launch_status();
 }
 
@@ -948,7 +975,7 @@ static int attn_launch(const void* q, int ldq, const void* k, int ldk, const voi
   if ((ldq % 8) || (ldk % 8) || (ldo % 4) || (v_pitch % 8) || ldq < HD || ldk < HD || ldo < HD) return GLARE_ERR_UNSUPPORTED;
   if (v_pitch < (long long)((N + BN - 1) / BN) * BN) return GLARE_ERR_INVALID;  // tiles read whole 32-key groups
   AttnParams p;
-  p.q = (const a16_t*)q; p.k = (const a16_t*)k; p.vt = (const a16_t*)v_t; p.o = (a16_t*)out;
+  p.q = (const a16_t*)q; p.k = (const a16_t*)k; p.vt = (const a16_t*)v_t; p.o = (a16_t*)out; p.o_lo = nullptr;
   p.B = B; p.N = N; p.Npad = v_pitch; p.ldq = ldq; p.ldk = ldk; p.ldo = ldo; p.lse = lse;
   p.n_qblocks = (N + BM - 1) / BM;
   p.key_splits = key_splits;

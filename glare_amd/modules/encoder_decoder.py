@@ -169,20 +169,20 @@ class AttnBlock(HipModule):
         b = (wp @ self.v.bias.double() + self.proj_out.bias.double()).float()
         return ops.PackedConv(w, b)
 
-    def _q_folded(self):
+    def _q_folded(self, split=0):
         # s_ij = (Wq h_i + bq).(Wk h_j + bk): the terms without j cancel in softmax_j, the rest is (Wk^T (Wq h_i + bq)) . h_j
         s = float(self.in_channels) ** -0.5 * math.log2(math.e)
         wq, wk = self.q.weight[:, :, 0, 0].double(), self.k.weight[:, :, 0, 0].double()
         w = (s * (wk.t() @ wq)).float()[:, :, None, None].contiguous()
         b = (s * (wk.t() @ self.q.bias.double())).float()
-        return ops.PackedConv(w, b)
+        return ops.PackedConv(w, b, split=split)
 
-    def _out_folded(self):
+    def _out_folded(self, split=0):
         # Wp (sum_j P_ij (Wv h_j + bv)) + bp = (Wp Wv) (sum_j P_ij h_j) + Wp bv + bp   (softmax rows sum to 1)
         wp, wv = self.proj_out.weight[:, :, 0, 0].double(), self.v.weight[:, :, 0, 0].double()
         w = (wp @ wv).float()[:, :, None, None].contiguous()
         b = (wp @ self.v.bias.double() + self.proj_out.bias.double()).float()
-        return ops.PackedConv(w, b)
+        return ops.PackedConv(w, b, split=split)
 
     def _fold_mats(self):
         s = float(self.in_channels) ** -0.5 * math.log2(math.e)
@@ -192,10 +192,22 @@ class AttnBlock(HipModule):
                 (wp @ wv).float().contiguous(), (wp @ self.v.bias.double() + self.proj_out.bias.double()).float().contiguous(),
                 self.norm.weight.detach().float().contiguous(), self.norm.bias.detach().float().contiguous())
 
-    def forward_nhwc(self, x):
+    def forward_nhwc(self, x, split=0):
         B, H, W, C = x.shape
         N = H * W
         stats = getattr(x, "_gn_stats", None)
+        if split:
+            # fp32-class (FP32_CLASS): the norm is materialised as a hi / lo pair instead of folded into per-image filters, the two
+            # folded 1x1 convs contract pairs against [w_hi | w_hi | w_lo], and the attention's fp32 accumulators leave as a pair.
+            # Keys / values are the pair's hi half (tools/precision_sites.py: 16-bit keys / values cost 1.6e-5 of latent error, the
+            # 16-bit attention output 2.8e-4, the two filters 1.3e-4 / 1.5e-4).
+            assert split == 3 and is_hilo(x) and SHARED_KV_ATTENTION
+            hn = gn_swish(x, self.norm, swish=False, pair=True)
+            q = ops.conv2d(hn, self._packed("q_folded3", lambda: self._q_folded(split=3)))
+            a = ops.attention_kv512(q, hn, N, pair=True)
+            av = a.view(B, H, W, C)
+            av._lo = a._lo.view(B, H, W, C)
+            return ops.conv2d(av, self._packed("out_folded3", lambda: self._out_folded(split=3)), residual=x, gn_stats=GN_FUSED, hilo=True)
         if SHARED_KV_ATTENTION and GN_FOLDED_ATTENTION and stats is not None and 64 % B == 0:
             wq, bq, wo, bo, gamma, beta = self._packed("fold_mats", self._fold_mats)
             wq_b, bq_b, wo_b, bo_b = ops.attn_fold_groupnorm(stats, N, gamma, beta, self.norm.eps, wq, bq, wo, bo)
@@ -289,11 +301,11 @@ class Encoder(HipModule):
             for i_block in range(self.num_res_blocks):
                 h = lvl.block[i_block].forward_nhwc(h, **kw)
                 if len(lvl.attn) > 0:
-                    h = lvl.attn[i_block].forward_nhwc(h)
+                    h = lvl.attn[i_block].forward_nhwc(h, **kw)
             if i_level != self.num_resolutions - 1:
                 feats.append(h)
                 h = lvl.downsample.forward_nhwc(h, **kw)
-        h = self.mid.block_2.forward_nhwc(self.mid.attn_1.forward_nhwc(self.mid.block_1.forward_nhwc(h, **kw)), **kw)
+        h = self.mid.block_2.forward_nhwc(self.mid.attn_1.forward_nhwc(self.mid.block_1.forward_nhwc(h, **kw), **kw), **kw)
         h = gn_swish(h, self.norm_out, pair=bool(split))
         z = ops.conv2d(h, packed_conv(self, self.conv_out, split=split), out_mode=ops.OUT_NHWC_F32)
         z._fp32_class = bool(split)          # ConEncoder1 hands cond_feat to the flow as a hi / lo pair then

@@ -808,7 +808,7 @@ def _attention_d512(q, k, v_t, N, ldq, ldk, out, key_splits, lse=None):
     return out
 
 
-def attention_kv512(q, kv, N, ldq=None, ldkv=None, out=None, key_splits=None):
+def attention_kv512(q, kv, N, ldq=None, ldkv=None, out=None, key_splits=None, pair=False):
     """Attention with SHARED keys / values: out[b,i] = sum_j softmax_j(q_i . kv_j) kv_j.  q, kv: bf16 [B, N, ld] views
     (d = 512 used; the caller folds 512^-0.5 * log2(e) and the key projection into q -- see AttnBlock); returns bf16 [B, N, 512]."""
     require_cuda(q, kv, out)
@@ -834,8 +834,14 @@ def attention_kv512(q, kv, N, ldq=None, ldkv=None, out=None, key_splits=None):
     if ATTENTION_LAUNCH_EVENTS is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    check(lib.glare_attention_kv512_bf16(ptr(q), _i(ldq), ptr(kv), _i(ldkv), ptr(out), _i(out.shape[-1]), _i(B), _i(N), _i(ks),
-                                         ptr(ws), _sz(nws), stream_handle()), "glare_attention_kv512_bf16")
+    if pair:      # the output as a hi / lo pair (`out._lo`): the operand of an fp32-class output projection
+        out_lo = torch.empty_like(out)
+        check(lib.glare_attention_kv512_pair_bf16(ptr(q), _i(ldq), ptr(kv), _i(ldkv), ptr(out), ptr(out_lo), _i(out.shape[-1]), _i(B), _i(N),
+                                                  _i(ks), ptr(ws), _sz(nws), stream_handle()), "glare_attention_kv512_pair_bf16")
+        out._lo = out_lo
+    else:
+        check(lib.glare_attention_kv512_bf16(ptr(q), _i(ldq), ptr(kv), _i(ldkv), ptr(out), _i(out.shape[-1]), _i(B), _i(N), _i(ks),
+                                             ptr(ws), _sz(nws), stream_handle()), "glare_attention_kv512_bf16")
     if ev is not None:
         ev[1].record()
         ATTENTION_LAUNCH_EVENTS.append((ev[0], ev[1], int(B), int(N)))

@@ -356,6 +356,10 @@ int glare_attention_d512_backward_bf16(const void* q, const void* k, const void*
  * key_splits > 1: keys split over workgroups as above (workspace of glare_attention_d512_splitk_workspace_bytes); 1: none needed. */
 int glare_attention_kv512_bf16(const void* q, int ldq, const void* kv, int ldkv, void* out, int ldo, int B, int N, int key_splits,
                                void* workspace, size_t workspace_bytes, glare_stream_t stream);
+/* ... with the output as a hi / lo pair (out_lo: same shape / ldo, value = out + out_lo; NULL = the call above): the fp32
+ * accumulators leave with 22 bits, as the operand pair of an fp32-class output projection (glare_conv_desc.k_wrap). */
+int glare_attention_kv512_pair_bf16(const void* q, int ldq, const void* kv, int ldkv, void* out, void* out_lo, int ldo, int B, int N,
+                                    int key_splits, void* workspace, size_t workspace_bytes, glare_stream_t stream);
 
 /* ---- a9: modulated deformable convolution (DCNv2), forward -----------------------------------
  * glare_mdcn_forward_f32 is the drop-in for the pybind function

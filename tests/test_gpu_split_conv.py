@@ -144,3 +144,26 @@ def test_flow_h1_pair():
     ref = F.relu(ftA[..., 64:] + F.conv2d(z[..., :1].permute(0, 3, 1, 2), wz.view(64, 1, 3, 3), None, 1, 1).permute(0, 2, 3, 1))
     assert torch.equal(h1, plain)
     within(float((_val(h1) - ref).abs().max() / ref.abs().max()), 2e-6)
+
+
+@pytest.mark.parametrize("B,N", [(8, 300), (1, 700)])       # one workgroup per query block / keys split over 4 workgroups
+def test_attention_pair_output_keeps_the_accumulators(B, N):
+    """attention_kv512(pair=True): hi + lo of the output equals softmax(q.x^T) x on the stored 16-bit operands to ~1e-5 (the
+    probabilities are rounded to 16 bits inside the kernel: that is the kernel's arithmetic, not storage), where hi alone carries
+    the 2^-11 storage rounding; hi is bit-identical to the plain call."""
+    g = torch.Generator().manual_seed(N)
+    x = (torch.randn((B, N, 512), generator=g)).half().cuda()
+    q = (torch.randn((B, N, 512), generator=g) * 0.08).half().cuda()
+    with ops.use_precision("fp16"):
+        a = ops.attention_kv512(q, x, N, pair=True)
+        plain = ops.attention_kv512(q, x, N)
+    assert torch.equal(a, plain)
+    s = torch.einsum("bid,bjd->bij", q.double(), x.double()) * 0.6931471805599453          # the kernel's scores are log2-domain
+    ref = torch.einsum("bij,bjd->bid", torch.softmax(s, -1), x.double()).float()
+    e_pair = float((_val(a) - ref).abs().max() / ref.abs().max())
+    e_hi = float((a.float() - ref).abs().max() / ref.abs().max())
+    within(e_pair, 4e-4, N)              # P rounded to fp16 before P.V: ~1e-4
+    assert e_hi >= e_pair
+    # the pair removes the STORAGE rounding: against the kernel's own fp32 result (hi + lo) hi is 2^-12-ish, lo exact to 2^-22
+    assert float((a._lo.float().abs().max())) > 0
+    assert float((a._lo.float().abs() / (a.float().abs() + 1e-3)).max()) < 2.0 ** -10
