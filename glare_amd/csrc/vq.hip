@@ -132,7 +132,9 @@ extern "C" int glare_vq_nearest_f32(const float* z_nhwc, const float* codebook, 
   long long lanes = (n_tokens + VQ_TPT - 1) / VQ_TPT;
   int slots = (int)(((lanes + 255) / 256 + 63) / 64 * 64);
   if (slots < 64) slots = 64;
-  if (slots > VQ_THREADS / 4) slots = VQ_THREADS / 4;
+  if (slots > 128) slots = VQ_THREADS / 4;   // divisors of VQ_THREADS only (64 / 128 / 256): with 192 the last wave had part == parts and
+                                             // scanned / exchanged past the resident chunk (its results were dropped, but it read and
+                                             // wrote LDS beyond the allocation)
   // per call, not cached: the attribute is per device and the library keeps no state
   if (hipFuncSetAttribute((const void*)vq_nearest_kernel<VQ_TPT>,
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

@@ -249,7 +249,31 @@ class FlowUpsamplerNet(HipModule):
             h1 = ops.flow_h1(z, ftA, 0, w0f[:, 0].reshape(64, 9).float().contiguous())
             ops.conv2d(tail(a, h1), ops.PackedConv(*a[4].folded()), out=h4, out_off=0, out_mode=F32)
             ops.flow_fwd_post(z, h4, eps, partial)
+        self._share_actnorm_init([m for m in self.actnorms() if id(m) in need])
         self.invalidate()
+
+    @staticmethod
+    def _share_actnorm_init(actnorms):
+        """Data-parallel training (one process per GPU): every rank has just initialised these ActNorms from ITS OWN crops, and the
+        gradient all-reduce only keeps EQUAL replicas equal.  The reference's single-process nn.DataParallel initialises the one
+        shared copy of the parameters from the replica on the first device (in-place `.data.copy_` on storage the replica shares
+        with the module, FlowActNorms.py:43-44): rank 0's statistics are everybody's -- one broadcast of the flat (bias, logs)."""
+        import torch.distributed as dist
+
+        if not actnorms or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        tensors = [t for m in actnorms for t in (m.bias.data, m.logs.data)]
+        flat = torch.cat([t.reshape(-1) for t in tensors])
+        if dist.get_backend() == "gloo" and flat.is_cuda:      # two ranks sharing one GPU in the tests: gloo carries host tensors
+            host = flat.cpu()
+            dist.broadcast(host, src=0)
+            flat = host.to(flat.device)
+        else:
+            dist.broadcast(flat, src=0)
+        off = 0
+        for t in tensors:
+            t.copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
 
     def _prepare_forward(self):
         """Host-side composition for the normal direction: per coupling step the affine map of its own

@@ -6,6 +6,7 @@ never uses (scale / bias / enc, conv_out) so that checkpoints load unchanged."""
 import torch
 import torch.nn as nn
 
+from .. import _lib
 from .. import autograd as A
 from .. import ops
 from ._base import HipModule, packed_conv, to_nchw, to_nhwc
@@ -15,10 +16,11 @@ from .ops.dcn import ModulatedDeformConvPack, modulated_deform_conv
 
 import os
 
-# Inference under the fp16 precision: the DCN contraction as ONE half-precision MFMA per product (GLARE_MDCN_SINGLE_PASS) -- the
-# arithmetic of every other convolution of the decoder -- instead of the split fp32-class form.  GLARE_DCN_SINGLE_PASS=0 keeps the
-# split form everywhere; bf16 inference (8 mantissa bits), the op-level API and training always use the split form.
-DCN_SINGLE_PASS = os.environ.get("GLARE_DCN_SINGLE_PASS", "1") != "0"
+# The DCN contraction is the split fp32-class form everywhere by default (the reference contracts in fp32:
+# deformableDecoder_arch.py:143,550-551, deform_conv_cuda.cpp:551-554).  GLARE_DCN_SINGLE_PASS=1 opts inference under the fp16
+# precision into ONE half-precision MFMA per product (GLARE_MDCN_SINGLE_PASS: the arithmetic of every other convolution of the decoder;
+# 1.1-1.5e-4 of max|out| against the split form, -0.9 / -0.6 ms per launch) -- an A/B switch, never the default (round 4).
+DCN_SINGLE_PASS = os.environ.get("GLARE_DCN_SINGLE_PASS", "0") == "1"
 
 
 class DCNv2Pack(ModulatedDeformConvPack, HipModule):
@@ -38,7 +40,16 @@ class DCNv2Pack(ModulatedDeformConvPack, HipModule):
         plane = (H * W + 63) // 64 * 64
         om = ops.conv2d(feat, packed_conv(self, self.conv_offset), out_mode=ops.OUT_PLANAR_F32, plane_pitch=plane)
         single = DCN_SINGLE_PASS and ops.precision() == "fp16" and x.dtype == torch.float16
-        pd = self._packed("dcn1" if single else "dcn", lambda: ops.PackedDcn(self.weight, self.bias, self.deformable_groups, single=single))
+        if single:
+            # the single-pass form lives in the fast kernel only (every tensor < 2 GB, < 2^31 pixels): shapes beyond it -- batch ~20 at
+            # 400x600, a few 1080p images -- take the split form, whose call falls through to the general-extent kernel
+            pd = self._packed("dcn1", lambda: ops.PackedDcn(self.weight, self.bias, self.deformable_groups, single=True))
+            try:
+                return ops.mdcn_forward_nhwc(x, om, pd, x_off=x_off, C=self.in_channels, mask_is_logit=True, padding=self.padding)
+            except _lib.GlareError as e:
+                if "unsupported" not in str(e).lower():
+                    raise
+        pd = self._packed("dcn", lambda: ops.PackedDcn(self.weight, self.bias, self.deformable_groups, single=False))
         return ops.mdcn_forward_nhwc(x, om, pd, x_off=x_off, C=self.in_channels, mask_is_logit=True, padding=self.padding)
 
     def train_nhwc(self, x, feat):

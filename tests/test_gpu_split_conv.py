@@ -1,8 +1,8 @@
 """GPU: the fp32-class form of the MFMA convolution (glare_conv_desc.k_wrap, ops.PackedConv(split=3)): activation and filter
 each a hi / lo pair of 16-bit tensors (22 mantissa bits), contracted as x_hi.w_hi + x_lo.w_hi + x_hi.w_lo in ONE accumulation
 over three K segments -- against F.conv2d in fp32 on the UNROUNDED fp32 operands (what the reference's fp32 nn.Conv2d computes,
-encoder_decoder.py:88-115).  Tolerance: the dropped x_lo.w_lo term (2^-22) + fp32 summation order: 2e-5 of max|ref| asserted
-(measured ~3e-6); the single-pass kernel on the same data is asserted to be >= 30x worse, so the test cannot pass on a launch
+encoder_decoder.py:88-115).  Tolerance: the dropped x_lo.w_lo term (2^-22) + fp32 summation order: 3.5e-6 of max|ref| asserted
+(measured 1.8e-6); the single-pass kernel on the same data is asserted to be >= 30x worse, so the test cannot pass on a launch
 that silently ignored the lo halves."""
 import pytest
 import torch
@@ -57,8 +57,7 @@ def test_split3_conv_matches_the_fp32_conv(prec, B, Cin, Cout, H, W, k, stride):
         out = ops.conv2d(xp, ops.PackedConv(w.cuda(), b.cuda(), split=3), stride=stride, out_mode=ops.OUT_NHWC_F32)
         plain = ops.conv2d(xp, ops.PackedConv(w.cuda(), b.cuda()), stride=stride, out_mode=ops.OUT_NHWC_F32)
     e3, e1 = _err(out, ref), _err(plain, ref)
-    bits = 11 if prec == "fp16" else 8
-    within(e3, 8.0 * 2.0 ** (-2 * bits), prec)           # fp16: 1.9e-6 ... measured ~5e-7; bf16: 1.2e-4
+    within(e3, 3.5e-6 if prec == "fp16" else 1.0e-5, prec)    # measured on MI355X (max over the cases): fp16 1.76e-6, bf16 5.0e-6
     assert e1 > 30 * e3, (e1, e3)
 
 

@@ -1030,7 +1030,7 @@ def test_step_with_nonfinite_gradients_is_skipped(device_state):
     assert opt.scaler_state_dict() == {**sd, "scale": sd["scale"] * 2, "_growth_tracker": 0, "growth_interval": 3}
 
 
-def _two_rank_stage2_worker(rank, world, port, q):
+def _two_rank_stage2_worker(rank, world, port, q, fresh_flow=False):
     import os
 
     import torch.distributed as dist
@@ -1043,7 +1043,12 @@ def _two_rank_stage2_worker(rank, world, port, q):
     from glare_amd.train import Stage2Trainer
 
     dev = torch.device("cuda", 0)
-    netG = seeded_init_(M.LLFlowVQGAN2().train(), 2).to(dev)
+    netG = seeded_init_(M.LLFlowVQGAN2().train(), 2)
+    if fresh_flow:       # a flow whose ActNorms take their data-dependent initialisation in the first step, per rank
+        from glare_amd.synthetic import reset_actnorms_
+
+        netG = reset_actnorms_(netG).train()
+    netG = netG.to(dev)
     net_hq = seeded_init_(M.VQModel().eval(), 1).to(dev)
     tr = Stage2Trainer(netG, net_hq, lr_G=1e-4)
     g = torch.Generator().manual_seed(100 + rank)                     # every rank trains on its own crops
@@ -1063,8 +1068,11 @@ def _two_rank_stage2_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_stage2_steps_keep_the_replicas_identical():
-    """BASELINE configs[3] on real kernels with world_size 2 (both ranks on this one GPU, gloo carrying the exchange -- RCCL cannot
+@pytest.mark.parametrize("fresh_flow", [False, True])
+def test_two_rank_stage2_steps_keep_the_replicas_identical(fresh_flow):
+    """fresh_flow: the ActNorm data-dependent initialisation happens inside the first step, from different crops on every rank --
+    rank 0's result is broadcast (FlowUpsamplerNet._share_actnorm_init), or the replicas would start apart and stay apart.
+    BASELINE configs[3] on real kernels with world_size 2 (both ranks on this one GPU, gloo carrying the exchange -- RCCL cannot
     put two ranks on one device; the code path is FlatGroup.all_reduce either way): different crops AND different `train_gt_ratio`
     branches per rank, three steps -- the replicas must hold bit-identical parameters afterwards (every rank applies the same
     all-reduced gradient to the same static parameter set), and color_conv must have moved on both."""
@@ -1078,7 +1086,7 @@ def test_two_rank_stage2_steps_keep_the_replicas_identical():
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_two_rank_stage2_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_two_rank_stage2_worker, args=(r, 2, port, q, fresh_flow)) for r in range(2)]
     for p in procs:
         p.start()
     got = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
