@@ -31,6 +31,44 @@ import torch  # noqa: E402
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 = dense fp16, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_TBS = 8.0
 H_IMG, W_IMG, PAD = 400, 600, 20
+# Tests only (tests/test_bench_launch.py): GLARE_BENCH_STUB=1 runs THIS file's rank / collective / timing skeleton -- process-group
+# init, per-step gather, barriers, max over ranks, the train block's exchange, the JSON line -- on CPU over gloo with the HIP
+# pipeline replaced by tensor stand-ins, so that the first real N > 1 run is not the first execution of that code.  The line it
+# prints says "stub": true and is never a measurement.
+STUB = os.environ.get("GLARE_BENCH_STUB") == "1"
+
+
+def device_sync():
+    if not STUB:
+        torch.cuda.synchronize()
+
+
+def timed_steps(step, steps, warmup, dist):
+    """The contract's timed region: W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + synchronize on both
+    sides; returns this rank's seconds and the last output."""
+    out = None
+    for i in range(warmup):
+        out = step(i)
+    device_sync()
+    if dist is not None:
+        dist.barrier()
+    device_sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        out = step(i)
+    device_sync()
+    if dist is not None:
+        dist.barrier()
+    device_sync()
+    return time.perf_counter() - t0, out
+
+
+def max_over_ranks(dt, dist, device):
+    if dist is None:
+        return dt
+    t = torch.tensor([dt], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
 
 
 def build_inputs(batch, device, seed=1234):
@@ -150,46 +188,58 @@ def train_block(device, rank, world, steps=8, warmup=3):
     flat fp32 gradient buffer inside every step (106 MB / 176 MB)."""
     import torch.distributed as dist
 
-    from glare_amd import modules as M
-    from glare_amd.synthetic import seeded_init_
-    from glare_amd.train import GraphedStep, Stage2Trainer, Stage3Trainer
+    from glare_amd.train import FlatGroup
 
     res = {"steps": steps, "warmup": warmup, "world": world,
-           "exchange": "none (1 GPU)" if world == 1 else "RCCL all-reduce of the flat fp32 gradient buffer per parameter group, every step"}
+           "exchange": "none (1 GPU)" if world == 1 else "RCCL all-reduce of the flat fp32 gradient buffer per parameter group, every step "
+                                                         "(stage 2: the flow group's starts under the conditional encoder's backward)"}
     g = torch.Generator().manual_seed(10 + rank)
-    net_hq = seeded_init_(M.VQModel().eval(), 1).to(device)
+    if STUB:
+        class _StubTrainer:          # the exchange of a real step (FlatGroup: early + blocking all-reduce) around a toy graph
+            def __init__(self):
+                self.a, self.b = torch.nn.Linear(4, 4), torch.nn.Linear(4, 2)
+                self.groups = [FlatGroup(list(self.b.parameters()), 1e-3), FlatGroup(list(self.a.parameters()), 1e-3)]
+
+            def step_tensor(self, gt, lr):
+                for grp in self.groups:
+                    grp.zero_grad()
+                loss = self.b(torch.tanh(self.a(lr))).sum()
+                self.groups[0].arm_early_all_reduce()
+                loss.backward()
+                for grp in self.groups:
+                    if grp.finish_early_all_reduce() is None:
+                        grp.collect()
+                        grp.all_reduce()
+                return loss.detach()
+        net_hq = None
+    else:
+        from glare_amd import modules as M
+        from glare_amd.synthetic import seeded_init_
+        from glare_amd.train import GraphedStep, Stage2Trainer, Stage3Trainer
+
+        net_hq = seeded_init_(M.VQModel().eval(), 1).to(device)
     for name, B, S in (("stage2", 2, 320), ("stage3", 1, 256)):
-        graph = world == 1 and name == "stage2"
-        if name == "stage2":
-            tr = Stage2Trainer(seeded_init_(M.LLFlowVQGAN2().train(), 2).to(device), net_hq, device_state=graph)
+        graph = world == 1 and name == "stage2" and not STUB
+        if STUB:
+            tr, gt, lr = _StubTrainer(), torch.zeros(B, 4), torch.randn(B, 4, generator=g)
         else:
-            tr = Stage3Trainer(seeded_init_(M.VQLLFLOWDeformable().train(), 0).to(device), net_hq, device_state=graph)
-        gt = torch.rand(B, 3, S, S, generator=g).to(device)
-        lr = (torch.randn(B, 3, S, S, generator=g) * 0.5 - 1.0).to(device)
+            if name == "stage2":
+                tr = Stage2Trainer(seeded_init_(M.LLFlowVQGAN2().train(), 2).to(device), net_hq, device_state=graph)
+            else:
+                tr = Stage3Trainer(seeded_init_(M.VQLLFLOWDeformable().train(), 0).to(device), net_hq, device_state=graph)
+            gt = torch.rand(B, 3, S, S, generator=g).to(device)
+            lr = (torch.randn(B, 3, S, S, generator=g) * 0.5 - 1.0).to(device)
         runner = GraphedStep(tr, gt, lr) if graph else tr
-        for _ in range(warmup):
-            loss = runner.step_tensor(gt, lr)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            loss = runner.step_tensor(gt, lr)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+        dt, loss = timed_steps(lambda i: runner.step_tensor(gt, lr), steps, warmup, dist if world > 1 else None)
+        dt = max_over_ranks(dt, dist if world > 1 else None, device)
         assert bool(torch.isfinite(loss).all())
         res["%s_ms_per_step" % name] = round(dt / steps * 1e3, 2)
         res["%s_samples_per_sec" % name] = round(B * world * steps / dt, 2)
         res["%s_graph" % name] = graph
         res["%s_crop" % name] = "%d x 3x%dx%d per GPU" % (B, S, S)
         del tr, runner
-        torch.cuda.empty_cache()
+        if not STUB:
+            torch.cuda.empty_cache()
     res["graph"] = res["stage2_graph"]
     return res
 
@@ -251,26 +301,36 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X (the HIP kernels are the only implementation)"
+    assert STUB or torch.cuda.is_available(), "bench.py needs an MI355X (the HIP kernels are the only implementation)"
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d: launch one rank per GPU (or let bench.py do it)" % (args.gpus, world)
-    assert torch.cuda.device_count() > local_rank, "rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count())
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    if STUB:
+        device = torch.device("cpu")
+    else:
+        assert torch.cuda.device_count() > local_rank, "rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count())
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)  # RCCL on ROCm
-        assert dist.get_world_size() == args.gpus and dist.get_backend() == "nccl"
+        if STUB:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)  # RCCL on ROCm
+        assert dist.get_world_size() == args.gpus and dist.get_backend() == ("gloo" if STUB else "nccl")
 
     from glare_amd import ops
 
     ops.use_precision(args.precision).__enter__()     # for the whole process
-    netG, net_vq = build_nets(device)
-    lr = build_inputs(args.batch, device, seed=1234 + rank)  # every rank enhances different images
+    if STUB:
+        netG = net_vq = None
+        lr = torch.full((args.batch, 3, 8, 12), float(rank + 1))
+    else:
+        netG, net_vq = build_nets(device)
+        lr = build_inputs(args.batch, device, seed=1234 + rank)  # every rank enhances different images
 
-    streams = [torch.cuda.Stream(device) for _ in range(args.streams)] if args.streams > 1 else None
+    streams = [torch.cuda.Stream(device) for _ in range(args.streams)] if (args.streams > 1 and not STUB) else None
 
     gatherer = None
     if world > 1:
@@ -279,9 +339,17 @@ def main():
         # the one exchange of the inference path (no data-path collective).  N = 1 has nothing to gather.
         from glare_amd import harness, parallel
 
-        gatherer = parallel.RankGather(torch.empty(args.batch, H_IMG, W_IMG, 3, dtype=torch.uint8, device=device), rank, world)
+        shape = (args.batch, 8, 12, 3) if STUB else (args.batch, H_IMG, W_IMG, 3)
+        gatherer = parallel.RankGather(torch.empty(shape, dtype=torch.uint8, device=device), rank, world)
 
     def enhance():
+        if STUB:
+            out = lr * 2.0                                          # stands in for the HIP pipeline
+            if gatherer is not None:
+                bufs = gatherer.gather(out.permute(0, 2, 3, 1).contiguous().to(torch.uint8))
+                if rank == 0:
+                    assert [int(b[0, 0, 0, 0]) for b in bufs] == [2 * (r + 1) for r in range(world)]   # every rank's batch arrived
+            return out
         out = netG.reverse_flow_nhwc(net_vq, lr)["out"]
         if gatherer is not None:
             restored, _ = harness.postprocess_device(out, H_IMG, W_IMG)
@@ -296,35 +364,18 @@ def main():
 
     with torch.no_grad():
         out = step()                                          # weights are packed once, on first use
-        torch.cuda.synchronize()
-        for i in range(args.warmup):
-            out = step(i)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        from glare_amd import ops
-
-        if rank == 0:
+        device_sync()
+        timed_steps(step, 0, args.warmup, dist)               # the W untimed warm-up steps (+ barrier)
+        if rank == 0 and not STUB:
             ops.ATTENTION_LAUNCH_EVENTS = []     # roofline: the dominant kernel's launches are timed where they run
-            ops.LAUNCH_EVENTS = {"conv3x3": [], "dcn": []}     # ... and the next two families (`rooflines`)
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            out = step(i)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+            ops.LAUNCH_EVENTS = {"conv3x3": [], "conv3x3_split": [], "dcn": []}     # ... and the next families (`rooflines`)
+        dt, out = timed_steps(step, args.steps, 0, dist)      # EXACTLY K steps between barrier + synchronize
         live_events, ops.ATTENTION_LAUNCH_EVENTS = ops.ATTENTION_LAUNCH_EVENTS or [], None
         family_events, ops.LAUNCH_EVENTS = ops.LAUNCH_EVENTS or {}, None
     assert bool(torch.isfinite(out).all())
-    if dist is not None:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(dt, dist, device)
 
-    if args.breakdown and rank == 0:
+    if args.breakdown and rank == 0 and not STUB:
         stage_breakdown(netG, net_vq, lr)
 
     train = None
@@ -350,11 +401,13 @@ def main():
                        "exchange": "none (1 GPU)" if world == 1 else "per step: crop/clamp/uint8 on device + RCCL gather of the "
                                    "enhanced [B,400,600,3] uint8 batches to rank 0 (inside the timed region)",
                        "weights": "random, name-seeded (no checkpoints offline)"},
-            "roofline": attention_roofline(device, args.batch, live_events),
-            "rooflines": family_rooflines(family_events, args.steps),
+            "roofline": None if STUB else attention_roofline(device, args.batch, live_events),
+            "rooflines": None if STUB else family_rooflines(family_events, args.steps),
             "train": train,
         }
-        if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
+        if STUB:
+            res["stub"] = True
+        if not args.no_cpu_baseline and world == 1 and not STUB:  # reported at N = 1 only
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)
     if dist is not None:

@@ -83,8 +83,9 @@ _DTYPE_AGNOSTIC = ("glare_vq_", "glare_harness_", "glare_ssim_")
 
 
 class _F16Lib:
-    """libglare_hip_f16.so behind the main library's names: `x_bf16` resolves to its export `x_f16`.  An entry point the half
-    library does not have (training kernels) raises -- it must never silently run a bf16 kernel on fp16 data."""
+    """libglare_hip_f16.so behind the main library's names: `x_bf16` resolves to its export `x_f16`.  Since round 4 the half
+    library is a build of EVERY source (inference and training kernels); an entry point it should ever lack raises -- it must
+    never silently run a bf16 kernel on fp16 data."""
 
     def __init__(self, cdll):
         self._c = cdll

@@ -45,13 +45,13 @@ constexpr int RB = 64;                 // resident rows per workgroup (2 blocks 
 constexpr int TILE_B = TB * HD * 2;    // bytes of one streamed tile (32 KB)
 
 struct BwdParams {
-  const bf16_t* r1;     // resident operand of the score product      [B][N][512]
-  const bf16_t* r2;     // resident operand of the dP product (WANT_DS)
-  const bf16_t* t1;     // streamed operands
-  const bf16_t* t2;
+  const a16_t* r1;     // resident operand of the score product      [B][N][512]
+  const a16_t* r2;     // resident operand of the dP product (WANT_DS)
+  const a16_t* t1;     // streamed operands
+  const a16_t* t2;
   const float* lse;     // [B][N] log2-sum-exp of the QUERY rows
   const float* dsum;    // [B][N] do . o of the query rows
-  bf16_t* out;          // [B][N][512] gradient of the resident rows
+  a16_t* out;          // [B][N][512] gradient of the resident rows
   int B, N, nblk, n_blocks;
   float ln2;
 };
@@ -62,8 +62,8 @@ template <int N>
 __device__ __forceinline__ void lgkm_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : "memory"); }
 __device__ __forceinline__ void tr_read(u32x2& dst, int addr) { asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst) : "v"(addr)); }
 __device__ __forceinline__ void pin(u32x2& a) { asm volatile("" : "+v"(a)); }
-__device__ __forceinline__ bf16x8 frag(const u32x2& lo, const u32x2& hi) {
-  return __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
+__device__ __forceinline__ a16x8 frag(const u32x2& lo, const u32x2& hi) {
+  return __builtin_bit_cast(a16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
 }
 
 // QS: the QUERIES are the streamed rows (dV, dK); WANT_DS: the output contracts dS with T1 (dK, dQ), else P with T2 (dV)
@@ -88,18 +88,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const BwdParams p) {
   const size_t img = (size_t)b * p.N;
 
   // ---- resident B fragments: lane (n, hi) holds row n, channels dh*256 + ks*16 + hi*8 .. +7
-  bf16x8 r1f[16], r2f[WANT_DS ? 16 : 1];
+  a16x8 r1f[16], r2f[WANT_DS ? 16 : 1];
   {
     const size_t base = (img + (r_ok ? rrow : 0)) * HD + dh * 256 + hi * 8;
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
       u32x4 a = *reinterpret_cast<const u32x4*>(p.r1 + base + ks * 16);
       if (!r_ok) a = u32x4{0u, 0u, 0u, 0u};
-      r1f[ks] = __builtin_bit_cast(bf16x8, a);
+      r1f[ks] = __builtin_bit_cast(a16x8, a);
       if (WANT_DS) {
         u32x4 c = *reinterpret_cast<const u32x4*>(p.r2 + base + ks * 16);
         if (!r_ok) c = u32x4{0u, 0u, 0u, 0u};
-        r2f[ks] = __builtin_bit_cast(bf16x8, c);
+        r2f[ks] = __builtin_bit_cast(a16x8, c);
       }
     }
   }
@@ -114,8 +114,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const BwdParams p) {
 
   // ---- DMA: one instruction = one row (64 lanes x 16 B); wave w moves rows w, w + 4, ... of both tiles; LDS chunk `lane` of row
   // r receives source chunk lane ^ swz(r), and swz(w + 4 i) = (w << 2) | (i & 3)
-  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.t1 + img * HD), 0, (int)((long long)p.N * HD * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.t2 + img * HD), 0, (int)((long long)p.N * HD * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<a16_t*>(p.t1 + img * HD), 0, (int)((long long)p.N * HD * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<a16_t*>(p.t2 + img * HD), 0, (int)((long long)p.N * HD * 2), 0x00020000);
   int dvo[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) dvo[i] = (lane ^ ((wave << 2) | i)) * 16;
@@ -189,14 +189,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const BwdParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { x[r] = 0.f; y[r] = 0.f; }
     // fragment reads one group (2 k-steps) ahead of the MFMAs that consume them
-    bf16x8 fa[2][2][2];   // [set][k-step of the group][T1 | T2]
-    auto ldg = [&](int g, bf16x8(&f)[2][2]) {
+    a16x8 fa[2][2][2];   // [set][k-step of the group][T1 | T2]
+    auto ldg = [&](int g, a16x8(&f)[2][2]) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int ks = 2 * g + j;
         const char* src = smem + BUF * 2 * TILE_B + (ks >> 3) * 256 + kofs[ks & 7];
-        f[j][0] = *reinterpret_cast<const bf16x8*>(src);
-        if (WANT_DS) f[j][1] = *reinterpret_cast<const bf16x8*>(src + TILE_B);
+        f[j][0] = *reinterpret_cast<const a16x8*>(src);
+        if (WANT_DS) f[j][1] = *reinterpret_cast<const a16x8*>(src + TILE_B);
       }
     };
     ldg(0, fa[0]);
@@ -205,8 +205,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const BwdParams p) {
       if (g + 1 < 8) ldg(g + 1, fa[(g + 1) & 1]);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g & 1][j][0], r1f[2 * g + j], x, 0, 0, 0);
-        if (WANT_DS) y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g & 1][j][1], r2f[2 * g + j], y, 0, 0, 0);
+        x = mfma_a16_32x32x16(fa[g & 1][j][0], r1f[2 * g + j], x, 0, 0, 0);
+        if (WANT_DS) y = mfma_a16_32x32x16(fa[g & 1][j][1], r2f[2 * g + j], y, 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const BwdParams p) {
     }
 #endif
     // ---- P / dS as bf16 B fragments: k-step e covers registers 8 e .. 8 e + 7 = streamed rows 16 e + 8 hi + 0..7
-    bf16x8 pf[2];
+    a16x8 pf[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       u32x4 w;
@@ -255,9 +255,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const BwdParams p) {
 #endif
           v[u] = WANT_DS ? pe * (y[r] - Dq) * p.ln2 : pe;
         }
-        w[j] = pack_bf2(v[0], v[1]);
+        w[j] = pack_a2(v[0], v[1]);
       }
-      pf[e] = __builtin_bit_cast(bf16x8, w);
+      pf[e] = __builtin_bit_cast(a16x8, w);
     }
     // ---- output: Out^T[d tile mt][r] += T^T[d][t] . (dS | P)[t][r]; 4 transposed reads per tile, one tile ahead of its MFMAs
     u32x2 tf[2][4];
@@ -277,8 +277,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const BwdParams p) {
       if (mt + 1 < 8) { rd(mt + 1, tf[(mt + 1) & 1]); lgkm_wait<4>(); } else { lgkm_wait<0>(); }
       u32x2(&f)[4] = tf[mt & 1];
       pin(f[0]); pin(f[1]); pin(f[2]); pin(f[3]);
-      o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(f[0], f[1]), pf[0], o[mt], 0, 0, 0);
-      o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(f[2], f[3]), pf[1], o[mt], 0, 0, 0);
+      o[mt] = mfma_a16_32x32x16(frag(f[0], f[1]), pf[0], o[mt], 0, 0, 0);
+      o[mt] = mfma_a16_32x32x16(frag(f[2], f[3]), pf[1], o[mt], 0, 0, 0);
     }
 #endif
   };
@@ -290,19 +290,19 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const BwdParams p) {
 
   // ---- store: a lane owns ONE resident row, 4 consecutive channels per 8-B store
   if (r_ok) {
-    bf16_t* d1 = p.out + (img + rrow) * HD + dh * 256;
+    a16_t* d1 = p.out + (img + rrow) * HD + dh * 256;
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
         const int d = mt * 32 + 8 * rq + 4 * hi;
-        *reinterpret_cast<u32x2*>(d1 + d) = u32x2{pack_bf2(o[mt][4 * rq], o[mt][4 * rq + 1]), pack_bf2(o[mt][4 * rq + 2], o[mt][4 * rq + 3])};
+        *reinterpret_cast<u32x2*>(d1 + d) = u32x2{pack_a2(o[mt][4 * rq], o[mt][4 * rq + 1]), pack_a2(o[mt][4 * rq + 2], o[mt][4 * rq + 3])};
       }
   }
 }
 
 // D[row] = do[row] . o[row] (fp32): one wave per row, 8 channels per lane
-__global__ __launch_bounds__(256) void attn_bwd_dsum_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+__global__ __launch_bounds__(256) void attn_bwd_dsum_kernel(const a16_t* __restrict__ o, const a16_t* __restrict__ dout,
                                                             float* __restrict__ dsum, long long rows) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dsum_kernel(const bf16_t* __rest
   const u32x4 g = *reinterpret_cast<const u32x4*>(dout + row * HD + lane * 8);
   float s = 0.f;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) s += bflo(a[e]) * bflo(g[e]) + bfhi(a[e]) * bfhi(g[e]);
+  for (int e = 0; e < 4; ++e) s += alo(a[e]) * alo(g[e]) + ahi(a[e]) * ahi(g[e]);
   s = wave_sum(s);
   if (lane == 0) dsum[row] = s;
 }
@@ -345,23 +345,23 @@ extern "C" int glare_attention_d512_backward_bf16(const void* q, const void* k, 
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* dsum = static_cast<float*>(workspace);
   const long long rows = (long long)B * N;
-  hipLaunchKernelGGL(attn_bwd_dsum_kernel, dim3((unsigned)cdivll(rows, 4)), dim3(256), 0, st, static_cast<const bf16_t*>(o),
-                     static_cast<const bf16_t*>(d_o), dsum, rows);
+  hipLaunchKernelGGL(attn_bwd_dsum_kernel, dim3((unsigned)cdivll(rows, 4)), dim3(256), 0, st, static_cast<const a16_t*>(o),
+                     static_cast<const a16_t*>(d_o), dsum, rows);
   BwdParams p;
   p.B = B; p.N = N; p.nblk = (N + RB - 1) / RB; p.n_blocks = B * p.nblk; p.ln2 = ln2_scale;
   p.lse = lse; p.dsum = dsum;
   // dV, dK: keys resident, queries streamed
-  p.r1 = static_cast<const bf16_t*>(k); p.r2 = static_cast<const bf16_t*>(v);
-  p.t1 = static_cast<const bf16_t*>(q); p.t2 = static_cast<const bf16_t*>(d_o);
-  p.out = static_cast<bf16_t*>(dv);
+  p.r1 = static_cast<const a16_t*>(k); p.r2 = static_cast<const a16_t*>(v);
+  p.t1 = static_cast<const a16_t*>(q); p.t2 = static_cast<const a16_t*>(d_o);
+  p.out = static_cast<a16_t*>(dv);
   int rc = launch_pass<true, false>(p, st);
   if (rc != GLARE_OK) return rc;
-  p.out = static_cast<bf16_t*>(dk);
+  p.out = static_cast<a16_t*>(dk);
   rc = launch_pass<true, true>(p, st);
   if (rc != GLARE_OK) return rc;
   // dQ: queries resident, keys streamed
-  p.r1 = static_cast<const bf16_t*>(q); p.r2 = static_cast<const bf16_t*>(d_o);
-  p.t1 = static_cast<const bf16_t*>(k); p.t2 = static_cast<const bf16_t*>(v);
-  p.out = static_cast<bf16_t*>(dq);
+  p.r1 = static_cast<const a16_t*>(q); p.r2 = static_cast<const a16_t*>(d_o);
+  p.t1 = static_cast<const a16_t*>(k); p.t2 = static_cast<const a16_t*>(v);
+  p.out = static_cast<a16_t*>(dq);
   return launch_pass<false, true>(p, st);
 }

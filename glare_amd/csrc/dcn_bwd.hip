@@ -53,7 +53,7 @@ template <bool XBF16>
 __device__ __forceinline__ void load8b(const void* base, long long elem_off, bool ok, Corner8<XBF16>& c) {
   const u32x4 z = {0u, 0u, 0u, 0u};
   if (XBF16) {
-    c.v0 = ok ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(base) + elem_off) : z;
+    c.v0 = ok ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const a16_t*>(base) + elem_off) : z;
   } else {
     const float* p = reinterpret_cast<const float*>(base) + elem_off;
     c.v0 = ok ? *reinterpret_cast<const u32x4*>(p) : z;
@@ -62,7 +62,7 @@ __device__ __forceinline__ void load8b(const void* base, long long elem_off, boo
 }
 template <bool XBF16>
 __device__ __forceinline__ float elem8(const Corner8<XBF16>& c, int e) {
-  if (XBF16) return (e & 1) ? bfhi(c.v0[e >> 1]) : bflo(c.v0[e >> 1]);
+  if (XBF16) return (e & 1) ? ahi(c.v0[e >> 1]) : alo(c.v0[e >> 1]);
   return __uint_as_float(e < 4 ? c.v0[e] : c.v1[e - 4]);
 }
 

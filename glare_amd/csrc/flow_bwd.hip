@@ -35,7 +35,7 @@ __global__ __launch_bounds__(FB_THREADS) void flow_nll_bwd_kernel(const float* _
 __global__ __launch_bounds__(FB_THREADS) void flow_post_bwd_kernel(float* __restrict__ gz, const float* __restrict__ z_pre,
                                                                    const float* __restrict__ h4, const float* __restrict__ g_logdet,
                                                                    long long pix_per_sample, long long npix, float eps,
-                                                                   bf16_t* __restrict__ gh4) {
+                                                                   a16_t* __restrict__ gh4) {
   const long long p = (long long)blockIdx.x * FB_THREADS + threadIdx.x;
   if (p >= npix) return;
   const float gl = g_logdet[p / pix_per_sample];
@@ -50,12 +50,12 @@ __global__ __launch_bounds__(FB_THREADS) void flow_post_bwd_kernel(float* __rest
     out[2 * c + 1] = gs * sg * (1.f - sg);    // d / d raw
     gz[p * 3 + 1 + c] = g * s;
   }
-  u32x4 o = {pack_bf2(out[0], out[1]), pack_bf2(out[2], out[3]), 0u, 0u};
+  u32x4 o = {pack_a2(out[0], out[1]), pack_a2(out[2], out[3]), 0u, 0u};
   *reinterpret_cast<u32x4*>(gh4 + p * 8) = o;
 }
 
 // g: masked gradient of h1's pre-activation, bf16 [pixel][g_pitch] channels [g_off, g_off+64)
-__global__ __launch_bounds__(FB_THREADS) void flow_h1_bwd_kernel(float* __restrict__ gz, const bf16_t* __restrict__ g, int g_pitch,
+__global__ __launch_bounds__(FB_THREADS) void flow_h1_bwd_kernel(float* __restrict__ gz, const a16_t* __restrict__ g, int g_pitch,
                                                                  int g_off, const float* __restrict__ z_pre,
                                                                  const float* __restrict__ wz, int B, int H, int W,
                                                                  float* __restrict__ gwz_partial) {
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(FB_THREADS) void flow_h1_bwd_kernel(float* __restri
       const u32x4 gs = *reinterpret_cast<const u32x4*>(g + pix * g_pitch + g_off + grp * 8);
       float ge[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { ge[2 * e] = bflo(gs[e]); ge[2 * e + 1] = bfhi(gs[e]); }
+      for (int e = 0; e < 4; ++e) { ge[2 * e] = alo(gs[e]); ge[2 * e + 1] = ahi(gs[e]); }
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int dy = t / 3 - 1, dx = t % 3 - 1;
@@ -95,8 +95,8 @@ __global__ __launch_bounds__(FB_THREADS) void flow_h1_bwd_kernel(float* __restri
           const u32x4 gn = *reinterpret_cast<const u32x4*>(g + (pix - (long long)dy * W - dx) * g_pitch + g_off + grp * 8);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            dz = fmaf(bflo(gn[e]), wl[t][grp * 8 + 2 * e], dz);
-            dz = fmaf(bfhi(gn[e]), wl[t][grp * 8 + 2 * e + 1], dz);
+            dz = fmaf(alo(gn[e]), wl[t][grp * 8 + 2 * e], dz);
+            dz = fmaf(ahi(gn[e]), wl[t][grp * 8 + 2 * e + 1], dz);
           }
         }
       }
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(FB_THREADS) void flow_pre_bwd_kernel(float* __restr
                                                                   const float* __restrict__ hF, int f_pitch, int f_off,
                                                                   const float* __restrict__ g_logdet, long long pix_per_sample,
                                                                   long long npix, AffineParams ap, const float* __restrict__ mt_dev,
-                                                                  float eps, bf16_t* __restrict__ ghF, int gf_pitch, int gf_off,
+                                                                  float eps, a16_t* __restrict__ ghF, int gf_pitch, int gf_off,
                                                                   float* __restrict__ partial) {
   __shared__ float red[FB_THREADS / 64][12];
   if (mt_dev) {
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(FB_THREADS) void flow_pre_bwd_kernel(float* __restr
       gf[2 * i] = g * s;
       gf[2 * i + 1] = gs * sg * (1.f - sg);
     }
-    u32x4 o = {pack_bf2(gf[0], gf[1]), pack_bf2(gf[2], gf[3]), pack_bf2(gf[4], gf[5]), 0u};
+    u32x4 o = {pack_a2(gf[0], gf[1]), pack_a2(gf[2], gf[3]), pack_a2(gf[4], gf[5]), 0u};
     *reinterpret_cast<u32x4*>(ghF + p * gf_pitch + gf_off) = o;
 #pragma unroll
     for (int j = 0; j < 3; ++j) gz[p * 3 + j] = ap.M[j] * gy[0] + ap.M[3 + j] * gy[1] + ap.M[6 + j] * gy[2];   // M^T gy
@@ -202,7 +202,7 @@ extern "C" int glare_flow_fwd_post_backward_f32(float* gz, const float* z_pre, c
   if (!gz || !z_pre || !h4 || !g_logdet_per_sample || !gh4_bf16x8 || B <= 0 || pixels_per_sample <= 0) return GLARE_ERR_INVALID;
   const long long npix = (long long)B * pixels_per_sample;
   hipLaunchKernelGGL(flow_post_bwd_kernel, dim3((unsigned)cdivll(npix, FB_THREADS)), dim3(FB_THREADS), 0, ST(stream), gz, z_pre, h4,
-                     g_logdet_per_sample, pixels_per_sample, npix, eps, static_cast<bf16_t*>(gh4_bf16x8));
+                     g_logdet_per_sample, pixels_per_sample, npix, eps, static_cast<a16_t*>(gh4_bf16x8));
   return glare_launch_status();
 }
 
@@ -211,7 +211,7 @@ extern "C" int glare_flow_h1_backward_f32(float* gz, const void* gh1_bf16, int g
   if (!gz || !gh1_bf16 || !z_pre || !wz_64x9 || !gwz_partial || B <= 0 || H <= 0 || W <= 0) return GLARE_ERR_INVALID;
   if ((g_pitch % 8) || (g_off % 8) || g_off + 64 > g_pitch) return GLARE_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(flow_h1_bwd_kernel, dim3(glare_flow_bwd_blocks((long long)B * H * W)), dim3(FB_THREADS), 0, ST(stream), gz,
-                     static_cast<const bf16_t*>(gh1_bf16), g_pitch, g_off, z_pre, wz_64x9, B, H, W, gwz_partial);
+                     static_cast<const a16_t*>(gh1_bf16), g_pitch, g_off, z_pre, wz_64x9, B, H, W, gwz_partial);
   return glare_launch_status();
 }
 
@@ -230,7 +230,7 @@ extern "C" int glare_flow_fwd_pre_backward_f32(float* gz, const float* z_in, con
   const long long npix = (long long)B * pixels_per_sample;
   hipLaunchKernelGGL(flow_pre_bwd_kernel, dim3(glare_flow_bwd_blocks(npix)), dim3(FB_THREADS), 0, ST(stream), gz, z_in, hF, hF_pitch,
                      hF_off, g_logdet_per_sample, pixels_per_sample, npix, ap, (const float*)nullptr, eps,
-                     static_cast<bf16_t*>(ghF_bf16), ghF_pitch, ghF_off, gMt_partial);
+                     static_cast<a16_t*>(ghF_bf16), ghF_pitch, ghF_off, gMt_partial);
   return glare_launch_status();
 }
 
@@ -245,7 +245,7 @@ extern "C" int glare_flow_fwd_pre_backward_dev_f32(float* gz, const float* z_in,
   AffineParams ap = {};
   const long long npix = (long long)B * pixels_per_sample;
   hipLaunchKernelGGL(flow_pre_bwd_kernel, dim3(glare_flow_bwd_blocks(npix)), dim3(FB_THREADS), 0, ST(stream), gz, z_in, hF, hF_pitch,
-                     hF_off, g_logdet_per_sample, pixels_per_sample, npix, ap, Mt_12_device, eps, static_cast<bf16_t*>(ghF_bf16),
+                     hF_off, g_logdet_per_sample, pixels_per_sample, npix, ap, Mt_12_device, eps, static_cast<a16_t*>(ghF_bf16),
                      ghF_pitch, ghF_off, gMt_partial);
   return glare_launch_status();
 }

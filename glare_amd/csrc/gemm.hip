@@ -19,8 +19,8 @@ namespace {
 constexpr int BM = 256, BN = 128, BK = 32;
 
 struct GemmParams {
-  const bf16_t* A;
-  const bf16_t* B;
+  const a16_t* A;
+  const a16_t* B;
   void* C;
   int M, N, K;
   long long lda, ldb, ldc, sA, sB, sC;
@@ -39,13 +39,13 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const GemmParams p) {
   const int tm = blockIdx.x % p.tiles_m, tn = blockIdx.x / p.tiles_m;  // m fastest: neighbours share the B tile in L2
   const int b = blockIdx.y;
   const int row0 = tm * BM, col0 = tn * BN;
-  const bf16_t* Ab = p.A + (long long)b * p.sA + (long long)row0 * p.lda;
-  const bf16_t* Bb = p.B + (long long)b * p.sB + (long long)col0 * p.ldb;
+  const a16_t* Ab = p.A + (long long)b * p.sA + (long long)row0 * p.lda;
+  const a16_t* Bb = p.B + (long long)b * p.sB + (long long)col0 * p.ldb;
   const int rowsA = min(p.M - row0, BM), rowsB = min(p.N - col0, BN);
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<bf16_t*>(Ab), 0, (int)((((long long)rowsA - 1) * p.lda + p.K) * 2), 0x00020000);
+      const_cast<a16_t*>(Ab), 0, (int)((((long long)rowsA - 1) * p.lda + p.K) * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<bf16_t*>(Bb), 0, (int)((((long long)rowsB - 1) * p.ldb + p.K) * 2), 0x00020000);
+      const_cast<a16_t*>(Bb), 0, (int)((((long long)rowsB - 1) * p.ldb + p.K) * 2), 0x00020000);
   // DMA lane geometry: one instruction = 16 rows x 64 B; lane -> (row r, LDS chunk c'), source chunk c' ^ s(r)
   const int dr = lane >> 2, dc = (lane & 3) ^ ((dr >> 2) & 3);
   const int voffA = (int)((dr * p.lda + dc * 8) * 2), voffB = (int)((dr * p.ldb + dc * 8) * 2);
@@ -86,15 +86,15 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const GemmParams p) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int c = (ks * 2 + khalf) ^ sw;
-      bf16x8 af[4], bfr[2];
+      a16x8 af[4], bfr[2];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bfr[j] = __builtin_bit_cast(bf16x8, cB[j * 128 + c]);
+      for (int j = 0; j < 2; ++j) bfr[j] = __builtin_bit_cast(a16x8, cB[j * 128 + c]);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = __builtin_bit_cast(bf16x8, cA[i * 128 + c]);
+      for (int i = 0; i < 4; ++i) af[i] = __builtin_bit_cast(a16x8, cA[i * 128 + c]);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma_a16_32x32x16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
   }
 
@@ -112,9 +112,9 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const GemmParams p) {
           const long long idx = cbase + (long long)m * p.ldc + n;
           float v = p.alpha * acc[i][j][r];
           if (p.out_bf16) {
-            bf16_t* o = reinterpret_cast<bf16_t*>(Cb) + idx;
-            if (p.accumulate) v += bf2f(*o);
-            *o = f2bf(v);
+            a16_t* o = reinterpret_cast<a16_t*>(Cb) + idx;
+            if (p.accumulate) v += a2f(*o);
+            *o = f2a(v);
           } else {
             float* o = reinterpret_cast<float*>(Cb) + idx;
             if (p.accumulate) v += *o;
@@ -194,8 +194,8 @@ static int gemm_launch(const void* A, const void* B, void* C, int M, int N, int 
   if ((BM * lda + K) * 2 >= (1ll << 31) || (BN * ldb + K) * 2 >= (1ll << 31)) return GLARE_ERR_UNSUPPORTED;  // 32-bit DMA offsets
   if (batch > 65535) return GLARE_ERR_UNSUPPORTED;
   GemmParams p;
-  p.A = static_cast<const bf16_t*>(A);
-  p.B = static_cast<const bf16_t*>(B);
+  p.A = static_cast<const a16_t*>(A);
+  p.B = static_cast<const a16_t*>(B);
   p.C = C;
   p.M = M; p.N = N; p.K = K;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.sA = strideA; p.sB = strideB; p.sC = strideC;

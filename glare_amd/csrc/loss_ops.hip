@@ -133,26 +133,26 @@ __global__ __launch_bounds__(LT) void ssim_bwd_gather_kernel(const float* __rest
 }
 
 // 2x2 max-pool, stride 2 (vgg16.features[4], [9]) on NHWC bf16; backward routes to the FIRST maximum in scan order (ATen)
-__global__ __launch_bounds__(LT) void maxpool2_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int B, int H, int W, int C) {
+__global__ __launch_bounds__(LT) void maxpool2_kernel(const a16_t* __restrict__ x, a16_t* __restrict__ y, int B, int H, int W, int C) {
   const int OH = H / 2, OW = W / 2;
   const long long i = (long long)blockIdx.x * LT + threadIdx.x;
   if (i >= (long long)B * OH * OW * C) return;
   const int c = (int)(i % C), ox = (int)((i / C) % OW), oy = (int)((i / ((long long)C * OW)) % OH), b = (int)(i / ((long long)C * OW * OH));
-  const bf16_t* p = x + (((long long)b * H + 2 * oy) * W + 2 * ox) * C + c;
-  const float v = fmaxf(fmaxf(bf2f(p[0]), bf2f(p[C])), fmaxf(bf2f(p[(long long)W * C]), bf2f(p[(long long)W * C + C])));
-  y[i] = f2bf(v);
+  const a16_t* p = x + (((long long)b * H + 2 * oy) * W + 2 * ox) * C + c;
+  const float v = fmaxf(fmaxf(a2f(p[0]), a2f(p[C])), fmaxf(a2f(p[(long long)W * C]), a2f(p[(long long)W * C + C])));
+  y[i] = f2a(v);
 }
-__global__ __launch_bounds__(LT) void maxpool2_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ g,
-                                                          bf16_t* __restrict__ gx, int B, int H, int W, int C) {
+__global__ __launch_bounds__(LT) void maxpool2_bwd_kernel(const a16_t* __restrict__ x, const a16_t* __restrict__ g,
+                                                          a16_t* __restrict__ gx, int B, int H, int W, int C) {
   const int OH = H / 2, OW = W / 2;
   const long long i = (long long)blockIdx.x * LT + threadIdx.x;
   if (i >= (long long)B * H * W * C) return;
   const int c = (int)(i % C), px = (int)((i / C) % W), py = (int)((i / ((long long)C * W)) % H), b = (int)(i / ((long long)C * W * H));
   const int oy = py >> 1, ox = px >> 1;
-  bf16_t r = 0;
+  a16_t r = 0;
   if (oy < OH && ox < OW) {
-    const bf16_t* p = x + (((long long)b * H + 2 * oy) * W + 2 * ox) * C + c;
-    const float v[4] = {bf2f(p[0]), bf2f(p[C]), bf2f(p[(long long)W * C]), bf2f(p[(long long)W * C + C])};
+    const a16_t* p = x + (((long long)b * H + 2 * oy) * W + 2 * ox) * C + c;
+    const float v[4] = {a2f(p[0]), a2f(p[C]), a2f(p[(long long)W * C]), a2f(p[(long long)W * C + C])};
     int arg = 0;
     for (int k = 1; k < 4; ++k)
       if (v[k] > v[arg]) arg = k;
@@ -162,14 +162,14 @@ __global__ __launch_bounds__(LT) void maxpool2_bwd_kernel(const bf16_t* __restri
 }
 
 // F.mse_loss of two bf16 feature maps: partial sums of (a-b)^2 and, optionally, grad_a = 2 (a-b) / n
-__global__ __launch_bounds__(LT) void mse_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, long long n, float inv_n,
-                                                 bf16_t* __restrict__ ga, double* __restrict__ partial) {
+__global__ __launch_bounds__(LT) void mse_kernel(const a16_t* __restrict__ a, const a16_t* __restrict__ b, long long n, float inv_n,
+                                                 a16_t* __restrict__ ga, double* __restrict__ partial) {
   __shared__ double red[LT / 64];
   double acc = 0.0;
   for (long long i = (long long)blockIdx.x * LT + threadIdx.x; i < n; i += (long long)gridDim.x * LT) {
-    const float d = bf2f(a[i]) - bf2f(b[i]);
+    const float d = a2f(a[i]) - a2f(b[i]);
     acc += (double)(d * d);
-    if (ga) ga[i] = f2bf(2.f * d * inv_n);
+    if (ga) ga[i] = f2a(2.f * d * inv_n);
   }
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -260,16 +260,16 @@ extern "C" int glare_ssim_backward_f32(const float* x_nhwc, const float* y_nhwc,
 extern "C" int glare_maxpool2_bf16(const void* x_nhwc, void* y_nhwc, int B, int H, int W, int C, glare_stream_t stream) {
   if (!x_nhwc || !y_nhwc || B <= 0 || H < 2 || W < 2 || C <= 0) return GLARE_ERR_INVALID;
   const long long n = (long long)B * (H / 2) * (W / 2) * C;
-  hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)cdivll(n, LT)), dim3(LT), 0, ST(stream), static_cast<const bf16_t*>(x_nhwc),
-                     static_cast<bf16_t*>(y_nhwc), B, H, W, C);
+  hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)cdivll(n, LT)), dim3(LT), 0, ST(stream), static_cast<const a16_t*>(x_nhwc),
+                     static_cast<a16_t*>(y_nhwc), B, H, W, C);
   return glare_launch_status();
 }
 extern "C" int glare_maxpool2_backward_bf16(const void* x_nhwc, const void* g_nhwc, void* gx_nhwc, int B, int H, int W, int C,
                                             glare_stream_t stream) {
   if (!x_nhwc || !g_nhwc || !gx_nhwc || B <= 0 || H < 2 || W < 2 || C <= 0) return GLARE_ERR_INVALID;
   const long long n = (long long)B * H * W * C;
-  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3((unsigned)cdivll(n, LT)), dim3(LT), 0, ST(stream), static_cast<const bf16_t*>(x_nhwc),
-                     static_cast<const bf16_t*>(g_nhwc), static_cast<bf16_t*>(gx_nhwc), B, H, W, C);
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3((unsigned)cdivll(n, LT)), dim3(LT), 0, ST(stream), static_cast<const a16_t*>(x_nhwc),
+                     static_cast<const a16_t*>(g_nhwc), static_cast<a16_t*>(gx_nhwc), B, H, W, C);
   return glare_launch_status();
 }
 
@@ -278,8 +278,8 @@ extern "C" int glare_mse_loss_bf16(const void* a, const void* b, long long n, fl
   if (n <= 0 || !a || !b || !loss_out) return GLARE_ERR_INVALID;
   if (!workspace || workspace_bytes < 256 * sizeof(double)) return GLARE_ERR_WORKSPACE;
   const int blocks = lblocks(n, 256);
-  hipLaunchKernelGGL(mse_kernel, dim3(blocks), dim3(LT), 0, ST(stream), static_cast<const bf16_t*>(a), static_cast<const bf16_t*>(b), n,
-                     1.0f / (float)n, static_cast<bf16_t*>(grad_a_or_null), static_cast<double*>(workspace));
+  hipLaunchKernelGGL(mse_kernel, dim3(blocks), dim3(LT), 0, ST(stream), static_cast<const a16_t*>(a), static_cast<const a16_t*>(b), n,
+                     1.0f / (float)n, static_cast<a16_t*>(grad_a_or_null), static_cast<double*>(workspace));
   hipLaunchKernelGGL(mse_finalize_kernel, dim3(1), dim3(64), 0, ST(stream), static_cast<const double*>(workspace), blocks, (double)n,
                      loss_out);
   return glare_launch_status();

@@ -19,14 +19,14 @@ constexpr int TT = 64;  // transpose tile
 // p = (b*OH + oy)*OW + ox, columns [P, ldp) zero.  x: bf16 NHWC [B][H][W][pitch] (channels [off, off+Ci)),
 // optionally read through a nearest x2 upsample.  ones_row >= 0: that row becomes 1 for p < P (bias gradient).
 struct Im2colParams {
-  const bf16_t* x;
-  bf16_t* col;
+  const a16_t* x;
+  a16_t* col;
   long long ldp, P;
   int B, H, W, pitch, off, Ci, KS, stride, pad, ups, OH, OW, row_base, ones_row, vec_ok;
 };
 
 __global__ __launch_bounds__(256) void im2col_t_kernel(const Im2colParams p) {
-  __shared__ __attribute__((aligned(16))) bf16_t tile[TT][TT + 8];
+  __shared__ __attribute__((aligned(16))) a16_t tile[TT][TT + 8];
   const int tid = threadIdx.x;
   const long long p0 = (long long)blockIdx.x * TT;
   const int c0 = blockIdx.y * TT, tap = blockIdx.z, ty = tap / p.KS, tx = tap % p.KS, KK = p.KS * p.KS;
@@ -41,13 +41,13 @@ __global__ __launch_bounds__(256) void im2col_t_kernel(const Im2colParams p) {
       const int iy = oy * p.stride + ty - p.pad, ix = ox * p.stride + tx - p.pad;
       if (iy >= 0 && iy < IH && ix >= 0 && ix < IW) {
         const int sy = p.ups ? iy >> 1 : iy, sx = p.ups ? ix >> 1 : ix;
-        const bf16_t* src = p.x + (((long long)b * p.H + sy) * p.W + sx) * p.pitch + p.off + c0 + ch;
+        const a16_t* src = p.x + (((long long)b * p.H + sy) * p.W + sx) * p.pitch + p.off + c0 + ch;
         if (p.vec_ok && c0 + ch + 8 <= p.Ci) {
           v = *reinterpret_cast<const u32x4*>(src);
         } else {
-          bf16_t e[8];
+          a16_t e[8];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) e[i] = (c0 + ch + i < p.Ci) ? src[i] : (bf16_t)0;
+          for (int i = 0; i < 8; ++i) e[i] = (c0 + ch + i < p.Ci) ? src[i] : (a16_t)0;
 #pragma unroll
           for (int i = 0; i < 4; ++i) v[i] = (uint32_t)e[2 * i] | ((uint32_t)e[2 * i + 1] << 16);
         }
@@ -64,23 +64,23 @@ __global__ __launch_bounds__(256) void im2col_t_kernel(const Im2colParams p) {
       const uint32_t w = (uint32_t)tile[sg * 16 + 2 * i][cl] | ((uint32_t)tile[sg * 16 + 2 * i + 1][cl] << 16);
       o[i >> 2][i & 3] = w;
     }
-    bf16_t* dst = p.col + ((long long)p.row_base + (long long)c * KK + tap) * p.ldp + p0 + sg * 16;
+    a16_t* dst = p.col + ((long long)p.row_base + (long long)c * KK + tap) * p.ldp + p0 + sg * 16;
     *reinterpret_cast<u32x4*>(dst) = o[0];
     *reinterpret_cast<u32x4*>(dst + 8) = o[1];
   }
   if (p.ones_row >= 0 && blockIdx.y == 0 && tap == 0 && tid < TT)
-    p.col[(long long)p.ones_row * p.ldp + p0 + tid] = (p0 + tid < p.P) ? (bf16_t)0x3f80 : (bf16_t)0;
+    p.col[(long long)p.ones_row * p.ldp + p0 + tid] = (p0 + tid < p.P) ? (a16_t)A16_ONE : (a16_t)0;
 }
 
 // same matrix from an fp32 tensor addressed by element strides (the NCHW image of conv_in, NHWC fp32 latents)
 __global__ __launch_bounds__(256) void im2col_t_f32_kernel(const float* __restrict__ x, long long sb, long long sc, long long sy,
-                                                          long long sx, bf16_t* __restrict__ col, long long ldp, long long P,
+                                                          long long sx, a16_t* __restrict__ col, long long ldp, long long P,
                                                           int H, int W, int Ci, int KS, int pad, int row_base, int ones_row) {
   const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
   const int row = blockIdx.y, KK = KS * KS;
   if (pix >= ldp) return;
   if (row == Ci * KK) {
-    if (ones_row >= 0) col[(long long)ones_row * ldp + pix] = pix < P ? (bf16_t)0x3f80 : (bf16_t)0;
+    if (ones_row >= 0) col[(long long)ones_row * ldp + pix] = pix < P ? (a16_t)A16_ONE : (a16_t)0;
     return;
   }
   const int c = row / KK, tap = row % KK, ty = tap / KS, tx = tap % KS;
@@ -90,14 +90,14 @@ __global__ __launch_bounds__(256) void im2col_t_f32_kernel(const float* __restri
     const int iy = oy + ty - pad, ix = ox + tx - pad;
     if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[b * sb + c * sc + iy * sy + ix * sx];
   }
-  col[((long long)row_base + row) * ldp + pix] = f2bf(v);
+  col[((long long)row_base + row) * ldp + pix] = f2a(v);
 }
 
 // out[b][c][r] = in[b][r][c] (bf16), columns r in [R, ld_out) zero
-__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ in, long long ld_in, long long sb_in,
-                                                        bf16_t* __restrict__ out, long long ld_out, long long sb_out, long long R,
+__global__ __launch_bounds__(256) void transpose_kernel(const a16_t* __restrict__ in, long long ld_in, long long sb_in,
+                                                        a16_t* __restrict__ out, long long ld_out, long long sb_out, long long R,
                                                         int C, int vec_ok) {
-  __shared__ __attribute__((aligned(16))) bf16_t tile[TT][TT + 8];
+  __shared__ __attribute__((aligned(16))) a16_t tile[TT][TT + 8];
   const int tid = threadIdx.x;
   const long long r0 = (long long)blockIdx.x * TT;
   const int c0 = blockIdx.y * TT;
@@ -109,13 +109,13 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
     const long long r = r0 + rl;
     u32x4 v = {0u, 0u, 0u, 0u};
     if (r < R && c0 + ch < C) {
-      const bf16_t* src = in + r * ld_in + c0 + ch;
+      const a16_t* src = in + r * ld_in + c0 + ch;
       if (vec_ok && c0 + ch + 8 <= C) {
         v = *reinterpret_cast<const u32x4*>(src);
       } else {
-        bf16_t e[8];
+        a16_t e[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) e[i] = (c0 + ch + i < C) ? src[i] : (bf16_t)0;
+        for (int i = 0; i < 8; ++i) e[i] = (c0 + ch + i < C) ? src[i] : (a16_t)0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = (uint32_t)e[2 * i] | ((uint32_t)e[2 * i + 1] << 16);
       }
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int i = 0; i < 8; ++i)
       o[i >> 2][i & 3] = (uint32_t)tile[sg * 16 + 2 * i][cl] | ((uint32_t)tile[sg * 16 + 2 * i + 1][cl] << 16);
-    bf16_t* dst = out + (long long)c * ld_out + r0 + sg * 16;
+    a16_t* dst = out + (long long)c * ld_out + r0 + sg * 16;
     *reinterpret_cast<u32x4*>(dst) = o[0];
     *reinterpret_cast<u32x4*>(dst + 8) = o[1];
   }
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
 // ---------------------------------------------------------------------------------------------------------
 // dilate2: out[b][2oy+1][2ox+1][c] = g[b][oy][ox][c], 0 elsewhere (out: [B][2OH][2OW][C]); a pad-1 3x3 conv of it with
 // the flipped filter is the data gradient of the (0,1,0,1)-padded stride-2 conv (encoder_decoder.py:71-74)
-__global__ __launch_bounds__(256) void dilate2_kernel(const bf16_t* __restrict__ g, bf16_t* __restrict__ out, int B, int OH, int OW,
+__global__ __launch_bounds__(256) void dilate2_kernel(const a16_t* __restrict__ g, a16_t* __restrict__ out, int B, int OH, int OW,
                                                       int C8) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long n = (long long)B * 2 * OH * 2 * OW * C8;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void dilate2_kernel(const bf16_t* __restrict__
 }
 
 // pool2_sum: out[b][y][x][c] = sum of the 2x2 block of g[b][2y..][2x..][c]  (gradient of the nearest x2 upsample)
-__global__ __launch_bounds__(256) void pool2_sum_kernel(const bf16_t* __restrict__ g, bf16_t* __restrict__ out, int B, int H, int W,
+__global__ __launch_bounds__(256) void pool2_sum_kernel(const a16_t* __restrict__ g, a16_t* __restrict__ out, int B, int H, int W,
                                                         int C8) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long n = (long long)B * H * W * C8;
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void pool2_sum_kernel(const bf16_t* __restrict
   u32x4 o;
 #pragma unroll
   for (int e = 0; e < 4; ++e)
-    o[e] = pack_bf2((bflo(a0[e]) + bflo(a1[e])) + (bflo(a2[e]) + bflo(a3[e])), (bfhi(a0[e]) + bfhi(a1[e])) + (bfhi(a2[e]) + bfhi(a3[e])));
+    o[e] = pack_a2((alo(a0[e]) + alo(a1[e])) + (alo(a2[e]) + alo(a3[e])), (ahi(a0[e]) + ahi(a1[e])) + (ahi(a2[e]) + ahi(a3[e])));
   reinterpret_cast<u32x4*>(out)[i] = o;
 }
 
@@ -185,31 +185,31 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(TG* __restrict__ g, int g_
   TG* gp = g + px * g_pitch + g_off + c;
   const TY yv = y[px * y_pitch + y_off + c];
   float gv, yf;
-  if constexpr (sizeof(TG) == 2) gv = bf2f(*gp); else gv = *gp;
-  if constexpr (sizeof(TY) == 2) yf = bf2f(yv); else yf = yv;
+  if constexpr (sizeof(TG) == 2) gv = a2f(*gp); else gv = *gp;
+  if constexpr (sizeof(TY) == 2) yf = a2f(yv); else yf = yv;
   gv = act == GLARE_ACT_RELU ? (yf > 0.f ? gv : 0.f) : gv * yf * (1.f - yf);
-  if constexpr (sizeof(TG) == 2) *gp = f2bf(gv); else *gp = gv;
+  if constexpr (sizeof(TG) == 2) *gp = f2a(gv); else *gp = gv;
 }
 
 // fp32 <-> bf16 with independent channel pitches / offsets (the gradient of an fp32-output conv enters the MFMA path as bf16)
 __global__ __launch_bounds__(256) void cast_f32_to_bf16_kernel(const float* __restrict__ in, int in_pitch, int in_off,
-                                                               bf16_t* __restrict__ out, int out_pitch, int out_off, long long pixels,
+                                                               a16_t* __restrict__ out, int out_pitch, int out_off, long long pixels,
                                                                int C) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= pixels * C) return;
   const long long px = i / C;
   const int c = (int)(i % C);
-  out[px * out_pitch + out_off + c] = f2bf(in[px * in_pitch + in_off + c]);
+  out[px * out_pitch + out_off + c] = f2a(in[px * in_pitch + in_off + c]);
 }
 
-__global__ __launch_bounds__(256) void cast_bf16_to_f32_kernel(const bf16_t* __restrict__ in, int in_pitch, int in_off,
+__global__ __launch_bounds__(256) void cast_bf16_to_f32_kernel(const a16_t* __restrict__ in, int in_pitch, int in_off,
                                                                float* __restrict__ out, int out_pitch, int out_off, long long pixels,
                                                                int C) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= pixels * C) return;
   const long long px = i / C;
   const int c = (int)(i % C);
-  out[px * out_pitch + out_off + c] = bf2f(in[px * in_pitch + in_off + c]);
+  out[px * out_pitch + out_off + c] = a2f(in[px * in_pitch + in_off + c]);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -238,8 +238,8 @@ __device__ __forceinline__ float swish_grad(float u) {
 }
 
 // partial[b][split][c][2]
-__global__ __launch_bounds__(GNT) void gn_bwd_reduce_kernel(const bf16_t* __restrict__ x, int pitch, int off,
-                                                            const bf16_t* __restrict__ dy, const float* __restrict__ stats,
+__global__ __launch_bounds__(GNT) void gn_bwd_reduce_kernel(const a16_t* __restrict__ x, int pitch, int off,
+                                                            const a16_t* __restrict__ dy, const float* __restrict__ stats,
                                                             int fsplits, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ partial,
                                                             long long HW, int C, float eps, int swish, int splits) {
@@ -258,13 +258,13 @@ __global__ __launch_bounds__(GNT) void gn_bwd_reduce_kernel(const bf16_t* __rest
     s1[e] = s2[e] = 0.f;
   }
   const long long per = (HW + splits - 1) / splits, q0 = sp * per, q1 = min(HW, q0 + per);
-  const bf16_t* xb = x + (size_t)b * HW * pitch + off + chunk * 8;
-  const bf16_t* gb = dy + (size_t)b * HW * C + chunk * 8;
+  const a16_t* xb = x + (size_t)b * HW * pitch + off + chunk * 8;
+  const a16_t* gb = dy + (size_t)b * HW * C + chunk * 8;
   auto accum = [&](const u32x4& xv, const u32x4& gv) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float xe = (e & 1) ? bfhi(xv[e >> 1]) : bflo(xv[e >> 1]);
-      float ge = (e & 1) ? bfhi(gv[e >> 1]) : bflo(gv[e >> 1]);
+      const float xe = (e & 1) ? ahi(xv[e >> 1]) : alo(xv[e >> 1]);
+      float ge = (e & 1) ? ahi(gv[e >> 1]) : alo(gv[e >> 1]);
       const float xh = (xe - mu[e]) * rs[e];
       if (swish) ge *= swish_grad(xh * sc[e] + sh[e]);
       s1[e] += ge;
@@ -342,11 +342,11 @@ __global__ __launch_bounds__(GNT) void gn_bwd_finalize_kernel(const float* __res
   }
 }
 
-__global__ __launch_bounds__(GNT) void gn_bwd_apply_kernel(const bf16_t* __restrict__ x, int pitch, int off,
-                                                           const bf16_t* __restrict__ dy, const float* __restrict__ stats,
+__global__ __launch_bounds__(GNT) void gn_bwd_apply_kernel(const a16_t* __restrict__ x, int pitch, int off,
+                                                           const a16_t* __restrict__ dy, const float* __restrict__ stats,
                                                            int fsplits, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ coef,
-                                                           bf16_t* __restrict__ dx, long long HW, int C, float eps, int swish,
+                                                           a16_t* __restrict__ dx, long long HW, int C, float eps, int swish,
                                                            int blocks_per_image) {
   __shared__ float mean_s[GNG], rstd_s[GNG];
   const int b = blockIdx.x / blocks_per_image, blk = blockIdx.x % blocks_per_image, cpg = C / GNG;
@@ -361,24 +361,24 @@ __global__ __launch_bounds__(GNT) void gn_bwd_apply_kernel(const bf16_t* __restr
     ca[e] = coef[((size_t)b * GNG + g) * 2]; cq[e] = coef[((size_t)b * GNG + g) * 2 + 1];
   }
   const long long per = (HW + blocks_per_image - 1) / blocks_per_image, q0 = blk * per, q1 = min(HW, q0 + per);
-  const bf16_t* xb = x + (size_t)b * HW * pitch + off + chunk * 8;
-  const bf16_t* gb = dy + (size_t)b * HW * C + chunk * 8;
-  bf16_t* ob = dx + (size_t)b * HW * C + chunk * 8;
+  const a16_t* xb = x + (size_t)b * HW * pitch + off + chunk * 8;
+  const a16_t* gb = dy + (size_t)b * HW * C + chunk * 8;
+  a16_t* ob = dx + (size_t)b * HW * C + chunk * 8;
   for (long long p = q0 + pl; p < q1; p += ppi) {
     const u32x4 xv = *reinterpret_cast<const u32x4*>(xb + (size_t)p * pitch);
     const u32x4 gv = *reinterpret_cast<const u32x4*>(gb + (size_t)p * C);
     float r[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float xe = (e & 1) ? bfhi(xv[e >> 1]) : bflo(xv[e >> 1]);
-      float ge = (e & 1) ? bfhi(gv[e >> 1]) : bflo(gv[e >> 1]);
+      const float xe = (e & 1) ? ahi(xv[e >> 1]) : alo(xv[e >> 1]);
+      float ge = (e & 1) ? ahi(gv[e >> 1]) : alo(gv[e >> 1]);
       const float xh = (xe - mu[e]) * rs[e];
       if (swish) ge *= swish_grad(xh * sc[e] + sh[e]);
       r[e] = rs[e] * (ge * sc[e] - ca[e] - xh * cq[e]);
     }
     u32x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = pack_bf2(r[2 * e], r[2 * e + 1]);
+    for (int e = 0; e < 4; ++e) o[e] = pack_a2(r[2 * e], r[2 * e + 1]);
     *reinterpret_cast<u32x4*>(ob + (size_t)p * C) = o;
   }
 }
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(GNT) void gn_bwd_apply_kernel(const bf16_t* __restr
 // ---------------------------------------------------------------------------------------------------------
 // P[i][j] = 2^(S[i][j] - max_j) / sum_j  (S = base-2 logits, fp32 [rows][lds]); bf16 out, columns [n, ldp) zero.
 // One workgroup per row.
-__global__ __launch_bounds__(256) void softmax2_rows_kernel(const float* __restrict__ S, long long lds, bf16_t* __restrict__ P,
+__global__ __launch_bounds__(256) void softmax2_rows_kernel(const float* __restrict__ S, long long lds, a16_t* __restrict__ P,
                                                             long long ldp, int n) {
   __shared__ float red[4];
   const long long row = blockIdx.x;
@@ -404,32 +404,32 @@ __global__ __launch_bounds__(256) void softmax2_rows_kernel(const float* __restr
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
   __syncthreads();
   const float inv = 1.f / ((red[0] + red[1]) + (red[2] + red[3]));
-  bf16_t* p = P + row * ldp;
-  for (int j = threadIdx.x; j < ldp; j += 256) p[j] = j < n ? f2bf(exp2f(s[j] - m) * inv) : (bf16_t)0;
+  a16_t* p = P + row * ldp;
+  for (int j = threadIdx.x; j < ldp; j += 256) p[j] = j < n ? f2a(exp2f(s[j] - m) * inv) : (a16_t)0;
 }
 
 // dS[i][j] = scale * P[i][j] * (dP[i][j] - delta_i),  delta_i = sum_c dO[i][c] O[i][c];  bf16 out, pad columns zero
-__global__ __launch_bounds__(256) void attn_ds_kernel(const bf16_t* __restrict__ P, long long ldp, const float* __restrict__ dP,
-                                                      long long lddp, const bf16_t* __restrict__ dO, int ld_do,
-                                                      const bf16_t* __restrict__ O, int ld_o, int d, bf16_t* __restrict__ dS,
+__global__ __launch_bounds__(256) void attn_ds_kernel(const a16_t* __restrict__ P, long long ldp, const float* __restrict__ dP,
+                                                      long long lddp, const a16_t* __restrict__ dO, int ld_do,
+                                                      const a16_t* __restrict__ O, int ld_o, int d, a16_t* __restrict__ dS,
                                                       long long ldds, int n, float scale) {
   __shared__ float red[4];
   const long long row = blockIdx.x;
   float acc = 0.f;
-  for (int c = threadIdx.x; c < d; c += 256) acc += bf2f(dO[row * ld_do + c]) * bf2f(O[row * ld_o + c]);
+  for (int c = threadIdx.x; c < d; c += 256) acc += a2f(dO[row * ld_do + c]) * a2f(O[row * ld_o + c]);
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
   const float delta = (red[0] + red[1]) + (red[2] + red[3]);
   for (int j = threadIdx.x; j < ldds; j += 256)
-    dS[row * ldds + j] = j < n ? f2bf(scale * bf2f(P[row * ldp + j]) * (dP[row * lddp + j] - delta)) : (bf16_t)0;
+    dS[row * ldds + j] = j < n ? f2a(scale * a2f(P[row * ldp + j]) * (dP[row * lddp + j] - delta)) : (a16_t)0;
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // Mix backward (deformableDecoder_arch.py:587-590): out = s a + (1-s) b, s = sigmoid(w)
 //   gb = (1-s) g, ga = s g (optional), partial[blk] = sum g (a - b)   (dw = s (1-s) * sum)
-__global__ __launch_bounds__(256) void mix_bwd_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ a,
-                                                      const bf16_t* __restrict__ b, bf16_t* __restrict__ ga, bf16_t* __restrict__ gb,
+__global__ __launch_bounds__(256) void mix_bwd_kernel(const a16_t* __restrict__ g, const a16_t* __restrict__ a,
+                                                      const a16_t* __restrict__ b, a16_t* __restrict__ ga, a16_t* __restrict__ gb,
                                                       long long n8, float s, const float* __restrict__ w_dev,
                                                       float* __restrict__ partial) {
   __shared__ float red[4];
@@ -444,10 +444,10 @@ __global__ __launch_bounds__(256) void mix_bwd_kernel(const bf16_t* __restrict__
     u32x4 oa, ob;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float g0 = bflo(gv[e]), g1 = bfhi(gv[e]);
-      acc += g0 * (bflo(av[e]) - bflo(bv[e])) + g1 * (bfhi(av[e]) - bfhi(bv[e]));
-      oa[e] = pack_bf2(s * g0, s * g1);
-      ob[e] = pack_bf2((1.f - s) * g0, (1.f - s) * g1);
+      const float g0 = alo(gv[e]), g1 = ahi(gv[e]);
+      acc += g0 * (alo(av[e]) - alo(bv[e])) + g1 * (ahi(av[e]) - ahi(bv[e]));
+      oa[e] = pack_a2(s * g0, s * g1);
+      ob[e] = pack_a2((1.f - s) * g0, (1.f - s) * g1);
     }
     if (ga) reinterpret_cast<u32x4*>(ga)[i] = oa;
     reinterpret_cast<u32x4*>(gb)[i] = ob;
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256) void mix_bwd_kernel(const bf16_t* __restrict__
 // Mean-rescale backward (deformableDecoder_arch.py:567): out = h + xw r, r = sum(h)/sum(xw) over the sample (or batch)
 //   D = sum g xw;  gh = g + D/Sx;  gxw = g r - D Sh/Sx^2
 // partial[b][blk][3] = (D, Sh, Sx) of a slice; coef[b][3] = (D/Sx, r, D Sh/Sx^2)
-__global__ __launch_bounds__(256) void rescale_bwd_reduce_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ h,
+__global__ __launch_bounds__(256) void rescale_bwd_reduce_kernel(const a16_t* __restrict__ g, const a16_t* __restrict__ h,
                                                                  const float* __restrict__ xw, long long n_per_sample, int blocks,
                                                                  float* __restrict__ partial) {
   __shared__ float red[3][4];
@@ -476,16 +476,16 @@ __global__ __launch_bounds__(256) void rescale_bwd_reduce_kernel(const bf16_t* _
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float xa = e < 2 ? x0[2 * e] : x1[2 * e - 4], xb = e < 2 ? x0[2 * e + 1] : x1[2 * e - 3];
-        d += bflo(gv[e]) * xa + bfhi(gv[e]) * xb;
-        sh += bflo(hv[e]) + bfhi(hv[e]);
+        d += alo(gv[e]) * xa + ahi(gv[e]) * xb;
+        sh += alo(hv[e]) + ahi(hv[e]);
         sx += xa + xb;
       }
     }
   } else {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_per_sample; i += (long long)blocks * 256) {
       const float x = xw[base + i];
-      d += bf2f(g[base + i]) * x;
-      sh += bf2f(h[base + i]);
+      d += a2f(g[base + i]) * x;
+      sh += a2f(h[base + i]);
       sx += x;
     }
   }
@@ -526,14 +526,14 @@ __global__ void rescale_bwd_finalize_kernel(const float* __restrict__ partial, i
     }
 }
 
-__global__ __launch_bounds__(256) void rescale_bwd_apply_kernel(const bf16_t* __restrict__ g, const float* __restrict__ coef,
-                                                                long long n_per_sample, long long total, bf16_t* __restrict__ gh,
+__global__ __launch_bounds__(256) void rescale_bwd_apply_kernel(const a16_t* __restrict__ g, const float* __restrict__ coef,
+                                                                long long n_per_sample, long long total, a16_t* __restrict__ gh,
                                                                 float* __restrict__ gxw) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const float* c = coef + (i / n_per_sample) * 3;
-  const float gv = bf2f(g[i]);
-  gh[i] = f2bf(gv + c[0]);
+  const float gv = a2f(g[i]);
+  gh[i] = f2a(gv + c[0]);
   gxw[i] = gv * c[1] - c[2];
 }
 
@@ -570,8 +570,8 @@ __global__ __launch_bounds__(256) void l1_loss_kernel(const float* __restrict__ 
 
 // out = a + b (+ c): the gradient accumulation at a fan-out point of the tape (an activation read by several consumers);
 // bf16 in / out, fp32 add.  Keeps the accumulation on this library instead of the autograd engine's own add.
-__global__ __launch_bounds__(256) void add_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
-                                                       const bf16_t* __restrict__ c, bf16_t* __restrict__ out, long long n8) {
+__global__ __launch_bounds__(256) void add_bf16_kernel(const a16_t* __restrict__ a, const a16_t* __restrict__ b,
+                                                       const a16_t* __restrict__ c, a16_t* __restrict__ out, long long n8) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n8) return;
   const u32x4 va = reinterpret_cast<const u32x4*>(a)[i], vb = reinterpret_cast<const u32x4*>(b)[i];
@@ -580,18 +580,18 @@ __global__ __launch_bounds__(256) void add_bf16_kernel(const bf16_t* __restrict_
   u32x4 o;
 #pragma unroll
   for (int e = 0; e < 4; ++e)
-    o[e] = pack_bf2(bflo(va[e]) + bflo(vb[e]) + bflo(vc[e]), bfhi(va[e]) + bfhi(vb[e]) + bfhi(vc[e]));
+    o[e] = pack_a2(alo(va[e]) + alo(vb[e]) + alo(vc[e]), ahi(va[e]) + ahi(vb[e]) + ahi(vc[e]));
   reinterpret_cast<u32x4*>(out)[i] = o;
 }
 
 // partial[blk][c] = sum over this block's pixel slice of g[p][c]  (bias gradient = column sums of the output gradient)
-__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ g, int pitch, long long P, int C, int blocks,
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const a16_t* __restrict__ g, int pitch, long long P, int C, int blocks,
                                                           float* __restrict__ partial) {
   const int c = blockIdx.y * 256 + threadIdx.x;
   if (c >= C) return;
   const long long per = (P + blocks - 1) / blocks, p0 = blockIdx.x * per, p1 = min(P, p0 + per);
   float acc = 0.f;
-  for (long long q = p0; q < p1; ++q) acc += bf2f(g[q * pitch + c]);
+  for (long long q = p0; q < p1; ++q) acc += a2f(g[q * pitch + c]);
   partial[(size_t)blockIdx.x * C + c] = acc;
 }
 
@@ -611,11 +611,13 @@ __global__ void adam_prepare_kernel(int* __restrict__ step_dev, float* __restric
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
                                                    float wd, float bc1, float bc2_sqrt, float grad_scale,
-                                                   const float* __restrict__ state_dev, const int* __restrict__ skip) {
+                                                   const float* __restrict__ state_dev, const int* __restrict__ skip,
+                                                   const float* __restrict__ loss_scale = nullptr) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   if (skip && *skip) return;   // GradScaler.step: inf / NaN somewhere in this step's gradients (wave-uniform scalar load)
   if (state_dev) { bc1 = state_dev[0]; bc2_sqrt = state_dev[1]; lr *= state_dev[2]; }
+  if (loss_scale) grad_scale /= loss_scale[0];   // scaler.unscale_(): the loss was multiplied by the (device-resident) scale
   float gi = g[i] * grad_scale;
   if (wd != 0.f) gi += wd * w[i];
   const float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -661,7 +663,7 @@ extern "C" int glare_im2col_t_bf16(const void* x_nhwc, int B, int H, int W, int 
   p.OW = stride == 1 ? IW + 2 * pad - ksize + 1 : (IW + 1 - ksize) / 2 + 1;
   p.P = (long long)B * p.OH * p.OW;
   if (ldp < p.P) return GLARE_ERR_INVALID;
-  p.x = static_cast<const bf16_t*>(x_nhwc); p.col = static_cast<bf16_t*>(colT); p.ldp = ldp;
+  p.x = static_cast<const a16_t*>(x_nhwc); p.col = static_cast<a16_t*>(colT); p.ldp = ldp;
   p.B = B; p.H = H; p.W = W; p.pitch = pitch; p.off = off; p.Ci = Ci; p.KS = ksize; p.stride = stride; p.pad = pad; p.ups = upsample;
   p.row_base = row_base; p.ones_row = ones_row;
   p.vec_ok = (pitch % 8 == 0 && off % 8 == 0 && (reinterpret_cast<uintptr_t>(x_nhwc) & 15) == 0) ? 1 : 0;
@@ -676,7 +678,7 @@ extern "C" int glare_im2col_t_f32(const float* x, long long stride_b, long long 
   const long long P = (long long)B * H * W;
   if (ldp < P) return GLARE_ERR_INVALID;
   hipLaunchKernelGGL(im2col_t_f32_kernel, dim3((unsigned)cdivll(ldp, 256), Ci * ksize * ksize + (ones_row >= 0 ? 1 : 0)), dim3(256), 0,
-                     ST(stream), x, stride_b, stride_c, stride_y, stride_x, static_cast<bf16_t*>(colT), ldp, P, H, W, Ci, ksize, pad,
+                     ST(stream), x, stride_b, stride_c, stride_y, stride_x, static_cast<a16_t*>(colT), ldp, P, H, W, Ci, ksize, pad,
                      row_base, ones_row);
   return glare_launch_status();
 }
@@ -689,7 +691,7 @@ extern "C" int glare_transpose_bf16(const void* in, long long ld_in, long long b
   const int vec_ok = (ld_in % 8 == 0 && batch_stride_in % 8 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0) ? 1 : 0;
   if ((reinterpret_cast<uintptr_t>(out) & 15) != 0 || batch_stride_out % 8 != 0) return GLARE_ERR_INVALID;
   hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)(ld_out / TT), cdiv(cols, TT), batch), dim3(256), 0, ST(stream),
-                     static_cast<const bf16_t*>(in), ld_in, batch_stride_in, static_cast<bf16_t*>(out), ld_out, batch_stride_out, rows,
+                     static_cast<const a16_t*>(in), ld_in, batch_stride_in, static_cast<a16_t*>(out), ld_out, batch_stride_out, rows,
                      cols, vec_ok);
   return glare_launch_status();
 }
@@ -697,16 +699,16 @@ extern "C" int glare_transpose_bf16(const void* in, long long ld_in, long long b
 extern "C" int glare_dilate2_bf16(const void* g, void* out, int B, int OH, int OW, int C, glare_stream_t stream) {
   if (!g || !out || B <= 0 || OH <= 0 || OW <= 0 || C <= 0 || C % 8) return GLARE_ERR_INVALID;
   const long long n = (long long)B * 4 * OH * OW * (C / 8);
-  hipLaunchKernelGGL(dilate2_kernel, dim3((unsigned)cdivll(n, 256)), dim3(256), 0, ST(stream), static_cast<const bf16_t*>(g),
-                     static_cast<bf16_t*>(out), B, OH, OW, C / 8);
+  hipLaunchKernelGGL(dilate2_kernel, dim3((unsigned)cdivll(n, 256)), dim3(256), 0, ST(stream), static_cast<const a16_t*>(g),
+                     static_cast<a16_t*>(out), B, OH, OW, C / 8);
   return glare_launch_status();
 }
 
 extern "C" int glare_pool2_sum_bf16(const void* g, void* out, int B, int H, int W, int C, glare_stream_t stream) {
   if (!g || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8) return GLARE_ERR_INVALID;
   const long long n = (long long)B * H * W * (C / 8);
-  hipLaunchKernelGGL(pool2_sum_kernel, dim3((unsigned)cdivll(n, 256)), dim3(256), 0, ST(stream), static_cast<const bf16_t*>(g),
-                     static_cast<bf16_t*>(out), B, H, W, C / 8);
+  hipLaunchKernelGGL(pool2_sum_kernel, dim3((unsigned)cdivll(n, 256)), dim3(256), 0, ST(stream), static_cast<const a16_t*>(g),
+                     static_cast<a16_t*>(out), B, H, W, C / 8);
   return glare_launch_status();
 }
 
@@ -719,11 +721,11 @@ extern "C" int glare_act_backward(void* g, int g_is_f32, int g_pitch, int g_off,
   if (g_is_f32 && y_is_f32)
     hipLaunchKernelGGL((act_bwd_kernel<float, float>), grid, dim3(256), 0, ST(stream), (float*)g, g_pitch, g_off, (const float*)y, y_pitch, y_off, pixels, C, act);
   else if (g_is_f32)
-    hipLaunchKernelGGL((act_bwd_kernel<float, bf16_t>), grid, dim3(256), 0, ST(stream), (float*)g, g_pitch, g_off, (const bf16_t*)y, y_pitch, y_off, pixels, C, act);
+    hipLaunchKernelGGL((act_bwd_kernel<float, a16_t>), grid, dim3(256), 0, ST(stream), (float*)g, g_pitch, g_off, (const a16_t*)y, y_pitch, y_off, pixels, C, act);
   else if (y_is_f32)
-    hipLaunchKernelGGL((act_bwd_kernel<bf16_t, float>), grid, dim3(256), 0, ST(stream), (bf16_t*)g, g_pitch, g_off, (const float*)y, y_pitch, y_off, pixels, C, act);
+    hipLaunchKernelGGL((act_bwd_kernel<a16_t, float>), grid, dim3(256), 0, ST(stream), (a16_t*)g, g_pitch, g_off, (const float*)y, y_pitch, y_off, pixels, C, act);
   else
-    hipLaunchKernelGGL((act_bwd_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, ST(stream), (bf16_t*)g, g_pitch, g_off, (const bf16_t*)y, y_pitch, y_off, pixels, C, act);
+    hipLaunchKernelGGL((act_bwd_kernel<a16_t, a16_t>), grid, dim3(256), 0, ST(stream), (a16_t*)g, g_pitch, g_off, (const a16_t*)y, y_pitch, y_off, pixels, C, act);
   return glare_launch_status();
 }
 
@@ -733,7 +735,7 @@ extern "C" int glare_cast_f32_bf16(const float* in, int in_pitch, int in_off, vo
   if (pixels == 0 || C == 0) return GLARE_OK;
   if (!in || !out) return GLARE_ERR_INVALID;
   hipLaunchKernelGGL(cast_f32_to_bf16_kernel, dim3((unsigned)cdivll(pixels * C, 256)), dim3(256), 0, ST(stream), in, in_pitch, in_off,
-                     static_cast<bf16_t*>(out), out_pitch, out_off, pixels, C);
+                     static_cast<a16_t*>(out), out_pitch, out_off, pixels, C);
   return glare_launch_status();
 }
 
@@ -743,7 +745,7 @@ extern "C" int glare_cast_bf16_f32(const void* in, int in_pitch, int in_off, flo
   if (pixels == 0 || C == 0) return GLARE_OK;
   if (!in || !out) return GLARE_ERR_INVALID;
   hipLaunchKernelGGL(cast_bf16_to_f32_kernel, dim3((unsigned)cdivll(pixels * C, 256)), dim3(256), 0, ST(stream),
-                     static_cast<const bf16_t*>(in), in_pitch, in_off, out, out_pitch, out_off, pixels, C);
+                     static_cast<const a16_t*>(in), in_pitch, in_off, out, out_pitch, out_off, pixels, C);
   return glare_launch_status();
 }
 
@@ -768,15 +770,15 @@ extern "C" int glare_groupnorm_swish_backward_bf16(const void* x, int in_pitch, 
   const int splits = gn_bwd_splits(HW);
   float* partial = static_cast<float*>(workspace);
   float* coef = partial + (size_t)B * splits * C * 2;
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(splits, B), dim3(GNT), 0, ST(stream), static_cast<const bf16_t*>(x), in_pitch, in_off,
-                     static_cast<const bf16_t*>(dy), stats, stat_splits, gamma, beta, partial, HW, C, eps, swish, splits);
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(splits, B), dim3(GNT), 0, ST(stream), static_cast<const a16_t*>(x), in_pitch, in_off,
+                     static_cast<const a16_t*>(dy), stats, stat_splits, gamma, beta, partial, HW, C, eps, swish, splits);
   const int CB = (C % 64 == 0 && 64 % (C / GNG) == 0) ? 64 : C;   // channel block of the finalize: whole groups
   hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(C / CB, B), dim3(GNT), 0, ST(stream), partial, gamma, dgamma_dbeta_per_image, coef, HW,
                      C, splits, CB);
   int bpi = (int)((HW * (C / 8) + 16 * GNT - 1) / (16 * GNT));
   if (bpi < 1) bpi = 1;
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)(bpi * B)), dim3(GNT), 0, ST(stream), static_cast<const bf16_t*>(x), in_pitch,
-                     in_off, static_cast<const bf16_t*>(dy), stats, stat_splits, gamma, beta, coef, static_cast<bf16_t*>(dx), HW, C, eps,
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)(bpi * B)), dim3(GNT), 0, ST(stream), static_cast<const a16_t*>(x), in_pitch,
+                     in_off, static_cast<const a16_t*>(dy), stats, stat_splits, gamma, beta, coef, static_cast<a16_t*>(dx), HW, C, eps,
                      swish, bpi);
   return glare_launch_status();
 }
@@ -786,7 +788,7 @@ extern "C" int glare_softmax2_rows_f32(const float* S, long long lds, void* P, l
   if (rows < 0 || n < 0) return GLARE_ERR_INVALID;
   if (rows == 0 || n == 0) return GLARE_OK;
   if (!S || !P || lds < n || ldp < n || rows > 0x7fffffffLL) return GLARE_ERR_INVALID;
-  hipLaunchKernelGGL(softmax2_rows_kernel, dim3((unsigned)rows), dim3(256), 0, ST(stream), S, lds, static_cast<bf16_t*>(P), ldp, n);
+  hipLaunchKernelGGL(softmax2_rows_kernel, dim3((unsigned)rows), dim3(256), 0, ST(stream), S, lds, static_cast<a16_t*>(P), ldp, n);
   return glare_launch_status();
 }
 
@@ -796,8 +798,8 @@ extern "C" int glare_attention_ds_bf16(const void* P, long long ldp, const float
   if (rows < 0 || n < 0) return GLARE_ERR_INVALID;
   if (rows == 0 || n == 0) return GLARE_OK;
   if (!P || !dP || !dO || !O || !dS || ldp < n || lddp < n || ldds < n || rows > 0x7fffffffLL) return GLARE_ERR_INVALID;
-  hipLaunchKernelGGL(attn_ds_kernel, dim3((unsigned)rows), dim3(256), 0, ST(stream), static_cast<const bf16_t*>(P), ldp, dP, lddp,
-                     static_cast<const bf16_t*>(dO), ld_do, static_cast<const bf16_t*>(O), ld_o, d, static_cast<bf16_t*>(dS), ldds, n,
+  hipLaunchKernelGGL(attn_ds_kernel, dim3((unsigned)rows), dim3(256), 0, ST(stream), static_cast<const a16_t*>(P), ldp, dP, lddp,
+                     static_cast<const a16_t*>(dO), ld_do, static_cast<const a16_t*>(O), ld_o, d, static_cast<a16_t*>(dS), ldds, n,
                      scale);
   return glare_launch_status();
 }
@@ -809,8 +811,8 @@ extern "C" int glare_mix_backward_bf16(const void* g, const void* a, const void*
   const int blocks = (int)(cdivll(n / 8, 256) < 1 ? 1 : (cdivll(n / 8, 256) > 512 ? 512 : cdivll(n / 8, 256)));
   if (!workspace || workspace_bytes < (size_t)blocks * sizeof(float)) return GLARE_ERR_WORKSPACE;
   const float s = 1.0f / (1.0f + expf(-w));
-  hipLaunchKernelGGL(mix_bwd_kernel, dim3(blocks), dim3(256), 0, ST(stream), static_cast<const bf16_t*>(g), static_cast<const bf16_t*>(a),
-                     static_cast<const bf16_t*>(b), static_cast<bf16_t*>(ga_or_null), static_cast<bf16_t*>(gb), n / 8, s,
+  hipLaunchKernelGGL(mix_bwd_kernel, dim3(blocks), dim3(256), 0, ST(stream), static_cast<const a16_t*>(g), static_cast<const a16_t*>(a),
+                     static_cast<const a16_t*>(b), static_cast<a16_t*>(ga_or_null), static_cast<a16_t*>(gb), n / 8, s,
                      (const float*)nullptr, static_cast<float*>(workspace));
   return glare_reduce_parts_f32(static_cast<const float*>(workspace), blocks, 1, s * (1.f - s), dw_out, 0, stream);
 }
@@ -822,8 +824,8 @@ extern "C" int glare_mix_backward_dev_bf16(const void* g, const void* a, const v
   if (!g || !a || !b || !gb || !dw_out || !w_device) return GLARE_ERR_INVALID;
   const int blocks = (int)(cdivll(n / 8, 256) < 1 ? 1 : (cdivll(n / 8, 256) > 512 ? 512 : cdivll(n / 8, 256)));
   if (!workspace || workspace_bytes < (size_t)blocks * sizeof(float)) return GLARE_ERR_WORKSPACE;
-  hipLaunchKernelGGL(mix_bwd_kernel, dim3(blocks), dim3(256), 0, ST(stream), static_cast<const bf16_t*>(g), static_cast<const bf16_t*>(a),
-                     static_cast<const bf16_t*>(b), static_cast<bf16_t*>(ga_or_null), static_cast<bf16_t*>(gb), n / 8, 0.f, w_device,
+  hipLaunchKernelGGL(mix_bwd_kernel, dim3(blocks), dim3(256), 0, ST(stream), static_cast<const a16_t*>(g), static_cast<const a16_t*>(a),
+                     static_cast<const a16_t*>(b), static_cast<a16_t*>(ga_or_null), static_cast<a16_t*>(gb), n / 8, 0.f, w_device,
                      static_cast<float*>(workspace));
   return glare_reduce_parts_f32(static_cast<const float*>(workspace), blocks, 1, 1.f, dw_out, 0, stream);
 }
@@ -842,12 +844,12 @@ extern "C" int glare_mean_rescale_backward_bf16(const void* g, const void* h, co
   if (!workspace || workspace_bytes < glare_mean_rescale_backward_workspace_bytes(B, n_per_sample)) return GLARE_ERR_WORKSPACE;
   float* partial = static_cast<float*>(workspace);
   float* coef = partial + (size_t)B * RESCALE_BWD_BLOCKS * 3;
-  hipLaunchKernelGGL(rescale_bwd_reduce_kernel, dim3(RESCALE_BWD_BLOCKS, B), dim3(256), 0, ST(stream), static_cast<const bf16_t*>(g),
-                     static_cast<const bf16_t*>(h), xw, n_per_sample, RESCALE_BWD_BLOCKS, partial);
+  hipLaunchKernelGGL(rescale_bwd_reduce_kernel, dim3(RESCALE_BWD_BLOCKS, B), dim3(256), 0, ST(stream), static_cast<const a16_t*>(g),
+                     static_cast<const a16_t*>(h), xw, n_per_sample, RESCALE_BWD_BLOCKS, partial);
   hipLaunchKernelGGL(rescale_bwd_finalize_kernel, dim3(1), dim3(64), 0, ST(stream), partial, B, RESCALE_BWD_BLOCKS, whole_batch_mean, coef);
   const long long total = (long long)B * n_per_sample;
-  hipLaunchKernelGGL(rescale_bwd_apply_kernel, dim3((unsigned)cdivll(total, 256)), dim3(256), 0, ST(stream), static_cast<const bf16_t*>(g),
-                     coef, n_per_sample, total, static_cast<bf16_t*>(gh), gxw);
+  hipLaunchKernelGGL(rescale_bwd_apply_kernel, dim3((unsigned)cdivll(total, 256)), dim3(256), 0, ST(stream), static_cast<const a16_t*>(g),
+                     coef, n_per_sample, total, static_cast<a16_t*>(gh), gxw);
   return glare_launch_status();
 }
 
@@ -875,8 +877,8 @@ extern "C" int glare_add_bf16(const void* a, const void* b, const void* c_or_nul
   if (n < 0 || n % 8) return GLARE_ERR_INVALID;
   if (n == 0) return GLARE_OK;
   if (!a || !b || !out) return GLARE_ERR_INVALID;
-  hipLaunchKernelGGL(add_bf16_kernel, dim3((unsigned)cdivll(n / 8, 256)), dim3(256), 0, ST(stream), static_cast<const bf16_t*>(a),
-                     static_cast<const bf16_t*>(b), static_cast<const bf16_t*>(c_or_null), static_cast<bf16_t*>(out), n / 8);
+  hipLaunchKernelGGL(add_bf16_kernel, dim3((unsigned)cdivll(n / 8, 256)), dim3(256), 0, ST(stream), static_cast<const a16_t*>(a),
+                     static_cast<const a16_t*>(b), static_cast<const a16_t*>(c_or_null), static_cast<a16_t*>(out), n / 8);
   return glare_launch_status();
 }
 
@@ -885,7 +887,7 @@ extern "C" int glare_colsum_bf16(const void* g, int pitch, long long P, int C, f
   if (!g || !out || P <= 0 || C <= 0 || pitch < C) return GLARE_ERR_INVALID;
   const int blocks = (int)(cdivll(P, 512) < 1 ? 1 : (cdivll(P, 512) > 256 ? 256 : cdivll(P, 512)));
   if (!workspace || workspace_bytes < (size_t)blocks * C * sizeof(float)) return GLARE_ERR_WORKSPACE;
-  hipLaunchKernelGGL(colsum_bf16_kernel, dim3(blocks, cdiv(C, 256)), dim3(256), 0, ST(stream), static_cast<const bf16_t*>(g), pitch, P, C,
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3(blocks, cdiv(C, 256)), dim3(256), 0, ST(stream), static_cast<const a16_t*>(g), pitch, P, C,
                      blocks, static_cast<float*>(workspace));
   return glare_reduce_parts_f32(static_cast<const float*>(workspace), blocks, C, 1.f, out, 0, stream);
 }
@@ -938,6 +940,18 @@ extern "C" int glare_adam_step_dev_guarded_f32(float* w, const float* grad, floa
   if (!w || !grad || !exp_avg || !exp_avg_sq || !state3_device) return GLARE_ERR_INVALID;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)cdivll(n, 256)), dim3(256), 0, ST(stream), w, grad, exp_avg, exp_avg_sq, n, lr, beta1,
                      beta2, eps, weight_decay, 1.f, 1.f, grad_scale, state3_device, skip_if_nonzero_device);
+  return glare_launch_status();
+}
+
+extern "C" int glare_adam_step_dev_scaled_f32(float* w, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
+                                              float beta1, float beta2, float eps, float weight_decay, const float* state3_device,
+                                              float grad_scale, const float* loss_scale_device, const int* skip_if_nonzero_device,
+                                              glare_stream_t stream) {
+  if (n < 0) return GLARE_ERR_INVALID;
+  if (n == 0) return GLARE_OK;
+  if (!w || !grad || !exp_avg || !exp_avg_sq || !state3_device || !loss_scale_device) return GLARE_ERR_INVALID;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)cdivll(n, 256)), dim3(256), 0, ST(stream), w, grad, exp_avg, exp_avg_sq, n, lr, beta1,
+                     beta2, eps, weight_decay, 1.f, 1.f, grad_scale, state3_device, skip_if_nonzero_device, loss_scale_device);
   return glare_launch_status();
 }
 

@@ -32,8 +32,8 @@ constexpr int MAX_NKS = 6;
 constexpr unsigned OOB = 0x80000000u;
 
 struct WgradParams {
-  const bf16_t* x;
-  const bf16_t* g;
+  const a16_t* x;
+  const a16_t* g;
   float* parts;
   int B, H, W, xpitch, xoff, Ci, gpitch, Co;
   long long x_gstride, g_gstride;      // elements between the operands of consecutive groups (independent filters, see the entry point)
@@ -48,8 +48,8 @@ __device__ __forceinline__ void lgkm_wait() { asm volatile("s_waitcnt lgkmcnt(%0
 __device__ __forceinline__ void tr_read(u32x2& dst, int addr) { asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst) : "v"(addr)); }
 __device__ __forceinline__ void pin(u32x2& a) { asm volatile("" : "+v"(a)); }   // nothing that reads `a` moves above this point
 
-__device__ __forceinline__ bf16x8 frag(const u32x2& lo, const u32x2& hi) {
-  return __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
+__device__ __forceinline__ a16x8 frag(const u32x2& lo, const u32x2& hi) {
+  return __builtin_bit_cast(a16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
 }
 
 template <int KS>   // 3: the nine taps of a pad-1 filter; 1: a 1x1 filter (no halo, one tap)
@@ -78,10 +78,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   // ---- DMA geometry: one instruction = 8 pixels x 128 B; lane -> (pixel 8 j + lane / 8, LDS chunk lane % 8), which receives
   // source chunk (lane % 8) ^ 4 * bit1(pixel)
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<bf16_t*>(p.x + grp * p.x_gstride + (size_t)b * p.H * p.W * p.xpitch), 0, (int)((long long)p.H * p.W * p.xpitch * 2),
+      const_cast<a16_t*>(p.x + grp * p.x_gstride + (size_t)b * p.H * p.W * p.xpitch), 0, (int)((long long)p.H * p.W * p.xpitch * 2),
       0x00020000);
   const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<bf16_t*>(p.g + grp * p.g_gstride + (size_t)b * p.H * p.W * p.gpitch), 0, (int)((long long)p.H * p.W * p.gpitch * 2),
+      const_cast<a16_t*>(p.g + grp * p.g_gstride + (size_t)b * p.H * p.W * p.gpitch), 0, (int)((long long)p.H * p.W * p.gpitch * 2),
       0x00020000);
   unsigned xvo[4], gvo[3];
 #pragma unroll
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     for (int tp = 0; tp < TAPS; ++tp) acc[tp][r] = 0.f;
   }
   const bool want_bias = tci == 0 && wci == 0;   // db comes from the ci-block-0 workgroups: one extra MFMA per k-step with A = ones
-  const bf16x8 ones = __builtin_bit_cast(bf16x8, u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
+  const a16x8 ones = __builtin_bit_cast(a16x8, u32x4{A16_ONE * 0x10001u, A16_ONE * 0x10001u, A16_ONE * 0x10001u, A16_ONE * 0x10001u});
 
   for (int dy = -HALO; dy <= HALO; ++dy) issue_x(y0 + dy);
   issue_g(y0);
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     const int gs = (y & (NG - 1)) * p.gslot;
 
     u32x2 af[KS][KS][2], bn[2];   // A fragments of tap row ty (KS tap columns x two halves); the next k-step's B halves
-    bf16x8 bcur;
+    a16x8 bcur;
     auto load_a = [&](int ks, int ty) {
 #pragma unroll
       for (int tx = 0; tx < KS; ++tx)
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     auto mma = [&](int ty) {
 #pragma unroll
       for (int tx = 0; tx < KS; ++tx)
-        acc[ty * KS + tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(af[ty][tx][0], af[ty][tx][1]), bcur, acc[ty * KS + tx], 0, 0, 0);
+        acc[ty * KS + tx] = mfma_a16_32x32x16(frag(af[ty][tx][0], af[ty][tx][1]), bcur, acc[ty * KS + tx], 0, 0, 0);
     };
     if constexpr (KS == 3) {
       load_a(0, 0);
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
         pin_a(0); pin(bn[0]); pin(bn[1]);
         bcur = frag(bn[0], bn[1]);
         mma(0);
-        if (want_bias) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bcur, accb, 0, 0, 0);
+        if (want_bias) accb = mfma_a16_32x32x16(ones, bcur, accb, 0, 0, 0);
         load_a(ks, 2);
         lgkm_wait<6>();
         pin_a(1);
@@ -217,9 +217,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
       };
       auto mm = [&](u32x2(&f)[4]) {
         pin(f[0]); pin(f[1]); pin(f[2]); pin(f[3]);
-        const bf16x8 bq = frag(f[2], f[3]);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(f[0], f[1]), bq, acc[0], 0, 0, 0);
-        if (want_bias) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bq, accb, 0, 0, 0);
+        const a16x8 bq = frag(f[2], f[3]);
+        acc[0] = mfma_a16_32x32x16(frag(f[0], f[1]), bq, acc[0], 0, 0, 0);
+        if (want_bias) accb = mfma_a16_32x32x16(ones, bq, accb, 0, 0, 0);
       };
       rd(f0, 0);
       for (int ks = 0; ks < p.nks; ks += 2) {
@@ -288,8 +288,8 @@ int wgrad_launch(const void* x, int xpitch, int xoff, long long x_gstride, const
   const size_t need = pl.S > 1 ? (size_t)G * pl.S * n_out * sizeof(float) : 0;
   if (need && (!workspace || workspace_bytes < need)) return GLARE_ERR_WORKSPACE;
   WgradParams p;
-  p.x = static_cast<const bf16_t*>(x);
-  p.g = static_cast<const bf16_t*>(g);
+  p.x = static_cast<const a16_t*>(x);
+  p.g = static_cast<const a16_t*>(g);
   p.parts = pl.S > 1 ? static_cast<float*>(workspace) : dWt;
   p.B = B; p.H = H; p.W = W; p.xpitch = xpitch; p.xoff = xoff; p.Ci = Ci; p.gpitch = gpitch; p.Co = Co;
   p.x_gstride = x_gstride; p.g_gstride = g_gstride;

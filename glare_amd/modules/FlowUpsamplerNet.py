@@ -458,7 +458,7 @@ class FlowNLLFn(torch.autograd.Function):
         z_in = torch.empty(n + 1, B, H, W, 3, dtype=torch.float32, device=dev)
         z_in[0].copy_(gt.detach())
         z_pre = torch.empty(n, B, H, W, 3, dtype=torch.float32, device=dev)
-        h1s = torch.empty(n, B, H, W, 64, dtype=torch.bfloat16, device=dev)
+        h1s = torch.empty(n, B, H, W, 64, dtype=ops.act_dtype(), device=dev)
         h2s = torch.empty_like(h1s)
         h4s = torch.empty(n, B, H, W, 4, dtype=torch.float32, device=dev)
         bps = ops.flow_blocks_per_sample(H * W)
@@ -486,13 +486,13 @@ class FlowNLLFn(torch.autograd.Function):
         dev = z.device
         gld = g_logdet.float().contiguous()
         gz, gmean = T.flow_nll_backward(z, mean, g_logp.float().contiguous())
-        gftA = torch.empty(B, H, W, n * 64, dtype=torch.bfloat16, device=dev)
-        ghF = torch.empty(B, H, W, n * 8, dtype=torch.bfloat16, device=dev)
+        gftA = torch.empty(B, H, W, n * 64, dtype=ops.act_dtype(), device=dev)
+        ghF = torch.empty(B, H, W, n * 8, dtype=ops.act_dtype(), device=dev)
         f32 = dict(dtype=torch.float32, device=dev)
         dMt, dwz = torch.empty(n, 12, **f32), torch.empty(n, 64, 9, **f32)
         P = B * H * W
-        gh4s = torch.empty(n, B, H, W, 8, dtype=torch.bfloat16, device=dev)     # kept: their filter gradients are batched below
-        gh2s = torch.empty(n, B, H, W, 64, dtype=torch.bfloat16, device=dev)
+        gh4s = torch.empty(n, B, H, W, 8, dtype=ops.act_dtype(), device=dev)     # kept: their filter gradients are batched below
+        gh2s = torch.empty(n, B, H, W, 64, dtype=ops.act_dtype(), device=dev)
         c4t, c2t = ops.packed_conv_batch(c4_w, dgrad_pad=8), ops.packed_conv_batch(c2_w, dgrad_pad=64)   # data-gradient filters
         f4t, f2t = ops.packed_conv_batch(f4_w, dgrad_pad=8), ops.packed_conv_batch(f2_w, dgrad_pad=64)
         for k in reversed(range(n)):                                   # the sequential adjoint sweep

@@ -70,33 +70,81 @@ class FlatGroup:
             off += k
         return [(a, b) for a, b in out]
 
-    def collect(self, chunk=64):
+    def collect(self, chunk=64, grads=None):
+        """grads: {id(param): gradient tensor or None} -- the gradients as a multi-grad hook receives them (arm_early_all_reduce),
+        BEFORE AccumulateGrad has stored them in .grad; None = read .grad."""
+        gof = (lambda p: p.grad) if grads is None else (lambda p: grads.get(id(p)))
         for i, p in enumerate(self.params):
-            if p.grad is not None and not self.has_grad[i]:
+            if gof(p) is not None and not self.has_grad[i]:
                 raise RuntimeError("a parameter declared never_used received a gradient (index %d, shape %s)" % (i, tuple(p.shape)))
         off = 0
         for i in range(0, len(self.params), chunk):
             ps = self.params[i:i + chunk]
             n = sum(p.numel() for p in ps)
-            if all(p.grad is None for p in ps):
+            if all(gof(p) is None for p in ps):
                 self.g[off:off + n].zero_()
             else:
-                torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(torch.float32) for p in ps],
+                torch.cat([(gof(p) if gof(p) is not None else torch.zeros_like(p)).reshape(-1).to(torch.float32) for p in ps],
                           out=self.g[off:off + n])
             off += n
+        if grads is not None:     # inside the backward pass: AccumulateGrad has yet to run for these parameters, and a .grad that
+            return                # aliases the flat buffer would be accumulated INTO, under the exchange (finish_early_all_reduce re-points)
         off = 0
         for p, used in zip(self.params, self.has_grad):   # expose the gathered gradient as .grad (a view of the flat buffer);
             k = p.numel()                                  # parameters the graph never reaches keep .grad = None, as in torch
             p.grad = self.g[off:off + k].view(p.shape) if used else None
             off += k
 
-    def all_reduce(self):
+    def arm_early_all_reduce(self):
+        """Data-parallel steps only: start THIS group's gradient exchange the moment its last gradient exists, while the backward
+        pass of the layers in front of it is still running -- stage 2's flow group (53 MB) is complete when FlowNLLFn.backward and
+        the fold nodes return, and the conditional encoder's whole backward (the larger half of the step) then hides the ring
+        all-reduce over xGMI.  The reference reduces everything through GPU 0 after backward (nn.DataParallel, LLFlow_model.py:
+        71-74).  Call before `loss.backward()`; FlatAdam.step() picks the result up (and falls back to the blocking path if the
+        hook never fired).  No-op at world size 1, so the single-GPU step and its hipGraph capture are untouched."""
+        self._early = None
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) or not self.params:
+            return
+        used = [p for p, u in zip(self.params, self.has_grad) if u]
+        state = {"fired": False, "work": None}
+
+        def fire(grads):
+            state["fired"] = True
+            by_id = {id(p): g for p, g in zip(used, grads)}
+            self.collect(grads=by_id)
+            state["work"] = self.all_reduce(async_op=True)
+
+        state["handle"] = torch.autograd.graph.register_multi_grad_hook(used, fire, mode="all")
+        self._early = state
+
+    def finish_early_all_reduce(self):
+        """-> the world size if the early exchange ran (the flat gradient buffer then holds the all-reduced sum and every .grad is
+        its view), else None (nothing armed, or the hook did not fire: the caller collects and reduces as usual)."""
+        state, self._early = getattr(self, "_early", None), None
+        if state is None:
+            return None
+        state["handle"].remove()
+        if not state["fired"]:
+            return None
+        work = state["work"]
+        if work is not None and not isinstance(work, int):
+            work.wait()
+        off = 0
+        for p, used in zip(self.params, self.has_grad):   # AccumulateGrad has since stored the LOCAL gradient tensors in .grad
+            k = p.numel()
+            p.grad = self.g[off:off + k].view(p.shape) if used else None
+            off += k
+        return dist.get_world_size()
+
+    def all_reduce(self, async_op=False):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             if self.g.is_cuda and dist.get_backend() == "gloo":
                 # test rigs only (two ranks on one GPU cannot use RCCL): the same exchange bounced through host memory
                 host = self.g.cpu()
                 dist.all_reduce(host)
                 self.g.copy_(host)
+            elif async_op:
+                return dist.all_reduce(self.g, async_op=True)   # the caller waits on the returned work (finish_early_all_reduce)
             else:
                 dist.all_reduce(self.g)        # sum (RCCL over xGMI); the 1/world of the mean is folded into the Adam kernel
             return dist.get_world_size()
@@ -109,9 +157,13 @@ class FlatAdam:
     loop runs ahead of the GPU; the whole step replays from a hipGraph, GraphedStep).  `device_state` is accepted for
     compatibility with round 2's two modes; the host-state mode is gone (its inf / NaN check would have cost a sync per step)."""
 
-    def __init__(self, groups, betas=(0.9, 0.999), eps=1e-8, device_state=True):
+    def __init__(self, groups, betas=(0.9, 0.999), eps=1e-8, device_state=True, loss_scaling=False):
+        """loss_scaling: fp16 training -- `scale_loss()` multiplies the loss by the scale before backward and step() divides it out
+        of the gradients (scaler.scale / scaler.unscale_, LLFlow_model.py:236-241); bf16 training keeps fp32's range and only runs
+        the scaler's bookkeeping."""
         self.groups, self.betas, self.eps = groups, betas, eps
         self.device_state = True
+        self.loss_scaling = bool(loss_scaling)
         dev = next(g.w.device for g in groups if g.w.numel())
         # GradScaler's state (torch.cuda.amp.GradScaler defaults, LLFlow_model.py:120): found_inf of the step in progress, the
         # scale and the growth tracker
@@ -138,6 +190,10 @@ class FlatAdam:
         for g in self.groups:
             g.zero_grad()
 
+    def scale_loss(self, loss):
+        """scaler.scale(loss): a device-side multiply (no host read of the scale); the identity without loss scaling."""
+        return loss * self.scale.to(loss.dtype).reshape(()) if self.loss_scaling else loss
+
     def step(self):
         """scaler.step(optimizer); scaler.update() (LLFlow_model.py:240-241): gather + all-reduce the gradients, then ONE Adam
         step over every group -- unless an inf / NaN sits anywhere in them (checked AFTER the all-reduce, so every rank
@@ -149,8 +205,11 @@ class FlatAdam:
             if g.w.numel() == 0:
                 worlds.append(1)
                 continue
-            g.collect()
-            worlds.append(g.all_reduce())
+            early = g.finish_early_all_reduce()      # the exchange that started during the backward pass, if one was armed
+            if early is None:
+                g.collect()
+                early = g.all_reduce()
+            worlds.append(early)
             T.grad_nonfinite_(g.g, self.found_inf)
         T.adam_prepare_guarded_(self.step_dev, self.state3, self.betas, self.found_inf)
         for g, world in zip(self.groups, worlds):
@@ -158,7 +217,7 @@ class FlatAdam:
                 continue
             for lo, hi in g.active_ranges():       # never-used parameters are skipped, as torch.optim.Adam does
                 T.adam_step_dev_guarded_(g.w[lo:hi], g.g[lo:hi], g.m[lo:hi], g.v[lo:hi], self.state3, g.lr, self.betas, self.eps,
-                                         g.weight_decay, 1.0 / world, self.found_inf)
+                                         g.weight_decay, 1.0 / world, self.found_inf, self.scale if self.loss_scaling else None)
         T.gradscaler_update_(self.scale, self.growth_tracker, self.found_inf, self.growth_factor, self.backoff_factor,
                              self.growth_interval)
 
@@ -191,7 +250,11 @@ class Stage2Trainer:
     """One optimisation step of the flow objective: a7 (frozen VQGAN encoder, no tape) -> a1 -> a4 -> mean NLL -> backward ->
     gradient mean over ranks -> Adam."""
 
-    def __init__(self, netG, net_hq, lr_G=5e-4, lr_RRDB=None, weight_decay_G=0.0, train_rrdb=True, device_state=False):
+    def __init__(self, netG, net_hq, lr_G=5e-4, lr_RRDB=None, weight_decay_G=0.0, train_rrdb=True, device_state=False, precision="bf16"):
+        """precision: the 16-bit format of activations and activation gradients -- "bf16" (fp32 range, no loss scaling needed) or
+        "fp16" (the reference's autocast dtype, 8x finer rounding; the loss is scaled by the device-resident GradScaler scale)."""
+        assert precision in ("bf16", "fp16")
+        self.precision = precision
         self.netG, self.net_hq = netG.train(), net_hq.eval()
         for p in net_hq.parameters():
             p.requires_grad_(False)
@@ -206,7 +269,7 @@ class Stage2Trainer:
         never = [p for n, p in netG.named_parameters() if n.startswith(STAGE2_NEVER_USED)]
         self.opt = FlatAdam([FlatGroup(other, lr_G, weight_decay_G, never_used=never),
                              FlatGroup(rrdb if train_rrdb else [], lr_G if lr_RRDB is None else lr_RRDB, 1e-5,
-                                       device=other[0].device)], device_state=device_state)
+                                       device=other[0].device)], device_state=device_state, loss_scaling=precision == "fp16")
         self.pack_cache = ops.PackCache([p for p in netG.parameters() if p.requires_grad])   # packed filters live across steps
 
     def draw_branch(self):
@@ -221,14 +284,16 @@ class Stage2Trainer:
         """The step without any host synchronisation: returns the loss as a device tensor.  mean_is_gt: None = draw with
         probability train_gt_ratio as the reference does; True / False = forced (GraphedStep draws before choosing a graph)."""
         flag = self.draw_branch() if mean_is_gt is None else bool(mean_is_gt)
-        with torch.no_grad(), ops.auto_cout_tile():
-            gt_latent = self.net_hq.encode_nhwc(gt_img)            # LLFlow_model.py:200-201
-        self.opt.zero_grad()
-        with self.pack_cache:
-            nll = self.netG.train_nll(gt_latent, lr_img, mean_is_gt=flag)   # :215
-            loss = nll.mean()
-            loss.backward()                                        # :236
-        self.opt.step()                                            # :240
+        with ops.use_precision(self.precision):
+            with torch.no_grad(), ops.auto_cout_tile():
+                gt_latent = self.net_hq.encode_nhwc(gt_img)            # LLFlow_model.py:200-201
+            self.opt.zero_grad()
+            with self.pack_cache:
+                nll = self.netG.train_nll(gt_latent, lr_img, mean_is_gt=flag)   # :215
+                loss = nll.mean()
+                self.opt.groups[0].arm_early_all_reduce()              # N > 1: the flow group's all-reduce runs under the encoder's backward
+                self.opt.scale_loss(loss).backward()                   # :236  scaler.scale(loss).backward()
+            self.opt.step()                                            # :240-241  scaler.step(); scaler.update()
         self.netG.invalidate()                                     # packed inference weights are stale now
         return loss.detach()
 
@@ -240,9 +305,12 @@ class Stage3Trainer:
     perceptual + 0.2 * (1 - MS-SSIM(normalize=True)).  The perceptual network's weights are the caller's (`perceptual=`): the
     reference downloads torchvision's pretrained VGG16, which is not available offline; pass None to train on L1 + MS-SSIM."""
 
-    def __init__(self, netG, net_hq, lr_G=5e-5, weight_decay_G=0.0, perceptual=None, use_msssim=True, device_state=False):
+    def __init__(self, netG, net_hq, lr_G=5e-5, weight_decay_G=0.0, perceptual=None, use_msssim=True, device_state=False, precision="bf16"):
         from . import autograd as A
         from . import losses
+
+        assert precision in ("bf16", "fp16")      # as Stage2Trainer
+        self.precision = precision
 
         self.A, self.losses, self.perceptual, self.use_msssim = A, losses, perceptual, use_msssim
         self.last_terms = {}
@@ -256,7 +324,7 @@ class Stage3Trainer:
         # conditional encoder is frozen (fix_modules), so its group is empty -- kept for `.state` file compatibility
         never = [p for n, p in netG.named_parameters() if n.startswith(STAGE3_NEVER_USED)]
         self.opt = FlatAdam([FlatGroup(dd, lr_G, weight_decay_G, never_used=never), FlatGroup([], lr_G, 1e-5, device=dd[0].device)],
-                            device_state=device_state)
+                            device_state=device_state, loss_scaling=precision == "fp16")
         self.pack_cache = ops.PackCache(dd)
 
     def step(self, gt_img, lr_img):
@@ -265,16 +333,17 @@ class Stage3Trainer:
 
     def step_tensor(self, gt_img, lr_img):
         G = self.netG
-        with torch.no_grad(), ops.auto_cout_tile():
-            enc = G.RRDB.forward_nhwc(lr_img)
-            lat = G.flowUpsamplerNet.decode_nhwc(enc["color_map"], enc["cond_feat"])
-            _, _, feats = self.net_hq.decode_nhwc(lat, want_image=False)
-        self.opt.zero_grad()
-        with self.pack_cache:
-            rec = G.deformable_decoder.train_nhwc(lat, feats, enc["mid_feat"], whole_batch_mean=True)
-            loss, self.last_terms = stage3_loss(rec, gt_img, self.perceptual, self.use_msssim)
-            loss.backward()
-        self.opt.step()
+        with ops.use_precision(self.precision):
+            with torch.no_grad(), ops.auto_cout_tile():
+                enc = G.RRDB.forward_nhwc(lr_img)
+                lat = G.flowUpsamplerNet.decode_nhwc(enc["color_map"], enc["cond_feat"])
+                _, _, feats = self.net_hq.decode_nhwc(lat, want_image=False)
+            self.opt.zero_grad()
+            with self.pack_cache:
+                rec = G.deformable_decoder.train_nhwc(lat, feats, enc["mid_feat"], whole_batch_mean=True)
+                loss, self.last_terms = stage3_loss(rec, gt_img, self.perceptual, self.use_msssim)
+                self.opt.scale_loss(loss).backward()
+            self.opt.step()
         G.deformable_decoder.invalidate()   # only its packed inference weights went stale; the frozen nets keep theirs
         return loss.detach()
 

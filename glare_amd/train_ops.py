@@ -7,7 +7,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import check, ptr, require_cuda, stream_handle
+from ._lib import act_dtype, check, ptr, require_cuda, stream_handle
 
 from .ops import count_flops as _count_flops
 
@@ -20,7 +20,7 @@ def gemm_nt(a, b, out=None, alpha=1.0, out_dtype=torch.float32, accumulate=False
     """C[.., m, n] = alpha * sum_k a[.., m, k] * b[.., n, k]  (+ C).  a, b: bf16, 2-D or 3-D (batched), last dim
     contiguous; rows may be strided (views of wider buffers are fine)."""
     require_cuda(a, b, out)
-    assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.stride(-1) == 1 and b.stride(-1) == 1
+    assert a.dtype == act_dtype() and b.dtype == act_dtype() and a.stride(-1) == 1 and b.stride(-1) == 1
     if a.dim() == 2:
         a, b = a.unsqueeze(0), b.unsqueeze(0)
         squeeze = True
@@ -35,12 +35,12 @@ def gemm_nt(a, b, out=None, alpha=1.0, out_dtype=torch.float32, accumulate=False
         if accumulate:
             out.zero_()
     o3 = out if out.dim() == 3 else out.unsqueeze(0)
-    assert o3.stride(-1) == 1 and o3.dtype in (torch.float32, torch.bfloat16)
+    assert o3.stride(-1) == 1 and o3.dtype in (torch.float32, act_dtype())
     _count_flops("gemm_nt", 2.0 * batch * M * N * K)
     check(_lib.lib().glare_gemm_nt_bf16(ptr(a), ptr(b), ptr(o3), _i(M), _i(N), _i(K), _ll(a.stride(1)), _ll(b.stride(1)),
                                         _ll(o3.stride(1)), _i(batch), _ll(a.stride(0) if batch > 1 else 0),
                                         _ll(b.stride(0) if batch > 1 else 0), _ll(o3.stride(0) if batch > 1 else 0),
-                                        _f(alpha), _i(int(o3.dtype == torch.bfloat16)), _i(int(accumulate)), stream_handle()),
+                                        _f(alpha), _i(int(o3.dtype == act_dtype())), _i(int(accumulate)), stream_handle()),
           "glare_gemm_nt_bf16")
     return out[0] if squeeze and out.dim() == 3 else out
 
@@ -68,12 +68,12 @@ def _rup(a, b):
 def transpose(x2d, ld_out=None, out=None):
     """bf16 [.., R, C] (row stride arbitrary, last dim contiguous) -> [.., C, ld_out] with zero-filled tail columns."""
     require_cuda(x2d, out)
-    assert x2d.dtype == torch.bfloat16 and x2d.stride(-1) == 1
+    assert x2d.dtype == act_dtype() and x2d.stride(-1) == 1
     x3 = x2d if x2d.dim() == 3 else x2d.unsqueeze(0)
     batch, R, C = x3.shape
     ld_out = _rup(R, 64) if ld_out is None else ld_out
     if out is None:
-        out = torch.empty(batch, C, ld_out, dtype=torch.bfloat16, device=x2d.device)
+        out = torch.empty(batch, C, ld_out, dtype=act_dtype(), device=x2d.device)
     o3 = out if out.dim() == 3 else out.unsqueeze(0)
     check(_lib.lib().glare_transpose_bf16(ptr(x3), _ll(x3.stride(1)), _ll(x3.stride(0) if batch > 1 else 0), ptr(o3), _ll(o3.stride(1)),
                                           _ll(o3.stride(0) if batch > 1 else 0), _ll(R), _i(C), _i(batch), stream_handle()),
@@ -85,7 +85,7 @@ def im2col_t(x, ksize, stride=1, pad=None, upsample=False, cin=None, in_off=0, l
              rows=None):
     """x bf16 NHWC [B,H,W,pitch] -> colT [rows, ldp] bf16 (row = c*k*k + tap), see include/glare_hip.h."""
     require_cuda(x, col)
-    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    assert x.dtype == act_dtype() and x.is_contiguous()
     B, H, W, pitch = x.shape
     cin = pitch - in_off if cin is None else cin
     pad = (1 if (ksize == 3 and stride == 1) else 0) if pad is None else pad
@@ -95,7 +95,7 @@ def im2col_t(x, ksize, stride=1, pad=None, upsample=False, cin=None, in_off=0, l
     ldp = _rup(P, 64) if ldp is None else ldp
     if col is None:
         nrows = (cin * ksize * ksize + (1 if ones_row >= 0 else 0)) if rows is None else rows
-        col = torch.empty(nrows, ldp, dtype=torch.bfloat16, device=x.device)
+        col = torch.empty(nrows, ldp, dtype=act_dtype(), device=x.device)
     check(_lib.lib().glare_im2col_t_bf16(ptr(x), _i(B), _i(H), _i(W), _i(pitch), _i(in_off), _i(cin), _i(ksize), _i(stride), _i(pad),
                                          _i(int(upsample)), ptr(col), _ll(ldp), _i(row_base), _i(ones_row), stream_handle()),
           "glare_im2col_t_bf16")
@@ -108,7 +108,7 @@ def im2col_t_f32(x, strides, shape_bhw, cin, ksize, pad, ldp=None, ones_row=-1):
     B, H, W = shape_bhw
     P = B * H * W
     ldp = _rup(P, 64) if ldp is None else ldp
-    col = torch.empty(cin * ksize * ksize + (1 if ones_row >= 0 else 0), ldp, dtype=torch.bfloat16, device=x.device)
+    col = torch.empty(cin * ksize * ksize + (1 if ones_row >= 0 else 0), ldp, dtype=act_dtype(), device=x.device)
     sb, sc, sy, sx = strides
     check(_lib.lib().glare_im2col_t_f32(ptr(x), _ll(sb), _ll(sc), _ll(sy), _ll(sx), _i(B), _i(H), _i(W), _i(cin), _i(ksize), _i(pad),
                                         ptr(col), _ll(ldp), _i(0), _i(ones_row), stream_handle()), "glare_im2col_t_f32")
@@ -117,18 +117,18 @@ def im2col_t_f32(x, strides, shape_bhw, cin, ksize, pad, ldp=None, ones_row=-1):
 
 def dilate2(g):
     require_cuda(g)
-    assert g.dtype == torch.bfloat16 and g.is_contiguous()
+    assert g.dtype == act_dtype() and g.is_contiguous()
     B, OH, OW, C = g.shape
-    out = torch.empty(B, 2 * OH, 2 * OW, C, dtype=torch.bfloat16, device=g.device)
+    out = torch.empty(B, 2 * OH, 2 * OW, C, dtype=act_dtype(), device=g.device)
     check(_lib.lib().glare_dilate2_bf16(ptr(g), ptr(out), _i(B), _i(OH), _i(OW), _i(C), stream_handle()), "glare_dilate2_bf16")
     return out
 
 
 def pool2_sum(g):
     require_cuda(g)
-    assert g.dtype == torch.bfloat16 and g.is_contiguous()
+    assert g.dtype == act_dtype() and g.is_contiguous()
     B, H2, W2, C = g.shape
-    out = torch.empty(B, H2 // 2, W2 // 2, C, dtype=torch.bfloat16, device=g.device)
+    out = torch.empty(B, H2 // 2, W2 // 2, C, dtype=act_dtype(), device=g.device)
     check(_lib.lib().glare_pool2_sum_bf16(ptr(g), ptr(out), _i(B), _i(H2 // 2), _i(W2 // 2), _i(C), stream_handle()),
           "glare_pool2_sum_bf16")
     return out
@@ -152,7 +152,7 @@ def cast_to_bf16(x, pitch=None):
     assert x.dtype == torch.float32 and x.is_contiguous()
     C = x.shape[-1]
     pitch = C if pitch is None else pitch
-    out = (torch.zeros if pitch != C else torch.empty)(*x.shape[:-1], pitch, dtype=torch.bfloat16, device=x.device)
+    out = (torch.zeros if pitch != C else torch.empty)(*x.shape[:-1], pitch, dtype=act_dtype(), device=x.device)
     check(_lib.lib().glare_cast_f32_bf16(ptr(x), _i(C), _i(0), ptr(out), _i(pitch), _i(0), _ll(x.numel() // C), _i(C), stream_handle()),
           "glare_cast_f32_bf16")
     return out
@@ -160,7 +160,7 @@ def cast_to_bf16(x, pitch=None):
 
 def cast_to_f32(x, C=None):
     require_cuda(x)
-    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    assert x.dtype == act_dtype() and x.is_contiguous()
     pitch = x.shape[-1]
     C = pitch if C is None else C
     out = torch.empty(*x.shape[:-1], C, dtype=torch.float32, device=x.device)
@@ -172,7 +172,7 @@ def cast_to_f32(x, C=None):
 def groupnorm_forward(x, gamma, beta, swish=True, eps=1e-6):
     """Training-mode GroupNorm: returns (y, stats) with stats = the [B][splits][32][2] block the backward consumes."""
     require_cuda(x, gamma, beta)
-    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    assert x.dtype == act_dtype() and x.is_contiguous()
     B, H, W, C = x.shape
     lib = _lib.lib()
     lib.glare_groupnorm_workspace_bytes.restype = _sz
@@ -187,7 +187,7 @@ def groupnorm_forward(x, gamma, beta, swish=True, eps=1e-6):
 def groupnorm_backward(x, dy, stats, gamma, beta, swish=True, eps=1e-6):
     """-> (dx bf16, dgamma fp32 [C], dbeta fp32 [C])."""
     require_cuda(x, dy, stats, gamma, beta)
-    assert x.dtype == dy.dtype == torch.bfloat16 and x.is_contiguous() and dy.is_contiguous()
+    assert x.dtype == dy.dtype == act_dtype() and x.is_contiguous() and dy.is_contiguous()
     B, H, W, C = x.shape
     lib = _lib.lib()
     lib.glare_groupnorm_backward_workspace_bytes.restype = _sz
@@ -207,7 +207,7 @@ def softmax2_rows(S, n, ldp=None):
     assert S.dtype == torch.float32 and S.dim() == 2 and S.stride(1) == 1
     rows = S.shape[0]
     ldp = _rup(n, 64) if ldp is None else ldp
-    P = torch.empty(rows, ldp, dtype=torch.bfloat16, device=S.device)
+    P = torch.empty(rows, ldp, dtype=act_dtype(), device=S.device)
     check(_lib.lib().glare_softmax2_rows_f32(ptr(S), _ll(S.stride(0)), ptr(P), _ll(ldp), _ll(rows), _i(n), stream_handle()),
           "glare_softmax2_rows_f32")
     return P
@@ -216,7 +216,7 @@ def softmax2_rows(S, n, ldp=None):
 def attention_ds(P, dP, dO, O, n, scale):
     require_cuda(P, dP, dO, O)
     rows, d = dO.shape
-    dS = torch.empty(rows, P.shape[1], dtype=torch.bfloat16, device=P.device)
+    dS = torch.empty(rows, P.shape[1], dtype=act_dtype(), device=P.device)
     check(_lib.lib().glare_attention_ds_bf16(ptr(P), _ll(P.stride(0)), ptr(dP), _ll(dP.stride(0)), ptr(dO), _i(dO.stride(0)), ptr(O),
                                              _i(O.stride(0)), _i(d), ptr(dS), _ll(dS.stride(0)), _ll(rows), _i(n), _f(scale),
                                              stream_handle()), "glare_attention_ds_bf16")
@@ -268,7 +268,7 @@ def attention_backward_fused(q, k, v, o, do, lse, ln2_scale=0.6931471805599453):
     [B, N] from the forward -> (dq, dk, dv) bf16.  No N^2 tensor: scores are recomputed per tile in two passes."""
     require_cuda(q, k, v, o, do, lse)
     B, N, d = q.shape
-    assert d == 512 and all(t.is_contiguous() and t.dtype == torch.bfloat16 for t in (q, k, v, o, do))
+    assert d == 512 and all(t.is_contiguous() and t.dtype == act_dtype() for t in (q, k, v, o, do))
     assert lse.dtype == torch.float32 and lse.is_contiguous() and lse.numel() == B * N
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     _count_flops("attn bwd", 10.0 * B * N * N * d)     # the five products of the backward (the kernel recomputes two more)
@@ -318,7 +318,7 @@ def flow_post_backward_(gz, z_pre, h4, g_logdet, eps, out=None):
     """-> gh4 bf16 [B,H,W,8] (4 used); gz[..., 1:] updated in place."""
     require_cuda(gz, z_pre, h4, g_logdet, out)
     B = gz.shape[0]
-    gh4 = torch.empty(*gz.shape[:-1], 8, dtype=torch.bfloat16, device=gz.device) if out is None else out
+    gh4 = torch.empty(*gz.shape[:-1], 8, dtype=act_dtype(), device=gz.device) if out is None else out
     check(_lib.lib().glare_flow_fwd_post_backward_f32(ptr(gz), ptr(z_pre), ptr(h4), ptr(g_logdet), _i(B), _ll(gz.numel() // 3 // B),
                                                       _f(eps), ptr(gh4), stream_handle()), "glare_flow_fwd_post_backward_f32")
     return gh4
@@ -362,7 +362,7 @@ def flow_pre_backward_(gz, z_in, hF, hF_off, g_logdet, M, t, eps, ghF, ghF_off, 
 def mix_backward(g, a, b, w, want_ga=False):
     """-> (ga or None, gb, dw fp32 [1])."""
     require_cuda(g, a, b)
-    assert g.dtype == a.dtype == b.dtype == torch.bfloat16 and g.is_contiguous() and a.is_contiguous() and b.is_contiguous()
+    assert g.dtype == a.dtype == b.dtype == act_dtype() and g.is_contiguous() and a.is_contiguous() and b.is_contiguous()
     gb = torch.empty_like(g)
     ga = torch.empty_like(g) if want_ga else None
     dw = torch.empty(1, dtype=torch.float32, device=g.device)
@@ -379,7 +379,7 @@ def mix_backward(g, a, b, w, want_ga=False):
 
 def mean_rescale_backward(g, h, xw, whole_batch):
     require_cuda(g, h, xw)
-    assert g.dtype == h.dtype == torch.bfloat16 and xw.dtype == torch.float32
+    assert g.dtype == h.dtype == act_dtype() and xw.dtype == torch.float32
     g, h, xw = g.contiguous(), h.contiguous(), xw.contiguous()
     B = h.shape[0]
     n = h.numel() // B
@@ -474,9 +474,9 @@ def ssim_backward(x, y, mom, window, C1, C2, g10, level, g_next):
 
 def maxpool2(x):
     require_cuda(x)
-    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    assert x.dtype == act_dtype() and x.is_contiguous()
     B, H, W, C = x.shape
-    y = torch.empty(B, H // 2, W // 2, C, dtype=torch.bfloat16, device=x.device)
+    y = torch.empty(B, H // 2, W // 2, C, dtype=act_dtype(), device=x.device)
     check(_lib.lib().glare_maxpool2_bf16(ptr(x), ptr(y), _i(B), _i(H), _i(W), _i(C), stream_handle()), "glare_maxpool2_bf16")
     return y
 
@@ -494,7 +494,7 @@ def maxpool2_backward(x, g):
 def mse_loss(a, b, want_grad=True):
     """bf16 feature maps -> (loss fp32 [1], grad_a bf16 or None)."""
     require_cuda(a, b)
-    assert a.dtype == b.dtype == torch.bfloat16 and a.is_contiguous() and b.is_contiguous() and a.shape == b.shape
+    assert a.dtype == b.dtype == act_dtype() and a.is_contiguous() and b.is_contiguous() and a.shape == b.shape
     loss = torch.empty(1, dtype=torch.float32, device=a.device)
     ga = torch.empty_like(a) if want_grad else None
     ws = torch.empty(256, dtype=torch.float64, device=a.device)
@@ -530,8 +530,14 @@ def adam_prepare_guarded_(step_dev, state3, betas, skip):
           "glare_adam_prepare_guarded")
 
 
-def adam_step_dev_guarded_(w, grad, exp_avg, exp_avg_sq, state3, lr, betas, eps, weight_decay, grad_scale, skip):
-    require_cuda(w, grad, exp_avg, exp_avg_sq, state3, skip)
+def adam_step_dev_guarded_(w, grad, exp_avg, exp_avg_sq, state3, lr, betas, eps, weight_decay, grad_scale, skip, loss_scale=None):
+    """loss_scale: fp32 device tensor [1] the loss was multiplied by (fp16 training: GradScaler's scale), divided out here."""
+    require_cuda(w, grad, exp_avg, exp_avg_sq, state3, skip, loss_scale)
+    if loss_scale is not None:
+        check(_lib.lib().glare_adam_step_dev_scaled_f32(ptr(w), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), _ll(w.numel()), _f(lr),
+                                                        _f(betas[0]), _f(betas[1]), _f(eps), _f(weight_decay), ptr(state3), _f(grad_scale),
+                                                        ptr(loss_scale), ptr(skip), stream_handle()), "glare_adam_step_dev_scaled_f32")
+        return w
     check(_lib.lib().glare_adam_step_dev_guarded_f32(ptr(w), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), _ll(w.numel()), _f(lr),
                                                      _f(betas[0]), _f(betas[1]), _f(eps), _f(weight_decay), ptr(state3), _f(grad_scale),
                                                      ptr(skip), stream_handle()), "glare_adam_step_dev_guarded_f32")
@@ -584,7 +590,7 @@ def add_bf16(a, b, c=None):
     require_cuda(a, b, c)
     a, b = a.contiguous(), b.contiguous()
     c = None if c is None else c.contiguous()
-    assert a.dtype == b.dtype == torch.bfloat16 and a.shape == b.shape
+    assert a.dtype == b.dtype == act_dtype() and a.shape == b.shape
     out = torch.empty_like(a)
     check(_lib.lib().glare_add_bf16(ptr(a), ptr(b), ptr(c), ptr(out), _ll(a.numel()), stream_handle()), "glare_add_bf16")
     return out
@@ -593,7 +599,7 @@ def add_bf16(a, b, c=None):
 def colsum(g2d, C):
     """bf16 [P, pitch] -> fp32 [C] column sums (bias gradient)."""
     require_cuda(g2d)
-    assert g2d.dtype == torch.bfloat16 and g2d.dim() == 2 and g2d.stride(1) == 1
+    assert g2d.dtype == act_dtype() and g2d.dim() == 2 and g2d.stride(1) == 1
     out = torch.empty(C, dtype=torch.float32, device=g2d.device)
     ws = torch.empty(256 * C, dtype=torch.float32, device=g2d.device)
     check(_lib.lib().glare_colsum_bf16(ptr(g2d), _i(g2d.stride(0)), _ll(g2d.shape[0]), _i(C), ptr(out), ptr(ws), _sz(ws.numel() * 4),
@@ -611,7 +617,7 @@ def conv_weight_grad_nhwc(ksize, x, g16, cout, cin=None, in_off=0, groups=1, x_g
     one group when the tensors hold several).  Returns fp32 [groups, ksize^2*cin + 1, cout]: row (ty*ksize+tx)*cin + ci, last
     row = the bias gradient."""
     require_cuda(x, g16, out)
-    assert x.dtype == torch.bfloat16 and g16.dtype == torch.bfloat16 and x.is_contiguous() and g16.is_contiguous()
+    assert x.dtype == act_dtype() and g16.dtype == act_dtype() and x.is_contiguous() and g16.is_contiguous()
     B, H, W = x.shape[:3] if shape is None else shape
     pitch, gpitch = x.shape[-1], g16.shape[-1]
     cin = pitch - in_off if cin is None else cin

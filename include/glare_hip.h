@@ -563,6 +563,12 @@ int glare_adam_prepare_guarded(int* step_device, float* state3_device, float bet
 int glare_adam_step_dev_guarded_f32(float* w, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1,
                                     float beta2, float eps, float weight_decay, const float* state3_device, float grad_scale,
                                     const int* skip_if_nonzero_device, glare_stream_t stream);
+/* ... under the fp16 precision (round 4: the training kernels exist in libglare_hip_f16.so too) the scale is REAL, as in the
+ * reference: the caller multiplies the loss by *loss_scale_device before backward (`scaler.scale(loss).backward()`), 16-bit
+ * activation gradients carry it, and this entry point divides it out of the fp32 gradient (`scaler.unscale_`) on the fly. */
+int glare_adam_step_dev_scaled_f32(float* w, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1,
+                                   float beta2, float eps, float weight_decay, const float* state3_device, float grad_scale,
+                                   const float* loss_scale_device, const int* skip_if_nonzero_device, glare_stream_t stream);
 int glare_gradscaler_update(float* scale_device, int* growth_tracker_device, const int* found_device, float growth_factor,
                             float backoff_factor, int growth_interval, glare_stream_t stream);
 /* The same step with ALL optimizer state on the device, so that a whole training step replays from a hipGraph:

@@ -154,3 +154,81 @@ def test_never_used_parameter_with_a_gradient_is_an_error():
     (p * 2).sum().backward()
     with pytest.raises(RuntimeError):
         grp.collect()
+
+
+def _early_worker(rank, world, port, q):
+    """The overlapped exchange of a training step (FlatGroup.arm_early_all_reduce): the LATE layers' group (the flow, in stage 2)
+    starts its all-reduce from a multi-grad hook while the backward pass of the early layers' group (the conditional encoder) is
+    still running; the result must equal the blocking path's, and .grad must end up as views of the all-reduced flat buffer."""
+    from glare_amd.train import FlatGroup
+
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    parallel.init_from_env(backend="gloo")
+    torch.manual_seed(0)
+    early_layers, late_layers = torch.nn.Linear(5, 4), torch.nn.Linear(4, 3)       # "encoder" in front of the "flow"
+    unused = torch.nn.Parameter(torch.ones(2))
+    g_late = FlatGroup(list(late_layers.parameters()) + [unused], lr=1e-3, never_used=[unused])
+    g_early = FlatGroup(list(early_layers.parameters()), lr=1e-3)
+    x = torch.full((2, 5), float(rank + 1))
+    order = []
+    early_layers.weight.register_hook(lambda g: order.append("early-layer grad"))
+
+    def run(overlap):
+        for g in (g_late, g_early):
+            g.zero_grad()
+        loss = late_layers(torch.tanh(early_layers(x))).sum()
+        if overlap:
+            g_late.arm_early_all_reduce()
+            fire = g_late._early["handle"]
+            assert fire is not None
+        loss.backward()
+        out = []
+        for g in (g_late, g_early):
+            w = g.finish_early_all_reduce()
+            if w is None:
+                g.collect()
+                w = g.all_reduce()
+            out.append((w, g.g.clone()))
+        return out
+
+    blocking = run(False)
+    overlapped = run(True)
+    views = all(p.grad is not None and p.grad.data_ptr() >= g_late.g.data_ptr() and
+                p.grad.data_ptr() < g_late.g.data_ptr() + g_late.g.numel() * 4 for p in late_layers.parameters())
+    q.put((rank, [w for w, _ in blocking], [w for w, _ in overlapped],
+           all(torch.equal(a[1], b[1]) for a, b in zip(blocking, overlapped)), views, unused.grad is None))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_early_all_reduce_equals_the_blocking_exchange():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_early_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, wb, wo, same, views, unused_none in got:
+        assert wb == wo == [2, 2]
+        assert same and views and unused_none
+
+
+def test_early_all_reduce_is_a_no_op_without_a_process_group():
+    from glare_amd.train import FlatGroup
+
+    lin = torch.nn.Linear(3, 2)
+    grp = FlatGroup(list(lin.parameters()), lr=1e-3)
+    grp.zero_grad()
+    grp.arm_early_all_reduce()
+    lin(torch.ones(1, 3)).sum().backward()
+    assert grp.finish_early_all_reduce() is None          # world size 1: the step's blocking path (and its hipGraph) is untouched
+    grp.collect()
+    assert grp.all_reduce() == 1

@@ -80,6 +80,32 @@ def bench_conv():
             print("conv  %-22s: igemm %.3f ms, weight-stationary %.3f ms = %.0f GB/s algorithmic (x in + out)" % (name, ms_old, ms_new, by / ms_new / 1e6))
 
 
+def bench_convsplit():
+    """The fp32-class form (glare_conv_desc.k_wrap; ops.PackedConv(split=3)) at the conditional encoder's shapes, fp16, pair in / pair
+    out: TFLOP/s by ALGORITHMIC FLOPs (one fp32 conv) and by executed MFMA FLOPs (3 K segments)."""
+    only = os.environ.get("KB_CONV")
+    cases = [("128->128 3x3 @full", 128, 128, 420, 620, 3), ("256->256 3x3 @half", 256, 256, 210, 310, 3),
+             ("512->512 3x3 @q", 512, 512, 105, 155, 3), ("512->512 1x1 @q", 512, 512, 105, 155, 1), ("64->1536 3x3 @q", 64, 1536, 105, 155, 3)]
+    with ops.use_precision("fp16"):
+        for name, ci, co, h, w, k in cases:
+            if only and only not in name:
+                continue
+            x = ops.split_hilo(torch.randn(B, h, w, ci, device=DEV))
+            wt = torch.randn(co, ci, k, k, device=DEV) * 0.02
+            pc = ops.PackedConv(wt, torch.zeros(co, device=DEV), split=3)
+            res = ops.split_hilo(torch.randn(B, h, w, co, device=DEV))
+            out = torch.empty(B, h, w, co, dtype=torch.float16, device=DEV)
+            out._lo = torch.empty_like(out)
+            ms = timeit(lambda: ops.conv2d(x, pc, out=out, hilo=True))
+            fl = 2.0 * B * h * w * ci * co * k * k
+            print("conv3 %-22s: %.3f ms  %.0f TFLOP/s algorithmic, %.0f executed (pair out)" % (name, ms, fl / ms / 1e9, 3 * fl / ms / 1e9))
+            ms = timeit(lambda: ops.conv2d(x, pc, out=out, residual=res, hilo=True, gn_stats=(co % 128 == 0)))
+            print("conv3 %-22s: %.3f ms  %.0f TFLOP/s algorithmic, %.0f executed (+ pair residual, statistics)" % (name, ms, fl / ms / 1e9, 3 * fl / ms / 1e9))
+            pc1 = ops.PackedConv(wt, torch.zeros(co, device=DEV))
+            ms1 = timeit(lambda: ops.conv2d(x, pc1, out=out))
+            print("conv3 %-22s: single pass, 16-bit out %.3f ms  %.0f TFLOP/s" % (name, ms1, fl / ms1 / 1e9))
+
+
 def bench_gn():
     for c, h, w in ((128, 420, 620), (256, 210, 310), (512, 105, 155)):
         x = torch.randn(B, h, w, c, device=DEV).to(torch.bfloat16)
@@ -91,15 +117,24 @@ def bench_gn():
 
 
 def bench_dcn():
-    for c, h, w in ((128, 420, 620), (256, 210, 310)):
-        x = torch.randn(B, h, w, c, device=DEV).to(torch.bfloat16)
-        plane = (h * w + 63) // 64 * 64
-        om = torch.randn(B, 108, plane, device=DEV)
-        wt = torch.randn(c, c, 3, 3, device=DEV) * 0.02
-        pd = ops.PackedDcn(wt, torch.zeros(c, device=DEV), 4)
-        ms = timeit(lambda: ops.mdcn_forward_nhwc(x, om, pd))
-        fl = 2.0 * B * h * w * c * c * 9 + 72.0 * B * h * w * c
-        print("dcn   C=%d %dx%d: %.3f ms  %.1f TFLOP/s (fp32)" % (c, h, w, ms, fl / ms / 1e9))
+    only = os.environ.get("KB_DCN")      # "128" / "256": one shape (per-shape PMC passes)
+    for prec in ("bf16", "fp16"):
+        with ops.use_precision(prec):
+            for c, h, w in ((128, 420, 620), (256, 210, 310)):
+                if only and only != str(c):
+                    continue
+                x = torch.randn(B, h, w, c, device=DEV).to(ops.act_dtype())
+                plane = (h * w + 63) // 64 * 64
+                om = torch.randn(B, 108, plane, device=DEV)
+                wt = torch.randn(c, c, 3, 3, device=DEV) * 0.02
+                pd = ops.PackedDcn(wt, torch.zeros(c, device=DEV), 4)
+                ms = timeit(lambda: ops.mdcn_forward_nhwc(x, om, pd))
+                fl = 2.0 * B * h * w * c * c * 9 + 72.0 * B * h * w * c
+                print("dcn   %s C=%d %dx%d split form: %.3f ms  %.1f TFLOP/s-equivalent" % (prec, c, h, w, ms, fl / ms / 1e9))
+                if prec == "fp16":
+                    pd1 = ops.PackedDcn(wt, torch.zeros(c, device=DEV), 4, single=True)
+                    ms = timeit(lambda: ops.mdcn_forward_nhwc(x, om, pd1))
+                    print("dcn   %s C=%d %dx%d single pass: %.3f ms" % (prec, c, h, w, ms))
 
 
 def bench_dcnbwd():
