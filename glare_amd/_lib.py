@@ -78,6 +78,24 @@ class use_precision:
         _TLS.precision = self._prev
 
 
+def keeps_precision(cls):
+    """Class decorator for torch.autograd.Function subclasses: the backward runs under the precision the forward ran under.
+    The autograd engine calls `backward` from ITS OWN worker threads, where this module's thread-local precision is unset -- without
+    this an fp16 training step would run its backward kernels of the bf16 library on fp16 tensors."""
+    fwd, bwd = cls.forward, cls.backward
+
+    def forward(ctx, *args, **kw):
+        ctx._glare_precision = _current()
+        return fwd(ctx, *args, **kw)
+
+    def backward(ctx, *grads):
+        with use_precision(getattr(ctx, "_glare_precision", None)):
+            return bwd(ctx, *grads)
+
+    cls.forward, cls.backward = staticmethod(forward), staticmethod(backward)
+    return cls
+
+
 # entry points without any 16-bit tensor in their signature: under "fp16" they resolve to the main library
 _DTYPE_AGNOSTIC = ("glare_vq_", "glare_harness_", "glare_ssim_")
 

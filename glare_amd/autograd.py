@@ -52,6 +52,7 @@ def _data_grad(g16, weight, cout, stride, upsample, out_f32=False):
     return T.pool2_sum(dx) if upsample else dx
 
 
+@_lib.keeps_precision
 class Conv2dFn(torch.autograd.Function):
     """y = act(conv(x [, x2]) + bias) [+ residual]; x bf16 NHWC; weight OIHW fp32 (3x3 pad 1 / 1x1; stride 2 with the
     (0,1,0,1) padding; optional fused nearest x2 upsample of the input)."""
@@ -122,6 +123,7 @@ def conv2d(x, weight, bias=None, residual=None, x2=None, stride=1, upsample=Fals
     return Conv2dFn.apply(x, weight, bias, residual, x2, stride, upsample, act, out_f32)
 
 
+@_lib.keeps_precision
 class SmallConv2dFn(torch.autograd.Function):
     """Convs whose input has <= 4 channels (conv_in on the image, cond / color convs, quant convs): x fp32 read through
     element strides (NCHW image or NHWC latent)."""
@@ -161,6 +163,7 @@ def conv2d_small(x, weight, bias=None, layout="nhwc", act="none", out_f32=False)
     return SmallConv2dFn.apply(x, weight, bias, layout, act, out_f32)
 
 
+@_lib.keeps_precision
 class GroupNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, swish, eps):
@@ -196,6 +199,7 @@ def _use_fused_attention_backward(B, N):
     return B * ((N + 63) // 64) >= 160 or N > 8192
 
 
+@_lib.keeps_precision
 class AttentionFn(torch.autograd.Function):
     """softmax(q k^T) v with q already carrying scale*log2(e) (base-2 logits): q, k, v bf16 [B, N, 512]."""
 
@@ -221,6 +225,7 @@ def attention(q, k, v):
     return AttentionFn.apply(q, k, v)
 
 
+@_lib.keeps_precision
 class MixFn(torch.autograd.Function):
     """Mix.forward (deformableDecoder_arch.py:587-590): sigmoid(w) a + (1 - sigmoid(w)) b."""
 
@@ -240,6 +245,7 @@ def mix(a, b, w):
     return MixFn.apply(a, b, w)
 
 
+@_lib.keeps_precision
 class MeanRescaleFn(torch.autograd.Function):
     """h + x_w * (mean(h) / mean(x_w)) (deformableDecoder_arch.py:567); h bf16, x_w fp32."""
 
@@ -260,6 +266,7 @@ def mean_rescale(h, xw, whole_batch):
     return MeanRescaleFn.apply(h, xw, whole_batch)
 
 
+@_lib.keeps_precision
 class DcnFn(torch.autograd.Function):
     """DCNv2 (DCNv2Pack.forward, deformableDecoder_arch.py:141-152) on the NHWC path: x bf16 NHWC, om = conv_offset's
     output fp32 NHWC [B,H,W,3*dg*9] (offsets | mask logits; the chunk/cat of :146-147 is the identity on that order and
@@ -310,6 +317,7 @@ def dcn(x, om, weight, bias, dg, padding=1):
     return DcnFn.apply(x, om, weight, bias, dg, padding)
 
 
+@_lib.keeps_precision
 class L1ClampLossFn(torch.autograd.Function):
     """l1_loss of VQLLFLOWDModel.optimize_parameters (VQLLFLOWD_model.py:209-217) on the NHWC output."""
 
@@ -329,6 +337,7 @@ def l1_clamp_loss(rec, gt_nchw):
     return L1ClampLossFn.apply(rec, gt_nchw)
 
 
+@_lib.keeps_precision
 class Clamp01Fn(torch.autograd.Function):
     """sr = rec.clamp(0, 1); sr[isnan] = 0 (VQLLFLOWD_model.py:209-215)."""
 
@@ -348,6 +357,7 @@ def clamp01(x):
     return Clamp01Fn.apply(x)
 
 
+@_lib.keeps_precision
 class MaxPool2Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -365,6 +375,7 @@ def maxpool2(x):
     return MaxPool2Fn.apply(x)
 
 
+@_lib.keeps_precision
 class MseFn(torch.autograd.Function):
     """F.mse_loss(a, b) of bf16 feature maps; only `a` is differentiated."""
 
@@ -384,6 +395,7 @@ def mse_loss(a, b):
     return MseFn.apply(a, b)
 
 
+@_lib.keeps_precision
 class MSSSIMTermsFn(torch.autograd.Function):
     """The ten level scalars of msssim() (pytorch_msssim/__init__.py:71-83): (sim[5], cs[5]) of sr vs gt, NHWC fp32, value range
     1 (sr is clamped to [0, 1], so ssim()'s data-dependent `L` is 1).  Backward: gradients of the ten scalars -> d / d sr."""
@@ -419,6 +431,7 @@ def msssim_terms(x, y, windows):
     return MSSSIMTermsFn.apply(x, y, windows)
 
 
+@_lib.keeps_precision
 class NhwcToNchwFn(torch.autograd.Function):
     """fp32 NHWC -> fp32 NCHW at the module surface, differentiable (backward = the opposite layout kernel)."""
 
@@ -439,6 +452,7 @@ def to_nhwc_f32(x_nchw):
     return ops.nchw_to_nhwc(x_nchw, bf16=False)
 
 
+@_lib.keeps_precision
 class ForkFn(torch.autograd.Function):
     """A fan-out point of the tape made explicit: returns n aliases of x; the backward sums their gradients with
     glare_add_bf16, so the accumulation of activation gradients runs on this library, not on the autograd engine's add."""

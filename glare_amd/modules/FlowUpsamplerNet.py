@@ -18,7 +18,7 @@ MI355X design of the reverse (sampling) pass, decode():
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import _lib, ops
 from .. import train_ops as T
 from ._base import HipModule, to_nchw, to_nhwc
 from .flow import ActNorm2d, Conv2d, Conv2dZeros, InvertibleConv1x1
@@ -432,6 +432,7 @@ def _wt(w, pad_to=None):
     return ops.PackedConv(w, dgrad_pad=w.shape[0] if pad_to is None else pad_to)
 
 
+@_lib.keeps_precision
 class FlowNLLFn(torch.autograd.Function):
     """The whole normal-direction flow (FlowUpsamplerNet.encode, :228-274) + Gaussian term as one tape node: forward =
     FlowUpsamplerNet.encode_nhwc keeping every step's activations, backward = the adjoint sweep of csrc/flow_bwd.hip with
