@@ -17,12 +17,16 @@ python tools/rocpd_stats.py $(ls gpurun_out/prof_$tag/*/b_results.db gpurun_out/
   echo "# rocprofv3 --pmc SQ counters (two passes of 8), kbench kernels at B=8, $tag"
   for k in attn conv dcn; do echo "== $k"; bash tools/pmc_kernel.sh ${tag}_$k $k 2>&1 | grep -v "amdgpu.ids"; done
 } > gpurun_out/${tag}_pmc_kernels.txt
-python tools/kbench.py > gpurun_out/${tag}_kbench.txt 2>&1
-# end-to-end parity table: both precisions, both weight regimes, 400x600 (one ~30 s oracle run each) + two more seeds of the default
-for prec in bf16 fp16; do for reg in adversarial representative; do
-  python tools/parity_probe.py 400 600 11 $prec $reg 2>&1 | grep -v Warn | grep "==\|full path\|ORACLE\|latent_rel" 
-done; done > gpurun_out/${tag}_parity_table.txt 2>&1
-for seed in 12 13 14 15 16; do python tools/parity_probe.py 400 600 $seed fp16 representative 2>&1 | grep -v Warn | grep "==\|full path\|ORACLE\|latent_rel"; done >> gpurun_out/${tag}_parity_table.txt 2>&1
+python tools/kbench.py attn conv convsplit gn dcn vq wgrad attnbwd > gpurun_out/${tag}_kbench.txt 2>&1
+bash tools/pmc_shapes.sh $tag > /dev/null 2>&1          # per-SHAPE traffic of the conv / DCN launches -> ${tag}_pmc_shapes.json
+# end-to-end parity: 12 scenes of the default path (tools/parity_scenes.py), then the precision ladder on three of them -- round 3's
+# single-pass fp16 path (GLARE_FP32_CLASS=0) and bf16 -- and the single-pass DCN as an A/B
+{
+  python tools/parity_scenes.py 400 600 2>&1 | grep -v "Warn\|amdgpu.ids"
+  GLARE_DCN_SINGLE_PASS=1 python tools/parity_scenes.py 400 600 11 13 15 2>&1 | grep -v "Warn\|amdgpu.ids"
+  GLARE_FP32_CLASS=0 python tools/parity_scenes.py 400 600 11 13 15 2>&1 | grep -v "Warn\|amdgpu.ids"
+  PARITY_PRECISION=bf16 python tools/parity_scenes.py 400 600 11 13 15 2>&1 | grep -v "Warn\|amdgpu.ids"
+} > gpurun_out/${tag}_parity_table.txt 2>&1
 for st in stage2 stage3; do
   python tools/train_bench.py $st 20 graph > gpurun_out/${tag}_train_${st}_graph.txt 2>&1
   python tools/train_bench.py $st 10 > gpurun_out/${tag}_train_$st.txt 2>&1

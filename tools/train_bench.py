@@ -18,14 +18,15 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 graph = len(sys.argv) > 3 and sys.argv[3] == "graph"
 flops = len(sys.argv) > 3 and sys.argv[3] == "flops"
 dev = torch.device("cuda", 0)
+PREC = os.environ.get("TRAIN_PRECISION", "bf16")      # "fp16": the reference's AMP form (loss scaling on the device)
 g = torch.Generator().manual_seed(10)
 net_hq = seeded_init_(M.VQModel().eval(), 1).to(dev)
 if which == "stage2":
     B, S = 2, 320
-    tr = Stage2Trainer(seeded_init_(M.LLFlowVQGAN2().train(), 2).to(dev), net_hq, device_state=graph)
+    tr = Stage2Trainer(seeded_init_(M.LLFlowVQGAN2().train(), 2).to(dev), net_hq, device_state=graph, precision=PREC)
 else:
     B, S = 1, 256
-    tr = Stage3Trainer(seeded_init_(M.VQLLFLOWDeformable().train(), 0).to(dev), net_hq, device_state=graph)
+    tr = Stage3Trainer(seeded_init_(M.VQLLFLOWDeformable().train(), 0).to(dev), net_hq, device_state=graph, precision=PREC)
 gt = torch.rand(B, 3, S, S, generator=g).to(dev)
 lr = (torch.randn(B, 3, S, S, generator=g) * 0.5 - 1.0).to(dev)
 if graph:
@@ -38,8 +39,8 @@ for _ in range(steps):
     loss = tr.step_tensor(gt, lr)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
-print("%s%s: B=%d %dx%d  %.1f ms/step  %.2f samples/s  loss %.4f  peak mem %.2f GB"
-      % (which, " (hipGraph replay)" if graph else "", B, S, S, dt * 1e3, B / dt, float(loss), torch.cuda.max_memory_allocated() / 2**30))
+print("%s%s [%s]: B=%d %dx%d  %.1f ms/step  %.2f samples/s  loss %.4f  peak mem %.2f GB"
+      % (which, " (hipGraph replay)" if graph else "", PREC, B, S, S, dt * 1e3, B / dt, float(loss), torch.cuda.max_memory_allocated() / 2**30))
 if flops:
     from glare_amd import ops
     ops.FLOP_COUNTER = {}
