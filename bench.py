@@ -327,6 +327,8 @@ def main():
                          "the precision the end-to-end tolerance is met in; libglare_hip_f16.so) or bf16 (libglare_hip.so, +2.7 %% "
                          "images/s, 8x the rounding per stored tensor).  The JSON line's `dtype` names what ran")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-streams2", action="store_true", help="skip the extra two-stream region behind the timed one (`value_streams2`): "
+                                                               "what a rocprofv3 kernel trace of this command should see is single-stream launches only")
     ap.add_argument("--no-train", action="store_true", help="skip the `train` block (stage-2 / stage-3 ms per step, measured after "
                                                             "the inference region)")
     ap.add_argument("--breakdown", action="store_true", help="per-stage timing on stderr")
@@ -417,7 +419,7 @@ def main():
     dt = max_over_ranks(dt, dist, device)
 
     value_streams2 = None
-    if world == 1 and args.streams == 1 and not STUB:
+    if world == 1 and args.streams == 1 and not STUB and not args.no_streams2:
         # the same K steps once more with consecutive batches on TWO HIP streams (what glare_amd.infer does): the tail of one batch's
         # kernels and its latency-bound flow section run under the next batch's convs.  Reported beside `value`, never as `value`:
         # a launch that shares the GPU has no per-launch duration for the roofline, which is measured in the single-stream region.

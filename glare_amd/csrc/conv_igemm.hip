@@ -355,6 +355,10 @@ extern "C" int glare_conv2d_bf16(const glare_conv_desc* d, glare_stream_t stream
     p.g_w_elems = glare_conv2d_packed_weight_elems_tile(d->Cout, p.CinTot, d->ksize, d->cout_tile);
     if (d->in2 && d->in2_off + (long long)(p.groups - 1) * d->group_in_step + d->Cin2 > d->in2_pitch) return GLARE_ERR_INVALID;
   }
+  p.gn_coef = d->gn_coef; p.gn_swish = d->gn_swish;
+  if (p.gn_coef && (d->ksize != 3 || d->stride != 1 || d->in2 || p.k_wrap || d->upsample || p.groups > 1 || p.out_lo || d->in_off != 0 ||
+                    d->Cin > 512))
+    return GLARE_ERR_UNSUPPORTED;
   if (p.res_lo && !(p.res && p.out_lo)) return GLARE_ERR_INVALID;
   // 16-B records everywhere -> LDS-staged epilogue
   p.fast_epilogue = (d->out_mode == GLARE_OUT_NHWC_BF16) && !(p.Cout % 8) && !(p.opitch % 8) && !(p.ooff % 8) &&

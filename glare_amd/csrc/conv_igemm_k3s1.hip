@@ -4,6 +4,7 @@
 
 int glare_conv_launch_k3s1(const ConvParams& p, int tn, bool hilo, hipStream_t stream) {
   if (hilo) return (tn == 128 && !CONV_TILE16) ? launch<3, 1, 4, 2, 2, 2, 1, true>(p, stream) : GLARE_ERR_UNSUPPORTED;
+  if (p.gn_coef) return (tn == 128 && !CONV_TILE16) ? launch<3, 1, 4, 2, 2, 2, 1, false, true>(p, stream) : GLARE_ERR_UNSUPPORTED;
   if (tn == 128) {
     if (3 == 3 && 1 == 1 && CONV_TILE16) return launch<3, 1, 4, 2, 4, 2, 1>(p, stream);   /* 16 x 32 px, 8 waves */
     /* a 12 x 32 px tile on 6 waves (fewer weight DMAs per MFMA) measured 20-25 % SLOWER: 6 waves map 2,2,1,1 onto the 4 SIMDs and */

@@ -46,6 +46,8 @@ struct ConvParams {
   int groups, g_in_step, g_out_step, g_bias_step;
   long long g_w_elems;
   int k_wrap;            // K segments [in0 | in1 | in0 again]: the fp32-class contraction on hi / lo operand pairs (glare_conv_desc.k_wrap)
+  const float* gn_coef;  // GNP instantiations: [B][Cin0][2] = (a, d) of the input's GroupNorm, applied to the halo tile in LDS
+  int gn_swish;
 };
 
 // kernel-family dispatchers, one per translation unit: tn = the output-channel tile (128 / 64 / 32); hilo = the hi / lo epilogue
@@ -97,6 +99,23 @@ __device__ __forceinline__ void with_act(int act, F&& f) {
 }
 
 
+// One 16-B piece (8 channels of one halo position) of the GNP prologue, in place in LDS.
+__device__ __forceinline__ void gn_prologue_piece(u32x4* slot, const float* cf, int swish) {
+  __builtin_amdgcn_sched_barrier(0);       // nothing of the MFMA loop is scheduled into the transform, and vice versa
+  u32x4 v = *slot;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const f32x4 q = *reinterpret_cast<const f32x4*>(cf + 4 * e);     // (a, d, a, d) of two channels
+    float lo = alo(v[e]) * q[0] + q[1];
+    float hi = ahi(v[e]) * q[2] + q[3];
+    if (swish) { lo = swishf_(lo); hi = swishf_(hi); }
+    v[e] = pack_a2(lo, hi);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  *slot = v;
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // KS kernel size, STRIDE, MT/NT 32x32 MFMA tiles per wave along pixel rows / couts,
 // WM x WN waves (WM*MT == 8 rows), KSTEPS 16-channel k-steps per input stage.
 //
@@ -104,7 +123,13 @@ __device__ __forceinline__ void with_act(int act, F&& f) {
 // "B stages" (one tap row each: KS taps x KSTEPS k-steps of weights).  Both images are
 // double-buffered in LDS and filled by LDS-DMA (global_load_lds_dwordx4), issued one B stage
 // ahead, right after the barrier that retires the buffer they overwrite; one barrier per B stage.
-template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int KSTEPS, bool HILO = false>
+// GNP (round 4): GroupNorm (+ swish) of the INPUT applied by the loader.  The halo tile reaches LDS raw by DMA as
+// always; every thread then rewrites THE PIECES IT ISSUED ITSELF in place -- y = round16(swish(a x + d)), (a, d) per (image, channel)
+// from a table in LDS -- behind its own `s_waitcnt vmcnt(0)` and in front of the stage barrier that is there anyway: no extra barrier
+// per stage, no cross-wave dependency, and the stage being transformed (chunk c + 1, landed during tap row 0 of chunk c) is not the
+// one the MFMAs read.  Padding positions (out-of-range DMA offsets = zeros) are skipped: zero padding stays zero, as the reference
+// pads the NORMALISED tensor.  The arithmetic is gn_apply_kernel's, term for term: the result is bit-identical to conv(gn_apply(x)).
+template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int KSTEPS, bool HILO = false, bool GNP = false>
 __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 2)) void conv_igemm_kernel(const ConvParams p_in) {
   ConvParams p = p_in;
   if (p.groups > 1) {               // uniform (scalar) adjustments: this workgroup's group
@@ -263,6 +288,30 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
     }
   };
 
+  [[maybe_unused]] float* lC = reinterpret_cast<float*>(lB + 2 * B_CHUNKS);   // GNP: (a, d) of this image's Cin0 channels
+  [[maybe_unused]] auto gn_transform = [&](int chunk, int buf) {
+    if constexpr (GNP) {
+      const int c0 = chunk * KC;
+#pragma unroll
+      for (int i = 0; i < A_PER_W; ++i) {
+        const int j = wave + NW * i;
+        if (j < A_INSTR && a_vo0[i] != A_OOB && c0 + a_ck[i] < p.Cin0) {
+          // the addresses are formed HERE, from a value the compiler cannot see through: hoisted out of the K loop as invariants
+          // (nine more live registers in a kernel that has none) they put a scratch store + load next to every MFMA -- 4.8 ms
+          // for a 0.6 ms conv, measured
+          int ln = lane, ck = a_ck[i];
+          asm volatile("" : "+v"(ln), "+v"(ck));
+          gn_prologue_piece(lA + buf * A_SLOTS + j * 64 + ln, lC + (c0 + ck) * 2, p.gn_swish);
+        }
+      }
+    }
+  };
+  if constexpr (GNP) {
+    const float* src = p.gn_coef + (size_t)b * p.Cin0 * 2;
+    for (int i = tid; i < p.Cin0 * 2; i += 64 * NW) lC[i] = src[i];
+    __syncthreads();
+  }
+
   const int khalf = lane >> 5, px = lane & 31;
   const int n_bstages = p.n_stages * KS;
   issue_a(0, 0);
@@ -274,6 +323,10 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
     for (int trow = 0; trow < KS; ++trow, ++bs) {
 #ifndef CONV_ABLATE_NOBARRIER  // timing ablations only (tools/ablate.sh): wrong results
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
+      if constexpr (GNP) {                               // ... and are normalised in place before anybody reads them
+        if (trow == 0 && chunk == 0) gn_transform(0, 0);
+        if (trow == 1 && chunk + 1 < p.n_stages) gn_transform(chunk + 1, (chunk + 1) & 1);
+      }
       __syncthreads();                                   // ... and everybody else's; stage bs-1 retired
 #endif
       // The next stage's DMA pieces are not issued in one burst behind the barrier (12 waves would queue 47 pieces on the
@@ -648,7 +701,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
   });
 }
 
-template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int KSTEPS, bool HILO = false>
+template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int KSTEPS, bool HILO = false, bool GNP = false>
 int launch(const ConvParams& p_in, hipStream_t stream) {
   using G = TileGeom<KS, STRIDE, WM * MT>;
   constexpr int TN = WN * NT * 32;
@@ -659,8 +712,8 @@ int launch(const ConvParams& p_in, hipStream_t stream) {
   p.n_blocks = (int)nb;
   p.gn_nparts = p.tiles_x * cdiv(p.OH, 8) * 2 * (KS == 2 ? 4 : 1);  // the 8 x 32 grid, 2 wave rows (4 rows each) per block
   if (p.gn_part && !(p.fast_epilogue && p.Cout % 32 == 0)) return GLARE_ERR_UNSUPPORTED;
-  const size_t lds = (size_t)(2 * (((KSTEPS * 2 * G::NPOS + 63) / 64) * 64) + 2 * KS * KSTEPS * 2 * TN) * 16;
-  auto kern = conv_igemm_kernel<KS, STRIDE, MT, NT, WM, WN, KSTEPS, HILO>;
+  const size_t lds = (size_t)(2 * (((KSTEPS * 2 * G::NPOS + 63) / 64) * 64) + 2 * KS * KSTEPS * 2 * TN) * 16 + (GNP ? (size_t)p.Cin0 * 8 : 0);
+  auto kern = conv_igemm_kernel<KS, STRIDE, MT, NT, WM, WN, KSTEPS, HILO, GNP>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GLARE_ERR_LAUNCH;

@@ -369,6 +369,43 @@ extern "C" int glare_groupnorm_hilo_pair_bf16(const void* x_hi, const void* x_lo
   return glare_launch_status();
 }
 
+// GroupNorm as a PROLOGUE of the consuming conv (conv_igemm_kernel<.., GNP>, round 4): per (image, channel) the pair
+// (a, d) with y = swish(a x + d), computed exactly as gn_apply_kernel computes them (fp64 combine of the partial blocks, then
+// a = rstd * gamma, d = beta - mean * a in fp32) -- the conv's loader applies them to its halo tile in LDS and the normalised tensor
+// is never written.  out: fp32 [B][C][2].
+__global__ __launch_bounds__(256) void gn_coeffs_kernel(const float* __restrict__ partial, int splits, long long HW, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps, float* __restrict__ out, int C) {
+  __shared__ float mean_s[GN_GROUPS], rstd_s[GN_GROUPS];
+  const int b = blockIdx.x, cpg = C / GN_GROUPS;
+  if (threadIdx.x < GN_GROUPS) {
+    double s = 0.0, q = 0.0;
+    for (int i = 0; i < splits; ++i) {
+      s += partial[((size_t)b * splits + i) * GN_GROUPS * 2 + threadIdx.x * 2];
+      q += partial[((size_t)b * splits + i) * GN_GROUPS * 2 + threadIdx.x * 2 + 1];
+    }
+    const double n = (double)HW * cpg;
+    const double m = s / n;
+    double var = q / n - m * m;
+    if (var < 0.0) var = 0.0;
+    mean_s[threadIdx.x] = (float)m;
+    rstd_s[threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int g = c / cpg;
+    const float a = rstd_s[g] * gamma[c];
+    out[((size_t)b * C + c) * 2] = a;
+    out[((size_t)b * C + c) * 2 + 1] = beta[c] - mean_s[g] * a;
+  }
+}
+
+extern "C" int glare_groupnorm_coeffs_f32(const float* stats, int splits, int B, long long HW, int C, const float* gamma, const float* beta,
+                                          float eps, float* coef_out, glare_stream_t stream) {
+  if (!stats || !gamma || !beta || !coef_out || splits <= 0 || B <= 0 || HW <= 0 || C <= 0 || C % GN_GROUPS || C > 2048) return GLARE_ERR_INVALID;
+  hipLaunchKernelGGL(gn_coeffs_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, stats, splits, HW, gamma, beta, eps, coef_out, C);
+  return glare_launch_status();
+}
+
 // stats: the [B][splits][32][2] (sum, sum of squares) block of the tensor's GroupNorm (from a conv's fused statistics or
 // glare_add_groupnorm_stats_bf16); wq / wo: fp32 [C][C] row-major (out, in), bq / bo fp32 [C]; outputs bf16 [B][C][C] and fp32 [B][C]
 // for glare_conv1x1_ws_image_bf16.  C a multiple of 32, <= 2048.

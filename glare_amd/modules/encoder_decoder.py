@@ -52,6 +52,11 @@ HILO_STREAM = os.environ.get("GLARE_HILO_STREAM", "1") != "0"
 # codebook search needs the latent to ~1e-4, which 11-bit MFMA operands miss 20-fold.  GLARE_FP32_CLASS=0:
 # round 3's single-pass convs (A/B measurements).
 FP32_CLASS = os.environ.get("GLARE_FP32_CLASS", "1") != "0"
+# GroupNorm + swish in front of a ResnetBlock's 3x3 convs as the conv loader's PROLOGUE (glare_conv_desc.gn_coef; bit-identical to the
+# separate apply pass).  Measured (tools/kbench.py gnpro, profiles/r04_gn_prologue.txt): -2 % on apply + conv at 128 channels, full
+# resolution; +12 % / +20 % at 256 / 512 channels, where 2 / 4 output-channel tiles repeat the transform -- the in-LDS transform sits
+# on each wave's critical path and costs half of the HBM pass it removes.  OFF by default (GLARE_GN_PROLOGUE=1: the <= 128-channel blocks).
+GN_PROLOGUE = os.environ.get("GLARE_GN_PROLOGUE", "0") == "1"
 SUBPIXEL_UPSAMPLE = True
 FOLD_PROJ_INTO_V = True
 # AttnBlock as attention with shared keys / values (csrc/attn.hip, attn_kv_fwd_kernel): the key projection folded into the
@@ -127,7 +132,15 @@ class ResnetBlock(HipModule):
             h = gn_swish(h, self.norm2, pair=True)
             res = x if self.in_channels == self.out_channels else ops.conv2d(x, packed_conv(self, self.nin_shortcut, split=3), hilo=True)
             return ops.conv2d(h, packed_conv(self, self.conv2, split=3), residual=res, gn_stats=fuse, hilo=True)
-        h = ops.conv2d(gn_swish(x, self.norm1), packed_conv(self, self.conv1), gn_stats=fuse)  # stats for norm2
+        if GN_PROLOGUE and not hl and self.in_channels <= 128 and getattr(x, "_gn_stats", None) is not None:
+            coef = lambda t, n: ops.groupnorm_coeffs(t, n.weight.detach().float(), n.bias.detach().float(), n.eps)
+            h = ops.conv2d(x, packed_conv(self, self.conv1), gn_stats=fuse, gn_prologue=(coef(x, self.norm1), True))
+            if fuse and self.out_channels <= 128 and out is None:
+                return ops.conv2d(h, packed_conv(self, self.conv2), gn_prologue=(coef(h, self.norm2), True),
+                                  residual=x if self.in_channels == self.out_channels else ops.conv2d(x, packed_conv(self, self.nin_shortcut)),
+                                  gn_stats=fuse)
+        else:
+            h = ops.conv2d(gn_swish(x, self.norm1), packed_conv(self, self.conv1), gn_stats=fuse)  # stats for norm2
         h = gn_swish(h, self.norm2)
         res = x if self.in_channels == self.out_channels else ops.conv2d(x, packed_conv(self, self.nin_shortcut), hilo=hl)
         # the block output feeds the next block's / attention's norm: its statistics ride along too

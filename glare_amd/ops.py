@@ -44,7 +44,8 @@ class ConvDesc(ctypes.Structure):
                 ("ksize", _i), ("stride", _i), ("upsample", _i), ("act", _i), ("out_mode", _i),
                 ("plane_pitch", _ll), ("gn_partial", ctypes.c_void_p), ("cout_tile", _i),
                 ("residual_lo", ctypes.c_void_p), ("out_lo", ctypes.c_void_p),
-                ("groups", _i), ("group_in_step", _i), ("group_out_step", _i), ("k_wrap", _i)]
+                ("groups", _i), ("group_in_step", _i), ("group_out_step", _i), ("k_wrap", _i),
+                ("gn_coef", ctypes.c_void_p), ("gn_swish", _i)]
 
 
 def split_filter(w, split):
@@ -434,7 +435,8 @@ def conv2d_grouped(x, pcs, *, cin, in_step, out, out_step, in_off=0, out_off=0, 
 
 
 def conv2d(x, pc, *, x2=None, cin=None, in_off=0, cin2=None, in2_off=0, stride=1, upsample=False, act="none",
-           residual=None, res_off=0, out=None, out_off=0, out_mode=OUT_NHWC_BF16, plane_pitch=0, gn_stats=False, hilo=False):
+           residual=None, res_off=0, out=None, out_off=0, out_mode=OUT_NHWC_BF16, plane_pitch=0, gn_stats=False, hilo=False,
+           gn_prologue=None):
     """x: NHWC bf16 [B,H,W,pitch] (channels [in_off, in_off+cin) are used), optional x2 concatenated
     after it.  Returns (or fills `out`) per out_mode; planar outputs are [B, planes, plane_pitch].
     hilo: the output keeps 22 mantissa bits as a hi / lo pair -- the returned tensor is `hi` (what every consumer reads), its
@@ -520,6 +522,11 @@ def conv2d(x, pc, *, x2=None, cin=None, in_off=0, cin2=None, in2_off=0, stride=1
         if rlo is not None:
             assert rlo.shape == residual.shape and rlo.dtype == residual.dtype and rlo.is_contiguous()
             d.residual_lo = rlo.data_ptr()
+    if gn_prologue is not None:      # (coef fp32 [B, Cin, 2], swish): GroupNorm of `x` applied by the loader (groupnorm_coeffs)
+        coef, swish = gn_prologue
+        assert coef.dtype == torch.float32 and coef.is_contiguous() and tuple(coef.shape) == (B, cin, 2)
+        assert pc.ksize == 3 and stride == 1 and x2 is None and not upsample and not split and not hilo and in_off == 0
+        d.gn_coef, d.gn_swish = coef.data_ptr(), int(bool(swish))
     subpixel = getattr(pc, "subpixel", False)
     assert not subpixel or upsample, "a sub-pixel packed filter only implements the upsample conv"
     d.ksize, d.stride, d.upsample, d.act, d.out_mode = pc.ksize, stride, (2 if subpixel else int(bool(upsample))), ACT[act], out_mode
@@ -638,6 +645,20 @@ def groupnorm(x, gamma, beta, swish=True, eps=1e-6, cin=None, in_off=0, pair=Fal
                                          _i(C), _f(eps), _i(int(swish)), ptr(ws), _sz(ws.numel()), stream_handle()),
           "glare_groupnorm_swish_bf16")
     return y
+
+
+def groupnorm_coeffs(x, gamma, beta, eps=1e-6):
+    """The (a, d) pairs of GroupNorm(32) of x -- y = act(a x + d) per (image, channel) -- from the fused statistics the producing
+    conv left on x (`x._gn_stats`): fp32 [B, C, 2] for conv2d(..., gn_prologue=(coef, swish)), which then normalises x inside its
+    loader instead of reading a normalised copy (glare_conv_desc.gn_coef)."""
+    require_cuda(x, gamma, beta)
+    stats = getattr(x, "_gn_stats", None)
+    assert stats is not None, "groupnorm_coeffs needs the producer's fused statistics on x"
+    B, H, W, C = x.shape
+    coef = torch.empty(B, C, 2, dtype=torch.float32, device=x.device)
+    check(_lib.lib().glare_groupnorm_coeffs_f32(ptr(stats), _i(int(stats.shape[1])), _i(B), _ll(H * W), _i(C), ptr(gamma), ptr(beta),
+                                                _f(eps), ptr(coef), stream_handle()), "glare_groupnorm_coeffs_f32")
+    return coef
 
 
 def split_hilo(x32):

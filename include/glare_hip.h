@@ -127,6 +127,13 @@ typedef struct glare_conv_desc {
    * 32-channel (1x1) stage.  Grouped launches shift both sources by group_in_step.  Where the reference contracts in fp32 and the
    * codebook search downstream needs it (the conditional encoder and the flow's nets under the fp16 inference precision). */
   int k_wrap;
+  /* ---- GroupNorm (+ swish) of the INPUT as the loader's prologue (round 4; NULL = none): gn_coef = fp32 [B][Cin][2] from
+   * glare_groupnorm_coeffs_f32, (a, d) per (image, channel); the kernel applies y = swish(a x + d) (gn_swish != 0) or y = a x + d,
+   * rounded to 16 bits exactly as glare_groupnorm_apply_bf16 would have stored it, to its halo tile in LDS -- zero padding stays zero --
+   * so `in` is the RAW tensor and the normalised one is never written (encoder_decoder.py:119-120,126-127: Normalize + swish in front
+   * of conv1 / conv2).  3x3 stride 1, one source, 128-wide tile, single pass only. */
+  const float* gn_coef;
+  int gn_swish;
 } glare_conv_desc;
 
 /* The output-channel tile (128, 64 or 32) that gives a B x OH x OW x cout conv enough workgroups (8 x 32 output pixels each). */
@@ -211,6 +218,9 @@ size_t glare_groupnorm_workspace_bytes(int B, long long HW);
  * proj_out has been folded into v, fused with the statistics pass of the norm that consumes the block's output. */
 int glare_add_groupnorm_stats_bf16(const void* a, const void* b, void* out, int B, long long HW, int C, void* stats,
                                    size_t stats_bytes, glare_stream_t stream);
+/* The (a, d) pairs of y = act(a x + d) per (image, channel), fp32 [B][C][2], from the statistics block: for glare_conv_desc.gn_coef. */
+int glare_groupnorm_coeffs_f32(const float* stats, int splits, int B, long long HW, int C, const float* gamma, const float* beta,
+                               float eps, float* coef_out, glare_stream_t stream);
 int glare_groupnorm_apply_bf16(const void* x, int in_pitch, int in_off, const float* gamma, const float* beta, void* y,
                                int B, long long HW, int C, float eps, int swish, const float* stats, int splits,
                                glare_stream_t stream);

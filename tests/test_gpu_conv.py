@@ -439,3 +439,24 @@ def test_grouped_launch_gives_the_bits_of_the_per_group_launches(k, cout, out_st
     # refusals: channel slices past the pitch; fusions the grouped launch does not carry
     with pytest.raises(RuntimeError):
         ops.conv2d_grouped(x, pcs, cin=cin, in_step=cin, in_off=8, out=one, out_step=out_step, out_mode=mode)
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("B,C,Co,H,W,swish", [(2, 128, 128, 19, 45, True), (1, 256, 256, 9, 33, True), (1, 128, 256, 8, 32, False)])
+def test_groupnorm_prologue_is_bit_identical_to_the_separate_pass(prec, B, C, Co, H, W, swish):
+    """glare_conv_desc.gn_coef: GroupNorm (+ swish) applied to the halo tile in LDS by the conv's loader == conv(groupnorm(x)) bit for
+    bit (same fp32 terms, same 16-bit rounding; zero padding stays zero), incl. ragged tile edges."""
+    g = torch.Generator().manual_seed(B * 100 + C + H)
+    with ops.use_precision(prec):
+        x0 = (_rand((B, H, W, C), g) * 2.0 + 0.3).to(ops.act_dtype()).cuda()
+        w0 = _rand((C, C, 3, 3), g, 0.03).cuda()
+        x = ops.conv2d(x0, ops.PackedConv(w0, None), gn_stats=True)            # a producer that leaves fused statistics
+        gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), (_rand((C,), g, 0.2)).cuda()
+        w = _rand((Co, C, 3, 3), g, 0.03).cuda()
+        b = _rand((Co,), g, 0.1).cuda()
+        pc = ops.PackedConv(w, b)
+        ref = ops.conv2d(ops.groupnorm(x, gamma, beta, swish=swish), pc, gn_stats=True)
+        got = ops.conv2d(x, pc, gn_prologue=(ops.groupnorm_coeffs(x, gamma, beta), swish), gn_stats=True)
+    assert torch.equal(got, ref)
+    assert torch.equal(got._gn_stats, ref._gn_stats)
+

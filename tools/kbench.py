@@ -106,6 +106,24 @@ def bench_convsplit():
             print("conv3 %-22s: single pass, 16-bit out %.3f ms  %.0f TFLOP/s" % (name, ms1, fl / ms1 / 1e9))
 
 
+def bench_gnpro():
+    """GroupNorm + swish as the conv's loader prologue (glare_conv_desc.gn_coef) against the separate apply pass + conv, fp16."""
+    with ops.use_precision("fp16"):
+        for name, c, h, w in (("128->128 3x3 @full", 128, 420, 620), ("256->256 3x3 @half", 256, 210, 310), ("512->512 3x3 @q", 512, 105, 155)):
+            x0 = torch.randn(B, h, w, c, device=DEV).half()
+            x = ops.conv2d(x0, ops.PackedConv(torch.randn(c, c, 3, 3, device=DEV) * 0.02, None), gn_stats=True)
+            g, b = torch.ones(c, device=DEV), torch.zeros(c, device=DEV)
+            pc = ops.PackedConv(torch.randn(c, c, 3, 3, device=DEV) * 0.02, torch.zeros(c, device=DEV))
+            out = torch.empty(B, h, w, c, dtype=torch.float16, device=DEV)
+            t_gn = timeit(lambda: ops.groupnorm(x, g, b, swish=True))
+            y = ops.groupnorm(x, g, b, swish=True)
+            t_conv = timeit(lambda: ops.conv2d(y, pc, out=out))
+            t_sep = timeit(lambda: ops.conv2d(ops.groupnorm(x, g, b, swish=True), pc, out=out))
+            t_pro = timeit(lambda: ops.conv2d(x, pc, out=out, gn_prologue=(ops.groupnorm_coeffs(x, g, b), True)))
+            print("gnpro %-20s: apply %.3f + conv %.3f = separate %.3f ms | prologue form %.3f ms (%+.1f %%)"
+                  % (name, t_gn, t_conv, t_sep, t_pro, 100.0 * (t_pro - t_sep) / t_sep))
+
+
 def bench_gn():
     for c, h, w in ((128, 420, 620), (256, 210, 310), (512, 105, 155)):
         x = torch.randn(B, h, w, c, device=DEV).to(torch.bfloat16)
