@@ -261,9 +261,14 @@ def _offset_conv(conv, x):
     ops.require_cuda(x)
     k, st, pd, dl = conv.kernel_size, conv.stride, conv.padding, conv.dilation
     taped = torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad)   # the DCN form below carries the tape
+    kc = 16 if k[0] == 3 else 32       # the implicit-GEMM kernel's channel stage: a K segment of the fp32-class form is whole stages
     if (not taped and k[0] == k[1] and k[0] in (1, 3) and st == (1, 1) and dl == (1, 1) and pd == (k[0] // 2, k[0] // 2) and conv.groups == 1
-            and conv.in_channels % 8 == 0):
-        y = ops.conv2d(ops.nchw_to_nhwc(x.float()), ops.PackedConv(conv.weight, conv.bias), out_mode=ops.OUT_NHWC_F32)
+            and conv.in_channels % kc == 0):
+        # the reference's conv_offset is an fp32 nn.Conv2d (deform_conv.py:357-364): the fp32-class form of the MFMA conv -- activation and
+        # filter as hi / lo pairs, three K segments (glare_conv_desc.k_wrap) -- so that this op-level API returns the same offsets /
+        # masks (to ~1e-6) with and without a tape (the single-pass 16-bit conv differed from the taped path by ~1e-2)
+        xp = ops.split_hilo(ops.nchw_to_nhwc(x.float(), bf16=False))
+        y = ops.conv2d(xp, ops.PackedConv(conv.weight, conv.bias, split=3), out_mode=ops.OUT_NHWC_F32)
         return ops.nhwc_to_nchw(y)
     if st[0] != st[1] or pd[0] != pd[1] or dl[0] != dl[1]:
         raise NotImplementedError("conv_offset with different vertical / horizontal stride, padding or dilation")

@@ -393,13 +393,30 @@ class GraphedStep:
         # the mean = gt branch exists only when it can be drawn (train_gt_ratio > 0: 0.2 in confs/train_stage2_LOL.yml, 0 in LOL.yml)
         both = self.branching and float(getattr(self.trainer.netG, "train_gt_ratio", 0.0)) > 0.0
         flags = (False, True) if both else (False,)
+        # The warm-up runs REAL steps (allocator pools, lazy folds, the PackCache's job table must exist before the capture), on the
+        # batch cloned at construction: the training state is snapshotted around it and put back, so that capturing -- at construction
+        # or again after `resume_training` / a weight load -- never advances the optimisation (it used to apply
+        # warmup x branches Adam updates on a stale batch and move the step counter and the scaler's tracker).  Only a FRESH flow's
+        # ActNorm initialisation (a property of the first training forward, FlowActNorms.py:82-83) deliberately survives.
+        opt = self.trainer.opt
+        snap = [(t, t.clone()) for g in opt.groups for t in (g.w, g.m, g.v)]
+        snap += [(t, t.clone()) for t in (opt.step_dev, opt.state3, opt.scale, opt.growth_tracker)]
+        actnorms = [m for m in self.trainer.netG.modules() if hasattr(m, "inited") and hasattr(m, "logs")]
+        # "fresh" as FlowActNorms.py:36-38 defines it: not yet initialised AND still all-zero (a seeded / loaded ActNorm is only marked)
+        fresh = {id(m) for m in actnorms if not m.inited and not bool((m.bias != 0).any())}
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(self.warmup):            # allocator / lazy-init warm-up outside the capture, every branch
                 for f in flags:
                     self._eager(f)
+            keep = [(t, t.clone()) for m in actnorms if id(m) in fresh for t in (m.bias.data, m.logs.data)]
+            for t, v in snap:
+                t.copy_(v)
+            for t, v in keep:                       # the parameters live inside the restored flat buffers: put the initialisation back
+                t.copy_(v)
         torch.cuda.current_stream().wait_stream(side)
+        self._invalidate()
         for f in flags:
             self._capture(f)
 

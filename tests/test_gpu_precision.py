@@ -150,10 +150,12 @@ def test_fp16_elementwise_and_dcn():
         got = ops.mdcn_forward_nhwc(x.to(torch.float16).cuda(), om, pd)
         ref = ops.mdcn_forward_nhwc(h16(x).cuda(), om, pd)
         assert rel(got, ref) < 2e-4, rel(got, ref)
-    with pytest.raises(Exception):   # training kernels are not part of the half library: loud, never a silent bf16 kernel on fp16 data
-        with ops.use_precision("fp16"):
-            from glare_amd import _lib
-            _lib.lib().glare_adam_step_f32
+    from glare_amd import _lib
+
+    with ops.use_precision("fp16"):   # since round 4 the half library is a build of every source: the training entry points resolve there
+        assert _lib.lib().glare_adam_step_f32 is not None and _lib.lib().glare_gemm_nt_bf16 is not None
+        with pytest.raises(_lib.GlareError):   # ... and a name it does not have is loud, never a silent bf16 kernel on fp16 data
+            _lib.lib().glare_no_such_entry_bf16
 
 
 # ---- graph level -------------------------------------------------------------------------------------------------------
@@ -344,6 +346,33 @@ def test_end_to_end_full_size_twelve_scenes(capsys):
         within(1.0 - agree, 1.5e-3, seed)          # measured max 7.4e-4 (12 tokens)
         assert psnr >= 54.2, (seed, psnr)          # measured min 57.22 dB
         within(delta, 0.01, seed)                  # measured max 0.0044 dB; BASELINE: 0.05
+
+
+def test_end_to_end_batch_of_8_against_eight_oracle_runs(capsys):
+    """BASELINE configs[1] is a batch of 8: the product's ONE batched launch sequence (default launch configuration: keys not split
+    at this size, as at 400x600 x 8) against the oracle run image by image, per image (100x156: eight 2 s oracle runs).  VERDICT r03:
+    until now "config I8 vs oracle" was an inference from B = 1 comparisons plus the batch-invariance test."""
+    og, ov, pg, pv, lr, ref = setup("representative", 100, 156, 21)
+    lows = synthetic_pair(8, 100, 156, seed=51)[0]
+    lrs = [O.preprocess(im) for im in lows]
+    with torch.no_grad():
+        r8 = pg.reverse_flow_nhwc(pv, torch.cat(lrs).cuda())
+        refs = [og.stages(ov, x) for x in lrs]
+    rows = []
+    for i, rf in enumerate(refs):
+        agree = float((r8["indices"].view(8, -1)[i].cpu() == rf["indices"].view(-1)).float().mean())
+        m = e2e_metrics(r8["out"][i:i + 1].cpu(), rf["out"], 100)
+        lat = float(rel(ops.nhwc_to_nchw(r8["latent"][i:i + 1]).cpu(), rf["latent"]))
+        rows.append((i, lat, agree, m["psnr_vs_oracle"], m["delta"]))
+    with capsys.disabled():
+        for row in rows:
+            print("\n[e2e batch of 8, image %d] latent rel %.2e | index agreement %.5f | PSNR(ours,oracle) %.2f dB | |dPSNR vs GT| %.4f dB" % row, end="")
+        print()
+    for i, lat, agree, psnr, delta in rows:
+        within(lat, 3.8e-5, i)             # measured 1.5-1.9e-5
+        within(1.0 - agree, 3.1e-3, i)     # measured: five of the eight images with EVERY index equal, the others 1-2 of 1 320 tokens
+        assert psnr >= 52.0, (i, psnr)     # measured 55-66 dB (a single flipped token moves a 100x156 image by ~8 dB of PSNR(ours, oracle))
+        within(delta, 0.0135, i)           # measured max 0.0066 dB
 
 
 def test_fp16_batch_of_8_equals_eight_single_runs():

@@ -700,11 +700,12 @@ def test_graphed_step_replays_the_eager_step_bit_identically():
         hip, _ = _stage2_pair(9)
         tr = Stage2Trainer(hip, net_hq, lr_G=2e-4, device_state=True)
         if graphed:
-            gs = GraphedStep(tr, gt_img, lr_img, warmup=2)         # 2 eager steps, then capture
+            gs = GraphedStep(tr, gt_img, lr_img, warmup=2)         # 2 eager warm-up steps whose effect is put back, then capture
+            assert tr.opt.t == 0                                    # capturing does not advance the optimisation
             losses = [gs.step(gt_img, lr_img) for _ in range(3)]   # 3 replays
         else:
-            losses = [tr.step(gt_img, lr_img) for _ in range(5)]
-        assert tr.opt.t == 5
+            losses = [tr.step(gt_img, lr_img) for _ in range(3)]
+        assert tr.opt.t == 3
         finals.append((losses[-1], torch.cat([grp.w for grp in tr.opt.groups]).clone()))
     assert finals[0][0] == finals[1][0]
     assert torch.equal(finals[0][1], finals[1][1])
