@@ -107,7 +107,7 @@ def profiled_traffic(batch):
     for line in block.splitlines():
         t = line.split()
         if line[:1] not in (" ", "\t") and t:
-            kernel = t[0]                      # "<kernel name>(<args>)  (<n> dispatches)" heads the counters of that kernel
+            kernel = t[1] if (t[0] == "void" and len(t) > 1) else t[0]   # "[void ]<kernel name>(<args>)  (<n> dispatches)" heads its counters
         elif kernel.startswith("attn_kv_fwd_kernel") and len(t) >= 2 and t[0] == "FETCH_SIZE":
             fetch = float(t[1])
         elif kernel.startswith("attn_kv_fwd_kernel") and len(t) >= 2 and t[0] == "WRITE_SIZE":
