@@ -223,9 +223,11 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
       const_cast<a16_t*>(p.in1 ? p.in1 + img * p.p1 : p.in0), 0, (int)(p.in1 ? p.in1_bytes : p.in0_bytes), 0x00020000);
   const a16_t* wbase = p.wpk + ((size_t)phase * p.co_tiles + ct) * p.n_stages * (size_t)(KS * B_CHUNKS) * 8;
 
-  // One A stage = KC channels [cbase, cbase + KC) of source 0 or 1 into LDS buffer `buf`; pieces [i_lo, i_hi) of this wave.
-  auto issue_a_src = [&](bool src0, int cbase, int buf, int i_lo = 0, int i_hi = 1 << 20) {
-    const int climit = src0 ? p.Cin0 : p.Cin1;
+  auto issue_a = [&](int chunk, int buf, int i_lo = 0, int i_hi = 1 << 20) {   // pieces [i_lo, i_hi) of this wave
+    const int c0 = chunk * KC;
+    // uniform: a stage never straddles two K segments -- [in0 | in1] and, with k_wrap, in0 once more behind them
+    const bool src0 = c0 < p.Cin0 || c0 >= p.Cin0 + p.Cin1;
+    const int cbase = c0 < p.Cin0 ? c0 : (src0 ? c0 - p.Cin0 - p.Cin1 : c0 - p.Cin0), climit = src0 ? p.Cin0 : p.Cin1;
 #pragma unroll
     for (int i = 0; i < A_PER_W; ++i) {
       const int j = wave + NW * i;
@@ -240,33 +242,6 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
                                                    cbase * 2, 0, 0);
       }
     }
-  };
-  // Stage order.  Plain / two-source concat: stage c = channels [c KC, (c + 1) KC) of [in0 | in1], buffers alternate.
-  // k_wrap (the fp32-class contraction, glare_conv_desc.k_wrap): the stages of a KC-channel group g come TOGETHER --
-  //   r = 0: x_hi(g) . w_hi(g)     r = 1: x_hi(g) . w_lo(g)  (the SAME LDS image: no DMA)     r = 2: x_lo(g) . w_hi(g)   [in1 given]
-  // so x_hi is fetched once per group, not twice: with in1, hi lives in buffer 0 and lo in buffer 1 (lo(g) lands during r = 0,
-  // hi(g + 1) during r = 2); without in1 (filter remainder only) the groups alternate buffers.  The filter is packed in the
-  // same order, [w_hi(g) | w_lo(g) | w_hi(g)] per group (ops.split_filter).
-  const int wrapP = p.k_wrap ? (p.in1 ? 3 : 2) : 1;
-  struct AStage { bool valid, src0; int cbase, buf; };
-  auto a_read_buf = [&](int stage) {                       // which LDS buffer stage `stage` reads
-    if (wrapP == 1) return stage & 1;
-    const int g = stage / wrapP, r = stage % wrapP;
-    return wrapP == 3 ? (r == 2 ? 1 : 0) : (g & 1);
-  };
-  auto a_next = [&](int stage) {                           // the A stage whose DMA is issued WHILE `stage` runs
-    AStage n = {false, true, 0, 0};
-    if (wrapP == 1) {
-      if (stage + 1 < p.n_stages) {
-        const int c0 = (stage + 1) * KC;
-        n.valid = true; n.src0 = c0 < p.Cin0; n.cbase = n.src0 ? c0 : c0 - p.Cin0; n.buf = (stage + 1) & 1;
-      }
-      return n;
-    }
-    const int g = stage / wrapP, r = stage % wrapP, G = p.n_stages / wrapP;
-    if (wrapP == 3 && r == 0) { n.valid = true; n.src0 = false; n.cbase = g * KC; n.buf = 1; }
-    else if (r == wrapP - 1 && g + 1 < G) { n.valid = true; n.src0 = true; n.cbase = (g + 1) * KC; n.buf = wrapP == 3 ? 0 : ((g + 1) & 1); }
-    return n;
   };
   // Weight stages go through a buffer descriptor: `buffer_load_dwordx4 ... offen lds` takes ONE per-lane
   // 32-bit offset (lane*16, loop-invariant) plus a scalar offset -- no per-instruction 64-bit VALU address.
@@ -339,12 +314,11 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
 
   const int khalf = lane >> 5, px = lane & 31;
   const int n_bstages = p.n_stages * KS;
-  issue_a_src(true, 0, 0);
+  issue_a(0, 0);
   issue_b(0, 0);
   int bs = 0;
   for (int chunk = 0; chunk < p.n_stages; ++chunk) {
-    const u32x4* cA = lA + a_read_buf(chunk) * A_SLOTS;
-    const AStage nxa = a_next(chunk);                    // wave-uniform
+    const u32x4* cA = lA + (chunk & 1) * A_SLOTS;
 #pragma unroll
     for (int trow = 0; trow < KS; ++trow, ++bs) {
 #ifndef CONV_ABLATE_NOBARRIER  // timing ablations only (tools/ablate.sh): wrong results
@@ -359,15 +333,15 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
       // CU's address path with the matrix pipe waiting): they are spread over the stage's KS*KSTEPS MFMA groups.
       constexpr int NGRP = KS * KSTEPS;
       [[maybe_unused]] constexpr int B_PG = (B_PER_W + NGRP - 1) / NGRP, A_PG = (A_PER_W + NGRP - 1) / NGRP;
-      const bool more_b = bs + 1 < n_bstages, more_a = trow == 0 && nxa.valid;
-      if (trow == 0 && chunk + 1 == p.n_stages && p.res_bytes) prefetch_residual(a_read_buf(chunk) ^ 1);
+      const bool more_b = bs + 1 < n_bstages, more_a = trow == 0 && chunk + 1 < p.n_stages;
+      if (trow == 0 && chunk + 1 == p.n_stages && p.res_bytes) prefetch_residual((chunk + 1) & 1);
 #if !CONV_DMA_SPREAD
 #ifndef CONV_ABLATE_NODMA
 #ifndef CONV_ABLATE_NODMA_B
       if (more_b) issue_b(bs + 1, (bs + 1) & 1);
 #endif
 #ifndef CONV_ABLATE_NODMA_A
-      if (more_a) issue_a_src(nxa.src0, nxa.cbase, nxa.buf);
+      if (more_a) issue_a(chunk + 1, (chunk + 1) & 1);
 #endif
 #endif
 #endif
@@ -387,7 +361,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
             if (more_b) issue_b(bs + 1, (bs + 1) & 1, grp * B_PG, (grp + 1) * B_PG);
 #endif
 #ifndef CONV_ABLATE_NODMA_A
-            if (more_a) issue_a_src(nxa.src0, nxa.cbase, nxa.buf, grp * A_PG, (grp + 1) * A_PG);
+            if (more_a) issue_a(chunk + 1, (chunk + 1) & 1, grp * A_PG, (grp + 1) * A_PG);
 #endif
           }
 #endif

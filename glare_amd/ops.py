@@ -49,23 +49,15 @@ class ConvDesc(ctypes.Structure):
 
 
 def split_filter(w, split):
-    """K segments of an fp32-class conv (glare_conv_desc.k_wrap) along the input channels of an fp32 [..., cout, cin, k, k] filter,
-    in the kernel's stage order: the stages of one KC-channel group come together (KC = 16 for 3x3, 32 for 1x1: conv_igemm_kernel.h),
-    split = 3: [w_hi(g) | w_lo(g) | w_hi(g)] for the operand stages [x_hi(g) | x_hi(g) again | x_lo(g)]; split = 2: [w_hi(g) | w_lo(g)]
-    for [x_hi(g) | x_hi(g)] (a 16-bit activation against a 22-bit filter).  w_hi = round16(w) is what the pack kernel makes of the
-    `w` segments by itself; w_lo = round16(w - w_hi)."""
+    """K segments of an fp32-class conv (glare_conv_desc.k_wrap), along the input channels of an fp32 [..., cout, cin, k, k] filter:
+    split = 3: [w_hi | w_hi | w_lo] for the operand segments [x_hi | x_lo | x_hi]; split = 2: [w_hi | w_lo] for [x_hi | x_hi]
+    (a 16-bit activation against a 22-bit filter).  w_hi = round16(w) is what the pack kernel makes of the first segments by
+    itself; w_lo = round16(w - w_hi)."""
     if not split:
         return w
     assert split in (2, 3)
-    k = w.shape[-1]
-    kc = 16 if k == 3 else 32
-    cin = w.shape[-3]
-    assert cin % kc == 0, "fp32-class conv: input channels must be a multiple of the kernel's %d-channel stage" % kc
     lo = w - w.to(act_dtype()).float()
-    lead, tail = w.shape[:-3], w.shape[-2:]
-    wg, lg = w.reshape(*lead, cin // kc, kc, *tail), lo.reshape(*lead, cin // kc, kc, *tail)
-    segs = [wg, lg, wg] if split == 3 else [wg, lg]
-    return torch.stack(segs, dim=len(lead) + 1).reshape(*lead, split * cin, *tail).contiguous()
+    return torch.cat([w, w, lo] if split == 3 else [w, lo], dim=-3).contiguous()
 
 
 class PackedConv:

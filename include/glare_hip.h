@@ -119,14 +119,13 @@ typedef struct glare_conv_desc {
    * lo half of a k_wrap launch (shifted like the first); out_lo follows out. */
   int groups, group_in_step, group_out_step;
   /* ---- fp32-class contraction on the 16-bit MFMA (round 4; zero = plain): with the activation and the filter each a hi / lo pair
-   * (22 mantissa bits), x . w = x_hi . w_hi + x_hi . w_lo + x_lo . w_hi up to 2^-22, i.e. ONE accumulation over three K segments.
-   * k_wrap != 0: in = x_hi, in2 = x_lo (same geometry, Cin2 = Cin) and the K loop walks, for every group g of KC input channels
-   * (KC = 16 for 3x3, 32 for 1x1), the stages x_hi(g), x_hi(g) AGAIN (the same LDS image: no second fetch), x_lo(g); weight_packed is
-   * the ordinary pack of the fp32 filter [w_hi(g) | w_lo(g) | w_hi(g)]_g concatenated along its input channels (3 Cin).  With
-   * in2 = NULL it is x_hi . (w_hi + w_lo): stages x_hi(g) twice against [w_hi(g) | w_lo(g)]_g (2 Cin).  The packed filter's
-   * input-channel count must be Cin + Cin2 + Cin; Cin (and Cin2) multiples of KC.  Grouped launches shift both sources by
-   * group_in_step.  Where the reference contracts in fp32 and the codebook search downstream needs it (the conditional encoder and
-   * the flow's nets under the fp16 inference precision). */
+   * (22 mantissa bits), x . w = x_hi . w_hi + x_lo . w_hi + x_hi . w_lo up to 2^-22, i.e. ONE accumulation over three K segments.
+   * k_wrap != 0: after the concatenated sources (`in`, then `in2`) the FIRST source is read again, so that with in = x_hi,
+   * in2 = x_lo (same geometry, Cin2 = Cin) and weight_packed = the pack of [w_hi | w_hi | w_lo] along the input channels (3 Cin) the
+   * launch computes exactly that sum; with in2 = NULL it is x_hi . (w_hi + w_lo) on a filter packed as [w_hi | w_lo] (2 Cin).
+   * The packed filter's input-channel count must be Cin + Cin2 + Cin; Cin (and Cin2) multiples of the kernel's 16-channel (3x3) /
+   * 32-channel (1x1) stage.  Grouped launches shift both sources by group_in_step.  Where the reference contracts in fp32 and the
+   * codebook search downstream needs it (the conditional encoder and the flow's nets under the fp16 inference precision). */
   int k_wrap;
   /* ---- GroupNorm (+ swish) of the INPUT as the loader's prologue (round 4; NULL = none): gn_coef = fp32 [B][Cin][2] from
    * glare_groupnorm_coeffs_f32, (a, d) per (image, channel); the kernel applies y = swish(a x + d) (gn_swish != 0) or y = a x + d,
