@@ -236,6 +236,8 @@ def train_block(device, rank, world, steps=8, warmup=3):
                 self.groups = [FlatGroup(list(self.b.parameters()), 1e-3), FlatGroup(list(self.a.parameters()), 1e-3)]
 
             def step_tensor(self, gt, lr):
+                if os.environ.get("GLARE_BENCH_STUB_HANG") == "1":     # tests: a collective that never returns
+                    time.sleep(3600)
                 for grp in self.groups:
                     grp.zero_grad()
                 loss = self.b(torch.tanh(self.a(lr))).sum()
@@ -331,6 +333,8 @@ def main():
                                                                "what a rocprofv3 kernel trace of this command should see is single-stream launches only")
     ap.add_argument("--no-train", action="store_true", help="skip the `train` block (stage-2 / stage-3 ms per step, measured after "
                                                             "the inference region)")
+    ap.add_argument("--train-timeout", type=int, default=600, help="seconds after which a train block that has not returned is "
+                                                                   "declared hung: the JSON line is printed without it")
     ap.add_argument("--breakdown", action="store_true", help="per-stage timing on stderr")
     args = ap.parse_args()
 
@@ -436,16 +440,7 @@ def main():
     if args.breakdown and rank == 0 and not STUB:
         stage_breakdown(netG, net_vq, lr)
 
-    train = None
-    if not args.no_train:
-        # after the timed inference region; never allowed to take the headline line down with it (the all-reduce leg has only
-        # ever run under gloo on CPU before a driver's N > 1 run): a failure is reported inside the block
-        try:
-            with ops.use_precision("bf16"):       # the training kernels' format (fp32 range for gradients)
-                train = train_block(device, rank, world)
-        except Exception as e:  # noqa: BLE001
-            train = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
-
+    res = None
     if rank == 0:
         total_images = args.batch * world * args.steps
         res = {
@@ -468,13 +463,45 @@ def main():
             "value_streams2": value_streams2,
             "roofline": None if STUB else attention_roofline(device, args.batch, live_events),
             "rooflines": None if STUB else family_rooflines(family_events, args.steps),
-            "train": train,
+            "train": None,
         }
         if STUB:
             res["stub"] = True
-        if not args.no_cpu_baseline and world == 1 and not STUB:  # reported at N = 1 only
-            res["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(res), flush=True)
+
+    printed = []
+
+    def emit():
+        if rank == 0 and not printed:
+            printed.append(True)
+            print(json.dumps(res), flush=True)
+
+    if not args.no_train:
+        # After the timed inference region, and never allowed to take the headline line down with it: an exception is reported
+        # inside the block, and -- the all-reduce leg has only ever run under gloo on CPU before a driver's N > 1 run -- a HANG
+        # is cut by a watchdog on rank 0 that prints the line with what it has and ends the job (torchrun then stops the others).
+        import threading
+
+        def on_timeout():
+            if res is not None:
+                res["train"] = {"error": "the train block did not finish within %d s (a hung collective?)" % args.train_timeout}
+            emit()
+            os._exit(0 if rank == 0 else 1)
+
+        dog = threading.Timer(args.train_timeout, on_timeout)
+        dog.daemon = True
+        dog.start()
+        try:
+            with ops.use_precision("bf16"):       # the plain-op default; the block's fp16 runs select their own precision
+                train = train_block(device, rank, world)
+        except Exception as e:  # noqa: BLE001
+            train = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        dog.cancel()
+        if res is not None:
+            res["train"] = train
+
+    if rank == 0 and not args.no_cpu_baseline and world == 1 and not STUB:  # reported at N = 1 only
+        res["cpu_baseline"] = cpu_baseline()
+    emit()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -72,3 +72,21 @@ def test_bench_world_2_skeleton_runs_over_gloo():
     assert res["config"]["global_batch"] == 4 and res["config"]["parallelism"] == "dp2"
     assert res["value"] > 0 and abs(res["value"] - 4 * 3 / (res["ms_per_step"] * 3e-3)) / res["value"] < 1e-3
     assert res["train"]["world"] == 2 and res["train"]["stage2_ms_per_step"] > 0 and "error" not in res["train"]
+
+
+def test_bench_prints_its_line_when_the_train_block_hangs():
+    """The all-reduce leg of the train block has never run on more than one GPU: if it ever hangs there, the headline line must
+    still come out.  A stub trainer that never returns (GLARE_BENCH_STUB_HANG=1) under `--train-timeout 3`: rank 0's watchdog prints
+    the inference line with the error recorded in `train` and ends the process."""
+    import json
+
+    env = dict(os.environ, GLARE_BENCH_STUB="1", GLARE_BENCH_STUB_HANG="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "2", "--train-timeout", "3"],
+                       env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["value"] > 0 and "did not finish" in res["train"]["error"]
