@@ -249,7 +249,7 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_kernel(const DcnParams p) 
 // of one wave do return in issue order (tools/probes/vmcnt_order_probe.hip).  The same blend in scalar fp32 is bit-stable
 // over every shape of tools/determinism_check.py and just as fast (the kernel is not VALU-bound enough to notice).
 #ifndef DCN_ABL
-#define DCN_ABL 0   // timing ablations only (tools/ablate.sh): 1 no weight loads, 2 no corner loads, 4 no MFMA, 8 no offset loads
+#define DCN_ABL 0   // timing ablations only (tools/ablate.sh): 1 no weight loads, 2 no corner loads, 4 no MFMA, 8 no offset loads, 16 no blend / split arithmetic
 #endif
 //
 // SINGLE = true (GLARE_MDCN_SINGLE_PASS): the blended sample and the filter are rounded ONCE to the library's 16-bit activation
@@ -424,6 +424,10 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_fast_kernel(const DcnParam
     for (int i = 0; i < ITEMS; ++i) {
       const float m = cm[i];
       u32x4 hi, lo;
+#if DCN_ABL & 16   // timing ablation only (wrong results): no blend / split arithmetic, the raw corners go to the tile
+      hi = cr[i][0] ^ cr[i][2]; lo = cr[i][1] ^ cr[i][3];
+      if (m == 12345.f) hi[0] = __float_as_uint(cw[i][0]);
+#else
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         // reference order: (w1*v1 + w2*v2 + w3*v3 + w4*v4) * mask   (kernel.cu:493-496,625), on (even, odd) channel pairs.
@@ -443,6 +447,7 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_fast_kernel(const DcnParam
           lo[e] = pack_bf2(r0, r1);
         }
       }
+#endif
       dst[it_lds[i]] = hi;
       if constexpr (!SINGLE) dst[NCH * PIX + it_lds[i]] = lo;
     }
