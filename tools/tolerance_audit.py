@@ -11,7 +11,9 @@ rec = json.load(open(path))
 loose = 0
 for k, v in sorted(rec.items()):
     ratio = v["limit"] / v["max_measured"] if v["max_measured"] > 0 else float("inf")
-    flag = "  <-- looser than 2x" if ratio > 2.0 and v["limit"] > 1e-6 else ""
+    # 5 % slack: bounds are written with two digits (2.04x is "2x"); bounds at fp32 rounding level (<= 1e-6) are not audited.  A bound
+    # shared by several configurations (tests/tolerances.py TOL) is 2x the LARGEST of them and shows up here for the others.
+    flag = "  <-- looser than 2x" if ratio > 2.1 and v["limit"] > 1e-6 else ""
     loose += bool(flag)
     print("%-110s measured %.3e  bound %.3e  (x%.1f)%s" % (k, v["max_measured"], v["limit"], ratio, flag))
 print("%d bounds, %d looser than 2x measured" % (len(rec), loose))
