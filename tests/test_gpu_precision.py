@@ -348,6 +348,25 @@ def test_end_to_end_full_size_twelve_scenes(capsys):
         within(delta, 0.0088)                      # measured max 0.0044 dB; BASELINE: 0.05
 
 
+@pytest.mark.parametrize("h,w", [(60, 92), (132, 72), (36, 28)])
+def test_end_to_end_other_image_sizes(h, w, capsys):
+    """The path is size-generic (infer_dataset_lol.py pads whatever it is given by 20): a small landscape, a portrait and a tiny image --
+    ragged 8 x 32 conv tiles, partial attention key tiles, DCN tiles that straddle images -- full path vs the oracle, default precision."""
+    og, ov, pg, pv, lr, ref = setup("representative", h, w, 33)
+    with torch.no_grad():
+        r = pg.reverse_flow_nhwc(pv, lr.cuda())
+    agree = float((r["indices"].cpu() == ref["indices"]).float().mean())
+    m = e2e_metrics(r["out"].cpu(), ref["out"], h)
+    lat = float(rel(ops.nhwc_to_nchw(r["latent"]).cpu(), ref["latent"]))
+    with capsys.disabled():
+        print("\n[e2e %dx%d] latent rel %.2e | index agreement %.5f | PSNR(ours,oracle) %.2f dB | |dPSNR vs GT| %.4f dB"
+              % (h, w, lat, agree, m["psnr_vs_oracle"], m["delta"]))
+    within(lat, 5.5e-5)                # measured 1.97e-5 / 1.72e-5 / 2.73e-5
+    tokens = ref["indices"].numel()
+    assert (1.0 - agree) * tokens <= 6.5, (agree, tokens)     # measured: 0 / 3 (of 874) / 0 tokens differ -- two of the three sizes bit-exact
+    within(m["delta"], 0.0045)         # measured 0.0012 / 0.0022 / 0.0010 dB
+
+
 def test_end_to_end_batch_of_8_against_eight_oracle_runs(capsys):
     """BASELINE configs[1] is a batch of 8: the product's ONE batched launch sequence (default launch configuration: keys not split
     at this size, as at 400x600 x 8) against the oracle run image by image, per image (100x156: eight 2 s oracle runs).  VERDICT r03:
@@ -371,7 +390,7 @@ def test_end_to_end_batch_of_8_against_eight_oracle_runs(capsys):
     for i, lat, agree, psnr, delta in rows:
         within(lat, 3.7e-5)                # measured 1.5-1.9e-5 (one record per quantity: the maximum over the eight images)
         within(1.0 - agree, 3.0e-3)        # measured: five of the eight images with EVERY index equal, the others 1-2 of 1 320 tokens
-        assert psnr >= 52.0, (i, psnr)     # measured 55-66 dB (a single flipped token moves a 100x156 image by ~8 dB of PSNR(ours, oracle))
+        assert psnr >= 49.7, (i, psnr)     # measured 52.7-67.3 dB (ONE flipped token moves a 100x156 image from ~66 to ~53 dB of PSNR(ours, oracle))
         within(delta, 0.0133)              # measured max 0.0066 dB
 
 
