@@ -460,3 +460,25 @@ def test_groupnorm_prologue_is_bit_identical_to_the_separate_pass(prec, B, C, Co
     assert torch.equal(got, ref)
     assert torch.equal(got._gn_stats, ref._gn_stats)
 
+
+
+def test_groupnorm_prologue_through_the_decoder_modules():
+    """GLARE_GN_PROLOGUE=1 (encoder_decoder.GN_PROLOGUE): the VQGAN decoder with its <= 128-channel ResnetBlocks on the prologue form --
+    the same bits as the default graph (the measured reason it is off by default is speed, profiles/r04_gn_prologue.txt)."""
+    from glare_amd import modules as M
+    from glare_amd.modules import encoder_decoder as ED
+    from glare_amd.synthetic import seeded_init_
+
+    pv = seeded_init_(M.VQModel().eval(), 1).cuda()
+    z = (torch.randn(2, 9, 13, 3, generator=torch.Generator().manual_seed(3)) * 0.5).cuda()
+    outs = []
+    with torch.no_grad(), ops.use_precision("fp16"):
+        for flag in (False, True):
+            keep, ED.GN_PROLOGUE = ED.GN_PROLOGUE, flag
+            try:
+                img, feats = pv.decoder.forward_nhwc(z, want_image=True)
+            finally:
+                ED.GN_PROLOGUE = keep
+            outs.append((img, feats))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))
