@@ -12,6 +12,9 @@
 #ifndef CONV_TILE16
 #define CONV_TILE16 0
 #endif
+#ifndef CONV_ABL_HILO
+#define CONV_ABL_HILO 0
+#endif
 #ifndef CONV_ABL_EPI
 #define CONV_ABL_EPI 0   // timing ablations only (tools/ablate.sh; wrong results): 1 residual add -> one xor, 2 phase 1 as a transposed layout would have it, 4 no output stores, 8 no epilogue at all
 #endif
@@ -398,6 +401,9 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
   // (Requesting a tile row's residual halves BEFORE its pass through the slab -- 32 more registers next to the 128 accumulators at
   // 168 -- spilled: 196 B/lane of scratch, 892 instead of 823 us per launch on the path's eight launches; kept out.)
   if constexpr (HILO) {
+#if CONV_ABL_HILO & 8   // timing ablations only (tools/ablate.sh): wrong results
+    if (acc[0][0][0] != 12345.f) return;
+#endif
     constexpr int ROWF = NT * 128 + 16;                  // slab row pitch in bytes (pad: bank spread between rows)
     constexpr int CPR = NT * 4;                          // 8-channel chunks per slab row
     static_assert(NW * 32 * ROWF <= (2 * A_SLOTS + 2 * B_CHUNKS) * 16, "hi/lo epilogue slab fits the pipeline LDS");
@@ -421,6 +427,9 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
         }
       });
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if CONV_ABL_HILO & 4
+      if (acc[0][0][0] == 12345.f)
+#endif
 #pragma unroll
       for (int it = 0; it < 32 * CPR / 64; ++it) {
         const int idx = lane + 64 * it;
@@ -447,11 +456,17 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
           for (int e = 0; e < 4; ++e) {
             const float a = apply_act<ACT>(v[2 * e]), c = apply_act<ACT>(v[2 * e + 1]);
             hi[e] = pack_a2(a, c);
+#if !(CONV_ABL_HILO & 1)
             lo[e] = pack_a2(a - alo(hi[e]), c - ahi(hi[e]));
+#endif
+#if !(CONV_ABL_HILO & 2)
             if (e < 2) { gs0 += a + c; gq0 += a * a + c * c; } else { gs1 += a + c; gq1 += a * a + c * c; }
+#endif
           }
           *reinterpret_cast<u32x4*>(reinterpret_cast<a16_t*>(p.out) + pix * p.opitch + p.ooff + co) = hi;
+#if !(CONV_ABL_HILO & 1)
           *reinterpret_cast<u32x4*>(p.out_lo + pix * p.opitch + p.ooff + co) = lo;
+#endif
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -101,6 +101,8 @@ def bench_convsplit():
             print("conv3 %-22s: %.3f ms  %.0f TFLOP/s algorithmic, %.0f executed (pair out)" % (name, ms, fl / ms / 1e9, 3 * fl / ms / 1e9))
             ms = timeit(lambda: ops.conv2d(x, pc, out=out, residual=res, hilo=True, gn_stats=(co % 128 == 0)))
             print("conv3 %-22s: %.3f ms  %.0f TFLOP/s algorithmic, %.0f executed (+ pair residual, statistics)" % (name, ms, fl / ms / 1e9, 3 * fl / ms / 1e9))
+            ms = timeit(lambda: ops.conv2d(x, pc, out=out))
+            print("conv3 %-22s: %.3f ms  %.0f TFLOP/s algorithmic, %.0f executed (16-bit out: what the pair epilogue costs)" % (name, ms, fl / ms / 1e9, 3 * fl / ms / 1e9))
             pc1 = ops.PackedConv(wt, torch.zeros(co, device=DEV))
             ms1 = timeit(lambda: ops.conv2d(x, pc1, out=out))
             print("conv3 %-22s: single pass, 16-bit out %.3f ms  %.0f TFLOP/s" % (name, ms1, fl / ms1 / 1e9))
