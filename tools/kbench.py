@@ -15,9 +15,16 @@ B = int(os.environ.get("KB_BATCH", "8"))
 REPS = int(os.environ.get("KB_REPS", "5"))
 
 
-def timeit(fn, reps=REPS, warm=2):
-    for _ in range(warm):
+def timeit(fn, reps=REPS, warm=2, warm_s=0.3):
+    # warm up by TIME, not by count: the first case measured after an idle stretch (allocation, a rebuild) ran 15 % slow with two
+    # warm-up launches (conv3 128 -> 128 @full: 2.01 ms first, 1.73 ms when measured again; round 4) -- clocks and first-touch mappings
+    import time
+    t0 = time.time()
+    n = 0
+    while n < warm or time.time() - t0 < warm_s:
         fn()
+        torch.cuda.synchronize()
+        n += 1
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     s.record()
@@ -103,6 +110,11 @@ def bench_convsplit():
             print("conv3 %-22s: %.3f ms  %.0f TFLOP/s algorithmic, %.0f executed (+ pair residual, statistics)" % (name, ms, fl / ms / 1e9, 3 * fl / ms / 1e9))
             ms = timeit(lambda: ops.conv2d(x, pc, out=out))
             print("conv3 %-22s: %.3f ms  %.0f TFLOP/s algorithmic, %.0f executed (16-bit out: what the pair epilogue costs)" % (name, ms, fl / ms / 1e9, 3 * fl / ms / 1e9))
+            if os.environ.get("KB_ORDER"):     # is the first case of a shape measured slow (clocks, placement)?  pair / 16-bit alternated
+                for _ in range(2):
+                    a = timeit(lambda: ops.conv2d(x, pc, out=out, hilo=True))
+                    c = timeit(lambda: ops.conv2d(x, pc, out=out))
+                    print("conv3 %-22s: again: pair out %.3f ms, 16-bit out %.3f ms" % (name, a, c))
             pc1 = ops.PackedConv(wt, torch.zeros(co, device=DEV))
             ms1 = timeit(lambda: ops.conv2d(x, pc1, out=out))
             print("conv3 %-22s: single pass, 16-bit out %.3f ms  %.0f TFLOP/s" % (name, ms1, fl / ms1 / 1e9))
