@@ -29,15 +29,16 @@ def main():
     h, w = (args[0], args[1]) if len(args) >= 2 else (400, 600)
     seeds = args[2:] or list(range(11, 23))
     torch.set_num_threads(min(32, os.cpu_count() or 1))
-    og, ov = representative_init_(O.VQLLFLOWDeformable(per_sample_mean=True).eval(), O.VQModel().eval(), 0)
+    wseed = int(os.environ.get("PARITY_WEIGHT_SEED", "0"))     # another trained-like weight set (codebook, ActNorms, filters)
+    og, ov = representative_init_(O.VQLLFLOWDeformable(per_sample_mean=True).eval(), O.VQModel().eval(), wseed)
     pg, pv = M.VQLLFLOWDeformable().eval(), M.VQModel().eval()
     pg.load_state_dict(og.state_dict())
     pv.load_state_dict(ov.state_dict())
     pg.cuda()
     pv.cuda()
     prec = os.environ.get("PARITY_PRECISION") or None
-    print("== %dx%d, representative weights, precision %s, GLARE_FP32_CLASS=%s GLARE_HILO_STREAM=%s GLARE_DCN_SINGLE_PASS=%s"
-          % (h, w, prec or "default", os.environ.get("GLARE_FP32_CLASS", "1"), os.environ.get("GLARE_HILO_STREAM", "1"),
+    print("== %dx%d, representative weights (seed %d), precision %s, GLARE_FP32_CLASS=%s GLARE_HILO_STREAM=%s GLARE_DCN_SINGLE_PASS=%s"
+          % (h, w, wseed, prec or "default", os.environ.get("GLARE_FP32_CLASS", "1"), os.environ.get("GLARE_HILO_STREAM", "1"),
              os.environ.get("GLARE_DCN_SINGLE_PASS", "default")))
     rows = []
     for s in seeds:
