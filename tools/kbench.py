@@ -48,6 +48,12 @@ def bench_attn():
     q = (torch.randn(B, N, C, device=DEV) * 0.3).to(torch.bfloat16)
     ms = timeit(lambda: ops.attention_kv512(q, x, N, out=out, key_splits=1))
     print("attnkv B=%d N=%d d=512 (shared K/V): %.3f ms  %.0f TFLOP/s" % (B, N, ms, 4.0 * B * N * N * C / ms / 1e9))
+    if os.environ.get("KB_ZERO"):   # the same launch on all-zero operands: same instruction stream, far less switching power -- what the
+        xz, qz = torch.zeros_like(x), torch.zeros_like(q)          # clock does to the figure (the kernel is power-limited)
+        ms = timeit(lambda: ops.attention_kv512(qz, xz, N, out=out, key_splits=1))
+        print("attnkv B=%d N=%d d=512 (shared K/V), ALL-ZERO operands: %.3f ms  %.0f TFLOP/s" % (B, N, ms, 4.0 * B * N * N * C / ms / 1e9))
+        ms = timeit(lambda: ops.attention_kv512(q, x, N, out=out, key_splits=1))
+        print("attnkv B=%d N=%d d=512 (shared K/V), random again: %.3f ms  %.0f TFLOP/s" % (B, N, ms, 4.0 * B * N * N * C / ms / 1e9))
     if os.environ.get("KB_PROF"):   # per-phase cycles of one wave (library built with GLARE_DEFS=-DATTNKV_PROFILE)
         ops.ATTENTION_PROFILE_BUFFER = torch.zeros(8, dtype=torch.int64, device=DEV)
         ops.attention_kv512(q, x, N, out=out, key_splits=1)
@@ -75,6 +81,11 @@ def bench_conv():
         ms = timeit(lambda: ops.conv2d(x, pc, out=out))
         fl = 2.0 * B * h * w * ci * co * k * k
         print("conv  %-22s: %.3f ms  %.0f TFLOP/s" % (name, ms, fl / ms / 1e9))
+        if os.environ.get("KB_ZERO"):
+            xz = torch.zeros_like(x)
+            pz = ops.PackedConv(torch.zeros_like(wt), torch.zeros(co, device=DEV))
+            msz = timeit(lambda: ops.conv2d(xz, pz, out=out))
+            print("conv  %-22s: %.3f ms  %.0f TFLOP/s  (ALL-ZERO operands)" % (name, msz, fl / msz / 1e9))
         res = torch.randn(B, h, w, co, device=DEV).to(torch.bfloat16)
         ms = timeit(lambda: ops.conv2d(x, pc, out=out, residual=res))
         print("conv  %-22s: %.3f ms  %.0f TFLOP/s  (+residual)" % (name, ms, fl / ms / 1e9))
