@@ -150,7 +150,9 @@ def attention_roofline(device, batch, live_events, reps=5):
             "traffic_unit": "HBM bytes per launch", "traffic_source": source, "algorithmic_bytes": int(3 * 2 * batch * N * C),
             "ms_per_launch": round(ms, 3), "launches_timed": len(live),
             "timing": "HIP event pairs around every launch inside the timed region" if live else "isolated launches (no live events)",
-            "isolated_ms_per_launch": round(isolated_ms, 3), "launch_shape": {"B": batch, "N": N, "d": C}}
+            "isolated_ms_per_launch": round(isolated_ms, 3), "launch_shape": {"B": batch, "N": N, "d": C},
+            "binds": "the socket's power budget, not the schedule: see `power` (this launch on all-zero operands runs ~30 % faster at the "
+                     "full clock; DESIGN.md section 3, 'the power wall')"}
 
 
 class Telemetry:
