@@ -182,8 +182,9 @@ class Telemetry:
                 pass
         return None
 
-    def probe(self, fn, secs, flop=None):
-        """Runs fn() back to back for `secs` seconds (after a 0.5 s ramp) and returns the median clock / power of the busiest device."""
+    def probe(self, fn, secs, flop=None, ramp=0.5):
+        """Runs fn() back to back for `secs` seconds (after `ramp` seconds unsampled: the hwmon power figure is a ~1 s average) and returns
+        the median clock / power of the busiest device."""
         import threading
 
         if not self.dirs:
@@ -195,7 +196,7 @@ class Telemetry:
                 rows.append(self._read())
                 time.sleep(0.02)
 
-        t_end = time.time() + 0.5
+        t_end = time.time() + ramp
         while time.time() < t_end:
             fn()
             torch.cuda.synchronize()
@@ -252,8 +253,8 @@ def power_block(device, batch, step):
         pipe = tel.probe(step, 2.0)
     return {"cap_w": tel.cap_w(), "nominal_sclk_mhz": NOMINAL_SCLK_MHZ, "source": "amdgpu hwmon freq1_input / power1_input, medians of 20-ms samples",
             "pipeline": pipe,
-            "attention_random_operands": tel.probe(lambda: ops.attention_kv512(q, x, N, out=out, key_splits=1), 1.5, fl),
-            "attention_zero_operands": tel.probe(lambda: ops.attention_kv512(qz, xz, N, out=out, key_splits=1), 1.5, fl),
+            "attention_random_operands": tel.probe(lambda: ops.attention_kv512(q, x, N, out=out, key_splits=1), 1.5, fl, ramp=2.0),
+            "attention_zero_operands": tel.probe(lambda: ops.attention_kv512(qz, xz, N, out=out, key_splits=1), 1.5, fl, ramp=2.5),
             "note": "same kernel, same launch, same bytes: only the operand VALUES differ (all zero = almost no switching power)"}
 
 

@@ -6,7 +6,7 @@ tag=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 python bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench.err
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o b -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train --no-streams2 > gpurun_out/${tag}_bench_prof.log 2>&1
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o b -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train --no-streams2 --no-power > gpurun_out/${tag}_bench_prof.log 2>&1
 python tools/rocpd_stats.py $(ls gpurun_out/prof_$tag/*/b_results.db gpurun_out/prof_$tag/b_results.db 2>/dev/null | head -1) > gpurun_out/${tag}_bench_kernel_stats.txt 2>&1
 {
   echo "# rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in SEPARATE runs, counters only), MI355X, B=8, $tag"
@@ -18,6 +18,7 @@ python tools/rocpd_stats.py $(ls gpurun_out/prof_$tag/*/b_results.db gpurun_out/
   for k in attn conv dcn; do echo "== $k"; bash tools/pmc_kernel.sh ${tag}_$k $k 2>&1 | grep -v "amdgpu.ids"; done
 } > gpurun_out/${tag}_pmc_kernels.txt
 python tools/kbench.py attn conv convsplit gn dcn vq wgrad attnbwd > gpurun_out/${tag}_kbench.txt 2>&1
+python tools/probes/power_clock_probe.py 4 2>&1 | grep -v "amdgpu.ids" > gpurun_out/${tag}_power_clock.txt   # the power wall: random vs all-zero operands
 bash tools/pmc_shapes.sh $tag > /dev/null 2>&1          # per-SHAPE traffic of the conv / DCN launches -> ${tag}_pmc_shapes.json
 # end-to-end parity: 12 scenes of the default path (tools/parity_scenes.py), then the precision ladder on three of them -- round 3's
 # single-pass fp16 path (GLARE_FP32_CLASS=0) and bf16 -- and the single-pass DCN as an A/B
@@ -26,6 +27,9 @@ bash tools/pmc_shapes.sh $tag > /dev/null 2>&1          # per-SHAPE traffic of t
   GLARE_DCN_SINGLE_PASS=1 python tools/parity_scenes.py 400 600 11 13 15 2>&1 | grep -v "Warn\|amdgpu.ids"
   GLARE_FP32_CLASS=0 python tools/parity_scenes.py 400 600 11 13 15 2>&1 | grep -v "Warn\|amdgpu.ids"
   PARITY_PRECISION=bf16 python tools/parity_scenes.py 400 600 11 13 15 2>&1 | grep -v "Warn\|amdgpu.ids"
+  echo; echo "# held-out scenes and a second trained-like weight set"
+  python tools/parity_scenes.py 400 600 101 102 103 104 105 106 107 108 109 110 111 112 2>&1 | grep -v "Warn\|amdgpu.ids"
+  PARITY_WEIGHT_SEED=1 python tools/parity_scenes.py 400 600 11 12 13 101 102 103 2>&1 | grep -v "Warn\|amdgpu.ids"
 } > gpurun_out/${tag}_parity_table.txt 2>&1
 for st in stage2 stage3; do
   python tools/train_bench.py $st 20 graph > gpurun_out/${tag}_train_${st}_graph.txt 2>&1
