@@ -71,12 +71,12 @@ def test_split3_hilo_output_residual_and_statistics():
     ref = F.conv2d(x.cuda(), w.cuda(), b.cuda(), 1, 1) + r.cuda()
     with ops.use_precision("fp16"):
         out = ops.conv2d(_pair(x), ops.PackedConv(w.cuda(), b.cuda(), split=3), residual=_pair(r), hilo=True, gn_stats=True)
-        within(_err(_val(out), ref), 4e-6)
+        within(_err(_val(out), ref), 2.2e-6)          # measured 1.07e-6
         # GroupNorm of the pair, output as a pair
         gamma, beta = torch.rand(128, generator=g).cuda() + 0.5, torch.randn(128, generator=g).cuda() * 0.1
         y = ops.groupnorm(out, gamma, beta, swish=True, pair=True)
         yref = F.silu(F.group_norm(ref, 32, gamma, beta, 1e-6))
-        within(_err(_val(y), yref), 1e-5)
+        within(_err(_val(y), yref), 2.3e-6)          # measured 1.13e-6
         assert float((y._lo.float().abs().max())) > 0
 
 
@@ -89,7 +89,7 @@ def test_split3_1x1_hilo_output_both_tiles():
         ref = F.relu(F.conv2d(x.cuda(), w.cuda(), b.cuda()))
         with ops.use_precision("fp16"):
             out = ops.conv2d(_pair(x), ops.PackedConv(w.cuda(), b.cuda(), split=3), act="relu", hilo=True)
-        within(_err(_val(out), ref), 4e-6, cout)
+        within(_err(_val(out), ref), 1.1e-6, cout)      # measured 5.3e-7 / 4.3e-7
 
 
 def test_split3_grouped_launch_equals_per_group_launches():
@@ -115,7 +115,7 @@ def test_split3_grouped_launch_equals_per_group_launches():
             ref = F.conv2d(x[:, 64 * i:64 * i + 64].cuda(), w[i].cuda(), b[i].cuda(), 1, k // 2)
             if not f32:
                 ref = F.relu(ref)
-            within(_err(got[..., step * i:step * i + cout], ref), 4e-6, "%d/%d" % (k, i))
+            within(_err(got[..., step * i:step * i + cout], ref), 1.5e-6, "%d/%d" % (k, i))     # measured <= 7.3e-7
 
 
 def test_split2_filter_remainder_only():
@@ -127,7 +127,7 @@ def test_split2_filter_remainder_only():
     with ops.use_precision("fp16"):
         xh = x.permute(0, 2, 3, 1).contiguous().cuda().half()
         out = ops.conv2d(xh, ops.PackedConv(w.cuda(), None, split=2), out_mode=ops.OUT_NHWC_F32)
-    within(_err(out, ref), 4e-6)
+    within(_err(out, ref), 2.0e-6)                  # measured 1.0e-6
 
 
 def test_flow_h1_pair():
@@ -142,7 +142,7 @@ def test_flow_h1_pair():
         plain = ops.flow_h1(z, ftA, 64, wz)
     ref = F.relu(ftA[..., 64:] + F.conv2d(z[..., :1].permute(0, 3, 1, 2), wz.view(64, 1, 3, 3), None, 1, 1).permute(0, 2, 3, 1))
     assert torch.equal(h1, plain)
-    within(float((_val(h1) - ref).abs().max() / ref.abs().max()), 2e-6)
+    within(float((_val(h1) - ref).abs().max() / ref.abs().max()), 4.5e-7)   # measured 2.2e-7
 
 
 @pytest.mark.parametrize("B,N", [(8, 300), (1, 700)])       # one workgroup per query block / keys split over 4 workgroups
