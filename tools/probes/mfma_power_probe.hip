@@ -26,7 +26,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 // KIND 0: v_mfma_f32_32x32x16_f16   1: v_mfma_f32_32x32x16_bf16   2: v_mfma_f32_16x16x32_f16
-template <int KIND>
+// ORDER (32x32 kinds): 0 = i outer / j inner (B changes every MFMA, A every 4th); 1 = snake (exactly one operand changes per MFMA);
+// 2 = both operands change on every MFMA.  Same 8 products per iteration in all three.
+template <int KIND, int ORDER = 0>
 __global__ __launch_bounds__(256) void mfma_loop(const u32x4* __restrict__ frag, int iters, float* sink) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // 6 fragments per wave, different per wave and lane: [block % 61][wave][6][64 lanes]
@@ -68,16 +70,22 @@ __global__ __launch_bounds__(256) void mfma_loop(const u32x4* __restrict__ frag,
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    constexpr int SEQ[3][8][2] = {{{0, 0}, {0, 1}, {0, 2}, {0, 3}, {1, 0}, {1, 1}, {1, 2}, {1, 3}},
+                                  {{0, 0}, {0, 1}, {0, 2}, {0, 3}, {1, 3}, {1, 2}, {1, 1}, {1, 0}},
+                                  {{0, 0}, {1, 1}, {0, 2}, {1, 3}, {0, 1}, {1, 0}, {0, 3}, {1, 2}}};
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
+      for (int q = 0; q < 8; ++q) {
+          constexpr int dummy = 0; (void)dummy;
+          const int i = SEQ[ORDER][q][0], j = SEQ[ORDER][q][1];
+          {
           if constexpr (KIND == 0)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[i]), __builtin_bit_cast(f16x8, b[j]), acc[i][j], 0, 0, 0);
           else
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
-        }
+          }
+      }
+      __builtin_amdgcn_sched_barrier(0);     // the issue order is the experiment
     }
     float s = 0.f;
 #pragma unroll
@@ -192,5 +200,31 @@ int main(int argc, char** argv) {
         fflush(stdout);
         std::this_thread::sleep_for(std::chrono::milliseconds(800));
       }
+  // operand ORDER at fixed data (fp16 32x32x16, random, 1 wave / SIMD): how much of the power is operand delivery?
+  for (int order = 0; order < 3; ++order) {
+    srand(1234);
+    for (size_t e = 0; e < n_frag * 8; ++e) host[e] = f2h(randn());
+    hipMemcpy(d_frag, host.data(), n_frag * 16, hipMemcpyHostToDevice);
+    const int blocks = cus, iters = 20000;
+    const double flop = (double)blocks * 4 * iters * 8 * 32768.0;
+    auto launch = [&]() {
+      if (order == 0) hipLaunchKernelGGL((mfma_loop<0, 0>), dim3(blocks), dim3(256), 0, 0, d_frag, iters, sink);
+      else if (order == 1) hipLaunchKernelGGL((mfma_loop<0, 1>), dim3(blocks), dim3(256), 0, 0, d_frag, iters, sink);
+      else hipLaunchKernelGGL((mfma_loop<0, 2>), dim3(blocks), dim3(256), 0, 0, d_frag, iters, sink);
+    };
+    launch(); hipDeviceSynchronize();
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const auto t0 = std::chrono::steady_clock::now();
+    float ms_tail = 0; int n_tail = 0;
+    while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < secs) {
+      hipEventRecord(e0); launch(); hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.4 * secs) { ms_tail += ms; ++n_tail; }
+    }
+    const char* on[3] = {"i outer, j inner (10 operand changes / 8)", "snake (8 / 8: one operand per MFMA)", "both change every MFMA (16 / 8)"};
+    printf("order: %-44s %9.0f TFLOP/s\n", on[order], flop / (ms_tail / std::max(n_tail, 1)) / 1e9);
+    fflush(stdout);
+    std::this_thread::sleep_for(std::chrono::milliseconds(800));
+  }
   return 0;
 }
