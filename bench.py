@@ -172,6 +172,15 @@ class Telemetry:
 
         self.dirs = [d for d in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")
                      if os.path.exists(d + "/freq1_input") and os.path.exists(d + "/power1_input")]
+        # a box may show the hwmon files of GPUs that belong to other tenants: keep only the device this process computes on
+        try:
+            pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+            bdf = "%04x:%02x:%02x." % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            mine = [d for d in self.dirs if os.path.basename(os.path.realpath(os.path.join(d, "..", ".."))).lower().startswith(bdf)]
+            if mine:
+                self.dirs = mine
+        except (AttributeError, RuntimeError):
+            pass            # older torch: the busiest device is reported
 
     def _read(self):
         out = []
@@ -299,6 +308,8 @@ def family_rooflines(events, steps):
                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "launches_timed": len(conv), "launches_per_step": len(conv) // max(steps, 1),
                "ms_per_step": round(ms / max(steps, 1), 3), "algorithmic_tflop_per_step": round(fl / max(steps, 1) / 1e12, 3),
                "timing": "HIP event pairs around every launch inside the timed region"}
+        # against what a register-only MFMA loop sustains on random fp16 operands on this chip (see `roofline.sustained_source`)
+        row["frac_of_sustained"] = round((3 if fam == "conv3x3_split" else 1) * ach / SUSTAINED_MFMA_F16_RANDOM_TFLOPS, 4)
         if fam == "conv3x3_split":
             row["executed_mfma_tflops"] = round(3 * ach, 1)          # what the matrix pipe ran: 3 K segments
             row["frac_executed"] = round(3 * ach / PEAK_BF16_TFLOPS, 4)

@@ -136,8 +136,19 @@ static float randn() {   // Box-Muller on rand()
 
 int main(int argc, char** argv) {
   const double secs = argc > 1 ? atof(argv[1]) : 3.0;
-  const auto dirs = hwmon_dirs();
+  auto dirs = hwmon_dirs();
   hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
+  {   // a box may show the hwmon files of GPUs that belong to other tenants: keep the device this process computes on
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, sizeof(bdf), 0) == hipSuccess) {
+      std::vector<std::string> mine;
+      for (const auto& d : dirs) {
+        char real[4096];
+        if (realpath((d + "/../..").c_str(), real) && strcasestr(real, bdf)) mine.push_back(d);
+      }
+      if (!mine.empty()) dirs = mine;
+    }
+  }
   const int cus = prop.multiProcessorCount;
   const size_t n_frag = (size_t)61 * 4 * 6 * 64;              // u32x4 elements
   u32x4* d_frag; float* sink;
