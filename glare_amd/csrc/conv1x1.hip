@@ -37,6 +37,8 @@ struct C1Params {
   const a16_t* res_lo;   // hi / lo form (conv_igemm.hip's HILO epilogue): remainder halves of the residual and of the output
   a16_t* out;
   a16_t* out_lo;
+  const a16_t* x_lo;     // SPLIT (fp32-class form): remainder halves of the activation and of the filter
+  const a16_t* w_lo;
   float* gn_part;        // [B][rbi][Cout/4][2] or null
   int B, N;              // images, pixels per image
   int Cin, Cout;
@@ -63,8 +65,16 @@ __device__ __forceinline__ void with_act1(int act, F&& f) {
   }
 }
 
-template <int KSTEPS, bool HILO = false>   // Cin / 16
+// SPLIT (round 4): the fp32-class form of glare_conv_desc.k_wrap on this kernel -- x and w are hi / lo pairs and
+//   out = x_hi . w_hi + x_lo . w_hi + x_hi . w_lo     (fp32 accumulation; the dropped x_lo . w_lo is 2^-22)
+// on a 64-cout tile: the resident LDS image holds rows 0-63 = w_hi and rows 64-127 = w_lo of the SAME 64 output channels, so the
+// four accumulators of a row block are (x_hi . w_hi | x_hi . w_lo) and the x_lo fragments feed the first two only: 6 MFMAs per k-step
+// for 64 channels = 3 per product, both halves of x read once per co-tile.  The epilogue is the hi / lo one (fp32 through the slab,
+// nothing rounded before the residual add); out_lo == nullptr writes the 16-bit value alone.
+template <int KSTEPS, bool HILO = false, bool SPLIT = false>   // Cin / 16
 __global__ __launch_bounds__(256, 1) void conv1x1_ws_kernel(const C1Params p) {
+  static_assert(!SPLIT || HILO, "the split form uses the hi / lo epilogue");
+  constexpr int CT = SPLIT ? 64 : 128;           // output channels per tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ROWB = KSTEPS * 32;              // bytes of one weight row
   constexpr int CPR = ROWB / 16;                 // 16-B chunks per weight row (16 / 32 / 64)
@@ -89,13 +99,15 @@ __global__ __launch_bounds__(256, 1) void conv1x1_ws_kernel(const C1Params p) {
 
   // ---- weights of this co-tile into LDS, once: row r, chunk c at r * CPR + (c ^ (r & 15)) (source-side swizzle)
   {
-    const a16_t* wt = p.w + (size_t)w_img * p.w_istride + (size_t)ct * 128 * p.Cin;
+    const a16_t* wt = p.w + (size_t)w_img * p.w_istride + (size_t)ct * CT * p.Cin;
+    [[maybe_unused]] const a16_t* wl = SPLIT ? p.w_lo + (size_t)ct * CT * p.Cin : nullptr;
     const int r_in = lane / CPR, c_ph = lane % CPR;
 #pragma unroll 4
     for (int piece = wave; piece < 128 / RPP; piece += 4) {
       const int r = piece * RPP + r_in;
       const int c_src = c_ph ^ (r & 15);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wt + (size_t)r * p.Cin + c_src * 8),
+      const a16_t* wrow = (SPLIT && r >= 64) ? wl + (size_t)(r - 64) * p.Cin : wt + (size_t)r * p.Cin;   // a piece never straddles the halves
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wrow + c_src * 8),
                                        (__attribute__((address_space(3))) void*)(smem + piece * 1024), 16, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -112,26 +124,33 @@ __global__ __launch_bounds__(256, 1) void conv1x1_ws_kernel(const C1Params p) {
   for (int bb = 0; bb < 8; ++bb) boff[bb] = px * ROWB + ((((bb >> 2) * 8 + 4 * khalf + (bb & 3)) ^ (px & 15)) * 16);
   char* const slab = slab_base + wave * 8192;
 
-  const int co0 = ct * 128;
+  const int co0 = ct * CT;
   float bias_v[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) bias_v[j] = p.bias ? p.bias[(size_t)w_img * p.b_istride + co0 + 32 * j + px] : 0.f;
+  for (int j = 0; j < 4; ++j) bias_v[j] = (p.bias && (!SPLIT || j < 2)) ? p.bias[(size_t)w_img * p.b_istride + co0 + 32 * j + px] : 0.f;
 
   // A fragments are fetched one UNIT (16 k-steps = 16 KB per wave) ahead of the MFMAs that consume them: with one wave per SIMD
   // nothing else hides the memory latency (8 k-steps ahead left the kernel latency-bound at 1.3 TB/s), and two whole row blocks of
   // fragments (256 registers) spill -- a scratch reload in this loop waits vmcnt(0), i.e. for every prefetch in flight.
-  constexpr int UNIT = KSTEPS < 16 ? KSTEPS : 16, UPB = KSTEPS / UNIT;          // units per row block
+  constexpr int UNIT = SPLIT ? 8 : (KSTEPS < 16 ? KSTEPS : 16), UPB = KSTEPS / UNIT;          // units per row block (SPLIT: two fragment sets)
   auto unit_ptr = [&](int q) {                                                   // unit q of this wave: row block + k offset
     const int rb_ = rb_lo + wave + 4 * (q / UPB), u_ = q % UPB;
     const int b_ = rb_ / p.rbi, r0_ = (rb_ - b_ * p.rbi) * 32;
     const int nrows_ = min(32, p.N - r0_);
-    return p.x + ((size_t)b_ * p.N + r0_ + min(px, nrows_ - 1)) * p.xpitch + p.xoff + khalf * 32 + u_ * UNIT * 16;
+    return ((size_t)b_ * p.N + r0_ + min(px, nrows_ - 1)) * p.xpitch + p.xoff + khalf * 32 + u_ * UNIT * 16;     // element offset
   };
   const int n_rb = rb_hi > rb_lo + wave ? (rb_hi - rb_lo - wave + 3) / 4 : 0, n_units = n_rb * UPB;
   a16x8 af[2][UNIT];
+  [[maybe_unused]] a16x8 al[2][SPLIT ? UNIT : 1];
   auto fetch = [&](auto parc, int q) {
     constexpr int P = decltype(parc)::value;
-    const a16_t* ap = unit_ptr(q);
+    const size_t aoff = unit_ptr(q);
+    const a16_t* ap = p.x + aoff;
+    if constexpr (SPLIT) {
+      const a16_t* lp = p.x_lo + aoff;
+#pragma unroll
+      for (int e = 0; e < UNIT; ++e) al[P][e] = *reinterpret_cast<const a16x8*>(lp + (e >> 2) * 64 + (e & 3) * 8);
+    }
 #pragma unroll
     for (int e = 0; e < UNIT; ++e) {
 #if C1_ABL & 1   // timing ablation: no A loads
@@ -158,7 +177,7 @@ __global__ __launch_bounds__(256, 1) void conv1x1_ws_kernel(const C1Params p) {
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
       if (p.res) {   // the residual rows of this block, fetched NOW: they land under the MFMAs instead of stalling the epilogue
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
+        for (int it = 0; it < (SPLIT ? 4 : 8); ++it) {   // SPLIT: one 64-channel half
           // hi / lo form: the epilogue runs in two 64-channel halves, item it = 4 * half + t is row (lane >> 3) + 8 t, chunk 8 half + (lane & 7)
           const int m = HILO ? min((lane >> 3) + 8 * (it & 3), nrows - 1) : min((lane >> 4) + 4 * it, nrows - 1);
           const int chn = HILO ? 8 * (it >> 2) + (lane & 7) : (lane & 15);
@@ -180,6 +199,10 @@ __global__ __launch_bounds__(256, 1) void conv1x1_ws_kernel(const C1Params p) {
           bf[j] = *reinterpret_cast<const a16x8*>(smem + boff[e & 7] + (ks >> 3) * 256 + j * 32 * ROWB);
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = mfma_a16_32x32x16(af[P][e], bf[j], acc[j], 0, 0, 0);
+        if constexpr (SPLIT) {   // x_lo . w_hi: the first two accumulators only (rows 0-63 of the image are w_hi)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[j] = mfma_a16_32x32x16(al[P][e], bf[j], acc[j], 0, 0, 0);
+        }
       }
     };
     if ((q & 1) == 0) body(std::integral_constant<int, 0>{});
@@ -200,7 +223,7 @@ __global__ __launch_bounds__(256, 1) void conv1x1_ws_kernel(const C1Params p) {
       with_act1(p.act, [&](auto actc) {
       constexpr int ACT = decltype(actc)::value;
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
+      for (int hf = 0; hf < (SPLIT ? 1 : 2); ++hf) {
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
           const int j = 2 * hf + jj;
@@ -208,7 +231,9 @@ __global__ __launch_bounds__(256, 1) void conv1x1_ws_kernel(const C1Params p) {
           for (int r = 0; r < 16; ++r) {
             const int m = (r & 3) + 8 * (r >> 2) + 4 * khalf;
             const int col = 32 * jj + px;                                      // 0..63 within the half
-            *reinterpret_cast<float*>(slab + m * 256 + (((col >> 2) ^ (m & 15)) * 16) + (col & 3) * 4) = acc[j][r] + bias_v[j];
+            float v0 = acc[j][r] + bias_v[j];
+            if constexpr (SPLIT) v0 = (acc[jj][r] + acc[2 + jj][r]) + bias_v[jj];   // (x_hi.w_hi + x_lo.w_hi) + x_hi.w_lo
+            *reinterpret_cast<float*>(slab + m * 256 + (((col >> 2) ^ (m & 15)) * 16) + (col & 3) * 4) = v0;
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -220,7 +245,7 @@ __global__ __launch_bounds__(256, 1) void conv1x1_ws_kernel(const C1Params p) {
             const f32x4 f1 = *reinterpret_cast<const f32x4*>(slab + m * 256 + (((2 * c8 + 1) ^ (m & 15)) * 16));
             float v[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
             if (p.res) {
-              const u32x4 rv = resv[4 * hf + t], rl = resl[4 * hf + t];
+              const u32x4 rv = resv[4 * hf + t], rl = resl[4 * hf + t];   // (a 16-bit residual: res_lo == nullptr arrives as zeros)
 #pragma unroll
               for (int e = 0; e < 4; ++e) { v[2 * e] += alo(rv[e]) + alo(rl[e]); v[2 * e + 1] += ahi(rv[e]) + ahi(rl[e]); }
             }
@@ -234,7 +259,7 @@ __global__ __launch_bounds__(256, 1) void conv1x1_ws_kernel(const C1Params p) {
             }
             const size_t o = (pix0 + m) * p.opitch + p.ooff + co0 + (8 * hf + c8) * 8;
             *reinterpret_cast<u32x4*>(p.out + o) = hi;
-            *reinterpret_cast<u32x4*>(p.out_lo + o) = lo;
+            if (!SPLIT || p.out_lo) *reinterpret_cast<u32x4*>(p.out_lo + o) = lo;
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -386,6 +411,7 @@ static int c1_launch(const void* x, int x_pitch, int x_off, const void* w_bf16, 
   p.x = (const a16_t*)x; p.w = (const a16_t*)w_bf16; p.bias = bias; p.res = (const a16_t*)residual; p.out = (a16_t*)out;
   p.gn_part = gn_partial;
   p.res_lo = (const a16_t*)residual_lo; p.out_lo = (a16_t*)out_lo;
+  p.x_lo = nullptr; p.w_lo = nullptr;
   if (residual_lo && !(residual && out_lo)) return GLARE_ERR_INVALID;
   p.B = B; p.N = (int)pixels_per_image; p.Cin = Cin; p.Cout = Cout;
   p.xpitch = x_pitch; p.xoff = x_off; p.opitch = out_pitch; p.ooff = out_off; p.rpitch = res_pitch; p.roff = res_off;
@@ -422,6 +448,48 @@ extern "C" int glare_conv1x1_ws_image_bf16(const void* x, int x_pitch, int x_off
   if (w_image_stride <= 0) return GLARE_ERR_INVALID;
   return c1_launch(x, x_pitch, x_off, w_bf16, w_image_stride, bias, bias_image_stride, residual, res_pitch, res_off, out, out_pitch, out_off,
                    B, pixels_per_image, Cin, Cout, act, gn_partial, stream);
+}
+
+// The fp32-class form (SPLIT, see conv1x1_ws_kernel): activation and filter as hi / lo pairs of 16-bit tensors, 64-cout tiles.
+extern "C" int glare_conv1x1_ws_split_supported(int Cin, int Cout) {
+  if (Cin != 128 && Cin != 256 && Cin != 512) return 0;
+  if (Cout <= 0 || Cout % 64) return 0;
+  const int nct = Cout / 64;
+  return (nct <= 32 && 32 % nct == 0) ? 1 : 0;
+}
+
+extern "C" int glare_conv1x1_ws_split_bf16(const void* x_hi, const void* x_lo, int x_pitch, int x_off, const void* w_hi, const void* w_lo,
+                                           const float* bias, const void* residual, const void* residual_lo, int res_pitch, int res_off,
+                                           void* out, void* out_lo, int out_pitch, int out_off, int B, long long pixels_per_image, int Cin,
+                                           int Cout, int act, float* gn_partial, glare_stream_t stream) {
+  if (!x_hi || !x_lo || !w_hi || !w_lo || !out || B <= 0 || pixels_per_image <= 0) return GLARE_ERR_INVALID;
+  if (!glare_conv1x1_ws_split_supported(Cin, Cout)) return GLARE_ERR_UNSUPPORTED;
+  if ((x_pitch % 8) || (x_off % 8) || (out_pitch % 8) || (out_off % 8) || x_off + Cin > x_pitch || out_off + Cout > out_pitch)
+    return GLARE_ERR_UNSUPPORTED;
+  if (residual && ((res_pitch % 8) || (res_off % 8) || res_off + Cout > res_pitch)) return GLARE_ERR_UNSUPPORTED;
+  if (residual_lo && !residual) return GLARE_ERR_INVALID;
+  if (gn_partial && Cout % 128) return GLARE_ERR_UNSUPPORTED;      // the statistics block is per 128-channel... group layout of gn_reduce
+  if (pixels_per_image > 0x7fffffffLL || (long long)B * cdivll(pixels_per_image, 32) > 0x7fffffffLL) return GLARE_ERR_INVALID;
+  C1Params p;
+  p.x = (const a16_t*)x_hi; p.x_lo = (const a16_t*)x_lo; p.w = (const a16_t*)w_hi; p.w_lo = (const a16_t*)w_lo; p.bias = bias;
+  p.res = (const a16_t*)residual; p.res_lo = (const a16_t*)residual_lo; p.out = (a16_t*)out; p.out_lo = (a16_t*)out_lo;
+  p.gn_part = gn_partial;
+  p.B = B; p.N = (int)pixels_per_image; p.Cin = Cin; p.Cout = Cout;
+  p.xpitch = x_pitch; p.xoff = x_off; p.opitch = out_pitch; p.ooff = out_off; p.rpitch = res_pitch; p.roff = res_off;
+  p.act = act; p.nct = Cout / 64; p.rbi = (int)cdivll(pixels_per_image, 32);
+  p.w_istride = 0; p.b_istride = 0;
+  const size_t lds = (size_t)128 * Cin * 2 + 4 * 8192;
+  hipStream_t s = (hipStream_t)stream;
+#define C1S_CASE(KS_)                                                                                                              \
+  if (Cin == 16 * KS_) {                                                                                                           \
+    if (hipFuncSetAttribute((const void*)conv1x1_ws_kernel<KS_, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+      return GLARE_ERR_LAUNCH;                                                                                                     \
+    hipLaunchKernelGGL((conv1x1_ws_kernel<KS_, true, true>), dim3(256), dim3(256), lds, s, p);                                     \
+    return glare_launch_status();                                                                                                  \
+  }
+  C1S_CASE(8) C1S_CASE(16) C1S_CASE(32)
+#undef C1S_CASE
+  return GLARE_ERR_UNSUPPORTED;
 }
 
 // hi / lo form of both entry points above (w_image_stride = 0: one filter for all images): the output leaves as hi = round16(v) in

@@ -114,8 +114,16 @@ class PackedConv:
                                                      stream_handle()), "glare_conv2d_pack_weight_dgrad")
         self.bias = None if bias is None else bias.detach().float().contiguous()
         self.w16 = None
+        self.w16_lo = None
         if split:
             self.cin = cin // split          # the conv's own input channels; the packed image holds `split` K segments of them
+            if kh == 1 and split == 3 and lib.glare_conv1x1_ws_split_supported(_i(self.cin), _i(cout)):
+                # the fp32-class form on the weight-stationary kernel: the two halves of the filter as plain [Cout][Cin] images
+                # (segment 0 of `w` is the fp32 filter -- the pack kernel rounds it to w_hi --, segment 2 is w_lo)
+                w2 = w.reshape(cout, 3, self.cin)
+                self.w16, self.w16_lo = (torch.empty(cout, self.cin, dtype=act_dtype(), device=w.device) for _ in range(2))
+                for src, dst in ((w2[:, 0].contiguous(), self.w16), (w2[:, 2].contiguous(), self.w16_lo)):
+                    check(lib.glare_conv1x1_ws_pack_weight(ptr(src), _i(cout), _i(self.cin), ptr(dst), stream_handle()), "glare_conv1x1_ws_pack_weight")
         if kh == 1 and dgrad_pad is None and not split and lib.glare_conv1x1_ws_supported(_i(cin), _i(cout)):
             # the weight-stationary 1x1 kernel (csrc/conv1x1.hip) takes the filter as plain bf16 [Cout][Cin]
             self.w16 = torch.empty(cout, cin, dtype=act_dtype(), device=w.device)
@@ -331,6 +339,42 @@ def _conv1x1_ws(x, pc, cin, in_off, act, residual, res_off, out, out_off, gn_sta
     return out
 
 
+def _conv1x1_ws_split(x, pc, cin, in_off, act, residual, res_off, out, out_off, gn_stats, hilo):
+    """The fp32-class 1x1 conv (PackedConv(split=3)) on the weight-stationary kernel (glare_conv1x1_ws_split_bf16): x and the filter as
+    hi / lo pairs, the output a pair (hilo) or its 16-bit rounding."""
+    xlo = getattr(x, "_lo", None)
+    assert xlo is not None and xlo.shape == x.shape and xlo.dtype == x.dtype and xlo.is_contiguous(), "a split-3 filter contracts the activation's hi / lo pair"
+    B, H, W, pitch = x.shape
+    N = H * W
+    if out is None:
+        out = torch.empty(B, H, W, pc.cout, dtype=act_dtype(), device=x.device)
+    lib = _lib.lib()
+    gn_part = None
+    if gn_stats:
+        lib.glare_conv1x1_ws_gn_partial_elems.restype = _ll
+        gn_part = torch.empty(lib.glare_conv1x1_ws_gn_partial_elems(_i(B), _ll(N), _i(pc.cout)), dtype=torch.float32, device=x.device)
+    out_lo = rlo = None
+    if hilo:
+        out_lo = getattr(out, "_lo", None)
+        if out_lo is None:
+            out_lo = torch.empty_like(out)
+    if residual is not None:
+        assert residual.dtype == act_dtype() and residual.is_contiguous()
+        rlo = getattr(residual, "_lo", None)
+    check(lib.glare_conv1x1_ws_split_bf16(ptr(x), ptr(xlo), _i(pitch), _i(in_off), ptr(pc.w16), ptr(pc.w16_lo), ptr(pc.bias), ptr(residual),
+                                          ptr(rlo), _i(residual.shape[3] if residual is not None else 0), _i(res_off), ptr(out), ptr(out_lo),
+                                          _i(out.shape[3]), _i(out_off), _i(B), _ll(N), _i(cin), _i(pc.cout), _i(ACT[act]), ptr(gn_part),
+                                          stream_handle()), "glare_conv1x1_ws_split_bf16")
+    if gn_stats:
+        stats = torch.empty(B, 1, 32, 2, dtype=torch.float32, device=x.device)
+        check(lib.glare_conv1x1_ws_gn_reduce(ptr(gn_part), ptr(stats), _i(B), _ll(N), _i(pc.cout), stream_handle()),
+              "glare_conv1x1_ws_gn_reduce")
+        out._gn_stats = stats
+    if out_lo is not None:
+        out._lo = out_lo
+    return out
+
+
 def _conv1x1_ws_plain(lib, x, pitch, in_off, pc, residual, res_off, out, out_off, B, N, cin, act, gn_part):
     check(lib.glare_conv1x1_ws_bf16(ptr(x), _i(pitch), _i(in_off), ptr(pc.w16), ptr(pc.bias), ptr(residual),
                                     _i(residual.shape[3] if residual is not None else 0), _i(res_off), ptr(out), _i(out.shape[3]),
@@ -453,13 +497,18 @@ def conv2d(x, pc, *, x2=None, cin=None, in_off=0, cin2=None, in2_off=0, stride=1
     if hilo and pc.ksize == 1 and not split:
         assert x2 is None and stride == 1 and not upsample and out is None and cin == pc.cin and getattr(pc, "w16", None) is not None
         return _conv1x1_ws(x, pc, cin, in_off, act, residual, res_off, None, 0, gn_stats, hilo=True)
-    if (CONV1X1_WEIGHT_STATIONARY and getattr(pc, "w16", None) is not None and x2 is None and stride == 1 and not upsample
+    if (CONV1X1_WEIGHT_STATIONARY and getattr(pc, "w16", None) is not None and not split and x2 is None and stride == 1 and not upsample
             and out_mode == OUT_NHWC_BF16 and cin == pc.cin and pitch % 8 == 0 and in_off % 8 == 0
             and (out is None or (out.dtype == act_dtype() and out.shape[3] % 8 == 0 and out_off % 8 == 0))
             and (residual is None or (residual.shape[3] % 8 == 0 and res_off % 8 == 0)) and (not gn_stats or out is None)):
         if residual is not None:
             assert residual.dtype == act_dtype() and residual.is_contiguous()
         return _conv1x1_ws(x, pc, cin, in_off, act, residual, res_off, out, out_off, gn_stats)
+    if (split == 3 and pc.ksize == 1 and CONV1X1_WEIGHT_STATIONARY and getattr(pc, "w16_lo", None) is not None and x2 is None and stride == 1
+            and not upsample and out_mode == OUT_NHWC_BF16 and cin == pc.cin and pitch % 8 == 0 and in_off % 8 == 0 and gn_prologue is None
+            and (out is None or (out.dtype == act_dtype() and out.shape[3] % 8 == 0 and out_off % 8 == 0 and (not hilo or (out_off == 0 and out.shape[3] == pc.cout))))
+            and (residual is None or (residual.shape[3] % 8 == 0 and res_off % 8 == 0)) and (not gn_stats or (pc.cout % 128 == 0 and (out is None or (out_off == 0 and out.shape[3] == pc.cout))))):
+        return _conv1x1_ws_split(x, pc, cin, in_off, act, residual, res_off, out, out_off, gn_stats, hilo)
     d = ConvDesc()
     d.in_, d.in2 = x.data_ptr(), (x2.data_ptr() if x2 is not None else None)
     d.B, d.H, d.W = B, H, W

@@ -324,6 +324,18 @@ int glare_conv1x1_ws_hilo_bf16(const void* x, int x_pitch, int x_off, const void
                                const float* bias, int bias_image_stride, const void* residual, const void* residual_lo,
                                int res_pitch, int res_off, void* out, void* out_lo, int out_pitch, int out_off, int B,
                                long long pixels_per_image, int Cin, int Cout, int act, float* gn_partial, glare_stream_t stream);
+
+/* The fp32-class form on the weight-stationary kernel (round 4; glare_conv_desc.k_wrap for the path's 1x1 convs with Cin in {128, 256,
+ * 512} and Cout a multiple of 64 dividing 2048: the conditional encoder's nin_shortcuts and its AttnBlocks' folded query / output
+ * projections, encoder_decoder.py:104-115,146-165 -- nn.Conv2d in fp32 there).  Activation and filter are hi / lo pairs of 16-bit
+ * tensors (x_lo: same pitch / offset as x_hi; w_hi / w_lo: [Cout][Cin] from glare_conv1x1_ws_pack_weight on the two halves of the
+ * fp32 filter); out = x_hi.w_hi + x_lo.w_hi + x_hi.w_lo + bias + residual (+ residual_lo) in fp32, then act; written as the pair
+ * (out, out_lo) or, with out_lo == NULL, as its 16-bit rounding alone.  gn_partial as in glare_conv1x1_ws_bf16 (Cout % 128 == 0). */
+int glare_conv1x1_ws_split_supported(int Cin, int Cout);
+int glare_conv1x1_ws_split_bf16(const void* x_hi, const void* x_lo, int x_pitch, int x_off, const void* w_hi, const void* w_lo,
+                                const float* bias, const void* residual, const void* residual_lo, int res_pitch, int res_off, void* out,
+                                void* out_lo, int out_pitch, int out_off, int B, long long pixels_per_image, int Cin, int Cout, int act,
+                                float* gn_partial, glare_stream_t stream);
 int glare_attn_fold_groupnorm_f32(const float* stats, int splits, int B, long long HW, int C, const float* gamma, const float* beta,
                                   float eps, const float* wq, const float* bq, const float* wo, const float* bo, void* wq_out,
                                   float* bq_out, void* wo_out, float* bo_out, glare_stream_t stream);

@@ -166,3 +166,45 @@ def test_attention_pair_output_keeps_the_accumulators(B, N):
     # the pair removes the STORAGE rounding: against the kernel's own fp32 result (hi + lo) hi is 2^-12-ish, lo exact to 2^-22
     assert float((a._lo.float().abs().max())) > 0
     assert float((a._lo.float().abs() / (a.float().abs() + 1e-3)).max()) < 2.0 ** -10
+
+
+@pytest.mark.parametrize("cin,cout,H,W", [(128, 256, 9, 37), (256, 512, 7, 45), (512, 512, 11, 29), (512, 64, 5, 33), (256, 128, 8, 32)])
+def test_split3_1x1_on_the_weight_stationary_kernel(cin, cout, H, W):
+    """glare_conv1x1_ws_split_bf16 (round 4): the fp32-class 1x1 convs of the conditional encoder (nin_shortcut, AttnBlock's folded
+    query / output projections) on the weight-stationary kernel, 64-cout tiles with (w_hi | w_lo) resident.  Three modes -- pair out,
+    16-bit out, pair residual + fused statistics -- against F.conv2d in fp32 on the unrounded operands and against the implicit-GEMM
+    launch of the same PackedConv (ops.CONV1X1_WEIGHT_STATIONARY = False); ragged pixel counts (H * W not a multiple of 32)."""
+    g = torch.Generator().manual_seed(cin + cout + H)
+    B = 2
+    x = torch.randn((B, cin, H, W), generator=g)
+    r = torch.randn((B, cout, H, W), generator=g)
+    w = torch.randn((cout, cin, 1, 1), generator=g) / cin ** 0.5
+    b = torch.randn((cout,), generator=g) * 0.1
+    ref = F.conv2d(x.cuda(), w.cuda(), b.cuda())
+    with ops.use_precision("fp16"):
+        xp, rp = _pair(x), _pair(r)
+        pc = ops.PackedConv(w.cuda(), b.cuda(), split=3)
+        assert pc.w16_lo is not None
+        got = {}
+        for ws in (True, False):
+            ops.CONV1X1_WEIGHT_STATIONARY = ws
+            try:
+                pair = ops.conv2d(xp, pc, hilo=True)
+                plain = ops.conv2d(xp, pc, act="relu")
+                full = ops.conv2d(xp, pc, residual=rp, hilo=True, gn_stats=(cout % 128 == 0))
+            finally:
+                ops.CONV1X1_WEIGHT_STATIONARY = True
+            got[ws] = (pair, plain, full)
+        pair, plain, full = got[True]
+        within(_err(_val(pair), ref), 1.9e-6, "pair")                                     # measured <= 9.5e-7
+        assert plain._lo is None if hasattr(plain, "_lo") else True
+        within(_err(plain.float(), F.relu(ref)), 8.8e-4, "16-bit")                         # measured 4.4e-4: one fp16 rounding of the output
+        within(_err(_val(full), ref + r.cuda()), 1.6e-6, "residual")                     # measured <= 7.7e-7
+        # the two kernels agree to fp32 summation order
+        within(_err(_val(pair), _val(got[False][0]).permute(0, 3, 1, 2)), 2.3e-6, "vs igemm")          # measured <= 1.13e-6
+        assert torch.equal(plain, got[False][1]) or _err(plain.float(), got[False][1].float().permute(0, 3, 1, 2)) < 6e-4
+        if cout % 128 == 0:     # fused statistics: GroupNorm of the pair from them equals GroupNorm of the fp32 value
+            gamma, beta = torch.rand(cout, generator=g).cuda() + 0.5, torch.randn(cout, generator=g).cuda() * 0.1
+            y = ops.groupnorm(full, gamma, beta, swish=False, pair=True)
+            yref = F.group_norm(ref + r.cuda(), 32, gamma, beta, 1e-6)
+            within(_err(_val(y), yref), 1.5e-6, "gn")                                        # measured <= 7.2e-7
