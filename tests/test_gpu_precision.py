@@ -262,7 +262,7 @@ BOUNDS = {
     (400, "adversarial", "bf16"): (0.970, 27.6, 3.4),        # 0.98415, 30.60 dB, 1.70 dB
     (400, "adversarial", "fp16"): (0.99988, 60.6, 0.01),     # 0.99994, 63.65 dB, 0.0020 dB (round 3: 0.99853, 40.57 dB, 0.22 dB)
     (400, "representative", "bf16"): (0.30, 32.2, 1.07),     # 0.47637, 35.19 dB, 0.53 dB
-    (400, "representative", "fp16"): (0.9995, 61.8, 0.01),   # 0.99975, 64.89 dB, 0.0007-0.0028 dB (round 3: 0.94015, 46.16 dB, 0.041 dB); 12 scenes: the next test
+    (400, "representative", "fp16"): (0.9995, 61.8, 0.01),   # 0.99969, 64.85 dB, 0.0023 dB (round 3: 0.94015, 46.16 dB, 0.041 dB); 12 scenes: the next test
     (100, "adversarial", "bf16"): (0.950, 25.5, 5.1),        # 0.97576, 28.48 dB, 2.54 dB
     (100, "adversarial", "fp16"): (0.9984, 63.2, 0.01),      # 1.00000 (bit-exact; bound = 2 of 1 320 tokens), 66.21 dB, 0.0028 dB
     (100, "representative", "bf16"): (0.30, 33.4, 0.76),     # 0.51742, 36.47 dB, 0.38 dB
@@ -323,7 +323,7 @@ SCENES = tuple(range(11, 23))       # 12 scenes, incl. the two (13, 15) that mis
 def test_end_to_end_full_size_twelve_scenes(capsys):
     """BASELINE.json: "codebook indices bit-exact and output PSNR within 0.05 dB of reference" -- the default path at 400x600 on
     TWELVE scenes against the fp32 oracle, its own codebook indices, asserted per scene.  Measured on MI355X
-    (profiles/r04_parity_table.txt): index agreement 0.99926-0.99975 (4-12 tokens of 16 275 differ), |dPSNR vs GT| 0.0013-0.0044 dB,
+    (profiles/r04_parity_table.txt): index agreement 0.99926-0.99969 (5-12 tokens of 16 275 differ), |dPSNR vs GT| 0.0017-0.0048 dB,
     PSNR(ours, oracle) 57.2-65.0 dB, latent error 1.2-1.4e-5.  Bounds: 2x the measured miss; 0.01 dB (a fifth of the tolerance) for
     the PSNR delta, which sits at the metric's noise floor (the same figure with the oracle's indices forced: 0.0008-0.0047 dB)."""
     rows = []
@@ -345,15 +345,15 @@ def test_end_to_end_full_size_twelve_scenes(capsys):
         within(lat, 2.8e-5)                        # measured max 1.42e-5
         within(1.0 - agree, 1.47e-3)               # measured max 7.4e-4 (12 tokens)
         assert psnr >= 54.2, (seed, psnr)          # measured min 57.22 dB
-        within(delta, 0.0088)                      # measured max 0.0044 dB; BASELINE: 0.05
+        within(delta, 0.0088)                      # measured max 0.0048 dB; BASELINE: 0.05
 
 
 @pytest.mark.parametrize("regime,seed", [("representative", 105), ("representative2", 101), ("representative2", 102)])
 def test_end_to_end_full_size_held_out(regime, seed, capsys):
     """Scenes and weights that played no part in choosing the precision scheme: a held-out scene on the usual weights (105: the worst
-    of 12 held-out scenes, 15 tokens differ) and two scenes on a SECOND trained-like weight set (another codebook, other ActNorm states
+    of 12 held-out scenes, 12 tokens differ) and two scenes on a SECOND trained-like weight set (another codebook, other ActNorm states
     and filters; PARITY_WEIGHT_SEED=1 in tools/parity_scenes.py).  Measured (profiles/r04_parity_table.txt, second half): agreement
-    0.99908 / 1.00000 (all 16 275 indices bit-exact) / 0.99951, |dPSNR vs GT| 0.0028 / 0.0009 / 0.0003 dB, latent 1.41e-5 / 1.05e-5 /
+    0.99926 / 0.99988 (2 of 16 275 tokens) / 0.99957, |dPSNR vs GT| 0.0035 / 0.0012 / 0.0001 dB, latent 1.43e-5 / 1.05e-5 /
     0.95e-5.  Same bounds as the twelve-scene test (only the agreement bound is 2x this test's own worst case)."""
     og, ov, pg, pv, lr, ref = setup(regime, 400, 600, seed)
     with torch.no_grad():
@@ -365,10 +365,10 @@ def test_end_to_end_full_size_held_out(regime, seed, capsys):
     with capsys.disabled():
         print("\n[e2e 400x600 %s seed %d] latent rel %.2e | index agreement %.5f | PSNR(ours,oracle) %.2f dB | |dPSNR vs GT| %.4f dB"
               % (regime, seed, lat, agree, full["psnr_vs_oracle"], full["delta"]))
-    within(lat, 2.8e-5)                 # measured max 1.41e-5
-    within(1.0 - agree, 1.84e-3)        # measured max 9.2e-4 (15 tokens)
+    within(lat, 2.8e-5)                 # measured max 1.43e-5
+    within(1.0 - agree, 1.47e-3)        # measured max 7.4e-4 (12 tokens)
     assert full["psnr_vs_oracle"] >= 54.2, full
-    within(full["delta"], 0.0056)       # measured max 0.0028 dB; BASELINE: 0.05
+    within(full["delta"], 0.0070)       # measured max 0.0035 dB; BASELINE: 0.05
 
 
 @pytest.mark.parametrize("h,w", [(60, 92), (132, 72), (36, 28)])
