@@ -25,6 +25,8 @@
 // and each of the 4 corners is dropped individually when it lies outside the image.
 #include <atomic>
 
+#include <type_traits>
+
 #include "common.h"
 #include "dcn_generic.h"
 
@@ -248,6 +250,9 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_kernel(const DcnParams p) 
 // matter: LDS barriers, counted vs full s_waitcnt, buffer vs global loads, scalar-offset operands, out-of-range loads; loads
 // of one wave do return in issue order (tools/probes/vmcnt_order_probe.hip).  The same blend in scalar fp32 is bit-stable
 // over every shape of tools/determinism_check.py and just as fast (the kernel is not VALU-bound enough to notice).
+#ifndef DCN_PC
+#define DCN_PC 0
+#endif
 #ifndef DCN_ABL
 #define DCN_ABL 0   // timing ablations only (tools/ablate.sh): 1 no weight loads, 2 no corner loads, 4 no MFMA, 8 no offset loads, 16 no blend / split arithmetic
 #endif
@@ -574,6 +579,17 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_fast_kernel(const DcnParam
   }
 }
 
+// The producer / consumer form of this kernel (consumer waves own the accumulators, producer waves the gather with 2-3 corner sets in
+// flight; bit-identical results, 45 parity / determinism tests green) measured 4.0-4.2 ms instead of 2.9 (C = 128) and 2.9-3.1 instead
+// of 2.25 (C = 256), the same for a gather depth of 2 and of 3: the stage time is not exposed gather LATENCY that more loads in flight
+// could hide.  It lives in tools/experiments/dcn_pc.inc (GLARE_DEFS="-DGLARE_ABLATE -DDCN_PC=2").
+#if DCN_PC
+#ifndef GLARE_ABLATE
+#error "DCN_PC is an experiment: build with GLARE_DEFS='-DGLARE_ABLATE -DDCN_PC=2'"
+#endif
+#include "dcn_pc.inc"
+#endif
+
 // [Co][C][kh][kw] fp32 (reference layout) -> split-bf16 B-fragment image
 // [stage = g*K + tap][c/8][Co][hi: 8 bf16 | lo: 8 bf16]  (same byte count as the fp32 filter)
 __global__ void dcn_pack_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ wt, int Co, int C, int K, int dg) {
@@ -644,6 +660,16 @@ int launch_dcn_fast(const DcnParams& p, bool single, hipStream_t stream) {
   const int pix = 64;
   const size_t lds = (size_t)2 * (single ? 1 : 2) * nch * pix * 16 + (size_t)2 * 3 * pix * 36;   // sample tiles + sampling plan
   const unsigned blocks = (unsigned)((p.total_pix + pix - 1) / pix);
+#if DCN_PC     // the producer / consumer form (split contraction only): DCN_PC = gather depth (2 or 3)
+  if (!single && nt == 2 && nch == 4) {
+    hipLaunchKernelGGL((dcn_fwd_pc_kernel<4, 4, 2, 2, DCN_PC>), dim3(blocks), dim3(256), lds, stream, p);
+    return glare_launch_status();
+  }
+  if (!single && nt == 4 && nch == 8) {
+    hipLaunchKernelGGL((dcn_fwd_pc_kernel<4, 8, 4, 4, DCN_PC>), dim3(blocks), dim3(512), lds, stream, p);
+    return glare_launch_status();
+  }
+#endif
 #define DCN_FAST(NT_, NCH_)                                                                                  \
   if (nt == NT_ && nch == NCH_) {                                                                            \
     if (single)                                                                                              \
