@@ -250,6 +250,12 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_kernel(const DcnParams p) 
 // matter: LDS barriers, counted vs full s_waitcnt, buffer vs global loads, scalar-offset operands, out-of-range loads; loads
 // of one wave do return in issue order (tools/probes/vmcnt_order_probe.hip).  The same blend in scalar fp32 is bit-stable
 // over every shape of tools/determinism_check.py and just as fast (the kernel is not VALU-bound enough to notice).
+#ifndef DCN_WN2
+#define DCN_WN2 0
+#endif
+#ifndef DCN_MT4
+#define DCN_MT4 0
+#endif
 #ifndef DCN_PC
 #define DCN_PC 0
 #endif
@@ -260,10 +266,15 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_kernel(const DcnParams p) 
 // SINGLE = true (GLARE_MDCN_SINGLE_PASS): the blended sample and the filter are rounded ONCE to the library's 16-bit activation
 // format and contracted by one MFMA per product -- the arithmetic of every other convolution on the path (16-bit operands, fp32
 // accumulation) instead of the split form's 3 MFMAs; half the sample tile in LDS, half the fragment reads and weight loads.
-template <int NT, int NCH, int MT, bool SINGLE = false>
+// WN = waves along the output channels (2 or 4; 4 / WN along the pixels).  WN = 4 with MT = 2 (round 4, late): every wave covers all 64
+// pixels and its own Co / 4 output channels, so no two waves of the workgroup fetch the same weight fragments -- with WN = 2 the two
+// wave rows each load all of them, and the texture-path counters say that is what this kernel is bound by: TA_BUSY 79 % of the launch,
+// 57 GB through the L1 per launch of which 37.5 GB weight fragments and 19 GB gathered corners (profiles/r04_pmc_dcn_ta.txt).
+// Measured (fp16, one box, alternated): 2.90 -> 2.64 ms at C = 128, 2.23 -> 2.09 ms at C = 256; results bit-identical.
+template <int NT, int NCH, int MT, bool SINGLE = false, int WN = 2>
 __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_fast_kernel(const DcnParams p) {
   constexpr int HL = SINGLE ? 1 : 2;                // 16-bit planes of the sample tile (hi | lo, or the one rounded value)
-  constexpr int PIX = 64 * MT;
+  constexpr int PIX = 32 * MT * (4 / WN);
   constexpr int ITEMS = PIX * NCH / DC_THREADS;
   constexpr int KSN = NCH / 2;                      // 16-channel MFMA k-steps per stage
   constexpr int CT = 3;                             // taps per staged sampling-plan chunk (K % 3 == 0 on this path)
@@ -278,7 +289,7 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_fast_kernel(const DcnParam
   const int n_stages = p.dg * K, n_chunks = n_stages / CT;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   // XCD-aware order: workgroups are dispatched round-robin over the 8 XCDs, so XCD j takes the j-th contiguous eighth of the
   // pixel tiles -- vertically adjacent tiles (which gather from the same rows of x) then share one L2 instead of eight
   unsigned tile = blockIdx.x;
@@ -660,6 +671,25 @@ int launch_dcn_fast(const DcnParams& p, bool single, hipStream_t stream) {
   const int pix = 64;
   const size_t lds = (size_t)2 * (single ? 1 : 2) * nch * pix * 16 + (size_t)2 * 3 * pix * 36;   // sample tiles + sampling plan
   const unsigned blocks = (unsigned)((p.total_pix + pix - 1) / pix);
+#if !DCN_WN2   // split form: four waves along Co (no duplicated weight-fragment loads); DCN_WN2=1 restores the 2 x 2 wave layout
+  if (!single && nch % 2 == 0 && (p.Co == 128 || p.Co == 256)) {
+#define DCN_WN4(NT_, NCH_)                                                                                                       \
+    if (p.Co == 128 * NT_ && nch == NCH_) {                                                                                       \
+      hipLaunchKernelGGL((dcn_fwd_fast_kernel<NT_, NCH_, 2, false, 4>), dim3(blocks), dim3(DC_THREADS), lds, stream, p);          \
+      return glare_launch_status();                                                                                               \
+    }
+#if DCN_MT4   // experiment: 128-pixel workgroups in this layout (half the weight-fragment loads per pixel again; 60 KB of LDS: 2 workgroups / CU):
+              // measured 2.80 ms against 2.64 (C = 128, fp16) -- the occupancy is worth more; kept off
+    if (p.Co == 128 && nch == 4) {
+      const size_t lds4 = (size_t)2 * 2 * nch * 128 * 16 + (size_t)2 * 3 * 128 * 36;
+      hipLaunchKernelGGL((dcn_fwd_fast_kernel<1, 4, 4, false, 4>), dim3((unsigned)((p.total_pix + 127) / 128)), dim3(DC_THREADS), lds4, stream, p);
+      return glare_launch_status();
+    }
+#endif
+    DCN_WN4(1, 4) DCN_WN4(2, 4) DCN_WN4(1, 8) DCN_WN4(2, 8)
+#undef DCN_WN4
+  }
+#endif
 #if DCN_PC     // the producer / consumer form (split contraction only): DCN_PC = gather depth (2 or 3)
   if (!single && nt == 2 && nch == 4) {
     hipLaunchKernelGGL((dcn_fwd_pc_kernel<4, 4, 2, 2, DCN_PC>), dim3(blocks), dim3(256), lds, stream, p);
