@@ -380,11 +380,17 @@ def train_block(device, rank, world, steps=8, warmup=3):
         from glare_amd.train import GraphedStep, Stage2Trainer, Stage3Trainer
 
         net_hq = seeded_init_(M.VQModel().eval(), 1).to(device)
-    # bf16 (fp32 range, no loss scaling) and fp16 (the reference's AMP form: `scaler.scale(loss).backward()`, LLFlow_model.py:236-241;
-    # the loss times the device-resident scale, divided out inside the Adam kernel) -- "stage2_*" keys are bf16 as in earlier rounds
-    runs = [("stage2", 2, 320, "bf16"), ("stage3", 1, 256, "bf16")]
+    # PRIMARY keys ("stage2_*", "stage3_*") = fp16, the reference's own AMP form and the trainers' default (`@autocast()` forward +
+    # `scaler.scale(loss).backward()`, LLFlow_model.py:236-241: the loss times the device-resident scale, divided out inside the Adam
+    # kernel) -- the precision every gradient-parity bound of tests/test_gpu_train.py is stated in.  bf16 is reported BESIDE it
+    # ("*_bf16_*") with its measured gradient error in `bf16_note`: it carries no parity claim.
+    runs = [("stage2", 2, 320, "fp16"), ("stage3", 1, 256, "fp16")]
     if not STUB:
-        runs += [("stage2_fp16", 2, 320, "fp16"), ("stage3_fp16", 1, 256, "fp16")]
+        runs += [("stage2_bf16", 2, 320, "bf16"), ("stage3_bf16", 1, 256, "bf16")]
+        res["bf16_note"] = ("bf16 activations / activation gradients (fp32 range, no loss scaling): per-parameter-tensor gradient error against "
+                            "fp32 autograd of the oracle, median / max -- stage-2 objective 0.36 % / 2.3 % (fp16: 0.06 % / 0.35 %), AFT decoder "
+                            "at the stage-3 crop on the pipeline's own inputs 8.2 % / 32 % (fp16: 2.05 % / 5.2 %; the reference's own fp16 "
+                            "autocast against its fp32 self: 3.3 % median, tools/amp_noise.py).  Offered as precision=\"bf16\", not the default")
     for name, B, S, precision in runs:
         graph = world == 1 and name.startswith("stage2") and not STUB
         if STUB:
@@ -444,6 +450,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="BASELINE configs[2] as written: the GLOBAL batch, split evenly over the ranks (`--gpus 8 --global-batch 32` = 4 images "
+                         "per GPU, strong scaling).  Default: unset = `--batch` images per GPU at every N (weak scaling, configs[1] per rank)")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams the steps are issued on round-robin.  1 (default): steps run back to back and the "
                          "roofline's per-launch event timing is the kernel's own duration.  2: consecutive batches overlap (the "
@@ -474,6 +483,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.global_batch is not None:
+        assert args.global_batch > 0 and args.global_batch % args.gpus == 0, "--global-batch must divide evenly over --gpus"
+        args.batch = args.global_batch // args.gpus
     assert STUB or torch.cuda.is_available(), "bench.py needs an MI355X (the HIP kernels are the only implementation)"
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d: launch one rank per GPU (or let bench.py do it)" % (args.gpus, world)
     if STUB:
@@ -572,9 +584,16 @@ def main():
         res = {
             "metric": "enhanced images/sec (400x600)", "value": round(total_images / dt, 3), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "LOL eval15-shaped 400x600 inference, batch=8 per GPU, full encoder->flow->VQ->decoder->AFT "
-                                   "(BASELINE configs[1])", "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+            "higher_is_better": True, "scaling": "strong" if args.global_batch is not None else "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": ("LOL-v2-real-shaped 400x600 inference, global batch=%d split over %d GPU(s) = %d per GPU, full "
+                                    "encoder->flow->VQ->decoder->AFT (BASELINE configs[2] as written)" % (args.global_batch, world, args.batch))
+                                   if args.global_batch is not None else
+                                   ("LOL eval15-shaped 400x600 inference, batch=%d per GPU, full encoder->flow->VQ->decoder->AFT (%s)"
+                                    % (args.batch, "BASELINE configs[1]" if args.batch == 8 else
+                                       "the per-rank workload of BASELINE configs[2]: 32 images over 8 GPUs" if args.batch == 4 else
+                                       "BASELINE configs[1] at another batch")),
+                       "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "input": "3x400x600 (reflect-padded to 420x620)", "parallelism": "dp%d" % world,
                        "streams_per_gpu": args.streams,
                        "exchange": "none (1 GPU)" if world == 1 else "per step: crop/clamp/uint8 on device + RCCL gather of the "
@@ -623,7 +642,7 @@ def main():
         dog.daemon = True
         dog.start()
         try:
-            with ops.use_precision("bf16"):       # the plain-op default; the block's fp16 runs select their own precision
+            with ops.use_precision("bf16"):       # the plain-op default; every run of the block selects its own precision
                 train = train_block(device, rank, world)
         except Exception as e:  # noqa: BLE001
             train = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}

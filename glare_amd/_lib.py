@@ -33,7 +33,14 @@ def _current():
 
 
 class GlareError(RuntimeError):
-    pass
+    """`status`: the numeric GLARE_ERR_* code of include/glare_hip.h (None for errors raised on the Python side)."""
+
+    def __init__(self, msg, status=None):
+        super().__init__(msg)
+        self.status = status
+
+
+ERR_INVALID, ERR_LAUNCH, ERR_WORKSPACE, ERR_UNSUPPORTED = -1, -2, -3, -4     # include/glare_hip.h:37-40
 
 
 def header_symbols():
@@ -153,7 +160,7 @@ def main_lib():
 
 def check(status, what):
     if status != 0:
-        raise GlareError("%s failed: %s (%d)" % (what, main_lib().glare_status_string(status).decode(), status))
+        raise GlareError("%s failed: %s (%d)" % (what, main_lib().glare_status_string(status).decode(), status), status)
 
 
 def ptr(t):

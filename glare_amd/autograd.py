@@ -377,18 +377,24 @@ def maxpool2(x):
 
 @_lib.keeps_precision
 class MseFn(torch.autograd.Function):
-    """F.mse_loss(a, b) of bf16 feature maps; only `a` is differentiated."""
+    """F.mse_loss(a, b) of 16-bit feature maps; only `a` is differentiated.  The gradient 2 (a - b) / n * g is formed in fp32 in
+    backward, where the upstream g (with the GradScaler's scale under fp16) is known, and rounded to 16 bits once -- as the
+    reference's autocast computes mse_loss in fp32 (losses.py:33-39); rounded before the scale, 2 d / n at n ~ 1e6 is an fp16
+    subnormal."""
 
     @staticmethod
     def forward(ctx, a, b):
-        loss, ga = T.mse_loss(a.contiguous(), b.contiguous(), want_grad=ctx.needs_input_grad[0])
-        ctx.save_for_backward(ga)
+        a, b = a.contiguous(), b.contiguous()
+        loss, _ = T.mse_loss(a, b, want_grad=False)
+        ctx.save_for_backward(a, b)
         return loss[0]
 
     @staticmethod
     def backward(ctx, g):
-        (ga,) = ctx.saved_tensors
-        return (ga * g.to(ga.dtype) if ga is not None else None), None
+        a, b = ctx.saved_tensors
+        if not ctx.needs_input_grad[0]:
+            return None, None
+        return T.mse_backward(a, b, g.detach().float().reshape(1).contiguous()), None
 
 
 def mse_loss(a, b):

@@ -15,6 +15,9 @@
 #ifndef CONV_ABL_HILO
 #define CONV_ABL_HILO 0
 #endif
+#ifndef CONV_EPI_RES_INLINE
+#define CONV_EPI_RES_INLINE 0   // 1: the residual pieces loaded one by one inside the epilogue loops (rounds 1-4; A/B measurements)
+#endif
 #ifndef CONV_ABL_EPI
 #define CONV_ABL_EPI 0   // timing ablations only (tools/ablate.sh; wrong results): 1 residual add -> one xor, 2 phase 1 as a transposed layout would have it, 4 no output stores, 8 no epilogue at all
 #endif
@@ -426,12 +429,34 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
           *reinterpret_cast<float*>(slab + m * ROWF + (j * 32 + ncol) * 4) = acc[i][j][r] + bv;
         }
       });
+      // The residual pieces of THIS tile row (hi and lo halves: 2 x 16 B per lane and iteration) are all requested here, behind the
+      // slab writes -- the row's accumulators died with those writes, so the 8 x 4 destination registers cost nothing -- and the loop
+      // below consumes them in issue order.  Loaded inside the loop (rounds 3-4) every iteration paid its own L2 round trip with
+      // nothing else in flight: 16 dependent trips per wave and tile, the larger half of what "+ pair residual" cost (r04_kbench).
+      // (Requested BEFORE the slab pass they competed with the live accumulators and spilled: 892 vs 823 us, round 3.)
+      constexpr int NIT = 32 * CPR / 64;
+      [[maybe_unused]] u32x4 rvv[NIT], rlv[NIT];
+#if !CONV_EPI_RES_INLINE
+      if (p.res) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int idx = lane + 64 * it;
+          const int row = idx / CPR, ch = idx % CPR;
+          const int oy = oy0 + wm * MT + i, ox = ox0 + row;
+          const int co = ct * TN + wn * NT * 32 + ch * 8;
+          const bool ok = oy < p.OH && ox < p.OW && co < p.Cout;
+          const size_t roffs = ok ? (((size_t)b * p.OH + oy) * p.OW + ox) * p.rpitch + p.roff + co : 0;
+          rvv[it] = *reinterpret_cast<const u32x4*>(p.res + roffs);
+          if (p.res_lo) rlv[it] = *reinterpret_cast<const u32x4*>(p.res_lo + roffs);
+        }
+      }
+#endif
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #if CONV_ABL_HILO & 4
       if (acc[0][0][0] == 12345.f)
 #endif
 #pragma unroll
-      for (int it = 0; it < 32 * CPR / 64; ++it) {
+      for (int it = 0; it < NIT; ++it) {
         const int idx = lane + 64 * it;
         const int row = idx / CPR, ch = idx % CPR;
         const int oy = oy0 + wm * MT + i, ox = ox0 + row;
@@ -442,11 +467,19 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
           float v[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
           const size_t pix = ((size_t)b * p.OH + oy) * p.OW + ox;
           if (p.res) {
+#if CONV_EPI_RES_INLINE
             const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + pix * p.rpitch + p.roff + co);
+#else
+            const u32x4 rv = rvv[it];
+#endif
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[2 * e] += alo(rv[e]); v[2 * e + 1] += ahi(rv[e]); }
             if (p.res_lo) {
+#if CONV_EPI_RES_INLINE
               const u32x4 rl = *reinterpret_cast<const u32x4*>(p.res_lo + pix * p.rpitch + p.roff + co);
+#else
+              const u32x4 rl = rlv[it];
+#endif
 #pragma unroll
               for (int e = 0; e < 4; ++e) { v[2 * e] += alo(rl[e]); v[2 * e + 1] += ahi(rl[e]); }
             }
@@ -549,9 +582,29 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
           }
         });
       });
+      // the residual pieces of this slab, all requested at once behind phase 1 (whose accumulators are dead by now): see the hi / lo
+      // epilogue above -- one L2 round trip per slab instead of one per iteration
+      constexpr int NIT = HROWS * CPR / 64;
+      constexpr bool RES_AHEAD = !CONV_EPI_RES_INLINE && NIT <= 8;
+      [[maybe_unused]] u32x4 rvv[RES_AHEAD ? NIT : 1];
+      if constexpr (RES_AHEAD) {
+        if (p.res) {
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) {
+            const int idx = lane + 64 * it;
+            const int row = idx / CPR, ch = idx % CPR;
+            const int oy = oy0 + wm * MT + half * HT + row / 32, ox = ox0 + (row & 31);
+            const int co = ct * TN + wn * NT * 32 + ch * 8;
+            const bool ok = oy < p.OH && ox < p.OW && co < p.Cout;
+            const size_t pix = KS == 2 ? ((size_t)b * (2 * p.OH) + 2 * oy + pa) * (size_t)(2 * p.OW) + 2 * ox + pb
+                                       : ((size_t)b * p.OH + oy) * p.OW + ox;
+            rvv[it] = *reinterpret_cast<const u32x4*>(p.res + (ok ? pix * p.rpitch + p.roff + co : 0));
+          }
+        }
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-      for (int it = 0; it < HROWS * CPR / 64; ++it) {
+      for (int it = 0; it < NIT; ++it) {
         const int idx = lane + 64 * it;
         const int row = idx / CPR, ch = idx % CPR;
         const int oy = oy0 + wm * MT + half * HT + row / 32, ox = ox0 + (row & 31);
@@ -561,7 +614,9 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
           const size_t pix = KS == 2 ? ((size_t)b * (2 * p.OH) + 2 * oy + pa) * (size_t)(2 * p.OW) + 2 * ox + pb
                                      : ((size_t)b * p.OH + oy) * p.OW + ox;
           if (p.res) {
-            const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + pix * p.rpitch + p.roff + co);
+            u32x4 rv;
+            if constexpr (RES_AHEAD) rv = rvv[it];
+            else rv = *reinterpret_cast<const u32x4*>(p.res + pix * p.rpitch + p.roff + co);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #if CONV_ABL_EPI & 1

@@ -180,6 +180,15 @@ __global__ __launch_bounds__(LT) void mse_kernel(const a16_t* __restrict__ a, co
     partial[blockIdx.x] = t;
   }
 }
+// backward of F.mse_loss w.r.t. a: grad_a = round16(2 (a - b) / n * g), g = the upstream scalar gradient ON THE DEVICE (it carries the
+// GradScaler's loss scale under fp16: the product is formed in fp32 BEFORE the 16-bit rounding, as autocast's fp32 mse_loss does --
+// rounded first, 2 d / n at n ~ 1e6 sits in fp16's subnormal range and loses most of the perceptual gradient)
+__global__ __launch_bounds__(LT) void mse_bwd_kernel(const a16_t* __restrict__ a, const a16_t* __restrict__ b, long long n, float inv_n,
+                                                     const float* __restrict__ g, a16_t* __restrict__ ga) {
+  const float s = 2.f * inv_n * g[0];
+  for (long long i = (long long)blockIdx.x * LT + threadIdx.x; i < n; i += (long long)gridDim.x * LT)
+    ga[i] = f2a((a2f(a[i]) - a2f(b[i])) * s);
+}
 __global__ void mse_finalize_kernel(const double* __restrict__ partial, int blocks, double n, float* __restrict__ out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double t = 0.0;
@@ -282,5 +291,12 @@ extern "C" int glare_mse_loss_bf16(const void* a, const void* b, long long n, fl
                      1.0f / (float)n, static_cast<a16_t*>(grad_a_or_null), static_cast<double*>(workspace));
   hipLaunchKernelGGL(mse_finalize_kernel, dim3(1), dim3(64), 0, ST(stream), static_cast<const double*>(workspace), blocks, (double)n,
                      loss_out);
+  return glare_launch_status();
+}
+
+extern "C" int glare_mse_backward_bf16(const void* a, const void* b, long long n, const float* g_dev, void* grad_a, glare_stream_t stream) {
+  if (n <= 0 || !a || !b || !g_dev || !grad_a) return GLARE_ERR_INVALID;
+  hipLaunchKernelGGL(mse_bwd_kernel, dim3(lblocks(n, 2048)), dim3(LT), 0, ST(stream), static_cast<const a16_t*>(a),
+                     static_cast<const a16_t*>(b), n, 1.0f / (float)n, g_dev, static_cast<a16_t*>(grad_a));
   return glare_launch_status();
 }

@@ -47,7 +47,7 @@ class DCNv2Pack(ModulatedDeformConvPack, HipModule):
             try:
                 return ops.mdcn_forward_nhwc(x, om, pd, x_off=x_off, C=self.in_channels, mask_is_logit=True, padding=self.padding)
             except _lib.GlareError as e:
-                if "unsupported" not in str(e).lower():
+                if e.status != _lib.ERR_UNSUPPORTED:      # only "valid request outside the fast kernel" falls back to the split form
                     raise
         pd = self._packed("dcn", lambda: ops.PackedDcn(self.weight, self.bias, self.deformable_groups, single=False))
         return ops.mdcn_forward_nhwc(x, om, pd, x_off=x_off, C=self.in_channels, mask_is_logit=True, padding=self.padding)

@@ -52,6 +52,26 @@ HILO_STREAM = os.environ.get("GLARE_HILO_STREAM", "1") != "0"
 # codebook search needs the latent to ~1e-4, which 11-bit MFMA operands miss 20-fold.  GLARE_FP32_CLASS=0:
 # round 3's single-pass convs (A/B measurements).
 FP32_CLASS = os.environ.get("GLARE_FP32_CLASS", "1") != "0"
+
+
+class fp32_class:
+    """`with fp32_class(False):` -- the conditional encoder and the flow's nets in the single-pass form inside the block (round 3's
+    arithmetic = the reference's own fp16 autocast: one 16-bit MFMA pass per conv).  Used by Stage3Trainer for its FROZEN front: the
+    fp32-class form exists for the inference contract (indices against the fp32 reference), which a training step does not have --
+    the reference trains stage 3 with these nets under `@autocast()` (VQLLFLOWDeformable_arch.py:222).  Process-global, like the
+    environment switch it overrides: one trainer per process."""
+
+    def __init__(self, on):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global FP32_CLASS
+        self._prev, FP32_CLASS = FP32_CLASS, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global FP32_CLASS
+        FP32_CLASS = self._prev
 # GroupNorm + swish in front of a ResnetBlock's 3x3 convs as the conv loader's PROLOGUE (glare_conv_desc.gn_coef; bit-identical to the
 # separate apply pass).  Measured (tools/kbench.py gnpro, profiles/r04_gn_prologue.txt): -2 % on apply + conv at 128 channels, full
 # resolution; +12 % / +20 % at 256 / 512 channels, where 2 / 4 output-channel tiles repeat the transform -- the in-LDS transform sits

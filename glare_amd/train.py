@@ -102,7 +102,9 @@ class FlatGroup:
         all-reduce over xGMI.  The reference reduces everything through GPU 0 after backward (nn.DataParallel, LLFlow_model.py:
         71-74).  Call before `loss.backward()`; FlatAdam.step() picks the result up (and falls back to the blocking path if the
         hook never fired).  No-op at world size 1, so the single-GPU step and its hipGraph capture are untouched."""
-        self._early = None
+        stale, self._early = getattr(self, "_early", None), None
+        if stale is not None:          # a backward that raised between arm and step(): its hook must not fire on a later backward
+            stale["handle"].remove()   # (a stray collect + all_reduce would desynchronise the ranks' collective order; ADVICE r04)
         if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) or not self.params:
             return
         used = [p for p, u in zip(self.params, self.has_grad) if u]
@@ -130,6 +132,9 @@ class FlatGroup:
         if work is not None and not isinstance(work, int):
             work.wait()
         off = 0
+        for i, (p, used) in enumerate(zip(self.params, self.has_grad)):   # collect()'s check, which the hook's id-keyed dict cannot make:
+            if not used and p.grad is not None:                            # a never_used parameter must not have received a gradient
+                raise RuntimeError("a parameter declared never_used received a gradient (index %d, shape %s)" % (i, tuple(p.shape)))
         for p, used in zip(self.params, self.has_grad):   # AccumulateGrad has since stored the LOCAL gradient tensors in .grad
             k = p.numel()
             p.grad = self.g[off:off + k].view(p.shape) if used else None
@@ -250,9 +255,13 @@ class Stage2Trainer:
     """One optimisation step of the flow objective: a7 (frozen VQGAN encoder, no tape) -> a1 -> a4 -> mean NLL -> backward ->
     gradient mean over ranks -> Adam."""
 
-    def __init__(self, netG, net_hq, lr_G=5e-4, lr_RRDB=None, weight_decay_G=0.0, train_rrdb=True, device_state=False, precision="bf16"):
-        """precision: the 16-bit format of activations and activation gradients -- "bf16" (fp32 range, no loss scaling needed) or
-        "fp16" (the reference's autocast dtype, 8x finer rounding; the loss is scaled by the device-resident GradScaler scale)."""
+    def __init__(self, netG, net_hq, lr_G=5e-4, lr_RRDB=None, weight_decay_G=0.0, train_rrdb=True, device_state=False, precision="fp16"):
+        """precision: the 16-bit format of activations and activation gradients.  "fp16" (the default) is the reference's own AMP form
+        (`@autocast()` forward + `scaler.scale(loss).backward()`, LLFlowVQGAN_arch.py:36, LLFlow_model.py:236-241): IEEE-half
+        activations, the loss multiplied by the device-resident GradScaler scale, and the precision every gradient-parity bound of
+        tests/test_gpu_train.py is stated in.  "bf16" (fp32 range, no loss scaling, ~1 % faster) rounds every stored tensor 8x
+        coarser and carries NO gradient-parity claim (AFT decoder on the pipeline's inputs: 8 % median / 32 % max against fp16's
+        2 % / 5 %)."""
         assert precision in ("bf16", "fp16")
         self.precision = precision
         self.netG, self.net_hq = netG.train(), net_hq.eval()
@@ -305,12 +314,20 @@ class Stage3Trainer:
     perceptual + 0.2 * (1 - MS-SSIM(normalize=True)).  The perceptual network's weights are the caller's (`perceptual=`): the
     reference downloads torchvision's pretrained VGG16, which is not available offline; pass None to train on L1 + MS-SSIM."""
 
-    def __init__(self, netG, net_hq, lr_G=5e-5, weight_decay_G=0.0, perceptual=None, use_msssim=True, device_state=False, precision="bf16"):
+    def __init__(self, netG, net_hq, lr_G=5e-5, weight_decay_G=0.0, perceptual=None, use_msssim=True, device_state=False, precision="fp16",
+                 frozen_fp32_class=False):
+        """precision: as Stage2Trainer ("fp16" = the reference's AMP form, the default).  frozen_fp32_class: run the FROZEN conditional
+        encoder + flow in the fp32-class inference form (hi / lo operand pairs, three MFMA passes per conv) instead of the single-pass
+        fp16 form.  Default False: the reference runs these nets under `@autocast()` in the stage-3 step (VQLLFLOWDeformable_arch.py:
+        222-248), i.e. single-pass fp16 is ITS arithmetic; the fp32-class form serves inference's index contract and costs the step
+        ~3.5 ms (23.0 -> 19.5 ms at 1 x 256^2, round 4 / 5)."""
         from . import autograd as A
         from . import losses
+        from .modules import encoder_decoder as ED
 
         assert precision in ("bf16", "fp16")      # as Stage2Trainer
         self.precision = precision
+        self._front = lambda: ED.fp32_class(bool(frozen_fp32_class))
 
         self.A, self.losses, self.perceptual, self.use_msssim = A, losses, perceptual, use_msssim
         self.last_terms = {}
@@ -334,7 +351,7 @@ class Stage3Trainer:
     def step_tensor(self, gt_img, lr_img):
         G = self.netG
         with ops.use_precision(self.precision):
-            with torch.no_grad(), ops.auto_cout_tile():
+            with torch.no_grad(), ops.auto_cout_tile(), self._front():
                 enc = G.RRDB.forward_nhwc(lr_img)
                 lat = G.flowUpsamplerNet.decode_nhwc(enc["color_map"], enc["cond_feat"])
                 _, _, feats = self.net_hq.decode_nhwc(lat, want_image=False)
@@ -407,10 +424,17 @@ class GraphedStep:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
+            keep = []
+            if fresh:
+                # The data-dependent initialisation happens inside the FIRST training forward (FlowActNorms.py:82-83).  It is run here on
+                # its own -- a forward without backward or optimizer step -- and cloned BEFORE any warm-up step: cloned after the warm-up
+                # (as this code did) the values put back were the initialisation PLUS warmup x branches Adam updates on the construction
+                # batch, with their moments and the step counter rewound to zero.
+                self._init_forward(flags[0])
+                keep = [(t, t.clone()) for m in actnorms if id(m) in fresh for t in (m.bias.data, m.logs.data)]
             for _ in range(self.warmup):            # allocator / lazy-init warm-up outside the capture, every branch
                 for f in flags:
                     self._eager(f)
-            keep = [(t, t.clone()) for m in actnorms if id(m) in fresh for t in (m.bias.data, m.logs.data)]
             for t, v in snap:
                 t.copy_(v)
             for t, v in keep:                       # the parameters live inside the restored flat buffers: put the initialisation back
@@ -422,6 +446,19 @@ class GraphedStep:
 
     def _eager(self, flag):
         return self.trainer.step_tensor(self.gt, self.lr, flag) if self.branching else self.trainer.step_tensor(self.gt, self.lr)
+
+    def _init_forward(self, flag):
+        """The forward half of a stage-2 step only (what initialises a fresh flow's ActNorms), no tape kept, nothing updated."""
+        tr = self.trainer
+        if not isinstance(tr, Stage2Trainer):
+            return
+        flow = tr.netG.flowUpsamplerNet
+        with ops.use_precision(tr.precision), torch.no_grad():
+            if flow.needs_actnorm_init():                      # exactly what train_nll() does first (LLFlowVQGAN_arch.train_nll)
+                with ops.auto_cout_tile():
+                    gt_latent = tr.net_hq.encode_nhwc(self.gt)
+                enc0 = tr.netG.RRDB.forward_nhwc(self.lr)
+                flow.initialize_actnorms_nhwc(gt_latent.detach(), enc0["cond_feat"])
 
     def _capture(self, flag):
         g = torch.cuda.CUDAGraph()

@@ -503,6 +503,16 @@ def mse_loss(a, b, want_grad=True):
     return loss, ga
 
 
+def mse_backward(a, b, g):
+    """grad_a = round16(2 (a - b) / n * g); g: the upstream gradient, a one-element fp32 DEVICE tensor (no host read)."""
+    require_cuda(a, b, g)
+    assert a.dtype == b.dtype == act_dtype() and a.is_contiguous() and b.is_contiguous() and a.shape == b.shape
+    assert g.dtype == torch.float32 and g.numel() == 1
+    ga = torch.empty_like(a)
+    check(_lib.lib().glare_mse_backward_bf16(ptr(a), ptr(b), _ll(a.numel()), ptr(g), ptr(ga), stream_handle()), "glare_mse_backward_bf16")
+    return ga
+
+
 def adam_prepare_(step_dev, state3, betas):
     require_cuda(step_dev, state3)
     assert step_dev.dtype == torch.int32 and state3.dtype == torch.float32 and state3.numel() == 3

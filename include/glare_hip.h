@@ -694,6 +694,9 @@ int glare_maxpool2_backward_bf16(const void* x_nhwc, const void* g_nhwc, void* g
                                  glare_stream_t stream);
 int glare_mse_loss_bf16(const void* a, const void* b, long long n, float* loss_out, void* grad_a_or_null, void* workspace,
                         size_t workspace_bytes, glare_stream_t stream);
+/* grad_a = round16(2 (a - b) / n * g_dev[0]): the upstream scalar gradient (incl. any loss scale) is multiplied in fp32 BEFORE the
+ * 16-bit rounding, as F.mse_loss under autocast (fp32) + the cast's backward do (losses.py:33-39 behind scaler.scale(loss).backward()) */
+int glare_mse_backward_bf16(const void* a, const void* b, long long n, const float* g_dev, void* grad_a, glare_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -246,6 +246,19 @@ def correlated_gt(ref_img, db=27.0, seed=5):
     return np.round(gt * 255).astype(np.uint8)
 
 
+def audit_flips(r, ref, ov):
+    """oracle/audit.py on one scene: every token whose index differs from the oracle's must be a near-tie the measured latent error
+    explains (margin on the ORACLE's latent <= 2 |dz| |de|, fp64).  Asserts, and returns (flips, worst margin / bound ratio)."""
+    from oracle.audit import flip_audit
+
+    C = ref["latent"].shape[1]
+    a = flip_audit(ref["latent"].permute(0, 2, 3, 1).reshape(-1, C).numpy(), r["latent"].float().cpu().reshape(-1, C).numpy(),
+                   ref["indices"].reshape(-1).numpy(), r["indices"].cpu().reshape(-1).numpy(),
+                   ov.quantize.embedding.weight.detach().float().cpu().numpy())
+    assert not a["violations"], ("index flips the latent error cannot explain (quantize.py:280-285)", a)
+    return a["flips"], a["worst_ratio"]
+
+
 def e2e_metrics(out, out_ref, h):
     a, b = O.postprocess(out, h), O.postprocess(out_ref, h)
     gt = correlated_gt(b)
@@ -278,6 +291,7 @@ def check_e2e(regime, h, w, seed, capsys):
             r = pg.reverse_flow_nhwc(pv, lr.cuda(), precision=prec)
             assert r["enc"]["cond_feat"].dtype == (torch.float16 if prec == "fp16" else torch.bfloat16)
             agree = float((r["indices"].cpu() == ref["indices"]).float().mean())
+            audit_flips(r, ref, ov)          # both precisions: whatever the latent error, a flipped token must be explained by it
             full = e2e_metrics(r["out"].cpu(), ref["out"], h)
             with ops.use_precision(prec):    # the same run with the VQ decoder fed the oracle's latent (=> its indices)
                 _, _, feats_i = pv.decode_nhwc(ops.nchw_to_nhwc(ref["latent"].cuda(), bf16=False), want_image=False)
@@ -334,14 +348,15 @@ def test_end_to_end_full_size_twelve_scenes(capsys):
         agree = float((r["indices"].cpu() == ref["indices"]).float().mean())
         full = e2e_metrics(r["out"].cpu(), ref["out"], 400)
         lat = float(rel(ops.nhwc_to_nchw(r["latent"]).cpu(), ref["latent"]))
-        rows.append((seed, lat, agree, full["psnr_vs_oracle"], full["delta"]))
+        flips, ratio = audit_flips(r, ref, ov)         # every flipped token is a near-tie (asserted inside)
+        rows.append((seed, lat, agree, full["psnr_vs_oracle"], full["delta"], flips, ratio))
         _CACHE.pop(("representative", 400, 600, seed), None)          # 12 full-size reference sets would be ~6 GB of host memory
     with capsys.disabled():
         for row in rows:
             print("\n[e2e 400x600 representative seed %d] latent rel %.2e | index agreement %.5f | PSNR(ours,oracle) %.2f dB | |dPSNR vs GT| %.4f dB"
-                  % row, end="")
+                  " | %d flipped tokens, all near-ties: worst margin / (2 |dz| |de|) = %.3f" % row, end="")
         print()
-    for seed, lat, agree, psnr, delta in rows:       # one record per quantity: tolerances.py keeps the maximum over the scenes
+    for seed, lat, agree, psnr, delta, flips, ratio in rows:       # one record per quantity: tolerances.py keeps the maximum over the scenes
         within(lat, 2.8e-5)                        # measured max 1.42e-5
         within(1.0 - agree, 1.47e-3)               # measured max 7.4e-4 (12 tokens)
         assert psnr >= 54.2, (seed, psnr)          # measured min 57.22 dB
@@ -361,10 +376,12 @@ def test_end_to_end_full_size_held_out(regime, seed, capsys):
     agree = float((r["indices"].cpu() == ref["indices"]).float().mean())
     full = e2e_metrics(r["out"].cpu(), ref["out"], 400)
     lat = float(rel(ops.nhwc_to_nchw(r["latent"]).cpu(), ref["latent"]))
+    flips, ratio = audit_flips(r, ref, ov)
     _CACHE.pop((regime, 400, 600, seed), None)
     with capsys.disabled():
         print("\n[e2e 400x600 %s seed %d] latent rel %.2e | index agreement %.5f | PSNR(ours,oracle) %.2f dB | |dPSNR vs GT| %.4f dB"
-              % (regime, seed, lat, agree, full["psnr_vs_oracle"], full["delta"]))
+              " | %d flipped tokens, all near-ties: worst margin / (2 |dz| |de|) = %.3f"
+              % (regime, seed, lat, agree, full["psnr_vs_oracle"], full["delta"], flips, ratio))
     within(lat, 2.8e-5)                 # measured max 1.43e-5
     within(1.0 - agree, 1.47e-3)        # measured max 7.4e-4 (12 tokens)
     assert full["psnr_vs_oracle"] >= 54.2, full
@@ -381,9 +398,10 @@ def test_end_to_end_other_image_sizes(h, w, capsys):
     agree = float((r["indices"].cpu() == ref["indices"]).float().mean())
     m = e2e_metrics(r["out"].cpu(), ref["out"], h)
     lat = float(rel(ops.nhwc_to_nchw(r["latent"]).cpu(), ref["latent"]))
+    flips, ratio = audit_flips(r, ref, ov)
     with capsys.disabled():
-        print("\n[e2e %dx%d] latent rel %.2e | index agreement %.5f | PSNR(ours,oracle) %.2f dB | |dPSNR vs GT| %.4f dB"
-              % (h, w, lat, agree, m["psnr_vs_oracle"], m["delta"]))
+        print("\n[e2e %dx%d] latent rel %.2e | index agreement %.5f | PSNR(ours,oracle) %.2f dB | |dPSNR vs GT| %.4f dB | %d flips, worst ratio %.3f"
+              % (h, w, lat, agree, m["psnr_vs_oracle"], m["delta"], flips, ratio))
     within(lat, 5.5e-5)                # measured 1.97e-5 / 1.72e-5 / 2.73e-5
     tokens = ref["indices"].numel()
     assert (1.0 - agree) * tokens <= 6.5, (agree, tokens)     # measured: 0 / 3 (of 874) / 0 tokens differ -- two of the three sizes bit-exact

@@ -479,7 +479,10 @@ def test_stage2_trainer_steps_reduce_the_loss(precision):
     assert p0.data_ptr() == grp.w.data_ptr() and p0.grad.data_ptr() == grp.g.data_ptr()   # views of the flat buffers
 
 
-@pytest.mark.parametrize("prec", PRECISIONS, indirect=True)
+# Row a13's gradient parity is stated in fp16 -- the reference's own AMP dtype and the trainers' default.  The bf16
+# legs of the two tests below are gone: bf16 measured 2.5 % / 8.5 % here and 8.2 % / 32 % on the pipeline's inputs, which only the
+# reference's (never used) bf16 autocast noise could have justified; bf16 training stays available and carries no parity claim.
+@pytest.mark.parametrize("prec", ["fp16"], indirect=True)
 def test_aft_decoder_backward_vs_oracle(prec):
     """Row a13's trainable part: every MultiScaleDecoder2 parameter gradient (trunk, Mix, WarpBlock convs, DCNv2 weight /
     bias through glare_mdcn_backward_f32, mean rescale) against fp32 autograd of the oracle (differentiable torch DCNv2)."""
@@ -501,21 +504,21 @@ def test_aft_decoder_backward_vs_oracle(prec):
     (out_r * wgt).sum().backward()
     nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(_dev())
     out = hip.train_nhwc(nh(z), [_nhwc16(c) for c in code], [_nhwc16(e) for e in enc], whole_batch_mean=True)
-    b = {"bf16": (9.1e-3, 5e-2, 0.17), "fp16": (1.1e-3, 1.9e-2, 4.7e-2)}[prec]   # fp16 measured: 5.6e-4; median 0.0092, max 0.0234
-    within(_rel(out.detach().cpu().permute(0, 3, 1, 2), out_r.detach()), b[0], prec)   # bf16 measured 4.78e-03
+    b = {"fp16": (1.1e-3, 1.9e-2, 4.7e-2)}[prec]   # fp16 measured: 5.6e-4; median 0.0092, max 0.0234
+    within(_rel(out.detach().cpu().permute(0, 3, 1, 2), out_r.detach()), b[0], prec)
     ((out * nh(wgt)).sum() * LOSS_SCALE[prec]).backward()
     errs = _param_grad_errors(hip, ref, LOSS_SCALE[prec])
-    _report(errs, b[1], b[2], ":" + prec)     # bf16 measured: median 0.0249, max 0.0847 over 152 tensors (random weights make mean(h)/mean(x_w) ill-conditioned)
+    _report(errs, b[1], b[2], ":" + prec)     # 152 tensors (random weights make mean(h)/mean(x_w) ill-conditioned: the next test is the step's own regime)
     assert any("warp.0.dcn.weight" in k for k in errs) and any(k.startswith("mix.") for k in errs)
 
 
-@pytest.mark.parametrize("prec", PRECISIONS, indirect=True)
+@pytest.mark.parametrize("prec", ["fp16"], indirect=True)
 def test_aft_decoder_backward_on_the_pipelines_own_inputs(prec):
     """Row a13 in the regime the step runs in: ONE 256x256 crop (BASELINE configs[4]'s per-GPU batch), the AFT decoder's inputs --
     latent, VQGAN-decoder features, conditional-encoder features -- produced by the (oracle) pipeline itself on a synthetic scene
     with trained-like weights (synthetic.representative_init_), instead of the 8x12 random tensors of the test above whose
     mean(h) / mean(x_w) ratio is ill-conditioned.  Every MultiScaleDecoder2 parameter gradient against fp32 autograd of the oracle
-    (differentiable torch DCNv2): median / max relative L2 error per tensor, in both training precisions."""
+    (differentiable torch DCNv2): median / max relative L2 error per tensor, in the training precision (fp16 AMP)."""
     from glare_amd import modules as M
     from glare_amd.synthetic import representative_init_, synthetic_pair
     from oracle import torch_ref as O
@@ -540,11 +543,11 @@ def test_aft_decoder_backward_on_the_pipelines_own_inputs(prec):
     (out_r * wgt).sum().backward()
     nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(_dev())
     out = hip.train_nhwc(nh(z), [_nhwc16(c) for c in code], [_nhwc16(e) for e in enc], whole_batch_mean=True)
-    # measured: forward 3.9e-3 / 4.8e-4; gradients bf16 median 0.0816, max 0.316 -- fp16 median 0.0205, max 0.0522 (mix.0.w, a scalar: a
-    # sum over the whole tensor with cancellation).  The gradients are 20-40x more sensitive than the forward here (random-sign loss weights).
-    # The noise floor: the REFERENCE's own autocast against its fp32 self, same inputs, on CPU (tools/amp_noise.py): fp16 forward
-    # 9.5e-4, gradient median 3.3 %; bf16 forward 6.6e-3, median 11.2 % -- the product sits inside it in both formats.
-    b = {"bf16": (7.7e-3, 0.165, 0.64), "fp16": (9.7e-4, 4.1e-2, 0.105)}[prec]
+    # measured (fp16): forward 4.8e-4; gradients median 0.0205, max 0.0522 (mix.0.w, a scalar: a sum over the whole tensor with
+    # cancellation); bounds = 2x measured.  The gradients are 20-40x more sensitive than the forward here (random-sign loss weights).
+    # The noise floor: the REFERENCE's own fp16 autocast against its fp32 self, same inputs, on CPU (tools/amp_noise.py): forward
+    # 9.5e-4, gradient median 3.3 % -- the product sits inside it.  (bf16, no longer asserted: median 0.0816, max 0.316.)
+    b = {"fp16": (9.7e-4, 4.1e-2, 0.105)}[prec]
     within(_rel(out.detach().cpu().permute(0, 3, 1, 2), out_r.detach()), b[0], prec)
     ((out * nh(wgt)).sum() * LOSS_SCALE[prec]).backward()
     errs = _param_grad_errors(hip, ref, LOSS_SCALE[prec])
@@ -634,7 +637,11 @@ def test_msssim_small_images_shrinking_window():
     within(_rel(ad.grad.cpu().permute(0, 3, 1, 2), ar.grad), 1.8e-5)   # measured 9.03e-06
 
 
-def test_perceptual_network_vs_oracle():
+@pytest.mark.parametrize("prec,shape", [("bf16", (2, 3, 32, 48)), ("fp16", (2, 3, 32, 48)), ("fp16", (1, 3, 192, 256))], indirect=["prec"])
+def test_perceptual_network_vs_oracle(prec, shape):
+    """fp16 at the LARGE shape is the regime of the step: relu1_2 has n = 3.1e6 elements there, so mse_loss's own
+    gradient 2 d / n is ~6e-7 d -- an fp16 subnormal.  The product multiplies the upstream gradient (with the loss scale) in BEFORE
+    the 16-bit rounding (glare_mse_backward_bf16), as autocast's fp32 mse_loss does; the loss is scaled as the trainers scale it."""
     from glare_amd import losses
     from glare_amd.synthetic import seeded_init_
     from oracle import torch_ref as O
@@ -644,22 +651,26 @@ def test_perceptual_network_vs_oracle():
     hip.load_state_dict(ref.state_dict(), strict=True)
     hip.to(_dev())
     g = torch.Generator().manual_seed(32)
-    gt = torch.rand(2, 3, 32, 48, generator=g)
-    a = (gt + 0.2 * torch.randn(2, 3, 32, 48, generator=g)).clamp(0, 1)
+    gt = torch.rand(*shape, generator=g)
+    a = (gt + 0.2 * torch.randn(*shape, generator=g)).clamp(0, 1)
     ar = a.clone().requires_grad_(True)
     lr_ = ref(ar, gt)
     lr_.backward()
     nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(_dev())
     ad = nh(a).requires_grad_(True)
     l = hip(ad, nh(gt))
-    l.backward()
+    S = LOSS_SCALE[prec]
+    (l * S).backward()
     assert abs(float(l.detach()) - float(lr_.detach())) < 3e-2 * abs(float(lr_.detach()))
-    within(_rel(ad.grad.cpu().permute(0, 3, 1, 2), ar.grad), 2.0e-2)   # measured 1.03e-02
+    # bf16 measured 1.03e-02; fp16: an 8x finer format must not do worse than bf16's bound even at n = 3.1e6
+    within(_rel(ad.grad.cpu().permute(0, 3, 1, 2) / S, ar.grad), 2.0e-2, "%s:%d" % (prec, shape[2]))
     assert all(p.grad is None for p in hip.parameters())          # the VGG weights are frozen (losses.py:18-19)
 
 
-def test_stage3_total_loss_vs_oracle():
-    """l1 + 0.01 percep + 0.2 (1 - msssim) and d/d rec (VQLLFLOWD_model.py:209-223), including clamp / NaN handling."""
+@pytest.mark.parametrize("prec,S_", [("bf16", 64), ("fp16", 256)], indirect=["prec"])
+def test_stage3_total_loss_vs_oracle(prec, S_):
+    """l1 + 0.01 percep + 0.2 (1 - msssim) and d/d rec (VQLLFLOWD_model.py:209-223), including clamp / NaN handling.  fp16: at the
+    step's own crop (1 x 256 x 256), the loss scaled as Stage3Trainer scales it."""
     from glare_amd import losses
     from glare_amd.synthetic import seeded_init_
     from glare_amd.train import stage3_loss
@@ -670,23 +681,25 @@ def test_stage3_total_loss_vs_oracle():
     hip.load_state_dict(ref.state_dict(), strict=True)
     hip.to(_dev())
     g = torch.Generator().manual_seed(33)
-    gt = torch.rand(1, 3, 64, 64, generator=g)
-    rec = gt + 0.3 * torch.randn(1, 3, 64, 64, generator=g)        # leaves [0,1] in places
+    gt = torch.rand(1, 3, S_, S_, generator=g)
+    rec = gt + 0.3 * torch.randn(1, 3, S_, S_, generator=g)        # leaves [0,1] in places
     rec[0, 2, 5, 7] = float("nan")
     rr = rec.clone().requires_grad_(True)
     tot_r, l1_r, pl_r, sl_r = O.stage3_loss(rr, gt, ref)
     tot_r.backward()
     rd = rec.permute(0, 2, 3, 1).contiguous().to(_dev()).requires_grad_(True)
     tot, terms = stage3_loss(rd, gt.to(_dev()), hip)
-    tot.backward()
+    (tot * LOSS_SCALE[prec]).backward()
     assert abs(float(terms["l1_loss"].detach()) - float(l1_r.detach())) < 1e-6
     assert abs(float(terms["ssim_loss"].detach()) - float(sl_r.detach())) < 1e-5
     assert abs(float(terms["percep_loss"].detach()) - float(pl_r.detach())) < 3e-2 * abs(float(pl_r.detach()))
     gref = torch.nan_to_num(rr.grad, nan=0.0)
-    within(_rel(rd.grad.cpu().permute(0, 3, 1, 2), gref), 2.4e-5)   # measured 1.25e-05
+    # bf16 @64 measured 1.25e-05 (the perceptual term is 1 % of the total and its 16-bit error barely shows); fp16 @256: same bound
+    within(_rel(rd.grad.cpu().permute(0, 3, 1, 2) / LOSS_SCALE[prec], gref), 2.4e-5, prec)
 
 
-def test_graphed_step_replays_the_eager_step_bit_identically():
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+def test_graphed_step_replays_the_eager_step_bit_identically(precision):
     """The whole stage-2 step (frozen encode, forward, backward, flat Adam with device-side state) captured into a hipGraph and
     replayed must produce exactly the parameters the eager steps produce: no host state, no synchronisation, no atomics."""
     from glare_amd import modules as M
@@ -700,10 +713,14 @@ def test_graphed_step_replays_the_eager_step_bit_identically():
     finals = []
     for graphed in (False, True):
         hip, _ = _stage2_pair(9)
-        tr = Stage2Trainer(hip, net_hq, lr_G=2e-4, device_state=True)
+        tr = Stage2Trainer(hip, net_hq, lr_G=2e-4, device_state=True, precision=precision)
+        if precision == "fp16":
+            tr.opt.scale.fill_(4096.0)      # a scale no step of this toy problem overflows at: every step is applied (GradScaler's
+                                            # initial 65536 would skip-and-halve its way there, identically in both runs)
         if graphed:
             gs = GraphedStep(tr, gt_img, lr_img, warmup=2)         # 2 eager warm-up steps whose effect is put back, then capture
             assert tr.opt.t == 0                                    # capturing does not advance the optimisation
+            assert float(tr.opt.scale.item()) == (4096.0 if precision == "fp16" else 65536.0)   # ... nor the scaler
             losses = [gs.step(gt_img, lr_img) for _ in range(3)]   # 3 replays
         else:
             losses = [tr.step(gt_img, lr_img) for _ in range(3)]
@@ -888,7 +905,7 @@ def test_training_steps_at_the_reference_crop_sizes(stage):
     gt = torch.rand(B, 3, S, S, generator=g).to(_dev())
     lr = (torch.randn(B, 3, S, S, generator=g) * 0.5 - 1.0).to(_dev())
     m0, f0 = moving.detach().clone(), frozen.detach().clone()
-    losses = [tr.step(gt, lr) for _ in range(6)]
+    losses = [tr.step(gt, lr) for _ in range(12)]     # the default precision is fp16 AMP: GradScaler's initial 65536 may skip-and-halve first
     assert all(l == l and abs(l) < 1e6 for l in losses), losses
     assert min(losses[3:]) < losses[0], losses
     assert not torch.equal(m0, moving.detach()) and torch.equal(f0, frozen.detach())
@@ -982,6 +999,8 @@ def test_adam_skips_parameters_without_gradient_and_graph_replay_invalidates():
     netG = seeded_init_(M.VQLLFLOWDeformable().train(), 0).to(_dev())
     net_hq = seeded_init_(M.VQModel().eval(), 1).to(_dev())
     tr = Stage3Trainer(netG, net_hq, lr_G=1e-4, weight_decay_G=0.1, use_msssim=False, device_state=True)
+    assert tr.precision == "fp16" and tr.opt.loss_scaling      # the default: the reference's AMP form
+    tr.opt.scale.fill_(1024.0)       # a scale the first step cannot overflow at: this test is about WHICH parameters an applied step moves
     g = torch.Generator().manual_seed(14)
     gt_img = torch.rand(1, 3, 64, 64, generator=g).to(_dev())
     lr_img = (torch.randn(1, 3, 64, 64, generator=g) * 0.5 - 1.0).to(_dev())
@@ -1133,7 +1152,8 @@ def _two_rank_stage2_worker(rank, world, port, q, fresh_flow=False):
         netG = reset_actnorms_(netG).train()
     netG = netG.to(dev)
     net_hq = seeded_init_(M.VQModel().eval(), 1).to(dev)
-    tr = Stage2Trainer(netG, net_hq, lr_G=1e-4)
+    tr = Stage2Trainer(netG, net_hq, lr_G=1e-4)                       # the default precision: fp16 AMP, loss scaling on the device
+    tr.opt.scale.fill_(4096.0)     # every one of the three steps is applied (from GradScaler's initial 65536 the first may be skipped -- on BOTH ranks alike)
     g = torch.Generator().manual_seed(100 + rank)                     # every rank trains on its own crops
     gt = torch.rand(1, 3, 64, 64, generator=g).to(dev)
     lr = (torch.randn(1, 3, 64, 64, generator=g) * 0.5 - 1.0).to(dev)

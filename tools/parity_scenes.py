@@ -21,7 +21,7 @@ from glare_amd import modules as M  # noqa: E402
 from glare_amd import ops  # noqa: E402
 from glare_amd.synthetic import representative_init_, synthetic_pair  # noqa: E402
 from oracle import torch_ref as O  # noqa: E402
-from test_gpu_precision import e2e_metrics, rel  # noqa: E402
+from test_gpu_precision import audit_flips, e2e_metrics, rel  # noqa: E402
 
 
 def main():
@@ -55,9 +55,11 @@ def main():
         agree = float((r["indices"].cpu() == ref["indices"]).float().mean())
         full, forced = e2e_metrics(r["out"].cpu(), ref["out"], h), e2e_metrics(out_i, ref["out"], h)
         lat = rel(ops.nhwc_to_nchw(r["latent"]).cpu(), ref["latent"])
+        # integer-contract audit (oracle/audit.py): every flipped token must be a near-tie the latent error explains (asserts inside)
+        flips, ratio = audit_flips(r, ref, ov)
         rows.append((s, lat, agree, full["psnr_vs_oracle"], full["delta"], forced["psnr_vs_oracle"], forced["delta"]))
         print("seed %3d  latent rel %.3e  idx agree %.5f  full path: PSNR(ours,oracle) %6.2f dB  |dPSNR vs GT| %.4f dB   oracle's indices: %6.2f dB  %.4f dB   (oracle %.0f s)"
-              % (rows[-1] + (t1 - t0,)), flush=True)
+              % (rows[-1] + (t1 - t0,)) + "   flips %2d, all near-ties: worst margin / (2|dz||de|) %.3f" % (flips, ratio), flush=True)
     n = len(rows)
     print("-- %d scenes: latent rel mean %.3e | agreement min %.5f mean %.5f | PSNR(ours,oracle) min %.2f | |dPSNR vs GT| max %.4f mean %.4f | forced max %.4f"
           % (n, sum(r[1] for r in rows) / n, min(r[2] for r in rows), sum(r[2] for r in rows) / n, min(r[3] for r in rows),

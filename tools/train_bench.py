@@ -18,7 +18,7 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 graph = len(sys.argv) > 3 and sys.argv[3] == "graph"
 flops = len(sys.argv) > 3 and sys.argv[3] == "flops"
 dev = torch.device("cuda", 0)
-PREC = os.environ.get("TRAIN_PRECISION", "bf16")      # "fp16": the reference's AMP form (loss scaling on the device)
+PREC = os.environ.get("TRAIN_PRECISION", "fp16")      # "fp16" (default): the reference's AMP form (loss scaling on the device); "bf16"
 g = torch.Generator().manual_seed(10)
 net_hq = seeded_init_(M.VQModel().eval(), 1).to(dev)
 if which == "stage2":
