@@ -9,9 +9,6 @@
 #ifndef CONV_DMA_SPREAD
 #define CONV_DMA_SPREAD 1
 #endif
-#ifndef CONV_TILE16
-#define CONV_TILE16 0
-#endif
 #ifndef CONV_ABL_HILO
 #define CONV_ABL_HILO 0
 #endif
@@ -56,11 +53,30 @@ struct ConvParams {
   int gn_swish;
 };
 
-// kernel-family dispatchers, one per translation unit: tn = the output-channel tile (128 / 64 / 32); hilo = the hi / lo epilogue
+// Which epilogue a launch takes is a COMPILE-TIME property of the kernel (round 5): with the three of them selected at run time inside
+// one kernel, hipcc's register allocator never reused a dead accumulator register -- everything behind the K loop lived in the ~38
+// registers above the 128 accumulators, with 80-500 B/lane of scratch (see ActSel below); one epilogue per kernel: none.
+enum { EPI_FAST = 0,      // 16-bit NHWC, 16-B records: LDS-staged slabs, residual, fused GroupNorm statistics, sub-pixel scatter
+       EPI_PLANAR = 1,    // fp32 planes through an fp32 LDS slab (the DCN's offset / mask-logit planes); 3x3 stride-1 4-wave kernels
+       EPI_GENERAL = 2 }; // everything else, element by element from the C/D layout (odd pitches, fp32 NHWC, 16-bit planes, sigmoid /
+                          // swish on the accumulators)
+__host__ inline int conv_pick_epilogue(const ConvParams& p, bool planar_kernel) {
+  const bool expk = p.act == GLARE_ACT_SIGMOID || p.act == GLARE_ACT_SWISH;
+  if (p.out_mode == GLARE_OUT_NHWC_BF16 && p.fast_epilogue && !(p.res == nullptr && expk)) return EPI_FAST;
+  if (planar_kernel && p.out_mode == GLARE_OUT_PLANAR_F32 && !p.res && !expk) return EPI_PLANAR;
+  return EPI_GENERAL;
+}
+
+// kernel-family dispatchers: tn = the output-channel tile (128 / 64 / 32); hilo = the hi / lo epilogue.  The instantiations of a
+// family are spread over one translation unit per epilogue kind so that the build compiles them in parallel.
 int glare_conv_launch_k3s1(const ConvParams& p, int tn, bool hilo, hipStream_t stream);
+int glare_conv_launch_k3s1_planar(const ConvParams& p, int tn, hipStream_t stream);
+int glare_conv_launch_k3s1_general(const ConvParams& p, int tn, hipStream_t stream);
 int glare_conv_launch_k3s2(const ConvParams& p, int tn, bool hilo, hipStream_t stream);
+int glare_conv_launch_k3s2_general(const ConvParams& p, int tn, hipStream_t stream);
 int glare_conv_launch_k1(const ConvParams& p, int tn, bool hilo, hipStream_t stream);
-int glare_conv_launch_k2(const ConvParams& p, int tn, hipStream_t stream);   // sub-pixel upsample form
+int glare_conv_launch_k1_general(const ConvParams& p, int tn, hipStream_t stream);
+int glare_conv_launch_k2(const ConvParams& p, int tn, hipStream_t stream);   // sub-pixel upsample form (fast epilogue only)
 
 namespace {
 
@@ -84,25 +100,29 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-// The activation is a COMPILE-TIME constant inside the epilogues (dispatched once per workgroup, `with_act` below): as a runtime
-// switch per output element it compiled to ~3 scalar branches per element -- 128 elements per thread, several thousand cycles per
-// tile, a quarter of a 128-channel tile's whole MFMA time (found in round 2 with a plain instruction histogram of the ISA).
-template <int ACT>
-__device__ __forceinline__ float apply_act(float v) {
-  if constexpr (ACT == GLARE_ACT_RELU) return fmaxf(v, 0.f);
-  else if constexpr (ACT == GLARE_ACT_SIGMOID) return sigmoidf_(v);
-  else if constexpr (ACT == GLARE_ACT_SWISH) return swishf_(v);
-  else return v;
+// The activation inside the epilogues.  History: as a runtime `switch` per output element it compiled to ~3 scalar branches per element
+// (round 1: a quarter of a 128-channel tile's MFMA time); dispatched ONCE per workgroup into four compile-time copies of the whole
+// epilogue (rounds 2-4) the branches were gone -- but so was the register allocator's view of the accumulators' lifetime: with the
+// epilogue cloned behind a switch, hipcc never reused a dead accumulator register, the entire epilogue lived in the ~38 registers above
+// the 128 accumulators (80 B/lane of scratch, every residual piece loaded into the SAME four registers and waited for one by one), and
+// any attempt to keep more in flight spilled (round 3's residual-rows-ahead: 196 B/lane; round 5's first try: 276 B/lane with
+// `s_waitcnt vmcnt(0)` behind every piece).  With ONE copy of the epilogue the residual pieces land in the dead accumulators.
+// So the activation is a run-time value again, but branch-FREE where it is hot: the path only ever fuses none / relu into this kernel
+// (flow nets, VGG), which is a v_max + a select on a wave-uniform flag; sigmoid / swish (tests, training-side convs) sit behind ONE
+// uniform branch per 8-element group, or -- where they act on the accumulators themselves -- in a pre-pass over them.
+struct ActSel {
+  bool relu;   // wave-uniform
+  int expk;    // 0, GLARE_ACT_SIGMOID or GLARE_ACT_SWISH (wave-uniform)
+};
+__device__ __forceinline__ ActSel act_sel(int act) { return ActSel{act == GLARE_ACT_RELU, (act == GLARE_ACT_SIGMOID || act == GLARE_ACT_SWISH) ? act : 0}; }
+__device__ __forceinline__ float act_cheap(float v, bool relu) {
+  const float r = fmaxf(v, 0.f);
+  return relu ? r : v;
 }
-template <typename F>
-__device__ __forceinline__ void with_act(int act, F&& f) {
-  switch (act) {
-    case GLARE_ACT_RELU: f(std::integral_constant<int, GLARE_ACT_RELU>{}); break;
-    case GLARE_ACT_SIGMOID: f(std::integral_constant<int, GLARE_ACT_SIGMOID>{}); break;
-    case GLARE_ACT_SWISH: f(std::integral_constant<int, GLARE_ACT_SWISH>{}); break;
-    default: f(std::integral_constant<int, GLARE_ACT_NONE>{}); break;
-  }
+__device__ __forceinline__ float act_exp(float v, int expk) {   // bit-identical to sigmoidf_ / swishf_ (common.h): numerator / (1 + e^-v)
+  return (expk == GLARE_ACT_SWISH ? v : 1.0f) / (1.0f + __expf(-v));
 }
+__device__ __forceinline__ float act_any(float v, const ActSel& a) { return a.expk ? act_exp(v, a.expk) : act_cheap(v, a.relu); }
 
 
 // One 16-B piece (8 channels of one halo position) of the GNP prologue, in place in LDS.
@@ -135,7 +155,7 @@ __device__ __forceinline__ void gn_prologue_piece(u32x4* slot, const float* cf, 
 // per stage, no cross-wave dependency, and the stage being transformed (chunk c + 1, landed during tap row 0 of chunk c) is not the
 // one the MFMAs read.  Padding positions (out-of-range DMA offsets = zeros) are skipped: zero padding stays zero, as the reference
 // pads the NORMALISED tensor.  The arithmetic is gn_apply_kernel's, term for term: the result is bit-identical to conv(gn_apply(x)).
-template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int KSTEPS, bool HILO = false, bool GNP = false>
+template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int KSTEPS, bool HILO = false, bool GNP = false, int EPI = EPI_FAST>
 __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 2)) void conv_igemm_kernel(const ConvParams p_in) {
   ConvParams p = p_in;
   if (p.groups > 1) {               // uniform (scalar) adjustments: this workgroup's group
@@ -415,8 +435,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
     char* slab = smem + wave * (32 * ROWF);
     const int ncol = lane & 31, rhalf = lane >> 5;
     float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
-    with_act(p.act, [&](auto actc) {
-    constexpr int ACT = decltype(actc)::value;
+    const ActSel asel = act_sel(p.act);
     static_for<MT>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       static_for<NT>([&](auto jc) {
@@ -436,21 +455,28 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
       // (Requested BEFORE the slab pass they competed with the live accumulators and spilled: 892 vs 823 us, round 3.)
       constexpr int NIT = 32 * CPR / 64;
       [[maybe_unused]] u32x4 rvv[NIT], rlv[NIT];
-#if !CONV_EPI_RES_INLINE
-      if (p.res) {
+      // through the per-image buffer descriptor of the L2 prefetch (p.res_bytes != 0): ONE loop-invariant 32-bit lane offset, the
+      // iteration's part a constant -- no 64-bit address pair per piece (eight of them spilled: 252 B/lane of scratch) -- and rows /
+      // channels beyond the image read zeros or unused neighbours instead of branching
+      const bool res_buf = !CONV_EPI_RES_INLINE && p.res && p.res_bytes;
+#ifndef CONV_EPI_NO_SCHED_BARRIER
+      __builtin_amdgcn_sched_barrier(0);   // the requests stay BEHIND the slab writes: hoisted above them they meet the row's live accumulators
+#endif
+      if (res_buf) {
+        const size_t rimg = (size_t)b * p.OH * p.OW * p.rpitch;
+        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<a16_t*>(p.res + rimg), 0, (int)p.res_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<a16_t*>((p.res_lo ? p.res_lo : p.res) + rimg), 0,
+                                                                            (int)p.res_bytes, 0x00020000);
+        const int oy = oy0 + wm * MT + i;
+        const unsigned vo = oy < p.OH ? (unsigned)((((oy * p.OW + ox0 + lane / CPR) * p.rpitch) + p.roff + ct * TN + wn * NT * 32 + (lane % CPR) * 8) * 2)
+                                      : 0x80000000u;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-          const int idx = lane + 64 * it;
-          const int row = idx / CPR, ch = idx % CPR;
-          const int oy = oy0 + wm * MT + i, ox = ox0 + row;
-          const int co = ct * TN + wn * NT * 32 + ch * 8;
-          const bool ok = oy < p.OH && ox < p.OW && co < p.Cout;
-          const size_t roffs = ok ? (((size_t)b * p.OH + oy) * p.OW + ox) * p.rpitch + p.roff + co : 0;
-          rvv[it] = *reinterpret_cast<const u32x4*>(p.res + roffs);
-          if (p.res_lo) rlv[it] = *reinterpret_cast<const u32x4*>(p.res_lo + roffs);
+          const unsigned o = vo + (unsigned)(it * (64 / CPR) * p.rpitch * 2);
+          rvv[it] = __builtin_amdgcn_raw_buffer_load_b128(rr, o, 0, 0);
+          if (p.res_lo) rlv[it] = __builtin_amdgcn_raw_buffer_load_b128(rl, o, 0, 0);
         }
       }
-#endif
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #if CONV_ABL_HILO & 4
       if (acc[0][0][0] == 12345.f)
@@ -467,27 +493,26 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
           float v[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
           const size_t pix = ((size_t)b * p.OH + oy) * p.OW + ox;
           if (p.res) {
-#if CONV_EPI_RES_INLINE
-            const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + pix * p.rpitch + p.roff + co);
-#else
-            const u32x4 rv = rvv[it];
-#endif
+            const u32x4 rv = res_buf ? rvv[it] : *reinterpret_cast<const u32x4*>(p.res + pix * p.rpitch + p.roff + co);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[2 * e] += alo(rv[e]); v[2 * e + 1] += ahi(rv[e]); }
             if (p.res_lo) {
-#if CONV_EPI_RES_INLINE
-              const u32x4 rl = *reinterpret_cast<const u32x4*>(p.res_lo + pix * p.rpitch + p.roff + co);
-#else
-              const u32x4 rl = rlv[it];
-#endif
+              const u32x4 rl = res_buf ? rlv[it] : *reinterpret_cast<const u32x4*>(p.res_lo + pix * p.rpitch + p.roff + co);
 #pragma unroll
               for (int e = 0; e < 4; ++e) { v[2 * e] += alo(rl[e]); v[2 * e + 1] += ahi(rl[e]); }
             }
           }
+          if (asel.expk) {            // one uniform branch per 8-element group
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = act_exp(v[e], asel.expk);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = act_cheap(v[e], asel.relu);
+          }
           u32x4 hi, lo;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float a = apply_act<ACT>(v[2 * e]), c = apply_act<ACT>(v[2 * e + 1]);
+            const float a = v[2 * e], c = v[2 * e + 1];
             hi[e] = pack_a2(a, c);
 #if !(CONV_ABL_HILO & 1)
             lo[e] = pack_a2(a - alo(hi[e]), c - ahi(hi[e]));
@@ -503,7 +528,6 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    });
     });
     if (p.gn_part) {  // lanes with the same channel chunk are CPR apart: fold them, one lane per chunk writes
 #pragma unroll
@@ -534,7 +558,9 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
 #if CONV_ABL_EPI & 8
   if (acc[0][0][0] != 12345.f) return;
 #endif
-  if (p.out_mode == GLARE_OUT_NHWC_BF16 && p.fast_epilogue) {
+  // (sigmoid / swish on the accumulators themselves -- no residual in between -- take the general epilogue: any form of it here, a
+  // pre-pass over the accumulators or a branch per 32 x 32 block, cost the hot none / relu path registers; conv_pick_epilogue)
+  if constexpr (EPI == EPI_FAST) {
     constexpr int HT = (NW == 8 || MT < 2) ? 1 : MT / 2;  // tile rows per slab (smaller slabs when 8 waves share the LDS)
     constexpr int HROWS = HT * 32;                       // slab rows
     constexpr int ROWB = NT * 64 + 16;                   // slab row pitch in bytes (pad: bank spread)
@@ -547,8 +573,8 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
     // fused GroupNorm statistics of the tensor being written (the consumer's gn_stats pass would re-read it):
     // per lane the sum / sum of squares of its two 4-channel units over its pixels, from the ROUNDED values
     float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
-    with_act(p.act, [&](auto actc) {
-    constexpr int ACT = decltype(actc)::value;
+    const ActSel asel = act_sel(p.act);
+    const bool relu_early = act_early && asel.relu;
     static_for<MT / HT>([&](auto hc) {
       constexpr int half = decltype(hc)::value;
       static_for<NT>([&](auto jc) {
@@ -571,8 +597,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
 #pragma unroll
           for (int t = 0; t < 8; ++t) {
             constexpr int i = half * HT + il;
-            float a = acc[i][j][2 * t] + bv, c = acc[i][j][2 * t + 1] + bv;
-            if (act_early) { a = apply_act<ACT>(a); c = apply_act<ACT>(c); }
+            const float a = act_cheap(acc[i][j][2 * t] + bv, relu_early), c = act_cheap(acc[i][j][2 * t + 1] + bv, relu_early);
             const float send = odd ? a : c;
             const float recv = __shfl_xor(send, 1, 64);
             const int r = 2 * t + odd;                                  // the register (row) this lane writes
@@ -585,20 +610,25 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
       // the residual pieces of this slab, all requested at once behind phase 1 (whose accumulators are dead by now): see the hi / lo
       // epilogue above -- one L2 round trip per slab instead of one per iteration
       constexpr int NIT = HROWS * CPR / 64;
-      constexpr bool RES_AHEAD = !CONV_EPI_RES_INLINE && NIT <= 8;
+      constexpr bool RES_AHEAD = !CONV_EPI_RES_INLINE && NIT <= 8 && KS != 2;
       [[maybe_unused]] u32x4 rvv[RES_AHEAD ? NIT : 1];
+      bool res_buf = false;
       if constexpr (RES_AHEAD) {
-        if (p.res) {
+        res_buf = p.res && p.res_bytes;     // the per-image descriptor of the L2 prefetch: one 32-bit lane offset + a constant per piece
+#ifndef CONV_EPI_NO_SCHED_BARRIER
+        __builtin_amdgcn_sched_barrier(0);  // the requests stay BEHIND phase 1: hoisted above it they meet the slab's live accumulators
+#endif
+        if (res_buf) {
+          const size_t rimg = (size_t)b * p.OH * p.OW * p.rpitch;
+          const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<a16_t*>(p.res + rimg), 0, (int)p.res_bytes, 0x00020000);
+          const int oyb = oy0 + wm * MT + half * HT;
+          const unsigned vo = (unsigned)((((oyb * p.OW + ox0 + lane / CPR) * p.rpitch) + p.roff + ct * TN + wn * NT * 32 + (lane % CPR) * 8) * 2);
 #pragma unroll
           for (int it = 0; it < NIT; ++it) {
-            const int idx = lane + 64 * it;
-            const int row = idx / CPR, ch = idx % CPR;
-            const int oy = oy0 + wm * MT + half * HT + row / 32, ox = ox0 + (row & 31);
-            const int co = ct * TN + wn * NT * 32 + ch * 8;
-            const bool ok = oy < p.OH && ox < p.OW && co < p.Cout;
-            const size_t pix = KS == 2 ? ((size_t)b * (2 * p.OH) + 2 * oy + pa) * (size_t)(2 * p.OW) + 2 * ox + pb
-                                       : ((size_t)b * p.OH + oy) * p.OW + ox;
-            rvv[it] = *reinterpret_cast<const u32x4*>(p.res + (ok ? pix * p.rpitch + p.roff + co : 0));
+            constexpr int RPI = 64 / CPR;                       // slab rows per iteration
+            const int dy = (it * RPI) / 32, dx = (it * RPI) % 32;
+            const unsigned o = oyb + dy < p.OH ? vo + (unsigned)((dy * p.OW + dx) * p.rpitch * 2) : 0x80000000u;
+            rvv[it] = __builtin_amdgcn_raw_buffer_load_b128(rr, o, 0, 0);
           }
         }
       }
@@ -615,14 +645,19 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
                                      : ((size_t)b * p.OH + oy) * p.OW + ox;
           if (p.res) {
             u32x4 rv;
-            if constexpr (RES_AHEAD) rv = rvv[it];
+            if (res_buf) rv = rvv[RES_AHEAD ? it : 0];
             else rv = *reinterpret_cast<const u32x4*>(p.res + pix * p.rpitch + p.roff + co);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
 #if CONV_ABL_EPI & 1
-              v[e] ^= rv[e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] ^= rv[e];
 #else
-              v[e] = pack_a2(apply_act<ACT>(alo(v[e]) + alo(rv[e])), apply_act<ACT>(ahi(v[e]) + ahi(rv[e])));
+            if (asel.expk) {            // one uniform branch per 8-element group
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = pack_a2(act_exp(alo(v[e]) + alo(rv[e]), asel.expk), act_exp(ahi(v[e]) + ahi(rv[e]), asel.expk));
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = pack_a2(act_cheap(alo(v[e]) + alo(rv[e]), asel.relu), act_cheap(ahi(v[e]) + ahi(rv[e]), asel.relu));
+            }
 #endif
           }
 #if CONV_ABL_EPI & 4
@@ -640,7 +675,6 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    });
     });
     if (p.gn_part) {  // lanes with the same channel chunk are CPR apart: fold them, one lane per chunk writes
 #pragma unroll
@@ -666,16 +700,16 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
   // layout a lane holds ONE output channel, so a direct planar store is 64 scattered 4-B words per instruction (32 planes x 2); via
   // a wave-private fp32 slab (one 32-pixel tile row at a time) each lane stores 4 consecutive pixels of one plane and 8 consecutive
   // lanes cover the 128 contiguous bytes of the row.  128 -> 108 at 8 x 420 x 620: 1.31 -> 0.83 ms; 256 -> 108 at half size: 0.45 -> 0.32 ms.
-  if constexpr (!HILO && KS == 3 && STRIDE == 1 && NW == 4) {
-    if (p.out_mode == GLARE_OUT_PLANAR_F32 && !p.res) {
+  if constexpr (EPI == EPI_PLANAR) {
+    static_assert(!HILO && KS == 3 && STRIDE == 1 && NW == 4, "the planar slab epilogue exists for the 3x3 stride-1 4-wave kernels");
+    {
       constexpr int ROWD = NT * 32 + 1;                 // slab row pitch in dwords (odd: column reads spread over the banks)
       static_assert(NW * 32 * ROWD * 4 <= (2 * A_SLOTS + 2 * B_CHUNKS) * 16, "planar epilogue slab fits the pipeline LDS");
       typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
       __syncthreads();  // every wave is done reading the pipeline buffers
       float* slab = reinterpret_cast<float*>(smem) + wave * (32 * ROWD);
       const int ncol = lane & 31, rhalf = lane >> 5;
-      with_act(p.act, [&](auto actc) {
-      constexpr int ACT = decltype(actc)::value;
+      const ActSel asel = act_sel(p.act);
       static_for<MT>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         static_for<NT>([&](auto jc) {
@@ -685,7 +719,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int m = (r & 3) + 8 * (r >> 2) + 4 * rhalf;
-            slab[m * ROWD + j * 32 + ncol] = apply_act<ACT>(acc[i][j][r] + bv);
+            slab[m * ROWD + j * 32 + ncol] = act_cheap(acc[i][j][r] + bv, asel.relu);
           }
         });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -710,17 +744,16 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       });
-      });
       return;
     }
   }
 
-  // ---- epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // ---- general epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  if constexpr (EPI == EPI_GENERAL) {
   const int ncol = lane & 31, rhalf = lane >> 5;
   // static_for: the accumulator indices must be compile-time constants (a runtime-indexed
   // ext_vector array is demoted to scratch memory)
-  with_act(p.act, [&](auto actc) {
-  constexpr int ACT = decltype(actc)::value;
+  const ActSel asel = act_sel(p.act);   // the general epilogue (odd pitches, fp32 NHWC, 16-bit planes): not a hot path, a branch per element is fine
   static_for<NT>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
     const int co = ct * TN + (wn * NT + j) * 32 + ncol;
@@ -743,7 +776,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
             if (row_ok && co_ok && xb + e < p.OW) {
               float y = v[e];
               if (p.res) y += a2f(p.res[(pix0 + e) * p.rpitch + p.roff + co]);
-              y = apply_act<ACT>(y);
+              y = act_any(y, asel);
               if (p.out_mode == GLARE_OUT_NHWC_BF16)
                 reinterpret_cast<a16_t*>(p.out)[(pix0 + e) * p.opitch + p.ooff + co] = f2a(y);
               else
@@ -756,7 +789,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               if (xb + e < p.OW) {
-                const float y = apply_act<ACT>(v[e]);
+                const float y = act_any(v[e], asel);
                 if (p.out_mode == GLARE_OUT_PLANAR_F32)
                   reinterpret_cast<float*>(p.out)[base + e] = y;
                 else
@@ -768,10 +801,10 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
       }
     });
   });
-  });
+  }
 }
 
-template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int KSTEPS, bool HILO = false, bool GNP = false>
+template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int KSTEPS, bool HILO = false, bool GNP = false, int EPI = EPI_FAST>
 int launch(const ConvParams& p_in, hipStream_t stream) {
   using G = TileGeom<KS, STRIDE, WM * MT>;
   constexpr int TN = WN * NT * 32;
@@ -782,8 +815,11 @@ int launch(const ConvParams& p_in, hipStream_t stream) {
   p.n_blocks = (int)nb;
   p.gn_nparts = p.tiles_x * cdiv(p.OH, 8) * 2 * (KS == 2 ? 4 : 1);  // the 8 x 32 grid, 2 wave rows (4 rows each) per block
   if (p.gn_part && !(p.fast_epilogue && p.Cout % 32 == 0)) return GLARE_ERR_UNSUPPORTED;
+  if (p.gn_part && !HILO && EPI != EPI_FAST) return GLARE_ERR_UNSUPPORTED;   // the fused statistics live in the slab epilogues
   const size_t lds = (size_t)(2 * (((KSTEPS * 2 * G::NPOS + 63) / 64) * 64) + 2 * KS * KSTEPS * 2 * TN) * 16 + (GNP ? (size_t)p.Cin0 * 8 : 0);
-  auto kern = conv_igemm_kernel<KS, STRIDE, MT, NT, WM, WN, KSTEPS, HILO, GNP>;
+  constexpr bool PLANAR_KERNEL = !HILO && KS == 3 && STRIDE == 1 && WM * WN == 4;
+  if (!HILO && conv_pick_epilogue(p, PLANAR_KERNEL) != EPI) return GLARE_ERR_INVALID;   // the dispatcher picked the wrong instantiation
+  auto kern = conv_igemm_kernel<KS, STRIDE, MT, NT, WM, WN, KSTEPS, HILO, GNP, EPI>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GLARE_ERR_LAUNCH;

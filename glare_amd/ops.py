@@ -553,8 +553,10 @@ def conv2d(x, pc, *, x2=None, cin=None, in_off=0, cin2=None, in2_off=0, stride=1
         d.out_pitch = out.shape[1]
         d.plane_pitch = out.shape[2]
     d.out, d.Cout, d.out_off = out.data_ptr(), pc.cout, out_off
+    # (the hi / lo epilogue and the GroupNorm prologue exist for the 128-wide tile only: those launches keep it -- a narrower tile came
+    # back as GLARE_ERR_UNSUPPORTED from the single-pass hi / lo stream at the training crops)
     if (AUTO_COUT_TILE and pc.ksize == 3 and pc.cout > 64 and getattr(pc, "cout_tile", 0) == 0 and not getattr(pc, "subpixel", False)
-            and getattr(pc, "_src", None) is not None):
+            and getattr(pc, "_src", None) is not None and not hilo and gn_prologue is None):
         tile = conv_cout_tile(B, OH, OW, pc.cout)
         if tile == 32 and gn_stats:
             tile = 64          # the fused GroupNorm statistics need 4-row wave slabs (128- and 64-wide tiles)

@@ -46,8 +46,9 @@ def test_product_refuses_cpu_tensors():
 
 
 def test_half_library_exports_the_inference_entry_points():
-    """libglare_hip_f16.so (IEEE-half activations / filters): its exports are declared in the header -- a *_bf16 entry point under
-    the name *_f16, identical signature -- and it is a subset (the inference kernels), never a superset."""
+    """libglare_hip_f16.so (IEEE-half activations / filters; since round 4 a build of EVERY source, training kernels included):
+    each export is declared in the header -- a *_bf16 entry point under the name *_f16, identical signature -- and it exports
+    nothing the header does not declare."""
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_F16_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r"\bT (glare_[a-z0-9_]+)", out))
     declared = set(_lib.header_symbols())

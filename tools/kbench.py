@@ -228,6 +228,38 @@ def bench_attnbwd():
     print("attnbwd B=%d N=%d d=512: fused %.3f ms  %.0f TFLOP/s algorithmic (5 products);  materialised %.3f ms" % (Bt, N, ms, fl / ms / 1e9, ms_old))
 
 
+def bench_attnfold():
+    """VERDICT r04 item 5 -- AttnBlock's two per-image 1x1 GEMMs as prologue / epilogue of attn_kv_fwd_kernel: what the separate
+    launches cost today against what the same MFMAs would cost INSIDE the attention kernel (fp16, B = 8, N = 16 275).
+    Inside the kernel a workgroup owns 128 query rows; producing its Q tile is 128 x 512 x 512 MACs = the score product against 512
+    keys (16 key tiles), projecting its O tile the same again as a P.V product -- together ONE pass of the main loop over 16 more key
+    tiles per workgroup, plus a 512 KB filter streamed through LDS per workgroup and product (the K / V stream is 16.7 MB)."""
+    with ops.use_precision("fp16"):
+        H, W, C = 105, 155, 512
+        N = H * W
+        x = torch.randn(B, H, W, C, device=DEV).half()
+        stats = ops.conv2d(x, ops.PackedConv(torch.randn(C, C, 1, 1, device=DEV) * 0.04, None), gn_stats=True)._gn_stats
+        wq, wo = torch.randn(C, C, device=DEV) * 0.04, torch.randn(C, C, device=DEV) * 0.04
+        bq, bo, g, b = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV), torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+        t_fold = timeit(lambda: ops.attn_fold_groupnorm(stats, N, g, b, 1e-6, wq, bq, wo, bo))
+        wq_b, bq_b, wo_b, bo_b = ops.attn_fold_groupnorm(stats, N, g, b, 1e-6, wq, bq, wo, bo)
+        t_q = timeit(lambda: ops.conv1x1_per_image(x, wq_b, bq_b))
+        q = ops.conv1x1_per_image(x, wq_b, bq_b)
+        out = torch.empty(B, N, C, dtype=torch.float16, device=DEV)
+        t_a = timeit(lambda: ops.attention_kv512(q.view(B, N, C), x.view(B, N, C), N, out=out, key_splits=1))
+        t_o = timeit(lambda: ops.conv1x1_per_image(out.view(B, H, W, C), wo_b, bo_b, residual=x, gn_stats=True))
+        qb, kt = (N + 127) // 128, (N + 31) // 32
+        per_tile = t_a / kt                       # one pass of every workgroup over one 32-key tile
+        inside = 16 * per_tile                    # 16 tile-equivalents: Q prologue (as a score product) + O epilogue (as a P.V product)
+        print("attnfold today, per block: fold kernel %.3f + q 1x1 %.3f + out 1x1 (+ residual, statistics) %.3f = %.3f ms in 3 launches; attention %.3f ms"
+              % (t_fold, t_q, t_o, t_fold + t_q + t_o, t_a))
+        print("attnfold inside the kernel: %d query blocks x %d key tiles at %.2f us per tile pass -> the two GEMMs = 16 tile passes = %.3f ms "
+              "(+%.1f %% of the launch), before the 2 x 512 KB filter stream per workgroup, the Q / O layout changes through LDS and the "
+              "residual + statistics epilogue that would move in with them" % (qb, kt, per_tile * 1e3, inside, 100 * inside / t_a))
+        print("attnfold bound on the gain: %.3f - %.3f = %.3f ms per block (the fold kernel stays: it builds the per-image filters), x 11 blocks = %.2f ms per step of %d images"
+              % (t_q + t_o, inside, t_q + t_o - inside, 11 * (t_q + t_o - inside), B))
+
+
 def bench_convin():
     """conv_in 3 -> 128 on the NCHW fp32 image at full resolution (conv_small_kernel): HBM-bound on its bf16 output."""
     H, W, co = 420, 620, 128

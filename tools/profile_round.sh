@@ -8,6 +8,8 @@ mkdir -p gpurun_out
 python bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench.err
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o b -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train --no-streams2 --no-power > gpurun_out/${tag}_bench_prof.log 2>&1
 python tools/rocpd_stats.py $(ls gpurun_out/prof_$tag/*/b_results.db gpurun_out/prof_$tag/b_results.db 2>/dev/null | head -1) > gpurun_out/${tag}_bench_kernel_stats.txt 2>&1
+python tools/agreement_check.py gpurun_out/${tag}_bench_line.json gpurun_out/${tag}_bench_kernel_stats.txt > gpurun_out/${tag}_agreement.txt 2>&1   # the README's "agreement check", generated
+python bench.py --batch 4 --steps 20 --warmup 5 --no-train --no-cpu-baseline > gpurun_out/${tag}_bench_line_b4.json 2>> gpurun_out/${tag}_bench.err   # the per-rank workload of BASELINE configs[2] (32 images over 8 GPUs)
 {
   echo "# rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in SEPARATE runs, counters only), MI355X, B=8, $tag"
   echo "# units: KB per dispatch as reported; gfx950: FETCH_SIZE reports 1/2 of a wide coalesced read stream -> x2 (MI355X_MICROARCH.md)"
@@ -18,6 +20,7 @@ python tools/rocpd_stats.py $(ls gpurun_out/prof_$tag/*/b_results.db gpurun_out/
   for k in attn conv dcn; do echo "== $k"; bash tools/pmc_kernel.sh ${tag}_$k $k 2>&1 | grep -v "amdgpu.ids"; done
 } > gpurun_out/${tag}_pmc_kernels.txt
 python tools/kbench.py attn conv convsplit gn dcn vq wgrad attnbwd > gpurun_out/${tag}_kbench.txt 2>&1
+python tools/kbench.py attnfold > gpurun_out/${tag}_attn_fold.txt 2>&1
 python tools/probes/power_clock_probe.py 4 2>&1 | grep -v "amdgpu.ids" > gpurun_out/${tag}_power_clock.txt   # the power wall: random vs all-zero operands
 bash tools/pmc_shapes.sh $tag > /dev/null 2>&1          # per-SHAPE traffic of the conv / DCN launches -> ${tag}_pmc_shapes.json
 # end-to-end parity: 12 scenes of the default path (tools/parity_scenes.py), then the precision ladder on three of them -- round 3's
