@@ -36,26 +36,13 @@ constexpr int BM = 128;          // query rows per workgroup
 constexpr int BN = 32;           // keys per tile
 constexpr int KCH = BN * (HD / 8);   // 16-B chunks per K tile  (2048)
 constexpr float RESCALE_THR = 8.0f;  // log2 units
-// ATTN_PIPELINED=1 selects a software-pipelined tile loop (S(j+1) on the matrix pipe while the vector ALU runs softmax(j);
-// the last quarter of Q moved to LDS to make room for the second score accumulator).  Measured on MI355X: +1 % (1036 vs 1023
-// TFLOP/s, run-to-run noise is 2 %), and 1206 vs 1303 TFLOP/s with the DMA ablated -- the serial softmax is NOT what
-// limits the kernel; the 64 LDS-DMA pieces per tile are (~25 %).  Kept as a reproducible negative result; default off.
-#ifndef ATTN_PIPELINED
-#define ATTN_PIPELINED 0
-#endif
-// ATTN_8WAVES=1 selects attn8w_fwd_kernel (8 waves x 16 query rows on v_mfma_f32_16x16x32_bf16, two waves per SIMD).  Measured:
-// 975-995 TFLOP/s vs 1 030-1 045 for the 4-wave kernel; with the DMA compiled out 1 056 vs 1 288.  Two waves per SIMD do hide
-// the DMA issue cost (8 % instead of 25 %), but every 1-KB fragment then feeds a 16-row MFMA: twice the LDS read traffic per
-// flop (512 KB per 32-key tile per CU) becomes the limit.  Kept as a reproducible alternative; default off.
-#ifndef ATTN_8WAVES
-#define ATTN_8WAVES 0
-#endif
-#ifndef ATTN_V_IN_PHASE_B
-#define ATTN_V_IN_PHASE_B 0
-#endif
-#ifndef ATTN_DMA_PER_GROUP
-#define ATTN_DMA_PER_GROUP 2  // DMA pieces issued per 4-MFMA group (2: all 16 during QK^T; 1: over the whole tile)
-#endif
+// Variants of this kernel measured in rounds 1-2 and not kept (their code left the tree in round 5; figures in DESIGN.md section 3): a
+// software-pipelined tile loop (S(j+1) on the matrix pipe while the vector ALU runs softmax(j), the last quarter of Q in LDS): +1 %
+// (1036 vs 1023 TFLOP/s; 1206 vs 1303 with the DMA compiled out) -- the serial softmax is NOT what limits the kernel, the 64 LDS-DMA
+// pieces per tile are (~25 %); an 8-wave form (16 query rows per wave on v_mfma_f32_16x16x32, two waves per SIMD): 975-995 vs 1 030-1 045
+// TFLOP/s -- two waves per SIMD do hide the DMA issue cost (8 % instead of 25 %), but every 1-KB fragment then feeds a 16-row MFMA and
+// twice the LDS read traffic per flop (512 KB per 32-key tile per CU) becomes the limit.
+constexpr int ATTN_DMA_PER_GROUP = 2;  // DMA pieces issued per 4-MFMA group (2: all 16 during QK^T; 1, over the whole tile, measured slower)
 
 __device__ __forceinline__ void dma16a(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -172,187 +159,13 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) vofs[ks] = 2 * KCH * 16 + (ql * 4 + ((2 * ks + hi) ^ ((ql >> 2) & 3))) * 16;
 
-#if ATTN_PIPELINED
-  // Software-pipelined tile loop: iteration j computes S(j+1) = K(j+1).Q^T on the matrix pipe WHILE the vector ALU turns
-  // S(j) into P(j) (online softmax), then O += V(j).P(j).  The softmax (max / exp2 / sum / bf16 pack, ~15 % of a tile when
-  // serialised) hides in the issue slack of the 32-deep dependent S accumulation.  K and V^T keep separate double buffers
-  // with different deadlines: during iteration j the DMA fetches K(j+2) and V^T(j+1).
-  const char* const kbuf[2] = {smem, smem + KCH * 16};
-  auto ldk = [&](int ks4, const char* kb, a16x8(&f)[4]) {   // ks4: compile-time group index
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int ks = 4 * ks4 + e;
-      f[e] = *reinterpret_cast<const a16x8*>(kb + kofs[ks & 7] + (ks >> 3) * 256);
-    }
-  };
-  auto ldv = [&](int g, const char* vb, a16x8(&f)[4]) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) f[e] = *reinterpret_cast<const a16x8*>(vb + vofs[e & 1] + (2 * g + (e >> 1)) * 2048);
-  };
-  auto issue_k = [&](auto ic, int tile, int buf) {   // piece i of a K tile (8 per wave)
-    constexpr int i = decltype(ic)::value;
-    const int r = wave + 4 * i;
-    const int kv = min(tile * BN + r, p.N - 1);
-    const char* row = reinterpret_cast<const char*>(kbase + (size_t)kv * p.ldk);
-    dma16a(row + (unsigned)((lane ^ (r & 15)) * 16), lK + buf * KCH + r * 64);
-  };
-  auto issue_v = [&](auto ic, int tile, int buf) {   // piece j of a V^T tile (8 per wave)
-    constexpr int j = decltype(ic)::value;
-    const char* grp = reinterpret_cast<const char*>(vbase + (size_t)(wave + 4 * j) * 16 * p.Npad + (size_t)tile * BN);
-    dma16a(grp + v_lane_off, lV + buf * KCH + (wave + 4 * j) * 64);
-  };
-  auto mask_tail = [&](f32x16& sc, int tile) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int kv = tile * BN + 16 * (r >> 3) + 8 * hi + (r & 7);
-      if (kv >= p.N) sc[r] = -__builtin_inff();
-    }
-  };
-
-  // The last quarter of Q (k-steps 24..31, 32 VGPRs) lives in a wave-private 8 KB LDS slab and is re-read per tile: the
-  // registers it frees hold the second score accumulator of the pipeline.
-  char* const qslab = smem + 4 * KCH * 16 + wave * 8192 + lane * 16;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) *reinterpret_cast<a16x8*>(qslab + i * 1024) = qf[24 + i];
-  auto ldq = [&](int g, a16x8(&f)[4]) {   // g = 6, 7
-#pragma unroll
-    for (int e = 0; e < 4; ++e) f[e] = *reinterpret_cast<const a16x8*>(qslab + (4 * (g - 6) + e) * 1024);
-  };
-
-  f32x16 s_cur;
-  {  // prologue: K(0), K(1), V^T(0) in flight; S(0)
-    static_for<8>([&](auto ic) { issue_k(ic, 0, 0); });
-    static_for<8>([&](auto ic) { issue_v(ic, 0, 0); });
-    static_for<8>([&](auto ic) { issue_k(ic, min(1, n_tiles - 1), 1); });
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s_cur[r] = 0.f;
-    a16x8 f0[4];
-    static_for<8>([&](auto gc) {
-      constexpr int g = decltype(gc)::value;
-      ldk(g, kbuf[0], f0);
-      if constexpr (g < 6) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s_cur = mfma_a16_32x32x16(f0[e], qf[4 * g + e], s_cur, 0, 0, 0);
-      } else {
-        a16x8 q0[4];
-        ldq(g, q0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s_cur = mfma_a16_32x32x16(f0[e], q0[e], s_cur, 0, 0, 0);
-      }
-    });
-    if (n_tiles == 1) mask_tail(s_cur, 0);
-  }
-
-  auto tile_body = [&](auto bufc, int tile) {
-    constexpr int BUF = decltype(bufc)::value;   // == tile & 1
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K(tile+1), V^T(tile) have landed ...
-    __syncthreads();                                    // ... for everybody; K(tile), V^T(tile-1) are retired
-    const int t1 = min(tile + 1, n_tiles - 1), t2 = min(tile + 2, n_tiles - 1);   // clamped: redundant reloads, branch-free
-    const char* kb = kbuf[BUF ^ 1];                     // K(tile+1)
-    const char* vb = smem + BUF * KCH * 16;             // V^T(tile) (vofs carries the V base)
-    a16x8 fr[3][4], qt[4];
-    f32x16 s_nxt;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s_nxt[r] = 0.f;
-    float mx = 0.f, psum = 0.f;
-    u32x4 w[2];
-    // ---- phase A: S(tile+1) on the matrix pipe, softmax(tile) in its shadow, one slice per MFMA group
-    ldk(0, kb, fr[0]);
-    ldk(1, kb, fr[1]);
-    static_for<8>([&](auto gc) {
-      constexpr int g = decltype(gc)::value;
-      if constexpr (g + 2 < 8) ldk(g + 2, kb, fr[(g + 2) % 3]);
-      else ldv(g + 2 - 8, vb, fr[(g + 2) % 3]);
-#ifndef ATTN_ABLATE_NODMA
-      issue_k(std::integral_constant<int, g>{}, t2, BUF);        // K(tile+2) over K(tile)'s buffer
-#if !ATTN_V_IN_PHASE_B
-      issue_v(std::integral_constant<int, g>{}, t1, BUF ^ 1);    // V^T(tile+1) over V^T(tile-1)'s buffer
-#endif
-#endif
-      if constexpr (g == 5) ldq(6, qt);                 // Q tail for group 6, one group ahead
-      if constexpr (g < 6) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s_nxt = mfma_a16_32x32x16(fr[g % 3][e], qf[4 * g + e], s_nxt, 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s_nxt = mfma_a16_32x32x16(fr[g % 3][e], qt[e], s_nxt, 0, 0, 0);
-        if constexpr (g == 6) ldq(7, qt);               // reuses the registers group 6 has just consumed
-      }
-      if constexpr (g == 0) {
-        mx = s_cur[0];
-#pragma unroll
-        for (int r = 1; r < 8; ++r) mx = fmaxf(mx, s_cur[r]);
-      } else if constexpr (g == 1) {
-#pragma unroll
-        for (int r = 8; r < 16; ++r) mx = fmaxf(mx, s_cur[r]);
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-        mx = fmaxf(mx, __uint_as_float(hi ? sw[0] : sw[1]));
-      } else if constexpr (g == 2) {
-        if (__any(mx > m_run + RESCALE_THR)) {  // wave-uniform, rare: rescale everything still at the old max
-          const float m_new = fmaxf(m_run, mx);
-          const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-          l_run *= alpha;
-#pragma unroll
-          for (int i = 0; i < HD / 32; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              float x = o[i][r], tmp;
-              asm volatile("v_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\tv_accvgpr_write_b32 %0, %1"
-                           : "+a"(x), "=&v"(tmp)
-                           : "v"(alpha));
-              o[i][r] = x;
-            }
-          m_run = m_new;
-        }
-      } else if constexpr (g <= 6) {   // g = 3..6: four scores each
-        constexpr int q4 = g - 3;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const float p0 = __builtin_amdgcn_exp2f(s_cur[4 * q4 + 2 * e] - m_run);
-          const float p1 = __builtin_amdgcn_exp2f(s_cur[4 * q4 + 2 * e + 1] - m_run);
-          psum += p0 + p1;
-          w[q4 >> 1][2 * (q4 & 1) + e] = pack_a2(p0, p1);
-        }
-      } else {
-        l_run += psum;
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    // branch-free (a conditional call here costs the register allocator ~60 spills): real tiles mask keys >= N, the redundant
-    // tile past the end is masked entirely and never consumed
-    mask_tail(s_nxt, tile + 1 < n_tiles ? tile + 1 : n_tiles);
-    const a16x8 pf[2] = {__builtin_bit_cast(a16x8, w[0]), __builtin_bit_cast(a16x8, w[1])};
-    s_cur = s_nxt;
-    // ---- phase B: O^T += V^T(tile) . P^T(tile)
-    static_for<8>([&](auto gc) {
-      constexpr int g = decltype(gc)::value;
-      if constexpr (g + 2 < 8) ldv(g + 2, vb, fr[(8 + g + 2) % 3]);
-#if ATTN_V_IN_PHASE_B && !defined(ATTN_ABLATE_NODMA)
-      issue_v(std::integral_constant<int, g>{}, t1, BUF ^ 1);
-#endif
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        o[2 * g + (e >> 1)] = mfma_a16_32x32x16(fr[(8 + g) % 3][e], pf[e & 1], o[2 * g + (e >> 1)], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    });
-  };
-
-  for (int tile = 0; tile < n_tiles; tile += 2) {
-    tile_body(std::integral_constant<int, 0>{}, tile);
-    if (tile + 1 < n_tiles) tile_body(std::integral_constant<int, 1>{}, tile + 1);
-  }
-#else
   // One key tile.  BUF is a compile-time constant so that the buffer offset folds into the ds_read
   // immediate.  Fragment reads run two groups (8 x ds_read_b128) ahead of the MFMAs that consume them
   // through a 3-deep rotating register set; the first V^T groups are fetched before the softmax.
   auto tile_body = [&](auto bufc, int tile) {
     constexpr int BUF = decltype(bufc)::value;
-#ifndef ATTN_ABLATE_NOBARRIER
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-#endif
     // The next tile's 16 DMA pieces are NOT issued here in one burst (all four waves would queue on the
     // texture-address path with the matrix pipe idle: measured -27 %); they are spread, ATTN_DMA_PER_GROUP per
     // MFMA group, so the address path works under the MFMAs.
@@ -384,12 +197,10 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
       constexpr int g = decltype(gc)::value;
       if constexpr (g + 2 < 8) ldk(std::integral_constant<int, g + 2>{}, fr[(g + 2) % 3]);
       else ldv(std::integral_constant<int, g + 2 - 8>{}, fr[(g + 2) % 3]);
-#ifndef ATTN_ABLATE_NODMA
       static_for<ATTN_DMA_PER_GROUP>([&](auto kc) {
         constexpr int piece = g * ATTN_DMA_PER_GROUP + decltype(kc)::value;
         if constexpr (piece < 16) issue_piece(std::integral_constant<int, piece>{}, nxt, BUF ^ 1);
       });
-#endif
 #pragma unroll
       for (int e = 0; e < 4; ++e) s = mfma_a16_32x32x16(fr[g % 3][e], qf[4 * g + e], s, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
@@ -434,12 +245,8 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
       u32x4 w;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-#ifdef ATTN_ABLATE_NOEXP  // timing ablation only (tools/): wrong results
-        const float p0 = s[8 * h + 2 * e], p1 = s[8 * h + 2 * e + 1];
-#else
         const float p0 = __builtin_amdgcn_exp2f(s[8 * h + 2 * e] - m_run);
         const float p1 = __builtin_amdgcn_exp2f(s[8 * h + 2 * e + 1] - m_run);
-#endif
         psum += p0 + p1;
         w[e] = pack_a2(p0, p1);
       }
@@ -451,12 +258,10 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
     static_for<8>([&](auto gc) {
       constexpr int g = decltype(gc)::value;
       if constexpr (g + 2 < 8) ldv(std::integral_constant<int, g + 2>{}, fr[(8 + g + 2) % 3]);
-#ifndef ATTN_ABLATE_NODMA
       static_for<ATTN_DMA_PER_GROUP>([&](auto kc) {
         constexpr int piece = (8 + g) * ATTN_DMA_PER_GROUP + decltype(kc)::value;
         if constexpr (piece < 16) issue_piece(std::integral_constant<int, piece>{}, nxt, BUF ^ 1);
       });
-#endif
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         o[2 * g + (e >> 1)] = mfma_a16_32x32x16(fr[(8 + g) % 3][e], pf[e & 1], o[2 * g + (e >> 1)], 0, 0, 0);
@@ -470,7 +275,6 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
     if (tile + 1 < t_end) tile_body(std::integral_constant<int, 1>{}, tile + 1);
   }
 
-#endif
 
   // ---- normalise and store O[q][d] (bf16): a lane owns ONE query row, 4 consecutive d per store
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -505,14 +309,6 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
   }
 }
 
-// The 8-wave variant (ATTN_8WAVES=1; measured 975-995 TFLOP/s against the 4-wave kernel's 1 020-1 050) lives in tools/experiments/.
-#if ATTN_8WAVES
-#ifndef GLARE_ABLATE
-#error "ATTN_8WAVES is an experiment: build with GLARE_DEFS='-DGLARE_ABLATE -DATTN_8WAVES=1' (build.py then adds -I tools/experiments)"
-#endif
-#include "attn_8waves.inc"   // found through -I tools/experiments, which only a GLARE_ABLATE build passes: the product build never reads tools/
-#endif
-
 // ---------------------------------------------------------------------------------------------------------------------
 // Shared-K/V form (attn_kv_fwd_kernel): out[i] = sum_j softmax_j(q'_i . x_j) x_j  -- keys AND values are the same tensor x.
 //
@@ -535,15 +331,6 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_fwd_kernel(const AttnParam
 // structure of attn_fwd_kernel above.
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
-#ifndef ATTNKV_PV_AHEAD
-#define ATTNKV_PV_AHEAD 1    // P.V fragment reads issued this many 4-MFMA groups ahead (1 or 2)
-#endif
-#ifndef ATTNKV_PIPELINED
-#define ATTNKV_PIPELINED 0   // 1: attn_kv_pipe_kernel (three-stage software pipeline); 0: attn_kv_fwd_kernel (sequential phases)
-#endif
-#ifndef ATTNKV_DMA_PHASE
-#define ATTNKV_DMA_PHASE 0   // 0: the tile's 8 DMA pieces go one per QK^T group; 1: one per P.V group
-#endif
 
 __device__ __forceinline__ int kv_swz(int key) { return ((key & 3) << 2) | ((key >> 2) & 3); }
 
@@ -593,7 +380,7 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_kv_fwd_kernel(const AttnPa
   for (int i = 0; i < HD / 32; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-  // Round 3, measured and NOT kept (alternated A/B on one box, tools/attn_ab.sh): (1) starting the score accumulator at -m_run
+  // Round 3, measured and NOT kept (alternated A/B on one box): (1) starting the score accumulator at -m_run
   // (written among the previous tile's last P.V MFMAs) so that the softmax needs no subtraction -- bit-correct, but 16 registers
   // carried across the loop in a register file that is exactly full (O 256 + Q 128) became 1036 B/lane of scratch: 21.4 ms
   // instead of 3.8; (2) the 16-score maximum as 7 v_max3_f32 + 1 v_max_f32 instead of hipcc's 15 v_max_f32: 3.82 vs 3.82 ms.
@@ -638,19 +425,12 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_kv_fwd_kernel(const AttnPa
       }
   }
 
-#ifdef ATTNKV_PROFILE   // per-phase cycle sums of wave 0 of workgroup 0 (s_memtime; costs ~10 %): tools/kbench.py KB_PROF=1
-  unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, pt = __builtin_readcyclecounter();
-#define PROF_MARK(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); pc[i] += t_ - pt; pt = t_; } while (0)
-#else
 #define PROF_MARK(i) do {} while (0)
-#endif
   auto tile_body = [&](auto bufc, int tile) {
     constexpr int BUF = decltype(bufc)::value;
     PROF_MARK(0);                                  // loop overhead
-#ifndef ATTN_ABLATE_NOBARRIER
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-#endif
     PROF_MARK(1);                                  // wait + barrier
     const int nxt = min(tile + 1, t_end - 1);  // last tile: a redundant reload keeps the loop branch-free
     const char* tb = smem + BUF * KCH * 16;
@@ -682,11 +462,7 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_kv_fwd_kernel(const AttnPa
     auto vfrag = [&](const u32x2(&f)[8], int e) {
       return __builtin_bit_cast(a16x8, u32x4{f[2 * e][0], f[2 * e][1], f[2 * e + 1][0], f[2 * e + 1][1]});
     };
-#if ATTNKV_PV_AHEAD == 2
-    u32x2 vf[3][8];   // fragments two groups ahead: 16 reads in flight behind the group being consumed, one more than lgkmcnt counts
-#else
     u32x2 vf[2][8];
-#endif
 
     // ---- S^T = K . Q^T
     f32x16 s;
@@ -697,18 +473,13 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_kv_fwd_kernel(const AttnPa
     static_for<8>([&](auto gc) {
       constexpr int g = decltype(gc)::value;
       if constexpr (g + 2 < 8) ldk(std::integral_constant<int, g + 2>{}, fr[(g + 2) % 3]);
-#if !defined(ATTN_ABLATE_NODMA) && !ATTNKV_DMA_PHASE
       issue_piece(gc, nxt, BUF ^ 1);
-#endif
 #pragma unroll
       for (int e = 0; e < 4; ++e) s = mfma_a16_32x32x16(fr[g % 3][e], qf[4 * g + e], s, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     });
     PROF_MARK(2);                                  // QK^T
     ldv(std::integral_constant<int, 0>{}, vf[0]);  // the first P.V fragments fly under the softmax
-#if ATTNKV_PV_AHEAD == 2
-    ldv(std::integral_constant<int, 1>{}, vf[1]);
-#endif
     if (tile == n_tiles - 1) {  // mask keys beyond N
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -716,7 +487,6 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_kv_fwd_kernel(const AttnPa
         if (kv >= p.N) s[r] = -__builtin_inff();
       }
     }
-#ifndef ATTN_ABLATE_NOSOFTMAX   // timing ablation only: wrong results
     // ---- online softmax, lane-local per query column
     float mx = s[0];
 #pragma unroll
@@ -741,7 +511,6 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_kv_fwd_kernel(const AttnPa
         }
       m_run = m_new;
     }
-#endif
     float psum = 0.f;
     a16x8 pf[2];
 #pragma unroll
@@ -749,15 +518,8 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_kv_fwd_kernel(const AttnPa
       u32x4 w;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-#if defined(ATTN_ABLATE_NOSOFTMAX)  // timing ablation only: wrong results (scores kept alive, P constant)
-        asm volatile("" ::"v"(s[8 * h + 2 * e]), "v"(s[8 * h + 2 * e + 1]));
-        const float p0 = 0.03125f, p1 = 0.03125f;
-#elif defined(ATTN_ABLATE_NOEXP)  // timing ablation only: wrong results
-        const float p0 = s[8 * h + 2 * e], p1 = s[8 * h + 2 * e + 1];
-#else
         const float p0 = __builtin_amdgcn_exp2f(s[8 * h + 2 * e] - m_run);
         const float p1 = __builtin_amdgcn_exp2f(s[8 * h + 2 * e + 1] - m_run);
-#endif
         psum += p0 + p1;
         w[e] = pack_a2(p0, p1);
       }
@@ -769,18 +531,6 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_kv_fwd_kernel(const AttnPa
     // ---- O^T += V^T . P^T  (512 d x 32 queries, contraction over the 32 keys); group g = d-tiles 2g, 2g+1
     static_for<8>([&](auto gc) {
       constexpr int g = decltype(gc)::value;
-#if ATTNKV_PV_AHEAD == 2
-      if constexpr (g + 2 < 8) {   // 7 reads of group g+2, the wait (15 newer in flight = the counter's maximum), then the 8th
-        static_for<7>([&](auto ic) { ldv1(std::integral_constant<int, g + 2>{}, ic, vf[(g + 2) % 3]); });
-        wait_v(std::integral_constant<int, 15>{}, vf[g % 3]);
-        ldv1(std::integral_constant<int, g + 2>{}, std::integral_constant<int, 7>{}, vf[(g + 2) % 3]);
-      } else if constexpr (g + 1 < 8) {
-        wait_v(std::integral_constant<int, 8>{}, vf[g % 3]);
-      } else {
-        wait_v(std::integral_constant<int, 0>{}, vf[g % 3]);
-      }
-#define VF_CUR vf[g % 3]
-#else
       if constexpr (g + 1 < 8) {
         ldv(std::integral_constant<int, g + 1>{}, vf[(g + 1) & 1]);
         wait_v(std::integral_constant<int, 8>{}, vf[g & 1]);
@@ -788,10 +538,6 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_kv_fwd_kernel(const AttnPa
         wait_v(std::integral_constant<int, 0>{}, vf[g & 1]);
       }
 #define VF_CUR vf[g & 1]
-#endif
-#if !defined(ATTN_ABLATE_NODMA) && ATTNKV_DMA_PHASE
-      issue_piece(gc, nxt, BUF ^ 1);
-#endif
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         o[2 * g + (e >> 1)] = mfma_a16_32x32x16(vfrag(VF_CUR, e), pf[e & 1], o[2 * g + (e >> 1)], 0, 0, 0);
@@ -806,13 +552,6 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_kv_fwd_kernel(const AttnPa
     if (tile + 1 < t_end) tile_body(std::integral_constant<int, 1>{}, tile + 1);
   }
 
-#ifdef ATTNKV_PROFILE
-  if (blockIdx.x == 0 && tid == 0 && p.key_splits == 1 && p.part_o) {
-    unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.part_o);
-    for (int i = 0; i < 5; ++i) dst[i] = pc[i];
-    dst[5] = (unsigned long long)(t_end - t_begin);
-  }
-#endif
   // ---- normalise and store O[q][d] (bf16): a lane owns ONE query row, 4 consecutive d per store
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   if (p.key_splits > 1) {
@@ -850,13 +589,8 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_kv_fwd_kernel(const AttnPa
   }
 }
 
-// The software-pipelined variants (ATTNKV_PIPELINED=1|2; measured 1 035-1 089 / 997 TFLOP/s against 1 127-1 163) live in tools/experiments/.
-#if ATTNKV_PIPELINED != 0
-#ifndef GLARE_ABLATE
-#error "ATTNKV_PIPELINED is an experiment: build with GLARE_DEFS='-DGLARE_ABLATE -DATTNKV_PIPELINED=1'"
-#endif
-#include "attn_kv_pipe.inc"
-#endif
+// (Software-pipelined forms of this kernel -- three-stage, and QK^T(i+1) || P.V(i-1) + softmax(i) -- measured 1 035-1 089 / 997 TFLOP/s
+// against 1 127-1 163 in round 2; 64-key tiles 8 % slower.  DESIGN.md section 3.)
 
 // out[q] = sum_s 2^(m_s - m) O_s[q] / sum_s 2^(m_s - m) l_s,  m = max_s m_s: merges the key splits (one wave per query row)
 __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
@@ -939,18 +673,11 @@ extern "C" int glare_attention_kv512_pair_bf16(const void* q, int ldq, const voi
   const long long nb = (long long)B * p.n_qblocks * key_splits;
   if (nb > 0x7fffffffLL) return GLARE_ERR_INVALID;
   p.n_blocks = (int)nb;
-#if ATTNKV_PIPELINED != 0
-  const size_t lds = (size_t)4 * KCH * 16 + 4 * 8192;   // 128 KB tile ring + 32 KB Q tail = all 160 KB
-  if (hipFuncSetAttribute((const void*)attn_kv_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return GLARE_ERR_LAUNCH;
-  hipLaunchKernelGGL(attn_kv_pipe_kernel, dim3(p.n_blocks), dim3(AT_THREADS), lds, (hipStream_t)stream, p);
-#else
   const size_t lds = (size_t)2 * KCH * 16;   // 64 KB: the double-buffered 32-key tile
   auto kern = (out_lo && key_splits == 1) ? attn_kv_fwd_kernel<true> : attn_kv_fwd_kernel<false>;   // with key splits the combine kernel writes the pair
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GLARE_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3(p.n_blocks), dim3(AT_THREADS), lds, (hipStream_t)stream, p);
-#endif
   if (key_splits > 1)
     hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)(((long long)B * N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p.part_o,
                        p.part_ml, p.o, ldo, B, N, key_splits, (float*)nullptr, p.o_lo);
@@ -965,11 +692,11 @@ extern "C" int glare_attention_d512_bf16(const void* q, int ldq, const void* k, 
 static int attn_launch(const void* q, int ldq, const void* k, int ldk, const void* v_t, long long v_pitch, void* out, int ldo, int B,
                        int N, int key_splits, void* workspace, size_t workspace_bytes, glare_stream_t stream, float* lse) {
   if (!q || !k || !v_t || !out || B <= 0 || N <= 0 || key_splits < 1) return GLARE_ERR_INVALID;
-  if (lse && (ATTN_8WAVES || ATTN_PIPELINED)) return GLARE_ERR_UNSUPPORTED;
+  
   if (key_splits > (N + BN - 1) / BN) return GLARE_ERR_INVALID;   // every split owns at least one key tile
   if (((long long)N * ldk + HD) * 2 >= 0x7ff00000LL || (long long)HD * v_pitch * 2 >= 0x7ff00000LL) return GLARE_ERR_UNSUPPORTED;  // 32-bit DMA offsets per image
   if (key_splits > 1) {
-    if (ATTN_PIPELINED) return GLARE_ERR_UNSUPPORTED;
+
     if ((ldo % 8) || !workspace || workspace_bytes < glare_attention_d512_splitk_workspace_bytes(B, N, key_splits)) return GLARE_ERR_WORKSPACE;
   }
   if ((ldq % 8) || (ldk % 8) || (ldo % 4) || (v_pitch % 8) || ldq < HD || ldk < HD || ldo < HD) return GLARE_ERR_UNSUPPORTED;
@@ -984,16 +711,10 @@ static int attn_launch(const void* q, int ldq, const void* k, int ldk, const voi
   const long long nb = (long long)B * p.n_qblocks * key_splits;
   if (nb > 0x7fffffffLL) return GLARE_ERR_INVALID;
   p.n_blocks = (int)nb;
-  const size_t lds = (size_t)4 * KCH * 16 + (ATTN_PIPELINED ? 4 * 8192 : 0);  // 128 KB K/V ring (+ 32 KB Q tail)
-#if ATTN_8WAVES && !ATTN_PIPELINED
-  if (hipFuncSetAttribute((const void*)attn8w_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return GLARE_ERR_LAUNCH;
-  hipLaunchKernelGGL(attn8w_fwd_kernel, dim3(p.n_blocks), dim3(512), lds, (hipStream_t)stream, p);
-#else
+  const size_t lds = (size_t)4 * KCH * 16;  // 128 KB K/V ring (+ 32 KB Q tail)
   if (hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GLARE_ERR_LAUNCH;
   hipLaunchKernelGGL(attn_fwd_kernel, dim3(p.n_blocks), dim3(AT_THREADS), lds, (hipStream_t)stream, p);
-#endif
   if (key_splits > 1)
     hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)(((long long)B * N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p.part_o,
                        p.part_ml, p.o, ldo, B, N, key_splits, lse);

@@ -33,9 +33,6 @@
 
 #include "common.h"
 
-#ifndef ATTNBWD_ABL
-#define ATTNBWD_ABL 0   // timing ablations only (wrong results): 1 no tile DMA, 2 no score exchange, 4 no exp / statistics, 8 no output product
-#endif
 
 namespace {
 
@@ -178,11 +175,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const BwdParams p) {
       if (tt + 1 < n_tiles) load_stats(tt + 1);
       __builtin_amdgcn_sched_barrier(0);
     }
-#if !(ATTNBWD_ABL & 1)
     // all 16 pieces here: spreading them over the MFMA groups of the score loop measured the same (1.46 vs 1.44 ms) -- with one
     // wave per SIMD at ~30 % of the MFMA rate the wave's in-order issue stream, not the matrix pipe, is what a piece delays
     if (tt + 1 < n_tiles) issue(tt + 1, BUF ^ 1);
-#endif
 
     // ---- partial score tiles over this wave's 256 channels
     f32x16 x, y;
@@ -211,7 +206,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const BwdParams p) {
       __builtin_amdgcn_sched_barrier(0);
     }
     // ---- publish the partial, add the partner's
-#if !(ATTNBWD_ABL & 2)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       xbuf[((wave * 2 + 0) * 4 + i) * 64 + lane] = f32x4{x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3]};
@@ -230,7 +224,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const BwdParams p) {
         for (int e = 0; e < 4; ++e) y[4 * i + e] += yp[e];
       }
     }
-#endif
     // ---- P / dS as bf16 B fragments: k-step e covers registers 8 e .. 8 e + 7 = streamed rows 16 e + 8 hi + 0..7
     a16x8 pf[2];
 #pragma unroll
@@ -244,15 +237,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const BwdParams p) {
           const int r = 8 * e + 2 * j + u, rr = 2 * j + u;                       // rr: row 0..7 inside the lane's 8-row run
           const int t = tt * TB + 16 * e + 8 * hi + rr;
           float Lq = Lr, Dq = Dr;
-          if (QS && !(ATTNBWD_ABL & 4)) {
+          if (QS) {
             Lq = __shfl(Lm, 16 * e + 8 * hi + rr, 64);
             Dq = WANT_DS ? __shfl(Dm, 16 * e + 8 * hi + rr, 64) : 0.f;
           }
-#if ATTNBWD_ABL & 4
-          const float pe = x[r] - Lq;
-#else
           const float pe = t < p.N ? __builtin_amdgcn_exp2f(x[r] - Lq) : 0.f;
-#endif
           v[u] = WANT_DS ? pe * (y[r] - Dq) * p.ln2 : pe;
         }
         w[j] = pack_a2(v[0], v[1]);
@@ -268,9 +257,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const BwdParams p) {
         for (int h = 0; h < 2; ++h)
           tr_read(f[2 * e + h], tofs[mt & 3][h] + (BUF * 2 * TILE_B + e * 16 * 1024 + (mt >> 2) * 256));
     };
-#if ATTNBWD_ABL & 8
-    asm volatile("" ::"v"(pf[0]), "v"(pf[1]));
-#else
     rd(0, tf[0]);
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {   // (two tiles ahead measured the same)
@@ -280,7 +266,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const BwdParams p) {
       o[mt] = mfma_a16_32x32x16(frag(f[0], f[1]), pf[0], o[mt], 0, 0, 0);
       o[mt] = mfma_a16_32x32x16(frag(f[2], f[3]), pf[1], o[mt], 0, 0, 0);
     }
-#endif
   };
 
   for (int tt = 0; tt < n_tiles; tt += 2) {

@@ -21,9 +21,6 @@
 // 0.189-0.206 with the residual); MFMA + LDS core alone 0.083 ms -- one 1-KB B fragment from LDS per MFMA is half the LDS
 // bandwidth; a two-row-block variant that halves it needs 128 more registers and spilled (tried, dropped).
 #include <type_traits>
-#ifndef C1_ABL
-#define C1_ABL 0
-#endif
 
 #include "common.h"
 
@@ -153,12 +150,7 @@ __global__ __launch_bounds__(256, 1) void conv1x1_ws_kernel(const C1Params p) {
     }
 #pragma unroll
     for (int e = 0; e < UNIT; ++e) {
-#if C1_ABL & 1   // timing ablation: no A loads
-      af[P][e] = __builtin_bit_cast(a16x8, u32x4{(unsigned)q, (unsigned)e, 0x3f803f80u, 0x3f803f80u});
-      asm volatile("" ::"v"(ap));
-#else
       af[P][e] = *reinterpret_cast<const a16x8*>(ap + (e >> 2) * 64 + (e & 3) * 8);
-#endif
     }
   };
   if (n_units > 0) fetch(std::integral_constant<int, 0>{}, 0);
@@ -208,10 +200,6 @@ __global__ __launch_bounds__(256, 1) void conv1x1_ws_kernel(const C1Params p) {
     if ((q & 1) == 0) body(std::integral_constant<int, 0>{});
     else body(std::integral_constant<int, 1>{});
     if (u != UPB - 1) continue;
-#if C1_ABL & 2   // timing ablation: no epilogue
-    asm volatile("" ::"v"(acc[0][0]), "v"(acc[1][5]), "v"(acc[2][9]), "v"(acc[3][15]));
-    continue;
-#endif
 
     // ---- epilogue: C/D layout col = lane & 31 (co within the 32-tile), row = (r & 3) + 8 (r >> 2) + 4 khalf (pixel).
     // Phase 1: + bias (+ act when there is no residual) -> bf16; neighbouring lanes (co, co + 1) exchange one value so that each

@@ -6,17 +6,8 @@
 
 #include "common.h"
 
-#ifndef CONV_DMA_SPREAD
-#define CONV_DMA_SPREAD 1
-#endif
-#ifndef CONV_ABL_HILO
-#define CONV_ABL_HILO 0
-#endif
 #ifndef CONV_EPI_RES_INLINE
 #define CONV_EPI_RES_INLINE 0   // 1: the residual pieces loaded one by one inside the epilogue loops (rounds 1-4; A/B measurements)
-#endif
-#ifndef CONV_ABL_EPI
-#define CONV_ABL_EPI 0   // timing ablations only (tools/ablate.sh; wrong results): 1 residual add -> one xor, 2 phase 1 as a transposed layout would have it, 4 no output stores, 8 no epilogue at all
 #endif
 
 
@@ -347,51 +338,28 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
     const u32x4* cA = lA + (chunk & 1) * A_SLOTS;
 #pragma unroll
     for (int trow = 0; trow < KS; ++trow, ++bs) {
-#ifndef CONV_ABLATE_NOBARRIER  // timing ablations only (tools/ablate.sh): wrong results
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
       if constexpr (GNP) {                               // ... and are normalised in place before anybody reads them
         if (trow == 0 && chunk == 0) gn_transform(0, 0);
         if (trow == 1 && chunk + 1 < p.n_stages) gn_transform(chunk + 1, (chunk + 1) & 1);
       }
       __syncthreads();                                   // ... and everybody else's; stage bs-1 retired
-#endif
       // The next stage's DMA pieces are not issued in one burst behind the barrier (12 waves would queue 47 pieces on the
       // CU's address path with the matrix pipe waiting): they are spread over the stage's KS*KSTEPS MFMA groups.
       constexpr int NGRP = KS * KSTEPS;
       [[maybe_unused]] constexpr int B_PG = (B_PER_W + NGRP - 1) / NGRP, A_PG = (A_PER_W + NGRP - 1) / NGRP;
       const bool more_b = bs + 1 < n_bstages, more_a = trow == 0 && chunk + 1 < p.n_stages;
       if (trow == 0 && chunk + 1 == p.n_stages && p.res_bytes) prefetch_residual((chunk + 1) & 1);
-#if !CONV_DMA_SPREAD
-#ifndef CONV_ABLATE_NODMA
-#ifndef CONV_ABLATE_NODMA_B
-      if (more_b) issue_b(bs + 1, (bs + 1) & 1);
-#endif
-#ifndef CONV_ABLATE_NODMA_A
-      if (more_a) issue_a(chunk + 1, (chunk + 1) & 1);
-#endif
-#endif
-#endif
       const u32x4* cB = lB + (bs & 1) * B_CHUNKS;
-#ifdef CONV_SETPRIO
-      __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
       for (int tcol = 0; tcol < KS; ++tcol) {
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
-#if CONV_DMA_SPREAD
-#ifndef CONV_ABLATE_NODMA
           {
             const int grp = tcol * KSTEPS + ks;
-#ifndef CONV_ABLATE_NODMA_B
             if (more_b) issue_b(bs + 1, (bs + 1) & 1, grp * B_PG, (grp + 1) * B_PG);
-#endif
-#ifndef CONV_ABLATE_NODMA_A
             if (more_a) issue_a(chunk + 1, (chunk + 1) & 1, grp * A_PG, (grp + 1) * A_PG);
-#endif
           }
-#endif
-#endif
           a16x8 bf[NT], af[MT];
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
@@ -411,9 +379,6 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
               acc[i][j] = mfma_a16_32x32x16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
       }
-#ifdef CONV_SETPRIO
-      __builtin_amdgcn_s_setprio(0);
-#endif
     }
   }
 
@@ -424,9 +389,6 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
   // (Requesting a tile row's residual halves BEFORE its pass through the slab -- 32 more registers next to the 128 accumulators at
   // 168 -- spilled: 196 B/lane of scratch, 892 instead of 823 us per launch on the path's eight launches; kept out.)
   if constexpr (HILO) {
-#if CONV_ABL_HILO & 8   // timing ablations only (tools/ablate.sh): wrong results
-    if (acc[0][0][0] != 12345.f) return;
-#endif
     constexpr int ROWF = NT * 128 + 16;                  // slab row pitch in bytes (pad: bank spread between rows)
     constexpr int CPR = NT * 4;                          // 8-channel chunks per slab row
     static_assert(NW * 32 * ROWF <= (2 * A_SLOTS + 2 * B_CHUNKS) * 16, "hi/lo epilogue slab fits the pipeline LDS");
@@ -478,9 +440,6 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#if CONV_ABL_HILO & 4
-      if (acc[0][0][0] == 12345.f)
-#endif
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const int idx = lane + 64 * it;
@@ -514,17 +473,11 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
           for (int e = 0; e < 4; ++e) {
             const float a = v[2 * e], c = v[2 * e + 1];
             hi[e] = pack_a2(a, c);
-#if !(CONV_ABL_HILO & 1)
             lo[e] = pack_a2(a - alo(hi[e]), c - ahi(hi[e]));
-#endif
-#if !(CONV_ABL_HILO & 2)
             if (e < 2) { gs0 += a + c; gq0 += a * a + c * c; } else { gs1 += a + c; gq1 += a * a + c * c; }
-#endif
           }
           *reinterpret_cast<u32x4*>(reinterpret_cast<a16_t*>(p.out) + pix * p.opitch + p.ooff + co) = hi;
-#if !(CONV_ABL_HILO & 1)
           *reinterpret_cast<u32x4*>(p.out_lo + pix * p.opitch + p.ooff + co) = lo;
-#endif
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -555,9 +508,6 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
   //   phase 1: acc + bias (+act when there is no residual) -> bf16; neighbouring lanes (co n, n+1) swap one
   //            value so every lane writes one packed 4-B word: even lanes row m(2t), odd lanes row m(2t+1)
   //   phase 2: 16-B LDS reads, + residual (16-B global load, fp32 add), act, 16-B global store
-#if CONV_ABL_EPI & 8
-  if (acc[0][0][0] != 12345.f) return;
-#endif
   // (sigmoid / swish on the accumulators themselves -- no residual in between -- take the general epilogue: any form of it here, a
   // pre-pass over the accumulators or a branch per 32 x 32 block, cost the hot none / relu path registers; conv_pick_epilogue)
   if constexpr (EPI == EPI_FAST) {
@@ -583,17 +533,6 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
         const float bv = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
         static_for<HT>([&](auto ic) {
           constexpr int il = decltype(ic)::value;
-#if CONV_ABL_EPI & 2   // timing only: what a transposed accumulator layout would leave of phase 1 (4 x 8-B LDS writes per tile, no swaps)
-          {
-            constexpr int i2 = half * HT + il;
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-              const u32x2 w2 = {pack_a2(acc[i2][j][4 * q4], acc[i2][j][4 * q4 + 1]), pack_a2(acc[i2][j][4 * q4 + 2], acc[i2][j][4 * q4 + 3])};
-              *reinterpret_cast<u32x2*>(slab + (il * 32 + ncol) * ROWB + (j * 32 + 8 * q4 + 4 * rhalf) * 2) = w2;
-            }
-          }
-          if (bv == 12345.f)
-#endif
 #pragma unroll
           for (int t = 0; t < 8; ++t) {
             constexpr int i = half * HT + il;
@@ -647,10 +586,6 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
             u32x4 rv;
             if (res_buf) rv = rvv[RES_AHEAD ? it : 0];
             else rv = *reinterpret_cast<const u32x4*>(p.res + pix * p.rpitch + p.roff + co);
-#if CONV_ABL_EPI & 1
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] ^= rv[e];
-#else
             if (asel.expk) {            // one uniform branch per 8-element group
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = pack_a2(act_exp(alo(v[e]) + alo(rv[e]), asel.expk), act_exp(ahi(v[e]) + ahi(rv[e]), asel.expk));
@@ -658,11 +593,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = pack_a2(act_cheap(alo(v[e]) + alo(rv[e]), asel.relu), act_cheap(ahi(v[e]) + ahi(rv[e]), asel.relu));
             }
-#endif
           }
-#if CONV_ABL_EPI & 4
-          if (v[0] == 0x12345678u)
-#endif
           *reinterpret_cast<u32x4*>(reinterpret_cast<a16_t*>(p.out) + pix * p.opitch + p.ooff + co) = v;
           if (p.gn_part) {
 #pragma unroll

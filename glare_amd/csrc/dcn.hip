@@ -229,7 +229,7 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_kernel(const DcnParams p) 
 
 // ---- fast path: bf16 x, every tensor < 2 GB, kh*kw % 3 == 0 ----------------------------------------------------------
 // Same algorithm and arithmetic as dcn_fwd_kernel; what changes is the instruction and memory-request count around it.
-// Ablation of the generic kernel at 8 x 420x620x128 (tools/ablate.sh, DCN_ABL): 1.35 ms with no loads at all, and each of
+// Compiled-out ablations of the generic kernel at 8 x 420x620x128 (round 1): 1.35 ms with no loads at all, and each of
 // the three load families (offset/mask triples, the 4 corners, the weight fragments) adds ~0.85 ms on top -- the cost is
 // per vector-memory instruction and per exposed latency, not per byte.  Hence:
 //   * every global access is a buffer load: 32-bit per-lane offsets computed once per item, the per-stage part (group,
@@ -250,18 +250,6 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_kernel(const DcnParams p) 
 // matter: LDS barriers, counted vs full s_waitcnt, buffer vs global loads, scalar-offset operands, out-of-range loads; loads
 // of one wave do return in issue order (tools/probes/vmcnt_order_probe.hip).  The same blend in scalar fp32 is bit-stable
 // over every shape of tools/determinism_check.py and just as fast (the kernel is not VALU-bound enough to notice).
-#ifndef DCN_WN2
-#define DCN_WN2 0
-#endif
-#ifndef DCN_MT4
-#define DCN_MT4 0
-#endif
-#ifndef DCN_PC
-#define DCN_PC 0
-#endif
-#ifndef DCN_ABL
-#define DCN_ABL 0   // timing ablations only (tools/ablate.sh): 1 no weight loads, 2 no corner loads, 4 no MFMA, 8 no offset loads, 16 no blend / split arithmetic
-#endif
 //
 // SINGLE = true (GLARE_MDCN_SINGLE_PASS): the blended sample and the filter are rounded ONCE to the library's 16-bit activation
 // format and contracted by one MFMA per product -- the arithmetic of every other convolution on the path (16-bit operands, fp32
@@ -334,14 +322,10 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_fast_kernel(const DcnParam
       const int tl = __builtin_amdgcn_readfirstlane((tid + q * DC_THREADS) / PIX);   // tap within the chunk, wave-uniform
       if (tl < CT) {
         const int s = c * CT + tl, g = s / K, tap = s - g * K;
-#if DCN_ABL & 8
-        s_oh[q] = __uint_as_float((s_ovo + s) & 0x3f800000u); s_ow[q] = 0.5f * s_oh[q]; s_m[q] = 0.5f;
-#else
         const unsigned so = (unsigned)((g * 2 * K + 2 * tap) * p.off_plane) * 4u;
         s_oh[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(offr, s_ovo, so, 0));
         s_ow[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(offr, s_ovo, so + (unsigned)p.off_plane * 4u, 0));
         s_m[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(mr, s_mvo, (unsigned)((g * K + tap) * p.mask_plane) * 4u, 0));
-#endif
       }
     }
   };
@@ -420,15 +404,10 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_fast_kernel(const DcnParam
       const u32x4 vo = reinterpret_cast<const u32x4*>(src)[e];
       cw[i] = reinterpret_cast<const f32x4*>(src + CT * PIX * 16)[e];
       cm[i] = reinterpret_cast<const float*>(src + CT * PIX * 32)[e];
-#if DCN_ABL & 2
-      cr[i][0] = u32x4{vo[0], sx, vo[1], vo[2]}; cr[i][1] = u32x4{vo[1], sx, vo[3], vo[2]};
-      cr[i][2] = u32x4{vo[2], sx, vo[0], vo[1]}; cr[i][3] = u32x4{vo[3], sx, vo[1], vo[0]};
-#else
       cr[i][0] = __builtin_amdgcn_raw_buffer_load_b128(xr, vo[0] + it_cb[i], sx, 0);
       cr[i][1] = __builtin_amdgcn_raw_buffer_load_b128(xr, vo[1] + it_cb[i], sx, 0);
       cr[i][2] = __builtin_amdgcn_raw_buffer_load_b128(xr, vo[2] + it_cb[i], sx, 0);
       cr[i][3] = __builtin_amdgcn_raw_buffer_load_b128(xr, vo[3] + it_cb[i], sx, 0);
-#endif
     }
   };
   auto gather_finish = [&](int buf, const CornerSet& cs) {
@@ -440,10 +419,6 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_fast_kernel(const DcnParam
     for (int i = 0; i < ITEMS; ++i) {
       const float m = cm[i];
       u32x4 hi, lo;
-#if DCN_ABL & 16   // timing ablation only (wrong results): no blend / split arithmetic, the raw corners go to the tile
-      hi = cr[i][0] ^ cr[i][2]; lo = cr[i][1] ^ cr[i][3];
-      if (m == 12345.f) hi[0] = __float_as_uint(cw[i][0]);
-#else
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         // reference order: (w1*v1 + w2*v2 + w3*v3 + w4*v4) * mask   (kernel.cu:493-496,625), on (even, odd) channel pairs.
@@ -463,7 +438,6 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_fast_kernel(const DcnParam
           lo[e] = pack_bf2(r0, r1);
         }
       }
-#endif
       dst[it_lds[i]] = hi;
       if constexpr (!SINGLE) dst[NCH * PIX + it_lds[i]] = lo;
     }
@@ -478,13 +452,8 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_fast_kernel(const DcnParam
     const unsigned ws = (unsigned)((s * NCH + 2 * ks) * p.Co) * WB;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-#if DCN_ABL & 1
-      dst[j][0] = u32x4{wvo + j, ws, wvo, ws};
-      if constexpr (!SINGLE) dst[j][HL - 1] = u32x4{wvo, ws + j, ws, wvo};
-#else
       dst[j][0] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvo + j * (32 * WB), ws, 0);
       if constexpr (!SINGLE) dst[j][HL - 1] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvo + j * 1024 + 16, ws, 0);
-#endif
     }
   };
   auto mfma_step = [&](const u32x4* a_src, int ks, const u32x4 (&b)[NT][HL]) {
@@ -515,13 +484,9 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_fast_kernel(const DcnParam
       const bf16x8 bl = __builtin_bit_cast(bf16x8, b[j][HL - 1]);
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-#if DCN_ABL & 4
-        acc[m][j][0] += (float)(al[m][0] + bh[0]) + (float)(ah[m][1] + bl[1]);
-#else
         acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh, acc[m][j], 0, 0, 0);
         acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl, acc[m][j], 0, 0, 0);
         acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh, acc[m][j], 0, 0, 0);
-#endif
       }
     }
     }
@@ -593,13 +558,7 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_fast_kernel(const DcnParam
 // The producer / consumer form of this kernel (consumer waves own the accumulators, producer waves the gather with 2-3 corner sets in
 // flight; bit-identical results, 45 parity / determinism tests green) measured 4.0-4.2 ms instead of 2.9 (C = 128) and 2.9-3.1 instead
 // of 2.25 (C = 256), the same for a gather depth of 2 and of 3: the stage time is not exposed gather LATENCY that more loads in flight
-// could hide.  It lives in tools/experiments/dcn_pc.inc (GLARE_DEFS="-DGLARE_ABLATE -DDCN_PC=2").
-#if DCN_PC
-#ifndef GLARE_ABLATE
-#error "DCN_PC is an experiment: build with GLARE_DEFS='-DGLARE_ABLATE -DDCN_PC=2'"
-#endif
-#include "dcn_pc.inc"
-#endif
+// could hide (round 4).
 
 // [Co][C][kh][kw] fp32 (reference layout) -> split-bf16 B-fragment image
 // [stage = g*K + tap][c/8][Co][hi: 8 bf16 | lo: 8 bf16]  (same byte count as the fp32 filter)
@@ -671,35 +630,15 @@ int launch_dcn_fast(const DcnParams& p, bool single, hipStream_t stream) {
   const int pix = 64;
   const size_t lds = (size_t)2 * (single ? 1 : 2) * nch * pix * 16 + (size_t)2 * 3 * pix * 36;   // sample tiles + sampling plan
   const unsigned blocks = (unsigned)((p.total_pix + pix - 1) / pix);
-#if !DCN_WN2   // split form: four waves along Co (no duplicated weight-fragment loads); DCN_WN2=1 restores the 2 x 2 wave layout
   if (!single && nch % 2 == 0 && (p.Co == 128 || p.Co == 256)) {
 #define DCN_WN4(NT_, NCH_)                                                                                                       \
     if (p.Co == 128 * NT_ && nch == NCH_) {                                                                                       \
       hipLaunchKernelGGL((dcn_fwd_fast_kernel<NT_, NCH_, 2, false, 4>), dim3(blocks), dim3(DC_THREADS), lds, stream, p);          \
       return glare_launch_status();                                                                                               \
     }
-#if DCN_MT4   // experiment: 128-pixel workgroups in this layout (half the weight-fragment loads per pixel again; 60 KB of LDS: 2 workgroups / CU):
-              // measured 2.80 ms against 2.64 (C = 128, fp16) -- the occupancy is worth more; kept off
-    if (p.Co == 128 && nch == 4) {
-      const size_t lds4 = (size_t)2 * 2 * nch * 128 * 16 + (size_t)2 * 3 * 128 * 36;
-      hipLaunchKernelGGL((dcn_fwd_fast_kernel<1, 4, 4, false, 4>), dim3((unsigned)((p.total_pix + 127) / 128)), dim3(DC_THREADS), lds4, stream, p);
-      return glare_launch_status();
-    }
-#endif
     DCN_WN4(1, 4) DCN_WN4(2, 4) DCN_WN4(1, 8) DCN_WN4(2, 8)
 #undef DCN_WN4
   }
-#endif
-#if DCN_PC     // the producer / consumer form (split contraction only): DCN_PC = gather depth (2 or 3)
-  if (!single && nt == 2 && nch == 4) {
-    hipLaunchKernelGGL((dcn_fwd_pc_kernel<4, 4, 2, 2, DCN_PC>), dim3(blocks), dim3(256), lds, stream, p);
-    return glare_launch_status();
-  }
-  if (!single && nt == 4 && nch == 8) {
-    hipLaunchKernelGGL((dcn_fwd_pc_kernel<4, 8, 4, 4, DCN_PC>), dim3(blocks), dim3(512), lds, stream, p);
-    return glare_launch_status();
-  }
-#endif
 #define DCN_FAST(NT_, NCH_)                                                                                  \
   if (nt == NT_ && nch == NCH_) {                                                                            \
     if (single)                                                                                              \

@@ -181,7 +181,9 @@ class ResnetBlock(HipModule):
 class AttnBlock(HipModule):
     def __init__(self, in_channels):
         super().__init__()
-        assert in_channels == 512, "the attention kernel is specialised for the GLARE head dim (512)"
+        # GLARE instantiates 512 only (the blockwise kernels of csrc/attn.hip); any other multiple of 32 -- the reference's class is
+        # generic, encoder_decoder.py:140-192 -- runs the materialised form (_forward_general)
+        assert in_channels % 32 == 0, "AttnBlock: channels must be a multiple of 32 (GroupNorm(32), 32-wide GEMM k-steps)"
         self.in_channels = in_channels
         self.norm = Normalize(in_channels)
         self.q = nn.Conv2d(in_channels, in_channels, 1)
@@ -225,9 +227,35 @@ class AttnBlock(HipModule):
                 (wp @ wv).float().contiguous(), (wp @ self.v.bias.double() + self.proj_out.bias.double()).float().contiguous(),
                 self.norm.weight.detach().float().contiguous(), self.norm.bias.detach().float().contiguous())
 
+    def _forward_general(self, x):
+        """Any head size: h = GN(x); q, k, v = 1x1(h); w = softmax_j(q.k / sqrt(C)); out = x + proj_out(w v)
+        (encoder_decoder.py:168-192) in the MATERIALISED form on the training step's kernels -- scores by `gemm_nt` (fp32 [N, N]), base-2
+        row softmax, P.V by `gemm_nt` against the transposed values -- instead of the d = 512 blockwise kernel.  Not on the GLARE path
+        (every AttnBlock there has 512 channels): it exists so that the operator surface equals the reference's, and it is what the
+        reference-generated AttnBlock(64) vector of tests/golden/blocks.npz is checked on."""
+        from .. import train_ops as T
+
+        B, H, W, C = x.shape
+        N = H * W
+        s = float(C) ** -0.5 * math.log2(math.e)
+        hn = gn_swish(x, self.norm, swish=False)
+        q = ops.conv2d(hn, self._packed("q_scaled", lambda: ops.PackedConv(self.q.weight * s, self.q.bias * s)))
+        k = ops.conv2d(hn, packed_conv(self, self.k))
+        v = ops.conv2d(hn, packed_conv(self, self.v))
+        o = torch.empty(B, N, C, dtype=ops.act_dtype(), device=x.device)
+        for b in range(B):                                    # per-sample attention: the N x N scores are per image
+            S = T.gemm_nt(q[b].view(N, C), k[b].view(N, C))   # fp32 [N, N], base-2 logits
+            P = T.softmax2_rows(S, N)                         # 16-bit [N, ldp], pad columns zero
+            Vt = T.transpose(v[b].view(N, C), P.shape[1])     # [C, ldp], pad columns zero
+            T.gemm_nt(P, Vt, out=o[b], out_dtype=ops.act_dtype())
+        return ops.conv2d(o.view(B, H, W, C), packed_conv(self, self.proj_out), residual=x)
+
     def forward_nhwc(self, x, split=0):
         B, H, W, C = x.shape
         N = H * W
+        if C != 512:
+            assert not split, "the fp32-class form exists for the GLARE head size only"
+            return self._forward_general(x)
         stats = getattr(x, "_gn_stats", None)
         if split:
             # fp32-class (FP32_CLASS): the norm is materialised as a hi / lo pair instead of folded into per-image filters, the two

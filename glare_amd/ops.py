@@ -827,8 +827,6 @@ def attention_key_splits(B, N):
 # (rounding), so the batch-invariance test pins both to one configuration.
 ATTENTION_KEY_SPLITS_OVERRIDE = None
 
-ATTENTION_PROFILE_BUFFER = None   # tools/kbench.py KB_PROF=1 (needs a -DATTNKV_PROFILE build)
-
 # Measurement hook (bench.py): when this is a list, every attention launch is bracketed by a pair of events recorded on the
 # stream the kernel is launched on, and (start, end, B, N) is appended.  None (the default) records nothing.
 ATTENTION_LAUNCH_EVENTS = None
@@ -902,8 +900,6 @@ def attention_kv512(q, kv, N, ldq=None, ldkv=None, out=None, key_splits=None, pa
     ks = attention_key_splits(B, N) if key_splits is None else key_splits
     lib = _lib.lib()
     ws, nws = None, 0
-    if ATTENTION_PROFILE_BUFFER is not None and ks == 1:   # tools only: a build with -DATTNKV_PROFILE leaves phase cycle sums here
-        ws, nws = ATTENTION_PROFILE_BUFFER, ATTENTION_PROFILE_BUFFER.numel() * ATTENTION_PROFILE_BUFFER.element_size()
     if ks > 1:
         lib.glare_attention_d512_splitk_workspace_bytes.restype = _sz
         nws = lib.glare_attention_d512_splitk_workspace_bytes(_i(B), _i(N), _i(ks))

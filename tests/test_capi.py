@@ -21,6 +21,21 @@ def test_library_exports_every_declared_symbol():
     assert lib.glare_status_string(-1) == b"invalid argument"
 
 
+def test_glare_error_carries_the_numeric_status():
+    """callers decide on `e.status` (a GLARE_ERR_* code of the header), never on the wording of the message."""
+    src = open(_lib.HEADER_PATH).read()
+    for name, val in (("INVALID", _lib.ERR_INVALID), ("LAUNCH", _lib.ERR_LAUNCH), ("WORKSPACE", _lib.ERR_WORKSPACE), ("UNSUPPORTED", _lib.ERR_UNSUPPORTED)):
+        assert re.search(r"#define GLARE_ERR_%s \(%d\)" % (name, val), src), name
+    with pytest.raises(_lib.GlareError) as ei:
+        _lib.check(_lib.ERR_UNSUPPORTED, "glare_something")
+    assert ei.value.status == _lib.ERR_UNSUPPORTED and "glare_something" in str(ei.value)
+    assert _lib.GlareError("raised on the Python side").status is None
+    _lib.check(0, "fine")
+    # the DCN's single-pass opt-in falls back on the status, not on the text
+    dd = open(os.path.join(os.path.dirname(_lib.__file__), "modules", "deformableDecoder_arch.py")).read()
+    assert "e.status != _lib.ERR_UNSUPPORTED" in dd and '"unsupported" not in' not in dd
+
+
 def test_no_extra_exports():
     """Everything exported with the glare_ prefix is declared in the header (the ABI is the header)."""
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout

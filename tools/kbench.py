@@ -54,15 +54,6 @@ def bench_attn():
         print("attnkv B=%d N=%d d=512 (shared K/V), ALL-ZERO operands: %.3f ms  %.0f TFLOP/s" % (B, N, ms, 4.0 * B * N * N * C / ms / 1e9))
         ms = timeit(lambda: ops.attention_kv512(q, x, N, out=out, key_splits=1))
         print("attnkv B=%d N=%d d=512 (shared K/V), random again: %.3f ms  %.0f TFLOP/s" % (B, N, ms, 4.0 * B * N * N * C / ms / 1e9))
-    if os.environ.get("KB_PROF"):   # per-phase cycles of one wave (library built with GLARE_DEFS=-DATTNKV_PROFILE)
-        ops.ATTENTION_PROFILE_BUFFER = torch.zeros(8, dtype=torch.int64, device=DEV)
-        ops.attention_kv512(q, x, N, out=out, key_splits=1)
-        torch.cuda.synchronize()
-        c = ops.ATTENTION_PROFILE_BUFFER.cpu().tolist()
-        ops.ATTENTION_PROFILE_BUFFER = None
-        nt = max(c[5], 1)
-        print("attnkv cycles per 32-key tile (wave 0, s_memtime): loop %.0f | wait+barrier %.0f | QK^T %.0f | softmax %.0f | P.V %.0f | total %.0f"
-              % (c[0] / nt, c[1] / nt, c[2] / nt, c[3] / nt, c[4] / nt, sum(c[:5]) / nt))
 
 
 def bench_conv():
