@@ -6,9 +6,6 @@
 
 #include "common.h"
 
-#ifndef CONV_EPI_RES_INLINE
-#define CONV_EPI_RES_INLINE 0   // 1: the residual pieces loaded one by one inside the epilogue loops (rounds 1-4; A/B measurements)
-#endif
 
 
 struct ConvParams {
@@ -420,10 +417,8 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
       // through the per-image buffer descriptor of the L2 prefetch (p.res_bytes != 0): ONE loop-invariant 32-bit lane offset, the
       // iteration's part a constant -- no 64-bit address pair per piece (eight of them spilled: 252 B/lane of scratch) -- and rows /
       // channels beyond the image read zeros or unused neighbours instead of branching
-      const bool res_buf = !CONV_EPI_RES_INLINE && p.res && p.res_bytes;
-#ifndef CONV_EPI_NO_SCHED_BARRIER
+      const bool res_buf = p.res && p.res_bytes;
       __builtin_amdgcn_sched_barrier(0);   // the requests stay BEHIND the slab writes: hoisted above them they meet the row's live accumulators
-#endif
       if (res_buf) {
         const size_t rimg = (size_t)b * p.OH * p.OW * p.rpitch;
         const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<a16_t*>(p.res + rimg), 0, (int)p.res_bytes, 0x00020000);
@@ -549,14 +544,12 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
       // the residual pieces of this slab, all requested at once behind phase 1 (whose accumulators are dead by now): see the hi / lo
       // epilogue above -- one L2 round trip per slab instead of one per iteration
       constexpr int NIT = HROWS * CPR / 64;
-      constexpr bool RES_AHEAD = !CONV_EPI_RES_INLINE && NIT <= 8 && KS != 2;
+      constexpr bool RES_AHEAD = NIT <= 8 && KS != 2;
       [[maybe_unused]] u32x4 rvv[RES_AHEAD ? NIT : 1];
       bool res_buf = false;
       if constexpr (RES_AHEAD) {
         res_buf = p.res && p.res_bytes;     // the per-image descriptor of the L2 prefetch: one 32-bit lane offset + a constant per piece
-#ifndef CONV_EPI_NO_SCHED_BARRIER
         __builtin_amdgcn_sched_barrier(0);  // the requests stay BEHIND phase 1: hoisted above it they meet the slab's live accumulators
-#endif
         if (res_buf) {
           const size_t rimg = (size_t)b * p.OH * p.OW * p.rpitch;
           const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<a16_t*>(p.res + rimg), 0, (int)p.res_bytes, 0x00020000);

@@ -22,6 +22,14 @@ python bench.py --batch 4 --steps 20 --warmup 5 --no-train --no-cpu-baseline > g
 python tools/kbench.py attn conv convsplit gn dcn vq wgrad attnbwd > gpurun_out/${tag}_kbench.txt 2>&1
 python tools/kbench.py attnfold > gpurun_out/${tag}_attn_fold.txt 2>&1
 python tools/probes/power_clock_probe.py 4 2>&1 | grep -v "amdgpu.ids" > gpurun_out/${tag}_power_clock.txt   # the power wall: random vs all-zero operands
+{
+  echo "# rocprofv3 --kernel-trace --pmc TA_BUSY_avr TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TOTAL_ACCESSES_sum -- python tools/kbench.py dcn   (one shape per run)"
+  for c in 128 256; do
+    KB_DCN=$c KB_REPS=2 rocprofv3 --kernel-trace --pmc TA_BUSY_avr TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TOTAL_ACCESSES_sum \
+      -d gpurun_out/pmc_${tag}_dcnta$c -o p -- python tools/kbench.py dcn > gpurun_out/pmc_${tag}_dcnta$c.log 2>&1
+    echo "== C = $c"; python tools/rocpd_pmc.py gpurun_out/pmc_${tag}_dcnta$c/p_results.db 2>&1 | grep -A7 "dcn_fwd"
+  done
+} > gpurun_out/${tag}_pmc_dcn_ta.txt 2>&1          # the DCN forward's texture-path counters (what binds it)
 bash tools/pmc_shapes.sh $tag > /dev/null 2>&1          # per-SHAPE traffic of the conv / DCN launches -> ${tag}_pmc_shapes.json
 # end-to-end parity: 12 scenes of the default path (tools/parity_scenes.py), then the precision ladder on three of them -- round 3's
 # single-pass fp16 path (GLARE_FP32_CLASS=0) and bf16 -- and the single-pass DCN as an A/B
@@ -37,6 +45,7 @@ bash tools/pmc_shapes.sh $tag > /dev/null 2>&1          # per-SHAPE traffic of t
 for st in stage2 stage3; do
   python tools/train_bench.py $st 20 graph > gpurun_out/${tag}_train_${st}_graph.txt 2>&1
   python tools/train_bench.py $st 10 > gpurun_out/${tag}_train_$st.txt 2>&1
+  TRAIN_PRECISION=bf16 python tools/train_bench.py $st 10 >> gpurun_out/${tag}_train_$st.txt 2>&1      # bf16 beside the default (fp16 AMP)
   rocprofv3 --kernel-trace --stats -d gpurun_out/proft_${tag}_$st -o t -- python tools/train_bench.py $st 5 > /dev/null 2>&1
   python tools/rocpd_stats.py $(ls gpurun_out/proft_${tag}_$st/*/t_results.db gpurun_out/proft_${tag}_$st/t_results.db 2>/dev/null | head -1) > gpurun_out/${tag}_train_${st}_kernel_stats.txt 2>&1
   python tools/train_bench.py $st 1 flops 2>&1 | grep flops_per_step > gpurun_out/${tag}_train_${st}_flops.txt
