@@ -662,8 +662,9 @@ def test_perceptual_network_vs_oracle(prec, shape):
     S = LOSS_SCALE[prec]
     (l * S).backward()
     assert abs(float(l.detach()) - float(lr_.detach())) < 3e-2 * abs(float(lr_.detach()))
-    # bf16 measured 1.03e-02; fp16: an 8x finer format must not do worse than bf16's bound even at n = 3.1e6
-    within(_rel(ad.grad.cpu().permute(0, 3, 1, 2) / S, ar.grad), 2.0e-2, "%s:%d" % (prec, shape[2]))
+    # measured: bf16 1.01e-02; fp16 2.86e-03 at 32 x 48 and 3.19e-03 at 192 x 256 (n = 3.1e6: the subnormal regime of ADVICE r04 -- with the
+    # gradient rounded before the loss scale this read ~0.5); bounds = 2x measured
+    within(_rel(ad.grad.cpu().permute(0, 3, 1, 2) / S, ar.grad), {"bf16": 2.0e-2, "fp16": 6.4e-3}[prec], "%s:%d" % (prec, shape[2]))
     assert all(p.grad is None for p in hip.parameters())          # the VGG weights are frozen (losses.py:18-19)
 
 
@@ -694,8 +695,8 @@ def test_stage3_total_loss_vs_oracle(prec, S_):
     assert abs(float(terms["ssim_loss"].detach()) - float(sl_r.detach())) < 1e-5
     assert abs(float(terms["percep_loss"].detach()) - float(pl_r.detach())) < 3e-2 * abs(float(pl_r.detach()))
     gref = torch.nan_to_num(rr.grad, nan=0.0)
-    # bf16 @64 measured 1.25e-05 (the perceptual term is 1 % of the total and its 16-bit error barely shows); fp16 @256: same bound
-    within(_rel(rd.grad.cpu().permute(0, 3, 1, 2) / LOSS_SCALE[prec], gref), 2.4e-5, prec)
+    # measured: bf16 @64 1.25e-05 (the perceptual term is 1 % of the total and its 16-bit error barely shows); fp16 @256 5.46e-06
+    within(_rel(rd.grad.cpu().permute(0, 3, 1, 2) / LOSS_SCALE[prec], gref), {"bf16": 2.4e-5, "fp16": 1.1e-5}[prec], prec)
 
 
 @pytest.mark.parametrize("precision", ["fp16", "bf16"])
