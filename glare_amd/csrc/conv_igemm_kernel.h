@@ -98,19 +98,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // So the activation is a run-time value again, but branch-FREE where it is hot: the path only ever fuses none / relu into this kernel
 // (flow nets, VGG), which is a v_max + a select on a wave-uniform flag; sigmoid / swish (tests, training-side convs) sit behind ONE
 // uniform branch per 8-element group, or -- where they act on the accumulators themselves -- in a pre-pass over them.
-struct ActSel {
-  bool relu;   // wave-uniform
-  int expk;    // 0, GLARE_ACT_SIGMOID or GLARE_ACT_SWISH (wave-uniform)
-};
-__device__ __forceinline__ ActSel act_sel(int act) { return ActSel{act == GLARE_ACT_RELU, (act == GLARE_ACT_SIGMOID || act == GLARE_ACT_SWISH) ? act : 0}; }
-__device__ __forceinline__ float act_cheap(float v, bool relu) {
-  const float r = fmaxf(v, 0.f);
-  return relu ? r : v;
-}
-__device__ __forceinline__ float act_exp(float v, int expk) {   // bit-identical to sigmoidf_ / swishf_ (common.h): numerator / (1 + e^-v)
-  return (expk == GLARE_ACT_SWISH ? v : 1.0f) / (1.0f + __expf(-v));
-}
-__device__ __forceinline__ float act_any(float v, const ActSel& a) { return a.expk ? act_exp(v, a.expk) : act_cheap(v, a.relu); }
+// (ActSel, act_sel, act_cheap, act_exp, act_any: common.h -- shared with conv1x1.hip)
 
 
 // One 16-B piece (8 channels of one halo position) of the GNP prologue, in place in LDS.
