@@ -20,6 +20,12 @@
 // Measured (MI355X, 8 x 105 x 155 pixels, 512 -> 512): 0.110-0.117 ms against 0.143-0.150 for the implicit-GEMM kernel (0.147 vs
 // 0.189-0.206 with the residual); MFMA + LDS core alone 0.083 ms -- one 1-KB B fragment from LDS per MFMA is half the LDS
 // bandwidth; a two-row-block variant that halves it needs 128 more registers and spilled (tried, dropped).
+// Round 5 built that variant properly (64 pixels per wave pass, every B fragment feeding two MFMAs, A fragments in a ring of 8 k-steps
+// refilled behind their MFMAs, units of a pass as an unrolled inner loop so that the accumulators stay in AGPRs, one epilogue copy: 0 B of
+// scratch, bit-identical outputs, 14 GPU tests): 512 -> 512 @q 0.109 ms against 0.109 (+ residual 0.143 against 0.138), 512 -> 1024 0.212
+// against 0.227 -- and 61.1 images/s either way.  The LDS fragment traffic is NOT what bounds this kernel: it is the L1 / texture path --
+// an A-fragment load instruction reads 16 B from each of 64 different 128-B lines (a lane's row is fixed by the MFMA layout), and the four
+// co-tiles of a pixel range each pull all of x through their CU's L1: 533 MB of 16-B accesses per launch.  Removed again.
 #include <type_traits>
 
 #include "common.h"
@@ -327,208 +333,6 @@ __global__ __launch_bounds__(256, 1) void conv1x1_ws_kernel(const C1Params p) {
   }
 }
 
-// ---- round 5: TWO row blocks per wave pass (the plain 16-bit form: AttnBlock's folded query / output projections, nin_shortcuts) --------
-// The kernel above reads one 1-KB B fragment from LDS per MFMA: 4 waves x 4 KB per k-step is the CU's whole LDS read bandwidth for the
-// duration of the 4 MFMAs it feeds, and with one wave per SIMD the fragment reads and their MFMAs do not overlap (core alone 0.083 ms at
-// 512 -> 512 @q, where its MFMAs are 0.03).  Here a wave owns 64 pixels per pass -- two row blocks, eight accumulators -- so every B
-// fragment feeds two MFMAs: half the LDS traffic per flop and twice the independent matrix work behind each fragment read.  Round 2 tried
-// this and spilled (256 A-fragment registers two units deep); the A prefetch is now 8 k-steps deep per row block (the same 16 KB per wave
-// in flight), and the epilogue is a single copy with a run-time activation (conv_igemm_kernel.h: cloned epilogues keep dead accumulators
-// allocated).  Same arithmetic and accumulation order per output element as conv1x1_ws_kernel: bit-identical results.
-template <int KSTEPS>   // Cin / 16
-__global__ __launch_bounds__(256, 1) void conv1x1_ws2_kernel(const C1Params p) {
-  constexpr int CT = 128;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int ROWB = KSTEPS * 32;              // bytes of one weight row
-  constexpr int CPR = ROWB / 16;                 // 16-B chunks per weight row
-  constexpr int RPP = 1024 / ROWB;               // weight rows per 1-KB DMA piece
-  char* const slab_base = smem + 128 * ROWB;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int ct = slot % p.nct, rng_in_xcd = slot / p.nct, rpx = 32 / p.nct;
-  const int range = xcd * rpx + rng_in_xcd, n_ranges = 8 * rpx;
-  const int total_rb = p.B * p.rbi;
-  int rb_lo = (int)((long long)total_rb * range / n_ranges), rb_hi = (int)((long long)total_rb * (range + 1) / n_ranges);
-  int w_img = 0;
-  if (p.w_istride != 0) {   // per-image filters: ranges are cut per image
-    const int rpi = n_ranges / p.B, sub = range % rpi;
-    w_img = range / rpi;
-    rb_lo = w_img * p.rbi + (int)((long long)p.rbi * sub / rpi);
-    rb_hi = w_img * p.rbi + (int)((long long)p.rbi * (sub + 1) / rpi);
-  }
-  {  // weights of this co-tile into LDS, once: row r, chunk c at r * CPR + (c ^ (r & 15)) (source-side swizzle)
-    const a16_t* wt = p.w + (size_t)w_img * p.w_istride + (size_t)ct * CT * p.Cin;
-    const int r_in = lane / CPR, c_ph = lane % CPR;
-#pragma unroll 4
-    for (int piece = wave; piece < 128 / RPP; piece += 4) {
-      const int r = piece * RPP + r_in;
-      const int c_src = c_ph ^ (r & 15);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wt + (size_t)r * p.Cin + c_src * 8),
-                                       (__attribute__((address_space(3))) void*)(smem + piece * 1024), 16, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-
-  const int px = lane & 31, khalf = lane >> 5;
-  int boff[8];     // B fragment (j, v): see conv1x1_ws_kernel
-#pragma unroll
-  for (int bb = 0; bb < 8; ++bb) boff[bb] = px * ROWB + ((((bb >> 2) * 8 + 4 * khalf + (bb & 3)) ^ (px & 15)) * 16);
-  char* const slab = slab_base + wave * 8192;
-  const int co0 = ct * CT;
-  float bias_v[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) bias_v[j] = p.bias ? p.bias[(size_t)w_img * p.b_istride + co0 + 32 * j + px] : 0.f;
-  const ActSel asel = act_sel(p.act);
-  const bool act_early = p.res == nullptr;
-  const bool relu_early = act_early && asel.relu;     // (sigmoid / swish without a residual: c1_launch keeps conv1x1_ws_kernel for it)
-
-  constexpr int UNIT = 8, UPB = KSTEPS / UNIT;     // a unit = 8 k-steps of BOTH row blocks of a pass (16 KB per wave in flight)
-  static_assert(KSTEPS % UNIT == 0, "Cin is a multiple of 128");
-  // pass t of this wave: row blocks rb_lo + 2 (wave + 4 t) and the one behind it (absent at the range's odd end: computed on the
-  // last block's rows again, never stored)
-  const int n_pass = rb_hi > rb_lo + 2 * wave ? (rb_hi - rb_lo - 2 * wave + 7) / 8 : 0, n_units = n_pass * UPB;
-  auto block_of = [&](int q, int k) { return min(rb_lo + 2 * (wave + 4 * (q / UPB)) + k, rb_hi - 1); };
-  auto unit_ptr = [&](int q, int k) {
-    const int rb_ = block_of(q, k), u_ = q % UPB;
-    const int b_ = rb_ / p.rbi, r0_ = (rb_ - b_ * p.rbi) * 32;
-    const int nrows_ = min(32, p.N - r0_);
-    return ((size_t)b_ * p.N + r0_ + min(px, nrows_ - 1)) * p.xpitch + p.xoff + khalf * 32 + u_ * UNIT * 16;     // element offset
-  };
-  // A fragments: a RING of UNIT k-steps per row block -- slot e is refilled with k-step e of the NEXT unit right behind the MFMAs that
-  // consumed it, so 16 KB per wave are in flight at all times on 64 registers (two whole units double-buffered, as in the kernel above,
-  // are 128: with 128 accumulators and two residual sets the allocator spilled 100 dwords per pass)
-  a16x8 af[2][UNIT];
-  auto load_slot = [&](int k, int e, const a16_t* base) { af[k][e] = *reinterpret_cast<const a16x8*>(base + (e >> 2) * 64 + (e & 3) * 8); };
-  if (n_units > 0) {
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const a16_t* ap = p.x + unit_ptr(0, k);
-#pragma unroll
-      for (int e = 0; e < UNIT; ++e) load_slot(k, e, ap);
-    }
-  }
-  f32x16 acc[2][4];
-  u32x4 resv[2][8];
-  auto fetch_res = [&](int k, int rbA_) {
-    const int rb = min(rbA_ + k, rb_hi - 1);
-    const int b = rb / p.rbi, r0 = (rb - b * p.rbi) * 32;
-    const int nrows = min(32, p.N - r0);
-    const size_t pix0 = (size_t)b * p.N + r0;
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int m = min((lane >> 4) + 4 * it, nrows - 1);
-      resv[k][it] = *reinterpret_cast<const u32x4*>(p.res + (pix0 + m) * p.rpitch + p.roff + co0 + (lane & 15) * 8);
-    }
-  };
-  // pass = (row-block pair); the units of a pass are an INNER loop, fully unrolled: with one flat loop over units and the epilogue behind an
-  // `if`, hipcc carried the accumulators across the back-edge in VGPRs and copied all 128 of them to / from the AGPRs the MFMAs use
-  // around EVERY unit (the one-block kernel above does: 64 v_accvgpr moves per 64 MFMAs)
-  for (int pass = 0; pass < n_pass; ++pass) {
-    const int rbA = rb_lo + 2 * (wave + 4 * pass);
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[k][j][r] = 0.f;
-    if (p.res) fetch_res(0, rbA);   // the residual rows of the first block, fetched NOW: they land under the MFMAs
-#pragma unroll
-    for (int u = 0; u < UPB; ++u) {
-      const int q = pass * UPB + u;
-      const int qn = q + 1 < n_units ? q + 1 : q;           // the last unit re-reads its own rows (see below)
-      const a16_t* nx0 = p.x + unit_ptr(qn, 0);
-      const a16_t* nx1 = p.x + unit_ptr(qn, 1);
-      a16x8 bf[2][4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bf[0][j] = *reinterpret_cast<const a16x8*>(smem + boff[0] + u * 256 + j * 32 * ROWB);
-#pragma unroll
-      for (int e = 0; e < UNIT; ++e) {
-        if (e + 1 < UNIT) {                                   // the next k-step's B fragments are read under this one's MFMAs
-#pragma unroll
-          for (int j = 0; j < 4; ++j) bf[(e + 1) & 1][j] = *reinterpret_cast<const a16x8*>(smem + boff[e + 1] + u * 256 + j * 32 * ROWB);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[0][j] = mfma_a16_32x32x16(af[0][e], bf[e & 1][j], acc[0][j], 0, 0, 0);
-        load_slot(0, e, nx0);      // UNCONDITIONAL and pinned in place (sched_barrier): behind a branch, or sunk to the end of the unit
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[1][j] = mfma_a16_32x32x16(af[1][e], bf[e & 1][j], acc[1][j], 0, 0, 0);
-        load_slot(1, e, nx1);      // as the scheduler prefers, the ring drains: s_waitcnt vmcnt(7), (6) ... (0) through every unit
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    // ---- epilogue, one row block after the other through the wave's slab (as conv1x1_ws_kernel's plain epilogue)
-    const int odd = lane & 1, ch = lane & 15;
-    // the second block's residual rows are requested HERE (they land under the first block's epilogue): two sets carried through the
-    // MFMA loop next to 128 accumulators and 128 A-fragment registers spilled; the unit just consumed has freed its 64
-    if (p.res) fetch_res(1, rbA);
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int rb = rbA + k;
-      if (rb >= rb_hi) continue;                       // the absent second block of an odd range end (wave-uniform)
-      const int b = rb / p.rbi, r0 = (rb - b * p.rbi) * 32;
-      const int nrows = min(32, p.N - r0);
-      const size_t pix0 = (size_t)b * p.N + r0;
-      float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const float a = act_cheap(acc[k][j][2 * t] + bias_v[j], relu_early), c = act_cheap(acc[k][j][2 * t + 1] + bias_v[j], relu_early);
-          const float send = odd ? a : c;
-          const float recv = __shfl_xor(send, 1, 64);
-          const int r = 2 * t + odd;
-          const int m = (r & 3) + 8 * (r >> 2) + 4 * khalf;
-          const uint32_t wv = odd ? pack_a2(recv, c) : pack_a2(a, recv);
-          const int col = 32 * j + (px & ~1);                               // even channel of the pair, 0..127
-          *reinterpret_cast<uint32_t*>(slab + m * 256 + (((col >> 3) ^ (m & 15)) * 16) + (col & 7) * 2) = wv;
-        }
-      }
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int m = (lane >> 4) + 4 * it;
-        if (m < nrows) {
-          u32x4 v = *reinterpret_cast<const u32x4*>(slab + m * 256 + ((ch ^ (m & 15)) * 16));
-          const size_t pix = pix0 + m;
-          const int co = co0 + ch * 8;
-          if (p.res) {
-            const u32x4 rv = resv[k][it];
-            if (asel.expk) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = pack_a2(act_exp(alo(v[e]) + alo(rv[e]), asel.expk), act_exp(ahi(v[e]) + ahi(rv[e]), asel.expk));
-            } else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = pack_a2(act_cheap(alo(v[e]) + alo(rv[e]), asel.relu), act_cheap(ahi(v[e]) + ahi(rv[e]), asel.relu));
-            }
-          }
-          *reinterpret_cast<u32x4*>(p.out + pix * p.opitch + p.ooff + co) = v;
-          if (p.gn_part) {
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-              const float x0 = alo(v[e]), x1 = ahi(v[e]), y0 = alo(v[2 + e]), y1 = ahi(v[2 + e]);
-              gs0 += x0 + x1; gq0 += x0 * x0 + x1 * x1;
-              gs1 += y0 + y1; gq1 += y0 * y0 + y1 * y1;
-            }
-          }
-        }
-      }
-      if (p.gn_part) {   // lanes 16 apart hold the same channel chunk
-#pragma unroll
-        for (int o = 16; o < 64; o <<= 1) {
-          gs0 += __shfl_xor(gs0, o, 64); gq0 += __shfl_xor(gq0, o, 64);
-          gs1 += __shfl_xor(gs1, o, 64); gq1 += __shfl_xor(gq1, o, 64);
-        }
-        if (lane < 16) {
-          float* dst = p.gn_part + (((size_t)b * p.rbi + (rb - b * p.rbi)) * (p.Cout / 4) + (co0 + lane * 8) / 4) * 2;
-          dst[0] = gs0; dst[1] = gq0; dst[2] = gs1; dst[3] = gq1;
-        }
-      }
-    }
-  }
-}
-
 // OIHW fp32 [Cout][Cin][1][1] -> bf16 [Cout][Cin]
 __global__ void c1_pack_kernel(const float* __restrict__ w, a16_t* __restrict__ out, long long n) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -609,13 +413,6 @@ static int c1_launch(const void* x, int x_pitch, int x_off, const void* w_bf16, 
   p.w_istride = w_istride; p.b_istride = w_istride != 0 ? b_istride : 0;
   const size_t lds = (size_t)128 * Cin * 2 + 4 * 8192;
   hipStream_t s = (hipStream_t)stream;
-#define C1_CASE2(KS_)     /* 16-bit output: two row blocks per wave pass (round 5) */                                       \
-  if (Cin == 16 * KS_ && out_lo == nullptr) {                                                                               \
-    if (hipFuncSetAttribute((const void*)conv1x1_ws2_kernel<KS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
-      return GLARE_ERR_LAUNCH;                                                                                             \
-    hipLaunchKernelGGL((conv1x1_ws2_kernel<KS_>), dim3(256), dim3(256), lds, s, p);                                        \
-    return glare_launch_status();                                                                                          \
-  }
 #define C1_CASE(KS_, HL_)                                                                                                  \
   if (Cin == 16 * KS_ && (out_lo != nullptr) == HL_) {                                                                     \
     if (hipFuncSetAttribute((const void*)conv1x1_ws_kernel<KS_, HL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
@@ -623,12 +420,8 @@ static int c1_launch(const void* x, int x_pitch, int x_off, const void* w_bf16, 
     hipLaunchKernelGGL((conv1x1_ws_kernel<KS_, HL_>), dim3(256), dim3(256), lds, s, p);                                    \
     return glare_launch_status();                                                                                          \
   }
-  const bool one_block = getenv("GLARE_CONV1X1_ONE_BLOCK") != nullptr;   // A/B switch, read per call: round 2's one-row-block kernel (bit-identical results)
-  const bool exp_on_acc = !residual && (act == GLARE_ACT_SIGMOID || act == GLARE_ACT_SWISH);   // not on the GLARE path: the one-block kernel has it
-  if (!one_block && !exp_on_acc) { C1_CASE2(8) C1_CASE2(16) C1_CASE2(32) }
   C1_CASE(8, false) C1_CASE(16, false) C1_CASE(32, false) C1_CASE(8, true) C1_CASE(16, true) C1_CASE(32, true)
 #undef C1_CASE
-#undef C1_CASE2
   return GLARE_ERR_UNSUPPORTED;
 }
 

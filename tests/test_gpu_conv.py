@@ -329,40 +329,6 @@ def test_conv1x1_weight_stationary_epilogue_residual_act_offsets_and_gn_statisti
     assert torch.allclose(n1.float(), n2.float(), rtol=2 ** -7, atol=2e-3)
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp16"])
-@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 512, 512, 7, 45), (1, 256, 128, 8, 33), (3, 128, 256, 5, 13), (8, 512, 512, 105, 155),
-                                             (1, 256, 512, 1, 1), (9, 128, 128, 3, 11), (1, 512, 256, 2, 32)])
-def test_conv1x1_two_row_blocks_per_wave_gives_the_bits_of_the_one_block_kernel(precision, B, Cin, Cout, H, W):
-    """Round 5: conv1x1_ws2_kernel (64 pixels per wave pass, every B fragment from LDS feeds two MFMAs, A fragments in a ring) against
-    round 2's conv1x1_ws_kernel (GLARE_CONV1X1_ONE_BLOCK=1): the same products accumulated in the same order -> bit-equal outputs and
-    fused statistics, with and without residual / relu; odd numbers of row blocks per range (the absent second block), one pixel."""
-    import os
-
-    with ops.use_precision(precision):
-        g = torch.Generator().manual_seed(Cin + Cout + H * W)
-        dt = ops.act_dtype()
-        x = _rand((B, H, W, Cin), g).to(dt).cuda()
-        res = _rand((B, H, W, Cout), g).to(dt).cuda()
-        pc = ops.PackedConv(_rand((Cout, Cin, 1, 1), g, 1.0 / Cin ** 0.5).cuda(), _rand((Cout,), g, 0.1).cuda())
-        assert pc.w16 is not None
-
-        def run():
-            a = ops.conv2d(x, pc)
-            b = ops.conv2d(x, pc, residual=res, act="relu", gn_stats=True)
-            c = ops.conv2d(x, pc, act="relu")
-            return a, b, b._gn_stats, c
-
-        new = run()
-        os.environ["GLARE_CONV1X1_ONE_BLOCK"] = "1"
-        try:
-            old = run()
-        finally:
-            del os.environ["GLARE_CONV1X1_ONE_BLOCK"]
-        for n, o in zip(new, old):
-            assert torch.equal(n, o)
-        assert float(new[0].float().abs().max()) > 0
-
-
 def test_conv1x1_weight_stationary_is_deterministic_and_falls_back_outside_its_shapes():
     g = torch.Generator().manual_seed(3)
     x = _rand((8, 512, 105, 155), g).permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()

@@ -87,14 +87,6 @@ def bench_conv():
             ms_new = timeit(lambda: ops.conv2d(x, pc, out=out))
             by = 2.0 * B * h * w * (ci + co)
             print("conv  %-22s: igemm %.3f ms, weight-stationary %.3f ms = %.0f GB/s algorithmic (x in + out)" % (name, ms_old, ms_new, by / ms_new / 1e6))
-            os.environ["GLARE_CONV1X1_ONE_BLOCK"] = "1"      # round 2's kernel (one row block per wave pass) against round 5's (two)
-            ms_1 = timeit(lambda: ops.conv2d(x, pc, out=out))
-            ms_1r = timeit(lambda: ops.conv2d(x, pc, out=out, residual=res))
-            del os.environ["GLARE_CONV1X1_ONE_BLOCK"]
-            ms_2 = timeit(lambda: ops.conv2d(x, pc, out=out))
-            ms_2r = timeit(lambda: ops.conv2d(x, pc, out=out, residual=res))
-            print("conv  %-22s: weight-stationary, one row block per wave pass %.3f ms (+residual %.3f) | two %.3f ms (+residual %.3f) = %.0f GB/s"
-                  % (name, ms_1, ms_1r, ms_2, ms_2r, by / ms_2 / 1e6))
 
 
 def bench_convsplit():
