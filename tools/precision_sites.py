@@ -143,6 +143,18 @@ def main():
     measure("+ filters + activations + conv1 out (fp32-class A+B)", full, alo=T, wlo=T, olo=T)
     measure("fp32-class A+B + cond_feat hi/lo", full, alo=T, wlo=T, olo=T, cond22=True)
     measure("fp32-class A+B + cond_feat hi/lo + fp32 softmax P", full, alo=T, wlo=T, olo=T, cond22=True, soft16=False)
+    if os.environ.get("SITES_PER_CONV", "0") == "1":
+        # is there ANY conv of the conditional encoder whose third MFMA pass (x_hi . w_lo: the filter's lo half) or
+        # second pass (x_lo . w_hi: the activation's lo half) can be dropped without moving the table?  One site at a time, everything
+        # else at the full fp32-class scheme.
+        names = [n for n, m in og.named_modules() if isinstance(m, nn.Conv2d) and n.startswith("RRDB") and n not in DIRECT]
+        measure("reference point: fp32-class A+B + cond_feat hi/lo", full, alo=T, wlo=T, olo=T, cond22=True)
+        for n in names:
+            measure("16-bit FILTER at %s only (2 passes there)" % n[5:], full, alo=T, wlo=(lambda x, n=n: x != n), olo=T, cond22=True)
+        for n in names:
+            measure("16-bit ACTIVATION OPERAND at %s only" % n[5:], full, alo=(lambda x, n=n: x != n), wlo=T, olo=T, cond22=True)
+        measure("16-bit filters in the whole flow only", full, alo=T, wlo=(lambda x: not x.startswith("flowUpsamplerNet")), olo=T, cond22=True)
+        return
     if os.environ.get("SITES_SHORT", "0") == "1":
         return
     measure("fp32-class encoder, flow as today", full, alo=enc, wlo=enc, olo=enc)
