@@ -190,24 +190,15 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const a16_t* __res
       apply2(*reinterpret_cast<const u32x4*>(xb + (size_t)p * pitch), *reinterpret_cast<const u32x4*>(lb + (size_t)p * pitch), p);
     return;
   }
-#ifndef GN_APPLY_DEPTH
-#define GN_APPLY_DEPTH 4
-#endif
-#ifndef GN_APPLY_NT
-#define GN_APPLY_NT 1   // nontemporal stores: +10 % on the apply pass (4.4 -> 4.9 TB/s at 8 x 420x620x128); depth 8 loses 8 %
-#endif
-  constexpr int D = GN_APPLY_DEPTH;               // independent 16-B loads in flight per lane
+  // nontemporal stores: +10 % on the apply pass (4.4 -> 4.9 TB/s at 8 x 420x620x128); a load depth of 8 instead of 4 loses 8 %
+  constexpr int D = 4;                            // independent 16-B loads in flight per lane
   for (; p + (long long)(D - 1) * ppi < p1; p += (long long)D * ppi) {
     u32x4 v[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) v[k] = *reinterpret_cast<const u32x4*>(xb + (size_t)(p + (long long)k * ppi) * pitch);
 #pragma unroll
     for (int k = 0; k < D; ++k) {
-#if GN_APPLY_NT
       __builtin_nontemporal_store(apply(v[k]), reinterpret_cast<u32x4*>(yb + (size_t)(p + (long long)k * ppi) * C));
-#else
-      *reinterpret_cast<u32x4*>(yb + (size_t)(p + (long long)k * ppi) * C) = apply(v[k]);
-#endif
     }
   }
   for (; p < p1; p += ppi) *reinterpret_cast<u32x4*>(yb + (size_t)p * C) = apply(*reinterpret_cast<const u32x4*>(xb + (size_t)p * pitch));
