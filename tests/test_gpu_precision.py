@@ -167,8 +167,9 @@ def _product(og, ov):
 
 
 def _oracle(regime):
-    if regime.startswith("representative"):     # "representative2": a second trained-like weight set (weight seed 1)
-        return representative_init_(O.VQLLFLOWDeformable(per_sample_mean=True).eval(), O.VQModel().eval(), 1 if regime.endswith("2") else 0)
+    if regime.startswith("representative"):     # "representative2" / "3": a second / third trained-like weight set (weight seed 1 / 2)
+        wseed = {"2": 1, "3": 2}.get(regime[-1], 0)
+        return representative_init_(O.VQLLFLOWDeformable(per_sample_mean=True).eval(), O.VQModel().eval(), wseed)
     return seeded_init_(O.VQLLFLOWDeformable(per_sample_mean=True).eval(), 0), seeded_init_(O.VQModel().eval(), 1)
 
 
@@ -363,13 +364,16 @@ def test_end_to_end_full_size_twelve_scenes(capsys):
         within(delta, 0.0088)                      # measured max 0.0048 dB; BASELINE: 0.05
 
 
-@pytest.mark.parametrize("regime,seed", [("representative", 105), ("representative2", 101), ("representative2", 102)])
+@pytest.mark.parametrize("regime,seed", [("representative", 105), ("representative2", 101), ("representative2", 102), ("representative3", 101)])
 def test_end_to_end_full_size_held_out(regime, seed, capsys):
     """Scenes and weights that played no part in choosing the precision scheme: a held-out scene on the usual weights (105: the worst
     of 12 held-out scenes, 12 tokens differ) and two scenes on a SECOND trained-like weight set (another codebook, other ActNorm states
     and filters; PARITY_WEIGHT_SEED=1 in tools/parity_scenes.py).  Measured (profiles/r04_parity_table.txt, second half): agreement
     0.99926 / 0.99988 (2 of 16 275 tokens) / 0.99957, |dPSNR vs GT| 0.0035 / 0.0012 / 0.0001 dB, latent 1.43e-5 / 1.05e-5 /
-    0.95e-5.  Same bounds as the twelve-scene test (only the agreement bound is 2x this test's own worst case)."""
+    0.95e-5.  Same bounds as the twelve-scene test (only the agreement bound is 2x this test's own worst case).
+    Round 5: a THIRD weight set (weight seed 2), its worst scene of six: agreement 0.99982 but |dPSNR vs GT| 0.0190 dB (0.0201 with the
+    oracle's indices forced: the decoders' 16-bit arithmetic behind the codebook, not the search) -- its own bound, 2x measured, still
+    inside BASELINE's 0.05."""
     og, ov, pg, pv, lr, ref = setup(regime, 400, 600, seed)
     with torch.no_grad():
         r = pg.reverse_flow_nhwc(pv, lr.cuda())
@@ -385,7 +389,10 @@ def test_end_to_end_full_size_held_out(regime, seed, capsys):
     within(lat, 2.8e-5)                 # measured max 1.43e-5
     within(1.0 - agree, 1.47e-3)        # measured max 7.4e-4 (12 tokens)
     assert full["psnr_vs_oracle"] >= 54.2, full
-    within(full["delta"], 0.0070)       # measured max 0.0035 dB; BASELINE: 0.05
+    if regime == "representative3":
+        within(full["delta"], 0.038, "set3")    # measured 0.0190 dB; BASELINE: 0.05
+    else:
+        within(full["delta"], 0.0070)           # measured max 0.0035 dB; BASELINE: 0.05
 
 
 @pytest.mark.parametrize("h,w", [(60, 92), (132, 72), (36, 28)])
