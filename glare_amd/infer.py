@@ -72,18 +72,20 @@ def run(n_images, batch=8, h=400, w=600, seed=1234, root=None, net_g=None, net_v
 
     # the host images in PINNED memory (once, outside the timed region: the dataset loader's job), so that every batch's H2D copy is an
     # asynchronous DMA on its own stream; from pageable memory each copy stalled the host behind the previous batch (53 -> 5x images/s)
-    lows_p = torch.from_numpy(np.ascontiguousarray(lows)).pin_memory()
-    gts_p = torch.from_numpy(np.ascontiguousarray(gts)).pin_memory()
+    base, top = parallel.shard_range(n_images, rank, world)        # only this rank's slice is pinned
+    lows_p = torch.from_numpy(np.ascontiguousarray(lows[base:top])).pin_memory()
+    gts_p = torch.from_numpy(np.ascontiguousarray(gts[base:top])).pin_memory()
 
-    def psnr_slice(lo, hi, prec=precision):
-        out = enhance_batch(netG, net_vq, lows_p[lo:hi], device, prec)
-        gt = gts_p[lo:hi].to(device, non_blocking=True)
+    def psnr_slice(lo, hi, prec=precision):        # global image indices inside [base, top)
+        out = enhance_batch(netG, net_vq, lows_p[lo - base:hi - base], device, prec)
+        gt = gts_p[lo - base:hi - base].to(device, non_blocking=True)
         restored, vals = harness.postprocess_device(out, h, w, gt)   # crop, clamp, GT-mean gain, PSNR: all on the device
         if with_ssim:                                                  # + SSIM (calculate_ssim, infer_dataset_lol.py:152)
             return torch.stack([vals, harness.ssim_device(restored, gt)], dim=1)
         return vals.view(-1, 1)
 
-    psnr_slice(0, min(batch, n_images))                           # warm-up: weight packing, workspace growth
+    if top > base:
+        psnr_slice(base, min(base + batch, top))                  # warm-up on this rank's first batch: weight packing, workspace growth
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     local = parallel.run_sharded(n_images, psnr_slice, rank, world, batch=batch, streams=2)
