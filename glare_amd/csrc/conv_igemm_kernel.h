@@ -36,7 +36,7 @@ struct ConvParams {
   // writes output channels ooff + g * g_out_step, with the g-th packed filter / bias.
   int groups, g_in_step, g_out_step, g_bias_step;
   long long g_w_elems;
-  int k_wrap;            // K segments [in0 | in1 | in0 again]: the fp32-class contraction on hi / lo operand pairs (glare_conv_desc.k_wrap)
+  int k_wrap;            // 1: K segments [in0 | in1 | in0 again]: the fp32-class contraction on hi / lo operand pairs (glare_conv_desc.k_wrap); 2: in0 tiles staged once
   const float* gn_coef;  // GNP instantiations: [B][Cin0][2] = (a, d) of the input's GroupNorm, applied to the halo tile in LDS
   int gn_swish;
 };
@@ -225,11 +225,21 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
       const_cast<a16_t*>(p.in1 ? p.in1 + img * p.p1 : p.in0), 0, (int)(p.in1 ? p.in1_bytes : p.in0_bytes), 0x00020000);
   const a16_t* wbase = p.wpk + ((size_t)phase * p.co_tiles + ct) * p.n_stages * (size_t)(KS * B_CHUNKS) * 8;
 
-  auto issue_a = [&](int chunk, int buf, int i_lo = 0, int i_hi = 1 << 20) {   // pieces [i_lo, i_hi) of this wave
+  // k_wrap = 2 (round 5): stages 2c and 2c + 1 contract the SAME x_hi halo tile (chunk c of source 0) with the filter's hi and lo halves,
+  // and the x_lo segment follows behind all of them: x_hi is staged once instead of twice (ops.split_filter, reuse_kc)
+  const bool reuse = KS == 3 && STRIDE == 1 && !GNP && p.k_wrap == 2;  // (glare_conv2d_bf16 rejects k_wrap = 2 anywhere else)
+  const int n_pair = reuse ? 2 * (p.Cin0 / KC) : 0;                    // stages of the paired (x_hi) part
+  auto a_is_new = [&](int stage) { return !(reuse && stage < n_pair && (stage & 1)); };
+  auto issue_a = [&](int chunk, int buf, int i_lo = 0, int i_hi = 1 << 20) {   // pieces [i_lo, i_hi) of this wave; chunk = K stage
     const int c0 = chunk * KC;
     // uniform: a stage never straddles two K segments -- [in0 | in1] and, with k_wrap, in0 once more behind them
-    const bool src0 = c0 < p.Cin0 || c0 >= p.Cin0 + p.Cin1;
-    const int cbase = c0 < p.Cin0 ? c0 : (src0 ? c0 - p.Cin0 - p.Cin1 : c0 - p.Cin0), climit = src0 ? p.Cin0 : p.Cin1;
+    bool src0 = c0 < p.Cin0 || c0 >= p.Cin0 + p.Cin1;
+    int cbase = c0 < p.Cin0 ? c0 : (src0 ? c0 - p.Cin0 - p.Cin1 : c0 - p.Cin0);
+    if (reuse) {
+      src0 = chunk < n_pair;
+      cbase = src0 ? (chunk >> 1) * KC : (chunk - n_pair) * KC;
+    }
+    const int climit = src0 ? p.Cin0 : p.Cin1;
 #pragma unroll
     for (int i = 0; i < A_PER_W; ++i) {
       const int j = wave + NW * i;
@@ -319,22 +329,24 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
   issue_a(0, 0);
   issue_b(0, 0);
   int bs = 0;
+  int a_cnt = 0;       // halo tiles staged so far - 1: tile t lives in A buffer t & 1 (= the stage index unless k_wrap = 2 reuses tiles)
   for (int chunk = 0; chunk < p.n_stages; ++chunk) {
-    const u32x4* cA = lA + (chunk & 1) * A_SLOTS;
+    const u32x4* cA = lA + (a_cnt & 1) * A_SLOTS;
+    const bool next_new = chunk + 1 < p.n_stages && a_is_new(chunk + 1);
 #pragma unroll
     for (int trow = 0; trow < KS; ++trow, ++bs) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
       if constexpr (GNP) {                               // ... and are normalised in place before anybody reads them
         if (trow == 0 && chunk == 0) gn_transform(0, 0);
-        if (trow == 1 && chunk + 1 < p.n_stages) gn_transform(chunk + 1, (chunk + 1) & 1);
+        if (trow == 1 && chunk + 1 < p.n_stages) gn_transform(chunk + 1, (a_cnt + 1) & 1);
       }
       __syncthreads();                                   // ... and everybody else's; stage bs-1 retired
       // The next stage's DMA pieces are not issued in one burst behind the barrier (12 waves would queue 47 pieces on the
       // CU's address path with the matrix pipe waiting): they are spread over the stage's KS*KSTEPS MFMA groups.
       constexpr int NGRP = KS * KSTEPS;
       [[maybe_unused]] constexpr int B_PG = (B_PER_W + NGRP - 1) / NGRP, A_PG = (A_PER_W + NGRP - 1) / NGRP;
-      const bool more_b = bs + 1 < n_bstages, more_a = trow == 0 && chunk + 1 < p.n_stages;
-      if (trow == 0 && chunk + 1 == p.n_stages && p.res_bytes) prefetch_residual((chunk + 1) & 1);
+      const bool more_b = bs + 1 < n_bstages, more_a = trow == 0 && next_new;
+      if (trow == 0 && chunk + 1 == p.n_stages && p.res_bytes) prefetch_residual((a_cnt + 1) & 1);
       const u32x4* cB = lB + (bs & 1) * B_CHUNKS;
 #pragma unroll
       for (int tcol = 0; tcol < KS; ++tcol) {
@@ -343,7 +355,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
           {
             const int grp = tcol * KSTEPS + ks;
             if (more_b) issue_b(bs + 1, (bs + 1) & 1, grp * B_PG, (grp + 1) * B_PG);
-            if (more_a) issue_a(chunk + 1, (chunk + 1) & 1, grp * A_PG, (grp + 1) * A_PG);
+            if (more_a) issue_a(chunk + 1, (a_cnt + 1) & 1, grp * A_PG, (grp + 1) * A_PG);
           }
           a16x8 bf[NT], af[MT];
 #pragma unroll
@@ -365,6 +377,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
         }
       }
     }
+    if (next_new) ++a_cnt;
   }
 
   // ---- hi / lo epilogue: the output keeps 22 mantissa bits as two 16-bit tensors (the residual stream of the conditional

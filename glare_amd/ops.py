@@ -2,6 +2,7 @@
 with torch (device memory + current stream are torch's: plumbing, not compute), one ctypes call.
 Every function raises on CPU tensors -- the HIP kernels are the only implementation."""
 import ctypes
+import os
 
 import torch
 
@@ -48,22 +49,36 @@ class ConvDesc(ctypes.Structure):
                 ("gn_coef", ctypes.c_void_p), ("gn_swish", _i)]
 
 
-def split_filter(w, split):
+# k_wrap = 2 (round 5): the K order of an fp32-class 3x3 conv in which every x_hi halo tile is staged ONCE for the two filter halves it
+# meets -- per 16-channel chunk c the stages (x_hi(c), w_hi(c)), (x_hi(c), w_lo(c)), and behind all of them the x_lo segment against
+# w_hi -- instead of the segment order [x_hi | x_lo | x_hi] that reads x_hi twice.  GLARE_SPLIT_A_REUSE=0: round 4's order.
+SPLIT_A_REUSE = os.environ.get("GLARE_SPLIT_A_REUSE", "1") == "1"
+
+
+def split_filter(w, split, reuse_kc=0):
     """K segments of an fp32-class conv (glare_conv_desc.k_wrap), along the input channels of an fp32 [..., cout, cin, k, k] filter:
     split = 3: [w_hi | w_hi | w_lo] for the operand segments [x_hi | x_lo | x_hi]; split = 2: [w_hi | w_lo] for [x_hi | x_hi]
     (a 16-bit activation against a 22-bit filter).  w_hi = round16(w) is what the pack kernel makes of the first segments by
-    itself; w_lo = round16(w - w_hi)."""
+    itself; w_lo = round16(w - w_hi).
+    reuse_kc = the kernel's channels per stage (16 for 3x3): the k_wrap = 2 order [w_hi(c0) | w_lo(c0) | w_hi(c1) | w_lo(c1) | ... | w_hi]
+    for the stages (x_hi(c), x_hi(c) again, ..., then x_lo): the same three products, x_hi staged once."""
     if not split:
         return w
     assert split in (2, 3)
     lo = w - w.to(act_dtype()).float()
+    if reuse_kc:
+        assert split == 3 and w.shape[-3] % reuse_kc == 0
+        lead, (cin, kh, kw) = w.shape[:-3], w.shape[-3:]
+        n = cin // reuse_kc
+        inter = torch.stack([w.reshape(*lead, n, reuse_kc, kh, kw), lo.reshape(*lead, n, reuse_kc, kh, kw)], dim=len(lead) + 1)
+        return torch.cat([inter.reshape(*lead, 2 * cin, kh, kw), w], dim=-3).contiguous()
     return torch.cat([w, w, lo] if split == 3 else [w, lo], dim=-3).contiguous()
 
 
 class PackedConv:
     """A conv filter packed once for the MFMA kernel (weights bf16 stage-ordered, bias fp32)."""
 
-    def __init__(self, weight_oihw, bias=None, dgrad_pad=None, upsample_subpixel=False, cout_tile=0, split=0):
+    def __init__(self, weight_oihw, bias=None, dgrad_pad=None, upsample_subpixel=False, cout_tile=0, split=0, stride=1):
         """dgrad_pad = P: pack the filter of the data-gradient conv (P >= cout input channels, cin outputs) instead.
         cout_tile: 0 = the default output-channel tile for this cout, or 64 / 32 for launches too small to fill the chip with it
         (conv_cout_tile(); the packed image is tile-specific and conv2d passes the tile on).
@@ -72,9 +87,14 @@ class PackedConv:
         require_cuda(weight_oihw)
         w = weight_oihw.detach().float().contiguous()
         self.split = int(split)
+        self.k_wrap = 1 if split else 0
         if split:       # the fp32-class form: conv2d() reads the activation's hi / lo pair against [w_hi | w_hi | w_lo]
             assert dgrad_pad is None and not upsample_subpixel and not cout_tile
-            w = split_filter(w, split)
+            if split == 3 and SPLIT_A_REUSE and stride == 1 and w.shape[-1] == 3 and w.shape[1] % 16 == 0:
+                self.k_wrap = 2
+                w = split_filter(w, split, reuse_kc=16)
+            else:
+                w = split_filter(w, split)
         cout, cin, kh, kw = w.shape
         assert kh == kw and kh in (1, 3)
         self.ksize = kh
@@ -137,7 +157,10 @@ def packed_conv_batch(weights, biases=None, dgrad_pad=None, cout_tile=0, split=0
     w = weights.detach().float().contiguous()
     if split:
         assert dgrad_pad is None
-        w = split_filter(w, split)
+        k_wrap = 2 if (split == 3 and SPLIT_A_REUSE and w.shape[-1] == 3 and w.shape[2] % 16 == 0) else 1
+        w = split_filter(w, split, reuse_kc=16 if k_wrap == 2 else 0)
+    else:
+        k_wrap = 0
     n, cout, cin, kh, kw = w.shape
     assert kh == kw and kh in (1, 3)
     lib = _lib.lib()
@@ -153,7 +176,7 @@ def packed_conv_batch(weights, biases=None, dgrad_pad=None, cout_tile=0, split=0
     for k in range(n):
         pc = PackedConv.__new__(PackedConv)
         pc.ksize, pc.subpixel, pc.cout, pc.cin, pc.packed, pc.w16, pc.cout_tile = kh, False, oc, ic // (split or 1), packed[k], None, cout_tile
-        pc.split = int(split)
+        pc.split, pc.k_wrap = int(split), k_wrap
         pc.bias = None if b is None else b[k]
         out.append(pc)
     return out
@@ -464,7 +487,7 @@ def conv2d_grouped(x, pcs, *, cin, in_step, out, out_step, in_off=0, out_off=0, 
     d.groups, d.group_in_step, d.group_out_step = G, in_step, out_step
     split = getattr(p0, "split", 0)
     if split:                                  # fp32-class: the hi / lo operand pair against [w_hi | w_hi | w_lo] (k_wrap)
-        d.k_wrap = 1
+        d.k_wrap = getattr(p0, "k_wrap", 1) or 1
         if split == 3:
             xlo = getattr(x, "_lo", None)
             assert xlo is not None and xlo.shape == x.shape and xlo.dtype == x.dtype and xlo.is_contiguous(), "split-3 filter: x needs its lo half"
@@ -521,7 +544,8 @@ def conv2d(x, pc, *, x2=None, cin=None, in_off=0, cin2=None, in2_off=0, stride=1
     d.Cin, d.in_pitch, d.in_off = cin, pitch, in_off
     if split:      # fp32-class: K segments [x_hi | x_lo | x_hi] against the filter packed as [w_hi | w_hi | w_lo] (k_wrap)
         assert x2 is None and not upsample and cin == pc.cin, (cin, pc.cin)
-        d.k_wrap = 1
+        d.k_wrap = getattr(pc, "k_wrap", 1) or 1
+        assert d.k_wrap != 2 or (stride == 1 and gn_prologue is None), "this filter was packed for the stride-1 K order: PackedConv(..., stride=2)"
         if split == 3:
             x2 = getattr(x, "_lo", None)
             assert x2 is not None and x2.shape == x.shape, "a split-3 filter contracts the activation's hi / lo pair: x._lo is missing"

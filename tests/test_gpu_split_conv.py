@@ -41,9 +41,13 @@ CASES = [  # B, Cin, Cout, H, W, k, stride
 ]
 
 
+@pytest.mark.parametrize("reuse", [True, False])
 @pytest.mark.parametrize("prec", ["fp16", "bf16"])
 @pytest.mark.parametrize("B,Cin,Cout,H,W,k,stride", CASES)
-def test_split3_conv_matches_the_fp32_conv(prec, B, Cin, Cout, H, W, k, stride):
+def test_split3_conv_matches_the_fp32_conv(monkeypatch, prec, B, Cin, Cout, H, W, k, stride, reuse):
+    """reuse: the K order k_wrap = 2 (every x_hi halo tile staged once for w_hi and w_lo: 3x3 stride 1, the default) against round 4's
+    segment order k_wrap = 1 -- the same three products in another accumulation order, the same bound."""
+    monkeypatch.setattr(ops, "SPLIT_A_REUSE", reuse)
     g = torch.Generator().manual_seed(B * 1000 + Cin + Cout + H + k)
     x = torch.randn((B, Cin, H, W), generator=g)
     w = torch.randn((Cout, Cin, k, k), generator=g) / (Cin * k * k) ** 0.5
@@ -54,7 +58,9 @@ def test_split3_conv_matches_the_fp32_conv(prec, B, Cin, Cout, H, W, k, stride):
         ref = F.conv2d(x.cuda(), w.cuda(), b.cuda(), 1, k // 2)
     with ops.use_precision(prec):
         xp = _pair(x)
-        out = ops.conv2d(xp, ops.PackedConv(w.cuda(), b.cuda(), split=3), stride=stride, out_mode=ops.OUT_NHWC_F32)
+        pc = ops.PackedConv(w.cuda(), b.cuda(), split=3, stride=stride)
+        assert pc.k_wrap == (2 if reuse and k == 3 and stride == 1 and Cin % 16 == 0 else 1)
+        out = ops.conv2d(xp, pc, stride=stride, out_mode=ops.OUT_NHWC_F32)
         plain = ops.conv2d(xp, ops.PackedConv(w.cuda(), b.cuda()), stride=stride, out_mode=ops.OUT_NHWC_F32)
     e3, e1 = _err(out, ref), _err(plain, ref)
     within(e3, 3.5e-6 if prec == "fp16" else 1.0e-5, prec)    # measured on MI355X (max over the cases): fp16 1.76e-6, bf16 5.0e-6
