@@ -101,6 +101,14 @@ __device__ __forceinline__ void static_for(F&& f) {
 // (ActSel, act_sel, act_cheap, act_exp, act_any: common.h -- shared with conv1x1.hip)
 
 
+// The lane id again, from nothing (v_mbcnt): the epilogues' `lane` would otherwise be carried -- at 168 registers: spilled -- through the
+// K loop, which needs only values derived from it.
+__device__ __forceinline__ int fresh_lane_id() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
 // One 16-B piece (8 channels of one halo position) of the GNP prologue, in place in LDS.
 __device__ __forceinline__ void gn_prologue_piece(u32x4* slot, const float* cf, int swish) {
   __builtin_amdgcn_sched_barrier(0);       // nothing of the MFMA loop is scheduled into the transform, and vice versa
@@ -193,7 +201,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // per-lane invariant part of the A addressing: this wave issues DMA instructions j = wave + NW*i; lane handles chunk
-  // c = j*64 + lane = (kstep*2 + khalf)*NPOS + pos.  The halo goes through buffer descriptors based at THIS IMAGE (32-bit byte
+  // c = j*64 + lane = (halo row * 2*KSTEPS + kstep*2 + khalf) * IW + x.  The halo goes through buffer descriptors based at THIS IMAGE (32-bit byte
   // offsets: one image of one source stays below 2 GB): a loop-invariant offset per lane and piece (pixel, 8-channel half)
   // plus the stage's channel offset as the scalar offset; padded positions, slots beyond the tile and channels beyond Cin
   // carry an offset beyond the descriptor's range, which the hardware turns into zeros -- no 64-bit address arithmetic, no
@@ -207,14 +215,18 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
     a_vo0[i] = a_vo1[i] = A_OOB;
     a_ck[i] = 0;
     if (c < A_CHUNKS) {
-      const int pos = c % G::NPOS, kk = c / G::NPOS;
+      // LDS image [halo row][8-channel plane][x]: the planes of one halo row are NEIGHBOURS in a DMA piece, so the 2 * KSTEPS lanes that
+      // read the same pixel's 128-B line sit in the same instruction (or the next) instead of NPOS slots apart -- the guide's "fragment-
+      // shaped loads cost TA cycles" at the scale this tile allows (round 5: 3x3 -1...2 %, the 1x1 form -11...18 %, +1.05 % on the bench)
+      const int prow = c / (2 * KSTEPS * G::IW), rem = c % (2 * KSTEPS * G::IW);
+      const int kk = rem / G::IW, pos = prow * G::IW + rem % G::IW;
       a_ck[i] = kk * 8;
       const int iy = iy0 + pos / G::IW, ix = ix0 + pos % G::IW;
       if (iy >= 0 && iy < p.IHs && ix >= 0 && ix < p.IWs) {
         const int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
         const unsigned pix = (unsigned)(sy * p.W + sx);
         a_vo0[i] = (pix * (unsigned)p.p0 + (unsigned)(p.o0 + kk * 8)) * 2u;
-        a_vo1[i] = (pix * (unsigned)p.p1 + (unsigned)(p.o1 + kk * 8)) * 2u;
+        if constexpr (!GNP) a_vo1[i] = (pix * (unsigned)p.p1 + (unsigned)(p.o1 + kk * 8)) * 2u;   // (the GroupNorm-prologue form has one source)
       }
     }
   }
@@ -233,7 +245,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
   auto issue_a = [&](int chunk, int buf, int i_lo = 0, int i_hi = 1 << 20) {   // pieces [i_lo, i_hi) of this wave; chunk = K stage
     const int c0 = chunk * KC;
     // uniform: a stage never straddles two K segments -- [in0 | in1] and, with k_wrap, in0 once more behind them
-    bool src0 = c0 < p.Cin0 || c0 >= p.Cin0 + p.Cin1;
+    bool src0 = GNP || c0 < p.Cin0 || c0 >= p.Cin0 + p.Cin1;
     int cbase = c0 < p.Cin0 ? c0 : (src0 ? c0 - p.Cin0 - p.Cin1 : c0 - p.Cin0);
     if (reuse) {
       src0 = chunk < n_pair;
@@ -311,7 +323,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
           // the addresses are formed HERE, from a value the compiler cannot see through: hoisted out of the K loop as invariants
           // (nine more live registers in a kernel that has none) they put a scratch store + load next to every MFMA -- 4.8 ms
           // for a 0.6 ms conv, measured
-          int ln = lane, ck = a_ck[i];
+          int ln = fresh_lane_id(), ck = a_ck[i];
           asm volatile("" : "+v"(ln), "+v"(ck));
           gn_prologue_piece(lA + buf * A_SLOTS + j * 64 + ln, lC + (c0 + ck) * 2, p.gn_swish);
         }
@@ -366,8 +378,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
 #pragma unroll
           for (int i = 0; i < MT; ++i) {
             const int row = wm * MT + i;
-            const int pos = (row * STRIDE + trow) * G::IW + px * STRIDE + tcol;
-            af[i] = __builtin_bit_cast(a16x8, cA[(ks * 2 + khalf) * G::NPOS + pos]);
+            af[i] = __builtin_bit_cast(a16x8, cA[((row * STRIDE + trow) * (2 * KSTEPS) + ks * 2 + khalf) * G::IW + px * STRIDE + tcol]);
           }
 #pragma unroll
           for (int i = 0; i < MT; ++i)
@@ -393,6 +404,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
     static_assert(KS != 2, "the sub-pixel form has no hi/lo epilogue");
     __syncthreads();  // every wave is done reading the pipeline buffers
     char* slab = smem + wave * (32 * ROWF);
+    const int lane = fresh_lane_id();
     const int ncol = lane & 31, rhalf = lane >> 5;
     float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
     const ActSel asel = act_sel(p.act);
@@ -514,6 +526,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
     static_assert(NW * HROWS * ROWB <= (2 * A_SLOTS + 2 * B_CHUNKS) * 16, "epilogue slab fits the pipeline LDS");
     __syncthreads();  // every wave is done reading the pipeline buffers
     char* slab = smem + wave * (HROWS * ROWB);
+    const int lane = fresh_lane_id();
     const int ncol = lane & 31, rhalf = lane >> 5, odd = lane & 1;
     const bool act_early = p.res == nullptr;
     // fused GroupNorm statistics of the tensor being written (the consumer's gn_stats pass would re-read it):
@@ -633,6 +646,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
       typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
       __syncthreads();  // every wave is done reading the pipeline buffers
       float* slab = reinterpret_cast<float*>(smem) + wave * (32 * ROWD);
+      const int lane = fresh_lane_id();
       const int ncol = lane & 31, rhalf = lane >> 5;
       const ActSel asel = act_sel(p.act);
       static_for<MT>([&](auto ic) {
@@ -675,6 +689,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
 
   // ---- general epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   if constexpr (EPI == EPI_GENERAL) {
+  const int lane = fresh_lane_id();
   const int ncol = lane & 31, rhalf = lane >> 5;
   // static_for: the accumulator indices must be compile-time constants (a runtime-indexed
   // ext_vector array is demoted to scratch memory)

@@ -270,6 +270,29 @@ def bench_vq():
     print("vq    %d tokens x 8192 codes: %.3f ms  %.2f Gtoken-code/s" % (n, ms, n * 8192 / ms / 1e6))
 
 
+def bench_conv1x1():
+    """Every 1x1 shape of the path on both kernels: the implicit-GEMM form (conv_igemm, KS = 1) against the weight-stationary one
+    (conv1x1.hip), 16-bit and fp32-class (pair in / pair out)."""
+    cases = [("128->256 @half", 128, 256, 210, 310), ("256->512 @q", 256, 512, 105, 155), ("512->512 @q", 512, 512, 105, 155),
+             ("256->128 @full", 256, 128, 420, 620), ("512->256 @half", 512, 256, 210, 310), ("512->1024 @q", 512, 1024, 105, 155)]
+    with ops.use_precision("fp16"):
+        for name, ci, co, h, w in cases:
+            wt = torch.randn(co, ci, 1, 1, device=DEV) * 0.02
+            x = ops.split_hilo(torch.randn(B, h, w, ci, device=DEV))
+            res = ops.split_hilo(torch.randn(B, h, w, co, device=DEV))
+            out = torch.empty(B, h, w, co, dtype=torch.float16, device=DEV)
+            out._lo = torch.empty_like(out)
+            pc, pc3 = ops.PackedConv(wt, torch.zeros(co, device=DEV)), ops.PackedConv(wt, torch.zeros(co, device=DEV), split=3)
+            t = {}
+            for ws in (False, True):
+                ops.CONV1X1_WEIGHT_STATIONARY = ws
+                t[ws] = (timeit(lambda: ops.conv2d(x, pc, out=out)), timeit(lambda: ops.conv2d(x, pc, out=out, residual=res)),
+                         timeit(lambda: ops.conv2d(x, pc3, out=out, hilo=True)), timeit(lambda: ops.conv2d(x, pc3, out=out, residual=res, hilo=True)))
+            ops.CONV1X1_WEIGHT_STATIONARY = True
+            print("conv1x1 %-16s: 16-bit igemm %.3f / ws %.3f | + residual %.3f / %.3f | fp32-class pair out %.3f / %.3f | + pair residual %.3f / %.3f ms"
+                  % (name, t[False][0], t[True][0], t[False][1], t[True][1], t[False][2], t[True][2], t[False][3], t[True][3]))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["attn", "conv", "gn", "dcn", "vq", "wgrad", "attnbwd"]
     for w in which:
