@@ -181,7 +181,7 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_kernel(const DcnParams p) 
   gather_issue(0);
   gather_finish(0);
   const int arow = (lane & 31) + 32 * wm, khalf = lane >> 5;
-  const u32x4* wq = reinterpret_cast<const u32x4*>(p.wt);  // [stage][cpg/8][Co][hi 16 B | lo 16 B]
+  const u32x4* wq = reinterpret_cast<const u32x4*>(p.wt);  // [stage][cpg/8][hi | lo][Co][16 B]
   for (int s = 0; s < n_stages; ++s) {
     __syncthreads();                            // sample tile s visible; tile s-1 retired
     if (s + 1 < n_stages) gather_issue(s + 1);  // corners of the next stage fly during the MFMAs
@@ -192,9 +192,9 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_kernel(const DcnParams p) 
       const bf16x8 al = __builtin_bit_cast(bf16x8, a_src[(nch + kk) * DC_PIX]);
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        const u32x4* wp = wq + (((size_t)s * nch + kk) * p.Co + (wn * NT + j) * 32 + (lane & 31)) * 2;
+        const u32x4* wp = wq + ((size_t)s * nch + kk) * 2 * p.Co + (wn * NT + j) * 32 + (lane & 31);
         const bf16x8 bh = __builtin_bit_cast(bf16x8, wp[0]);
-        const bf16x8 bl = __builtin_bit_cast(bf16x8, wp[1]);
+        const bf16x8 bl = __builtin_bit_cast(bf16x8, wp[p.Co]);
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
@@ -443,17 +443,18 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_fast_kernel(const DcnParam
     }
   };
 
-  // ---- weight fragments: [stage][c/8][Co][hi 16 B | lo 16 B], one (hi, lo) pair per (k-step, N tile) ----
-  // (SINGLE: [stage][c/8][Co][16 B], one fragment per (k-step, N tile))
+  // ---- weight fragments: [stage][c/8][hi | lo][Co][16 B], one (hi, lo) pair per (k-step, N tile): every load reads 2 x 512
+  // contiguous bytes ----  (SINGLE: [stage][c/8][Co][16 B], one fragment per (k-step, N tile))
   const int khalf = lane >> 5;
-  constexpr unsigned WB = SINGLE ? 16u : 32u;       // bytes per (8 channels, output channel) record of the packed filter
-  const unsigned wvo = (unsigned)(khalf * p.Co + wn * NT * 32 + (lane & 31)) * WB;
+  constexpr unsigned WP = SINGLE ? 1u : 2u;         // 16-B planes per (8 channels, output channel) of the packed filter
+  const unsigned wvo = (unsigned)(khalf * WP * p.Co + wn * NT * 32 + (lane & 31)) * 16u;
+  const unsigned wlo = (unsigned)p.Co * 16u;        // from a chunk's hi plane to its lo plane
   auto load_b = [&](int s, int ks, u32x4 (&dst)[NT][HL]) {
-    const unsigned ws = (unsigned)((s * NCH + 2 * ks) * p.Co) * WB;
+    const unsigned ws = (unsigned)((s * NCH + 2 * ks) * p.Co) * (16u * WP);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      dst[j][0] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvo + j * (32 * WB), ws, 0);
-      if constexpr (!SINGLE) dst[j][HL - 1] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvo + j * 1024 + 16, ws, 0);
+      dst[j][0] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvo + j * 512, ws, 0);
+      if constexpr (!SINGLE) dst[j][HL - 1] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvo + j * 512, ws + wlo, 0);   // (the plane step rides in the scalar offset)
     }
   };
   auto mfma_step = [&](const u32x4* a_src, int ks, const u32x4 (&b)[NT][HL]) {
@@ -561,7 +562,9 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_fast_kernel(const DcnParam
 // could hide (round 4).
 
 // [Co][C][kh][kw] fp32 (reference layout) -> split-bf16 B-fragment image
-// [stage = g*K + tap][c/8][Co][hi: 8 bf16 | lo: 8 bf16]  (same byte count as the fp32 filter)
+// [stage = g*K + tap][c/8][hi | lo][Co][8 bf16]  (same byte count as the fp32 filter).  Round 5: the hi and the lo fragments of a
+// chunk are two PLANES of Co contiguous 16-B records, not interleaved 32-B records -- a B-fragment load of 32 consecutive output channels
+// then reads 512 contiguous bytes (4 lines) instead of every other 16 B of 1 KB (8 lines, half of each unused).
 __global__ void dcn_pack_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ wt, int Co, int C, int K, int dg) {
   const long long total = (long long)Co * C * K;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -576,9 +579,9 @@ __global__ void dcn_pack_weight_kernel(const float* __restrict__ w, bf16_t* __re
   const int g = s / K, tap = s % K;
   const float v = w[((size_t)co * C + g * cpg + kk * 8 + e) * K + tap];
   const bf16_t hi = f2bf(v);
-  const size_t base = (((size_t)s * nch + kk) * Co + co) * 16;
+  const size_t base = ((((size_t)s * nch + kk) * 2) * Co + co) * 8;     // the hi plane of this (stage, chunk); its lo plane Co records further
   wt[base + e] = hi;
-  wt[base + 8 + e] = f2bf(v - bf2f(hi));
+  wt[base + (size_t)Co * 8 + e] = f2bf(v - bf2f(hi));
 }
 
 // the single-pass image: [stage][c/8][Co][8 x a16], the filter rounded once to the library's activation format
