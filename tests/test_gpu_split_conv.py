@@ -86,6 +86,51 @@ def test_split3_hilo_output_residual_and_statistics():
         assert float((y._lo.float().abs().max())) > 0
 
 
+def test_tile_reuse_order_error_behaviour_and_agreement_with_the_segment_order(monkeypatch):
+    """glare_conv_desc.k_wrap = 2 (include/glare_hip.h): 3x3 stride 1 only, needs the lo half with the hi half's channel count; any
+    other value is invalid.  Against k_wrap = 1 on the same operands (pair in, pair residual, pair out, statistics) the result differs
+    by accumulation order only."""
+    from glare_amd import _lib
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn((1, 64, 9, 33), generator=g)
+    w3 = torch.randn((32, 64, 3, 3), generator=g) * 0.05
+    with ops.use_precision("fp16"):
+        xp = _pair(x)
+        pc = ops.PackedConv(w3.cuda(), None, split=3)
+        assert pc.k_wrap == 2
+        with pytest.raises(AssertionError):          # host side: a filter packed for the stride-1 order
+            ops.conv2d(xp, pc, stride=2)
+        out = torch.empty(1, 9, 33, 32, dtype=torch.float16, device="cuda")
+        d = ops.ConvDesc()
+        d.in_, d.B, d.H, d.W, d.Cin, d.in_pitch = xp.data_ptr(), 1, 9, 33, 64, 64
+        d.in2, d.Cin2, d.in2_pitch = xp._lo.data_ptr(), 64, 64
+        d.out, d.Cout, d.out_pitch = out.data_ptr(), 32, 32
+        d.weight_packed, d.ksize, d.stride, d.out_mode = pc.packed.data_ptr(), 3, 1, ops.OUT_NHWC_BF16
+        lib = _lib.lib()
+        import ctypes
+        for k_wrap, stride, in2, cin2, want in ((2, 1, True, 64, 0), (2, 2, True, 64, _lib.ERR_UNSUPPORTED), (3, 1, True, 64, _lib.ERR_INVALID),
+                                                (-1, 1, True, 64, _lib.ERR_INVALID), (2, 1, False, 0, _lib.ERR_INVALID), (2, 1, True, 48, _lib.ERR_INVALID)):
+            d.k_wrap, d.stride = k_wrap, stride
+            d.in2, d.Cin2 = (xp._lo.data_ptr() if in2 else None), cin2
+            assert lib.glare_conv2d_bf16(ctypes.byref(d), ops.stream_handle()) == want, (k_wrap, stride, in2, cin2)
+        torch.cuda.synchronize()
+    x = torch.randn((2, 128, 12, 40), generator=g)
+    r = torch.randn((2, 128, 12, 40), generator=g)
+    w = torch.randn((128, 128, 3, 3), generator=g) * 0.03
+    b = torch.randn((128,), generator=g) * 0.1
+    res = {}
+    with ops.use_precision("fp16"):
+        for reuse in (True, False):
+            monkeypatch.setattr(ops, "SPLIT_A_REUSE", reuse)
+            o = ops.conv2d(_pair(x), ops.PackedConv(w.cuda(), b.cuda(), split=3), residual=_pair(r), hilo=True, gn_stats=True)
+            res[reuse] = (_val(o), o._gn_stats.clone())
+    ref = F.conv2d(x.cuda(), w.cuda(), b.cuda(), 1, 1) + r.cuda()
+    within(_err(res[True][0], ref), 2.2e-6)
+    within(_err(res[False][0], ref), 2.2e-6)
+    assert float((res[True][0] - res[False][0]).abs().max() / ref.abs().max()) < 1.5e-6
+    assert torch.allclose(res[True][1], res[False][1], rtol=1e-5, atol=1e-3)
+
+
 def test_split3_1x1_hilo_output_both_tiles():
     g = torch.Generator().manual_seed(12)
     for cin, cout in ((128, 256), (64, 64)):
