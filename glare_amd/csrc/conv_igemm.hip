@@ -311,7 +311,7 @@ extern "C" int glare_conv2d_bf16(const glare_conv_desc* d, glare_stream_t stream
     p.OH = p.IHs; p.OW = p.IWs;
   }
   if (d->k_wrap < 0 || d->k_wrap > 2 || (d->k_wrap == 2 && !(d->in2 && d->Cin2 == d->Cin))) return GLARE_ERR_INVALID;
-  if (d->k_wrap == 2 && (d->ksize != 3 || d->stride != 1 || d->gn_coef || d->upsample || d->Cin % 16)) return GLARE_ERR_UNSUPPORTED;
+  if (d->k_wrap == 2 && (d->ksize != 3 || d->gn_coef || d->upsample || d->Cin % 16)) return GLARE_ERR_UNSUPPORTED;
   p.k_wrap = d->k_wrap;
   p.Cin0 = d->Cin; p.Cin1 = d->in2 ? d->Cin2 : 0; p.CinTot = p.Cin0 + p.Cin1 + (p.k_wrap ? p.Cin0 : 0);
   p.p0 = d->in_pitch; p.o0 = d->in_off; p.p1 = d->in2_pitch; p.o1 = d->in2_off;

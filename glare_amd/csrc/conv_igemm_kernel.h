@@ -239,7 +239,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
 
   // k_wrap = 2 (round 5): stages 2c and 2c + 1 contract the SAME x_hi halo tile (chunk c of source 0) with the filter's hi and lo halves,
   // and the x_lo segment follows behind all of them: x_hi is staged once instead of twice (ops.split_filter, reuse_kc)
-  const bool reuse = KS == 3 && STRIDE == 1 && !GNP && p.k_wrap == 2;  // (glare_conv2d_bf16 rejects k_wrap = 2 anywhere else)
+  const bool reuse = KS == 3 && !GNP && p.k_wrap == 2;                 // (glare_conv2d_bf16 rejects k_wrap = 2 anywhere else)
   const int n_pair = reuse ? 2 * (p.Cin0 / KC) : 0;                    // stages of the paired (x_hi) part
   auto a_is_new = [&](int stage) { return !(reuse && stage < n_pair && (stage & 1)); };
   auto issue_a = [&](int chunk, int buf, int i_lo = 0, int i_hi = 1 << 20) {   // pieces [i_lo, i_hi) of this wave; chunk = K stage

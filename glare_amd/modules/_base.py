@@ -25,7 +25,7 @@ class HipModule(nn.Module):
         return super()._apply(fn, *a, **k)
 
 
-def packed_conv(mod, conv, key=None, scale=None, split=0, stride=1):
+def packed_conv(mod, conv, key=None, scale=None, split=0):
     """PackedConv of an nn.Conv2d owned by `mod` (optionally scaling weight and bias first; split: the fp32-class form of
     ops.PackedConv -- K segments [w_hi | w_hi | w_lo] for an activation hi / lo pair)."""
     key = key or ("conv", id(conv), split)
@@ -35,7 +35,7 @@ def packed_conv(mod, conv, key=None, scale=None, split=0, stride=1):
         if scale is not None:
             w = w * scale
             b = None if b is None else b * scale
-        return ops.PackedConv(w, b, split=split, stride=stride)
+        return ops.PackedConv(w, b, split=split)
 
     return mod._packed(key, build)
 

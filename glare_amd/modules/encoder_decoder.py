@@ -120,7 +120,7 @@ class Downsample(HipModule):
         self.conv = nn.Conv2d(in_channels, in_channels, 3, 2, 0)
 
     def forward_nhwc(self, x, split=0):
-        return ops.conv2d(x, packed_conv(self, self.conv, split=split, stride=2), stride=2,  # pad (0,1,0,1) fused in the loader
+        return ops.conv2d(x, packed_conv(self, self.conv, split=split), stride=2,  # pad (0,1,0,1) fused in the loader
                           gn_stats=GN_FUSED and self.conv.out_channels % 128 == 0, hilo=is_hilo(x))
 
     def train_nhwc(self, x):

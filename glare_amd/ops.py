@@ -78,7 +78,7 @@ def split_filter(w, split, reuse_kc=0):
 class PackedConv:
     """A conv filter packed once for the MFMA kernel (weights bf16 stage-ordered, bias fp32)."""
 
-    def __init__(self, weight_oihw, bias=None, dgrad_pad=None, upsample_subpixel=False, cout_tile=0, split=0, stride=1):
+    def __init__(self, weight_oihw, bias=None, dgrad_pad=None, upsample_subpixel=False, cout_tile=0, split=0):
         """dgrad_pad = P: pack the filter of the data-gradient conv (P >= cout input channels, cin outputs) instead.
         cout_tile: 0 = the default output-channel tile for this cout, or 64 / 32 for launches too small to fill the chip with it
         (conv_cout_tile(); the packed image is tile-specific and conv2d passes the tile on).
@@ -90,7 +90,7 @@ class PackedConv:
         self.k_wrap = 1 if split else 0
         if split:       # the fp32-class form: conv2d() reads the activation's hi / lo pair against [w_hi | w_hi | w_lo]
             assert dgrad_pad is None and not upsample_subpixel and not cout_tile
-            if split == 3 and SPLIT_A_REUSE and stride == 1 and w.shape[-1] == 3 and w.shape[1] % 16 == 0:
+            if split == 3 and SPLIT_A_REUSE and w.shape[-1] == 3 and w.shape[1] % 16 == 0:
                 self.k_wrap = 2
                 w = split_filter(w, split, reuse_kc=16)
             else:
@@ -545,7 +545,7 @@ def conv2d(x, pc, *, x2=None, cin=None, in_off=0, cin2=None, in2_off=0, stride=1
     if split:      # fp32-class: K segments [x_hi | x_lo | x_hi] against the filter packed as [w_hi | w_hi | w_lo] (k_wrap)
         assert x2 is None and not upsample and cin == pc.cin, (cin, pc.cin)
         d.k_wrap = getattr(pc, "k_wrap", 1) or 1
-        assert d.k_wrap != 2 or (stride == 1 and gn_prologue is None), "this filter was packed for the stride-1 K order: PackedConv(..., stride=2)"
+        assert d.k_wrap != 2 or gn_prologue is None
         if split == 3:
             x2 = getattr(x, "_lo", None)
             assert x2 is not None and x2.shape == x.shape, "a split-3 filter contracts the activation's hi / lo pair: x._lo is missing"

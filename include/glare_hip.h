@@ -125,7 +125,7 @@ typedef struct glare_conv_desc {
    * launch computes exactly that sum; with in2 = NULL it is x_hi . (w_hi + w_lo) on a filter packed as [w_hi | w_lo] (2 Cin).
    * k_wrap == 2 (round 5; needs in2): the same three products with every halo tile of `in` staged ONCE -- stages 2c and 2c + 1 contract
    * chunk c of `in` (one stage = 16 channels for 3x3) with the 2c-th and (2c + 1)-th chunk of the packed filter, the `in2` segment
-   * follows: weight_packed = the pack of [w_hi(c0) | w_lo(c0) | w_hi(c1) | w_lo(c1) | ... | w_hi] (3 Cin).  3x3, stride 1, Cin % 16 == 0,
+   * follows: weight_packed = the pack of [w_hi(c0) | w_lo(c0) | w_hi(c1) | w_lo(c1) | ... | w_hi] (3 Cin).  3x3 (either stride), Cin % 16 == 0,
    * Cin2 == Cin, no upsample / gn_coef (GLARE_ERR_UNSUPPORTED / GLARE_ERR_INVALID otherwise); any other k_wrap value is GLARE_ERR_INVALID.
    * The packed filter's input-channel count must be Cin + Cin2 + Cin; Cin (and Cin2) multiples of the kernel's 16-channel (3x3) /
    * 32-channel (1x1) stage.  Grouped launches shift both sources by group_in_step.  Where the reference contracts in fp32 and the

@@ -45,7 +45,7 @@ CASES = [  # B, Cin, Cout, H, W, k, stride
 @pytest.mark.parametrize("prec", ["fp16", "bf16"])
 @pytest.mark.parametrize("B,Cin,Cout,H,W,k,stride", CASES)
 def test_split3_conv_matches_the_fp32_conv(monkeypatch, prec, B, Cin, Cout, H, W, k, stride, reuse):
-    """reuse: the K order k_wrap = 2 (every x_hi halo tile staged once for w_hi and w_lo: 3x3 stride 1, the default) against round 4's
+    """reuse: the K order k_wrap = 2 (every x_hi halo tile staged once for w_hi and w_lo: the 3x3 convs, the default) against round 4's
     segment order k_wrap = 1 -- the same three products in another accumulation order, the same bound."""
     monkeypatch.setattr(ops, "SPLIT_A_REUSE", reuse)
     g = torch.Generator().manual_seed(B * 1000 + Cin + Cout + H + k)
@@ -58,8 +58,8 @@ def test_split3_conv_matches_the_fp32_conv(monkeypatch, prec, B, Cin, Cout, H, W
         ref = F.conv2d(x.cuda(), w.cuda(), b.cuda(), 1, k // 2)
     with ops.use_precision(prec):
         xp = _pair(x)
-        pc = ops.PackedConv(w.cuda(), b.cuda(), split=3, stride=stride)
-        assert pc.k_wrap == (2 if reuse and k == 3 and stride == 1 and Cin % 16 == 0 else 1)
+        pc = ops.PackedConv(w.cuda(), b.cuda(), split=3)
+        assert pc.k_wrap == (2 if reuse and k == 3 and Cin % 16 == 0 else 1)
         out = ops.conv2d(xp, pc, stride=stride, out_mode=ops.OUT_NHWC_F32)
         plain = ops.conv2d(xp, ops.PackedConv(w.cuda(), b.cuda()), stride=stride, out_mode=ops.OUT_NHWC_F32)
     e3, e1 = _err(out, ref), _err(plain, ref)
@@ -87,7 +87,7 @@ def test_split3_hilo_output_residual_and_statistics():
 
 
 def test_tile_reuse_order_error_behaviour_and_agreement_with_the_segment_order(monkeypatch):
-    """glare_conv_desc.k_wrap = 2 (include/glare_hip.h): 3x3 stride 1 only, needs the lo half with the hi half's channel count; any
+    """glare_conv_desc.k_wrap = 2 (include/glare_hip.h): 3x3 only, needs the lo half with the hi half's channel count; any
     other value is invalid.  Against k_wrap = 1 on the same operands (pair in, pair residual, pair out, statistics) the result differs
     by accumulation order only."""
     from glare_amd import _lib
@@ -98,8 +98,6 @@ def test_tile_reuse_order_error_behaviour_and_agreement_with_the_segment_order(m
         xp = _pair(x)
         pc = ops.PackedConv(w3.cuda(), None, split=3)
         assert pc.k_wrap == 2
-        with pytest.raises(AssertionError):          # host side: a filter packed for the stride-1 order
-            ops.conv2d(xp, pc, stride=2)
         out = torch.empty(1, 9, 33, 32, dtype=torch.float16, device="cuda")
         d = ops.ConvDesc()
         d.in_, d.B, d.H, d.W, d.Cin, d.in_pitch = xp.data_ptr(), 1, 9, 33, 64, 64
@@ -108,11 +106,11 @@ def test_tile_reuse_order_error_behaviour_and_agreement_with_the_segment_order(m
         d.weight_packed, d.ksize, d.stride, d.out_mode = pc.packed.data_ptr(), 3, 1, ops.OUT_NHWC_BF16
         lib = _lib.lib()
         import ctypes
-        for k_wrap, stride, in2, cin2, want in ((2, 1, True, 64, 0), (2, 2, True, 64, _lib.ERR_UNSUPPORTED), (3, 1, True, 64, _lib.ERR_INVALID),
-                                                (-1, 1, True, 64, _lib.ERR_INVALID), (2, 1, False, 0, _lib.ERR_INVALID), (2, 1, True, 48, _lib.ERR_INVALID)):
-            d.k_wrap, d.stride = k_wrap, stride
+        for k_wrap, ksize, in2, cin2, want in ((2, 3, True, 64, 0), (2, 1, True, 64, _lib.ERR_UNSUPPORTED), (3, 3, True, 64, _lib.ERR_INVALID),
+                                               (-1, 3, True, 64, _lib.ERR_INVALID), (2, 3, False, 0, _lib.ERR_INVALID), (2, 3, True, 48, _lib.ERR_INVALID)):
+            d.k_wrap, d.ksize = k_wrap, ksize
             d.in2, d.Cin2 = (xp._lo.data_ptr() if in2 else None), cin2
-            assert lib.glare_conv2d_bf16(ctypes.byref(d), ops.stream_handle()) == want, (k_wrap, stride, in2, cin2)
+            assert lib.glare_conv2d_bf16(ctypes.byref(d), ops.stream_handle()) == want, (k_wrap, ksize, in2, cin2)
         torch.cuda.synchronize()
     x = torch.randn((2, 128, 12, 40), generator=g)
     r = torch.randn((2, 128, 12, 40), generator=g)
