@@ -41,6 +41,9 @@ bash tools/pmc_shapes.sh $tag > /dev/null 2>&1          # per-SHAPE traffic of t
   echo; echo "# held-out scenes and a second trained-like weight set"
   python tools/parity_scenes.py 400 600 101 102 103 104 105 106 107 108 109 110 111 112 2>&1 | grep -v "Warn\|amdgpu.ids"
   PARITY_WEIGHT_SEED=1 python tools/parity_scenes.py 400 600 11 12 13 101 102 103 2>&1 | grep -v "Warn\|amdgpu.ids"
+  echo; echo "# a THIRD trained-like weight set (PARITY_WEIGHT_SEED=2: another codebook, ActNorm states and filters), 6 scenes, and 6 more held-out scenes of the first (42 full-size scenes on the default path in all)"
+  PARITY_WEIGHT_SEED=2 python tools/parity_scenes.py 400 600 11 12 13 101 102 103 2>&1 | grep -v "Warn\|amdgpu.ids"
+  python tools/parity_scenes.py 400 600 201 202 203 204 205 206 2>&1 | grep -v "Warn\|amdgpu.ids"
 } > gpurun_out/${tag}_parity_table.txt 2>&1
 for st in stage2 stage3; do
   python tools/train_bench.py $st 20 graph > gpurun_out/${tag}_train_${st}_graph.txt 2>&1
