@@ -336,7 +336,8 @@ def family_rooflines(events, steps):
                     "bound": "mfma", "binds": "the texture path: weight-fragment and corner lane-loads (TA busy 65 % / 47 % at C = 128 / 256 with four waves along Co and the filter fragments as contiguous planes, 79 % in round 4: profiles/r05_pmc_dcn_ta.txt; DESIGN.md section 3)", "achieved": round(tfl, 1),
                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tfl / PEAK_BF16_TFLOPS, 4),
                     "hbm_gbs_algorithmic": round(tbs * 1e3, 1), "hbm_frac": round(tbs / PEAK_HBM_TBS, 4),
-                    "ms_per_launch": round(ms, 3), "launches_timed": len(ts), "traffic": traffic.get(key), "traffic_source": tsrc if key in traffic else None,
+                    "ms_per_launch": round(ms, 3), "ms_per_launch_median": round(sorted(ts)[len(ts) // 2], 3), "ms_per_launch_max": round(max(ts), 3),
+                    "launches_timed": len(ts), "traffic": traffic.get(key), "traffic_source": tsrc if key in traffic else None,
                     "timing": "HIP event pairs around every launch inside the timed region"})
     return out
 
