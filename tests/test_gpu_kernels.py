@@ -47,6 +47,30 @@ def test_smallcin_conv_nchw_and_nhwc_inputs():
         assert torch.allclose(out2.float().permute(0, 3, 1, 2), ref, rtol=2 ** -7, atol=2e-3)
 
 
+def test_smallcin_lds_staged_kernel_gives_the_bits_of_the_generic_one():
+    """conv_small3_kernel (Cin = 3, 3x3, Cout a multiple of 64 ... 512: input patches through LDS) keeps the generic kernel's FMA order.
+    The generic kernel is reached with a FOURTH input channel whose filter is zero -- fma(v, 0, acc) = acc, so it must return the same bits;
+    ragged widths (W % 4 != 0), quads that wrap from one image row into the next, more iterations than blocks, pair and fp32 outputs."""
+    g = torch.Generator().manual_seed(31)
+    for (B, H, W), cout, act in (((2, 19, 23), 128, "none"), ((1, 7, 33), 64, "sigmoid"), ((3, 70, 301), 128, "none"), ((1, 33, 40), 512, "none")):
+        x3 = torch.randn(B, 3, H, W, generator=g).cuda()
+        x4 = torch.cat([x3, torch.randn(B, 1, H, W, generator=g).cuda()], 1).contiguous()
+        w3 = (torch.randn(cout, 3, 3, 3, generator=g) * 0.2).cuda()
+        w4 = torch.cat([w3, torch.zeros(cout, 1, 3, 3, device="cuda")], 1).contiguous()
+        b = (torch.randn(cout, generator=g) * 0.1).cuda()
+        for kw in (dict(out_f32=True), dict(), dict(hilo=True)):
+            if kw.get("hilo") and act != "none":
+                continue
+            with ops.use_precision("fp16"):
+                a = ops.conv2d_smallcin(x3, (3 * H * W, H * W, W, 1), (B, H, W), w3, b, act=act, **kw)
+                # (the generic kernel holds at most 64 KB of filter in LDS: 4 x 9 x 256 output channels at a time)
+                cs = [ops.conv2d_smallcin(x4, (4 * H * W, H * W, W, 1), (B, H, W), w4[o:o + 256], b[o:o + 256], act=act, **kw)
+                      for o in range(0, cout, 256)]
+            assert torch.equal(a, torch.cat(cs, 3)), (B, H, W, cout, kw)
+            if kw.get("hilo"):
+                assert torch.equal(a._lo, torch.cat([c._lo for c in cs], 3))
+
+
 def test_mix_rescale_layout():
     g = torch.Generator().manual_seed(4)
     a = _bf(torch.randn(2, 6, 10, 128, generator=g)).cuda()
