@@ -15,6 +15,8 @@ MI355X design of the reverse (sampling) pass, decode():
     a fp64 inverse and an slogdet per step per call);
   * per coupling step: flow_h1 -> 1x1 MFMA conv -> 3x3 MFMA conv -> flow_tail; z stays fp32.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -22,6 +24,11 @@ from .. import _lib, ops
 from .. import train_ops as T
 from ._base import HipModule, to_nchw, to_nhwc
 from .flow import ActNorm2d, Conv2d, Conv2dZeros, InvertibleConv1x1
+
+
+# Round 6: a coupling step of the reverse pass is ONE launch (csrc/flow_fused.hip; the step's two MFMA convs, flow_h1 and flow_tail
+# fused per pixel tile, fp32-class arithmetic in every precision).  GLARE_FLOW_FUSED=0 keeps rounds 1-5's four launches per step.
+FUSED_STEP = os.environ.get("GLARE_FLOW_FUSED", "1") == "1"
 
 
 def _opt_get(opt, keys, default=None):
@@ -128,8 +135,10 @@ class FlowUpsamplerNet(HipModule):
             wa_ft.append(w0[:, 1:])
             ba_ft.append(b0)
             st["wz"] = w0[:, 0].reshape(64, 9).float().contiguous()
-            st["c2"] = ops.PackedConv(*aff.fAffine[2].folded(), split=split)
+            st["c2"] = ops.PackedConv(*aff.fAffine[2].folded(), split=split)      # the four-launch form and encode_nhwc
             st["c4"] = ops.PackedConv(*aff.fAffine[4].folded(), split=split)
+            if FUSED_STEP:     # the whole step as one launch: the filters as the fused kernel's fragment image (csrc/flow_fused.hip)
+                st["image"] = ops.flow_fused_image(st["wz"], *aff.fAffine[2].folded(), *aff.fAffine[4].folded())
             f0w, f0b = aff.fFeatures[0].folded()
             wf0.append(f0w)
             bf0.append(f0b)
@@ -160,12 +169,17 @@ class FlowUpsamplerNet(HipModule):
         # z-independent, batched up front: the n second layers, then the n third layers, one grouped launch each
         ops.conv2d_grouped(h1f, P["f2"], cin=64, in_step=64, out=h2f, out_step=64, act="relu", out_lo=torch.empty_like(h2f) if pair else None)
         ops.conv2d_grouped(h2f, P["f4"], cin=64, in_step=64, out=hF, out_step=8, out_mode=ops.OUT_NHWC_F32)
+        if FUSED_STEP:                                                             # the sequential part: one launch per step
+            zs = [z, torch.empty_like(z)]
+            for s, st in enumerate(P["steps"]):
+                ops.flow_step_fused(zs[s & 1], zs[(s + 1) & 1], ftA, 64 * s, st["image"], hF, 8 * s, st["M"], st["t"], st["eps"])
+            return zs[n & 1]
         h1 = torch.empty(B, H, W, 64, dtype=ops.act_dtype(), device=z.device)
         h2 = torch.empty_like(h1)
         if pair:
             h1._lo, h2._lo = torch.empty_like(h1), torch.empty_like(h2)
         h4 = torch.empty(B, H, W, 4, dtype=torch.float32, device=z.device)
-        for s, st in enumerate(P["steps"]):                                        # the sequential part
+        for s, st in enumerate(P["steps"]):                                        # the sequential part (rounds 1-5: four launches per step)
             ops.flow_h1(z, ftA, 64 * s, st["wz"], out=h1)
             ops.conv2d(h1, st["c2"], act="relu", out=h2, hilo=pair)
             ops.conv2d(h2, st["c4"], out=h4, out_mode=ops.OUT_NHWC_F32)

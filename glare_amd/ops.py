@@ -837,6 +837,60 @@ def flow_tail(z, h4, hF, hF_off, M, t, eps=1e-4):
     return z
 
 
+def flow_fused_image(wz, w2, b2, w4, b4):
+    """The filters of one coupling step as the fragment image of csrc/flow_fused.hip (fp32-class: every filter a hi / lo pair of
+    16-bit values in the current precision).  wz fp32 [64, 9] (fAffine[0]'s z1 column, tap = 3 ky + kx), w2 [64, 64(,1,1)], b2 [64],
+    w4 [4, 64, 3, 3], b4 [4] -- all with ActNorm / Conv2dZeros already folded (flow.Conv2d.folded()).
+    An A fragment is [half h][row m][8]; the kernel contracts k-step (j, u), half h, element i against channel
+    32 j + 16 u + 8 (i >> 2) + 4 h + (i & 3) -- the order in which a lane's accumulator registers of the PREVIOUS product hold its
+    pixel's channels -- and the 9-tap conv of z0 against tap 8 h + i.  The 3x3 conv 64 -> 4 is packed as 36 rows (tap * 4 + cout)."""
+    require_cuda(wz, w2, b2, w4, b4)
+    dev = wz.device
+    dt = act_dtype()
+    ks = torch.arange(4, device=dev).view(4, 1, 1)
+    h = torch.arange(2, device=dev).view(1, 2, 1)
+    i = torch.arange(8, device=dev).view(1, 1, 8)
+    cidx = (32 * (ks // 2) + 16 * (ks % 2) + 8 * (i // 4) + 4 * h + (i % 4)).reshape(-1)        # [ks, h, i]
+
+    def frags(Wm):            # fp32 [64, 64] -> [jt, ks, h, m, i]
+        return Wm.reshape(2, 32, 64)[:, :, cidx].reshape(2, 32, 4, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
+
+    def pair(x):
+        hi = x.to(dt)
+        return hi, (x - hi.float()).to(dt)
+
+    wzp = torch.zeros(64, 16, dtype=torch.float32, device=dev)
+    wzp[:, :9] = wz.detach().float().reshape(64, 9)
+    wzf = wzp.reshape(2, 32, 2, 8).permute(0, 2, 1, 3).contiguous()                              # [jt, h, m, i], tap = 8 h + i
+    w4r = torch.zeros(64, 64, dtype=torch.float32, device=dev)
+    w4r[:36] = w4.detach().float().permute(2, 3, 0, 1).reshape(36, 64)                           # row = tap * 4 + cout
+    r = torch.arange(16, device=dev).view(1, 1, 16)
+    bidx = (32 * torch.arange(2, device=dev).view(2, 1, 1) + 8 * (r // 4) + 4 * torch.arange(2, device=dev).view(1, 2, 1) + (r % 4)).reshape(-1)
+    parts = []
+    for t in (wzf, frags(w2.detach().float().reshape(64, 64)), frags(w4r)):
+        parts += [p.reshape(-1).view(torch.uint8) for p in pair(t)]
+    parts.append(b2.detach().float()[bidx].contiguous().view(torch.uint8))
+    parts.append(b4.detach().float().contiguous().view(torch.uint8))
+    img = torch.cat(parts)
+    lib = _lib.lib()
+    lib.glare_flow_step_fused_image_bytes.restype = _ll
+    assert img.numel() == lib.glare_flow_step_fused_image_bytes(), img.numel()
+    return img
+
+
+def flow_step_fused(z_in, z_out, ftA, ftA_off, image, hF, hF_off, M, t, eps=1e-4):
+    """One reverse coupling step in one launch (csrc/flow_fused.hip): z_in -> z_out, fp32 [B,H,W,3], different buffers."""
+    require_cuda(z_in, z_out, ftA, image, hF)
+    assert z_in.data_ptr() != z_out.data_ptr() and z_in.dtype == z_out.dtype == ftA.dtype == hF.dtype == torch.float32
+    B, H, W, _ = z_in.shape
+    Ma = (ctypes.c_float * 9)(*[float(v) for v in M])
+    ta = (ctypes.c_float * 3)(*[float(v) for v in t])
+    check(_lib.lib().glare_flow_step_fused_bf16(ptr(z_in), ptr(z_out), ptr(ftA), _i(ftA.shape[3]), _i(ftA_off), ptr(image), ptr(hF),
+                                                _i(hF.shape[3]), _i(hF_off), _i(B), _i(H), _i(W), Ma, ta, _f(eps), stream_handle()),
+          "glare_flow_step_fused_bf16")
+    return z_out
+
+
 # ---- attention ------------------------------------------------------------------------------------
 def attention_key_splits(B, N):
     """Workgroups = B * ceil(N/128) query blocks; below two full rounds of the 256 CUs the keys are split to fill the chip."""

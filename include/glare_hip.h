@@ -277,6 +277,19 @@ int glare_flow_h1_pair_f32(const float* z_nhwc3, const float* ftA, int ftA_pitch
 int glare_flow_tail_f32(float* z_nhwc3, const float* h4, const float* hF, int hF_pitch, int hF_off,
                         long long n_pixels, const float* M_3x3_host, const float* t_3_host, float eps,
                         glare_stream_t stream);
+/* The whole coupling step as ONE launch (round 6; csrc/flow_fused.hip): the three launches above and the two convs between them
+ * (FlowAffineCouplingsAblation.py:143-151: 3x3 65 -> 64, ReLU, 1x1 64 -> 64, ReLU, Conv2dZeros 3x3 64 -> 4) fused per 8 x 32
+ * pixel tile with the halo recomputed, every contraction in the fp32-class form (hi / lo operand pairs, three MFMA products),
+ * h1 / h2 chained through registers.  z_in -> z_out, both fp32 [B*H*W][3], must be DIFFERENT buffers (a tile reads the
+ * neighbouring tiles' z_in channel 0).  `image`: the step's filters as the kernel's fragment image, 16-B aligned,
+ * glare_flow_step_fused_image_bytes() bytes, laid out as glare_amd.ops.flow_fused_image documents:
+ *   [wz hi | wz lo] 2 x 2 KB, [W2 hi | W2 lo] 2 x 8 KB, [W4 hi | W4 lo] 2 x 8 KB of A fragments ([half][row][8] 16-bit each),
+ *   then fp32 b2 in accumulator order [tile][half][16] and fp32 b4[4].
+ * ftA / hF / M / t / eps as in glare_flow_h1_f32 / glare_flow_tail_f32. */
+long long glare_flow_step_fused_image_bytes(void);
+int glare_flow_step_fused_bf16(const float* z_in, float* z_out, const float* ftA, int ftA_pitch, int ftA_off, const void* image,
+                               const float* hF, int hF_pitch, int hF_off, int B, int H, int W, const float* M_3x3_host,
+                               const float* t_3_host, float eps, glare_stream_t stream);
 
 /* ---- ActNorm data-dependent initialisation (a12: the first training forward of a fresh flow) ----------------------------
  * Replaces _ActNorm.initialize_parameters (FlowActNorms.py:32-46), reached from _ActNorm.forward (:82-83) for the 28 step

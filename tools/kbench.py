@@ -293,6 +293,33 @@ def bench_conv1x1():
                   % (name, t[False][0], t[True][0], t[False][1], t[True][1], t[False][2], t[True][2], t[False][3], t[True][3]))
 
 
+def bench_flow():
+    """The flow's reverse pass at the path's latent size (8 x 105 x 155): round 6's fused step (one launch) against rounds 1-5's
+    four launches per step, fp32-class (pair cond_feat) in fp16."""
+    from glare_amd import modules as M
+    import importlib
+    FU = importlib.import_module("glare_amd.modules.FlowUpsamplerNet")
+    from glare_amd.synthetic import seeded_init_
+    net = seeded_init_(M.VQLLFLOWDeformable().eval(), 0).to(DEV).flowUpsamplerNet
+    with ops.use_precision("fp16"), torch.no_grad():
+        z = torch.randn(B, 105, 155, 3, device=DEV) * 0.7
+        ft = ops.split_hilo(torch.sigmoid(torch.randn(B, 105, 155, 64, device=DEV)))
+        for fused in (True, False, True, False):
+            FU.FUSED_STEP = fused
+            net.invalidate()
+            ms = timeit(lambda: net.decode_nhwc(z, ft))
+            print("flow decode B=%d 105x155 (24 coupling steps + the batched z-independent convs), %s: %.3f ms" % (B, "fused step" if fused else "four launches per step", ms))
+        FU.FUSED_STEP = True
+        net.invalidate()
+        P = net._packed(("flow", 3), lambda: net._prepare(3))
+        ftA = torch.randn(B, 105, 155, 64 * P["n"], device=DEV)
+        hF = torch.randn(B, 105, 155, 8 * P["n"], device=DEV)
+        z2 = torch.empty_like(z)
+        st = P["steps"][0]
+        ms = timeit(lambda: ops.flow_step_fused(z, z2, ftA, 0, st["image"], hF, 0, st["M"], st["t"], st["eps"]), reps=20)
+        print("flow_step_fused alone: %.4f ms per step" % ms)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["attn", "conv", "gn", "dcn", "vq", "wgrad", "attnbwd"]
     for w in which:
