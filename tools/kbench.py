@@ -35,6 +35,24 @@ def timeit(fn, reps=REPS, warm=2, warm_s=0.3):
     return s.elapsed_time(e) / reps
 
 
+def timeit_queued(fn, reps=50):
+    """GPU time of `fn` when the host is AHEAD of the device (as inside the pipeline): a ~4 ms attention launch goes first, the `reps`
+    launches queue up behind it, and the events bracket only them -- python / ctypes call overhead (10-20 us) is off the clock."""
+    N, C = 105 * 155, 512
+    q = torch.zeros(8, N, C, dtype=ops.act_dtype(), device=DEV)
+    out = torch.empty_like(q)
+    fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ops.attention_kv512(q, q, N, out=out, key_splits=1)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps
+
+
 def bench_attn():
     N, C = 105 * 155, 512
     qk = (torch.randn(B, N, 2 * C, device=DEV) * 0.3).to(torch.bfloat16)
@@ -317,7 +335,13 @@ def bench_flow():
         z2 = torch.empty_like(z)
         st = P["steps"][0]
         ms = timeit(lambda: ops.flow_step_fused(z, z2, ftA, 0, st["image"], hF, 0, st["M"], st["t"], st["eps"]), reps=20)
-        print("flow_step_fused alone: %.4f ms per step" % ms)
+        msq = timeit_queued(lambda: ops.flow_step_fused(z, z2, ftA, 0, st["image"], hF, 0, st["M"], st["t"], st["eps"]), reps=100)
+        print("flow_step_fused alone: %.4f ms per step host-paced, %.4f ms queued behind a long launch (device time)" % (ms, msq))
+        for fused in (True, False):
+            FU.FUSED_STEP = fused
+            net.invalidate()
+            print("flow decode queued, %s: %.3f ms" % ("fused step" if fused else "four launches per step", timeit_queued(lambda: net.decode_nhwc(z, ft), reps=3)))
+        FU.FUSED_STEP = True
 
 
 if __name__ == "__main__":
