@@ -41,6 +41,9 @@ H_IMG, W_IMG, PAD = 400, 600, 20
 # pipeline replaced by tensor stand-ins, so that the first real N > 1 run is not the first execution of that code.  The line it
 # prints says "stub": true and is never a measurement.
 STUB = os.environ.get("GLARE_BENCH_STUB") == "1"
+# where the roofline's event pairs were taken (set by main(): the timed region itself when it runs on one stream, else the single-stream
+# region of the same K steps right behind it)
+EVENT_REGION = "the timed region"
 
 
 def device_sync():
@@ -153,7 +156,7 @@ def attention_roofline(device, batch, live_events, reps=5):
             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
             "traffic_unit": "HBM bytes per launch", "traffic_source": source, "algorithmic_bytes": int(3 * 2 * batch * N * C),
             "ms_per_launch": round(ms, 3), "launches_timed": len(live),
-            "timing": "HIP event pairs around every launch inside the timed region" if live else "isolated launches (no live events)",
+            "timing": ("HIP event pairs around every launch inside %s" % EVENT_REGION) if live else "isolated launches (no live events)",
             "isolated_ms_per_launch": round(isolated_ms, 3), "launch_shape": {"B": batch, "N": N, "d": C},
             "binds": "the socket's power budget, not the schedule: see `power` (this launch on all-zero operands runs ~30 % faster at the "
                      "full clock; DESIGN.md section 3, 'the power wall')",
@@ -307,7 +310,7 @@ def family_rooflines(events, steps):
         row = {"kernel": label, "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "launches_timed": len(conv), "launches_per_step": len(conv) // max(steps, 1),
                "ms_per_step": round(ms / max(steps, 1), 3), "algorithmic_tflop_per_step": round(fl / max(steps, 1) / 1e12, 3),
-               "timing": "HIP event pairs around every launch inside the timed region"}
+               "timing": "HIP event pairs around every launch inside %s" % EVENT_REGION}
         # against what a register-only MFMA loop sustains on random fp16 operands on this chip (see `roofline.sustained_source`)
         row["frac_of_sustained"] = round((3 if fam == "conv3x3_split" else 1) * ach / SUSTAINED_MFMA_F16_RANDOM_TFLOPS, 4)
         if fam == "conv3x3_split":
@@ -338,7 +341,7 @@ def family_rooflines(events, steps):
                     "hbm_gbs_algorithmic": round(tbs * 1e3, 1), "hbm_frac": round(tbs / PEAK_HBM_TBS, 4),
                     "ms_per_launch": round(ms, 3), "ms_per_launch_median": round(sorted(ts)[len(ts) // 2], 3), "ms_per_launch_max": round(max(ts), 3),
                     "launches_timed": len(ts), "traffic": traffic.get(key), "traffic_source": tsrc if key in traffic else None,
-                    "timing": "HIP event pairs around every launch inside the timed region"})
+                    "timing": "HIP event pairs around every launch inside %s" % EVENT_REGION})
     return out
 
 
@@ -460,19 +463,20 @@ def main():
     ap.add_argument("--global-batch", type=int, default=None,
                     help="BASELINE configs[2] as written: the GLOBAL batch, split evenly over the ranks (`--gpus 8 --global-batch 32` = 4 images "
                          "per GPU, strong scaling).  Default: unset = `--batch` images per GPU at every N (weak scaling, configs[1] per rank)")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="HIP streams the steps are issued on round-robin.  1 (default): steps run back to back and the "
-                         "roofline's per-launch event timing is the kernel's own duration.  2: consecutive batches overlap (the "
-                         "tail of one step's kernels and its latency-bound flow section run under the next step's convs): +3 %% "
-                         "throughput, but a launch then shares the GPU and its event-timed duration is no longer a kernel figure")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams the K timed steps are issued on round-robin.  2 (default since round 6): consecutive batches overlap -- "
+                         "the tail round of one step's full-resolution convs (8 480 tiles on 768 slots) and its latency-bound flow section run "
+                         "under the next step's kernels (+1.7-3 %% images/s; what glare_amd.infer does); a launch that shares the GPU has no "
+                         "per-launch duration, so the roofline is event-timed in a SINGLE-STREAM region of the same K steps right behind the "
+                         "timed one (`value_single_stream`).  1: the steps back to back on one stream (rounds 1-5's headline)")
     ap.add_argument("--precision", choices=("bf16", "fp16"), default="fp16",
                     help="16-bit format of activations and filters: fp16 (default: IEEE half, the reference's own autocast dtype and "
                          "the precision the end-to-end tolerance is met in; libglare_hip_f16.so) or bf16 (libglare_hip.so, +2.7 %% "
                          "images/s, 8x the rounding per stored tensor).  The JSON line's `dtype` names what ran")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-power", action="store_true", help="skip the clock / power annotation (`power`: 5 s after the timed region)")
-    ap.add_argument("--no-streams2", action="store_true", help="skip the extra two-stream region behind the timed one (`value_streams2`): "
-                                                               "what a rocprofv3 kernel trace of this command should see is single-stream launches only")
+    ap.add_argument("--no-single-stream", "--no-streams2", dest="no_single_stream", action="store_true",
+                    help="with --streams > 1: skip the single-stream region behind the timed one (the roofline then comes from isolated launches)")
     ap.add_argument("--no-train", action="store_true", help="skip the `train` block (stage-2 / stage-3 ms per step, measured after "
                                                             "the inference region)")
     ap.add_argument("--train-timeout", type=int, default=600, help="seconds after which a train block that has not returned is "
@@ -524,7 +528,7 @@ def main():
 
     streams = [torch.cuda.Stream(device) for _ in range(args.streams)] if (args.streams > 1 and not STUB) else None
 
-    gatherer = None
+    gatherers = None
     if world > 1:
         # BASELINE configs[2] ("data-parallel across 8 MI355X, RCCL gather only"): every step each rank crops / clamps its
         # enhanced batch on the device (harness.hip) and the [B,400,600,3] results are gathered to rank 0 over RCCL --
@@ -532,9 +536,11 @@ def main():
         from glare_amd import harness, parallel
 
         shape = (args.batch, 8, 12, 3) if STUB else (args.batch, H_IMG, W_IMG, 3)
-        gatherer = parallel.RankGather(torch.empty(shape, dtype=torch.uint8, device=device), rank, world)
+        # one set of receive buffers per stream: two steps in flight never gather into the same memory
+        gatherers = [parallel.RankGather(torch.empty(shape, dtype=torch.uint8, device=device), rank, world) for _ in range(max(1, args.streams))]
 
-    def enhance():
+    def enhance(slot=0):
+        gatherer = gatherers[slot] if gatherers is not None else None
         if STUB:
             out = lr * 2.0                                          # stands in for the HIP pipeline
             if gatherer is not None:
@@ -552,13 +558,17 @@ def main():
         if streams is None:
             return enhance()
         with torch.cuda.stream(streams[i % len(streams)]):   # every op launches on torch's current stream
-            return enhance()
+            return enhance(i % len(streams))
+
+    def step_single(i=0):                                     # the same step on the default stream (roofline region, power probe)
+        return enhance()
 
     with torch.no_grad():
         out = step()                                          # weights are packed once, on first use
         device_sync()
         timed_steps(step, 0, args.warmup, dist)               # the W untimed warm-up steps (+ barrier)
-        if rank == 0 and not STUB:
+        single = streams is None
+        if rank == 0 and not STUB and single:
             ops.ATTENTION_LAUNCH_EVENTS = []     # roofline: the dominant kernel's launches are timed where they run
             ops.LAUNCH_EVENTS = {"conv3x3": [], "conv3x3_split": [], "dcn": []}     # ... and the next families (`rooflines`)
         dt, out = timed_steps(step, args.steps, 0, dist)      # EXACTLY K steps between barrier + synchronize
@@ -567,20 +577,22 @@ def main():
     assert bool(torch.isfinite(out).all())
     dt = max_over_ranks(dt, dist, device)
 
-    value_streams2 = None
-    if world == 1 and args.streams == 1 and not STUB and not args.no_streams2:
-        # the same K steps once more with consecutive batches on TWO HIP streams (what glare_amd.infer does): the tail of one batch's
-        # kernels and its latency-bound flow section run under the next batch's convs.  Reported beside `value`, never as `value`:
-        # a launch that shares the GPU has no per-launch duration for the roofline, which is measured in the single-stream region.
-        pool = [torch.cuda.Stream(device) for _ in range(2)]
-
-        def step2(i=0):
-            with torch.cuda.stream(pool[i % 2]):
-                return enhance()
-
+    value_single_stream = None
+    if not single and rank == 0 and not STUB and not args.no_single_stream:
+        # The same K steps once more on ONE stream, rank 0 only, no collective (at N > 1 the other ranks wait at the next barrier): a
+        # launch that shares the GPU with the other stream's kernels has no duration of its own, so the roofline's event pairs are taken
+        # here -- same pipeline, same data, launches back to back.  Reported beside `value` (`value_single_stream`: rounds 1-5's headline).
+        global EVENT_REGION
+        EVENT_REGION = "the single-stream region (the same K steps, one stream) right behind the two-stream timed region"
+        keep, gatherers = gatherers, None
+        ops.ATTENTION_LAUNCH_EVENTS = []
+        ops.LAUNCH_EVENTS = {"conv3x3": [], "conv3x3_split": [], "dcn": []}
         with torch.no_grad():
-            dt2, _ = timed_steps(step2, args.steps, 2, None)
-        value_streams2 = round(args.batch * args.steps / dt2, 3)
+            dt1, _ = timed_steps(step_single, args.steps, 1, None)
+        live_events, ops.ATTENTION_LAUNCH_EVENTS = ops.ATTENTION_LAUNCH_EVENTS or [], None
+        family_events, ops.LAUNCH_EVENTS = ops.LAUNCH_EVENTS or {}, None
+        gatherers = keep
+        value_single_stream = round(args.batch * args.steps / dt1, 3)
 
     if args.breakdown and rank == 0 and not STUB:
         stage_breakdown(netG, net_vq, lr)
@@ -612,7 +624,7 @@ def main():
                                     "(12 scenes: index agreement >= 0.9992, |dPSNR vs GT| <= 0.005 dB; tests/test_gpu_precision.py).  Cost "
                                     "against round 3's single-pass fp16 path: -19 % images/s.  bf16 (BASELINE configs[1]'s literal dtype) "
                                     "misses the tolerance by 10x (0.53 dB, 0.48 index agreement) and is offered as --precision bf16 only"},
-            "value_streams2": value_streams2,
+            "value_single_stream": value_single_stream,
             "roofline": None if STUB else attention_roofline(device, args.batch, live_events),
             "rooflines": None if STUB else family_rooflines(family_events, args.steps),
             "power": None,
@@ -620,7 +632,7 @@ def main():
         }
         if not STUB and world == 1 and not args.no_power:
             try:
-                res["power"] = power_block(device, args.batch, step)
+                res["power"] = power_block(device, args.batch, step_single)
             except Exception as ex:      # telemetry is an annotation: it must never cost the line
                 res["power"] = {"error": repr(ex)[:200]}
         if STUB:
