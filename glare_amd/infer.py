@@ -45,10 +45,13 @@ def load_lol_pairs(root):
     return lows, gts
 
 
-def run(n_images, batch=8, h=400, w=600, seed=1234, root=None, net_g=None, net_vq=None, pairs=None, with_ssim=False, precision=None):
+def run(n_images, batch=8, h=400, w=600, seed=1234, root=None, net_g=None, net_vq=None, pairs=None, with_ssim=False, precision=None,
+        with_lpips=False, lpips_weights=None):
     """Synthetic LOL-shaped pairs by default; `root` = a LOL dataset folder (eval15 split), `net_g` / `net_vq` = checkpoint
     files in the reference's format (glare_amd.checkpoint) -- without them the weights are name-seeded; `pairs` = (lows, gts)
-    uint8 stacks [n,h,w,3] supplied by the caller."""
+    uint8 stacks [n,h,w,3] supplied by the caller.  with_ssim / with_lpips: the loop's other two metrics (infer_dataset_lol.py:152-153)
+    as further columns of the result; lpips_weights: a state dict saved from `lpips.LPIPS(net='alex')` (its AlexNet + linear heads cannot be
+    downloaded here: without the file the LPIPS net is name-seeded and the column only exercises the path)."""
     from . import checkpoint
 
     rank, world, device = parallel.init_from_env()
@@ -60,6 +63,20 @@ def run(n_images, batch=8, h=400, w=600, seed=1234, root=None, net_g=None, net_v
     if net_vq:
         checkpoint.load_network(net_vq, net_vq_m, strict=False)
     netG, net_vq = netG.to(device), net_vq_m.to(device)
+    lpips_net = None
+    if with_lpips:
+        from . import metrics
+
+        lpips_net = metrics.LPIPS(net="alex")
+        if lpips_weights:
+            lpips_net.load_state_dict(torch.load(lpips_weights, map_location="cpu"), strict=False)   # the package's own files hold the heads only
+        else:
+            seeded_init_(lpips_net, 7)
+            with torch.no_grad():
+                for lin in lpips_net.lins:                  # the package's trained heads are non-negative: keep the stand-in a valid distance
+                    lin.model[-1].weight.abs_()
+        lpips_net = lpips_net.to(device)
+    ncols = 1 + int(with_ssim) + int(with_lpips)
     if pairs is not None:
         lows, gts = pairs
         n_images, h, w = lows.shape[0], lows.shape[1], lows.shape[2]
@@ -80,9 +97,15 @@ def run(n_images, batch=8, h=400, w=600, seed=1234, root=None, net_g=None, net_v
         out = enhance_batch(netG, net_vq, lows_p[lo - base:hi - base], device, prec)
         gt = gts_p[lo - base:hi - base].to(device, non_blocking=True)
         restored, vals = harness.postprocess_device(out, h, w, gt)   # crop, clamp, GT-mean gain, PSNR: all on the device
+        cols = [vals]
         if with_ssim:                                                  # + SSIM (calculate_ssim, infer_dataset_lol.py:152)
-            return torch.stack([vals, harness.ssim_device(restored, gt)], dim=1)
-        return vals.view(-1, 1)
+            cols.append(harness.ssim_device(restored, gt))
+        if with_lpips:                                                 # + LPIPS (measure.lpips on the two uint8 images, :153)
+            from . import metrics
+
+            a, b = metrics.to_lpips_input(harness.to_ubyte_device(restored)), metrics.to_lpips_input(gt)
+            cols.append(lpips_net(a, b).view(-1).double())
+        return torch.stack(cols, dim=1)
 
     if top > base:
         psnr_slice(base, min(base + batch, top))                  # warm-up on this rank's first batch: weight packing, workspace growth
@@ -90,7 +113,7 @@ def run(n_images, batch=8, h=400, w=600, seed=1234, root=None, net_g=None, net_v
     t0 = time.perf_counter()
     local = parallel.run_sharded(n_images, psnr_slice, rank, world, batch=batch, streams=2)
     if local is None:
-        local = torch.zeros(0, 2 if with_ssim else 1, dtype=torch.float64, device=device)
+        local = torch.zeros(0, ncols, dtype=torch.float64, device=device)
     # fp16 (the default) has fp16's range: a checkpoint whose activations pass 65504 yields inf / NaN where bf16 would not.  The
     # PSNRs come back to the host anyway; an image whose value is not finite is enhanced again in bf16 (fp32 range, same kernels)
     # bf16 misses the end-to-end tolerance 10x: a re-run image is a flagged exception, listed BY INDEX in the
@@ -116,7 +139,7 @@ def run(n_images, batch=8, h=400, w=600, seed=1234, root=None, net_g=None, net_v
         torch.distributed.destroy_process_group()
     if full is None:
         return None
-    return full.cpu().numpy() if with_ssim else full.view(-1).cpu().numpy()   # with_ssim: columns (PSNR, SSIM)
+    return full.cpu().numpy() if ncols > 1 else full.view(-1).cpu().numpy()   # several metrics: columns (PSNR[, SSIM][, LPIPS])
 
 
 def main():
@@ -129,15 +152,23 @@ def main():
     ap.add_argument("--net-g", default=None, help="net_G checkpoint (reference format)")
     ap.add_argument("--net-vq", default=None, help="VQGAN checkpoint (reference format)")
     ap.add_argument("--ssim", action="store_true", help="also report SSIM (utils2.calculate_ssim) per image")
+    ap.add_argument("--lpips", action="store_true", help="also report LPIPS-alex (Measure.lpips) per image")
+    ap.add_argument("--lpips-weights", default=None, help="state dict of lpips.LPIPS(net='alex') (torch.save); without it the net is name-seeded")
     ap.add_argument("--precision", choices=("fp16", "bf16"), default=None,
                     help="16-bit format of activations and filters (default fp16, the reference's autocast dtype; images whose fp16 "
                          "result is not finite are re-run in bf16)")
     args = ap.parse_args()
-    res = run(args.images, args.batch, args.height, args.width, root=args.root, net_g=args.net_g, net_vq=args.net_vq, with_ssim=args.ssim, precision=args.precision)
+    res = run(args.images, args.batch, args.height, args.width, root=args.root, net_g=args.net_g, net_vq=args.net_vq, with_ssim=args.ssim,
+              precision=args.precision, with_lpips=args.lpips, lpips_weights=args.lpips_weights)
     if res is not None:
         world = int(os.environ.get("WORLD_SIZE", "1"))
-        psnrs = res[:, 0] if args.ssim else res
+        multi = args.ssim or args.lpips
+        psnrs = res[:, 0] if multi else res
         extra = {"mean_ssim": float(np.mean(res[:, 1])), "ssim": [round(float(v), 5) for v in res[:, 1]]} if args.ssim else {}
+        if args.lpips:
+            col = res[:, 2 if args.ssim else 1]
+            extra.update({"mean_lpips": float(np.mean(col)), "lpips": [round(float(v), 5) for v in col],
+                          "lpips_weights": args.lpips_weights or "name-seeded (the package's weights are not available offline)"})
         print(json.dumps({"images": int(len(psnrs)), "mean_psnr": float(np.mean(psnrs)), "psnr": [round(float(v), 4) for v in psnrs], **extra,
                           "images_per_sec_incl_host_transfers": round(len(psnrs) / run.last_seconds, 2), "ranks": world,
                           # images whose fp16 result was not finite and whose figure therefore comes from the bf16 precision (which

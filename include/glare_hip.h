@@ -715,6 +715,23 @@ int glare_mse_loss_bf16(const void* a, const void* b, long long n, float* loss_o
  * 16-bit rounding, as F.mse_loss under autocast (fp32) + the cast's backward do (losses.py:33-39 behind scaler.scale(loss).backward()) */
 int glare_mse_backward_bf16(const void* a, const void* b, long long n, const float* g_dev, void* grad_a, glare_stream_t stream);
 
+/* ---- f4: LPIPS (AlexNet) of the evaluation loop ---------------------------------------------------------------------------
+ * Replaces `lpips.LPIPS(net='alex').forward(tA, tB)` as called by Measure.lpips (code/Measure.py:17-30; infer_dataset_lol.py:153).
+ * The `lpips` package (Zhang et al. 2018, PyPI lpips 0.1.x) is a third-party dependency absent from the reference tree; its published
+ * forward is restated by oracle/torch_ref.py LPIPSAlex.  All fp32, NCHW, as the package computes it (csrc/metrics.hip):
+ * glare_conv2d_direct_f32: out = act(bias + conv(x; w [Cout][Cin][k][k], stride, zero padding)); in_shift / in_scale (both or neither,
+ *   fp32 [Cin]): the input is (x - shift) / scale, padded with zeros AFTER the scaling (LPIPS' ScalingLayer in front of conv1).
+ *   Any Cin / Cout / stride / padding, k <= 16.   glare_maxpool2d_f32: nn.MaxPool2d(k, stride) (no padding, floor mode).
+ * glare_lpips_tap_f32: one feature tap -- both feature maps unit-normalised over the channels (x / (|x| + eps)), squared difference,
+ *   the 1x1 head lin_w [C], spatial mean; dist_out[b] (fp64) = or += the tap's value (accumulate), deterministic two-level sum. */
+int glare_conv2d_direct_f32(const float* x_nchw, const float* w_oihw, const float* bias_or_null, float* out_nchw, int B, int Cin, int H,
+                            int W, int Cout, int ksize, int stride, int pad, int relu, const float* in_shift_or_null,
+                            const float* in_scale_or_null, glare_stream_t stream);
+int glare_maxpool2d_f32(const float* x_nchw, float* out_nchw, int B, int C, int H, int W, int ksize, int stride, glare_stream_t stream);
+size_t glare_lpips_tap_workspace_bytes(int B, long long HW);
+int glare_lpips_tap_f32(const float* feat0_nchw, const float* feat1_nchw, const float* lin_w, int B, int C, long long HW, float eps,
+                        int accumulate, double* dist_out, void* workspace, size_t workspace_bytes, glare_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

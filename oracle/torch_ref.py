@@ -702,6 +702,62 @@ def psnr(a, b):  # utils2.py:32-36
     mse = np.mean((a - b) ** 2)
     return 10 * np.log10(1.0 / mse)
 
+# --------------------------------------------------------------------------------------------
+# LPIPS (AlexNet)            Measure.py:17-30 -> third-party package `lpips` (absent from /root/reference)
+# --------------------------------------------------------------------------------------------
+class LPIPSAlex(nn.Module):
+    """`lpips.LPIPS(net='alex')` (Measure.py:20) restated from the package's published definition (Zhang et al., CVPR 2018; PyPI
+    lpips 0.1.x, `lpips/lpips.py` + `lpips/pretrained_networks.py`; the reference does not pin a version).  PARITY UNPINNED BY
+    EXECUTION: neither the package, nor torchvision's AlexNet, nor their downloaded weights exist in this image; anchored on the
+    reference's call site (uint8 HWC images -> Measure.t -> x / 127.5 - 1 -> model.forward(tA, tB).item()) and on the metric's
+    properties (d(x, x) = 0, symmetry, non-negativity for non-negative heads).
+      forward(in0, in1): ScalingLayer (x - shift) / scale; alexnet.features cut at the five ReLUs (conv 11x11 s4 p2 | maxpool 3 s2,
+      conv 5x5 p2 | maxpool 3 s2, conv 3x3 p1 | conv 3x3 p1 | conv 3x3 p1); per tap k: normalize_tensor(f) = f / (sqrt(sum_c f^2) + 1e-10),
+      d = (n0 - n1)^2, lin_k = 1x1 conv C_k -> 1 without bias (Dropout in front is the identity in eval), spatial mean; sum over k.
+    Same state-dict keys as the package (and as glare_amd.metrics.LPIPS)."""
+
+    CONVS = ((0, 3, 64, 11, 4, 2), (3, 64, 192, 5, 1, 2), (6, 192, 384, 3, 1, 1), (8, 384, 256, 3, 1, 1), (10, 256, 256, 3, 1, 1))
+
+    def __init__(self):
+        super().__init__()
+        self.scaling_layer = nn.Module()
+        self.scaling_layer.register_buffer("shift", torch.Tensor([-.030, -.088, -.188])[None, :, None, None])
+        self.scaling_layer.register_buffer("scale", torch.Tensor([.458, .448, .450])[None, :, None, None])
+        self.net = nn.Module()
+        for s, (idx, cin, cout, k, st, pd) in enumerate(self.CONVS):
+            seq = nn.Sequential()
+            if s in (1, 2):
+                seq.add_module(str(idx - 1), nn.MaxPool2d(kernel_size=3, stride=2))
+            seq.add_module(str(idx), nn.Conv2d(cin, cout, kernel_size=k, stride=st, padding=pd))
+            seq.add_module(str(idx + 1), nn.ReLU(inplace=False))
+            setattr(self.net, "slice%d" % (s + 1), seq)
+        for k, (_, _, c, _, _, _) in enumerate(self.CONVS):
+            lin = nn.Module()
+            lin.model = nn.Sequential(nn.Dropout(), nn.Conv2d(c, 1, 1, stride=1, padding=0, bias=False))
+            setattr(self, "lin%d" % k, lin)
+        self.lins = nn.ModuleList([getattr(self, "lin%d" % k) for k in range(5)])
+        self.eval()
+
+    def forward(self, in0, in1, normalize=False):
+        if normalize:
+            in0, in1 = 2 * in0 - 1, 2 * in1 - 1
+        h0 = (in0 - self.scaling_layer.shift) / self.scaling_layer.scale
+        h1 = (in1 - self.scaling_layer.shift) / self.scaling_layer.scale
+        val = 0
+        for k in range(5):
+            sl = getattr(self.net, "slice%d" % (k + 1))
+            h0, h1 = sl(h0), sl(h1)
+            n0 = h0 / (torch.sqrt(torch.sum(h0 ** 2, dim=1, keepdim=True)) + 1e-10)
+            n1 = h1 / (torch.sqrt(torch.sum(h1 ** 2, dim=1, keepdim=True)) + 1e-10)
+            val = val + self.lins[k].model(((n0 - n1) ** 2)).mean([2, 3], keepdim=True)
+        return val
+
+
+def lpips_input(img_u8):
+    """Measure.t (Measure.py:48-64): HWC uint8 -> 1x3xHxW float in [-1, 1]."""
+    return torch.Tensor(np.transpose(img_u8, [2, 0, 1])[None]) / 127.5 - 1
+
+
 
 # --------------------------------------------------------------------------------------------
 # Stage-3 loss terms         modules/pytorch_msssim/__init__.py, modules/losses.py, VQLLFLOWD_model.py:209-223
