@@ -51,20 +51,57 @@ def device_sync():
         torch.cuda.synchronize()
 
 
-def timed_steps(step, steps, warmup, dist):
+class Watchdog:
+    """One timer over every stage of the N > 1 body (process-group init, the first collective, the warm-up's gathers, the barriers of the
+    timed region, the MAX all-reduce, the final barrier): RCCL between processes has only ever run under gloo on CPU before a driver's
+    N > 1 run, and a collective that never returns must not cost the JSON line.  `stage(name)` re-arms the timer; if a stage does not
+    finish within `seconds`, `on_fire(name)` runs on the timer thread (rank 0 prints the line with what it has and the job ends)."""
+
+    def __init__(self, seconds, on_fire):
+        self.seconds, self.on_fire, self.timer, self.name = seconds, on_fire, None, None
+
+    def stage(self, name):
+        import threading
+
+        self.cancel()
+        self.name = name
+        if self.seconds and self.seconds > 0:
+            self.timer = threading.Timer(self.seconds, self.on_fire, args=(name,))
+            self.timer.daemon = True
+            self.timer.start()
+
+    def cancel(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+
+LOCAL_SECONDS = [None]     # this rank's own time for the K timed steps (to ITS device sync, before the closing barrier)
+
+
+def timed_steps(step, steps, warmup, dist, dog=None):
     """The contract's timed region: W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + synchronize on both
     sides; returns this rank's seconds and the last output."""
     out = None
+    if dog is not None and warmup:
+        dog.stage("warm-up steps (the first per-step gather)")
     for i in range(warmup):
         out = step(i)
     device_sync()
+    if dog is not None:
+        dog.stage("barrier before the timed region" if steps else "barrier behind the warm-up")
     if dist is not None:
         dist.barrier()
     device_sync()
+    if dog is not None and steps:
+        dog.stage("timed region (K steps incl. their gathers)")
     t0 = time.perf_counter()
     for i in range(steps):
         out = step(i)
     device_sync()
+    LOCAL_SECONDS[0] = time.perf_counter() - t0
+    if dog is not None and steps:
+        dog.stage("barrier behind the timed region")
     if dist is not None:
         dist.barrier()
     device_sync()
@@ -481,6 +518,9 @@ def main():
                                                             "the inference region)")
     ap.add_argument("--train-timeout", type=int, default=600, help="seconds after which a train block that has not returned is "
                                                                    "declared hung: the JSON line is printed without it")
+    ap.add_argument("--dist-timeout", type=int, default=300, help="N > 1: seconds any one stage of the multi-rank body (init, first collective, "
+                                                                  "warm-up gathers, barriers, timed region, MAX all-reduce) may take before rank 0 "
+                                                                  "prints the line with `config.exchange.error` and the job ends")
     ap.add_argument("--breakdown", action="store_true", help="per-stage timing on stderr")
     args = ap.parse_args()
 
@@ -505,16 +545,50 @@ def main():
         assert torch.cuda.device_count() > local_rank, "rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
+    printed = []
+    res = None
+    skeleton = {"metric": "enhanced images/sec (400x600)", "value": None, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+                "scaling": "strong" if args.global_batch is not None else "weak", "vs_baseline": None, "dtype": args.precision,
+                "data": "synthetic", "config": {"workload": "LOL-shaped 400x600 inference, %d images per GPU on %d GPU(s)" % (args.batch, world),
+                                                "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world}}
+
+    def emit():
+        if rank == 0 and not printed:
+            printed.append(True)
+            print(json.dumps(res if res is not None else skeleton), flush=True)
+
+    def dist_hung(stage):
+        # a stage of the multi-rank body never returned: the line goes out with what this rank has -- its own throughput over the K
+        # timed steps if they finished locally -- and the error where the exchange is described; torchrun then stops the other ranks
+        tgt = res if res is not None else skeleton
+        loc = LOCAL_SECONDS[0]
+        tgt["config"]["exchange"] = {"error": "stage '%s' did not finish within %d s (a hung collective?)" % (stage, args.dist_timeout),
+                                     "rank0_local_images_per_sec": round(args.batch * args.steps / loc, 3) if loc else None}
+        if STUB:
+            tgt["stub"] = True
+        emit()
+        os._exit(0 if rank == 0 else 1)
+
+    dog = Watchdog(args.dist_timeout, dist_hung) if world > 1 else None
     dist = None
+    ranks_seen = 1
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dog.stage("init_process_group")
         if STUB:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)  # RCCL on ROCm
         assert dist.get_world_size() == args.gpus and dist.get_backend() == ("gloo" if STUB else "nccl")
+        dog.stage("first collective (4-byte all-reduce)")
+        one = torch.ones(1, dtype=torch.int32, device=device)
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())                         # every rank contributed: the communicator really spans N processes
+        assert ranks_seen == world, "all-reduce of ones saw %d ranks, expected %d" % (ranks_seen, world)
+        dog.cancel()
 
     from glare_amd import ops
 
@@ -539,10 +613,14 @@ def main():
         # one set of receive buffers per stream: two steps in flight never gather into the same memory
         gatherers = [parallel.RankGather(torch.empty(shape, dtype=torch.uint8, device=device), rank, world) for _ in range(max(1, args.streams))]
 
+    GATHER_EVENTS = None
+
     def enhance(slot=0):
         gatherer = gatherers[slot] if gatherers is not None else None
         if STUB:
             out = lr * 2.0                                          # stands in for the HIP pipeline
+            if gatherer is not None and rank == 1 and os.environ.get("GLARE_BENCH_STUB_HANG_GATHER") == "1":
+                time.sleep(3600)                                    # tests: a rank that never reaches the step's gather
             if gatherer is not None:
                 bufs = gatherer.gather(out.permute(0, 2, 3, 1).contiguous().to(torch.uint8))
                 if rank == 0:
@@ -551,7 +629,15 @@ def main():
         out = netG.reverse_flow_nhwc(net_vq, lr)["out"]
         if gatherer is not None:
             restored, _ = harness.postprocess_device(out, H_IMG, W_IMG)
-            gatherer.gather(harness.to_ubyte_device(restored))      # img_as_ubyte: 5.8 MB per rank and step instead of 23 MB
+            u8 = harness.to_ubyte_device(restored)                  # img_as_ubyte: 5.8 MB per rank and step instead of 23 MB
+            if rank == 0 and GATHER_EVENTS is not None:             # the exchange timed where it runs (event pair on the launch stream)
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+                gatherer.gather(u8)
+                ev[1].record()
+                GATHER_EVENTS.append(ev)
+            else:
+                gatherer.gather(u8)
         return out
 
     def step(i=0):
@@ -564,18 +650,32 @@ def main():
         return enhance()
 
     with torch.no_grad():
+        if dog is not None:
+            dog.stage("first step (weight packing + the first gather)")
         out = step()                                          # weights are packed once, on first use
         device_sync()
-        timed_steps(step, 0, args.warmup, dist)               # the W untimed warm-up steps (+ barrier)
+        timed_steps(step, 0, args.warmup, dist, dog)          # the W untimed warm-up steps (+ barrier)
         single = streams is None
         if rank == 0 and not STUB and single:
             ops.ATTENTION_LAUNCH_EVENTS = []     # roofline: the dominant kernel's launches are timed where they run
             ops.LAUNCH_EVENTS = {"conv3x3": [], "conv3x3_split": [], "dcn": []}     # ... and the next families (`rooflines`)
-        dt, out = timed_steps(step, args.steps, 0, dist)      # EXACTLY K steps between barrier + synchronize
+        if rank == 0 and world > 1 and not STUB:
+            GATHER_EVENTS = []
+        dt, out = timed_steps(step, args.steps, 0, dist, dog) # EXACTLY K steps between barrier + synchronize
         live_events, ops.ATTENTION_LAUNCH_EVENTS = ops.ATTENTION_LAUNCH_EVENTS or [], None
         family_events, ops.LAUNCH_EVENTS = ops.LAUNCH_EVENTS or {}, None
+        gather_events, GATHER_EVENTS = GATHER_EVENTS or [], None
     assert bool(torch.isfinite(out).all())
+    if dog is not None:
+        dog.stage("MAX all-reduce of the step time + all-gather of the per-rank times")
     dt = max_over_ranks(dt, dist, device)
+    per_rank = None
+    if dist is not None:                                      # every rank's own K-step time (to its device sync): who is the straggler
+        mine = torch.tensor([LOCAL_SECONDS[0]], device=device, dtype=torch.float64)
+        allt = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allt, mine)
+        per_rank = [round(args.batch * args.steps / float(t.item()), 3) for t in allt]
+        dog.cancel()
 
     value_single_stream = None
     if not single and rank == 0 and not STUB and not args.no_single_stream:
@@ -617,6 +717,9 @@ def main():
                        "streams_per_gpu": args.streams,
                        "exchange": "none (1 GPU)" if world == 1 else "per step: crop/clamp/uint8 on device + RCCL gather of the "
                                    "enhanced [B,400,600,3] uint8 batches to rank 0 (inside the timed region)",
+                       "ranks_seen": ranks_seen, "per_rank_images_per_sec": per_rank,
+                       "gather_ms_per_step": (round(sum(a.elapsed_time(b) for a, b in gather_events) / len(gather_events), 3)
+                                              if gather_events else None),
                        "weights": "random, name-seeded (no checkpoints offline)",
                        "precision": "fp16 = the reference's own autocast dtype (infer_dataset_lol.py:134), with the conditional encoder and the "
                                     "flow's nets contracted in the fp32-class form (hi / lo operand pairs, three MFMA passes per conv) and the "
@@ -638,13 +741,6 @@ def main():
         if STUB:
             res["stub"] = True
 
-    printed = []
-
-    def emit():
-        if rank == 0 and not printed:
-            printed.append(True)
-            print(json.dumps(res), flush=True)
-
     if not args.no_train:
         # After the timed inference region, and never allowed to take the headline line down with it: an exception is reported
         # inside the block, and -- the all-reduce leg has only ever run under gloo on CPU before a driver's N > 1 run -- a HANG
@@ -657,15 +753,15 @@ def main():
             emit()
             os._exit(0 if rank == 0 else 1)
 
-        dog = threading.Timer(args.train_timeout, on_timeout)
-        dog.daemon = True
-        dog.start()
+        train_dog = threading.Timer(args.train_timeout, on_timeout)
+        train_dog.daemon = True
+        train_dog.start()
         try:
             with ops.use_precision("bf16"):       # the plain-op default; every run of the block selects its own precision
                 train = train_block(device, rank, world)
         except Exception as e:  # noqa: BLE001
             train = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
-        dog.cancel()
+        train_dog.cancel()
         if res is not None:
             res["train"] = train
 
@@ -673,7 +769,9 @@ def main():
         res["cpu_baseline"] = cpu_baseline()
     emit()
     if dist is not None:
+        dog.stage("final barrier")                 # the line is out: a hang here only ends the job
         dist.barrier()
+        dog.cancel()
         dist.destroy_process_group()
 
 

@@ -99,3 +99,42 @@ def test_bench_prints_its_line_when_the_train_block_hangs():
     assert len(lines) == 1
     res = json.loads(lines[0])
     assert res["value"] > 0 and "did not finish" in res["train"]["error"]
+
+
+def _run_bench_stub(args, extra_env=None, timeout=900):
+    import json
+
+    env = dict(os.environ, GLARE_BENCH_STUB="1", **(extra_env or {}))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, [json.loads(l) for l in lines]
+
+
+@pytest.mark.parametrize("n", [4, 8])
+def test_bench_configs2_as_written_on_4_and_8_ranks(n):
+    """BASELINE configs[2] as the driver would launch it on a full node -- `--gpus N --global-batch 32` -- through bench.py's own
+    multi-rank body over gloo: every rank counted by the 4-byte all-reduce (`ranks_seen`), the per-rank rates
+    gathered, one line."""
+    r, lines = _run_bench_stub(["--gpus", str(n), "--steps", "2", "--warmup", "1", "--global-batch", "32", "--no-train"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = lines[0]
+    cfg = res["config"]
+    assert res["n_gpus"] == n and cfg["global_batch"] == 32 and cfg["batch_per_gpu"] == 32 // n and res["scaling"] == "strong"
+    assert cfg["ranks_seen"] == n and len(cfg["per_rank_images_per_sec"]) == n and all(v > 0 for v in cfg["per_rank_images_per_sec"])
+    assert isinstance(cfg["exchange"], str) and res["value"] > 0
+
+
+def test_bench_prints_its_line_when_the_first_gather_hangs():
+    """A rank that never reaches the per-step gather (GLARE_BENCH_STUB_HANG_GATHER=1: rank 1 sleeps in front of it): rank 0 sits in the
+    collective of its FIRST step.  The watchdog over the whole N > 1 body (`--dist-timeout`) prints the line with the stage that hung in
+    `config.exchange.error` and ends the job -- no line at all was the failure mode before."""
+    r, lines = _run_bench_stub(["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--dist-timeout", "8", "--no-train"],
+                               {"GLARE_BENCH_STUB_HANG_GATHER": "1"}, timeout=300)
+    assert len(lines) == 1, (r.stdout[-1500:], r.stderr[-1500:])
+    res = lines[0]
+    assert res["stub"] is True and res["n_gpus"] == 2 and res["value"] is None
+    err = res["config"]["exchange"]["error"]
+    assert "did not finish within 8 s" in err and ("first step" in err or "gather" in err)
