@@ -28,17 +28,20 @@ __global__ __launch_bounds__(256) void pre_kernel(const uint8_t* __restrict__ im
 // pass 1: r = clamp(crop(out)) -> restored (NHWC), per-block sums of gray(r) and gray(gt/255)
 __global__ __launch_bounds__(256) void post_crop_kernel(const float* __restrict__ out, const uint8_t* __restrict__ gt, int h, int w,
                                                         int Hp, int Wp, int pad, float* __restrict__ restored,
-                                                        double* __restrict__ partial) {
+                                                        double* __restrict__ partial, int* __restrict__ bad_partial) {
   __shared__ double red[2][4];
+  __shared__ int redc[4];
   const int b = blockIdx.y;
   const long long npix = (long long)h * w;
   double sr = 0.0, sg = 0.0;
+  int bad = 0;       // non-finite values of the network output inside the crop, counted BEFORE the clamp: the clamp turns +inf into 1.0
   for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long long)HB * 256) {
     const int y = (int)(p / w), x = (int)(p % w);
     float r[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float v = out[(((long long)b * 3 + c) * Hp + y) * Wp + x + pad];
+      bad += (__float_as_uint(v) & 0x7f800000u) == 0x7f800000u;   // exponent all ones: inf or NaN (an fp16 overflow upstream)
       r[c] = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);     // torch.clamp (infer_dataset_lol.py:138): a NaN stays a NaN -- fminf / fmaxf
                                                       // would turn it into 0 and hide a broken image behind a finite PSNR
       restored[((long long)b * npix + p) * 3 + c] = r[c];
@@ -49,12 +52,21 @@ __global__ __launch_bounds__(256) void post_crop_kernel(const float* __restrict_
       sg += 0.114 * (g[0] / 255.0) + 0.587 * (g[1] / 255.0) + 0.299 * (g[2] / 255.0);
     }
   }
-  for (int o = 32; o > 0; o >>= 1) { sr += __shfl_xor(sr, o, 64); sg += __shfl_xor(sg, o, 64); }
-  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sr; red[1][threadIdx.x >> 6] = sg; }
+  for (int o = 32; o > 0; o >>= 1) { sr += __shfl_xor(sr, o, 64); sg += __shfl_xor(sg, o, 64); bad += __shfl_xor(bad, o, 64); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sr; red[1][threadIdx.x >> 6] = sg; redc[threadIdx.x >> 6] = bad; }
   __syncthreads();
   if (threadIdx.x < 2)
     partial[((size_t)b * HB + blockIdx.x) * 2 + threadIdx.x] =
         (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+  if (threadIdx.x == 2 && bad_partial) bad_partial[(size_t)b * HB + blockIdx.x] = (redc[0] + redc[1]) + (redc[2] + redc[3]);
+}
+
+__global__ void post_count_kernel(const int* __restrict__ bad_partial, int B, int* __restrict__ nonfinite) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int s = 0;
+  for (int k = 0; k < HB; ++k) s += bad_partial[(size_t)b * HB + k];
+  nonfinite[b] = s;
 }
 
 // pass 2: r = clip(r * gain), per-block sum of (gt/255 - r)^2
@@ -137,21 +149,31 @@ extern "C" int glare_harness_preprocess_u8(const unsigned char* img_hwc, int B, 
   return glare_launch_status();
 }
 
-extern "C" size_t glare_harness_postprocess_workspace_bytes(int B) { return B <= 0 ? 0 : (size_t)B * HB * 3 * sizeof(double); }
+extern "C" size_t glare_harness_postprocess_workspace_bytes(int B) { return B <= 0 ? 0 : (size_t)B * HB * (3 * sizeof(double) + sizeof(int)); }
 
-extern "C" int glare_harness_postprocess_f32(const float* out_nchw, const unsigned char* gt_hwc_or_null, int B, int h, int w,
-                                             int Hp, int Wp, int pad, float* restored_hwc, double* psnr_or_null, void* workspace,
-                                             size_t workspace_bytes, glare_stream_t stream) {
+extern "C" int glare_harness_postprocess_flagged_f32(const float* out_nchw, const unsigned char* gt_hwc_or_null, int B, int h, int w,
+                                                     int Hp, int Wp, int pad, float* restored_hwc, double* psnr_or_null,
+                                                     int* nonfinite_or_null, void* workspace, size_t workspace_bytes, glare_stream_t stream) {
   if (!out_nchw || !restored_hwc || B <= 0 || h <= 0 || w <= 0 || h > Hp || w + pad > Wp || pad < 0) return GLARE_ERR_INVALID;
   if (psnr_or_null && !gt_hwc_or_null) return GLARE_ERR_INVALID;
   if (!workspace || workspace_bytes < glare_harness_postprocess_workspace_bytes(B)) return GLARE_ERR_WORKSPACE;
   double* partial = static_cast<double*>(workspace);
   double* mse_partial = partial + (size_t)B * HB * 2;
+  int* bad_partial = reinterpret_cast<int*>(mse_partial + (size_t)B * HB);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(post_crop_kernel, dim3(HB, B), dim3(256), 0, s, out_nchw, gt_hwc_or_null, h, w, Hp, Wp, pad, restored_hwc, partial);
+  hipLaunchKernelGGL(post_crop_kernel, dim3(HB, B), dim3(256), 0, s, out_nchw, gt_hwc_or_null, h, w, Hp, Wp, pad, restored_hwc, partial,
+                     nonfinite_or_null ? bad_partial : (int*)nullptr);
   const long long n = (long long)h * w * 3;
   hipLaunchKernelGGL(post_gain_kernel, dim3(HB, B), dim3(256), 0, s, restored_hwc, gt_hwc_or_null, n, partial, gt_hwc_or_null ? 1 : 0,
                      mse_partial);
   if (psnr_or_null) hipLaunchKernelGGL(post_psnr_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s, mse_partial, n, B, psnr_or_null);
+  if (nonfinite_or_null) hipLaunchKernelGGL(post_count_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s, bad_partial, B, nonfinite_or_null);
   return glare_launch_status();
+}
+
+extern "C" int glare_harness_postprocess_f32(const float* out_nchw, const unsigned char* gt_hwc_or_null, int B, int h, int w,
+                                             int Hp, int Wp, int pad, float* restored_hwc, double* psnr_or_null, void* workspace,
+                                             size_t workspace_bytes, glare_stream_t stream) {
+  return glare_harness_postprocess_flagged_f32(out_nchw, gt_hwc_or_null, B, h, w, Hp, Wp, pad, restored_hwc, psnr_or_null, nullptr, workspace,
+                                               workspace_bytes, stream);
 }

@@ -28,8 +28,10 @@ def preprocess_device(imgs_u8):
     return out
 
 
-def postprocess_device(out_nchw, h, w, gts_u8=None):
-    """network output [B,3,Hp,Wp] (device) -> (restored float [B,h,w,3], psnr float64 [B] or None), all on the device."""
+def postprocess_device(out_nchw, h, w, gts_u8=None, want_nonfinite=False):
+    """network output [B,3,Hp,Wp] (device) -> (restored float [B,h,w,3], psnr float64 [B] or None), all on the device.
+    want_nonfinite: a third result, int32 [B] = inf / NaN values of the network output inside each crop BEFORE the clamp (which maps
+    +inf to 1.0 and would hide an fp16 overflow behind a finite PSNR)."""
     from . import _lib
 
     _lib.require_cuda(out_nchw, gts_u8)
@@ -45,9 +47,12 @@ def postprocess_device(out_nchw, h, w, gts_u8=None):
         assert gts_u8.dtype == torch.uint8 and tuple(gts_u8.shape) == (B, h, w, 3) and gts_u8.is_contiguous()
         psnr_t = torch.empty(B, dtype=torch.float64, device=out_nchw.device)
     i = ctypes.c_int
-    _lib.check(lib.glare_harness_postprocess_f32(_lib.ptr(out_nchw), _lib.ptr(gts_u8), i(B), i(h), i(w), i(Hp), i(Wp), i(PAD),
-                                                 _lib.ptr(restored), _lib.ptr(psnr_t), _lib.ptr(ws), ctypes.c_size_t(nws),
-                                                 _lib.stream_handle()), "glare_harness_postprocess_f32")
+    bad = torch.empty(B, dtype=torch.int32, device=out_nchw.device) if want_nonfinite else None
+    _lib.check(lib.glare_harness_postprocess_flagged_f32(_lib.ptr(out_nchw), _lib.ptr(gts_u8), i(B), i(h), i(w), i(Hp), i(Wp), i(PAD),
+                                                         _lib.ptr(restored), _lib.ptr(psnr_t), _lib.ptr(bad), _lib.ptr(ws), ctypes.c_size_t(nws),
+                                                         _lib.stream_handle()), "glare_harness_postprocess_flagged_f32")
+    if want_nonfinite:
+        return restored, psnr_t, bad
     return restored, psnr_t
 
 

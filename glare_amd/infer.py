@@ -46,18 +46,24 @@ def load_lol_pairs(root):
 
 
 def run(n_images, batch=8, h=400, w=600, seed=1234, root=None, net_g=None, net_vq=None, pairs=None, with_ssim=False, precision=None,
-        with_lpips=False, lpips_weights=None):
+        with_lpips=False, lpips_weights=None, nets=None):
     """Synthetic LOL-shaped pairs by default; `root` = a LOL dataset folder (eval15 split), `net_g` / `net_vq` = checkpoint
     files in the reference's format (glare_amd.checkpoint) -- without them the weights are name-seeded; `pairs` = (lows, gts)
     uint8 stacks [n,h,w,3] supplied by the caller.  with_ssim / with_lpips: the loop's other two metrics (infer_dataset_lol.py:152-153)
     as further columns of the result; lpips_weights: a state dict saved from `lpips.LPIPS(net='alex')` (its AlexNet + linear heads cannot be
-    downloaded here: without the file the LPIPS net is name-seeded and the column only exercises the path)."""
+    downloaded here: without the file the LPIPS net is name-seeded and the column only exercises the path); nets = (netG, net_vq)
+    module instances supplied by the caller (tests).
+    The LAST column of the per-rank result is the overflow flag: the number of non-finite values of the network output inside the
+    image's crop, counted on the device before the clamp; it is dropped from the returned array and reported as `run.nonfinite_values`."""
     from . import checkpoint
 
     rank, world, device = parallel.init_from_env()
     assert device.type == "cuda", "glare_amd.infer needs an MI355X: the HIP kernels are the only implementation"
-    netG = seeded_init_(M.VQLLFLOWDeformable().eval(), 0)
-    net_vq_m = seeded_init_(M.VQModel().eval(), 1)
+    if nets is not None:
+        netG, net_vq_m = nets
+    else:
+        netG = seeded_init_(M.VQLLFLOWDeformable().eval(), 0)
+        net_vq_m = seeded_init_(M.VQModel().eval(), 1)
     if net_g:
         checkpoint.load_network(net_g, netG, strict=False)       # VQLLFLOWD_model.py:53-63 loads with strict=False
     if net_vq:
@@ -76,7 +82,7 @@ def run(n_images, batch=8, h=400, w=600, seed=1234, root=None, net_g=None, net_v
                 for lin in lpips_net.lins:                  # the package's trained heads are non-negative: keep the stand-in a valid distance
                     lin.model[-1].weight.abs_()
         lpips_net = lpips_net.to(device)
-    ncols = 1 + int(with_ssim) + int(with_lpips)
+    ncols = 1 + int(with_ssim) + int(with_lpips)          # metric columns; one more (the overflow flag) rides along inside this function
     if pairs is not None:
         lows, gts = pairs
         n_images, h, w = lows.shape[0], lows.shape[1], lows.shape[2]
@@ -96,7 +102,7 @@ def run(n_images, batch=8, h=400, w=600, seed=1234, root=None, net_g=None, net_v
     def psnr_slice(lo, hi, prec=precision):        # global image indices inside [base, top)
         out = enhance_batch(netG, net_vq, lows_p[lo - base:hi - base], device, prec)
         gt = gts_p[lo - base:hi - base].to(device, non_blocking=True)
-        restored, vals = harness.postprocess_device(out, h, w, gt)   # crop, clamp, GT-mean gain, PSNR: all on the device
+        restored, vals, bad = harness.postprocess_device(out, h, w, gt, want_nonfinite=True)   # crop, clamp, GT-mean gain, PSNR + overflow flag
         cols = [vals]
         if with_ssim:                                                  # + SSIM (calculate_ssim, infer_dataset_lol.py:152)
             cols.append(harness.ssim_device(restored, gt))
@@ -105,6 +111,7 @@ def run(n_images, batch=8, h=400, w=600, seed=1234, root=None, net_g=None, net_v
 
             a, b = metrics.to_lpips_input(harness.to_ubyte_device(restored)), metrics.to_lpips_input(gt)
             cols.append(lpips_net(a, b).view(-1).double())
+        cols.append(bad.double())
         return torch.stack(cols, dim=1)
 
     if top > base:
@@ -113,27 +120,35 @@ def run(n_images, batch=8, h=400, w=600, seed=1234, root=None, net_g=None, net_v
     t0 = time.perf_counter()
     local = parallel.run_sharded(n_images, psnr_slice, rank, world, batch=batch, streams=2)
     if local is None:
-        local = torch.zeros(0, ncols, dtype=torch.float64, device=device)
+        local = torch.zeros(0, ncols + 1, dtype=torch.float64, device=device)
     # fp16 (the default) has fp16's range: a checkpoint whose activations pass 65504 yields inf / NaN where bf16 would not.  The
     # PSNRs come back to the host anyway; an image whose value is not finite is enhanced again in bf16 (fp32 range, same kernels)
     # bf16 misses the end-to-end tolerance 10x: a re-run image is a flagged exception, listed BY INDEX in the
     # output (`bf16_rerun_images`), not a silent substitution
+    # Round 6: the trigger is the DEVICE-SIDE count of non-finite output values before the clamp, not only a non-finite PSNR -- the
+    # clamp maps +inf to 1.0, so an overflowed image could come back with a finite figure
     run.bf16_reruns = 0
     run.bf16_rerun_images = []
-    if precision != "bf16" and local.numel() and not bool(torch.isfinite(local[:, 0]).all()):
+    run.nonfinite_values = {}
+    flagged = (~torch.isfinite(local[:, 0])) | (local[:, -1] > 0) if local.numel() else None
+    if flagged is not None and bool(flagged.any()):
         lo0, _ = parallel.shard_range(n_images, rank, world)
-        for j in (~torch.isfinite(local[:, 0])).nonzero().flatten().tolist():
-            local[j] = psnr_slice(lo0 + j, lo0 + j + 1, "bf16")[0]
-            run.bf16_reruns += 1
-            run.bf16_rerun_images.append(lo0 + j)
+        for j in flagged.nonzero().flatten().tolist():
+            run.nonfinite_values[lo0 + j] = int(local[j, -1].item())
+            if precision != "bf16":
+                local[j] = psnr_slice(lo0 + j, lo0 + j + 1, "bf16")[0]
+                run.bf16_reruns += 1
+                run.bf16_rerun_images.append(lo0 + j)
+    local = local[:, :ncols].contiguous()
     torch.cuda.synchronize()
     run.last_seconds = time.perf_counter() - t0                   # host uint8 in -> PSNR on the device, this rank's share
     full = parallel.gather_results(local, n_images, rank, world)
     if world > 1:      # which images were re-run, from every rank (a few integers)
         lists = [None] * world
-        torch.distributed.all_gather_object(lists, run.bf16_rerun_images)
-        run.bf16_rerun_images = sorted(i for l in lists for i in l)
+        torch.distributed.all_gather_object(lists, (run.bf16_rerun_images, run.nonfinite_values))
+        run.bf16_rerun_images = sorted(i for l, _ in lists for i in l)
         run.bf16_reruns = len(run.bf16_rerun_images)
+        run.nonfinite_values = {k: v for _, d in lists for k, v in d.items()}
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
@@ -173,7 +188,10 @@ def main():
                           "images_per_sec_incl_host_transfers": round(len(psnrs) / run.last_seconds, 2), "ranks": world,
                           # images whose fp16 result was not finite and whose figure therefore comes from the bf16 precision (which
                           # misses the end-to-end tolerance): flagged per image, empty on every input this build has seen
-                          "bf16_rerun_images": run.bf16_rerun_images}))
+                          "bf16_rerun_images": run.bf16_rerun_images,
+                          # the overflow flag: per flagged image, how many values of the network output inside its crop were inf / NaN
+                          # BEFORE the clamp (counted on the device, csrc/harness.hip) in the precision first tried
+                          "nonfinite_output_values": {str(k): v for k, v in sorted(run.nonfinite_values.items())}}))
 
 
 if __name__ == "__main__":

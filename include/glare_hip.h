@@ -685,6 +685,12 @@ size_t glare_harness_postprocess_workspace_bytes(int B);
 int glare_harness_postprocess_f32(const float* out_nchw, const unsigned char* gt_hwc_or_null, int B, int h, int w, int Hp,
                                   int Wp, int pad, float* restored_hwc, double* psnr_or_null, void* workspace,
                                   size_t workspace_bytes, glare_stream_t stream);
+/* ... and nonfinite_or_null[b] (int32 [B]) = the number of inf / NaN values of the network output inside image b's crop, counted BEFORE
+ * the clamp: torch.clamp turns +inf into 1.0, so an fp16 overflow upstream can leave a finite PSNR behind (the reference masks NaNs only
+ * in its training loss, VQLLFLOWD_model.py:214-217); glare_amd.infer re-runs a flagged image in bf16 and lists it. */
+int glare_harness_postprocess_flagged_f32(const float* out_nchw, const unsigned char* gt_hwc_or_null, int B, int h, int w, int Hp,
+                                          int Wp, int pad, float* restored_hwc, double* psnr_or_null, int* nonfinite_or_null,
+                                          void* workspace, size_t workspace_bytes, glare_stream_t stream);
 
 /* ---- f1: the rest of the stage-3 loss (VQLLFLOWD_model.py:209-223) -------------------------------------------------
  * glare_clamp01_f32 / _backward: sr = clamp(rec, 0, 1) with NaN -> 0 (:209-215) and torch.clamp's gradient mask.

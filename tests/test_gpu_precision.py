@@ -475,9 +475,52 @@ def test_inference_driver_reruns_fp16_overflows_in_bf16(tmp_path):
     psnr = infer.run(2, batch=2, pairs=(lows, gts), net_g=path)
     assert np.isfinite(psnr).all(), psnr
     assert infer.run.bf16_reruns == 2 and infer.run.bf16_rerun_images == [0, 1]     # WHICH images, not only how many
+    # round 6: the trigger is the device-side count of non-finite output values before the clamp (every value of both crops here)
+    assert infer.run.nonfinite_values == {0: 40 * 60 * 3, 1: 40 * 60 * 3}
     ref = infer.run(2, batch=2, pairs=(lows, gts), net_g=path, precision="bf16")
-    assert infer.run.bf16_reruns == 0 and infer.run.bf16_rerun_images == []
+    assert infer.run.bf16_reruns == 0 and infer.run.bf16_rerun_images == [] and infer.run.nonfinite_values == {}
     assert np.allclose(psnr, ref, atol=0.05)      # single-image reruns split the attention keys differently: rounding-level changes
+
+
+def test_overflow_flag_catches_what_the_clamp_hides():
+    """+inf in the network output is clamped to 1.0 by the post-process and leaves a FINITE PSNR (torch.clamp, infer_dataset_lol.py:138;
+    the reference masks NaNs only in its training loss, VQLLFLOWD_model.py:214-217): the device-side counter sees it before the clamp,
+    and the driver keys the bf16 re-run on the counter."""
+    from glare_amd import harness, infer
+
+    g = torch.Generator().manual_seed(0)
+    out = torch.rand(3, 3, 30, 50, generator=g)
+    out[1, 0, 3, 25] = float("inf")            # inside image 1's crop [:, :, :24, 20:]
+    out[1, 2, 7, 49] = float("-inf")
+    out[2, 1, 5, 21] = float("nan")
+    out[0, 0, 3, 5] = float("inf")             # in the padding columns: not part of any image
+    out[0, 0, 28, 30] = float("inf")           # below the crop
+    gts = (torch.rand(3, 24, 30, 3, generator=g) * 255).to(torch.uint8)
+    restored, ps, bad = harness.postprocess_device(out.cuda(), 24, 30, gts.cuda(), want_nonfinite=True)
+    assert bad.cpu().tolist() == [0, 2, 1]
+    ps = ps.cpu().numpy()
+    assert np.isfinite(ps[:2]).all() and not np.isfinite(ps[2])          # image 1: a finite PSNR over two clamped infinities
+    assert bool(torch.isfinite(restored[1]).all()) and float(restored[1, 7, 29, 2]) == 0.0      # +inf -> 1.0 (x gain), -inf -> 0.0
+    plain, _, bad2 = harness.postprocess_device(out.cuda(), 24, 30, want_nonfinite=True)         # no GT: crop + clamp only
+    assert float(plain[1, 3, 5, 0]) == 1.0 and bad2.cpu().tolist() == [0, 2, 1]
+
+    class Saturating(torch.nn.Module):         # a network whose fp16 run saturates one output value of image 1; its bf16 run is clean
+        def __init__(self, net):
+            super().__init__()
+            self.net = net
+
+        def reverse_flow_nhwc(self, net_vq, lr, precision=None):
+            r = self.net.reverse_flow_nhwc(net_vq, lr, precision=precision)
+            if precision != "bf16" and lr.shape[0] > 1:
+                r["out"][1, 0, 4, 30] = float("inf")
+            return r
+
+    netG = Saturating(seeded_init_(M.VQLLFLOWDeformable().eval(), 0))
+    net_vq = seeded_init_(M.VQModel().eval(), 1)
+    lows, gts2 = synthetic_lowlight(2, 40, 60, seed=5), synthetic_lowlight(2, 40, 60, seed=6)
+    psnr = infer.run(2, batch=2, pairs=(lows, gts2), nets=(netG, net_vq))
+    assert np.isfinite(psnr).all()
+    assert infer.run.bf16_rerun_images == [1] and infer.run.nonfinite_values == {1: 1}
 
 
 # ---- hi / lo residual stream (fp16, conditional encoder) ----------------------------------------------------------------
