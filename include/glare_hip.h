@@ -95,7 +95,11 @@ typedef struct glare_conv_desc {
                              /* convs of the source, 16 instead of 36 tap-MACs per source pixel; weight_packed    */
                              /* from glare_conv2d_pack_weight_upsample, gn_partial sized / reduced by the         */
                              /* glare_conv2d_upsample_gn_* pair                                                   */
-  int act;                   /* GLARE_ACT_*                                                        */
+  int act;                   /* GLARE_ACT_*.  SIGMOID / SWISH without a residual run on the accumulators in the general  */
+                             /* (element-wise) epilogue (round 5: one epilogue per kernel instantiation): such a launch   */
+                             /* cannot ALSO ask for gn_partial or upsample == 2 (both live in the 16-B slab epilogue) --  */
+                             /* GLARE_ERR_UNSUPPORTED; with a residual, or with NONE / RELU, every combination holds.     */
+                             /* The path fuses sigmoid / swish only into the small-Cin convs (glare_conv2d_smallcin_*)    */
   int out_mode;              /* GLARE_OUT_*                                                        */
   long long plane_pitch;     /* planar modes: elements per plane (>= OH*OW); 0 = OH*OW             */
   float* gn_partial;         /* optional: fused GroupNorm statistics of the OUTPUT (bf16 NHWC, Cout % 128 == 0): */

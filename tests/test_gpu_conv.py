@@ -482,3 +482,29 @@ def test_groupnorm_prologue_through_the_decoder_modules():
             outs.append((img, feats))
     assert torch.equal(outs[0][0], outs[1][0])
     assert all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))
+
+
+def test_exp_activation_without_residual_excludes_the_slab_epilogue_features():
+    """include/glare_hip.h, glare_conv_desc.act: sigmoid / swish on the accumulators (no residual) run in the general
+    epilogue, which has neither the fused GroupNorm statistics nor the sub-pixel upsample form -- those two combinations are a
+    stated GLARE_ERR_UNSUPPORTED, everything around them works and agrees with the two-step form."""
+    from glare_amd import _lib
+
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(1, 16, 32, 128, generator=g) * 0.5).to(ops.act_dtype()).cuda()
+    w = torch.randn(128, 128, 3, 3, generator=g).cuda() * 0.03
+    b = torch.randn(128, generator=g).cuda() * 0.1
+    pc = ops.PackedConv(w, b)
+    plain = ops.conv2d(x, pc)                                     # none: slab epilogue
+    sw = ops.conv2d(x, pc, act="swish")                           # swish, no residual: general epilogue
+    ref = plain.float() * torch.sigmoid(plain.float())
+    assert float((sw.float() - ref).abs().max() / ref.abs().max()) < 1.5e-2     # `plain` is rounded to 16 bits before the two-step swish
+    with pytest.raises(_lib.GlareError) as e:
+        ops.conv2d(x, pc, act="swish", gn_stats=True)
+    assert e.value.status == _lib.ERR_UNSUPPORTED
+    with pytest.raises(_lib.GlareError) as e:
+        ops.conv2d(x, ops.PackedConv(w, b, upsample_subpixel=True), act="sigmoid", upsample=True)
+    assert e.value.status == _lib.ERR_UNSUPPORTED
+    res = (torch.randn(1, 16, 32, 128, generator=g) * 0.5).to(ops.act_dtype()).cuda()
+    out = ops.conv2d(x, pc, act="swish", residual=res, gn_stats=True)            # with a residual the slab epilogue applies it: allowed
+    assert hasattr(out, "_gn_stats") and bool(torch.isfinite(out.float()).all())
