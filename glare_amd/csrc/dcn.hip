@@ -35,6 +35,9 @@ namespace {
 constexpr int DC_THREADS = 256;
 constexpr int DC_PIX = 64;          // output pixels per workgroup
 
+// the extra outputs of glare_mdcn_forward_nhwc_fused
+struct MdcnFusedOut { float* out32; void* out16; float* sum_part; };
+
 struct DcnParams {
   const void* x;          // NHWC, fp32 or bf16
   const float* offset;    // [B][dg*2K][off_plane]
@@ -52,6 +55,10 @@ struct DcnParams {
   long long out_plane;
   long long total_pix;
   unsigned x_bytes, off_bytes, mask_bytes, wt_bytes;   // buffer-descriptor extents (fast path only; each < 2^31)
+  // round 6 (fast kernel only; both optional):
+  a16_t* out16;           // the output as 16-bit NHWC [p][opitch] at ooff instead of fp32 `out` (rounded once from the fp32 accumulator + bias)
+  float* sum_part;        // [B][ceil(Ho Wo / PIX)]: per pixel tile the sum of its fp32 outputs (before any rounding); the tiles are then cut PER
+                          // IMAGE: mean(x_w) of `h + x_w mean(h) / mean(x_w)` (deformableDecoder_arch.py:567) without another pass over x_w
 };
 
 template <bool XBF16>
@@ -285,8 +292,15 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_fast_kernel(const DcnParam
     const unsigned n = gridDim.x, q = n / 8, r = n % 8, xcd = tile % 8, k = tile / 8;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
   }
-  const unsigned pix0 = tile * (unsigned)PIX;
-  const unsigned total = (unsigned)p.total_pix;
+  // sum_part (round 6): tiles are cut PER IMAGE (the last tile of an image is ragged) so that a tile's sum belongs to one image and an
+  // image's tiles -- hence its mean -- are the same whatever batch it sits in; otherwise tiles run over the flattened B * Ho * Wo pixels
+  const unsigned hw = (unsigned)p.Ho * p.Wo;
+  unsigned pix0 = tile * (unsigned)PIX, total = (unsigned)p.total_pix;
+  if (p.sum_part) {
+    const unsigned tpi = (hw + PIX - 1) / PIX, b = tile / tpi;
+    pix0 = b * hw + (tile - b * tpi) * (unsigned)PIX;
+    total = (b + 1u) * hw;                                   // rows at or beyond it are not this tile's (plan: dropped; stores: skipped)
+  }
 
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t offr =
@@ -528,7 +542,7 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_fast_kernel(const DcnParam
   for (int s = 0; s < n_stages; ++s) stage_body(s);
 
   // epilogue: C/D layout col = lane&31 (co), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel)
-  const unsigned hw = (unsigned)p.Ho * p.Wo;
+  float s0 = 0.f;                                       // sum of this lane's outputs (sum_part)
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     const unsigned gp_t = pix0 + 32 * (MT * wm + m) + 4 * khalf;   // first row of this lane in the tile
@@ -537,12 +551,31 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_fast_kernel(const DcnParam
     for (int j = 0; j < NT; ++j) {
       const int co = (wn * NT + j) * 32 + (lane & 31);
       const float bv = p.bias ? p.bias[co] : 0.f;
+      if (p.out16) {
+        // 16-bit NHWC: lanes (co, co + 1) exchange one value per register pair so that every lane stores one packed 4-B word --
+        // even lanes row 2t, odd lanes row 2t + 1 (the conv kernels' phase-1 trick, without the LDS slab: 64-B runs per row)
+        const int odd = lane & 1;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const float a = acc[m][j][2 * t] + bv, c = acc[m][j][2 * t + 1] + bv;
+          const unsigned ra = ((2 * t) & 3) + 8 * ((2 * t) >> 2), rc = ((2 * t + 1) & 3) + 8 * ((2 * t + 1) >> 2);
+          s0 += gp_t + ra < total ? a : 0.f;
+          s0 += gp_t + rc < total ? c : 0.f;
+          const float send = odd ? a : c;
+          const float recv = __shfl_xor(send, 1, 64);
+          const unsigned gp = gp_t + (odd ? rc : ra);
+          const uint32_t wv = odd ? pack_a2(recv, c) : pack_a2(a, recv);
+          if (gp < total) *reinterpret_cast<uint32_t*>(p.out16 + (size_t)gp * p.opitch + p.ooff + (co & ~1)) = wv;
+        }
+        continue;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const unsigned dr = (r & 3) + 8 * (r >> 2);
         const unsigned gp = gp_t + dr;
         if (gp < total) {
           const float v = acc[m][j][r] + bv;
+          s0 += v;
           if (p.out_planar) {
             unsigned b = b_t, pin = pin_t + dr;
             while (pin >= hw) { pin -= hw; ++b; }
@@ -552,6 +585,18 @@ __global__ __launch_bounds__(DC_THREADS) void dcn_fwd_fast_kernel(const DcnParam
           }
         }
       }
+    }
+  }
+  if (p.sum_part) {      // fixed order: lane tree, then the waves one after the other -- deterministic
+    s0 = wave_sum(s0);
+    __syncthreads();     // every wave is done with the sample tiles: the LDS is free
+    float* red = reinterpret_cast<float*>(smem);
+    if (lane == 0) red[wave] = s0;
+    __syncthreads();
+    if (tid == 0) {
+      float a = 0.f;
+      for (int wv = 0; wv < DC_THREADS / 64; ++wv) a += red[wv];
+      p.sum_part[tile] = a;
     }
   }
 }
@@ -626,13 +671,15 @@ int launch_dcn_fast(const DcnParams& p, bool single, hipStream_t stream) {
     // split form (measured in round 2, see above launch_dcn_fast).
     const int pix2 = 128;
     const size_t lds2 = (size_t)2 * nch * pix2 * 16 + (size_t)2 * 3 * pix2 * 36;
-    hipLaunchKernelGGL((dcn_fwd_fast_kernel<2, 4, 2, true>), dim3((unsigned)((p.total_pix + pix2 - 1) / pix2)), dim3(DC_THREADS), lds2,
-                       stream, p);
+    const long long hw2 = (long long)p.Ho * p.Wo;
+    const unsigned blocks2 = p.sum_part ? (unsigned)(p.B * ((hw2 + pix2 - 1) / pix2)) : (unsigned)((p.total_pix + pix2 - 1) / pix2);
+    hipLaunchKernelGGL((dcn_fwd_fast_kernel<2, 4, 2, true>), dim3(blocks2), dim3(DC_THREADS), lds2, stream, p);
     return glare_launch_status();
   }
   const int pix = 64;
   const size_t lds = (size_t)2 * (single ? 1 : 2) * nch * pix * 16 + (size_t)2 * 3 * pix * 36;   // sample tiles + sampling plan
-  const unsigned blocks = (unsigned)((p.total_pix + pix - 1) / pix);
+  const long long hw = (long long)p.Ho * p.Wo;
+  const unsigned blocks = p.sum_part ? (unsigned)(p.B * ((hw + pix - 1) / pix)) : (unsigned)((p.total_pix + pix - 1) / pix);   // sum_part: tiles per image
   if (!single && nch % 2 == 0 && (p.Co == 128 || p.Co == 256)) {
 #define DCN_WN4(NT_, NCH_)                                                                                                       \
     if (p.Co == 128 * NT_ && nch == NCH_) {                                                                                       \
@@ -687,14 +734,14 @@ extern "C" int glare_mdcn_pack_weight_single_f32(const float* weight_oihw, void*
   return glare_launch_status();
 }
 
-extern "C" int glare_mdcn_forward_nhwc(const void* x, int x_is_bf16, int x_pitch, int x_off, const float* offset,
-                                       long long offset_plane, long long offset_batch_stride, const float* mask,
-                                       long long mask_plane, long long mask_batch_stride, int mask_is_logit,
-                                       const float* weight_packed, const float* bias, float* out, int out_planar,
-                                       int out_pitch, int out_off, long long out_plane, int B, int C, int H, int W, int Co,
-                                       int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int groups, int dg,
-                                       int flags, glare_stream_t stream) {
-  if (!x || !offset || !mask || !weight_packed || !out) return GLARE_ERR_INVALID;
+static int mdcn_forward_nhwc_impl(const void* x, int x_is_bf16, int x_pitch, int x_off, const float* offset,
+                                  long long offset_plane, long long offset_batch_stride, const float* mask,
+                                  long long mask_plane, long long mask_batch_stride, int mask_is_logit,
+                                  const float* weight_packed, const float* bias, float* out, int out_planar,
+                                  int out_pitch, int out_off, long long out_plane, int B, int C, int H, int W, int Co,
+                                  int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int groups, int dg,
+                                  int flags, const MdcnFusedOut* fo, glare_stream_t stream) {
+  if (!x || !offset || !mask || !weight_packed || (!out && !fo)) return GLARE_ERR_INVALID;
   const int st = dcn_check(B, C, H, W, Co, kh, kw, sh, sw, dh, dw, groups, dg);
   if (st != GLARE_OK) return st;
   if ((x_pitch % 8) || (x_off % 8) || x_off + C > x_pitch) return GLARE_ERR_UNSUPPORTED;
@@ -715,6 +762,12 @@ extern "C" int glare_mdcn_forward_nhwc(const void* x, int x_is_bf16, int x_pitch
   p.out_plane = out_plane > 0 ? out_plane : (long long)p.Ho * p.Wo;
   if (!out_planar && out_off + Co > out_pitch) return GLARE_ERR_INVALID;
   p.total_pix = (long long)B * p.Ho * p.Wo;
+  p.out16 = nullptr; p.sum_part = nullptr;
+  if (fo) {                                                        // glare_mdcn_forward_nhwc_fused
+    if (out_planar) return GLARE_ERR_UNSUPPORTED;
+    p.out = fo->out32; p.out16 = (a16_t*)fo->out16; p.sum_part = fo->sum_part;
+    if (p.out16 ? ((out_pitch % 2) || (out_off % 2)) : !p.out) return GLARE_ERR_INVALID;
+  }
   // fast path: bf16 x and every extent addressable by a 31-bit buffer offset (the out-of-range sentinel is 2^31)
   const long long LIM = 0x7fffffffLL;
   const long long x_bytes = (long long)B * H * W * x_pitch * 2;
@@ -730,9 +783,43 @@ extern "C" int glare_mdcn_forward_nhwc(const void* x, int x_is_bf16, int x_pitch
     p.wt_bytes = (unsigned)(single ? wt_bytes / 2 : wt_bytes);
     return launch_dcn_fast(p, single, (hipStream_t)stream);
   }
-  if (single) return GLARE_ERR_UNSUPPORTED;   // the single-pass form exists on the fast path only (16-bit x, 3 | kh * kw, < 2 GB tensors)
+  if (single || p.out16 || p.sum_part) return GLARE_ERR_UNSUPPORTED;   // these forms exist on the fast path only (16-bit x, 3 | kh * kw, < 2 GB tensors)
   p.x_bytes = p.off_bytes = p.mask_bytes = p.wt_bytes = 0;
   return x_is_bf16 ? launch_dcn<true>(p, (hipStream_t)stream) : launch_dcn<false>(p, (hipStream_t)stream);
+}
+
+extern "C" int glare_mdcn_forward_nhwc(const void* x, int x_is_bf16, int x_pitch, int x_off, const float* offset,
+                                       long long offset_plane, long long offset_batch_stride, const float* mask,
+                                       long long mask_plane, long long mask_batch_stride, int mask_is_logit,
+                                       const float* weight_packed, const float* bias, float* out, int out_planar,
+                                       int out_pitch, int out_off, long long out_plane, int B, int C, int H, int W, int Co,
+                                       int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int groups, int dg,
+                                       int flags, glare_stream_t stream) {
+  if (!out || (flags & ~(GLARE_MDCN_GENERAL_KERNEL | GLARE_MDCN_SINGLE_PASS))) return GLARE_ERR_INVALID;
+  return mdcn_forward_nhwc_impl(x, x_is_bf16, x_pitch, x_off, offset, offset_plane, offset_batch_stride, mask, mask_plane, mask_batch_stride,
+                                mask_is_logit, weight_packed, bias, out, out_planar, out_pitch, out_off, out_plane, B, C, H, W, Co, kh, kw, sh,
+                                sw, ph, pw, dh, dw, groups, dg, flags, nullptr, stream);
+}
+
+extern "C" int glare_mdcn_tile_pixels(int C, int Co, int dg, int flags) {
+  if (C <= 0 || Co <= 0 || dg <= 0 || C % dg) return GLARE_ERR_INVALID;
+  return ((flags & GLARE_MDCN_SINGLE_PASS) && Co / 64 == 2 && (C / dg) / 8 == 4) ? 128 : 64;     // launch_dcn_fast's tile sizes
+}
+
+// The pipeline's form of the call above (round 6): the output as 16-bit NHWC (out16, else fp32 out32) and / or the
+// per-tile sums of the fp32 outputs (tile_sums [B][ceil(Ho Wo / glare_mdcn_tile_pixels())]: the tiles are then cut per image).  Fast kernel
+// only (16-bit x, 3 | kh kw, tensors < 2 GB): GLARE_ERR_UNSUPPORTED otherwise -- the caller falls back to the plain call.
+extern "C" int glare_mdcn_forward_nhwc_fused(const void* x, int x_pitch, int x_off, const float* offset, long long offset_plane,
+                                             long long offset_batch_stride, const float* mask, long long mask_plane,
+                                             long long mask_batch_stride, int mask_is_logit, const float* weight_packed, const float* bias,
+                                             float* out32_or_null, void* out16_or_null, int out_pitch, int out_off, float* tile_sums_or_null,
+                                             int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                                             int groups, int dg, int flags, glare_stream_t stream) {
+  if ((flags & ~GLARE_MDCN_SINGLE_PASS) || (!out16_or_null && !tile_sums_or_null) || (!out16_or_null && !out32_or_null)) return GLARE_ERR_INVALID;
+  const MdcnFusedOut fo = {out16_or_null ? nullptr : out32_or_null, out16_or_null, tile_sums_or_null};
+  return mdcn_forward_nhwc_impl(x, 1, x_pitch, x_off, offset, offset_plane, offset_batch_stride, mask, mask_plane, mask_batch_stride,
+                                mask_is_logit, weight_packed, bias, nullptr, 0, out_pitch, out_off, 0, B, C, H, W, Co, kh, kw, sh, sw, ph, pw,
+                                dh, dw, groups, dg, flags, &fo, stream);
 }
 
 extern "C" size_t glare_mdcn_workspace_bytes(int B, int C, int H, int W, int Co, int kh, int kw) {

@@ -93,6 +93,90 @@ __global__ __launch_bounds__(EW_THREADS) void rescale_apply_kernel(const a16_t* 
   }
 }
 
+// ---- round 6: the mean rescale without its own statistics pass -------------------------------------------------------------------
+// sum(h) comes from the kernel that PRODUCES h (the Mix in front of the warp), sum(x_w) from the DCN's epilogue (dcn.hip, per-tile
+// sums of its fp32 outputs, tiles cut per image), a one-block-per-image kernel turns the two partial sets into the ratio, and the apply pass reads x_w as
+// the 16-bit tensor the DCN wrote (or fp32).  Same arithmetic as rescale_sum / rescale_apply above: fp64 combine, ratio in fp32.
+
+// Mix.forward + partial[b][blk] = sum of the block's ROUNDED outputs (what rescale_sum_kernel reads back); dense tensors of n_per_sample elements
+__global__ __launch_bounds__(EW_THREADS) void mix_sum_kernel(const a16_t* __restrict__ a, const a16_t* __restrict__ b, a16_t* __restrict__ out,
+                                                             long long n_per_sample, int blocks_per_sample, float f,
+                                                             const float* __restrict__ w_dev, float* __restrict__ partial) {
+  __shared__ float red[EW_THREADS / 64];
+  if (w_dev) f = 1.0f / (1.0f + expf(-w_dev[0]));
+  const int bi = blockIdx.x / blocks_per_sample, blk = blockIdx.x % blocks_per_sample;
+  const long long nvec = n_per_sample / 8;
+  const long long per = (nvec + blocks_per_sample - 1) / blocks_per_sample;
+  const long long v0 = blk * per, v1 = min(nvec, v0 + per);
+  const size_t base = (size_t)bi * n_per_sample;
+  float sh = 0.f;
+  for (long long v = v0 + threadIdx.x; v < v1; v += EW_THREADS) {
+    const u32x4 va = *reinterpret_cast<const u32x4*>(a + base + v * 8);
+    const u32x4 vb = *reinterpret_cast<const u32x4*>(b + base + v * 8);
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[e] = pack_a2(alo(va[e]) * f + alo(vb[e]) * (1.f - f), ahi(va[e]) * f + ahi(vb[e]) * (1.f - f));
+      sh += alo(o[e]) + ahi(o[e]);
+    }
+    *reinterpret_cast<u32x4*>(out + base + v * 8) = o;
+  }
+  sh = wave_sum(sh);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sh;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ratio[b] = sum(h_b) / sum(x_b) (whole_batch: one ratio from all images, written to every slot).  h_part: [B][h_bps]; x_part: the
+// DCN's per-image tile sums [B][x_tpi].  One block per image; every thread sums a fixed strided subset in fp64, the block combines in a
+// fixed order: an image's ratio depends on its own tiles only -- the same in a batch of 8 as alone.
+__global__ __launch_bounds__(256) void rescale_ratio_kernel(const float* __restrict__ h_part, int h_bps, const float* __restrict__ x_part,
+                                                            int x_tpi, int B, int whole_batch, float* __restrict__ ratio) {
+  __shared__ double red[2][256];
+  const int b = blockIdx.x;
+  const int b0 = whole_batch ? 0 : b, b1 = whole_batch ? B : b + 1;
+  double sh = 0.0, sx = 0.0;
+  for (long long i = (long long)b0 * h_bps + threadIdx.x; i < (long long)b1 * h_bps; i += 256) sh += (double)h_part[i];
+  for (long long i = (long long)b0 * x_tpi + threadIdx.x; i < (long long)b1 * x_tpi; i += 256) sx += (double)x_part[i];
+  red[0][threadIdx.x] = sh;
+  red[1][threadIdx.x] = sx;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) ratio[b] = (float)(red[0][0] / red[1][0]);
+}
+
+template <bool X16>
+__global__ __launch_bounds__(EW_THREADS) void rescale_apply2_kernel(const a16_t* __restrict__ h, const void* __restrict__ xw_,
+                                                                    const float* __restrict__ ratio, a16_t* __restrict__ out,
+                                                                    long long n_per_sample, int blocks_per_sample) {
+  const int b = blockIdx.x / blocks_per_sample, blk = blockIdx.x % blocks_per_sample;
+  const float r = ratio[b];
+  const long long nvec = n_per_sample / 8;
+  const long long per = (nvec + blocks_per_sample - 1) / blocks_per_sample;
+  const long long v0 = blk * per, v1 = min(nvec, v0 + per);
+  const size_t base = (size_t)b * n_per_sample;
+  for (long long v = v0 + threadIdx.x; v < v1; v += EW_THREADS) {
+    const u32x4 hv = *reinterpret_cast<const u32x4*>(h + base + v * 8);
+    u32x4 o;
+    if constexpr (X16) {
+      const u32x4 xv = *reinterpret_cast<const u32x4*>(reinterpret_cast<const a16_t*>(xw_) + base + v * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = pack_a2(alo(hv[e]) + alo(xv[e]) * r, ahi(hv[e]) + ahi(xv[e]) * r);
+    } else {
+      const float* xb = reinterpret_cast<const float*>(xw_) + base + v * 8;
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(xb), x1 = *reinterpret_cast<const f32x4*>(xb + 4);
+      o[0] = pack_a2(alo(hv[0]) + x0[0] * r, ahi(hv[0]) + x0[1] * r);
+      o[1] = pack_a2(alo(hv[1]) + x0[2] * r, ahi(hv[1]) + x0[3] * r);
+      o[2] = pack_a2(alo(hv[2]) + x1[0] * r, ahi(hv[2]) + x1[1] * r);
+      o[3] = pack_a2(alo(hv[3]) + x1[2] * r, ahi(hv[3]) + x1[3] * r);
+    }
+    *reinterpret_cast<u32x4*>(out + base + v * 8) = o;
+  }
+}
+
 // [B][C][HW] (fp32) <-> [B][HW][C] (fp32 or bf16) through a 32 x 33 LDS tile.
 template <bool TO_NHWC, bool BF16>
 __global__ __launch_bounds__(256) void layout_kernel(const void* __restrict__ src, void* __restrict__ dst, int C,
@@ -219,6 +303,39 @@ extern "C" int glare_mean_rescale_bf16(const void* h, const float* xw, void* out
                      n_per_sample, bps);
   hipLaunchKernelGGL(rescale_apply_kernel, dim3(B * bps), dim3(EW_THREADS), 0, stream, (const a16_t*)h, xw,
                      (const float*)workspace, (a16_t*)out, n_per_sample, bps, B, whole_batch_mean);
+  return glare_launch_status();
+}
+
+extern "C" int glare_mix_sum_blocks(long long n_per_sample) { return n_per_sample <= 0 ? 0 : rescale_bps(n_per_sample); }
+
+extern "C" int glare_mix_sum_bf16(const void* a, const void* b, void* out, int B, long long n_per_sample, float mix_w,
+                                  const float* mix_w_dev_or_null, float* sum_partial, glare_stream_t stream) {
+  if (!a || !b || !out || !sum_partial || B <= 0 || n_per_sample <= 0) return GLARE_ERR_INVALID;
+  if (n_per_sample % 8) return GLARE_ERR_UNSUPPORTED;
+  const int bps = rescale_bps(n_per_sample);
+  const float f = 1.0f / (1.0f + expf(-mix_w));
+  hipLaunchKernelGGL(mix_sum_kernel, dim3(B * bps), dim3(EW_THREADS), 0, (hipStream_t)stream, (const a16_t*)a, (const a16_t*)b, (a16_t*)out,
+                     n_per_sample, bps, f, mix_w_dev_or_null, sum_partial);
+  return glare_launch_status();
+}
+
+extern "C" int glare_mean_rescale_fused_bf16(const void* h, const void* xw, int xw_is_16bit, void* out, int B, long long n_per_sample,
+                                             long long pixels_per_sample, const float* h_sum_partial, const float* xw_tile_sums, int tile_pixels,
+                                             int whole_batch_mean, float* ratio_scratch, glare_stream_t stream_) {
+  if (!h || !xw || !out || !h_sum_partial || !xw_tile_sums || !ratio_scratch || B <= 0 || n_per_sample <= 0 || pixels_per_sample <= 0 ||
+      tile_pixels <= 0)
+    return GLARE_ERR_INVALID;
+  if (n_per_sample % 8) return GLARE_ERR_UNSUPPORTED;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int bps = rescale_bps(n_per_sample);
+  hipLaunchKernelGGL(rescale_ratio_kernel, dim3(B), dim3(256), 0, stream, h_sum_partial, bps, xw_tile_sums,
+                     (int)cdivll(pixels_per_sample, tile_pixels), B, whole_batch_mean, ratio_scratch);
+  if (xw_is_16bit)
+    hipLaunchKernelGGL(rescale_apply2_kernel<true>, dim3(B * bps), dim3(EW_THREADS), 0, stream, (const a16_t*)h, xw, (const float*)ratio_scratch,
+                       (a16_t*)out, n_per_sample, bps);
+  else
+    hipLaunchKernelGGL(rescale_apply2_kernel<false>, dim3(B * bps), dim3(EW_THREADS), 0, stream, (const a16_t*)h, xw, (const float*)ratio_scratch,
+                       (a16_t*)out, n_per_sample, bps);
   return glare_launch_status();
 }
 

@@ -21,6 +21,12 @@ import os
 # precision into ONE half-precision MFMA per product (GLARE_MDCN_SINGLE_PASS: the arithmetic of every other convolution of the decoder;
 # 1.1-1.5e-4 of max|out| against the split form, -0.9 / -0.6 ms per launch) -- an A/B switch, never the default (round 4).
 DCN_SINGLE_PASS = os.environ.get("GLARE_DCN_SINGLE_PASS", "0") == "1"
+# Round 6: inside the AFT decoder the warp's output x_w leaves the DCN kernel as a 16-bit tensor (rounded once from the fp32 accumulator;
+# its only consumer, h + x_w * mean(h) / mean(x_w), rounds the sum to 16 bits anyway) and the two means of that rescale come from the
+# producers' epilogues (Mix, DCN) instead of a pass over both tensors.  GLARE_DCN_OUT_16BIT=0: fp32 x_w (the sums stay fused);
+# GLARE_RESCALE_FUSED=0: rounds 1-5's form (fp32 x_w, mean_rescale's own statistics pass).  The op-level API is unchanged (fp32 out).
+DCN_OUT_16BIT = os.environ.get("GLARE_DCN_OUT_16BIT", "1") == "1"
+RESCALE_FUSED = os.environ.get("GLARE_RESCALE_FUSED", "1") == "1"
 
 
 class DCNv2Pack(ModulatedDeformConvPack, HipModule):
@@ -33,13 +39,29 @@ class DCNv2Pack(ModulatedDeformConvPack, HipModule):
         return modulated_deform_conv(x.float(), offset, torch.sigmoid(mask), self.weight, self.bias, self.stride,
                                      self.padding, self.dilation, self.groups, self.deformable_groups)
 
-    def forward_nhwc(self, x, feat, x_off=0):
+    def forward_nhwc(self, x, feat, x_off=0, fused=False):
         """x: bf16 NHWC (the VQ-decoder feature), feat: bf16 NHWC.  conv_offset writes offsets and mask
-        logits as fp32 planes; the DCN kernel applies the sigmoid while sampling.  -> fp32 NHWC."""
+        logits as fp32 planes; the DCN kernel applies the sigmoid while sampling.  -> fp32 NHWC.
+        fused (round 6, the AFT decoder's call): -> (x_w, tile sums of its fp32 values, tile pixels) with x_w 16-bit when
+        DCN_OUT_16BIT -- the DCN's epilogue feeds the mean rescale behind the warp; None where the lean kernel does not apply."""
         B, H, W, _ = feat.shape
         plane = (H * W + 63) // 64 * 64
         om = ops.conv2d(feat, packed_conv(self, self.conv_offset), out_mode=ops.OUT_PLANAR_F32, plane_pitch=plane)
         single = DCN_SINGLE_PASS and ops.precision() == "fp16" and x.dtype == torch.float16
+        if fused and x.dtype == ops.act_dtype():
+            pdf = (self._packed("dcn1", lambda: ops.PackedDcn(self.weight, self.bias, self.deformable_groups, single=True)) if single else
+                   self._packed("dcn", lambda: ops.PackedDcn(self.weight, self.bias, self.deformable_groups, single=False)))
+            try:
+                return ops.mdcn_forward_nhwc_fused(x, om, pdf, x_off=x_off, C=self.in_channels, mask_is_logit=True, padding=self.padding,
+                                                   out16=DCN_OUT_16BIT)
+            except _lib.GlareError as e:          # outside the lean kernel's shapes: the plain call below, sums by mean_rescale's own pass
+                if e.status != _lib.ERR_UNSUPPORTED:
+                    raise
+        if fused:
+            return self._forward_plain(x, om, x_off, single), None, 0
+        return self._forward_plain(x, om, x_off, single)
+
+    def _forward_plain(self, x, om, x_off, single):
         if single:
             # the single-pass form lives in the fast kernel only (every tensor < 2 GB, < 2^31 pixels): shapes beyond it -- batch ~20 at
             # 400x600, a few 1080p images -- take the split form, whose call falls through to the general-extent kernel
@@ -63,9 +85,9 @@ class WarpBlock(HipModule):
         self.offset = nn.Conv2d(in_channel * 2, in_channel, 3, stride=1, padding=1)
         self.dcn = DCNv2Pack(in_channel, in_channel, 3, padding=1, deformable_groups=4)
 
-    def forward_nhwc(self, x_vq, x_residual):
+    def forward_nhwc(self, x_vq, x_residual, fused=False):
         r = ops.conv2d(x_vq, packed_conv(self, self.offset), x2=x_residual)  # torch.cat fused: two conv sources
-        return self.dcn.forward_nhwc(x_vq, r)
+        return self.dcn.forward_nhwc(x_vq, r, fused=fused)
 
     def train_nhwc(self, x_vq, x_residual):
         return self.dcn.train_nhwc(x_vq, conv_t(x_vq, self.offset, x2=x_residual))
@@ -80,9 +102,12 @@ class Mix(HipModule):
         self.w = nn.Parameter(torch.FloatTensor([m]))
         self.mix_block = nn.Sigmoid()
 
-    def forward_nhwc(self, fea1, fea2):
+    def forward_nhwc(self, fea1, fea2, with_sums=False):
         # the scalar is read back once (cached with the packed weights): no host sync inside the launch sequence
-        return ops.mix(fea1, fea2, self._packed("w", lambda: float(self.w.detach())))
+        w = self._packed("w", lambda: float(self.w.detach()))
+        if with_sums:          # + the per-block sums of the result: mean(h) of the rescale behind the warp (ops.mix_with_sums)
+            return ops.mix_with_sums(fea1, fea2, w)
+        return ops.mix(fea1, fea2, w)
 
     def train_nhwc(self, fea1, fea2):
         return A.mix(fea1, fea2, self.w)
@@ -136,9 +161,18 @@ class MultiScaleDecoder2(HipModule):
                     h = lvl.attn[i_block].forward_nhwc(h)
             if i_level != 2:  # :546-567
                 x_code = code_feats[1 - i_level]
-                h = self.mix[1 - i_level].forward_nhwc(enc_feats[i_level], h)
-                x_w = self.warp[1 - i_level].forward_nhwc(x_code, h)
-                h = ops.mean_rescale(h, x_w, whole_batch=self.whole_batch_mean)
+                e = enc_feats[i_level]
+                if RESCALE_FUSED and e.is_contiguous() and h.is_contiguous() and e.shape == h.shape:
+                    h, h_sums = self.mix[1 - i_level].forward_nhwc(e, h, with_sums=True)
+                    x_w, x_sums, tile = self.warp[1 - i_level].forward_nhwc(x_code, h, fused=True)
+                    if x_sums is not None:
+                        h = ops.mean_rescale_fused(h, x_w, h_sums, x_sums, tile, whole_batch=self.whole_batch_mean)
+                    else:
+                        h = ops.mean_rescale(h, x_w, whole_batch=self.whole_batch_mean)
+                else:
+                    h = self.mix[1 - i_level].forward_nhwc(e, h)
+                    x_w = self.warp[1 - i_level].forward_nhwc(x_code, h)
+                    h = ops.mean_rescale(h, x_w, whole_batch=self.whole_batch_mean)
             if i_level != 0:
                 h = lvl.upsample.forward_nhwc(h)
         h = gn_swish(h, self.norm_out)

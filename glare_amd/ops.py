@@ -1098,6 +1098,68 @@ def _mdcn_forward_nhwc_launch(x, om, pd, out, mask, pitch, x_off, plane, mask_is
     return out
 
 
+def mdcn_forward_nhwc_fused(x, om, pd, x_off=0, C=None, mask_is_logit=True, padding=1, out16=True, want_sums=True):
+    """The pipeline's DCN call (glare_mdcn_forward_nhwc_fused, round 6): the output as a 16-bit NHWC tensor (out16) and / or the per-tile
+    sums of its fp32 values for the mean rescale that follows.  Returns (out, tile_sums or None, tile_pixels).  Raises GlareError with
+    status ERR_UNSUPPORTED outside the lean kernel's shapes -- the caller then takes mdcn_forward_nhwc + mean_rescale."""
+    require_cuda(x, om)
+    assert x.dtype == act_dtype(), (x.dtype, act_dtype())
+    B, H, W, pitch = x.shape
+    C = pd.c if C is None else C
+    K = pd.kh * pd.kw
+    plane = om.shape[2]
+    flags = 0
+    if getattr(pd, "single", False):
+        assert pd.packed.dtype == act_dtype()
+        flags |= MDCN_SINGLE_PASS
+    lib = _lib.lib()
+    tile = int(lib.glare_mdcn_tile_pixels(_i(C), _i(pd.co), _i(pd.dg), _i(flags)))
+    out = torch.empty(B, H, W, pd.co, dtype=act_dtype() if out16 else torch.float32, device=x.device)
+    sums = torch.empty(B, (H * W + tile - 1) // tile, dtype=torch.float32, device=x.device) if want_sums else None   # tiles cut per image
+    mask = om[:, 2 * pd.dg * K:]
+    with _timed_launch("dcn", 2.0 * B * H * W * C * pd.co * K + 8.0 * K * B * H * W * C,      # SURVEY 8d: contraction + sampling; bytes as the fp32-output form
+                       2.0 * B * H * W * C + 4.0 * B * H * W * (3 * pd.dg * K + pd.co) + 4.0 * pd.co * C * K):
+        check(lib.glare_mdcn_forward_nhwc_fused(ptr(x), _i(pitch), _i(x_off), ptr(om), _ll(plane), _ll(om.shape[1] * plane),
+                                                ctypes.c_void_p(mask.data_ptr()), _ll(plane), _ll(om.shape[1] * plane), _i(int(mask_is_logit)),
+                                                ptr(pd.packed), ptr(pd.bias), ptr(None if out16 else out), ptr(out if out16 else None), _i(pd.co),
+                                                _i(0), ptr(sums), _i(B), _i(C), _i(H), _i(W), _i(pd.co), _i(pd.kh), _i(pd.kw), _i(1), _i(1),
+                                                _i(padding), _i(padding), _i(1), _i(1), _i(1), _i(pd.dg), _i(flags), stream_handle()),
+              "glare_mdcn_forward_nhwc_fused")
+    return out, sums, tile
+
+
+def mix_with_sums(a, b, w):
+    """Mix.forward on dense tensors + the per-block sums of the rounded output (glare_mix_sum_bf16): (out, sums [B * blocks])."""
+    require_cuda(a, b)
+    assert a.dtype == b.dtype == act_dtype() and a.shape == b.shape and a.is_contiguous() and b.is_contiguous()
+    B = a.shape[0]
+    n = a.numel() // B
+    lib = _lib.lib()
+    bps = int(lib.glare_mix_sum_blocks(_ll(n)))
+    out = torch.empty_like(a)
+    sums = torch.empty(B * bps, dtype=torch.float32, device=a.device)
+    wdev = w.detach().float().reshape(1) if torch.is_tensor(w) else None
+    check(lib.glare_mix_sum_bf16(ptr(a), ptr(b), ptr(out), _i(B), _ll(n), _f(0.0 if wdev is not None else float(w)), ptr(wdev), ptr(sums),
+                                 stream_handle()), "glare_mix_sum_bf16")
+    return out, sums
+
+
+def mean_rescale_fused(h, xw, h_sums, xw_tile_sums, tile_pixels, whole_batch=False):
+    """h + xw * (mean(h) / mean(xw)) from sums gathered by the producers (mix_with_sums, mdcn_forward_nhwc_fused): one tiny ratio launch
+    + the apply pass; xw fp32 or 16-bit."""
+    require_cuda(h, xw, h_sums, xw_tile_sums)
+    assert h.dtype == act_dtype() and xw.dtype in (torch.float32, act_dtype()) and h.shape == xw.shape and h.is_contiguous() and xw.is_contiguous()
+    B = h.shape[0]
+    n = h.numel() // B
+    pix = n // h.shape[-1]
+    out = torch.empty_like(h)
+    ratio = torch.empty(B, dtype=torch.float32, device=h.device)
+    check(_lib.lib().glare_mean_rescale_fused_bf16(ptr(h), ptr(xw), _i(int(xw.dtype != torch.float32)), ptr(out), _i(B), _ll(n), _ll(pix),
+                                                   ptr(h_sums), ptr(xw_tile_sums), _i(tile_pixels), _i(int(whole_batch)), ptr(ratio),
+                                                   stream_handle()), "glare_mean_rescale_fused_bf16")
+    return out
+
+
 def flow_blocks_per_sample(pixels_per_sample):
     return int(_lib.lib().glare_flow_blocks_per_sample(_ll(pixels_per_sample)))
 

@@ -259,6 +259,17 @@ int glare_mix_bf16(const void* a, int a_pitch, int a_off, const void* b, int b_p
 size_t glare_mean_rescale_workspace_bytes(int B, long long n_per_sample);
 int glare_mean_rescale_bf16(const void* h, const float* xw, void* out, int B, long long n_per_sample,
                             int whole_batch_mean, void* workspace, size_t workspace_bytes, glare_stream_t stream);
+/* The same rescale WITHOUT its own statistics pass (round 6): sum(h) from the kernel that produces h -- glare_mix_sum_bf16 = Mix.forward on
+ * dense [B][n_per_sample] tensors + sum_partial[B * glare_mix_sum_blocks(n)] (per-block sums of the ROUNDED outputs; mix_w_dev != NULL: the
+ * logit read on the device) --, sum(xw) from the DCN's epilogue (glare_mdcn_forward_nhwc_fused: per-tile sums of its fp32 outputs).
+ * glare_mean_rescale_fused_bf16: ratio per image (or whole batch) in fp64 from the two partial sets, then out = h + xw * ratio with xw
+ * fp32 or 16-bit (xw_is_16bit); ratio_scratch: fp32 [B]; tile_pixels = glare_mdcn_tile_pixels() of the DCN launch that wrote xw_tile_sums. */
+int glare_mix_sum_blocks(long long n_per_sample);
+int glare_mix_sum_bf16(const void* a, const void* b, void* out, int B, long long n_per_sample, float mix_w, const float* mix_w_dev_or_null,
+                       float* sum_partial, glare_stream_t stream);
+int glare_mean_rescale_fused_bf16(const void* h, const void* xw, int xw_is_16bit, void* out, int B, long long n_per_sample,
+                                  long long pixels_per_sample, const float* h_sum_partial, const float* xw_tile_sums, int tile_pixels,
+                                  int whole_batch_mean, float* ratio_scratch, glare_stream_t stream);
 
 /* Layout conversion at the module boundary: the reference's tensors are NCHW fp32. */
 int glare_nchw_to_nhwc(const float* src_nchw, void* dst_nhwc, int B, int C, long long HW, int dst_pitch, int dst_off,
@@ -440,6 +451,17 @@ int glare_mdcn_forward_nhwc(const void* x, int x_is_bf16, int x_pitch, int x_off
                             const float* weight_packed, const float* bias, float* out, int out_planar, int out_pitch,
                             int out_off, long long out_plane, int B, int C, int H, int W, int Co, int kh, int kw, int sh,
                             int sw, int ph, int pw, int dh, int dw, int groups, int dg, int flags, glare_stream_t stream);
+/* The pipeline's form (round 6; the lean kernel only: 16-bit x, 3 | kh kw, every tensor < 2 GB -- GLARE_ERR_UNSUPPORTED
+ * otherwise, the caller then uses the call above): the output as 16-bit NHWC (out16 != NULL: rounded once from the fp32 accumulator +
+ * bias; else fp32 out32) and / or tile_sums [B][ceil(Ho Wo / glare_mdcn_tile_pixels(C, Co, dg, flags))] = per pixel tile the sum of
+ * its fp32 outputs -- the tiles are then cut PER IMAGE (the last one ragged), so an image's sums are the same in any batch: mean(x_w)
+ * of the rescale that follows the warp (deformableDecoder_arch.py:567) without another pass.  flags: 0 or GLARE_MDCN_SINGLE_PASS. */
+int glare_mdcn_tile_pixels(int C, int Co, int dg, int flags);
+int glare_mdcn_forward_nhwc_fused(const void* x, int x_pitch, int x_off, const float* offset, long long offset_plane,
+                                  long long offset_batch_stride, const float* mask, long long mask_plane, long long mask_batch_stride,
+                                  int mask_is_logit, const float* weight_packed, const float* bias, float* out32_or_null, void* out16_or_null,
+                                  int out_pitch, int out_off, float* tile_sums_or_null, int B, int C, int H, int W, int Co, int kh, int kw,
+                                  int sh, int sw, int ph, int pw, int dh, int dw, int groups, int dg, int flags, glare_stream_t stream);
 /* glare_mdcn_forward_nhwc picks between two MFMA kernels with the same arithmetic: the general-extent one (fp32 or bf16 x) and a
  * leaner one for bf16 x when every tensor is < 2 GB and kh*kw % 3 == 0.  `flags` & GLARE_MDCN_GENERAL_KERNEL pins the former for
  * this call (a per-call argument: the library keeps no state; tests compare the two kernels on one input with it). */

@@ -341,3 +341,66 @@ def test_pack_modules_run_conv_offset_on_the_hip_kernels(monkeypatch):
         y2 = m(x.requires_grad_(True))                     # with a tape: the DCN form, gradients reach conv_offset
         y2.sum().backward()
         assert m.conv_offset.weight.grad is not None and float(m.conv_offset.weight.grad.abs().sum()) > 0
+
+
+# ---- round 6: the pipeline's form of the call -- 16-bit output and per-tile sums from the epilogue, the mean rescale fed by them ------
+def _nhwc_case(seed, B, C, H, W, precision):
+    g = torch.Generator().manual_seed(seed)
+    with ops.use_precision(precision):
+        x = (torch.randn(B, H, W, C, generator=g) * 0.7).to(ops.act_dtype()).cuda()
+        plane = (H * W + 63) // 64 * 64
+        om = torch.zeros(B, 108, plane)
+        om[:, :72, :H * W] = torch.randn(B, 72, H * W, generator=g) * 2.0
+        om[:, 72:, :H * W] = torch.randn(B, 36, H * W, generator=g)
+        w = torch.randn(C, C, 3, 3, generator=g) * (1.0 / (C * 9) ** 0.5)
+        b = torch.randn(C, generator=g) * 0.3 + 0.2
+    return x, om.cuda(), w.cuda(), b.cuda()
+
+
+@pytest.mark.parametrize("B,C,H,W", [(3, 128, 13, 21), (2, 256, 12, 17), (1, 128, 16, 8)])
+@pytest.mark.parametrize("precision,single", [("fp16", False), ("fp16", True), ("bf16", False)])
+def test_fused_epilogue_is_the_plain_output_rounded_once_and_summed(B, C, H, W, precision, single):
+    """glare_mdcn_forward_nhwc_fused against glare_mdcn_forward_nhwc on the same launch shape: the 16-bit output is the fp32 output
+    rounded once (bit for bit -- same accumulators), the tile sums add up to the fp32 output's per-image sums (ragged last tiles:
+    13 * 21 = 273 pixels per image against 64- / 128-pixel tiles), and an image's sums do not depend on the batch it sits in."""
+    x, om, w, b = _nhwc_case(B * 100 + C + H, B, C, H, W, precision)
+    with ops.use_precision(precision):
+        pd = ops.PackedDcn(w, b, 4, single=single)
+        ref = ops.mdcn_forward_nhwc(x, om, pd)
+        out16, sums, tile = ops.mdcn_forward_nhwc_fused(x, om, pd, out16=True, want_sums=True)
+        out32, sums2, _ = ops.mdcn_forward_nhwc_fused(x, om, pd, out16=False, want_sums=True)
+        assert out16.dtype == ops.act_dtype() and torch.equal(out16, ref.to(ops.act_dtype()))
+        assert torch.equal(out32, ref) and torch.equal(sums, sums2)
+        assert tuple(sums.shape) == (B, (H * W + tile - 1) // tile)               # tiles are cut per image (the last one ragged)
+        per_img = sums.double().sum(dim=1).cpu()
+        want = ref.double().sum(dim=(1, 2, 3)).cpu()
+        assert float(((per_img - want).abs() / want.abs()).max()) < 2e-6
+        one16, one_sums, _ = ops.mdcn_forward_nhwc_fused(x[B - 1:].contiguous(), om[B - 1:].contiguous(), pd)       # the last image alone
+        assert torch.equal(one16[0], out16[B - 1]) and torch.equal(one_sums[0], sums[B - 1])
+        # the rescale fed by the producers' sums == the rescale with its own statistics pass (fp32 x_w), and its 16-bit-x_w form
+        g = torch.Generator().manual_seed(7)
+        e = (torch.randn(B, H, W, C, generator=g) * 0.5 + 0.3).to(ops.act_dtype()).cuda()
+        h0 = (torch.randn(B, H, W, C, generator=g) * 0.5 + 0.3).to(ops.act_dtype()).cuda()
+        h, hs = ops.mix_with_sums(e, h0, -0.6)
+        assert torch.equal(h, ops.mix(e, h0, -0.6))
+        for whole in (False, True):
+            old = ops.mean_rescale(h, ref, whole_batch=whole)
+            new32 = ops.mean_rescale_fused(h, out32, hs, sums, tile, whole_batch=whole)
+            new16 = ops.mean_rescale_fused(h, out16, hs, sums, tile, whole_batch=whole)
+            ulp = 2.0 ** (-10 if precision == "fp16" else -7)
+            d32 = (new32.float() - old.float()).abs() / old.float().abs().clamp_min(1e-3)
+            assert float(d32.max()) <= 1.01 * ulp and float((d32 > 0).float().mean()) < 1e-3      # the ratio's summation order: rare 1-ulp flips
+            ratio = (h.double().sum(dim=(1, 2, 3)) if not whole else h.double().sum().expand(B)) / (ref.double().sum(dim=(1, 2, 3)) if not whole else ref.double().sum().expand(B))
+            want16 = (h.double() + out16.double() * ratio.view(B, 1, 1, 1)).float()
+            d16 = (new16.float() - want16).abs() / want16.abs().clamp_min(1e-3)
+            assert float(d16.max()) <= 1.01 * ulp
+
+
+def test_fused_call_on_images_smaller_than_a_tile():
+    x, om, w, b = _nhwc_case(1, 3, 128, 5, 7, "fp16")        # 35 pixels per image: one ragged 64-pixel tile each
+    with ops.use_precision("fp16"):
+        pd = ops.PackedDcn(w, b, 4)
+        ref = ops.mdcn_forward_nhwc(x, om, pd)
+        out16, sums, tile = ops.mdcn_forward_nhwc_fused(x, om, pd)
+        assert torch.equal(out16, ref.to(torch.float16)) and tuple(sums.shape) == (3, 1)
+        assert float(((sums[:, 0].double().cpu() - ref.double().sum(dim=(1, 2, 3)).cpu()).abs() / ref.double().sum(dim=(1, 2, 3)).cpu().abs()).max()) < 2e-6

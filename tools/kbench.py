@@ -311,6 +311,34 @@ def bench_conv1x1():
                   % (name, t[False][0], t[True][0], t[False][1], t[True][1], t[False][2], t[True][2], t[False][3], t[True][3]))
 
 
+def bench_winograd():
+    """VERDICT r05 item 5, step 2 priced with the kernels that exist: F(2x2, 3x3) on 256 -> 256 @half (8 x 210 x 310) is 16 independent
+    [T x 256] . [256 x 256] products over T = 8 x 105 x 155 tiles (2.25x fewer MACs than the direct conv) between an input transform that
+    writes 4x the activation bytes and an output transform that reads 4x the output bytes.  Measured: the direct single-pass conv, and the
+    16 products alone as ONE batched launch of gemm_nt (16-bit in / out, operands resident: no transform cost at all).  A fused Winograd
+    kernel has to beat the direct conv by 1.5x INCLUDING both transforms; the products alone bound what is left for them."""
+    from glare_amd import train_ops as T
+    with ops.use_precision("fp16"):
+        h, w, c = 210, 310, 256
+        x = (torch.randn(B, h, w, c, device=DEV) * 0.5).to(torch.float16)
+        pc = ops.PackedConv(torch.randn(c, c, 3, 3, device=DEV) * 0.02, torch.zeros(c, device=DEV))
+        out = torch.empty(B, h, w, c, dtype=torch.float16, device=DEV)
+        ms_d = timeit(lambda: ops.conv2d(x, pc, out=out))
+        fl_d = 2.0 * B * h * w * c * c * 9
+        tiles = B * (h // 2) * (w // 2)
+        V = (torch.randn(16, tiles, c, device=DEV) * 0.5).to(torch.float16)
+        U = (torch.randn(16, c, c, device=DEV) * 0.02).to(torch.float16)
+        M = torch.empty(16, tiles, c, dtype=torch.float16, device=DEV)
+        ms_g = timeit(lambda: T.gemm_nt(V, U, out=M, out_dtype=torch.float16))
+        fl_g = 2.0 * 16 * tiles * c * c
+        act = B * h * w * c * 2.0
+        print("winograd 256->256 @half: direct conv %.3f ms (%.0f TFLOP/s) | the 16 Winograd products alone, one batched gemm_nt: %.3f ms (%.0f TFLOP/s on "
+              "%.0f GFLOP = 1/2.25 of the direct conv's) | a 1.5x win needs <= %.3f ms in all: %.3f ms left for an input transform writing %.2f GB and an output "
+              "transform reading %.2f GB if they went through HBM (%.3f ms at 5 TB/s)"
+              % (ms_d, fl_d / ms_d / 1e9, ms_g, fl_g / ms_g / 1e9, fl_g / 1e9, ms_d / 1.5, ms_d / 1.5 - ms_g, 4 * act / 1e9, 4 * act / 1e9,
+                 (act + 4 * act + 4 * act + act) / 5e12 * 1e3))
+
+
 def bench_flow():
     """The flow's reverse pass at the path's latent size (8 x 105 x 155): round 6's fused step (one launch) against rounds 1-5's
     four launches per step, fp32-class (pair cond_feat) in fp16."""
