@@ -191,6 +191,34 @@ extern "C" int glare_conv2d_cout_tile(int B, int OH, int OW, int cout) {
   return 32;
 }
 
+// Rounding of a filter to the library's 16-bit format WITH ERROR FEEDBACK along the flattened (cin, ky, kx) axis of every output channel
+// (round 6): q_i = round16(w_i + carry), carry = (w_i + carry) - q_i.  Every weight stays within one 16-bit ulp OF THE CHANNEL'S LARGEST
+// WEIGHTS of its value (|error| <= 1/2 ulp + |carry|) and the SUM of an output channel's rounding errors stays below half such an ulp, where round-to-nearest leaves a random walk of ~sqrt(n) / 3.5 ulps:
+// a filter's rounding error is the same perturbation at EVERY pixel (a coherent gain / offset error of the output channel), which is what
+// stages D / E lose against the fp32 reference (tools/winograd_study.py: filters kept in fp32 0.0002-0.0018 dB, rounded 0.015-0.018;
+// tools/filter_rounding_study.py: this rounding 0.001-0.008).  Output: fp32 values that ARE 16-bit numbers (the pack kernels' own
+// rounding is then exact).  One thread per output channel; a pack-time kernel (once per weight set).
+__global__ void filter_feedback_kernel(const float* __restrict__ w, float* __restrict__ out, int K, long long n) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  const float* src = w + (size_t)k * n;
+  float* dst = out + (size_t)k * n;
+  double carry = 0.0;
+  for (long long i = 0; i < n; ++i) {
+    const double t = (double)src[i] + carry;
+    const float q = a2f(f2a((float)t));
+    dst[i] = q;
+    carry = t - (double)q;
+  }
+}
+
+extern "C" int glare_filter_feedback_round_bf16(const float* w_oihw, float* out_oihw, int cout, long long elems_per_cout, glare_stream_t stream) {
+  if (!w_oihw || !out_oihw || cout <= 0 || elems_per_cout <= 0) return GLARE_ERR_INVALID;
+  hipLaunchKernelGGL(filter_feedback_kernel, dim3((unsigned)cdiv(cout, 64)), dim3(64), 0, (hipStream_t)stream, w_oihw, out_oihw, cout,
+                     elems_per_cout);
+  return glare_launch_status();
+}
+
 extern "C" int glare_conv2d_pack_weight(const float* w_oihw, int cout, int cin_total, int ksize, void* packed_bf16,
                                         glare_stream_t stream) {
   const long long total = glare_conv2d_packed_weight_elems(cout, cin_total, ksize);

@@ -35,6 +35,10 @@ def packed_conv(mod, conv, key=None, scale=None, split=0):
         if scale is not None:
             w = w * scale
             b = None if b is None else b * scale
+        if not split and ops.FILTER_FEEDBACK and w.dim() == 4 and w.shape[1] >= 8:
+            # a single-pass 16-bit filter of the inference path: rounded with error feedback per output channel (ops.filter_feedback_round);
+            # the fp32-class filters (split) are hi / lo pairs and keep 22 bits anyway
+            w = ops.filter_feedback_round(w)
         return ops.PackedConv(w, b, split=split)
 
     return mod._packed(key, build)

@@ -75,6 +75,23 @@ def split_filter(w, split, reuse_kc=0):
     return torch.cat([w, w, lo] if split == 3 else [w, lo], dim=-3).contiguous()
 
 
+# Round 6: inference rounds its single-pass 16-bit filters with error feedback (csrc/conv_igemm.hip filter_feedback_kernel) instead of
+# round-to-nearest per weight: each weight within one ulp of the channel's largest weights, the rounding errors of an output channel summing
+# to < 1/2 ulp (round-to-nearest: a random walk) -- the coherent per-channel gain error is what stages D / E lost (profiles/r06_filter_feedback.txt).
+# GLARE_FILTER_FEEDBACK=0: round-to-nearest (rounds 1-5).
+FILTER_FEEDBACK = os.environ.get("GLARE_FILTER_FEEDBACK", "1") == "1"
+
+
+def filter_feedback_round(w):
+    """fp32 [cout, ...] filter -> fp32 tensor of 16-bit-representable values (current precision), error feedback along the trailing axes."""
+    require_cuda(w)
+    w = w.detach().float().contiguous()
+    out = torch.empty_like(w)
+    check(_lib.lib().glare_filter_feedback_round_bf16(ptr(w), ptr(out), _i(w.shape[0]), _ll(w.numel() // w.shape[0]), stream_handle()),
+          "glare_filter_feedback_round_bf16")
+    return out
+
+
 class PackedConv:
     """A conv filter packed once for the MFMA kernel (weights bf16 stage-ordered, bias fp32)."""
 

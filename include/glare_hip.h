@@ -152,6 +152,11 @@ long long glare_conv2d_packed_weight_elems_tile(int cout, int cin_total, int ksi
 /* Number of bf16 elements of the packed weight image for an OIHW [cout][cin_total][k][k] filter. */
 long long glare_conv2d_packed_weight_elems(int cout, int cin_total, int ksize);
 /* Packs fp32 OIHW weights (device) into the kernel's stage-ordered bf16 image (device). */
+/* Filter rounding with error feedback (round 6): out = the filter rounded to the library's 16-bit format (as fp32 values) with the rounding
+ * error of each weight carried into the next along (cin, ky, kx) of its output channel -- every weight within one 16-bit ulp of the
+ * channel's largest weights, the sum of a channel's errors below half such an ulp.  A filter's rounding is the same perturbation at every pixel; this keeps each output channel's
+ * response to the input's mean exact.  Inference packs its single-pass filters from this (glare_amd.modules._base.packed_conv). */
+int glare_filter_feedback_round_bf16(const float* w_oihw, float* out_oihw, int cout, long long elems_per_cout, glare_stream_t stream);
 int glare_conv2d_pack_weight(const float* w_oihw, int cout, int cin_total, int ksize, void* packed_bf16,
                              glare_stream_t stream);
 /* Packs the filter of the DATA-GRADIENT convolution straight from the forward OIHW filter: w'[ci][co][tap] =

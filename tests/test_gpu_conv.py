@@ -508,3 +508,33 @@ def test_exp_activation_without_residual_excludes_the_slab_epilogue_features():
     res = (torch.randn(1, 16, 32, 128, generator=g) * 0.5).to(ops.act_dtype()).cuda()
     out = ops.conv2d(x, pc, act="swish", residual=res, gn_stats=True)            # with a residual the slab epilogue applies it: allowed
     assert hasattr(out, "_gn_stats") and bool(torch.isfinite(out.float()).all())
+
+
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+def test_filter_feedback_rounding(precision):
+    """ops.filter_feedback_round (round 6): the inference filters' rounding with error feedback per output channel -- bit for bit the
+    sequential definition (q_i = round16(w_i + carry), carry = (w_i + carry) - q_i in double), every weight within one 16-bit ulp OF THE
+    CHANNEL'S LARGEST WEIGHTS of its value (a tiny weight inherits the carry of its big neighbour), and the sum of a channel's rounding
+    errors below half such an ulp (round-to-nearest: a random walk of sqrt(n) / 3.5 ulps)."""
+    g = torch.Generator().manual_seed(2)
+    w = torch.randn(24, 40, 3, 3, generator=g) * 0.03
+    with ops.use_precision(precision):
+        dt = ops.act_dtype()
+        got = ops.filter_feedback_round(w.cuda()).cpu()
+    flat = w.reshape(24, -1).double()
+    want = torch.empty_like(flat)
+    carry = torch.zeros(24, dtype=torch.float64)
+    for i in range(flat.shape[1]):
+        t = flat[:, i] + carry
+        q = t.float().to(dt).double()
+        want[:, i] = q
+        carry = t - q
+    assert torch.equal(got.reshape(24, -1).double(), want)
+    assert torch.equal(got.to(dt).float(), got)                                   # 16-bit numbers: the pack kernel's own rounding is exact
+    ulp = 2.0 ** (torch.floor(torch.log2(w.abs().clamp_min(1e-30))) - (10 if precision == "fp16" else 7))
+    ulp_max = ulp.reshape(24, -1).max(1).values.view(24, 1, 1, 1)
+    assert bool(((got - w).abs() <= ulp_max * 1.0001).all())                     # |error| <= 1/2 ulp(t_i) + |carry|: one ulp of the channel's largest weights
+    err_fb = (got.double() - w.double()).reshape(24, -1).sum(1).abs()
+    err_rne = (w.to(dt).double() - w.double()).reshape(24, -1).sum(1).abs()
+    half_ulp_max = 0.5 * ulp.reshape(24, -1).max(1).values.double()
+    assert bool((err_fb <= half_ulp_max * 1.0001).all()) and float(err_rne.mean()) > 4 * float(err_fb.mean())
