@@ -88,11 +88,14 @@ class Conv2dFn(torch.autograd.Function):
             # (image, strip, row range) splits and one image must stay below 2 GB: beyond either limit it reports
             # GLARE_ERR_UNSUPPORTED / needs a workspace past WGRAD_MAX_WORKSPACE, and the im2col + GEMM form below takes over
             try:
-                wgrad = T.conv3x3_weight_grad if k == 3 else T.conv1x1_weight_grad
-                dw, db = wgrad(x, g16, cout)
+                # straight into the filter's own layout (round 6: the reduction of the kernel's partials writes OIHW, the bias row into
+                # db): autograd takes a gradient laid out like its parameter over as it is -- as a permuted view of [row][cout] it
+                # was cloned by one copy_ launch per parameter, and a two-source conv needed a torch.cat on top
+                dw = torch.empty(cout, cin_tot, k, k, dtype=torch.float32, device=x.device)
+                db = torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None
+                T.conv_weight_grad_oihw(k, x, g16, cout, dw, 0, db)
                 if has_x2:      # torch.cat((x, x2), 1) as the conv's input: the filter's input-channel blocks, one launch per source
-                    dw = torch.cat([dw, wgrad(x2, g16, cout)[0]], 1)
-                db = db if has_bias else None
+                    T.conv_weight_grad_oihw(k, x2, g16, cout, dw, c1, None)
             except _lib.GlareError:
                 implicit = False
         if implicit:

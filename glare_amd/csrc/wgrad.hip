@@ -274,23 +274,46 @@ Plan make_plan(int G, int B, int H, int W, int Ci, int Co) {
   return pl;
 }
 
+// The fixed-order sum of the fp32 partials [S][TAPS * Ci + 1][Co] written straight into the filter's own layout (round 6): dW OIHW
+// [Co][ci_total][KS][KS] at input-channel offset ci_off (a conv over torch.cat((x, x2), 1): one launch per source), the bias row into db.
+// A gradient that is laid out like its parameter is taken over by autograd's AccumulateGrad as it is; the [row][Co] form reached it as
+// a permuted view and was cloned by one copy_ launch per parameter (tools/probes/small_ops.py).
+__global__ __launch_bounds__(256) void wgrad_reduce_oihw_kernel(const float* __restrict__ parts, int S, int taps, int Ci, int Co, int ci_total,
+                                                                 int ci_off, float* __restrict__ dW, float* __restrict__ db) {
+  const long long n = (long long)(taps * Ci + 1) * Co;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < S; ++k) s += parts[(long long)k * n + i];       // ascending order: the same bits as reduce_parts_kernel
+  const int r = (int)(i / Co), co = (int)(i - (long long)r * Co);
+  if (r < taps * Ci) {
+    const int tap = r / Ci, ci = r - tap * Ci;
+    dW[((size_t)co * ci_total + ci_off + ci) * taps + tap] = s;
+  } else if (db) {
+    db[co] = s;
+  }
+}
+
 template <int KS>
 int wgrad_launch(const void* x, int xpitch, int xoff, long long x_gstride, const void* g, int gpitch, long long g_gstride, float* dWt,
-                 int G, int B, int H, int W, int Ci, int Co, void* workspace, size_t workspace_bytes, glare_stream_t stream) {
+                 int G, int B, int H, int W, int Ci, int Co, void* workspace, size_t workspace_bytes, glare_stream_t stream,
+                 float* dW_oihw = nullptr, int ci_total = 0, int ci_off = 0, float* db = nullptr) {
   constexpr int TAPS = KS * KS;
-  if (!x || !g || !dWt || G <= 0 || B <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0) return GLARE_ERR_INVALID;
+  const bool oihw = dW_oihw != nullptr;
+  if (oihw && (G != 1 || ci_off < 0 || ci_off + Ci > ci_total)) return GLARE_ERR_INVALID;
+  if (!x || !g || (!dWt && !oihw) || G <= 0 || B <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0) return GLARE_ERR_INVALID;
   if (Ci % 8 || Co % 8 || xoff % 8 || xpitch % 8 || gpitch % 8 || xoff + Ci > xpitch || Co > gpitch || x_gstride % 8 || g_gstride % 8)
     return GLARE_ERR_INVALID;
   if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g)) & 15) != 0) return GLARE_ERR_INVALID;
   if ((long long)H * W * xpitch * 2 >= (1ll << 31) || (long long)H * W * gpitch * 2 >= (1ll << 31)) return GLARE_ERR_UNSUPPORTED;
   const Plan pl = make_plan(G, B, H, W, Ci, Co);
   const size_t n_out = (size_t)(TAPS * Ci + 1) * Co;
-  const size_t need = pl.S > 1 ? (size_t)G * pl.S * n_out * sizeof(float) : 0;
+  const size_t need = (pl.S > 1 || oihw) ? (size_t)G * pl.S * n_out * sizeof(float) : 0;     // oihw: the partials always go through the workspace
   if (need && (!workspace || workspace_bytes < need)) return GLARE_ERR_WORKSPACE;
   WgradParams p;
   p.x = static_cast<const a16_t*>(x);
   p.g = static_cast<const a16_t*>(g);
-  p.parts = pl.S > 1 ? static_cast<float*>(workspace) : dWt;
+  p.parts = (pl.S > 1 || oihw) ? static_cast<float*>(workspace) : dWt;
   p.B = B; p.H = H; p.W = W; p.xpitch = xpitch; p.xoff = xoff; p.Ci = Ci; p.gpitch = gpitch; p.Co = Co;
   p.x_gstride = x_gstride; p.g_gstride = g_gstride;
   p.nks = pl.nks; p.nstrips = pl.nstrips; p.ysplits = pl.ysplits; p.rps = pl.rps;
@@ -305,6 +328,11 @@ int wgrad_launch(const void* x, int xpitch, int xoff, long long x_gstride, const
       hipFuncSetAttribute((const void*)wgrad_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, NX * 13 * 1024 + NG * 12 * 1024);
   if (attr != hipSuccess) return GLARE_ERR_LAUNCH;
   hipLaunchKernelGGL(wgrad_kernel<KS>, dim3((unsigned)nb), dim3(256), lds, static_cast<hipStream_t>(stream), p);
+  if (oihw) {
+    hipLaunchKernelGGL(wgrad_reduce_oihw_kernel, dim3((unsigned)cdivll((long long)n_out, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       (const float*)p.parts, pl.S, TAPS, Ci, Co, ci_total, ci_off, dW_oihw, db);
+    return glare_launch_status();
+  }
   if (pl.S > 1) return glare_reduce_parts_grouped_f32(p.parts, G, pl.S, (long long)n_out, 1.0f, dWt, 0, stream);
   return glare_launch_status();
 }
@@ -329,5 +357,27 @@ extern "C" int glare_conv_wgrad_bf16(int ksize, const void* x, int xpitch, int x
     return wgrad_launch<3>(x, xpitch, xoff, x_gstride, g, gpitch, g_gstride, dWt, groups, B, H, W, Ci, Co, workspace, workspace_bytes, stream);
   if (ksize == 1)
     return wgrad_launch<1>(x, xpitch, xoff, x_gstride, g, gpitch, g_gstride, dWt, groups, B, H, W, Ci, Co, workspace, workspace_bytes, stream);
+  return GLARE_ERR_UNSUPPORTED;
+}
+
+// The same for ONE conv with the result in the filter's own layout: dW_oihw fp32 [Co][ci_total][ksize][ksize], this launch filling the
+// input channels [ci_off, ci_off + Ci) (a conv over a channel concatenation: one launch per source); db fp32 [Co] or NULL.  The workspace
+// is always used (glare_conv_wgrad_oihw_workspace_bytes).
+extern "C" size_t glare_conv_wgrad_oihw_workspace_bytes(int ksize, int B, int H, int W, int Ci, int Co) {
+  if ((ksize != 1 && ksize != 3) || B <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0) return 0;
+  const Plan pl = make_plan(1, B, H, W, Ci, Co);
+  return (size_t)pl.S * ((size_t)ksize * ksize * Ci + 1) * Co * sizeof(float);
+}
+
+extern "C" int glare_conv_wgrad_oihw_bf16(int ksize, const void* x, int xpitch, int xoff, const void* g, int gpitch, float* dW_oihw, int ci_total,
+                                          int ci_off, float* db_or_null, int B, int H, int W, int Ci, int Co, void* workspace,
+                                          size_t workspace_bytes, glare_stream_t stream) {
+  if (!dW_oihw) return GLARE_ERR_INVALID;
+  if (ksize == 3)
+    return wgrad_launch<3>(x, xpitch, xoff, 0, g, gpitch, 0, nullptr, 1, B, H, W, Ci, Co, workspace, workspace_bytes, stream, dW_oihw, ci_total, ci_off,
+                           db_or_null);
+  if (ksize == 1)
+    return wgrad_launch<1>(x, xpitch, xoff, 0, g, gpitch, 0, nullptr, 1, B, H, W, Ci, Co, workspace, workspace_bytes, stream, dW_oihw, ci_total, ci_off,
+                           db_or_null);
   return GLARE_ERR_UNSUPPORTED;
 }

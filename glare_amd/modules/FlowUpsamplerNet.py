@@ -531,14 +531,24 @@ class FlowNLLFn(torch.autograd.Function):
         # ... and their filter gradients: step s owns a channel block of both tensors (group stride = the block)
         of4 = T.conv_weight_grad_nhwc(3, h2f, ghF, 8, 64, groups=n, x_gstride=64, g_gstride=8)      # [n,577,8], 6 of 8 used
         of2 = T.conv_weight_grad_nhwc(1, h1f, gh2f, 64, 64, groups=n, x_gstride=64, g_gstride=64)   # [n,65,64]
-        df0w, df0b = T.conv3x3_weight_grad(ft, gh1f, n * 64)
-        dftAw, dftAb = T.conv3x3_weight_grad(ft, gftA, n * 64)
+        def wgrad_oihw(g16):       # [n * 64, 64, 3, 3] laid out like the (stacked) filter: its 24 slices are taken over by autograd as they are
+            dw = torch.empty(n * 64, ft.shape[-1], 3, 3, dtype=torch.float32, device=dev)
+            db = torch.empty(n * 64, dtype=torch.float32, device=dev)
+            T.conv_weight_grad_oihw(3, ft, g16, n * 64, dw, 0, db)
+            return dw, db
 
+        df0w, df0b = wgrad_oihw(gh1f)
+        dftAw, dftAb = wgrad_oihw(gftA)
+
+        # .contiguous(): ONE permuting copy per conv family here instead of one per LAYER later -- the fold's backward (mul) keeps its
+        # operand's strides and stack's backward hands AccumulateGrad 24 slices each; a slice that is not laid out like its
+        # parameter is cloned (a copy_ launch per layer: 170 of a stage-2 step's 438 stock launches, tools/probes/small_ops.py),
+        # a contiguous one is taken over as it is
         def w3(o, co):   # [n, 9*64 + 1, 8] -> ([n, co, 64, 3, 3], [n, co])
-            return o[:, :576, :co].unflatten(1, (3, 3, 64)).permute(0, 4, 3, 1, 2), o[:, 576, :co]
+            return o[:, :576, :co].unflatten(1, (3, 3, 64)).permute(0, 4, 3, 1, 2).contiguous(), o[:, 576, :co].contiguous()
 
         def w1(o):       # [n, 64 + 1, 64] -> ([n, 64, 64, 1, 1], [n, 64])
-            return o[:, :64].transpose(1, 2).unsqueeze(-1).unsqueeze(-1), o[:, 64]
+            return o[:, :64].transpose(1, 2).contiguous().unsqueeze(-1).unsqueeze(-1), o[:, 64].contiguous()
 
         (dc4w, dc4b), (dc2w, dc2b), (df4w, df4b), (df2w, df2b) = w3(o4, 4), w1(o2), w3(of4, 6), w1(of2)
         gft = ops.conv2d(gh1f, _wt(f0_w))

@@ -84,8 +84,26 @@ class FlatGroup:
             if all(gof(p) is None for p in ps):
                 self.g[off:off + n].zero_()
             else:
-                torch.cat([(gof(p) if gof(p) is not None else torch.zeros_like(p)).reshape(-1).to(torch.float32) for p in ps],
-                          out=self.g[off:off + n])
+                # runs of parameters WITH a gradient are concatenated into their slot, runs without one zeroed in place (one launch per
+                # run; a torch.zeros_like per missing parameter inside the cat was 38 launches of a stage-3 step)
+                o2, run, run_off, miss_off = off, [], off, None
+                for p in ps + [None]:                                   # (the sentinel closes the last run)
+                    gp = gof(p) if p is not None else None
+                    if p is not None and gp is not None:
+                        if miss_off is not None:
+                            self.g[miss_off:o2].zero_()
+                            miss_off, run_off = None, o2
+                        run.append(gp.reshape(-1).to(torch.float32))
+                    else:
+                        if run:
+                            torch.cat(run, out=self.g[run_off:o2])
+                            run = []
+                        if p is not None and miss_off is None:
+                            miss_off = o2
+                    if p is not None:
+                        o2 += p.numel()
+                if miss_off is not None:
+                    self.g[miss_off:o2].zero_()
             off += n
         if grads is not None:     # inside the backward pass: AccumulateGrad has yet to run for these parameters, and a .grad that
             return                # aliases the flat buffer would be accumulated INTO, under the exchange (finish_early_all_reduce re-points)

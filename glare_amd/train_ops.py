@@ -647,6 +647,25 @@ def conv_weight_grad_nhwc(ksize, x, g16, cout, cin=None, in_off=0, groups=1, x_g
     return out
 
 
+def conv_weight_grad_oihw(ksize, x, g16, cout, dw, ci_off=0, db=None):
+    """The weight (and bias) gradient of ONE stride-1 conv straight into the filter's layout: dw fp32 [cout, ci_total, k, k] contiguous,
+    this call filling input channels [ci_off, ci_off + x.shape[-1]); db fp32 [cout] or None (glare_conv_wgrad_oihw_bf16)."""
+    require_cuda(x, g16, dw, db)
+    assert x.dtype == act_dtype() and g16.dtype == act_dtype() and x.is_contiguous() and g16.is_contiguous()
+    assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.shape[0] == cout and dw.shape[2] == dw.shape[3] == ksize
+    B, H, W, cin = x.shape
+    _count_flops("wgrad k%d" % ksize, 2.0 * B * H * W * ksize * ksize * cin * cout)
+    lib = _lib.lib()
+    lib.glare_conv_wgrad_oihw_workspace_bytes.restype = ctypes.c_size_t
+    nws = lib.glare_conv_wgrad_oihw_workspace_bytes(_i(ksize), _i(B), _i(H), _i(W), _i(cin), _i(cout))
+    if nws > WGRAD_MAX_WORKSPACE:
+        raise _lib.GlareError("glare_conv_wgrad_oihw_bf16: %.1f GB of fp32 partials (limit %.1f GB)" % (nws / 2 ** 30, WGRAD_MAX_WORKSPACE / 2 ** 30))
+    ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=x.device)
+    check(lib.glare_conv_wgrad_oihw_bf16(_i(ksize), ptr(x), _i(cin), _i(0), ptr(g16), _i(g16.shape[-1]), ptr(dw), _i(dw.shape[1]), _i(ci_off), ptr(db),
+                                         _i(B), _i(H), _i(W), _i(cin), _i(cout), ptr(ws), _sz(nws), stream_handle()), "glare_conv_wgrad_oihw_bf16")
+    return dw
+
+
 def conv3x3_weight_grad(x, g16, cout, cin=None, in_off=0):
     """-> (dW fp32 [cout,cin,3,3] (a permuted view), db fp32 [cout]) of one 3x3 / stride-1 / pad-1 conv."""
     cin = x.shape[-1] - in_off if cin is None else cin

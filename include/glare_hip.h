@@ -572,6 +572,13 @@ size_t glare_conv_wgrad_workspace_bytes(int ksize, int groups, int B, int H, int
 int glare_conv_wgrad_bf16(int ksize, const void* x, int xpitch, int xoff, long long x_gstride, const void* g, int gpitch,
                           long long g_gstride, float* dWt, int groups, int B, int H, int W, int Ci, int Co, void* workspace,
                           size_t workspace_bytes, glare_stream_t stream);
+/* ... of ONE conv with the result laid out like the filter itself (round 6): dW_oihw fp32 [Co][ci_total][ksize][ksize], this launch
+ * filling the input channels [ci_off, ci_off + Ci) (torch.cat((x, x2), 1) as the conv's input: one launch per source), db fp32 [Co] or
+ * NULL.  A gradient laid out like its parameter is taken over by autograd as it is (no per-parameter copy). */
+size_t glare_conv_wgrad_oihw_workspace_bytes(int ksize, int B, int H, int W, int Ci, int Co);
+int glare_conv_wgrad_oihw_bf16(int ksize, const void* x, int xpitch, int xoff, const void* g, int gpitch, float* dW_oihw, int ci_total,
+                               int ci_off, float* db_or_null, int B, int H, int W, int Ci, int Co, void* workspace, size_t workspace_bytes,
+                               glare_stream_t stream);
 /* out[c] = sum_p g[p][c] (bias gradient); g bf16 [P][pitch]; workspace >= 256 * C floats */
 int glare_colsum_bf16(const void* g, int pitch, long long P, int C, float* out, void* workspace, size_t workspace_bytes,
                       glare_stream_t stream);
