@@ -30,6 +30,9 @@ def r22(t):
     return hi + (t - hi).half().float()
 
 
+FEEDBACK16 = None      # set by main() under SITES_FEEDBACK=1: 16-bit filters rounded with error feedback (tools/filter_rounding_study.py) instead of RNE
+
+
 DIRECT = ("RRDB.encoder.conv_in", "RRDB.color_conv", "RRDB.cond_conv.0")   # fp32 direct convs (conv_small.hip)
 F32_OUT = ("RRDB.encoder.conv_out", "RRDB.color_conv")
 
@@ -67,7 +70,7 @@ class Sites:
                 continue
             stream = name.endswith(("conv2", "proj_out", "nin_shortcut", "downsample.conv"))
             is_flow = name.startswith("flowUpsamplerNet")
-            wf = r22 if wlo(name) else r16
+            wf = r22 if wlo(name) else (FEEDBACK16 or r16)
             self.saved.append((m.weight, m.weight.data.clone()))
             w = m.weight.data
             if is_flow and name.endswith("fAffine.0"):
@@ -143,6 +146,19 @@ def main():
     measure("+ filters + activations + conv1 out (fp32-class A+B)", full, alo=T, wlo=T, olo=T)
     measure("fp32-class A+B + cond_feat hi/lo", full, alo=T, wlo=T, olo=T, cond22=True)
     measure("fp32-class A+B + cond_feat hi/lo + fp32 softmax P", full, alo=T, wlo=T, olo=T, cond22=True, soft16=False)
+    if os.environ.get("SITES_FEEDBACK", "0") == "1":
+        # round 6: can the THIRD pass of the fp32-class convs (x_hi . w_lo, the filter's lo half) go if the 16-bit filter is rounded with error
+        # feedback per output channel (ops.filter_feedback_round)?  Stages D / E gained 3 dB from it; here the question is the LATENT
+        global FEEDBACK16
+        from filter_rounding_study import round_feedback
+        measure("reference point: fp32-class A+B + cond_feat hi/lo", full, alo=T, wlo=T, olo=T, cond22=True)
+        measure("16-bit RNE filters everywhere (2 passes), acts / outputs hi/lo", full, alo=T, wlo=Fa, olo=T, cond22=True)
+        FEEDBACK16 = lambda w: round_feedback(w) if w.dim() == 4 else r16(w)
+        measure("16-bit FEEDBACK filters everywhere (2 passes), acts / outputs hi/lo", full, alo=T, wlo=Fa, olo=T, cond22=True)
+        for g in ("down0", "down1", "down2", "mid", "attn", "out", "flow"):
+            measure("16-bit FEEDBACK filters in %s only" % g, full, alo=T, wlo=(lambda n, g=g: group_of(n) != g), olo=T, cond22=True)
+        FEEDBACK16 = None
+        return
     if os.environ.get("SITES_PER_CONV", "0") == "1":
         # is there ANY conv of the conditional encoder whose third MFMA pass (x_hi . w_lo: the filter's lo half) or
         # second pass (x_lo . w_hi: the activation's lo half) can be dropped without moving the table?  One site at a time, everything
