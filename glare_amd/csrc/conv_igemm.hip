@@ -98,8 +98,10 @@ __global__ void pack_weight_multi_kernel(const glare_pack_job* __restrict__ jobs
 // Sub-pixel upsample filters: [phase = a*2+b][co_tile][stage][tap = r*2+c][khalf][TN][8] (KSTEPS = 1), where tap (r, c)
 // of phase (a, b) is the sum of the 3x3 taps (ky, kx) that read the same source pixel: rows a=0: r=0 <- {0}, r=1 <- {1,2};
 // a=1: r=0 <- {0,1}, r=1 <- {2}; columns alike with b.
+// presummed: w is already the four phase filters, fp32 [phase][Cout][Cin][2][2] (round 6: summed and rounded with error feedback on the
+// host side, ops.PackedConv(upsample_subpixel=True)); otherwise the 3x3 filter, summed here.
 __global__ void pack_weight_subpix_kernel(const float* __restrict__ w, a16_t* __restrict__ out, int Cout, int Cin, int TN,
-                                          int n_stages, int co_tiles, long long total) {
+                                          int n_stages, int co_tiles, long long total, int presummed) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   long long t = i;
@@ -117,9 +119,13 @@ __global__ void pack_weight_subpix_kernel(const float* __restrict__ w, a16_t* __
   const int ci = s * 16 + khalf * 8 + e;
   float v = 0.f;
   if (co < Cout && ci < Cin) {
-    const float* wp = w + ((size_t)co * Cin + ci) * 9;
-    for (int ky = ky0; ky <= ky1; ++ky)
-      for (int kx = kx0; kx <= kx1; ++kx) v += wp[ky * 3 + kx];
+    if (presummed) {
+      v = w[((((size_t)phase * Cout + co) * Cin + ci) * 2 + r) * 2 + c];
+    } else {
+      const float* wp = w + ((size_t)co * Cin + ci) * 9;
+      for (int ky = ky0; ky <= ky1; ++ky)
+        for (int kx = kx0; kx <= kx1; ++kx) v += wp[ky * 3 + kx];
+    }
   }
   out[i] = f2a(v);
 }
@@ -204,12 +210,26 @@ __global__ void filter_feedback_kernel(const float* __restrict__ w, float* __res
   const float* src = w + (size_t)k * n;
   float* dst = out + (size_t)k * n;
   double carry = 0.0;
-  for (long long i = 0; i < n; ++i) {
-    const double t = (double)src[i] + carry;
+  auto step = [&](float v) {
+    const double t = (double)v + carry;
     const float q = a2f(f2a((float)t));
-    dst[i] = q;
     carry = t - (double)q;
+    return q;
+  };
+  long long i = 0;
+  if ((n & 3) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {     // 16-B accesses, two in flight: the chain is the carry, not the loads
+    for (; i + 8 <= n; i += 8) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(src + i), b = *reinterpret_cast<const f32x4*>(src + i + 4);
+      f32x4 qa, qb;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) qa[e] = step(a[e]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) qb[e] = step(b[e]);
+      *reinterpret_cast<f32x4*>(dst + i) = qa;
+      *reinterpret_cast<f32x4*>(dst + i + 4) = qb;
+    }
   }
+  for (; i < n; ++i) dst[i] = step(src[i]);
 }
 
 extern "C" int glare_filter_feedback_round_bf16(const float* w_oihw, float* out_oihw, int cout, long long elems_per_cout, glare_stream_t stream) {
@@ -244,7 +264,18 @@ extern "C" int glare_conv2d_pack_weight_upsample(const float* w_oihw, int cout, 
   if (total < 0 || !w_oihw || !packed_bf16) return GLARE_ERR_INVALID;
   const Variant v = pick_variant(3, cout);
   hipLaunchKernelGGL(pack_weight_subpix_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     w_oihw, (a16_t*)packed_bf16, cout, cin_total, v.tn, (cin_total + 15) / 16, (cout + v.tn - 1) / v.tn, total);
+                     w_oihw, (a16_t*)packed_bf16, cout, cin_total, v.tn, (cin_total + 15) / 16, (cout + v.tn - 1) / v.tn, total, 0);
+  return glare_launch_status();
+}
+
+// The same image from the four phase filters themselves: w_phases fp32 [4][cout][cin][2][2], phase = 2 a + b the output sub-pixel, tap (r, c)
+// the source pixel (the sums the entry above forms from the 3x3 filter) -- for callers that round the phase filters their own way.
+extern "C" int glare_conv2d_pack_weight_upsample_phases(const float* w_phases, int cout, int cin_total, void* packed_bf16, glare_stream_t stream) {
+  const long long total = glare_conv2d_upsample_packed_weight_elems(cout, cin_total);
+  if (total < 0 || !w_phases || !packed_bf16) return GLARE_ERR_INVALID;
+  const Variant v = pick_variant(3, cout);
+  hipLaunchKernelGGL(pack_weight_subpix_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     w_phases, (a16_t*)packed_bf16, cout, cin_total, v.tn, (cin_total + 15) / 16, (cout + v.tn - 1) / v.tn, total, 1);
   return glare_launch_status();
 }
 

@@ -222,8 +222,9 @@ __global__ __launch_bounds__(256) void attn_fold_kernel(const float* __restrict_
                                                         const float* __restrict__ bq, const float* __restrict__ wo,
                                                         const float* __restrict__ bo, a16_t* __restrict__ wq_out,
                                                         float* __restrict__ bq_out, a16_t* __restrict__ wo_out,
-                                                        float* __restrict__ bo_out, int C) {
+                                                        float* __restrict__ bo_out, int C, int feedback) {
   __shared__ float a_s[2048], d_s[2048];
+  __shared__ float vq_s[2048], vo_s[2048];     // the two filter rows in fp32, rounded afterwards with error feedback (feedback != 0)
   __shared__ float red[2][4];
   const int o = blockIdx.x, b = blockIdx.y, cpg = C / GN_GROUPS;
   for (int c = threadIdx.x; c < C; c += 256) {
@@ -247,10 +248,31 @@ __global__ __launch_bounds__(256) void attn_fold_kernel(const float* __restrict_
   const size_t row = ((size_t)b * C + o) * C;
   for (int c = threadIdx.x; c < C; c += 256) {
     const float wqv = wq[(size_t)o * C + c], wov = wo[(size_t)o * C + c];
-    wq_out[row + c] = f2a(ao * wqv * a_s[c]);
-    wo_out[row + c] = f2a(wov * a_s[c]);
+    if (feedback) {
+      vq_s[c] = ao * wqv * a_s[c];
+      vo_s[c] = wov * a_s[c];
+    } else {
+      wq_out[row + c] = f2a(ao * wqv * a_s[c]);
+      wo_out[row + c] = f2a(wov * a_s[c]);
+    }
     dq = fmaf(wqv, d_s[c], dq);
     dv = fmaf(wov, d_s[c], dv);
+  }
+  if (feedback) {
+    // round 6: the per-image filters rounded like every other single-pass filter of inference (conv_igemm.hip filter_feedback_kernel):
+    // q_c = round16(v_c + carry) along the input channels of this output row, one lane per filter (512 dependent steps, ~7 us per block)
+    __syncthreads();
+    if (threadIdx.x == 0 || threadIdx.x == 64) {
+      const float* v = threadIdx.x == 0 ? vq_s : vo_s;
+      a16_t* dst = (threadIdx.x == 0 ? wq_out : wo_out) + row;
+      double carry = 0.0;
+      for (int c = 0; c < C; ++c) {
+        const double t = (double)v[c] + carry;
+        const a16_t q = f2a((float)t);
+        dst[c] = q;
+        carry = t - (double)a2f(q);
+      }
+    }
   }
   dq = wave_sum(dq);
   dv = wave_sum(dv);
@@ -403,10 +425,10 @@ extern "C" int glare_groupnorm_coeffs_f32(const float* stats, int splits, int B,
 extern "C" int glare_attn_fold_groupnorm_f32(const float* stats, int splits, int B, long long HW, int C, const float* gamma,
                                              const float* beta, float eps, const float* wq, const float* bq, const float* wo,
                                              const float* bo, void* wq_out, float* bq_out, void* wo_out, float* bo_out,
-                                             glare_stream_t stream) {
+                                             int feedback, glare_stream_t stream) {
   if (!stats || !gamma || !beta || !wq || !bq || !wo || !bo || !wq_out || !bq_out || !wo_out || !bo_out) return GLARE_ERR_INVALID;
   if (splits <= 0 || B <= 0 || B > 65535 || HW <= 0 || C <= 0 || C % GN_GROUPS || C > 2048) return GLARE_ERR_INVALID;
   hipLaunchKernelGGL(attn_fold_kernel, dim3(C, B), dim3(256), 0, (hipStream_t)stream, stats, splits, HW, gamma, beta, eps, wq, bq, wo, bo,
-                     (a16_t*)wq_out, bq_out, (a16_t*)wo_out, bo_out, C);
+                     (a16_t*)wq_out, bq_out, (a16_t*)wo_out, bo_out, C, feedback);
   return glare_launch_status();
 }

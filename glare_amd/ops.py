@@ -82,6 +82,13 @@ def split_filter(w, split, reuse_kc=0):
 FILTER_FEEDBACK = os.environ.get("GLARE_FILTER_FEEDBACK", "1") == "1"
 
 
+# ... but NOT the per-image attention filters (glare_attn_fold_groupnorm_f32's `feedback`): measured with it, the third weight set's |dPSNR vs GT|
+# went 0.0061 -> 0.0121 dB and PSNR(ours, oracle) 65.2 -> 63.8 dB -- those filters multiply the RAW activation (per-channel means and scales
+# all over the place), so the vanishing sum of a row's rounding errors buys nothing and the doubled per-weight variance costs.
+# GLARE_ATTN_FOLD_FEEDBACK=1 switches it on for A/B runs.
+ATTN_FOLD_FEEDBACK = os.environ.get("GLARE_ATTN_FOLD_FEEDBACK", "0") == "1"
+
+
 def filter_feedback_round(w):
     """fp32 [cout, ...] filter -> fp32 tensor of 16-bit-representable values (current precision), error feedback along the trailing axes."""
     require_cuda(w)
@@ -95,12 +102,13 @@ def filter_feedback_round(w):
 class PackedConv:
     """A conv filter packed once for the MFMA kernel (weights bf16 stage-ordered, bias fp32)."""
 
-    def __init__(self, weight_oihw, bias=None, dgrad_pad=None, upsample_subpixel=False, cout_tile=0, split=0):
+    def __init__(self, weight_oihw, bias=None, dgrad_pad=None, upsample_subpixel=False, cout_tile=0, split=0, feedback=False):
         """dgrad_pad = P: pack the filter of the data-gradient conv (P >= cout input channels, cin outputs) instead.
         cout_tile: 0 = the default output-channel tile for this cout, or 64 / 32 for launches too small to fill the chip with it
         (conv_cout_tile(); the packed image is tile-specific and conv2d passes the tile on).
         upsample_subpixel: pack the four 2x2 sub-pixel filters of "nearest x2 upsample, then this 3x3 conv" (conv2d then runs
-        desc.upsample = 2: 16 instead of 36 tap-MACs per source pixel)."""
+        desc.upsample = 2: 16 instead of 36 tap-MACs per source pixel); feedback (with it): round the four phase filters with error
+        feedback per output channel (filter_feedback_round; plain filters are fed pre-rounded by modules._base.packed_conv)."""
         require_cuda(weight_oihw)
         w = weight_oihw.detach().float().contiguous()
         self.split = int(split)
@@ -134,8 +142,19 @@ class PackedConv:
             n = lib.glare_conv2d_upsample_packed_weight_elems(_i(cout), _i(cin))
             assert n > 0
             self.packed = torch.empty(n, dtype=act_dtype(), device=w.device)
-            check(lib.glare_conv2d_pack_weight_upsample(ptr(w), _i(cout), _i(cin), ptr(self.packed), stream_handle()),
-                  "glare_conv2d_pack_weight_upsample")
+            if feedback:
+                # the four phase filters (the taps of the 3x3 filter that read one source pixel, summed) rounded with error feedback per
+                # (phase, output channel) -- the sub-pixel form of filter_feedback_round: rows a = 0: r = 0 <- {0}, r = 1 <- {1, 2};
+                # a = 1: r = 0 <- {0, 1}, r = 1 <- {2}; columns alike
+                rows = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}
+                ph = torch.stack([torch.stack([torch.stack([w[:, :, list(rows[a][r])][:, :, :, list(rows[b][c])].sum(dim=(2, 3)) for c in (0, 1)], -1)
+                                               for r in (0, 1)], -2) for a in (0, 1) for b in (0, 1)])           # [4, cout, cin, 2, 2]
+                ph = filter_feedback_round(ph.reshape(4 * cout, cin, 2, 2))
+                check(lib.glare_conv2d_pack_weight_upsample_phases(ptr(ph), _i(cout), _i(cin), ptr(self.packed), stream_handle()),
+                      "glare_conv2d_pack_weight_upsample_phases")
+            else:
+                check(lib.glare_conv2d_pack_weight_upsample(ptr(w), _i(cout), _i(cin), ptr(self.packed), stream_handle()),
+                      "glare_conv2d_pack_weight_upsample")
             self.bias = None if bias is None else bias.detach().float().contiguous()
             return
         lib.glare_conv2d_packed_weight_elems.restype = _ll
@@ -475,7 +494,8 @@ def attn_fold_groupnorm(stats, HW, gamma, beta, eps, wq, bq, wo, bo):
     bo_b = torch.empty_like(bq_b)
     check(_lib.lib().glare_attn_fold_groupnorm_f32(ptr(stats), _i(splits), _i(B), _ll(HW), _i(C), ptr(gamma), ptr(beta), _f(eps), ptr(wq),
                                                    ptr(bq), ptr(wo), ptr(bo), ptr(wq_b), ptr(bq_b), ptr(wo_b), ptr(bo_b),
-                                                   stream_handle()), "glare_attn_fold_groupnorm_f32")
+                                                   _i(int(ATTN_FOLD_FEEDBACK)), stream_handle()),
+          "glare_attn_fold_groupnorm_f32")
     return wq_b, bq_b, wo_b, bo_b
 
 

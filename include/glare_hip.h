@@ -193,6 +193,9 @@ int glare_conv2d_pack_weight_batched(const float* w_boihw, int batch, int cout, 
  * that read the same source pixel are summed in fp32 and rounded to bf16 once (rows a=0: {0},{1,2}; a=1: {0,1},{2}). */
 long long glare_conv2d_upsample_packed_weight_elems(int cout, int cin_total);
 int glare_conv2d_pack_weight_upsample(const float* w_oihw, int cout, int cin_total, void* packed_bf16, glare_stream_t stream);
+/* ... from the four phase filters themselves: w_phases fp32 [4][cout][cin][2][2] (phase = 2 a + b the output sub-pixel, tap (r, c) the source
+ * pixel: the sums the entry above forms) -- inference rounds them with error feedback first (glare_filter_feedback_round_bf16). */
+int glare_conv2d_pack_weight_upsample_phases(const float* w_phases, int cout, int cin_total, void* packed_bf16, glare_stream_t stream);
 int glare_conv2d_bf16(const glare_conv_desc* desc_host, glare_stream_t stream);
 /* Fused GroupNorm statistics: the conv epilogue leaves per-tile partial sums of its output; the reduce turns
  * them into the [B][1][32][2] (sum, sum of squares per group) block glare_groupnorm_apply_bf16 consumes, so the
@@ -375,7 +378,9 @@ int glare_conv1x1_ws_split_bf16(const void* x_hi, const void* x_lo, int x_pitch,
                                 float* gn_partial, glare_stream_t stream);
 int glare_attn_fold_groupnorm_f32(const float* stats, int splits, int B, long long HW, int C, const float* gamma, const float* beta,
                                   float eps, const float* wq, const float* bq, const float* wo, const float* bo, void* wq_out,
-                                  float* bq_out, void* wo_out, float* bo_out, glare_stream_t stream);
+                                  float* bq_out, void* wo_out, float* bo_out, int feedback, glare_stream_t stream);
+/* feedback != 0 (round 6): the two 16-bit filters rounded with error feedback along the input channels of every output row, as
+ * glare_filter_feedback_round_bf16 rounds the static filters (0: round-to-nearest per weight). */
 
 /* ---- a2: blockwise spatial self-attention, one head, d = 512 ---------------------------------
  * Replaces the bmm / softmax / bmm of AttnBlock.forward (encoder_decoder.py:176-188) without the

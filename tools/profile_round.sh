@@ -20,7 +20,9 @@ python bench.py --batch 4 --steps 20 --warmup 5 --no-train --no-cpu-baseline > g
   for k in attn conv dcn; do echo "== $k"; bash tools/pmc_kernel.sh ${tag}_$k $k 2>&1 | grep -v "amdgpu.ids"; done
 } > gpurun_out/${tag}_pmc_kernels.txt
 python tools/kbench.py attn conv convsplit gn dcn vq wgrad attnbwd > gpurun_out/${tag}_kbench.txt 2>&1
-python tools/kbench.py attnfold > gpurun_out/${tag}_attn_fold.txt 2>&1
+python tools/kbench.py flow winograd > gpurun_out/${tag}_kbench_flow_winograd.txt 2>&1        # round 6: the fused flow step against the four-launch form; the Winograd products priced
+python tools/probes/infer_ops_by_line.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_infer_stock_ops.txt   # stock torch ops of one steady-state inference step, by source line
+for st in stage2 stage3; do python tools/probes/small_ops.py $st 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_train_${st}_stock_ops.txt; done
 python tools/probes/power_clock_probe.py 4 2>&1 | grep -v "amdgpu.ids" > gpurun_out/${tag}_power_clock.txt   # the power wall: random vs all-zero operands
 {
   echo "# rocprofv3 --kernel-trace --pmc TA_BUSY_avr TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TOTAL_ACCESSES_sum -- python tools/kbench.py dcn   (one shape per run)"
