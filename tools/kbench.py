@@ -168,6 +168,17 @@ def bench_gn():
         print("gn    C=%d %dx%d: %.3f ms  %.0f GB/s (algorithmic 2 reads + 1 write)" % (c, h, w, ms, gb / ms * 1e3))
 
 
+def bench_gnapply():
+    """The GroupNorm + swish APPLY pass alone (statistics from the producer), fp16, the path's three shapes."""
+    with ops.use_precision("fp16"):
+        for c, h, w in ((128, 420, 620), (256, 210, 310), (512, 105, 155)):
+            x = torch.randn(B, h, w, c, device=DEV).half()
+            g, b = torch.ones(c, device=DEV), torch.zeros(c, device=DEV)
+            x._gn_stats = torch.rand(B, 4, 32, 2, device=DEV) * 1000 + 1000
+            ms = timeit(lambda: ops.groupnorm(x, g, b, swish=True), reps=10)
+            print("gn apply C=%d %dx%d: %.3f ms  %.2f TB/s (1 read + 1 write)" % (c, h, w, ms, 2.0 * x.numel() * 2 / ms / 1e9))
+
+
 def bench_dcn():
     only = os.environ.get("KB_DCN")      # "128" / "256": one shape (per-shape PMC passes)
     for prec in ("bf16", "fp16"):
