@@ -66,69 +66,7 @@ int glare_conv_launch_k1(const ConvParams& p, int tn, bool hilo, hipStream_t str
 int glare_conv_launch_k1_general(const ConvParams& p, int tn, hipStream_t stream);
 int glare_conv_launch_k2(const ConvParams& p, int tn, hipStream_t stream);   // sub-pixel upsample form (fast epilogue only)
 
-// Tile rows beyond the image (round 6).  OH is rarely a multiple of the 8-row tile -- 105 = 13 x 8 + 1, 210 = 26 x 8 + 2,
-// 420 = 52 x 8 + 4 -- and the waves of the LAST tile row used to contract their out-of-range output rows like any other (the
-// epilogues mask them): 6.25 % / 2.8 % / 0.9 % of a launch's MFMAs at 105 / 210 / 420 rows, on a chip whose matrix pipe is bound by
-// the socket's power.  GLARE_ROW_SKIP = 1 (the 4 x 2-block kernels): one k-step's fragment reads and MFMAs are ONE inline-asm
-// statement that repeats the compiler's own schedule of that group (read a row's A fragment into the one fragment register, wait,
-// two MFMAs, next row) with a scalar `i < nv` in front of every row -- nv = the wave's tile rows inside the image, uniform.  Written
-// in C++ the same guard cost 16-132 B/lane of scratch with reloads inside the K loop, as a second guarded copy of the loop, as
-// branches in the one loop, and as guarded MFMA-only asm statements (the compiler then keeps all four A fragments in flight): the
-// register file is exactly full.  Skipped accumulators stay zero and are never stored: outputs and statistics are bit-identical.
-#ifndef GLARE_ROW_SKIP
-#define GLARE_ROW_SKIP 1
-#endif
-
 namespace {
-
-#ifdef GLARE_ACT_F16
-#define GLARE_MFMA_A16_ASM "v_mfma_f32_32x32x16_f16"
-#else
-#define GLARE_MFMA_A16_ASM "v_mfma_f32_32x32x16_bf16"
-#endif
-
-// One k-step of a wave with 4 tile rows x 2 cout blocks: c[i][j] += A_i x B_j for the rows i < nv.  a_addr / b_addr: this lane's LDS
-// byte addresses of row 0's A fragment and of B block 0; OA = A bytes from one tile row to the next; B block 1 is 512 B behind block 0.
-// The hazard recogniser does not look inside: the K loop is followed by mfma_drain().
-template <int OA>
-__device__ __forceinline__ void kstep_rows_guarded(unsigned a_addr, unsigned b_addr, int nv, f32x16 (&c)[4][2], const int OA0, const int OB0) {
-  u32x4 a, b0, b1;
-  asm volatile("s_cmp_gt_i32 %[nv], 0\n\t"
-               "s_cbranch_scc0 .Lkstep_end%=\n\t"
-               "ds_read_b128 %[a], %[aaddr] offset:%[oa0]\n\t"
-               "ds_read_b128 %[b0], %[baddr] offset:%[ob0]\n\t"
-               "ds_read_b128 %[b1], %[baddr] offset:%[ob1]\n\t"
-               "s_waitcnt lgkmcnt(1)\n\t"
-               GLARE_MFMA_A16_ASM " %[c00], %[a], %[b0], %[c00]\n\t"
-               "s_waitcnt lgkmcnt(0)\n\t"
-               GLARE_MFMA_A16_ASM " %[c01], %[a], %[b1], %[c01]\n\t"
-               "s_cmp_gt_i32 %[nv], 1\n\t"
-               "s_cbranch_scc0 .Lkstep_end%=\n\t"
-               "ds_read_b128 %[a], %[aaddr] offset:%[oa1]\n\t"
-               "s_waitcnt lgkmcnt(0)\n\t"
-               GLARE_MFMA_A16_ASM " %[c10], %[a], %[b0], %[c10]\n\t"
-               GLARE_MFMA_A16_ASM " %[c11], %[a], %[b1], %[c11]\n\t"
-               "s_cmp_gt_i32 %[nv], 2\n\t"
-               "s_cbranch_scc0 .Lkstep_end%=\n\t"
-               "ds_read_b128 %[a], %[aaddr] offset:%[oa2]\n\t"
-               "s_waitcnt lgkmcnt(0)\n\t"
-               GLARE_MFMA_A16_ASM " %[c20], %[a], %[b0], %[c20]\n\t"
-               GLARE_MFMA_A16_ASM " %[c21], %[a], %[b1], %[c21]\n\t"
-               "s_cmp_gt_i32 %[nv], 3\n\t"
-               "s_cbranch_scc0 .Lkstep_end%=\n\t"
-               "ds_read_b128 %[a], %[aaddr] offset:%[oa3]\n\t"
-               "s_waitcnt lgkmcnt(0)\n\t"
-               GLARE_MFMA_A16_ASM " %[c30], %[a], %[b0], %[c30]\n\t"
-               GLARE_MFMA_A16_ASM " %[c31], %[a], %[b1], %[c31]\n"
-               ".Lkstep_end%=:"
-               : [c00] "+v"(c[0][0]), [c01] "+v"(c[0][1]), [c10] "+v"(c[1][0]), [c11] "+v"(c[1][1]), [c20] "+v"(c[2][0]),
-                 [c21] "+v"(c[2][1]), [c30] "+v"(c[3][0]), [c31] "+v"(c[3][1]), [a] "=&v"(a), [b0] "=&v"(b0), [b1] "=&v"(b1)
-               : [aaddr] "v"(a_addr), [baddr] "v"(b_addr), [nv] "s"(nv), [oa0] "i"(OA0), [oa1] "i"(OA0 + OA), [oa2] "i"(OA0 + 2 * OA),
-                 [oa3] "i"(OA0 + 3 * OA), [ob0] "i"(OB0), [ob1] "i"(OB0 + 512)   // ("i": constants once the K loop is unrolled)
-               : "scc");
-}
-// 8-pass MFMA result -> VALU read of it: 11 wait states, which the compiler inserts only for MFMAs it issued itself
-__device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 7\n\ts_nop 7"); }
 
 constexpr int TW = 32;   // output tile cols == MFMA M
 
@@ -400,7 +338,6 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
 
   const int khalf = lane >> 5, px = lane & 31;
   const int n_bstages = p.n_stages * KS;
-  constexpr bool ROW_SKIP = GLARE_ROW_SKIP && MT == 4 && NT == 2 && STRIDE == 1;   // (the stride-2 kernels spilled 20 B/lane with it: 2 launches per step, left alone)
   issue_a(0, 0);
   issue_b(0, 0);
   int bs = 0;
@@ -432,19 +369,6 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
             if (more_b) issue_b(bs + 1, (bs + 1) & 1, grp * B_PG, (grp + 1) * B_PG);
             if (more_a) issue_a(chunk + 1, (a_cnt + 1) & 1, grp * A_PG, (grp + 1) * A_PG);
           }
-          if constexpr (ROW_SKIP) {
-            // nv = this wave's tile rows inside the image; this lane's fragment addresses in LDS buffer 0: A = tile row wm * MT, plane
-            // khalf, column px * STRIDE; B = plane khalf, cout wn * NT * 32 + px  (loop invariants)
-            const int nv = __builtin_amdgcn_readfirstlane(min(MT, max(0, p.OH - oy0 - wm * MT)));
-            const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem);
-            const unsigned a_lane = lds0 + (unsigned)(((wm * MT * STRIDE * 2 * KSTEPS + khalf) * G::IW + px * STRIDE) * 16);
-            const unsigned b_lane = lds0 + (unsigned)((2 * A_SLOTS + khalf * TN + wn * NT * 32 + px) * 16);
-            // (row * STRIDE + trow) * 2 * KSTEPS + ks * 2 planes of IW 16-B slots each, + tcol; B: (tcol * KSTEPS + ks) * 2 planes of TN slots
-            kstep_rows_guarded<STRIDE * 2 * KSTEPS * G::IW * 16>(a_lane + (unsigned)((a_cnt & 1) * A_SLOTS * 16),
-                                                                 b_lane + (unsigned)((bs & 1) * B_CHUNKS * 16), nv, acc,
-                                                                 ((trow * 2 * KSTEPS + ks * 2) * G::IW + tcol) * 16, (tcol * KSTEPS + ks) * 2 * TN * 16);
-            continue;
-          }
           a16x8 bf[NT], af[MT];
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
@@ -466,7 +390,6 @@ __global__ __launch_bounds__(64 * WM * WN, ((STRIDE == 1 && WM * WN == 4) ? 3 : 
     }
     if (next_new) ++a_cnt;
   }
-  if constexpr (ROW_SKIP) mfma_drain();
 
   // ---- hi / lo epilogue: the output keeps 22 mantissa bits as two 16-bit tensors (the residual stream of the conditional
   // encoder in the fp16 precision).  The accumulators go through a wave-private fp32 slab, one tile row
