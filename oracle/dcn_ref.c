@@ -12,11 +12,14 @@
  *   col2im_coord (grad_offset, grad_mask)  deform_conv_cuda_kernel.cu:695-767
  *   host orchestration         deform_conv_cuda.cpp:490-569 (forward), :571-685 (backward)
  *
- * PARITY UNPINNED BY EXECUTION: the reference is CUDA-only (deform_conv_ext.cpp:124 errors on
- * CPU), no nvcc / GPU / alternative implementation exists in the build image, and the reference
- * holds no test vectors for it.  This file is pinned by identities instead
- * (tests/test_dcn_oracle.py): zero offsets == conv2d, integer offsets == shifted conv, mask
- * linearity, border partial weights, fp64 finite differences of all five gradients, and
+ * PINNED BY EXECUTION since round 6: the reference's own extension -- its three source files, read where they lie, through
+ * PyTorch-ROCm's standard CUDA-extension path (torch's hipify renaming + hipcc for gfx950; oracle/build_ref.py ->
+ * oracle/_ref/deform_conv_ext_ref.so, no hand edit, no stand-in header) -- runs on the MI355X, and
+ * tests/test_gpu_dcn_reference.py holds this file against it: forward and all five gradients over seven geometries
+ * (conv groups, deformable groups, stride, dilation, padding, 1x1, no bias, samples outside the image) and the v1
+ * operator: max|difference| / max|reference| <= 5.8e-7 (profiles/r06_dcn_reference_pin.txt).  Rounds 1-5 had the
+ * identities only, which stay as the CPU-side tests (tests/test_dcn_oracle.py): zero offsets == conv2d, integer offsets ==
+ * shifted conv, mask linearity, border partial weights, fp64 finite differences of all five gradients, and
  * agreement with the independent pure-torch formulation in oracle/torch_ref.py.
  *
  * Layouts are the reference's: NCHW fp32, offset [B][dg*2*K][Ho][Wo], mask [B][dg*K][Ho][Wo],

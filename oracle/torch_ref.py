@@ -8,10 +8,11 @@ state-dict produced by the reference loads unchanged, and cites the file:line it
 Pinning: tests/test_oracle_vs_reference.py loads the *imported* reference modules (build
 container only, via oracle/refimport.py) with seeded weights and checks every stage of this file
 against them; small tensors from that import are committed under tests/golden/ so the pin also
-holds where /root/reference does not exist.  The deformable convolution is the exception: the
-reference implements it in CUDA only (ops/dcn/src/*), it cannot run here, so that part is
-"parity unpinned" by execution and pinned by identities instead (tests/test_dcn_oracle.py); it
-follows deform_conv_cuda_kernel.cu:468-497,571-633 and deform_conv_cuda.cpp:490-569 line by line.
+holds where /root/reference does not exist.  The deformable convolution: the reference implements
+it in CUDA only (ops/dcn/src/*), so on the CPU it is pinned by identities (tests/test_dcn_oracle.py);
+since round 6 the reference's own extension, built for gfx950 by oracle/build_ref.py, runs on the GPU
+box and pins the restatement BY EXECUTION (tests/test_gpu_dcn_reference.py: <= 5.8e-7).  It follows
+deform_conv_cuda_kernel.cu:468-497,571-633 and deform_conv_cuda.cpp:490-569 line by line.
 
 Tolerance contract of the float kernels tested against this oracle is written in each test.
 """

@@ -1,0 +1,250 @@
+"""GPU: the REFERENCE's own DCN extension executed on the MI355X -- oracle/_ref/deform_conv_ext_ref.so, the three source files of
+`deform_conv_ext` (ops/dcn/src/) hipified by torch's standard extension path and compiled for gfx950 by oracle/build_ref.py --
+against (i) the plain-C restatement oracle/dcn_ref.c, which every other DCN test uses as its oracle (this is its pin BY
+EXECUTION: rows a9 / a10 / c of SURVEY section 8), and (ii) the product's drop-in `deform_conv_ext`
+(glare_amd/modules/ops/dcn/deform_conv.py) called with the SAME positional argument lists, all five entry points.
+
+All three compute in fp32 and differ in summation order only: the reference = im2col + rocBLAS sgemm (fp32) with atomicAdd in
+col2im; the C oracle accumulates the contraction in double; the product contracts split-bf16 operand pairs on MFMA (~fp32).
+Bounds = the repository's rule (<= 2-4x the measured miss, tests/tolerances.py): measured values in profiles/r06_dcn_reference_pin.txt."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_ref, ref_ext
+from tolerances import within
+
+pytestmark = pytest.mark.gpu
+
+if not ref_ext.exists():      # built by __graft_entry__.build() / oracle/build_ref.py where /root/reference is present; travels with the tree
+    pytest.skip("oracle/_ref/deform_conv_ext_ref.so not built (python oracle/build_ref.py needs /root/reference)", allow_module_level=True)
+
+# max|difference| / max|reference|, measured on MI355X (profiles/r06_dcn_reference_pin.txt); the reference's col2im accumulates with
+# atomicAdd (run-to-run order), so the bounds sit at ~3-4x the largest value seen instead of the repository's usual 2x
+ORACLE_TOL = 2.0e-6         # C restatement vs the reference's kernels, forward and every gradient    (measured <= 5.8e-7)
+PRODUCT_FWD_TOL = 1.0e-5    # product forward (split-bf16 contraction, ~fp32) vs the reference's       (measured <= 3.8e-6)
+PRODUCT_BWD_TOL = 2.0e-6    # product gradients (fp32 MFMA) vs the reference's                         (measured <= 5.0e-7)
+FULL_BWD_TOL = 5.0e-5       # ... at the path's full sizes: fp32 scatter-adds of hundreds of terms per pixel on BOTH sides (see the attribution test)
+
+
+def _rel(got, ref):
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    return float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30))
+
+
+def _case(seed, B, C, H, W, Co, groups, dg, k=3, stride=1, pad=1, dil=1, off_scale=2.0):
+    g = torch.Generator().manual_seed(seed)
+    Ho = (H + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+    Wo = (W + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+    x = torch.randn(B, C, H, W, generator=g)
+    off = torch.randn(B, dg * 2 * k * k, Ho, Wo, generator=g) * off_scale
+    m = torch.rand(B, dg * k * k, Ho, Wo, generator=g)
+    w = torch.randn(Co, C // groups, k, k, generator=g) * (1.0 / (C // groups * k * k) ** 0.5)
+    b = torch.randn(Co, generator=g)
+    go = torch.randn(B, Co, Ho, Wo, generator=g)
+    return x, off, m, w, b, go
+
+
+def _v2_forward(ext, x, off, m, w, b, k, stride, pad, dil, groups, dg, with_bias):
+    """ModulatedDeformConvFunction.forward's call, verbatim (deform_conv.py:143-156)."""
+    B, Co = x.shape[0], w.shape[0]
+    out = x.new_empty(B, Co, off.shape[2], off.shape[3])
+    bias = b if with_bias else x.new_empty(1)
+    bufs = [x.new_empty(0), x.new_empty(0)]
+    ext.modulated_deform_conv_forward(x, w, bias, bufs[0], off, m, out, bufs[1], k, k, stride, stride, pad, pad, dil, dil, groups, dg,
+                                      with_bias)
+    return out
+
+
+def _v2_backward(ext, x, off, m, w, b, go, k, stride, pad, dil, groups, dg, with_bias):
+    """ModulatedDeformConvFunction.backward's call, verbatim (deform_conv.py:160-176)."""
+    bias = b if with_bias else x.new_empty(1)
+    gx, goff, gm, gw, gb = (torch.zeros_like(t) for t in (x, off, m, w, bias))
+    bufs = [x.new_empty(0), x.new_empty(0)]
+    ext.modulated_deform_conv_backward(x, w, bias, bufs[0], off, m, bufs[1], gx, gw, gb, goff, gm, go, k, k, stride, stride, pad, pad,
+                                       dil, dil, groups, dg, with_bias)
+    return gx, goff, gm, gw, (gb if with_bias else None)
+
+
+V2_CASES = [  # B, C, H, W, Co, groups, dg, k, stride, pad, dil, bias, off_scale
+    (1, 128, 9, 13, 128, 1, 4, 3, 1, 1, 1, True, 2.0),      # the AFT decoder's level-1 warp geometry (fast kernel)
+    (2, 256, 6, 11, 256, 1, 4, 3, 1, 1, 1, True, 2.0),      # level 2
+    (1, 128, 7, 9, 128, 1, 4, 3, 1, 1, 1, False, 6.0),      # most samples leave the image; no bias
+    (2, 64, 8, 8, 64, 1, 2, 3, 1, 1, 1, True, 1.0),         # general kernel
+    (1, 32, 10, 12, 48, 2, 2, 3, 2, 2, 2, True, 1.5),       # conv groups, stride 2, dilation 2
+    (3, 16, 5, 17, 8, 1, 1, 3, 1, 0, 1, False, 0.7),        # no padding, one deformable group
+    (1, 24, 6, 7, 24, 1, 3, 1, 1, 0, 1, True, 1.0),         # 1x1 kernel
+]
+
+
+@pytest.mark.parametrize("case", V2_CASES)
+def test_c_oracle_forward_is_the_reference_kernel(case):
+    B, C, H, W, Co, groups, dg, k, stride, pad, dil, with_bias, sc = case
+    R = ref_ext.load()
+    x, off, m, w, b, _ = _case(11 + C + H, B, C, H, W, Co, groups, dg, k, stride, pad, dil, sc)
+    ref = _v2_forward(R, x.cuda(), off.cuda(), m.cuda(), w.cuda(), b.cuda(), k, stride, pad, dil, groups, dg, with_bias).cpu().numpy()
+    got = c_ref.dcn_forward(x.numpy(), off.numpy(), m.numpy(), w.numpy(), b.numpy() if with_bias else None, stride=stride, padding=pad,
+                            dilation=dil, groups=groups, dg=dg)
+    e = _rel(got, ref)
+    print("[dcn pin] forward  oracle vs reference %s: %.2e" % (case, e))
+    within(e, ORACLE_TOL)
+
+
+@pytest.mark.parametrize("case", V2_CASES)
+def test_c_oracle_backward_is_the_reference_kernel(case):
+    B, C, H, W, Co, groups, dg, k, stride, pad, dil, with_bias, sc = case
+    R = ref_ext.load()
+    x, off, m, w, b, go = _case(23 + C + W, B, C, H, W, Co, groups, dg, k, stride, pad, dil, sc)
+    ref = _v2_backward(R, x.cuda(), off.cuda(), m.cuda(), w.cuda(), b.cuda(), go.cuda(), k, stride, pad, dil, groups, dg, with_bias)
+    got = c_ref.dcn_backward(x.numpy(), off.numpy(), m.numpy(), w.numpy(), go.numpy(), with_bias=with_bias, stride=stride, padding=pad,
+                             dilation=dil, groups=groups, dg=dg)
+    for name, g_, r_ in zip(("grad_input", "grad_offset", "grad_mask", "grad_weight", "grad_bias"), got, ref):
+        if r_ is None:
+            continue
+        e = _rel(g_, r_.cpu().numpy())
+        print("[dcn pin] backward oracle vs reference %s %s: %.2e" % (case, name, e))
+        within(e, ORACLE_TOL, name)
+
+
+@pytest.mark.parametrize("case", V2_CASES)
+def test_product_drop_in_matches_the_reference_extension(case):
+    """The SAME call on both modules: the product's `deform_conv_ext` is a drop-in for the reference's (north_star's boundary)."""
+    from glare_amd.modules.ops.dcn.deform_conv import deform_conv_ext as P
+
+    B, C, H, W, Co, groups, dg, k, stride, pad, dil, with_bias, sc = case
+    R = ref_ext.load()
+    x, off, m, w, b, go = (t.cuda() for t in _case(37 + C + H, B, C, H, W, Co, groups, dg, k, stride, pad, dil, sc))
+    ref = _v2_forward(R, x, off, m, w, b, k, stride, pad, dil, groups, dg, with_bias)
+    got = _v2_forward(P, x, off, m, w, b, k, stride, pad, dil, groups, dg, with_bias)
+    e = _rel(got.cpu().numpy(), ref.cpu().numpy())
+    print("[dcn pin] forward  product vs reference %s: %.2e" % (case, e))
+    within(e, PRODUCT_FWD_TOL)
+    refs = _v2_backward(R, x, off, m, w, b, go, k, stride, pad, dil, groups, dg, with_bias)
+    gots = _v2_backward(P, x, off, m, w, b, go, k, stride, pad, dil, groups, dg, with_bias)
+    for name, g_, r_ in zip(("grad_input", "grad_offset", "grad_mask", "grad_weight", "grad_bias"), gots, refs):
+        if r_ is None:
+            continue
+        e = _rel(g_.cpu().numpy(), r_.cpu().numpy())
+        print("[dcn pin] backward product vs reference %s %s: %.2e" % (case, name, e))
+        within(e, PRODUCT_BWD_TOL, name)
+
+
+V1_CASES = [  # B, C, H, W, Co, groups, dg, stride, pad, dil, im2col_step
+    (1, 16, 9, 11, 16, 1, 1, 1, 1, 1, 1),
+    (1, 32, 8, 10, 24, 2, 2, 2, 1, 1, 1),
+    (1, 64, 7, 9, 64, 1, 4, 1, 2, 2, 1),      # dilation 2, four deformable groups
+    (2, 16, 9, 11, 16, 1, 1, 1, 1, 1, 2),     # cur_im2col_step = min(64, batch) = 2: see the note in _v1
+]
+
+
+def _v1(ext, x, off, w, go, stride, pad, dil, groups, dg, step, want_gw=True):
+    """DeformConvFunction.forward / backward's three calls, verbatim (deform_conv.py:56-111): NOTE W before H.
+    With im2col_step > 1 the REFERENCE's deform_conv_backward_parameters raises in this PyTorch (a `.view` of a transposed
+    gradOutput, deform_conv_cuda.cpp:430-440: "view size is not compatible ..."), so the weight gradient is compared at step 1
+    (the same mathematics: the step only batches the im2col) and the step-2 case covers the other two entry points."""
+    kH, kW = w.shape[2], w.shape[3]
+    out = x.new_empty(x.shape[0], w.shape[0], off.shape[2], off.shape[3])
+    bufs = [x.new_empty(0), x.new_empty(0)]
+    ext.deform_conv_forward(x, w, off, out, bufs[0], bufs[1], kW, kH, stride, stride, pad, pad, dil, dil, groups, dg, step)
+    gx, goff, gw = torch.zeros_like(x), torch.zeros_like(off), torch.zeros_like(w)
+    ext.deform_conv_backward_input(x, off, go, gx, goff, w, bufs[0], kW, kH, stride, stride, pad, pad, dil, dil, groups, dg, step)
+    if want_gw:
+        ext.deform_conv_backward_parameters(x, off, go, gw, bufs[0], bufs[1], kW, kH, stride, stride, pad, pad, dil, dil, groups, dg, 1, step)
+    return out, gx, goff, gw
+
+
+@pytest.mark.parametrize("case", V1_CASES)
+def test_v1_entry_points_match_the_reference_extension(case):
+    from glare_amd.modules.ops.dcn.deform_conv import deform_conv_ext as P
+
+    B, C, H, W, Co, groups, dg, stride, pad, dil, step = case
+    R = ref_ext.load()
+    x, off, _, w, _, go = (t.cuda() for t in _case(51 + C, B, C, H, W, Co, groups, dg, 3, stride, pad, dil, 1.5))
+    refs = _v1(R, x, off, w, go, stride, pad, dil, groups, dg, step, want_gw=step == 1)
+    gots = _v1(P, x, off, w, go, stride, pad, dil, groups, dg, step, want_gw=step == 1)
+    # ... and the C oracle with mask == 1, no bias (the unmodulated operator: deform_conv_cuda_kernel.cu:190-236 vs :571-633)
+    ones = np.ones((B, dg * 9, off.shape[2], off.shape[3]), dtype=np.float32)
+    o_out = c_ref.dcn_forward(x.cpu().numpy(), off.cpu().numpy(), ones, w.cpu().numpy(), None, stride=stride, padding=pad, dilation=dil,
+                              groups=groups, dg=dg)
+    e = _rel(o_out, refs[0].cpu().numpy())
+    print("[dcn pin] v1 forward oracle vs reference %s: %.2e" % (case, e))
+    within(e, ORACLE_TOL)
+    for name, g_, r_ in zip(("output", "grad_input", "grad_offset", "grad_weight"), gots, refs):
+        if name == "grad_weight" and step != 1:
+            continue
+        e = _rel(g_.cpu().numpy(), r_.cpu().numpy())
+        print("[dcn pin] v1 %s product vs reference %s: %.2e" % (name, case, e))
+        within(e, PRODUCT_FWD_TOL if name == "output" else PRODUCT_BWD_TOL, name)
+
+
+def test_pipeline_shape_and_reference_error_behaviour():
+    """One warp of the path at its real width (128 channels, dg 4) on a 105 x 155 level, and the reference's own argument checks."""
+    from glare_amd.modules.ops.dcn.deform_conv import deform_conv_ext as P
+
+    R = ref_ext.load()
+    x, off, m, w, b, _ = (t.cuda() for t in _case(77, 1, 128, 105, 155, 128, 1, 4, 3, 1, 1, 1, 3.0))
+    ref = _v2_forward(R, x, off, m, w, b, 3, 1, 1, 1, 1, 4, True)
+    got = _v2_forward(P, x, off, m, w, b, 3, 1, 1, 1, 1, 4, True)
+    e = _rel(got.cpu().numpy(), ref.cpu().numpy())
+    print("[dcn pin] 128 ch 105x155 product vs reference: %.2e" % e)
+    within(e, PRODUCT_FWD_TOL)
+    o = c_ref.dcn_forward(x.cpu().numpy(), off.cpu().numpy(), m.cpu().numpy(), w.cpu().numpy(), b.cpu().numpy(), dg=4)
+    within(_rel(o, ref.cpu().numpy()), ORACLE_TOL, "oracle")
+    # both refuse a kernel / channel mismatch and CPU tensors (deform_conv_cuda.cpp:511-516, deform_conv_ext.cpp:124)
+    for ext in (R, P):
+        with pytest.raises(RuntimeError):
+            _v2_forward(ext, x, off, m, w[:, :64].contiguous(), b, 3, 1, 1, 1, 1, 4, True)
+        with pytest.raises(RuntimeError):
+            _v2_forward(ext, x.cpu(), off.cpu(), m.cpu(), w.cpu(), b.cpu(), 3, 1, 1, 1, 1, 4, True)
+
+
+@pytest.mark.parametrize("B,C,H,W,dg", [(2, 128, 420, 620, 4), (2, 256, 210, 310, 4)])
+def test_full_size_warps_of_the_path_against_the_reference_kernels(B, C, H, W, dg):
+    """BASELINE's full sizes: the two warp levels of the AFT decoder at 400x600 (padded 420x620 / 210x310), forward through
+    the drop-in entry point AND through the pipeline's NHWC kernel, against the reference's im2col + sgemm on the same
+    inputs (its `columns` buffer alone is 1.2 GB per image here -- the tensor the fused kernel never materialises)."""
+    from glare_amd import ops
+    from glare_amd.modules.ops.dcn.deform_conv import deform_conv_ext as P
+
+    R = ref_ext.load()
+    x, off, m, w, b, go = (t.cuda() for t in _case(90 + C, B, C, H, W, C, 1, dg, 3, 1, 1, 1, 2.5))
+    ref = _v2_forward(R, x, off, m, w, b, 3, 1, 1, 1, 1, dg, True)
+    got = _v2_forward(P, x, off, m, w, b, 3, 1, 1, 1, 1, dg, True)
+    e = _rel(got.cpu().numpy(), ref.cpu().numpy())
+    print("[dcn pin] full size %dx%dx%d forward product vs reference: %.2e" % (C, H, W, e))
+    within(e, PRODUCT_FWD_TOL, "drop-in")
+    # the pipeline's own entry: 16-bit NHWC activations, offsets + mask LOGITS in one planar buffer (deformableDecoder_arch.py:143)
+    xh = x.to(ops.act_dtype())
+    logits = torch.log(m / (1 - m)).clamp(-20, 20)
+    om = torch.cat([off.reshape(B, dg * 18, H * W), logits.reshape(B, dg * 9, H * W)], 1).contiguous()
+    pd = ops.PackedDcn(w, b, dg)
+    got2 = ops.mdcn_forward_nhwc(xh.permute(0, 2, 3, 1).contiguous(), om, pd, x_off=0, C=C).permute(0, 3, 1, 2)
+    ref2 = _v2_forward(R, xh.float(), off, torch.sigmoid(logits), w, b, 3, 1, 1, 1, 1, dg, True)
+    e2 = _rel(got2.float().cpu().numpy(), ref2.cpu().numpy())
+    print("[dcn pin] full size %dx%dx%d forward NHWC pipeline kernel vs reference: %.2e" % (C, H, W, e2))
+    within(e2, PRODUCT_FWD_TOL, "nhwc")
+    # gradients at the full size: all five against the reference's col2im / sgemm
+    refs = _v2_backward(R, x, off, m, w, b, go, 3, 1, 1, 1, 1, dg, True)
+    gots = _v2_backward(P, x, off, m, w, b, go, 3, 1, 1, 1, 1, dg, True)
+    for name, g_, r_ in zip(("grad_input", "grad_offset", "grad_mask", "grad_weight", "grad_bias"), gots, refs):
+        e = _rel(g_.cpu().numpy(), r_.cpu().numpy())
+        print("[dcn pin] full size %dx%dx%d backward product vs reference %s: %.2e" % (C, H, W, name, e))
+        within(e, FULL_BWD_TOL, name)
+
+
+def test_backward_noise_attribution_at_a_path_level():
+    """Whose rounding is the gradient difference at large extents?  One 128-channel warp at 105 x 155: the reference's gradients and
+    the product's, each against the C oracle (double accumulation).  Both sit at fp32 accumulation noise; neither is the outlier."""
+    from glare_amd.modules.ops.dcn.deform_conv import deform_conv_ext as P
+
+    R = ref_ext.load()
+    x, off, m, w, b, go = _case(123, 1, 128, 105, 155, 128, 1, 4, 3, 1, 1, 1, 2.5)
+    orc = c_ref.dcn_backward(x.numpy(), off.numpy(), m.numpy(), w.numpy(), go.numpy(), with_bias=True, dg=4)
+    xs = [t.cuda() for t in (x, off, m, w, b, go)]
+    refs = _v2_backward(R, *xs, 3, 1, 1, 1, 1, 4, True)
+    gots = _v2_backward(P, *xs, 3, 1, 1, 1, 1, 4, True)
+    for name, o_, r_, g_ in zip(("grad_input", "grad_offset", "grad_mask", "grad_weight", "grad_bias"), orc, refs, gots):
+        er, ep = _rel(r_.cpu().numpy(), o_), _rel(g_.cpu().numpy(), o_)
+        print("[dcn pin] 105x155 %s vs C oracle: reference %.2e, product %.2e" % (name, er, ep))
+        within(er, FULL_BWD_TOL, name + ":reference")
+        within(ep, FULL_BWD_TOL, name + ":product")
