@@ -769,6 +769,16 @@ def main():
 
     if rank == 0 and not args.no_cpu_baseline and world == 1 and not STUB:  # reported at N = 1 only
         res["cpu_baseline"] = cpu_baseline()
+        # NOT measured by this run (bench.py executes nothing under oracle/ outside cpu_baseline): a citation of the committed GPU-side
+        # measurement of the reference's own path on this hardware, beside the CPU figure above
+        res["reference_on_mi355x"] = {
+            "measured_by_this_run": False,
+            "images_per_sec_fp16_autocast": 12.7, "images_per_sec_fp32": 7.2, "batch": 8,
+            "what": "the reference's algorithm on stock PyTorch-ROCm ops (the torch oracle moved to the GPU, bit-identical to the imported "
+                    "reference on the CPU) with the reference's OWN deform_conv_ext built for gfx950 (oracle/build_ref.py), fp16 autocast as "
+                    "infer_dataset_lol.py:134 runs it; same box: product 62.5-63.7 images/s on one stream",
+            "index_agreement_with_reference_fp32": {"reference_fp16_autocast": 0.6576, "product": 0.9995},
+            "source": "profiles/r06_reference_on_device.txt (tests/test_gpu_reference_on_device.py, -m gpu)"}
     emit()
     if dist is not None:
         dog.stage("final barrier")                 # the line is out: a hang here only ends the job

@@ -1,0 +1,181 @@
+"""GPU: the REFERENCE'S ALGORITHM EXECUTED ON THE MI355X -- the torch oracle (oracle/torch_ref.py, bit-identical to the imported
+reference on the CPU: tests/test_oracle_vs_reference.py) moved to cuda:0 on stock PyTorch-ROCm ops, with its deformable convolution
+replaced by the REFERENCE'S OWN extension built for gfx950 (oracle/_ref/deform_conv_ext_ref.so, oracle/build_ref.py).  That is
+what a user of the reference gets on this hardware today: eager torch ops + the reference's DCN kernels.
+
+Two uses, both test infrastructure:
+  1. parity at BASELINE's full size against an fp32 run of the reference's algorithm ON THE DEVICE (the CPU oracle needs ~20 s
+     per 400x600 image; this one a fraction of a second, so a batch of scenes is cheap), with the reference's own DCN kernels
+     inside the graph instead of their restatement;
+  2. the reference path's own rate on the MI355X, in fp32 and under fp16 autocast (`infer_dataset_lol.py:134`), printed beside
+     the product's on the same box (profiles/r06_reference_on_device.txt).  Reported, never asserted as a target."""
+import os
+import time
+
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")     # the stock-op side: no exhaustive per-shape search on a fresh box
+
+import numpy as np
+import pytest
+import torch
+
+from glare_amd import harness
+from glare_amd import modules as M
+from glare_amd.synthetic import representative_init_, synthetic_pair
+from oracle import ref_ext
+from oracle import torch_ref as O
+from tolerances import within
+
+pytestmark = pytest.mark.gpu
+
+if not ref_ext.exists():
+    pytest.skip("oracle/_ref/deform_conv_ext_ref.so not built (python oracle/build_ref.py needs /root/reference)", allow_module_level=True)
+
+
+def _reference_dcn(x, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1):
+    """ModulatedDeformConvFunction.forward's call on the reference's extension (deform_conv.py:143-156); fp32 as the reference
+    runs it (deformableDecoder_arch.py:139: `out.to(torch.float32)`; the extension dispatches on ONE scalar type)."""
+    R = ref_ext.load()
+    x, offset, mask, weight = x.float().contiguous(), offset.float().contiguous(), mask.float().contiguous(), weight.float().contiguous()
+    with_bias = bias is not None
+    b = bias.float().contiguous() if with_bias else x.new_empty(1)
+    Co, _, kh, kw = weight.shape
+    out = x.new_empty(x.shape[0], Co, offset.shape[2], offset.shape[3])
+    R.modulated_deform_conv_forward(x, weight, b, x.new_empty(0), offset, mask, out, x.new_empty(0), kh, kw, stride, stride, padding,
+                                    padding, dilation, dilation, groups, deformable_groups, with_bias)
+    return out
+
+
+_CPU_DCN = [None]      # the oracle's own (pure-torch) deformable convolution, for the CPU leg of the last test
+
+
+@pytest.fixture(scope="module")
+def nets():
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    og, ov = representative_init_(O.VQLLFLOWDeformable(per_sample_mean=True).eval(), O.VQModel().eval(), 0)
+    pg, pv = M.VQLLFLOWDeformable().eval(), M.VQModel().eval()
+    pg.load_state_dict(og.state_dict(), strict=True)
+    pv.load_state_dict(ov.state_dict(), strict=True)
+    og, ov, pg, pv = og.cuda(), ov.cuda(), pg.cuda(), pv.cuda()
+    keep = O.modulated_deform_conv
+    _CPU_DCN[0] = keep
+    O.modulated_deform_conv = _reference_dcn          # the reference's kernels inside the reference's graph
+    torch.backends.cuda.matmul.allow_tf32 = False
+    torch.backends.cudnn.allow_tf32 = False
+    yield og, ov, pg, pv
+    O.modulated_deform_conv = keep
+
+
+def _psnr(a, b):
+    return float(10 * np.log10(1.0 / max(float(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2)), 1e-30)))
+
+
+def test_full_size_scenes_against_the_reference_algorithm_run_on_the_device(nets, capsys):
+    """Four 400x600 scenes as ONE batch: the product (fp16 default, fp32-class front) against the fp32 run of the reference's
+    algorithm on the same GPU with the reference's DCN kernels.  Same quantities and bounds as the CPU-oracle test
+    (tests/test_gpu_precision.py: latent 2.8e-5, 1 - agreement 1.47e-3, |dPSNR vs GT| 0.0088 dB)."""
+    og, ov, pg, pv = nets
+    h, w, B = 400, 600, 4
+    pairs = [synthetic_pair(1, h, w, seed=31 + i) for i in range(B)]
+    lr = torch.cat([harness.preprocess_batch(p[0]) for p in pairs]).cuda()
+    gts = [p[1][0] for p in pairs]
+    with torch.no_grad():
+        ref = og.stages(ov, lr)
+        got = pg.reverse_flow_nhwc(pv, lr)
+    torch.cuda.synchronize()
+    assert ref["out"].dtype == torch.float32
+    rows = []
+    for i in range(B):
+        lat_r = ref["latent"][i].float()
+        lat_g = got["latent"][i].permute(2, 0, 1).float() if got["latent"].shape[-1] == lat_r.shape[0] else got["latent"][i].float()
+        lat = float((lat_g - lat_r).norm() / lat_r.norm())
+        agree = float((got["indices"].view(B, -1)[i] == ref["indices"].view(B, -1)[i]).float().mean())
+        a = O.postprocess(got["out"][i:i + 1].float().cpu(), h, gts[i])
+        b = O.postprocess(ref["out"][i:i + 1].float().cpu(), h, gts[i])
+        pa, pb = O.psnr(gts[i] / 255, a), O.psnr(gts[i] / 255, b)
+        rows.append((i, lat, agree, _psnr(O.postprocess(got["out"][i:i + 1].float().cpu(), h), O.postprocess(ref["out"][i:i + 1].float().cpu(), h)),
+                     float(abs(pa - pb))))
+    with capsys.disabled():
+        for r in rows:
+            print("\n[reference on device, 400x600 scene %d] latent rel %.2e | index agreement %.5f | PSNR(ours, reference) %.2f dB | "
+                  "|dPSNR vs GT| %.4f dB" % r, end="")
+        print()
+    for i, lat, agree, psnr, delta in rows:
+        within(lat, 2.8e-5)
+        within(1.0 - agree, 1.47e-3)
+        within(delta, 0.0088)
+
+
+def _rate(fn, batch, reps):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return batch * reps / (time.time() - t0)
+
+
+def test_rate_of_the_reference_path_on_this_gpu(nets, capsys):
+    """images/s of the reference's algorithm on the MI355X (stock torch ops + the reference's DCN kernels): fp32, and under fp16
+    autocast as `infer_dataset_lol.py:134` runs it, batch 8 of 400x600 -- BASELINE configs[1] -- beside the product on this box."""
+    og, ov, pg, pv = nets
+    B = 8
+    lr = torch.cat([harness.preprocess_batch(synthetic_pair(1, 400, 600, seed=50 + i)[0]) for i in range(B)]).cuda()
+    res = {}
+    with torch.no_grad():
+        res["reference fp32 (eager torch + reference DCN)"] = _rate(lambda: og.stages(ov, lr), B, 2)
+        with torch.autocast("cuda", dtype=torch.float16):
+            o16 = og.stages(ov, lr)["out"]
+            res["reference fp16 autocast (infer_dataset_lol.py:134)"] = _rate(lambda: og.stages(ov, lr), B, 3)
+            i16 = ov.last_indices.clone()
+        res["product (fp16 default, one stream)"] = _rate(lambda: pg.reverse_flow_nhwc(pv, lr), B, 5)
+        o32 = og.stages(ov, lr)["out"]
+        i32 = ov.last_indices.clone()
+        got = pg.reverse_flow_nhwc(pv, lr)
+    # what the reference's OWN autocast costs against its fp32 self on this GPU -- the context of the product's parity figures
+    d16 = _psnr(O.postprocess(o16[:1].float().cpu(), 400), O.postprocess(o32[:1].float().cpu(), 400))
+    dpr = _psnr(O.postprocess(got["out"][:1].float().cpu(), 400), O.postprocess(o32[:1].float().cpu(), 400))
+    a16 = float((i16.view(-1) == i32.view(-1)).float().mean())
+    apr = float((got["indices"].view(-1) == i32.view(-1)).float().mean())
+    with capsys.disabled():
+        for k, v in res.items():
+            print("\n[reference on device] %-52s %8.2f images/s" % (k, v), end="")
+        print("\n[reference on device] against the reference's fp32 run, batch of 8: reference under fp16 autocast -- index agreement %.5f, "
+              "PSNR %.2f dB (scene 0); product -- index agreement %.5f, PSNR %.2f dB" % (a16, d16, apr, dpr))
+    assert torch.isfinite(o32).all()
+    assert apr >= a16 and dpr >= d16          # the product is closer to the reference's fp32 self than the reference's own autocast run
+    assert res["product (fp16 default, one stream)"] > res["reference fp16 autocast (infer_dataset_lol.py:134)"]
+
+
+def test_two_fp32_runs_of_the_reference_algorithm_cpu_and_gpu(nets, capsys):
+    """The SAME fp32 algorithm on two stock back ends (torch CPU = the oracle every other test uses; torch ROCm + the reference's
+    DCN kernels) on one 400x600 scene: the CPU oracle's pin carried onto the device.  Measured: latent 5.0e-6 apart, EVERY one of
+    the 16 275 indices equal, outputs 118 dB apart (the product on the same scene: 1.2e-5, 5 tokens, 64.7 dB) -- two fp32 runs do
+    not flip tokens on this scene, the product's 2-13 flips per scene are its own and each is audited as a near-tie (oracle/audit.py)."""
+    og, ov, pg, pv = nets
+    h = 400
+    lr = harness.preprocess_batch(synthetic_pair(1, h, 600, seed=31)[0])
+    with torch.no_grad():
+        g = og.stages(ov, lr.cuda())
+        gi, glat, gout = ov.last_indices.clone().cpu(), g["latent"].float().cpu(), g["out"].float().cpu()
+        og.cpu(), ov.cpu()
+        keep, O.modulated_deform_conv = O.modulated_deform_conv, _CPU_DCN[0]
+        try:
+            c = og.stages(ov, lr)
+        finally:
+            O.modulated_deform_conv = keep
+            og.cuda(), ov.cuda()
+        got = pg.reverse_flow_nhwc(pv, lr.cuda())
+    ci = c["indices"].cpu()
+    agree_gc = float((gi.view(-1) == ci.view(-1)).float().mean())
+    agree_pc = float((got["indices"].cpu().view(-1) == ci.view(-1)).float().mean())
+    agree_pg = float((got["indices"].cpu().view(-1) == gi.view(-1)).float().mean())
+    lat = float((glat - c["latent"]).norm() / c["latent"].norm())
+    psnr = _psnr(O.postprocess(gout, h), O.postprocess(c["out"], h))
+    with capsys.disabled():
+        print("\n[reference on device] fp32 on ROCm vs fp32 on the CPU, one 400x600 scene: latent rel %.2e | index agreement %.5f (%d tokens) | PSNR %.2f dB"
+              "\n[reference on device] product vs the CPU run %.5f, vs the ROCm run %.5f"
+              % (lat, agree_gc, round((1 - agree_gc) * ci.numel()), psnr, agree_pc, agree_pg))
+    within(lat, 1.0e-5)                       # measured 4.95e-6
+    assert (1.0 - agree_gc) * ci.numel() <= 2.5, agree_gc      # measured: 0 of 16 275 tokens differ
+    within(200.0 - psnr, 200.0 - 112.0)       # measured 118.0 dB
