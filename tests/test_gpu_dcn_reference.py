@@ -248,3 +248,43 @@ def test_backward_noise_attribution_at_a_path_level():
         print("[dcn pin] 105x155 %s vs C oracle: reference %.2e, product %.2e" % (name, er, ep))
         within(er, FULL_BWD_TOL, name + ":reference")
         within(ep, FULL_BWD_TOL, name + ":product")
+
+
+def test_timing_of_the_reference_kernels_at_the_path_shapes(capsys):
+    """Reported, not a target: the reference's own im2col + sgemm forward (and its backward) at the AFT decoder's two warp levels,
+    batch 8, against the product's drop-in entry point and its pipeline kernel on the same box."""
+    from glare_amd import ops
+    from glare_amd.modules.ops.dcn.deform_conv import deform_conv_ext as P
+
+    R = ref_ext.load()
+
+    def ms(fn, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / reps
+
+    rows = []
+    for C, H, W in ((128, 420, 620), (256, 210, 310)):
+        x, off, m, w, b, go = (t.cuda() for t in _case(5 + C, 8, C, H, W, C, 1, 4, 3, 1, 1, 1, 2.0))
+        fr = ms(lambda: _v2_forward(R, x, off, m, w, b, 3, 1, 1, 1, 1, 4, True))
+        fp = ms(lambda: _v2_forward(P, x, off, m, w, b, 3, 1, 1, 1, 1, 4, True))
+        br = ms(lambda: _v2_backward(R, x, off, m, w, b, go, 3, 1, 1, 1, 1, 4, True), 3)
+        bp = ms(lambda: _v2_backward(P, x, off, m, w, b, go, 3, 1, 1, 1, 1, 4, True), 3)
+        xh = x.to(ops.act_dtype()).permute(0, 2, 3, 1).contiguous()
+        om = torch.cat([off.reshape(8, 72, H * W), torch.zeros(8, 36, H * W, device="cuda")], 1).contiguous()
+        pd = ops.PackedDcn(w, b, 4)
+        fk = ms(lambda: ops.mdcn_forward_nhwc(xh, om, pd, x_off=0, C=C))
+        rows.append((C, H, W, fr, fp, fk, br, bp))
+    with capsys.disabled():
+        for r in rows:
+            print("\n[dcn pin] timing 8x%dx%dx%d: forward reference %.2f ms | drop-in (NCHW fp32 in / out) %.2f ms | pipeline NHWC kernel %.2f ms || "
+                  "backward reference %.2f ms | drop-in %.2f ms" % r, end="")
+        print()
+    for C, H, W, fr, fp, fk, br, bp in rows:
+        assert fp < fr and bp < br
