@@ -107,6 +107,28 @@ def bench_conv():
             print("conv  %-22s: igemm %.3f ms, weight-stationary %.3f ms = %.0f GB/s algorithmic (x in + out)" % (name, ms_old, ms_new, by / ms_new / 1e6))
 
 
+def bench_convtile():
+    """The output-channel tile (glare_conv_desc.cout_tile) at the path's shapes: 128 (default) against 64 -- twice the workgroups of
+    half the accumulators (4 instead of 3 workgroups per CU), for the launches whose K loop is short (Cin = 128) or whose tile count
+    rounds badly (8 480 tiles on 768 slots at full resolution)."""
+    for name, ci, co, h, w in (("128->128 3x3 @full", 128, 128, 420, 620), ("256->256 3x3 @half", 256, 256, 210, 310),
+                               ("512->512 3x3 @q", 512, 512, 105, 155), ("256->128 3x3 @full", 256, 128, 420, 620)):
+        x = torch.randn(B, h, w, ci, device=DEV).to(ops.act_dtype())
+        wt = torch.randn(co, ci, 3, 3, device=DEV) * 0.02
+        res = torch.randn(B, h, w, co, device=DEV).to(ops.act_dtype())
+        out = torch.empty(B, h, w, co, dtype=ops.act_dtype(), device=DEV)
+        fl = 2.0 * B * h * w * ci * co * 9
+        ref = None
+        for tile in (0, 64, 0, 64):
+            pc = ops.PackedConv(wt, torch.zeros(co, device=DEV), cout_tile=tile)
+            ms = timeit(lambda: ops.conv2d(x, pc, out=out, gn_stats=True))
+            msr = timeit(lambda: ops.conv2d(x, pc, out=out, residual=res, gn_stats=True))
+            same = "" if ref is None else ("  bit-identical" if torch.equal(out, ref) else "  DIFFERS")
+            ref = out.clone() if ref is None else ref
+            print("convtile %-20s tile %3d: %.3f ms %.0f TFLOP/s | + residual %.3f ms %.0f TFLOP/s%s"
+                  % (name, tile or 128, ms, fl / ms / 1e9, msr, fl / msr / 1e9, same))
+
+
 def bench_convsplit():
     """The fp32-class form (glare_conv_desc.k_wrap; ops.PackedConv(split=3)) at the conditional encoder's shapes, fp16, pair in / pair
     out: TFLOP/s by ALGORITHMIC FLOPs (one fp32 conv) and by executed MFMA FLOPs (3 K segments)."""
