@@ -778,7 +778,10 @@ def main():
                     "reference on the CPU) with the reference's OWN deform_conv_ext built for gfx950 (oracle/build_ref.py), fp16 autocast as "
                     "infer_dataset_lol.py:134 runs it; same box: product 62.5-63.7 images/s on one stream",
             "index_agreement_with_reference_fp32": {"reference_fp16_autocast": 0.6576, "product": 0.9995},
-            "source": "profiles/r06_reference_on_device.txt (tests/test_gpu_reference_on_device.py, -m gpu)"}
+            "train_ms_per_step": {"stage2_reference": 98.9, "stage2_product": 20.7, "stage3_reference": 124.1, "stage3_product": 19.6,
+                                  "what": "the reference's step bodies (LLFlow_model.py:181-250, VQLLFLOWD_model.py:187-232) on stock ops under autocast + "
+                                          "GradScaler + torch.optim.Adam with the reference's DCN forward / backward, per-GPU crops of BASELINE configs[3] / [4]"},
+            "source": "profiles/r06_reference_on_device.txt (tests/test_gpu_reference_on_device.py, tests/test_gpu_reference_training_on_device.py, -m gpu)"}
     emit()
     if dist is not None:
         dog.stage("final barrier")                 # the line is out: a hang here only ends the job

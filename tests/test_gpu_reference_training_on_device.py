@@ -1,0 +1,145 @@
+"""GPU: the reference's two TRAINING steps executed on the MI355X -- rows a12 / a13 -- as a user of the reference gets them on this
+hardware: the torch oracle's modules on stock PyTorch-ROCm ops under `torch.autocast` + `GradScaler` + `torch.optim.Adam`, the
+step bodies of `LLFlow_model.py:181-250` and `VQLLFLOWD_model.py:187-232` (including their `torch.cuda.empty_cache()` and
+`.item()`), the DCN forward AND backward through the reference's own extension (oracle/_ref/deform_conv_ext_ref.so) wrapped the
+way `deform_conv.py:136-176` wraps it.  Printed beside the product's trainers on the same box at BASELINE configs[3] / [4]'s
+per-GPU crops (2 x 3x320x320, 1 x 3x256x256); reported, not a target (profiles/r06_reference_on_device.txt)."""
+import os
+import time
+
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+
+import pytest
+import torch
+
+from glare_amd import modules as M
+from glare_amd.synthetic import seeded_init_
+from oracle import ref_ext
+from oracle import torch_ref as O
+
+pytestmark = pytest.mark.gpu
+
+if not ref_ext.exists():
+    pytest.skip("oracle/_ref/deform_conv_ext_ref.so not built (python oracle/build_ref.py needs /root/reference)", allow_module_level=True)
+
+
+class _RefDCN(torch.autograd.Function):
+    """ModulatedDeformConvFunction (deform_conv.py:136-176) on the reference's extension."""
+
+    @staticmethod
+    def forward(ctx, x, offset, mask, weight, bias, stride, padding, dilation, groups, dg):
+        R = ref_ext.load()
+        x, offset, mask, weight, bias = (t.float().contiguous() for t in (x, offset, mask, weight, bias))
+        ctx.cfg = (stride, padding, dilation, groups, dg)
+        ctx.save_for_backward(x, offset, mask, weight, bias)
+        Co, _, kh, kw = weight.shape
+        out = x.new_empty(x.shape[0], Co, offset.shape[2], offset.shape[3])
+        ctx.bufs = [x.new_empty(0), x.new_empty(0)]
+        R.modulated_deform_conv_forward(x, weight, bias, ctx.bufs[0], offset, mask, out, ctx.bufs[1], kh, kw, stride, stride, padding, padding,
+                                        dilation, dilation, groups, dg, True)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        R = ref_ext.load()
+        x, offset, mask, weight, bias = ctx.saved_tensors
+        stride, padding, dilation, groups, dg = ctx.cfg
+        gx, goff, gm, gw, gb = (torch.zeros_like(t) for t in (x, offset, mask, weight, bias))
+        R.modulated_deform_conv_backward(x, weight, bias, ctx.bufs[0], offset, mask, ctx.bufs[1], gx, gw, gb, goff, gm, go.float().contiguous(),
+                                         weight.shape[2], weight.shape[3], stride, stride, padding, padding, dilation, dilation, groups, dg, True)
+        return gx, goff, gm, gw, gb, None, None, None, None, None
+
+
+def _ref_dcn(x, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1):
+    return _RefDCN.apply(x, offset, mask, weight, bias, stride, padding, dilation, groups, deformable_groups)
+
+
+def _ms(fn, steps, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.time() - t0) / steps * 1e3
+
+
+def test_training_steps_of_the_reference_on_this_gpu(capsys):
+    from glare_amd.train import GraphedStep, Stage2Trainer, Stage3Trainer
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(10)
+    rows = []
+    keep = O.modulated_deform_conv
+    O.modulated_deform_conv = _ref_dcn
+    try:
+        # ---- stage 2 (row a12): frozen VQGAN encoder -> NLL of the flow in the normal direction -> Adam on RRDB + flow
+        B, S = 2, 320
+        gt = torch.rand(B, 3, S, S, generator=g).to(dev)
+        lr = (torch.randn(B, 3, S, S, generator=g) * 0.5 - 1.0).to(dev)
+        ref_hq = seeded_init_(O.VQModel().eval(), 1).to(dev)
+        ref_g = seeded_init_(O.LLFlowVQGAN2().train(), 2).to(dev)
+        opt = torch.optim.Adam([p for p in ref_g.parameters() if p.requires_grad], lr=1e-4, betas=(0.9, 0.99))
+        scaler = torch.amp.GradScaler("cuda")
+
+        def ref_step2():
+            torch.cuda.empty_cache()                                   # LLFlow_model.py:182
+            opt.zero_grad()
+            with torch.no_grad():
+                enc_gt = ref_hq.encode(gt)
+                enc_gt = enc_gt[0] if isinstance(enc_gt, (tuple, list)) else enc_gt
+            with torch.autocast("cuda", dtype=torch.float16):          # @autocast() on the forward, LLFlowVQGAN_arch.py:36
+                _, nll, _ = ref_g.normal_flow(enc_gt.detach(), lr)
+            loss = nll.float().mean()
+            scaler.scale(loss).backward()
+            scaler.step(opt)
+            scaler.update()
+            return loss.item()                                         # :247
+
+        l0 = ref_step2()
+        ref2 = _ms(ref_step2, 5)
+        hq = seeded_init_(M.VQModel().eval(), 1).to(dev)
+        tr2 = Stage2Trainer(seeded_init_(M.LLFlowVQGAN2().train(), 2).to(dev), hq, device_state=True, precision="fp16")
+        run2 = GraphedStep(tr2, gt, lr)
+        ours2 = _ms(lambda: run2.step_tensor(gt, lr), 10, 3)
+        rows.append(("stage 2 (2 x 3x320x320)", ref2, ours2, l0))
+        del ref_g, opt, tr2, run2
+        torch.cuda.empty_cache()
+
+        # ---- stage 3 (row a13): the whole path with only the AFT decoder on the tape -> l1 + 0.01 perceptual + 0.2 (1 - MS-SSIM)
+        B, S = 1, 256
+        gt = torch.rand(B, 3, S, S, generator=g).to(dev)
+        lr = (torch.randn(B, 3, S, S, generator=g) * 0.5 - 1.0).to(dev)
+        ref_g = seeded_init_(O.VQLLFLOWDeformable().train(), 0).to(dev)
+        for n, p in ref_g.named_parameters():
+            p.requires_grad_(n.startswith("deformable_decoder."))
+        percep = seeded_init_(O.PerceptualNetwork(), 4).to(dev)
+        opt = torch.optim.Adam([p for p in ref_g.parameters() if p.requires_grad], lr=1e-4, betas=(0.9, 0.99))
+        scaler = torch.amp.GradScaler("cuda")
+
+        def ref_step3():
+            torch.cuda.empty_cache()                                   # VQLLFLOWD_model.py:188
+            opt.zero_grad()
+            with torch.autocast("cuda", dtype=torch.float16):
+                rec, _ = ref_g(ref_hq, lr)
+            total = O.stage3_loss(rec, gt, percep)[0]                  # :205-223
+            scaler.scale(total).backward()
+            scaler.step(opt)
+            scaler.update()
+            return total.item()
+
+        l0 = ref_step3()
+        ref3 = _ms(ref_step3, 5)
+        tr3 = Stage3Trainer(seeded_init_(M.VQLLFLOWDeformable().train(), 0).to(dev), hq, precision="fp16")
+        ours3 = _ms(lambda: tr3.step_tensor(gt, lr), 10, 3)
+        rows.append(("stage 3 (1 x 3x256x256)", ref3, ours3, l0))
+    finally:
+        O.modulated_deform_conv = keep
+    with capsys.disabled():
+        for name, r, o, l0 in rows:
+            print("\n[reference on device] %-26s reference step %8.1f ms | product step %6.2f ms | %.1fx   (reference's first loss %.4f)"
+                  % (name, r, o, r / o, l0), end="")
+        print()
+    for name, r, o, l0 in rows:
+        assert l0 == l0 and o < r
