@@ -12,8 +12,6 @@ Two uses, both test infrastructure:
 import os
 import time
 
-os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")     # the stock-op side: no exhaustive per-shape search on a fresh box
-
 import numpy as np
 import pytest
 import torch

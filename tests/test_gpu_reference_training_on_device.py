@@ -7,8 +7,6 @@ per-GPU crops (2 x 3x320x320, 1 x 3x256x256); reported, not a target (profiles/r
 import os
 import time
 
-os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
-
 import pytest
 import torch
 
