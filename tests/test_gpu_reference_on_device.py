@@ -130,16 +130,29 @@ def test_rate_of_the_reference_path_on_this_gpu(nets, capsys):
         o32 = og.stages(ov, lr)["out"]
         i32 = ov.last_indices.clone()
         got = pg.reverse_flow_nhwc(pv, lr)
+        # the product with the conditional encoder + flow in the SINGLE-PASS fp16 form (one 16-bit MFMA pass per conv = the arithmetic of
+        # the reference's autocast; round 3's path, `GLARE_FP32_CLASS=0`): NOT the default -- it misses the index contract -- shown
+        # because it is what the reference's own inference mode is comparable with
+        from glare_amd.modules import encoder_decoder as ED
+
+        pg.invalidate()
+        with ED.fp32_class(False):
+            got1 = pg.reverse_flow_nhwc(pv, lr)
+            res["product, single-pass front (not the default)"] = _rate(lambda: pg.reverse_flow_nhwc(pv, lr), B, 5)
+        pg.invalidate()
     # what the reference's OWN autocast costs against its fp32 self on this GPU -- the context of the product's parity figures
     d16 = _psnr(O.postprocess(o16[:1].float().cpu(), 400), O.postprocess(o32[:1].float().cpu(), 400))
     dpr = _psnr(O.postprocess(got["out"][:1].float().cpu(), 400), O.postprocess(o32[:1].float().cpu(), 400))
     a16 = float((i16.view(-1) == i32.view(-1)).float().mean())
     apr = float((got["indices"].view(-1) == i32.view(-1)).float().mean())
+    ap1 = float((got1["indices"].view(-1) == i32.view(-1)).float().mean())
+    dp1 = _psnr(O.postprocess(got1["out"][:1].float().cpu(), 400), O.postprocess(o32[:1].float().cpu(), 400))
     with capsys.disabled():
         for k, v in res.items():
             print("\n[reference on device] %-52s %8.2f images/s" % (k, v), end="")
         print("\n[reference on device] against the reference's fp32 run, batch of 8: reference under fp16 autocast -- index agreement %.5f, "
-              "PSNR %.2f dB (scene 0); product -- index agreement %.5f, PSNR %.2f dB" % (a16, d16, apr, dpr))
+              "PSNR %.2f dB (scene 0); product -- index agreement %.5f, PSNR %.2f dB; product with the single-pass front -- %.5f, %.2f dB"
+              % (a16, d16, apr, dpr, ap1, dp1))
     assert torch.isfinite(o32).all()
     assert apr >= a16 and dpr >= d16          # the product is closer to the reference's fp32 self than the reference's own autocast run
     assert res["product (fp16 default, one stream)"] > res["reference fp16 autocast (infer_dataset_lol.py:134)"]
