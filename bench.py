@@ -779,7 +779,7 @@ def main():
                     "infer_dataset_lol.py:134 runs it; same box: product 62.5-64.0 images/s on one stream (4.2x), 75.4 with the single-pass front that the "
                     "reference's autocast arithmetic corresponds to (index agreement with the fp32 run 0.941; not the default)",
             "index_agreement_with_reference_fp32": {"reference_fp16_autocast": 0.653, "product": 0.9995, "product_single_pass_front": 0.9415},
-            "train_ms_per_step": {"stage2_reference": 98.9, "stage2_product": 20.7, "stage3_reference": 124.1, "stage3_product": 19.6,
+            "train_ms_per_step": {"stage2_reference": 102.9, "stage2_product": 20.6, "stage3_reference": 111.8, "stage3_product": 19.5,
                                   "what": "the reference's step bodies (LLFlow_model.py:181-250, VQLLFLOWD_model.py:187-232) on stock ops under autocast + "
                                           "GradScaler + torch.optim.Adam with the reference's DCN forward / backward, per-GPU crops of BASELINE configs[3] / [4]"},
             "source": "profiles/r06_reference_on_device.txt (tests/test_gpu_reference_on_device.py, tests/test_gpu_reference_training_on_device.py, -m gpu)"}
