@@ -8,6 +8,8 @@ torch ops on 5-element tensors.
 """
 from math import exp
 
+import functools
+
 import torch
 import torch.nn as nn
 
@@ -18,10 +20,11 @@ MSSSIM_WEIGHTS = (0.0448, 0.2856, 0.3001, 0.2363, 0.1333)   # pytorch_msssim/__i
 _WEIGHTS = {}
 
 
+@functools.lru_cache(maxsize=None)      # five windows per MS-SSIM call, the same every step: built once (was ~15 small CPU tensor ops per step)
 def gaussian(window_size, sigma=1.5):
     """The 1-D window of create_window() (:8-17) with the same float32 rounding: its outer product is the 2-D window."""
     g = torch.Tensor([exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(window_size)])
-    return (g / g.sum()).tolist()
+    return tuple((g / g.sum()).tolist())     # immutable: the cached object is shared by every caller
 
 
 def msssim(sr, gt, window_size=11, normalize=False):
