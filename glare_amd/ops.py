@@ -1154,8 +1154,8 @@ def mdcn_forward_nhwc_fused(x, om, pd, x_off=0, C=None, mask_is_logit=True, padd
     out = torch.empty(B, H, W, pd.co, dtype=act_dtype() if out16 else torch.float32, device=x.device)
     sums = torch.empty(B, (H * W + tile - 1) // tile, dtype=torch.float32, device=x.device) if want_sums else None   # tiles cut per image
     mask = om[:, 2 * pd.dg * K:]
-    with _timed_launch("dcn", 2.0 * B * H * W * C * pd.co * K + 8.0 * K * B * H * W * C,      # contraction + sampling; bytes as the fp32-output form
-                       2.0 * B * H * W * C + 4.0 * B * H * W * (3 * pd.dg * K + pd.co) + 4.0 * pd.co * C * K):
+    with _timed_launch("dcn", 2.0 * B * H * W * C * pd.co * K + 8.0 * K * B * H * W * C,      # contraction + sampling; bytes: x 16-bit, offsets + mask logits fp32, output as written
+                       2.0 * B * H * W * C + 4.0 * B * H * W * 3 * pd.dg * K + (2.0 if out16 else 4.0) * B * H * W * pd.co + 4.0 * pd.co * C * K):
         check(lib.glare_mdcn_forward_nhwc_fused(ptr(x), _i(pitch), _i(x_off), ptr(om), _ll(plane), _ll(om.shape[1] * plane),
                                                 ctypes.c_void_p(mask.data_ptr()), _ll(plane), _ll(om.shape[1] * plane), _i(int(mask_is_logit)),
                                                 ptr(pd.packed), ptr(pd.bias), ptr(None if out16 else out), ptr(out if out16 else None), _i(pd.co),

@@ -40,8 +40,9 @@ def main(key):
             plane = (h * w + 63) // 64 * 64
             om = torch.randn(B, 108, plane, device=dev)
             pd = ops.PackedDcn(torch.randn(c, c, 3, 3, device=dev) * 0.02, torch.zeros(c, device=dev), 4)
-            fn = lambda: ops.mdcn_forward_nhwc(x, om, pd)
-            algo = 2.0 * B * h * w * c + 4.0 * B * h * w * (108 + c) + 4.0 * c * c * 9
+            # the pipeline's call since round 6 (glare_mdcn_forward_nhwc_fused): 16-bit output + per-tile sums; out: 2 B / channel
+            fn = lambda: ops.mdcn_forward_nhwc_fused(x, om, pd, x_off=0, C=c, out16=True, want_sums=True)
+            algo = 2.0 * B * h * w * c + 4.0 * B * h * w * 108 + 2.0 * B * h * w * c + 4.0 * c * c * 9
         else:
             raise SystemExit("unknown key " + key)
         for _ in range(4):
