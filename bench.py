@@ -373,7 +373,7 @@ def family_rooflines(events, steps):
         # turns the per-lane 16-B loads (weight fragments first, gathered corners second) into L1 / L2 requests;
         # reported against the MFMA peak as the contract's schema has two bounds, with the HBM figures beside it
         out.append({"kernel": "dcn_fwd_fast_kernel (DCNv2 warp: bilinear gather + 9-tap contraction, %s; %.0f MB algorithmic)" % (form, nb / 1e6),
-                    "bound": "mfma", "binds": "the texture path: weight-fragment and corner lane-loads (TA busy 65 % / 47 % at C = 128 / 256 with four waves along Co and the filter fragments as contiguous planes, 79 % in round 4: profiles/r05_pmc_dcn_ta.txt; DESIGN.md section 3)", "achieved": round(tfl, 1),
+                    "bound": "mfma", "binds": "the texture path: weight-fragment and corner lane-loads (TA busy 65 % / 47 % at C = 128 / 256 with four waves along Co and the filter fragments as contiguous planes, 79 % in round 4: profiles/r06_pmc_dcn_ta.txt; DESIGN.md section 3)", "achieved": round(tfl, 1),
                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tfl / PEAK_BF16_TFLOPS, 4),
                     "hbm_gbs_algorithmic": round(tbs * 1e3, 1), "hbm_frac": round(tbs / PEAK_HBM_TBS, 4),
                     "ms_per_launch": round(ms, 3), "ms_per_launch_median": round(sorted(ts)[len(ts) // 2], 3), "ms_per_launch_max": round(max(ts), 3),
