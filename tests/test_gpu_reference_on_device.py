@@ -113,6 +113,12 @@ def _rate(fn, batch, reps):
     return batch * reps / (time.time() - t0)
 
 
+RATES = pytest.mark.skipif(os.environ.get("GLARE_REFERENCE_RATES") != "1",
+                           reason="a measurement, not a parity test: MIOpen's per-shape search for the reference's fp32 + fp16 graphs at batch 8 takes ~2 min on a "
+                                  "fresh box; GLARE_REFERENCE_RATES=1 runs it (its output: profiles/r06_reference_on_device.txt)")
+
+
+@RATES
 def test_rate_of_the_reference_path_on_this_gpu(nets, capsys):
     """images/s of the reference's algorithm on the MI355X (stock torch ops + the reference's DCN kernels): fp32, and under fp16
     autocast as `infer_dataset_lol.py:134` runs it, batch 8 of 400x600 -- BASELINE configs[1] -- beside the product on this box."""

@@ -63,6 +63,9 @@ def _ms(fn, steps, warm=2):
     return (time.time() - t0) / steps * 1e3
 
 
+@pytest.mark.skipif(os.environ.get("GLARE_REFERENCE_RATES") != "1",
+                    reason="a measurement, not a parity test (MIOpen searches every forward / backward shape of both steps: ~1 min); GLARE_REFERENCE_RATES=1 runs "
+                           "it (its output: profiles/r06_reference_on_device.txt)")
 def test_training_steps_of_the_reference_on_this_gpu(capsys):
     from glare_amd.train import GraphedStep, Stage2Trainer, Stage3Trainer
 
