@@ -170,7 +170,19 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream_handle():
+    """The calling thread's current HIP stream as a void* (what every launch of the C ABI takes).  Through torch's two C entry points:
+    `torch.cuda.current_stream().cuda_stream` builds a Stream object behind three Python-level device lookups -- 9 us per call, measured
+    (tools/probes/train_host_profile.py), i.e. ~12 ms of the ~1 400 launches of a training step that the HOST paces (round 6)."""
+    if _raw_stream is not None:
+        try:
+            return ctypes.c_void_p(_raw_stream(_cur_device()))
+        except Exception:      # no initialised HIP context (CPU-side tests of the error paths): the documented route decides what to raise
+            pass
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
