@@ -115,13 +115,15 @@ class _F16Lib:
     def __init__(self, cdll):
         self._c = cdll
 
-    def __getattr__(self, name):
+    def __getattr__(self, name):          # reached on the FIRST use of a name only: the resolved function is kept on the instance
         try:
-            return getattr(self._c, name.replace("bf16", "f16"))
+            fn = getattr(self._c, name.replace("bf16", "f16"))
         except AttributeError:
-            if name.startswith(_DTYPE_AGNOSTIC):
-                return getattr(main_lib(), name)
-            raise GlareError("%s is not part of libglare_hip_f16.so (the fp16 precision covers the inference kernels)" % name)
+            if not name.startswith(_DTYPE_AGNOSTIC):
+                raise GlareError("%s is not part of libglare_hip_f16.so (the fp16 precision covers the inference kernels)" % name)
+            fn = getattr(main_lib(), name)
+        self.__dict__[name] = fn
+        return fn
 
 
 def lib():
